@@ -1,0 +1,159 @@
+/*
+ * llamole_hip.h -- C ABI of the MI355X (gfx950) implementation of Llamole's graph hot path.
+ *
+ * The reference (liugangcode/Llamole) has NO native/FFI interface: its seam is the Python
+ * class level.  This header is therefore the boundary a maintainer
+ * would bind from Python with ctypes; every entry point cites the
+ * reference Python interface it replaces.  Conventions:
+ *   - plain pointers and sizes only; all data pointers are DEVICE pointers unless named h_*;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls are asynchronous
+ *     on that stream unless stated otherwise;
+ *   - every function returns 0 on success or a negative LL_E* code; the message is available
+ *     through ll_last_error() (thread-local).  No C++ exception crosses the boundary;
+ *   - one in-flight call per handle; handles are independent of each other.
+ */
+#ifndef LLAMOLE_HIP_H
+#define LLAMOLE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LL_OK 0
+#define LL_EINVAL (-1)   /* bad argument / unsupported shape */
+#define LL_EHIP (-2)     /* a HIP runtime call failed        */
+#define LL_ESTATE (-3)   /* call order violated              */
+
+#define LL_F32 0
+#define LL_BF16 1
+
+#define LL_XDIM 16       /* atom classes   (reference diffusion_utils.py:58-59) */
+#define LL_EDIM 5        /* bond classes                                          */
+#define LL_YDIM 10       /* property slots                                        */
+#define LL_TEXT_DIM 768  /* text-embedding width (diffusion_model.py:62)          */
+
+int ll_version(void);
+const char *ll_last_error(void);
+
+/* ------------------------------------------------------------------ dense linear (building block)
+ * C[M,N] = epi(A[M,K] * W[N,K]^T + bias)   -- torch.nn.Linear layout, used by every Linear on the
+ * path (reference layers.py:47,53,106-109; transformer.py:116-130).  dtype selects the operand type
+ * of A and W (LL_F32: exact f32 FMA chains; LL_BF16: MFMA 16x16x32 with f32 accumulation).
+ * epi: 0 none, 1 GELU(erf), 2 SiLU, 3 Softsign.  out_f32 != 0 writes f32, else the operand dtype.
+ * A must be readable for round_up(M,128) rows. */
+int ll_linear(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
+              int M, int N, int K, int epi, int out_f32, void *stream);
+
+/* ------------------------------------------------------------------ GraphDiT sampler
+ * Replaces reference GraphDiT.generate / sample_p_zs_given_zt / Transformer.forward
+ * (src/model/graph_decoder/diffusion_model.py:252-399, transformer.py:93-187,
+ *  diffusion_utils.py:273-349,376-413,476-518). */
+typedef struct LLDitConfig {
+    int hidden;        /* H            (config.yaml hidden_size)      */
+    int depth;         /* L            (depth)                        */
+    int heads;         /* num_heads                                    */
+    int mlp_hidden;    /* int(H * mlp_ratio)                           */
+    int max_nodes;     /* N            (data.meta.json max_node)       */
+    int T;             /* diffusion_steps                              */
+    float guide_scale; /* classifier-free guidance scale (1 = off)     */
+    int dtype;         /* LL_F32 | LL_BF16: operand type of the Linears */
+} LLDitConfig;
+
+/* Host-side tables built from data.meta.json exactly as the reference does
+ * (diffusion_model.py:78-103, diffusion_utils.py:172-187). */
+typedef struct LLDitTables {
+    const float *h_x_marg;     /* [16]     */
+    const float *h_e_marg;     /* [5]      */
+    const float *h_u_xe;       /* [16*5]   row-normalised S            */
+    const float *h_u_ex;       /* [5*16]   row-normalised S^T          */
+    const float *h_betas;      /* [T+1]    */
+    const float *h_alphas_bar; /* [T+1]    */
+} LLDitTables;
+
+/* Weight arena layout: parameters in the order of the reference Transformer.state_dict()
+ * (SURVEY.md section 8b).  idx in [0, ll_dit_param_count).  offset/numel in f32 elements. */
+int ll_dit_param_count(const LLDitConfig *cfg);
+int ll_dit_param_info(const LLDitConfig *cfg, int idx, char *name, int name_cap, int64_t *numel, int64_t *offset);
+int64_t ll_dit_arena_elems(const LLDitConfig *cfg);
+
+/* d_weights_f32: device arena laid out as above (f32 masters; converted once to cfg->dtype). Synchronous. */
+int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *tables, const float *d_weights_f32, void **handle);
+int ll_dit_destroy(void *handle);
+
+/* Start a batch (GraphDiT.generate up to the loop, diffusion_model.py:259-268; conditions.py:19-123):
+ * properties [B,10] (NaN = absent), text [B,768] (a NaN in a row drops the row), n_nodes [B] int32.
+ * Hoists every step-invariant piece out of the T-step loop: c = c_t + c_y + c_txt for all T steps and
+ * all L+1 adaLN modulations (transformer.py:125-130,156-160). */
+int ll_dit_begin(void *handle, int B, const float *props, const float *text, const int32_t *n_nodes, void *stream);
+
+/* z_T ~ limit marginals (diffusion_utils.py:495-518).  qx [B*N,16], qe [B*N*N,5] = Exp(1) race noise in the
+ * reference's draw order, or NULL/NULL to draw on device from Philox4x32-10(seed). */
+int ll_dit_init_state(void *handle, const float *qx, const float *qe, uint64_t seed, void *stream);
+
+/* One reverse step z_{s+1} -> z_s (sample_p_zs_given_zt, diffusion_model.py:309-399), s in [0,T). */
+int ll_dit_step(void *handle, int s, const float *qx, const float *qe, uint64_t seed, void *stream);
+
+/* Whole trajectory T-1 .. 0 with on-device noise; the step is captured once as a hipGraph and replayed. */
+int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream);
+
+/* State I/O: X int8 [B,N] (-1 = masked), E int8 [B,N,N] (-1 = all-zero one-hot: masked pair or z_T diagonal). */
+int ll_dit_set_state(void *handle, const int8_t *X, const int8_t *E, void *stream);
+int ll_dit_get_state(void *handle, int8_t *X, int8_t *E, void *stream);
+
+/* Parity taps (tests only): run the denoiser on the current state at step s.
+ * logX [2,B,N,16], logE [2,B,N,N,5] (pass 0 = conditional, 1 = unconditional), masked like
+ * Transformer.forward's PlaceHolder.mask; hidden (nullable) [2,B,N,H] = residual stream after `tap_layer`
+ * blocks (0 = after x_embedder). */
+int ll_dit_denoise(void *handle, int s, float *logX, float *logE, float *hidden, int tap_layer, void *stream);
+/* Guided probabilities of step s as handed to sample_discrete_features: pX [B,N,16], pE [B,N,N,5]
+ * (only rows of valid nodes / pairs i<j of valid nodes are defined; others are written as 0). */
+int ll_dit_step_probs(void *handle, int s, float *pX, float *pE, void *stream);
+/* Conditioning vectors c [B+1,H] at step s (rows 0..B-1 conditional, row B unconditional). */
+int ll_dit_cvec(void *handle, int s, float *c, void *stream);
+
+/* Timing of the most recent ll_dit_run measured with HIP events on `stream`: total ms and steps. */
+int ll_dit_last_run_ms(void *handle, float *ms, int *steps);
+
+/* ------------------------------------------------------------------ GIN encoder / predictor
+ * Replaces GNNEncoder.forward + ProjectionHead (src/model/graph_encoder/model.py:124-205) and
+ * GNNRetrosynthsizer.forward (src/model/graph_predictor/model.py:306-353). */
+typedef struct LLGinConfig {
+    int num_layer;
+    int hidden;     /* H_gin                                   */
+    int kind;       /* 0 = encoder (+projection head), 1 = predictor (+decoder) */
+    int out_dim;    /* predictor: #templates (num_task); encoder: ignored          */
+    int text_dim;   /* predictor: 768                                              */
+    int dtype;      /* LL_F32 | LL_BF16                                            */
+} LLGinConfig;
+
+int ll_gin_param_count(const LLGinConfig *cfg);
+int ll_gin_param_info(const LLGinConfig *cfg, int idx, char *name, int name_cap, int64_t *numel, int64_t *offset);
+int64_t ll_gin_arena_elems(const LLGinConfig *cfg);
+int ll_gin_create(const LLGinConfig *cfg, const float *d_weights_f32, void **handle);
+int ll_gin_destroy(void *handle);
+
+/* x [n] atom ids in [0,118).  Edges in CSR-by-destination form: rowptr [n+1], and for e in
+ * [rowptr[v], rowptr[v+1]) the message source src[e] and bond class attr[e] in 0..4 (the PyG
+ * edge_index[0] / edge_attr of the edges whose edge_index[1] == v, in stable order).
+ * batch [n] sorted graph ids, gptr [G+1] node offsets of each graph.
+ * c [G,text_dim] or NULL (predictor: NULL -> text_dropping row, model.py:315-316).
+ * out: encoder [G,H] L2-normalised embedding; predictor [G,out_dim] template logits.
+ * pooled (nullable) [G,H]: add-pooled node states before the head. */
+int ll_gin_forward(void *handle, const int32_t *x, const int32_t *rowptr, const int32_t *src, const int32_t *attr,
+                   const int32_t *batch, const int32_t *gptr, int n_nodes, int n_edges, int n_graphs, const float *c,
+                   float *out, float *pooled, void *stream);
+
+/* softmax over out_dim then top-k (GraphPredictor.sample_templates, graph_predictor/model.py:174-179).
+ * probs [rows,k] descending, idx [rows,k]. k <= 64. */
+int ll_softmax_topk(const float *logits, int rows, int out_dim, int k, float *probs, int32_t *idx, void *stream);
+
+/* CostMLP (graph_predictor/model.py:356-391): softplus(W3 relu(W0 fp + b0) + b3); fps [n,2048] f32 0/1.
+ * weights: device f32 arena = [layers.0.weight 128x2048 | layers.0.bias 128 | layers.3.weight 1x128 | layers.3.bias 1]. */
+int ll_cost_mlp(const float *weights, const float *fps, int n, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLAMOLE_HIP_H */

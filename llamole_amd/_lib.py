@@ -1,0 +1,117 @@
+"""ctypes binding of libllamole_hip.so (the C ABI declared in include/llamole_hip.h).
+
+The product path has no CPU fallback: importing this module on a machine where the shared
+library has not been built raises, and every wrapper raises ``RuntimeError`` with the
+library's own message when a call returns a negative code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libllamole_hip.so")
+
+LL_F32, LL_BF16 = 0, 1
+
+
+class LLDitConfig(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("depth", C.c_int), ("heads", C.c_int), ("mlp_hidden", C.c_int),
+                ("max_nodes", C.c_int), ("T", C.c_int), ("guide_scale", C.c_float), ("dtype", C.c_int)]
+
+
+class LLDitTables(C.Structure):
+    _fields_ = [("h_x_marg", C.c_void_p), ("h_e_marg", C.c_void_p), ("h_u_xe", C.c_void_p),
+                ("h_u_ex", C.c_void_p), ("h_betas", C.c_void_p), ("h_alphas_bar", C.c_void_p)]
+
+
+class LLGinConfig(C.Structure):
+    _fields_ = [("num_layer", C.c_int), ("hidden", C.c_int), ("kind", C.c_int), ("out_dim", C.c_int),
+                ("text_dim", C.c_int), ("dtype", C.c_int)]
+
+
+_P, _I, _I64, _U64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+
+# name -> (restype, argtypes); mirrors include/llamole_hip.h one to one
+SIGNATURES = {
+    "ll_version": (_I, []),
+    "ll_last_error": (C.c_char_p, []),
+    "ll_linear": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ll_dit_param_count": (_I, [C.POINTER(LLDitConfig)]),
+    "ll_dit_param_info": (_I, [C.POINTER(LLDitConfig), _I, C.c_char_p, _I, C.POINTER(_I64), C.POINTER(_I64)]),
+    "ll_dit_arena_elems": (_I64, [C.POINTER(LLDitConfig)]),
+    "ll_dit_create": (_I, [C.POINTER(LLDitConfig), C.POINTER(LLDitTables), _P, C.POINTER(_P)]),
+    "ll_dit_destroy": (_I, [_P]),
+    "ll_dit_begin": (_I, [_P, _I, _P, _P, _P, _P]),
+    "ll_dit_init_state": (_I, [_P, _P, _P, _U64, _P]),
+    "ll_dit_step": (_I, [_P, _I, _P, _P, _U64, _P]),
+    "ll_dit_run": (_I, [_P, _U64, _I, _P]),
+    "ll_dit_set_state": (_I, [_P, _P, _P, _P]),
+    "ll_dit_get_state": (_I, [_P, _P, _P, _P]),
+    "ll_dit_denoise": (_I, [_P, _I, _P, _P, _P, _I, _P]),
+    "ll_dit_step_probs": (_I, [_P, _I, _P, _P, _P]),
+    "ll_dit_cvec": (_I, [_P, _I, _P, _P]),
+    "ll_dit_last_run_ms": (_I, [_P, C.POINTER(_F), C.POINTER(_I)]),
+    "ll_gin_param_count": (_I, [C.POINTER(LLGinConfig)]),
+    "ll_gin_param_info": (_I, [C.POINTER(LLGinConfig), _I, C.c_char_p, _I, C.POINTER(_I64), C.POINTER(_I64)]),
+    "ll_gin_arena_elems": (_I64, [C.POINTER(LLGinConfig)]),
+    "ll_gin_create": (_I, [C.POINTER(LLGinConfig), _P, C.POINTER(_P)]),
+    "ll_gin_destroy": (_I, [_P]),
+    "ll_gin_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "ll_softmax_topk": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "ll_cost_mlp": (_I, [_P, _P, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m llamole_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the graph hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().ll_last_error()
+        raise RuntimeError(f"{what or 'llamole_hip'} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def param_table(kind: str, cfg) -> list:
+    """[(name, numel, offset)] of the weight arena for a 'dit' or 'gin' config."""
+    lib = load()
+    n = getattr(lib, f"ll_{kind}_param_count")(C.byref(cfg))
+    if n < 0:
+        check(n, f"ll_{kind}_param_count")
+    out = []
+    buf = C.create_string_buffer(256)
+    ne, off = _I64(), _I64()
+    for i in range(n):
+        check(getattr(lib, f"ll_{kind}_param_info")(C.byref(cfg), i, buf, 256, C.byref(ne), C.byref(off)))
+        out.append((buf.value.decode(), ne.value, off.value))
+    return out
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t):
+    """Device pointer of a (contiguous) torch tensor, or NULL."""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_contiguous(), "tensor handed to the C ABI must be contiguous"
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,109 @@
+// Shared helpers for the gfx950 kernels of the Llamole graph hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/llamole_hip.h"
+
+namespace ll {
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+void set_error(const char *fmt, ...);
+
+#define LL_HIP(call)                                                                            \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            ll::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return LL_EHIP;                                                                     \
+        }                                                                                       \
+    } while (0)
+
+#define LL_CHECK(cond, ...)            \
+    do {                               \
+        if (!(cond)) {                 \
+            ll::set_error(__VA_ARGS__); \
+            return LL_EINVAL;          \
+        }                              \
+    } while (0)
+
+#define LL_TRY(expr)            \
+    do {                        \
+        int rc__ = (expr);      \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+#define LL_LAUNCH_CHECK()                                                                   \
+    do {                                                                                    \
+        hipError_t e__ = hipGetLastError();                                                 \
+        if (e__ != hipSuccess) {                                                            \
+            ll::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+            return LL_EHIP;                                                                 \
+        }                                                                                   \
+    } while (0)
+
+__host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- device numerics
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float softsign(float x) { return x / (1.0f + fabsf(x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Philox4x32-10 counter-based generator (Salmon et al. 2011); one call = 4 x 32 random bits.
+__device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+        uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += W0;
+        key.y += W1;
+    }
+    return ctr;
+}
+// Exp(1) variate from 32 random bits: -log(u), u uniform in (0,1].
+__device__ __forceinline__ float exp1_from_bits(uint32_t r) { return -__logf(((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f)); }
+
+// ---------------------------------------------------------------- host helpers
+int linear_launch(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
+                  int M, int N, int K, int epi, int out_f32, hipStream_t stream);
+
+// split-K variant: writes `splits` f32 slabs C[z][M][ldc] (no bias / epilogue); consumer sums slabs in order.
+int linear_splitk_launch(int dtype, const void *A, int lda, const void *W, int ldw, float *Cslabs, int ldc,
+                         int64_t slab_stride, int M, int N, int K, int splits, hipStream_t stream);
+
+int convert_f32_to_bf16(const float *src, bf16_t *dst, int64_t n, hipStream_t stream);
+
+}  // namespace ll

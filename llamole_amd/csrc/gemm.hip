@@ -1,0 +1,302 @@
+// Dense Linear for gfx950:  C[M,N] = epi(A[M,K] * W[N,K]^T + bias)   (torch.nn.Linear layout)
+//
+// Replaces every nn.Linear on the GraphDiT / GIN path (reference layers.py:47,53,106-109;
+// transformer.py:41-44,116-130,151-160; graph_encoder/model.py:164; graph_predictor/model.py:272-278).
+//
+// bf16 path : LDS-tiled MFMA (v_mfma_f32_16x16x32_bf16, 64-lane waves), BK=64 (one 128-B line per tile
+//             row), XOR-swizzled LDS image read with ds_read_b128, register-staged double buffering
+//             (global loads for tile t+1 are issued before the MFMAs of tile t, written after them).
+//             Both operands are K-contiguous, so A and W tiles are staged identically.
+//             Tile shape is picked per call so that the launch has >= ~256 workgroups when the
+//             problem allows it (the sampler's GEMMs are skinny: M = 2*B*N tokens).
+// f32 path  : exact-f32 VALU tile kernel, used by the parity mode (dtype = LL_F32).
+#include "common.h"
+
+namespace ll {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_SILU = 2, EPI_SOFTSIGN = 3 };
+
+__device__ __forceinline__ float apply_epi(float v, int epi) {
+    switch (epi) {
+        case EPI_GELU: return gelu_erf(v);
+        case EPI_SILU: return silu(v);
+        case EPI_SOFTSIGN: return softsign(v);
+        default: return v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bf16 MFMA
+// grid = (ceil(N/BN), ceil(M/BM), splits).  blockIdx.z selects a K range [z*kchunk, (z+1)*kchunk) and an
+// output slab C + z*slab_stride (split-K writes raw f32 partial sums, epilogue/bias skipped).
+template <int BM, int BN, int WM, int WN, typename OutT>
+__global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_kernel(const bf16_t *__restrict__ A, int lda,
+                                                                 const bf16_t *__restrict__ W, int ldw,
+                                                                 OutT *__restrict__ C, int ldc,
+                                                                 const float *__restrict__ bias, int M, int N,
+                                                                 int kchunk, int64_t slab_stride, int epi) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BK = 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MT = TM / 16, NTL = TN / 16;
+    constexpr int A_CH = BM * 8, B_CH = BN * 8;  // 16-byte chunks per tile
+    constexpr int ITA = (A_CH + NT - 1) / NT, ITB = (B_CH + NT - 1) / NT;
+    static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16x16");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * BK * 2];
+    unsigned char *As = smem;                    // [2][BM][128 B]
+    unsigned char *Bs = smem + 2 * BM * BK * 2;  // [2][BN][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * kchunk;
+    const int nk = kchunk / BK;
+
+    uint4 ra[ITA], rb[ITB];
+    auto gload = [&](int kt) {
+        const int k0 = kbeg + kt * BK;
+#pragma unroll
+        for (int it = 0; it < ITA; ++it) {
+            const int c = tid + it * NT;
+            if (A_CH % NT == 0 || c < A_CH) {
+                const int row = c >> 3, ch = c & 7;
+                ra[it] = *reinterpret_cast<const uint4 *>(A + (int64_t)(m0 + row) * lda + k0 + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITB; ++it) {
+            const int c = tid + it * NT;
+            if (B_CH % NT == 0 || c < B_CH) {
+                const int row = c >> 3, ch = c & 7;
+                int gr = n0 + row;
+                gr = gr < N ? gr : N - 1;  // N edge: re-read a valid row, result discarded
+                rb[it] = *reinterpret_cast<const uint4 *>(W + (int64_t)gr * ldw + k0 + ch * 8);
+            }
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < ITA; ++it) {
+            const int c = tid + it * NT;
+            if (A_CH % NT == 0 || c < A_CH) {
+                const int row = c >> 3, ch = c & 7;
+                *reinterpret_cast<uint4 *>(As + buf * BM * 128 + row * 128 + ((ch ^ (row & 7)) << 4)) = ra[it];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITB; ++it) {
+            const int c = tid + it * NT;
+            if (B_CH % NT == 0 || c < B_CH) {
+                const int row = c >> 3, ch = c & 7;
+                *reinterpret_cast<uint4 *>(Bs + buf * BN * 128 + row * 128 + ((ch ^ (row & 7)) << 4)) = rb[it];
+            }
+        }
+    };
+
+    f32x4 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    swrite(0);
+    __syncthreads();
+
+    const int frow = lane & 15;  // row (A) / col (B) inside a 16x16 MFMA tile
+    const int fk = lane >> 4;    // which 8-element K group this lane feeds
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const unsigned char *Ab = As + buf * BM * 128;
+        const unsigned char *Bb = Bs + buf * BN * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[MT], fb[NTL];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = wm * TM + i * 16 + frow;
+                const int ch = kk * 4 + fk;
+                fa[i] = *reinterpret_cast<const bf16x8 *>(Ab + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int row = wn * TN + j * 16 + frow;
+                const int ch = kk * 4 + fk;
+                fb[j] = *reinterpret_cast<const bf16x8 *>(Bb + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            swrite(buf ^ 1);  // the other buffer was last read in iteration kt-1, fenced by the barrier below
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+    OutT *Cz = C + (int64_t)blockIdx.z * slab_stride;
+    const bool raw = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const int col = n0 + wn * TN + j * 16 + (lane & 15);
+            if (col >= N) continue;
+            const float bv = (!raw && bias) ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * TM + i * 16 + (lane >> 4) * 4 + r;
+                if (row < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (!raw) v = apply_epi(v, epi);
+                    Cz[(int64_t)row * ldc + col] = from_f32<OutT>(v);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ f32 VALU
+// 64x64 tile, BK=16, 256 threads, 4x4 outputs per thread; k-ordered fmaf chain per output.
+template <typename OutT>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ A, int lda, const float *__restrict__ W,
+                                                        int ldw, OutT *__restrict__ C, int ldc,
+                                                        const float *__restrict__ bias, int M, int N, int kchunk,
+                                                        int64_t slab_stride, int epi) {
+    __shared__ float As[16][64 + 4];
+    __shared__ float Bs[16][64 + 4];
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int kbeg = blockIdx.z * kchunk;
+    const int lrow = tid >> 2, lk = (tid & 3) * 4;
+    const int ty = tid >> 4, tx = tid & 15;
+    float acc[4][4] = {};
+    int brow = n0 + lrow;
+    brow = brow < N ? brow : N - 1;
+    for (int k0 = kbeg; k0 < kbeg + kchunk; k0 += 16) {
+        const float4 av = *reinterpret_cast<const float4 *>(A + (int64_t)(m0 + lrow) * lda + k0 + lk);
+        const float4 bv = *reinterpret_cast<const float4 *>(W + (int64_t)brow * ldw + k0 + lk);
+        As[lk + 0][lrow] = av.x; As[lk + 1][lrow] = av.y; As[lk + 2][lrow] = av.z; As[lk + 3][lrow] = av.w;
+        Bs[lk + 0][lrow] = bv.x; Bs[lk + 1][lrow] = bv.y; Bs[lk + 2][lrow] = bv.z; Bs[lk + 3][lrow] = bv.w;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(&As[k][ty * 4]);
+            const float4 b4 = *reinterpret_cast<const float4 *>(&Bs[k][tx * 4]);
+            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    OutT *Cz = C + (int64_t)blockIdx.z * slab_stride;
+    const bool raw = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + ty * 4 + i;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + tx * 4 + j;
+            if (col >= N) continue;
+            float v = acc[i][j] + ((!raw && bias) ? bias[col] : 0.f);
+            if (!raw) v = apply_epi(v, epi);
+            Cz[(int64_t)row * ldc + col] = from_f32<OutT>(v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dispatch
+template <int BM, int BN, int WM, int WN>
+static void launch_bf16(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M,
+                        int N, int K, int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), splits);
+    dim3 block(WM * WN * 64);
+    const int kchunk = K / splits;
+    if (out_f32)
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, float>), grid, block, 0, s, A, lda, W, ldw, (float *)C, ldc,
+                           bias, M, N, kchunk, slab_stride, epi);
+    else
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, bf16_t>), grid, block, 0, s, A, lda, W, ldw, (bf16_t *)C,
+                           ldc, bias, M, N, kchunk, slab_stride, epi);
+}
+
+static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
+                         int M, int N, int K, int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
+    LL_CHECK(M > 0 && N > 0 && K > 0, "ll_linear: empty problem M=%d N=%d K=%d", M, N, K);
+    LL_CHECK(splits >= 1 && K % splits == 0, "ll_linear: K=%d not divisible by splits=%d", K, splits);
+    const int kchunk = K / splits;
+    if (dtype == LL_BF16) {
+        LL_CHECK(kchunk % 64 == 0, "ll_linear(bf16): K per split (%d) must be a multiple of 64", kchunk);
+        LL_CHECK(lda % 8 == 0 && ldw % 8 == 0, "ll_linear(bf16): lda/ldw must be multiples of 8 elements");
+        const bf16_t *a = (const bf16_t *)A;
+        const bf16_t *w = (const bf16_t *)W;
+        // Tile choice: fill >= ~256 workgroups when the problem allows it.
+        const long wg128 = (long)cdiv(M, 128) * cdiv(N, 128) * splits;
+        const long wg64 = (long)cdiv(M, 64) * cdiv(N, 64) * splits;
+        const long wg6432 = (long)cdiv(M, 64) * cdiv(N, 32) * splits;
+        if (wg128 >= 512)
+            launch_bf16<128, 128, 2, 2>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s);
+        else if (wg64 >= 256 || (M > 64 && wg6432 < 256))
+            launch_bf16<64, 64, 2, 2>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s);
+        else if (wg6432 >= 256 || N % 16 != 0)
+            launch_bf16<64, 32, 4, 1>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s);
+        else
+            launch_bf16<64, 16, 4, 1>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s);
+    } else if (dtype == LL_F32) {
+        LL_CHECK(kchunk % 16 == 0, "ll_linear(f32): K per split (%d) must be a multiple of 16", kchunk);
+        LL_CHECK(lda % 4 == 0 && ldw % 4 == 0, "ll_linear(f32): lda/ldw must be multiples of 4 elements");
+        dim3 grid(cdiv(N, 64), cdiv(M, 64), splits);
+        // out_f32 is implied (operand dtype is f32)
+        hipLaunchKernelGGL((gemm_f32_kernel<float>), grid, dim3(256), 0, s, (const float *)A, lda, (const float *)W,
+                           ldw, (float *)C, ldc, bias, M, N, kchunk, slab_stride, epi);
+    } else {
+        LL_CHECK(false, "ll_linear: unknown dtype %d", dtype);
+    }
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+int linear_launch(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, int M,
+                  int N, int K, int epi, int out_f32, hipStream_t stream) {
+    return gemm_dispatch(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, 1, 0, epi, out_f32, stream);
+}
+
+int linear_splitk_launch(int dtype, const void *A, int lda, const void *W, int ldw, float *Cslabs, int ldc,
+                         int64_t slab_stride, int M, int N, int K, int splits, hipStream_t stream) {
+    return gemm_dispatch(dtype, A, lda, W, ldw, nullptr, Cslabs, ldc, M, N, K, splits, slab_stride, EPI_NONE, 1, stream);
+}
+
+__global__ void cvt_f32_bf16_kernel(const float *__restrict__ src, bf16_t *__restrict__ dst, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = f32_to_bf16(src[i]);
+}
+
+int convert_f32_to_bf16(const float *src, bf16_t *dst, int64_t n, hipStream_t stream) {
+    if (n <= 0) return LL_OK;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n);
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+}  // namespace ll
+
+extern "C" int ll_linear(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
+                         int M, int N, int K, int epi, int out_f32, void *stream) {
+    return ll::linear_launch(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, epi, out_f32, (hipStream_t)stream);
+}

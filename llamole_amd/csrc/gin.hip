@@ -1,0 +1,575 @@
+// GIN encoder (GraphCLIP) and GIN predictor (template classifier) for MI355X (gfx950).
+//
+// Replaces reference GNNEncoder.forward + ProjectionHead (src/model/graph_encoder/model.py:124-205),
+// GNNRetrosynthsizer.forward (src/model/graph_predictor/model.py:306-353), the softmax/top-k of
+// GraphPredictor.sample_templates (:174-179) and CostMLP.forward (:385-391).
+//
+// Structure: the PyG scatter-add of the reference (gather x[src] -> +bond embedding -> GELU -> index_add
+// into dst) becomes a CSR-by-destination pull: one 64-lane wave owns one destination node, walks its
+// (degree <= ~6) incoming edges and accumulates in registers -- no atomics, deterministic summation order,
+// feature rows read as coalesced 256-B segments.  Virtual-node max-pool / add-pool are segment reductions
+// over the sorted `batch` vector (one workgroup per graph).  All Linears go through the shared MFMA GEMM.
+#include <vector>
+
+#include "common.h"
+
+namespace ll {
+
+struct GinParam {
+    std::string name;
+    int64_t numel, offset;
+};
+
+static std::vector<GinParam> gin_layout(const LLGinConfig &c) {
+    std::vector<GinParam> v;
+    int64_t off = 0;
+    auto add = [&](const std::string &n, int64_t ne) {
+        v.push_back({n, ne, off});
+        off += (ne + 63) / 64 * 64;
+    };
+    const int64_t H = c.hidden;
+    add("atom_encoder.weight", 118 * H);
+    add("virtualnode_embedding.weight", H);
+    if (c.kind == 1) add("text_dropping.weight", c.text_dim);
+    for (int i = 0; i < c.num_layer; ++i) {
+        const std::string p = "convs." + std::to_string(i) + ".";
+        add(p + "eps", 1);
+        add(p + "mlp.0.weight", 4 * H * H);
+        add(p + "mlp.0.bias", 4 * H);
+        add(p + "mlp.1.weight", 4 * H);
+        add(p + "mlp.1.bias", 4 * H);
+        add(p + "mlp.4.weight", H * 4 * H);
+        add(p + "mlp.4.bias", H);
+        add(p + "bond_encoder.weight", 5 * H);
+        if (c.kind == 0) {
+            add("norms." + std::to_string(i) + ".weight", H);
+            add("norms." + std::to_string(i) + ".bias", H);
+        } else {
+            add("adapters." + std::to_string(i) + ".1.weight", 3 * H * c.text_dim);
+            add("adapters." + std::to_string(i) + ".1.bias", 3 * H);
+        }
+        if (i < c.num_layer - 1) {
+            const std::string q = "mlp_virtualnode_list." + std::to_string(i) + ".";
+            add(q + "0.weight", 4 * H * H);
+            add(q + "0.bias", 4 * H);
+            add(q + "1.weight", 4 * H);
+            add(q + "1.bias", 4 * H);
+            add(q + "4.weight", H * 4 * H);
+            add(q + "4.bias", H);
+        }
+    }
+    if (c.kind == 0) {  // ProjectionHead, keys prefixed "proj."
+        add("proj.fc1.weight", H * H);
+        add("proj.fc1.bias", H);
+        add("proj.norm1.weight", H);
+        add("proj.norm1.bias", H);
+        add("proj.fc2.weight", H * H);
+        add("proj.fc2.bias", H);
+    } else {
+        add("decoder.0.weight", 4 * H * H);
+        add("decoder.0.bias", 4 * H);
+        add("decoder.1.weight", 4 * H);
+        add("decoder.1.bias", 4 * H);
+        add("decoder.4.weight", (int64_t)c.out_dim * 4 * H);
+        add("decoder.4.bias", c.out_dim);
+    }
+    return v;
+}
+
+static int gin_check(const LLGinConfig *c) {
+    LL_CHECK(c != nullptr, "config is null");
+    LL_CHECK(c->num_layer >= 2, "Number of GNN layers must be greater than 1.");
+    LL_CHECK(c->hidden >= 64 && c->hidden % 64 == 0 && c->hidden <= 2048, "hidden=%d must be a multiple of 64 in [64,2048]", c->hidden);
+    LL_CHECK(c->kind == 0 || c->kind == 1, "kind must be 0 (encoder) or 1 (predictor)");
+    LL_CHECK(c->dtype == LL_F32 || c->dtype == LL_BF16, "unknown dtype %d", c->dtype);
+    if (c->kind == 1) {
+        LL_CHECK(c->out_dim >= 1, "predictor needs out_dim >= 1");
+        LL_CHECK(c->text_dim >= 64 && c->text_dim % 64 == 0, "text_dim=%d must be a multiple of 64", c->text_dim);
+    }
+    return LL_OK;
+}
+
+// ------------------------------------------------------------------------------------------ kernels
+// h0 = atom_encoder[x]
+__global__ __launch_bounds__(256) void gin_embed_kernel(const int *__restrict__ x, const float *__restrict__ emb,
+                                                         float *__restrict__ h, int n, int H) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n) return;
+    const int lane = threadIdx.x & 63;
+    const float *r = emb + (int64_t)x[v] * H;
+    for (int k = lane; k < H; k += 64) h[(int64_t)v * H + k] = r[k];
+}
+
+// One wave per destination node:
+//   h_in[v] = h[v] + vn[batch[v]]
+//   z0[v]   = (1+eps) h_in[v] + sum_{e: dst(e)=v} GELU(h_in[src(e)] + bond_emb[attr(e)])
+// (graph_encoder/model.py:133-134,167-173).  Edges of a graph never cross graphs, so vn[batch[src]] == vn[batch[v]].
+template <typename T>
+__global__ __launch_bounds__(256) void gin_aggregate_kernel(const float *__restrict__ h, const float *__restrict__ vn,
+                                                             const int *__restrict__ batch,
+                                                             const int *__restrict__ rowptr, const int *__restrict__ src,
+                                                             const int *__restrict__ attr, const float *__restrict__ bond,
+                                                             const float *__restrict__ eps, float *__restrict__ h_in,
+                                                             T *__restrict__ z0, int n, int H) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n) return;
+    const int lane = threadIdx.x & 63;
+    const float *vr = vn + (int64_t)batch[v] * H;
+    const float e1 = 1.f + eps[0];
+    const int e0 = rowptr[v], e_end = rowptr[v + 1];
+    for (int k = lane; k < H; k += 64) {
+        const float vk = vr[k];
+        const float hv = h[(int64_t)v * H + k] + vk;
+        float agg = 0.f;
+        for (int e = e0; e < e_end; ++e) agg += gelu_erf(h[(int64_t)src[e] * H + k] + vk + bond[(int64_t)attr[e] * H + k]);
+        h_in[(int64_t)v * H + k] = hv;
+        z0[(int64_t)v * H + k] = from_f32<T>(e1 * hv + agg);
+    }
+}
+
+// out[r] = act(LayerNorm_affine(in[r]))  -> operand dtype.  One wave per row, any C.
+template <typename T>
+__global__ __launch_bounds__(256) void rows_ln_act_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                           const float *__restrict__ b, T *__restrict__ out, int R,
+                                                           int C, int gelu) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int lane = threadIdx.x & 63;
+    const float *x = in + (int64_t)r * C;
+    float s = 0.f;
+    for (int k = lane; k < C; k += 64) s += x[k];
+    const float mean = wave_sum(s) / (float)C;
+    float vr = 0.f;
+    for (int k = lane; k < C; k += 64) {
+        const float d = x[k] - mean;
+        vr += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(vr) / (float)C + 1e-5f);
+    for (int k = lane; k < C; k += 64) {
+        float y = (x[k] - mean) * rstd * w[k] + b[k];
+        if (gelu) y = gelu_erf(y);
+        out[(int64_t)r * C + k] = from_f32<T>(y);
+    }
+}
+
+// Layer tail.  Encoder: z = LN_affine(z); predictor: z = LN0(z) * (1 + scale) + shift, residual gated.
+//   if not last: z = GELU(z);  h = (gate *) z + h_in         (model.py:137-145 / predictor :331-340)
+__global__ __launch_bounds__(256) void gin_post_kernel(const float *__restrict__ z, const float *__restrict__ h_in,
+                                                        const float *__restrict__ lnw, const float *__restrict__ lnb,
+                                                        const float *__restrict__ mod /*[G][3H] or null*/,
+                                                        const int *__restrict__ batch, float *__restrict__ h, int n,
+                                                        int H, int gelu) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n) return;
+    const int lane = threadIdx.x & 63;
+    const float *x = z + (int64_t)v * H;
+    float s = 0.f;
+    for (int k = lane; k < H; k += 64) s += x[k];
+    const float mean = wave_sum(s) / (float)H;
+    float vr = 0.f;
+    for (int k = lane; k < H; k += 64) {
+        const float d = x[k] - mean;
+        vr += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(vr) / (float)H + 1e-5f);
+    const float *m = mod ? mod + (int64_t)batch[v] * 3 * H : nullptr;
+    for (int k = lane; k < H; k += 64) {
+        float y = (x[k] - mean) * rstd;
+        float gate = 1.f;
+        if (m) {
+            y = y * (1.f + m[H + k]) + m[k];
+            gate = m[2 * H + k];
+        } else {
+            y = y * lnw[k] + lnb[k];
+        }
+        if (gelu) y = gelu_erf(y);
+        h[(int64_t)v * H + k] = gate * y + h_in[(int64_t)v * H + k];
+    }
+}
+
+// segment max / sum over the sorted batch vector: one workgroup per graph, threads over features.
+template <typename T, bool MAX>
+__global__ __launch_bounds__(256) void segment_pool_kernel(const float *__restrict__ h, const int *__restrict__ gptr,
+                                                            float *__restrict__ out32, T *__restrict__ outa, int H) {
+    const int g = blockIdx.x;
+    const int v0 = gptr[g], v1 = gptr[g + 1];
+    for (int k = threadIdx.x; k < H; k += 256) {
+        float acc = MAX ? -INFINITY : 0.f;
+        for (int v = v0; v < v1; ++v) {
+            const float x = h[(int64_t)v * H + k];
+            acc = MAX ? fmaxf(acc, x) : acc + x;
+        }
+        if (out32) out32[(int64_t)g * H + k] = acc;
+        if (outa) outa[(int64_t)g * H + k] = from_f32<T>(acc);
+    }
+}
+
+__global__ void add_rows_kernel(float *__restrict__ dst, const float *__restrict__ src, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+__global__ void bcast_rows_kernel(float *__restrict__ dst, const float *__restrict__ row, int G, int H) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)G * H; i += (int64_t)gridDim.x * blockDim.x) dst[i] = row[i % H];
+}
+// SiLU(c) -> operand dtype; c == null -> broadcast the text_dropping row (predictor model.py:315-316,322)
+template <typename T>
+__global__ void silu_rows_kernel(const float *__restrict__ c, const float *__restrict__ drop, T *__restrict__ out, int G, int D) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)G * D; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = c ? c[i] : drop[i % D];
+        out[i] = from_f32<T>(silu(v));
+    }
+}
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float *__restrict__ in, float *__restrict__ out, int R, int C) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int k = lane; k < C; k += 64) {
+        const float v = in[(int64_t)r * C + k];
+        s += v * v;
+    }
+    const float inv = 1.f / sqrtf(wave_sum(s));
+    for (int k = lane; k < C; k += 64) out[(int64_t)r * C + k] = in[(int64_t)r * C + k] * inv;
+}
+
+// ------------------------------------------------------------------------------------------ softmax + top-k
+// One 1024-thread workgroup per row.  Pass 0: online softmax statistics.  Passes 1-4: MSB-first radix select of
+// the k-th largest key on the order-preserving uint32 image of the float.  Then gather (> kth, then == kth),
+// rank-sort the k survivors in LDS, emit probabilities.
+__device__ __forceinline__ uint32_t f2key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ __launch_bounds__(1024) void softmax_topk_kernel(const float *__restrict__ logits, int D, int k,
+                                                             float *__restrict__ probs, int *__restrict__ idx) {
+    __shared__ unsigned int hist[256];
+    __shared__ float redm[16], reds[16];
+    __shared__ unsigned int s_prefix, s_need, s_cnt;
+    __shared__ float selv[64];
+    __shared__ int seli[64];
+    const float *x = logits + (int64_t)blockIdx.x * D;
+    const int tid = threadIdx.x;
+    // pass 0: max and sum(exp)
+    float m = -INFINITY, s = 0.f;
+    for (int i = tid; i < D; i += 1024) {
+        const float v = x[i];
+        if (v > m) {
+            s = s * expf(m - v) + 1.f;
+            m = v;
+        } else {
+            s += expf(v - m);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        const float mn = fmaxf(m, m2);
+        s = ((m == -INFINITY) ? 0.f : s * expf(m - mn)) + ((m2 == -INFINITY) ? 0.f : s2 * expf(m2 - mn));
+        m = mn;
+    }
+    if ((tid & 63) == 0) {
+        redm[tid >> 6] = m;
+        reds[tid >> 6] = s;
+    }
+    __syncthreads();
+    float gm = -INFINITY;
+    for (int w = 0; w < 16; ++w) gm = fmaxf(gm, redm[w]);
+    float gs = 0.f;
+    for (int w = 0; w < 16; ++w) gs += (redm[w] == -INFINITY) ? 0.f : reds[w] * expf(redm[w] - gm);
+    // radix select
+    if (tid == 0) {
+        s_prefix = 0;
+        s_need = (unsigned)k;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const unsigned pmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int i = tid; i < D; i += 1024) {
+            const unsigned key = f2key(x[i]);
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned need = s_need, acc = 0;
+            int b = 255;
+            for (; b > 0; --b) {
+                if (acc + hist[b] >= need) break;
+                acc += hist[b];
+            }
+            s_need = need - acc;
+            s_prefix = prefix | ((unsigned)b << shift);
+        }
+        __syncthreads();
+    }
+    const unsigned kth = s_prefix;   // key of the k-th largest element
+    const unsigned need_eq = s_need;  // how many elements equal to kth belong to the top-k
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < D; i += 1024) {
+        const float v = x[i];
+        if (f2key(v) > kth) {
+            const unsigned p = atomicAdd(&s_cnt, 1u);
+            selv[p] = v;
+            seli[p] = i;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {  // ties at the threshold: lowest indices first (rare; serial scan keeps it deterministic)
+        unsigned p = s_cnt, taken = 0;
+        for (int i = 0; i < D && taken < need_eq; ++i)
+            if (f2key(x[i]) == kth) {
+                selv[p] = x[i];
+                seli[p] = i;
+                ++p;
+                ++taken;
+            }
+    }
+    __syncthreads();
+    if (tid < k) {
+        const float v = selv[tid];
+        const int id = seli[tid];
+        int rank = 0;
+        for (int j = 0; j < k; ++j) rank += (selv[j] > v) || (selv[j] == v && seli[j] < id);
+        probs[(int64_t)blockIdx.x * k + rank] = expf(v - gm) / gs;
+        idx[(int64_t)blockIdx.x * k + rank] = id;
+    }
+}
+
+// CostMLP: softplus(w3 . relu(W0 fp + b0) + b3), W0 [128][2048].  One workgroup per fingerprint.
+__global__ __launch_bounds__(256) void cost_mlp_kernel(const float *__restrict__ w, const float *__restrict__ fps,
+                                                        float *__restrict__ out) {
+    __shared__ float part[4];
+    const float *W0 = w, *b0 = w + 128 * 2048, *w3 = b0 + 128, *b3 = w3 + 128;
+    const float *fp = fps + (int64_t)blockIdx.x * 2048;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (int hdn = wave; hdn < 128; hdn += 4) {
+        float d = 0.f;
+        for (int k = lane; k < 2048; k += 64) d = fmaf(W0[(int64_t)hdn * 2048 + k], fp[k], d);
+        d = wave_sum(d) + b0[hdn];
+        acc += fmaxf(d, 0.f) * w3[hdn];
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float y = part[0] + part[1] + part[2] + part[3] + b3[0];
+        out[blockIdx.x] = logf(1.f + expf(y));
+    }
+}
+
+// ------------------------------------------------------------------------------------------ engine
+struct GBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t n) {
+        if (n <= bytes) return LL_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        LL_HIP(hipMalloc(&p, n));
+        LL_HIP(hipMemset(p, 0, n));
+        bytes = n;
+        return LL_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct GinEngine {
+    LLGinConfig cfg;
+    std::vector<GinParam> layout;
+    const float *w32 = nullptr;
+    GBuf wop;
+    GBuf h, h_in, z0, t1, t1a, z, vn, pool32, poola, vt1, vt1a, vt2, mod, csilu, head1, head1a, head2;
+    const float *pf(const std::string &n) const {
+        for (auto &p : layout)
+            if (p.name == n) return w32 + p.offset;
+        return nullptr;
+    }
+    const void *pw(const std::string &n) const {
+        for (auto &p : layout)
+            if (p.name == n) return cfg.dtype == LL_BF16 ? (const void *)(wop.as<bf16_t>() + p.offset) : (const void *)(w32 + p.offset);
+        return nullptr;
+    }
+};
+
+template <typename T>
+static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const int *src, const int *attr,
+                         const int *batch, const int *gptr, int n, int ne, int G, const float *c, float *out,
+                         float *pooled, hipStream_t st) {
+    const LLGinConfig &cf = e->cfg;
+    const int H = cf.hidden, L = cf.num_layer, dt = cf.dtype, es = sizeof(T);
+    const int np = round_up(n, 128), Gp = round_up(G, 128);
+    LL_TRY(e->h.ensure((size_t)np * H * 4));
+    LL_TRY(e->h_in.ensure((size_t)np * H * 4));
+    LL_TRY(e->z0.ensure((size_t)np * H * es));
+    LL_TRY(e->t1.ensure((size_t)np * 4 * H * 4));
+    LL_TRY(e->t1a.ensure((size_t)np * 4 * H * es));
+    LL_TRY(e->z.ensure((size_t)np * H * 4));
+    LL_TRY(e->vn.ensure((size_t)Gp * H * 4));
+    LL_TRY(e->pool32.ensure((size_t)Gp * H * 4));
+    LL_TRY(e->poola.ensure((size_t)Gp * H * es));
+    LL_TRY(e->vt1.ensure((size_t)Gp * 4 * H * 4));
+    LL_TRY(e->vt1a.ensure((size_t)Gp * 4 * H * es));
+    LL_TRY(e->vt2.ensure((size_t)Gp * H * 4));
+    const dim3 rows_n(cdiv(n, 4)), rows_g(cdiv(G, 4)), blk(256);
+
+    hipLaunchKernelGGL(gin_embed_kernel, rows_n, blk, 0, st, x, e->pf("atom_encoder.weight"), e->h.as<float>(), n, H);
+    hipLaunchKernelGGL(bcast_rows_kernel, dim3(cdiv(G * H, 256)), blk, 0, st, e->vn.as<float>(), e->pf("virtualnode_embedding.weight"), G, H);
+    LL_LAUNCH_CHECK();
+    if (cf.kind == 1) {
+        LL_TRY(e->csilu.ensure((size_t)Gp * cf.text_dim * es));
+        LL_TRY(e->mod.ensure((size_t)L * Gp * 3 * H * 4));
+        hipLaunchKernelGGL((silu_rows_kernel<T>), dim3(cdiv(G * cf.text_dim, 256)), blk, 0, st, c, e->pf("text_dropping.weight"), e->csilu.as<T>(), G, cf.text_dim);
+        LL_LAUNCH_CHECK();
+        for (int l = 0; l < L; ++l) {
+            const std::string p = "adapters." + std::to_string(l) + ".1.";
+            LL_TRY(linear_launch(dt, e->csilu.p, cf.text_dim, e->pw(p + "weight"), cf.text_dim, e->pf(p + "bias"),
+                                 e->mod.as<float>() + (size_t)l * Gp * 3 * H, 3 * H, G, 3 * H, cf.text_dim, 0, 1, st));
+        }
+    }
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "convs." + std::to_string(l) + ".";
+        const bool last = (l == L - 1);
+        hipLaunchKernelGGL((gin_aggregate_kernel<T>), rows_n, blk, 0, st, e->h.as<float>(), e->vn.as<float>(), batch, rowptr, src, attr,
+                           e->pf(p + "bond_encoder.weight"), e->pf(p + "eps"), e->h_in.as<float>(), e->z0.as<T>(), n, H);
+        LL_LAUNCH_CHECK();
+        LL_TRY(linear_launch(dt, e->z0.p, H, e->pw(p + "mlp.0.weight"), H, e->pf(p + "mlp.0.bias"), e->t1.p, 4 * H, n, 4 * H, H, 0, 1, st));
+        hipLaunchKernelGGL((rows_ln_act_kernel<T>), rows_n, blk, 0, st, e->t1.as<float>(), e->pf(p + "mlp.1.weight"), e->pf(p + "mlp.1.bias"), e->t1a.as<T>(), n, 4 * H, 1);
+        LL_LAUNCH_CHECK();
+        LL_TRY(linear_launch(dt, e->t1a.p, 4 * H, e->pw(p + "mlp.4.weight"), 4 * H, e->pf(p + "mlp.4.bias"), e->z.p, H, n, H, 4 * H, 0, 1, st));
+        const float *lnw = cf.kind == 0 ? e->pf("norms." + std::to_string(l) + ".weight") : nullptr;
+        const float *lnb = cf.kind == 0 ? e->pf("norms." + std::to_string(l) + ".bias") : nullptr;
+        const float *mod = cf.kind == 1 ? e->mod.as<float>() + (size_t)l * Gp * 3 * H : nullptr;
+        hipLaunchKernelGGL(gin_post_kernel, rows_n, blk, 0, st, e->z.as<float>(), e->h_in.as<float>(), lnw, lnb, mod, batch, e->h.as<float>(), n, H, last ? 0 : 1);
+        LL_LAUNCH_CHECK();
+        if (!last) {  // virtual node update from max-pooled h_in (model.py:147-150)
+            const std::string q = "mlp_virtualnode_list." + std::to_string(l) + ".";
+            hipLaunchKernelGGL((segment_pool_kernel<T, true>), dim3(G), blk, 0, st, e->h_in.as<float>(), gptr, (float *)nullptr, e->poola.as<T>(), H);
+            LL_LAUNCH_CHECK();
+            LL_TRY(linear_launch(dt, e->poola.p, H, e->pw(q + "0.weight"), H, e->pf(q + "0.bias"), e->vt1.p, 4 * H, G, 4 * H, H, 0, 1, st));
+            hipLaunchKernelGGL((rows_ln_act_kernel<T>), rows_g, blk, 0, st, e->vt1.as<float>(), e->pf(q + "1.weight"), e->pf(q + "1.bias"), e->vt1a.as<T>(), G, 4 * H, 1);
+            LL_LAUNCH_CHECK();
+            LL_TRY(linear_launch(dt, e->vt1a.p, 4 * H, e->pw(q + "4.weight"), 4 * H, e->pf(q + "4.bias"), e->vt2.p, H, G, H, 4 * H, 0, 1, st));
+            hipLaunchKernelGGL(add_rows_kernel, dim3(cdiv(G * H, 256)), blk, 0, st, e->vn.as<float>(), e->vt2.as<float>(), (int64_t)G * H);
+            LL_LAUNCH_CHECK();
+        }
+    }
+    hipLaunchKernelGGL((segment_pool_kernel<T, false>), dim3(G), blk, 0, st, e->h.as<float>(), gptr, e->pool32.as<float>(), e->poola.as<T>(), H);
+    LL_LAUNCH_CHECK();
+    if (pooled) LL_HIP(hipMemcpyAsync(pooled, e->pool32.p, (size_t)G * H * 4, hipMemcpyDeviceToDevice, st));
+    if (cf.kind == 0) {  // ProjectionHead + L2 normalise (model.py:37-41,198-205)
+        LL_TRY(e->head1.ensure((size_t)Gp * H * 4));
+        LL_TRY(e->head1a.ensure((size_t)Gp * H * es));
+        LL_TRY(e->head2.ensure((size_t)Gp * H * 4));
+        LL_TRY(linear_launch(dt, e->poola.p, H, e->pw("proj.fc1.weight"), H, e->pf("proj.fc1.bias"), e->head1.p, H, G, H, H, 0, 1, st));
+        hipLaunchKernelGGL((rows_ln_act_kernel<T>), rows_g, blk, 0, st, e->head1.as<float>(), e->pf("proj.norm1.weight"), e->pf("proj.norm1.bias"), e->head1a.as<T>(), G, H, 1);
+        LL_LAUNCH_CHECK();
+        LL_TRY(linear_launch(dt, e->head1a.p, H, e->pw("proj.fc2.weight"), H, e->pf("proj.fc2.bias"), e->head2.p, H, G, H, H, 0, 1, st));
+        hipLaunchKernelGGL(l2norm_rows_kernel, rows_g, blk, 0, st, e->head2.as<float>(), out, G, H);
+        LL_LAUNCH_CHECK();
+    } else {  // decoder: Linear(H,4H) -> LN -> GELU -> Linear(4H,out_dim)  (model.py:272-278)
+        LL_TRY(e->head1.ensure((size_t)Gp * 4 * H * 4));
+        LL_TRY(e->head1a.ensure((size_t)Gp * 4 * H * es));
+        LL_TRY(linear_launch(dt, e->poola.p, H, e->pw("decoder.0.weight"), H, e->pf("decoder.0.bias"), e->head1.p, 4 * H, G, 4 * H, H, 0, 1, st));
+        hipLaunchKernelGGL((rows_ln_act_kernel<T>), rows_g, blk, 0, st, e->head1.as<float>(), e->pf("decoder.1.weight"), e->pf("decoder.1.bias"), e->head1a.as<T>(), G, 4 * H, 1);
+        LL_LAUNCH_CHECK();
+        LL_TRY(linear_launch(dt, e->head1a.p, 4 * H, e->pw("decoder.4.weight"), 4 * H, e->pf("decoder.4.bias"), out, cf.out_dim, G, cf.out_dim, 4 * H, 0, 1, st));
+    }
+    return LL_OK;
+}
+
+}  // namespace ll
+
+using namespace ll;
+
+extern "C" {
+
+int ll_gin_param_count(const LLGinConfig *cfg) {
+    if (gin_check(cfg) != LL_OK) return LL_EINVAL;
+    return (int)gin_layout(*cfg).size();
+}
+int ll_gin_param_info(const LLGinConfig *cfg, int idx, char *name, int name_cap, int64_t *numel, int64_t *offset) {
+    LL_TRY(gin_check(cfg));
+    auto v = gin_layout(*cfg);
+    LL_CHECK(idx >= 0 && idx < (int)v.size(), "param index %d out of range", idx);
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", v[idx].name.c_str());
+    if (numel) *numel = v[idx].numel;
+    if (offset) *offset = v[idx].offset;
+    return LL_OK;
+}
+int64_t ll_gin_arena_elems(const LLGinConfig *cfg) {
+    if (gin_check(cfg) != LL_OK) return LL_EINVAL;
+    auto v = gin_layout(*cfg);
+    return v.back().offset + (v.back().numel + 63) / 64 * 64;
+}
+int ll_gin_create(const LLGinConfig *cfg, const float *d_weights_f32, void **handle) {
+    LL_TRY(gin_check(cfg));
+    LL_CHECK(d_weights_f32 && handle, "null argument");
+    GinEngine *e = new GinEngine();
+    e->cfg = *cfg;
+    e->layout = gin_layout(*cfg);
+    e->w32 = d_weights_f32;
+    if (cfg->dtype == LL_BF16) {
+        const int64_t elems = ll_gin_arena_elems(cfg);
+        int rc = e->wop.ensure((size_t)elems * 2);
+        if (rc == LL_OK) rc = convert_f32_to_bf16(d_weights_f32, e->wop.as<bf16_t>(), elems, 0);
+        if (rc != LL_OK) {
+            delete e;
+            return rc;
+        }
+    }
+    if (hipDeviceSynchronize() != hipSuccess) {
+        set_error("hipDeviceSynchronize failed in ll_gin_create");
+        delete e;
+        return LL_EHIP;
+    }
+    *handle = e;
+    return LL_OK;
+}
+int ll_gin_destroy(void *handle) {
+    GinEngine *e = (GinEngine *)handle;
+    if (!e) return LL_OK;
+    (void)hipDeviceSynchronize();
+    GBuf *bufs[] = {&e->wop, &e->h, &e->h_in, &e->z0, &e->t1, &e->t1a, &e->z, &e->vn, &e->pool32, &e->poola, &e->vt1,
+                    &e->vt1a, &e->vt2, &e->mod, &e->csilu, &e->head1, &e->head1a, &e->head2};
+    for (GBuf *b : bufs) b->release();
+    delete e;
+    return LL_OK;
+}
+
+int ll_gin_forward(void *handle, const int32_t *x, const int32_t *rowptr, const int32_t *src, const int32_t *attr,
+                   const int32_t *batch, const int32_t *gptr, int n_nodes, int n_edges, int n_graphs, const float *c,
+                   float *out, float *pooled, void *stream) {
+    GinEngine *e = (GinEngine *)handle;
+    LL_CHECK(e && x && rowptr && batch && gptr && out, "null argument");
+    LL_CHECK(n_nodes >= 1 && n_graphs >= 1 && n_edges >= 0, "empty graph batch");
+    LL_CHECK(n_edges == 0 || (src && attr), "edges given without src/attr");
+    if (e->cfg.dtype == LL_BF16)
+        return gin_forward_t<bf16_t>(e, x, rowptr, src, attr, batch, gptr, n_nodes, n_edges, n_graphs, c, out, pooled, (hipStream_t)stream);
+    return gin_forward_t<float>(e, x, rowptr, src, attr, batch, gptr, n_nodes, n_edges, n_graphs, c, out, pooled, (hipStream_t)stream);
+}
+
+int ll_softmax_topk(const float *logits, int rows, int out_dim, int k, float *probs, int32_t *idx, void *stream) {
+    LL_CHECK(logits && probs && idx, "null argument");
+    LL_CHECK(rows >= 1 && out_dim >= 1, "empty input");
+    LL_CHECK(k >= 1 && k <= 64 && k <= out_dim, "k=%d must be in [1, min(64, out_dim)]", k);
+    hipLaunchKernelGGL(softmax_topk_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, out_dim, k, probs, idx);
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+int ll_cost_mlp(const float *weights, const float *fps, int n, float *out, void *stream) {
+    LL_CHECK(weights && fps && out && n >= 1, "bad argument");
+    hipLaunchKernelGGL(cost_mlp_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, weights, fps, out);
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,352 @@
+"""GraphDiT on MI355X: drop-in for reference ``src/model/graph_decoder/diffusion_model.py:GraphDiT``.
+
+Same constructor, attributes and method signatures:
+``GraphDiT(model_config_path, data_info_path, model_dtype)``, ``init_model(dir)``,
+``save_pretrained(dir)``, ``disable_grads()``, ``generate(properties, text_embedding,
+no_label_index) -> List[Optional[str]]``, ``check_valid(smiles)``, plus ``.denoiser`` whose
+``state_dict()`` keys are the reference ``Transformer``'s.  The arithmetic (denoiser, posterior,
+guidance, sampling) runs in the HIP engine behind ``include/llamole_hip.h``; nothing here falls
+back to PyTorch math, and a missing library raises at import of ``_lib``.
+
+Differences that are deliberate and documented:
+  * the schedule / marginal tables and the posterior are f32 even when ``model_dtype`` is bf16
+    (the reference builds them in the compute dtype, diffusion_model.py:78-101);
+  * per-step sampling noise comes from an on-device Philox4x32-10 stream, so trajectories are
+    reproducible per ``seed`` but not bit-identical to torch's CUDA generator; tests inject noise;
+  * ``n_nodes`` and ``z_T`` consume torch's *CPU* generator exactly like the reference does
+    (Categorical.sample, then two multinomial(1) draws: diffusion_utils.py:143-170, 495-518).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from types import SimpleNamespace
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .synth import dit_weight_shapes
+from .weights import WeightBag, engine_dtype, pack_arena
+
+XDIM, EDIM, YDIM = 16, 5, 10
+
+
+def _to_namespace(d):
+    return SimpleNamespace(**{k: _to_namespace(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+
+class DataInfos:
+    """Parsed ``data.meta.json`` (reference diffusion_utils.py:29-59)."""
+
+    def __init__(self, meta_filename: str):
+        if not os.path.exists(meta_filename):
+            raise FileNotFoundError(f"Meta file {meta_filename} not found.")
+        with open(meta_filename, "r") as f:
+            meta = json.load(f)
+        self.meta = meta
+        self.active_atoms = meta["active_atoms"]
+        self.atom_decoder = meta["active_atoms"]
+        self.max_n_nodes = int(meta["max_node"])
+        self.n_nodes = torch.tensor(meta["n_atoms_per_mol_dist"], dtype=torch.float32)
+        self.edge_types = torch.tensor(meta["bond_type_dist"], dtype=torch.float32)
+        self.transition_E = torch.tensor(meta["transition_E"], dtype=torch.float32)
+        atom_dist = torch.tensor(meta["atom_type_dist"], dtype=torch.float32)
+        self.active_index = (atom_dist > 0).nonzero().squeeze()
+        self.node_types = atom_dist[self.active_index]
+        val_len = 3 * self.max_n_nodes - 2
+        mv = torch.tensor(meta["valencies"], dtype=torch.float32)
+        self.valency_distribution = torch.zeros(val_len)
+        k = min(val_len, len(mv))
+        self.valency_distribution[:k] = mv[:k]
+        self.input_dims = {"X": XDIM, "E": EDIM, "y": YDIM}
+        self.output_dims = {"X": XDIM, "E": EDIM, "y": YDIM}
+        if self.node_types.numel() != XDIM:
+            raise ValueError(f"data.meta.json has {self.node_types.numel()} active atom types, expected {XDIM}")
+
+
+def load_config(config_path, data_meta_info_path):
+    """reference diffusion_utils.py:62-75."""
+    import yaml
+    if not os.path.exists(config_path):
+        raise FileNotFoundError(f"Configuration file not found: {config_path}")
+    if not os.path.exists(data_meta_info_path):
+        raise FileNotFoundError(f"Data meta info file not found: {data_meta_info_path}")
+    with open(config_path, "r") as f:
+        cfg = _to_namespace(yaml.safe_load(f))
+    return cfg, DataInfos(str(data_meta_info_path))
+
+
+def cosine_beta_schedule_discrete(timesteps: int, s: float = 0.008) -> np.ndarray:
+    """Cosine schedule in f64 (reference diffusion_utils.py:364-373)."""
+    steps = timesteps + 2
+    x = np.linspace(0, steps, steps)
+    ac = np.cos(0.5 * np.pi * ((x / steps) + s) / (1 + s)) ** 2
+    ac = ac / ac[0]
+    return (1 - ac[1:] / ac[:-1]).squeeze()
+
+
+def transition_tables(data_info: DataInfos, T: int):
+    """Marginals, cross conditionals and schedule (diffusion_model.py:78-103, diffusion_utils.py:172-187)."""
+    nt, et = data_info.node_types.float(), data_info.edge_types.float()
+    x_marg = nt / nt.sum()
+    e_marg = et / et.sum()
+    x_marg = x_marg / x_marg.sum()
+    e_marg = e_marg / e_marg.sum()
+    ai = data_info.active_index
+    xe = data_info.transition_E.float()[ai][:, ai].sum(dim=1)
+    ex = xe.t()
+    xe = xe / xe.sum(dim=-1, keepdim=True)
+    ex = ex / ex.sum(dim=-1, keepdim=True)
+    betas = torch.from_numpy(cosine_beta_schedule_discrete(T)).float()
+    alphas = 1 - torch.clamp(betas, min=0, max=1)
+    alphas_bar = torch.exp(torch.cumsum(torch.log(alphas), dim=0))
+    return dict(x_marg=x_marg.contiguous(), e_marg=e_marg.contiguous(), u_xe=xe.contiguous(),
+                u_ex=ex.contiguous(), betas=betas.contiguous(), alphas_bar=alphas_bar.contiguous())
+
+
+class GraphDiT(nn.Module):
+    def __init__(self, model_config_path, data_info_path, model_dtype):
+        super().__init__()
+        dm_cfg, data_info = load_config(model_config_path, data_info_path)
+        self.model_config = dm_cfg
+        self.data_info = data_info
+        self.T = int(dm_cfg.diffusion_steps)
+        self.guide_scale = dm_cfg.guide_scale
+        self.Xdim = self.Xdim_output = XDIM
+        self.Edim = self.Edim_output = EDIM
+        self.ydim = self.ydim_output = YDIM
+        self.active_index = data_info.active_index
+        self.max_n_nodes = data_info.max_n_nodes
+        self.atom_decoder = data_info.atom_decoder
+        self.hidden_size = int(dm_cfg.hidden_size)
+        self.text_input_size = 768
+        self.model_dtype = model_dtype
+        self.node_hist = data_info.n_nodes.clone()
+        cfgd = dict(hidden_size=self.hidden_size, depth=int(dm_cfg.depth), num_heads=int(dm_cfg.num_heads),
+                    mlp_ratio=float(getattr(dm_cfg, "mlp_ratio", 4.0)))
+        self._cfgd = cfgd
+        self.denoiser = WeightBag(dit_weight_shapes(cfgd, self.max_n_nodes))
+        self.tables = transition_tables(data_info, self.T)
+        self._handle = None
+        self._arena = None
+        self._fingerprint = None
+        self._engine_dtype = None
+        self.last_run = None   # (ms, steps) of the most recent on-device trajectory
+
+    # ------------------------------------------------------------------ reference surface
+    def init_model(self, model_dir, verbose=False):
+        model_file = os.path.join(model_dir, "model.pt")
+        if not os.path.exists(model_file):
+            raise FileNotFoundError(f"Model file not found: {model_file}")
+        self.denoiser.load_state_dict(torch.load(model_file, map_location="cpu", weights_only=True))
+        if verbose:
+            print("GraphDiT Denoiser Model initialized.")
+
+    def save_pretrained(self, output_dir):
+        import yaml
+        os.makedirs(output_dir, exist_ok=True)
+        torch.save(self.denoiser.state_dict(), os.path.join(output_dir, "model.pt"))
+        with open(os.path.join(output_dir, "model_config.yaml"), "w") as f:
+            yaml.dump(vars(self.model_config), f)
+        di = self.data_info
+        with open(os.path.join(output_dir, "data.meta.json"), "w") as f:
+            json.dump({"active_atoms": di.active_atoms, "max_node": di.max_n_nodes,
+                       "n_atoms_per_mol_dist": di.n_nodes.tolist(), "bond_type_dist": di.edge_types.tolist(),
+                       "transition_E": di.transition_E.tolist(), "atom_type_dist": di.meta["atom_type_dist"],
+                       "valencies": di.valency_distribution.tolist()}, f, indent=2)
+
+    def disable_grads(self):
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def check_valid(self, smiles):
+        from .molecule_utils import check_valid
+        return check_valid(smiles)
+
+    def forward(self, x, edge_index, edge_attr, graph_batch, properties, text_embedding, no_label_index):
+        # SFT loss (diffusion_model.py:148-177).  The reference computes it and discards it
+        # (modeling_llamole.py:421-425); it is outside the generation hot path.
+        raise NotImplementedError("GraphDiT training loss is not part of the MI355X generation path")
+
+    # ------------------------------------------------------------------ engine management
+    def _device(self) -> torch.device:
+        p = next(self.denoiser.parameters())
+        if p.device.type != "cuda":
+            raise RuntimeError("GraphDiT runs on the HIP device only: call .to('cuda') first (no CPU path)")
+        return p.device
+
+    def _config(self, dtype_code: int) -> "_lib.LLDitConfig":
+        c = self._cfgd
+        gs = 1.0 if self.guide_scale is None else float(self.guide_scale)
+        return _lib.LLDitConfig(c["hidden_size"], c["depth"], c["num_heads"], int(c["hidden_size"] * c["mlp_ratio"]),
+                                self.max_n_nodes, self.T, gs, dtype_code)
+
+    def _ensure_engine(self):
+        dev = self._device()
+        fp = self.denoiser.fingerprint()
+        if self._handle is not None and fp == self._fingerprint:
+            return
+        self._release()
+        lib = _lib.load()
+        p0 = next(self.denoiser.parameters())
+        code = engine_dtype(p0.dtype if p0.dtype != torch.float32 else self.model_dtype)
+        cfg = self._config(code)
+        with torch.cuda.device(dev):
+            self._arena = pack_arena("dit", cfg, self.denoiser.state_dict().items(), dev)
+            t = self.tables
+            tabs = _lib.LLDitTables(*[C.c_void_p(t[k].data_ptr()) for k in
+                                      ("x_marg", "e_marg", "u_xe", "u_ex", "betas", "alphas_bar")])
+            torch.cuda.synchronize(dev)
+            h = C.c_void_p()
+            _lib.check(lib.ll_dit_create(C.byref(cfg), C.byref(tabs), _lib.dptr(self._arena), C.byref(h)), "ll_dit_create")
+        self._handle, self._fingerprint, self._engine_dtype = h, fp, code
+        self._cfg_struct = cfg
+
+    def _release(self):
+        if self._handle is not None:
+            _lib.load().ll_dit_destroy(self._handle)
+        self._handle = None
+        self._arena = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ sampling
+    def sample_n_nodes(self, batch_size: int) -> torch.Tensor:
+        """Categorical(hist).sample((B,)) on the CPU generator (diffusion_utils.py:143-170)."""
+        p = self.node_hist / self.node_hist.sum()
+        return torch.multinomial(p, batch_size, replacement=True)
+
+    @torch.no_grad()
+    def begin(self, properties: torch.Tensor, text_embedding: torch.Tensor, no_label_index, n_nodes=None):
+        """Start a batch on the engine; returns n_nodes (CPU int64)."""
+        self._ensure_engine()
+        dev = self._device()
+        props = properties.detach().to(device=dev, dtype=torch.float32)
+        props = torch.where(props == no_label_index, torch.full_like(props, float("nan")), props).contiguous()
+        text = text_embedding.detach().to(device=dev, dtype=torch.float32).contiguous()
+        B = props.shape[0]
+        if props.shape != (B, YDIM) or text.shape != (B, self.text_input_size):
+            raise ValueError(f"expected properties [B,10] and text_embedding [B,768], got {tuple(props.shape)}, {tuple(text.shape)}")
+        if n_nodes is None:
+            n_nodes = self.sample_n_nodes(B)
+        n_nodes = torch.as_tensor(n_nodes).to("cpu", torch.int64)
+        if int(n_nodes.max()) > self.max_n_nodes or int(n_nodes.min()) < 0:
+            raise ValueError("n_nodes out of range")
+        self._n_nodes_dev = n_nodes.to(device=dev, dtype=torch.int32).contiguous()
+        self._B = B
+        _lib.check(_lib.load().ll_dit_begin(self._handle, B, _lib.dptr(props), _lib.dptr(text),
+                                            _lib.dptr(self._n_nodes_dev), _lib.current_stream_ptr()), "ll_dit_begin")
+        self._keep = (props, text)
+        return n_nodes
+
+    def init_state(self, qx: Optional[torch.Tensor] = None, qe: Optional[torch.Tensor] = None, seed: int = 0):
+        dev = self._device()
+        if qx is not None:
+            qx = qx.to(device=dev, dtype=torch.float32).contiguous()
+            qe = qe.to(device=dev, dtype=torch.float32).contiguous()
+        _lib.check(_lib.load().ll_dit_init_state(self._handle, _lib.dptr(qx), _lib.dptr(qe), C.c_uint64(seed),
+                                                 _lib.current_stream_ptr()), "ll_dit_init_state")
+        self._keep_noise = (qx, qe)
+
+    def step(self, s: int, qx: Optional[torch.Tensor] = None, qe: Optional[torch.Tensor] = None, seed: int = 0):
+        dev = self._device()
+        if qx is not None:
+            qx = qx.to(device=dev, dtype=torch.float32).contiguous()
+            qe = qe.to(device=dev, dtype=torch.float32).contiguous()
+        _lib.check(_lib.load().ll_dit_step(self._handle, int(s), _lib.dptr(qx), _lib.dptr(qe), C.c_uint64(seed),
+                                           _lib.current_stream_ptr()), "ll_dit_step")
+        self._keep_noise = (qx, qe)
+
+    def run(self, seed: int = 0, use_graph: bool = True):
+        _lib.check(_lib.load().ll_dit_run(self._handle, C.c_uint64(seed), int(use_graph), _lib.current_stream_ptr()), "ll_dit_run")
+
+    def last_run_ms(self) -> Tuple[float, int]:
+        ms, steps = C.c_float(), C.c_int()
+        _lib.check(_lib.load().ll_dit_last_run_ms(self._handle, C.byref(ms), C.byref(steps)), "ll_dit_last_run_ms")
+        return ms.value, steps.value
+
+    def get_state(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        dev = self._device()
+        N = self.max_n_nodes
+        X = torch.empty(self._B, N, dtype=torch.int8, device=dev)
+        E = torch.empty(self._B, N, N, dtype=torch.int8, device=dev)
+        _lib.check(_lib.load().ll_dit_get_state(self._handle, _lib.dptr(X), _lib.dptr(E), _lib.current_stream_ptr()), "ll_dit_get_state")
+        return X, E
+
+    def set_state(self, X: torch.Tensor, E: torch.Tensor):
+        dev = self._device()
+        X = X.to(device=dev, dtype=torch.int8).contiguous()
+        E = E.to(device=dev, dtype=torch.int8).contiguous()
+        _lib.check(_lib.load().ll_dit_set_state(self._handle, _lib.dptr(X), _lib.dptr(E), _lib.current_stream_ptr()), "ll_dit_set_state")
+        torch.cuda.current_stream().synchronize()
+
+    # parity taps -----------------------------------------------------------------------------
+    def denoise_logits(self, s: int, tap_layer: Optional[int] = None):
+        dev = self._device()
+        B, N, H = self._B, self.max_n_nodes, self.hidden_size
+        lx = torch.empty(2, B, N, XDIM, device=dev)
+        le = torch.empty(2, B, N, N, EDIM, device=dev)
+        hid = torch.empty(2, B, N, H, device=dev) if tap_layer is not None else None
+        _lib.check(_lib.load().ll_dit_denoise(self._handle, int(s), _lib.dptr(lx), _lib.dptr(le), _lib.dptr(hid),
+                                              -1 if tap_layer is None else int(tap_layer), _lib.current_stream_ptr()), "ll_dit_denoise")
+        return (lx, le, hid) if tap_layer is not None else (lx, le)
+
+    def step_probs(self, s: int):
+        dev = self._device()
+        B, N = self._B, self.max_n_nodes
+        px = torch.empty(B, N, XDIM, device=dev)
+        pe = torch.empty(B, N, N, EDIM, device=dev)
+        _lib.check(_lib.load().ll_dit_step_probs(self._handle, int(s), _lib.dptr(px), _lib.dptr(pe), _lib.current_stream_ptr()), "ll_dit_step_probs")
+        return px, pe
+
+    def cvec(self, s: int):
+        dev = self._device()
+        c = torch.empty(self._B + 1, self.hidden_size, device=dev)
+        _lib.check(_lib.load().ll_dit_cvec(self._handle, int(s), _lib.dptr(c), _lib.current_stream_ptr()), "ll_dit_cvec")
+        return c
+
+    # ------------------------------------------------------------------ generation
+    @torch.no_grad()
+    def generate_graphs(self, properties, text_embedding, no_label_index, n_nodes=None,
+                        noise_fn: Optional[Callable[[int], Tuple[torch.Tensor, torch.Tensor]]] = None,
+                        seed: Optional[int] = None, use_graph: bool = True):
+        """GraphDiT.generate up to the integer graphs (diffusion_model.py:252-298).
+
+        Returns ``(molecule_list, n_nodes)`` where ``molecule_list[i] = [atom_types[n_i] int64,
+        edge_types[n_i,n_i] int64]`` on the CPU -- exactly what the reference hands to graph_to_smiles.
+        ``noise_fn(step) -> (qx [B*N,16], qe [B*N*N,5])`` injects Exp(1) race noise (step == T is z_T)."""
+        n_nodes = self.begin(properties, text_embedding, no_label_index, n_nodes)
+        B, N, T = self._B, self.max_n_nodes, self.T
+        if noise_fn is not None:
+            self.init_state(*noise_fn(T))
+            for s in reversed(range(T)):
+                self.step(s, *noise_fn(s))
+        else:
+            # z_T from torch's CPU generator, in the reference's draw order
+            qx = torch.empty(B * N, XDIM).exponential_()
+            qe = torch.empty(B * N * N, EDIM).exponential_()
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            self.init_state(qx, qe, seed)
+            self.run(seed, use_graph)
+        X, E = self.get_state()
+        X, E = X.cpu().long(), E.cpu().long()
+        mols = []
+        for i in range(B):
+            n = int(n_nodes[i])
+            mols.append([X[i, :n].clone(), E[i, :n, :n].clone()])
+        return mols, n_nodes
+
+    @torch.no_grad()
+    def generate(self, properties, text_embedding, no_label_index) -> List[Optional[str]]:
+        mols, _ = self.generate_graphs(properties, text_embedding, no_label_index)
+        from .molecule_utils import graph_to_smiles
+        return graph_to_smiles(mols, self.atom_decoder)

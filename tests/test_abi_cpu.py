@@ -1,0 +1,93 @@
+"""CPU-side checks of the C-ABI boundary: the library builds, loads, and exports every symbol that
+include/llamole_hip.h declares; layout queries (pure host code) agree with the reference state-dict
+key tables.  No compute call is made (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from llamole_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from llamole_amd.build import build
+    build(verbose=False)
+    return _lib.load()
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "llamole_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ll_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in llamole_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes signature table out of sync with the header"
+
+
+def test_version_and_error_string(lib):
+    assert lib.ll_version() >= 100
+    bad = _lib.LLDitConfig(100, 2, 4, 400, 32, 50, 2.0, 0)      # hidden not a multiple of 64
+    assert lib.ll_dit_param_count(C.byref(bad)) < 0
+    assert b"hidden" in lib.ll_last_error()
+    with pytest.raises(RuntimeError, match="hidden"):
+        _lib.check(lib.ll_dit_param_info(C.byref(bad), 0, None, 0, None, None))
+
+
+@pytest.mark.parametrize("H,L,heads,N", [(128, 2, 4, 32), (256, 2, 4, 50), (1024, 28, 16, 32)])
+def test_dit_layout_matches_reference_state_dict(lib, H, L, heads, N):
+    cfg = _lib.LLDitConfig(H, L, heads, 4 * H, N, 50, 2.0, 1)
+    table = _lib.param_table("dit", cfg)
+    shapes = synth.dit_weight_shapes(synth.make_dit_config(H, L, heads), N)
+    assert [t[0] for t in table] == list(shapes.keys())
+    end = 0
+    for (name, numel, off), shp in zip(table, shapes.values()):
+        n = 1
+        for d in shp:
+            n *= d
+        assert numel == n, name
+        assert off >= end and off % 64 == 0
+        end = off + numel
+    assert lib.ll_dit_arena_elems(C.byref(cfg)) >= end
+    if (H, L) == (1024, 28):   # parameter count of the reference-default denoiser
+        assert sum(t[1] for t in table) == 573_662_736
+
+
+@pytest.mark.parametrize("kind", ["encoder", "predictor"])
+def test_gin_layout_matches_reference_state_dict(lib, kind):
+    L, H, out_dim = 3, 64, 1000
+    cfg = _lib.LLGinConfig(L, H, 0 if kind == "encoder" else 1, out_dim, 768, 0)
+    table = {t[0]: t[1] for t in _lib.param_table("gin", cfg)}
+    shapes = dict(synth.gin_weight_shapes(L, H, kind, out_dim))
+    if kind == "encoder":
+        shapes.update({"proj." + k: v for k, v in synth.proj_weight_shapes(H).items()})
+    assert sorted(table) == sorted(shapes)
+    for k, shp in shapes.items():
+        n = 1
+        for d in shp:
+            n *= d
+        assert table[k] == n, k
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "llamole_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
