@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Benchmark of the Llamole interleaved-generation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload graphdit|e2e]
+
+One "step" = one pass of the hot path over one batch of synthetic prompts+conditions:
+  * graphdit : B property/text conditions -> full T-step GraphDiT reverse diffusion -> B integer
+               molecule graphs (BASELINE.json configs[0] shape at the reference-default denoiser size);
+  * e2e      : BASELINE.json configs[1]: Qwen2-7B (random-init, HF on PyTorch-ROCm) decodes to the
+               design trigger, query-token re-forward, connector, then the GraphDiT trajectory.
+Prints ONE JSON line (rank 0).  `value` = molecules/s over all ranks (weak scaling: every rank runs
+its own batch of independent prompts; no data-path collective, one small all-gather of the graphs).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from llamole_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0
+
+
+def dit_step_bytes(H, L, Hm, N, B, esz):
+    """Algorithmic HBM bytes of one reverse step: in-loop weights once
+    (qkv, proj, fc1, fc2 per block + decoder; adaLN weights are hoisted out of the loop) plus the
+    hoisted modulation rows, the int8 state and the decoder output."""
+    F = 16 + 5 * N
+    w = L * (3 * H * H + H * H + 2 * H * Hm) + H * H + F * H
+    mod = (B + 1) * (L * 6 * H + 2 * F) * 4
+    state = 2 * (B * N + B * N * N) + 2 * B * N * F * 4
+    return w * esz + mod + state
+
+
+def dit_step_flops(H, L, Hm, N, B):
+    F = 16 + 5 * N
+    M2 = 2 * B * N
+    lin = 2 * M2 * (L * (4 * H * H + 2 * H * Hm) + H * H + F * H)
+    att = 2 * B * L * 4 * N * N * H
+    return lin + att
+
+
+def build_model(args, device):
+    import tempfile
+    from llamole_amd.graph_decoder import GraphDiT
+    cfg = synth.make_dit_config(args.hidden, args.depth, args.heads, args.T, args.guide)
+    meta = synth.make_data_meta(args.nodes, 0, fixed_n_nodes=args.nodes)
+    sd = synth.make_dit_weights(cfg, args.nodes, 0)
+    d = tempfile.mkdtemp()
+    synth.write_dit_dir(d, cfg, meta, {})          # config.yaml + data.meta.json only
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    m = GraphDiT(os.path.join(d, "config.yaml"), os.path.join(d, "data.meta.json"), dtype)
+    m.denoiser.load_state_dict(sd)
+    m.to(device)
+    if dtype != torch.float32:
+        for p in m.parameters():
+            p.data = p.data.to(dtype)
+    return m, cfg, meta, sd
+
+
+def cpu_baseline(args, cfg, meta, sd, props, text, n_nodes):
+    """The oracle (CPU restatement of the reference path, fp32) timed on the host cores of this box,
+    on a bounded sample: a few reverse steps of the same batch, extrapolated to T steps."""
+    from oracle import graphdit_oracle as do
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    spec = do.build_spec(cfg, meta)
+    B, N = props.shape[0], spec.N
+    y = torch.where(props == -200.0, torch.tensor(float("nan")), props)
+    mask = torch.arange(N).unsqueeze(0).expand(B, -1) < n_nodes.unsqueeze(1)
+    X, E = do.initial_state(spec, mask, *synth.exp_noise(0, spec.T, B, N))
+    nsteps, t_used = 0, 0.0
+    with torch.no_grad():
+        s = spec.T - 1
+        do.guided_probs(sd, spec, X, E, mask, y, text, s)   # warm-up
+        while nsteps < 3 or (t_used < 10.0 and nsteps < 8):
+            t0 = time.perf_counter()
+            pX, pE = do.guided_probs(sd, spec, X, E, mask, y, text, s)
+            Xs, Es = do.sample_features(pX, pE, mask, *synth.exp_noise(0, s, B, N))
+            X, E = do.to_onehot_masked(Xs, Es, mask)
+            t_used += time.perf_counter() - t0
+            nsteps += 1
+            s -= 1
+    s_per_step = t_used / nsteps
+    return {"value": B / (spec.T * s_per_step), "unit": "molecules/s", "cores": cores, "kind": "port",
+            "sample": f"{nsteps} reverse steps of the same B={B} batch on {cores} threads (fp32 oracle), "
+                      f"{s_per_step:.3f} s/step, extrapolated to T={spec.T}",
+            "denoise_steps_per_s": 1.0 / s_per_step}
+
+
+def time_dominant_kernel(args, device):
+    """Event-bracketed loop of the dominant kernel (the MLP fc1 GEMM of one block) with the bench's own
+    shapes, on the stream it is launched on.  Returns (avg_ms, bytes, flops, name)."""
+    import ctypes as C
+    from llamole_amd import _lib
+    lib = _lib.load()
+    H, Hm = args.hidden, int(args.hidden * 4)
+    M2 = 2 * args.batch * args.nodes
+    Mp = (M2 + 127) // 128 * 128
+    bf = args.dtype == "bf16"
+    dt = torch.bfloat16 if bf else torch.float32
+    # cycle over enough distinct weight matrices to defeat the 256 MiB Infinity Cache, like the real step
+    nw = max(2, int(600e6 // (Hm * H * (2 if bf else 4))))
+    Ws = [(torch.randn(Hm, H, device=device) * 0.02).to(dt).contiguous() for _ in range(nw)]
+    A = (torch.randn(Mp, H, device=device)).to(dt).contiguous()
+    bias = torch.zeros(Hm, device=device)
+    out = torch.empty(Mp, Hm, device=device, dtype=dt)
+    st = torch.cuda.current_stream()
+    sp = C.c_void_p(st.cuda_stream)
+
+    def launch(i):
+        _lib.check(lib.ll_linear(1 if bf else 0, _lib.dptr(A), H, _lib.dptr(Ws[i % nw]), H, _lib.dptr(bias),
+                                 _lib.dptr(out), Hm, M2, Hm, H, 1, 0, sp))
+    for i in range(nw):
+        launch(i)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 4 * nw
+    e0.record(st)
+    for i in range(iters):
+        launch(i)
+    e1.record(st)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    esz = 2 if bf else 4
+    nbytes = Hm * H * esz + M2 * H * esz + M2 * Hm * esz + Hm * 4
+    flops = 2.0 * M2 * Hm * H
+    return ms, nbytes, flops, f"gemm fc1 [{M2}x{H}]x[{Hm}x{H}]^T {args.dtype}"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="graphdit", choices=["graphdit", "e2e"])
+    ap.add_argument("--batch", type=int, default=None, help="prompts per GPU per step")
+    ap.add_argument("--nodes", type=int, default=32)
+    ap.add_argument("--hidden", type=int, default=1024)
+    ap.add_argument("--depth", type=int, default=28)
+    ap.add_argument("--heads", type=int, default=16)
+    ap.add_argument("--T", type=int, default=50)
+    ap.add_argument("--guide", type=float, default=2.0)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--llm", default="qwen2-7b")
+    ap.add_argument("--new-tokens", type=int, default=128)
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 8 if args.workload == "graphdit" else 1
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    m, cfg, meta, sd = build_model(args, device)
+    B, N, T = args.batch, args.nodes, args.T
+    props, text, n_nodes = synth.make_dit_inputs(B, seed=rank, max_node=N, n_nodes_fixed=N)
+
+    if args.workload == "e2e":
+        from llamole_amd.e2e import build_e2e_step
+        step_fn, e2e_info = build_e2e_step(args, m, device, props, rank)
+    else:
+        e2e_info = {}
+
+        def step_fn(i):
+            mols, _ = m.generate_graphs(props, text, -200.0, n_nodes=n_nodes, seed=1000 * rank + i,
+                                        use_graph=not args.no_graph)
+            return mols
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step_fn(i)
+    barrier()
+    t0 = time.perf_counter()
+    dit_ms = []
+    for i in range(args.steps):
+        mols = step_fn(args.warmup + i)
+        dit_ms.append(m.last_run_ms()[0])
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        # the path's only exchange: all-gather of the generated integer graphs (fixed-size records)
+        rec = torch.full((B, N + N * N), -1, dtype=torch.int8, device=device)
+        for b, (a, e) in enumerate(mols):
+            rec[b, :a.numel()] = a.to(torch.int8).to(device)
+            rec[b, N:N + e.numel()] = e.reshape(-1).to(torch.int8).to(device)
+        allrec = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(allrec, rec)
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    mol_per_s = world * B * args.steps / dt
+    step_ms = float(np.mean(dit_ms)) / T
+    esz = 2 if args.dtype == "bf16" else 4
+    Hm = int(args.hidden * 4)
+    sbytes = dit_step_bytes(args.hidden, args.depth, Hm, N, B, esz)
+    sflops = dit_step_flops(args.hidden, args.depth, Hm, N, B)
+    kms, kbytes, kflops, kname = time_dominant_kernel(args, device)
+    hbm_t, mfma_t = kbytes / (HBM_PEAK_GBS * 1e9), kflops / (MFMA_BF16_PEAK_TF * 1e12)
+    if hbm_t >= mfma_t or args.dtype != "bf16":
+        roof = {"bound": "hbm", "achieved": kbytes / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    else:
+        roof = {"bound": "mfma", "achieved": kflops / (kms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["traffic"] = None
+    roof["kernel"] = kname
+    roof["kernel_ms"] = kms
+    out = {
+        "metric": "generated molecules/sec (end-to-end)" if args.workload == "e2e"
+                  else "generated molecules/sec (GraphDiT reverse diffusion, no LLM)",
+        "value": mol_per_s, "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": ("Qwen2-7B + GraphDiT material design, batch=%d/GPU" % B) if args.workload == "e2e"
+                   else "GraphDiT %d-step reverse diffusion on %d synthetic %d-node graphs/GPU, no LLM" % (T, B, N),
+                   "denoiser": {"hidden": args.hidden, "depth": args.depth, "heads": args.heads, "max_nodes": N,
+                                "T": T, "guide_scale": args.guide},
+                   "hip_graph": not args.no_graph, **e2e_info},
+        "denoise_steps_per_s": world * 1e3 / step_ms,
+        "denoise_step_ms": step_ms,
+        "step_roofline": {"hbm_bytes": sbytes, "flops": sflops,
+                          "hbm_frac": sbytes / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                          "mfma_frac": sflops / (step_ms * 1e-3) / (MFMA_BF16_PEAK_TF * 1e12)},
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, cfg, meta, sd, props, text, n_nodes)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
