@@ -48,30 +48,69 @@ def dit_step_flops(H, L, Hm, N, B):
     return lin + att
 
 
+def log(*a):
+    if os.environ.get("BENCH_VERBOSE"):
+        print("[bench %.1fs]" % (time.perf_counter() - _T0), *a, file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def fast_dit_weights(cfg, max_node, device):
+    """Random-init weights of the reference denoiser's shapes, drawn on the device (seeded):
+    same distributions as synth.make_dit_weights, without the minute of host RNG at 573 M params."""
+    g = torch.Generator(device=device).manual_seed(1234)
+    sd = {}
+    for k, shp in synth.dit_weight_shapes(cfg, max_node).items():
+        if len(shp) == 1:
+            gain = k.endswith(("norm.weight", "x_embedder.1.weight"))
+            sd[k] = (1.0 if gain else 0.0) + (0.1 if gain else 0.05) * torch.randn(shp, generator=g, device=device)
+        elif "embedding" in k:
+            sd[k] = 0.5 * torch.randn(shp, generator=g, device=device)
+        else:
+            sd[k] = (2.0 / (shp[0] + shp[1])) ** 0.5 * torch.randn(shp, generator=g, device=device)
+    return sd
+
+
 def build_model(args, device):
     import tempfile
     from llamole_amd.graph_decoder import GraphDiT
     cfg = synth.make_dit_config(args.hidden, args.depth, args.heads, args.T, args.guide)
     meta = synth.make_data_meta(args.nodes, 0, fixed_n_nodes=args.nodes)
-    sd = synth.make_dit_weights(cfg, args.nodes, 0)
+    sd = fast_dit_weights(cfg, args.nodes, device)
+    log("weights drawn")
     d = tempfile.mkdtemp()
     synth.write_dit_dir(d, cfg, meta, {})          # config.yaml + data.meta.json only
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     m = GraphDiT(os.path.join(d, "config.yaml"), os.path.join(d, "data.meta.json"), dtype)
-    m.denoiser.load_state_dict(sd)
     m.to(device)
+    m.denoiser.load_state_dict(sd)
     if dtype != torch.float32:
         for p in m.parameters():
             p.data = p.data.to(dtype)
     return m, cfg, meta, sd
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box shows 256 logical CPUs but grants a 16-CPU quota; oversubscribing it stalls)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("BENCH_CPU_THREADS", "64"))))
+
+
 def cpu_baseline(args, cfg, meta, sd, props, text, n_nodes):
     """The oracle (CPU restatement of the reference path, fp32) timed on the host cores of this box,
     on a bounded sample: a few reverse steps of the same batch, extrapolated to T steps."""
     from oracle import graphdit_oracle as do
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in sd.items()}
     spec = do.build_spec(cfg, meta)
     B, N = props.shape[0], spec.N
     y = torch.where(props == -200.0, torch.tensor(float("nan")), props)
@@ -171,6 +210,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     m, cfg, meta, sd = build_model(args, device)
+    log("model built")
     B, N, T = args.batch, args.nodes, args.T
     props, text, n_nodes = synth.make_dit_inputs(B, seed=rank, max_node=N, n_nodes_fixed=N)
 
@@ -192,6 +232,7 @@ def main():
 
     for i in range(args.warmup):
         step_fn(i)
+        log("warmup", i)
     barrier()
     t0 = time.perf_counter()
     dit_ms = []
@@ -222,7 +263,9 @@ def main():
     Hm = int(args.hidden * 4)
     sbytes = dit_step_bytes(args.hidden, args.depth, Hm, N, B, esz)
     sflops = dit_step_flops(args.hidden, args.depth, Hm, N, B)
+    log("timed region done", dt)
     kms, kbytes, kflops, kname = time_dominant_kernel(args, device)
+    log("dominant kernel timed", kms)
     hbm_t, mfma_t = kbytes / (HBM_PEAK_GBS * 1e9), kflops / (MFMA_BF16_PEAK_TF * 1e12)
     if hbm_t >= mfma_t or args.dtype != "bf16":
         roof = {"bound": "hbm", "achieved": kbytes / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}

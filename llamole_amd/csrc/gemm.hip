@@ -10,6 +10,8 @@
 //             Tile shape is picked per call so that the launch has >= ~256 workgroups when the
 //             problem allows it (the sampler's GEMMs are skinny: M = 2*B*N tokens).
 // f32 path  : exact-f32 VALU tile kernel, used by the parity mode (dtype = LL_F32).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace ll {
@@ -165,6 +167,136 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_kernel(const bf16_t *__
     }
 }
 
+// ------------------------------------------------------------------------------------------ bf16 MFMA, pipelined
+// Same math and LDS image as gemm_bf16_kernel, but the tiles are filled by direct global->LDS DMA
+// (global_load_lds_dwordx4, no VGPR staging) into a ring of STAGES buffers, with a COUNTED s_waitcnt
+// vmcnt(N) so that STAGES-2 tiles stay in flight across each barrier.  The sampler's GEMMs run ~1
+// workgroup per CU with only 8-16 K-tiles each, so HBM/L2 latency (~0.7 us) per K-tile -- not bandwidth
+// or MFMA rate -- bounds a 2-stage loop; the ring hides it.  The XOR swizzle is applied to the per-lane
+// SOURCE address (the DMA destination is lane-linear: wave-uniform base + lane*16).
+template <int BM, int BN, int WM, int WN, int STAGES, typename OutT>
+__global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipe_kernel(const bf16_t *__restrict__ A, int lda,
+                                                                      const bf16_t *__restrict__ W, int ldw,
+                                                                      OutT *__restrict__ C, int ldc,
+                                                                      const float *__restrict__ bias, int M, int N,
+                                                                      int kchunk, int64_t slab_stride, int epi) {
+    constexpr int NT = WM * WN * 64, NW = WM * WN;
+    constexpr int BK = 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MT = TM / 16, NTL = TN / 16;
+    constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT;  // DMA instructions per thread per tile
+    constexpr int LPT = LA + LB;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "every wave must issue the same number of DMAs per tile");
+    static_assert((STAGES - 2) * LPT <= 63, "vmcnt immediate overflow");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pipe[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * kchunk;
+    const int nk = kchunk / BK;
+
+    // per-lane source pointers (swizzled chunk of the lane's row), advanced by BK elements per tile
+    const bf16_t *pa[LA];
+    const bf16_t *pb[LB];
+#pragma unroll
+    for (int it = 0; it < LA; ++it) {
+        const int c = (it * NW + wave) * 64 + lane;
+        const int row = c >> 3, slot = c & 7;
+        pa[it] = A + (int64_t)(m0 + row) * lda + kbeg + ((slot ^ (row & 7)) << 3);
+    }
+#pragma unroll
+    for (int it = 0; it < LB; ++it) {
+        const int c = (it * NW + wave) * 64 + lane;
+        const int row = c >> 3, slot = c & 7;
+        int gr = n0 + row;
+        gr = gr < N ? gr : N - 1;
+        pb[it] = W + (int64_t)gr * ldw + kbeg + ((slot ^ (row & 7)) << 3);
+    }
+    auto issue = [&](int kt) {
+        unsigned char *sa = smem_pipe + (kt % STAGES) * STAGE_BYTES;
+        unsigned char *sb = sa + BM * 128;
+#pragma unroll
+        for (int it = 0; it < LA; ++it)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa[it] + (int64_t)kt * BK),
+                                             (__attribute__((address_space(3))) void *)(sa + (it * NW + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int it = 0; it < LB; ++it)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb[it] + (int64_t)kt * BK),
+                                             (__attribute__((address_space(3))) void *)(sb + (it * NW + wave) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p)
+        if (p < nk) issue(p);
+
+    const int frow = lane & 15, fk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed once at most (STAGES-2) younger tiles of this wave are still in flight
+        if (kt + STAGES - 2 < nk) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);  // overwrites the buffer read in iteration kt-1
+        const unsigned char *Ab = smem_pipe + (kt % STAGES) * STAGE_BYTES;
+        const unsigned char *Bb = Ab + BM * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[MT], fb[NTL];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = wm * TM + i * 16 + frow;
+                const int ch = kk * 4 + fk;
+                fa[i] = *reinterpret_cast<const bf16x8 *>(Ab + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int row = wn * TN + j * 16 + frow;
+                const int ch = kk * 4 + fk;
+                fb[j] = *reinterpret_cast<const bf16x8 *>(Bb + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    OutT *Cz = C + (int64_t)blockIdx.z * slab_stride;
+    const bool raw = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const int col = n0 + wn * TN + j * 16 + (lane & 15);
+            if (col >= N) continue;
+            const float bv = (!raw && bias) ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * TM + i * 16 + (lane >> 4) * 4 + r;
+                if (row < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (!raw) v = apply_epi(v, epi);
+                    Cz[(int64_t)row * ldc + col] = from_f32<OutT>(v);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ f32 VALU
 // 64x64 tile, BK=16, 256 threads, 4x4 outputs per thread; k-ordered fmaf chain per output.
 template <typename OutT>
@@ -233,6 +365,32 @@ static void launch_bf16(const bf16_t *A, int lda, const bf16_t *W, int ldw, void
                            ldc, bias, M, N, kchunk, slab_stride, epi);
 }
 
+template <int BM, int BN, int WM, int WN, int STAGES>
+static int launch_pipe(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M,
+                       int N, int K, int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
+    constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_bf16_pipe_kernel<BM, BN, WM, WN, STAGES, float>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_bf16_pipe_kernel<BM, BN, WM, WN, STAGES, bf16_t>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), splits);
+    dim3 block(WM * WN * 64);
+    const int kchunk = K / splits;
+    if (out_f32)
+        hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, WM, WN, STAGES, float>), grid, block, lds, s, A, lda, W, ldw,
+                           (float *)C, ldc, bias, M, N, kchunk, slab_stride, epi);
+    else
+        hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, WM, WN, STAGES, bf16_t>), grid, block, lds, s, A, lda, W, ldw,
+                           (bf16_t *)C, ldc, bias, M, N, kchunk, slab_stride, epi);
+    return LL_OK;
+}
+
+static int g_gemm_variant = -1;  // LL_GEMM_VARIANT=0 forces the 2-stage register-staged kernels (A/B testing)
+
 static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
                          int M, int N, int K, int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
     LL_CHECK(M > 0 && N > 0 && K > 0, "ll_linear: empty problem M=%d N=%d K=%d", M, N, K);
@@ -243,6 +401,23 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
         LL_CHECK(lda % 8 == 0 && ldw % 8 == 0, "ll_linear(bf16): lda/ldw must be multiples of 8 elements");
         const bf16_t *a = (const bf16_t *)A;
         const bf16_t *w = (const bf16_t *)W;
+        if (g_gemm_variant < 0) {
+            const char *ev = getenv("LL_GEMM_VARIANT");
+            g_gemm_variant = ev ? atoi(ev) : 1;
+        }
+        if (g_gemm_variant != 0) {
+            // pipelined kernels: prefer the largest tile that still gives >= ~1 workgroup per CU
+            const long w12864 = (long)cdiv(M, 128) * cdiv(N, 64) * splits;
+            const long w6464 = (long)cdiv(M, 64) * cdiv(N, 64) * splits;
+            if (w12864 >= 224)
+                LL_TRY((launch_pipe<128, 64, 2, 2, 4>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
+            else if (w6464 >= 200 || (N % 32 != 0 && N < 64))
+                LL_TRY((launch_pipe<64, 64, 2, 2, 4>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
+            else
+                LL_TRY((launch_pipe<64, 32, 4, 1, 4>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
+            LL_LAUNCH_CHECK();
+            return LL_OK;
+        }
         // Tile choice: fill >= ~256 workgroups when the problem allows it.
         const long wg128 = (long)cdiv(M, 128) * cdiv(N, 128) * splits;
         const long wg64 = (long)cdiv(M, 64) * cdiv(N, 64) * splits;

@@ -15,6 +15,7 @@
 //   * a step is ~7 launches per block; the step index lives in device memory so ONE captured
 //     hipGraph is replayed T times (no host sync inside the trajectory; the reference syncs 3x/step).
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -154,6 +155,7 @@ struct DitEngine {
     int graph_B = -1;
     int last_steps = 0;
     bool timed = false;
+    bool force_generic_attn = false;
 
     const float *pf(const char *name) const {
         for (auto &p : layout)
@@ -190,9 +192,25 @@ template <typename T> static void launch_embed(DitEngine *e, hipStream_t st) {
                        e->E.as<int8_t>(), e->wxT.as<float>(), e->pf("x_embedder.1.weight"), e->pf("x_embedder.1.bias"),
                        e->x32.as<float>(), e->xa.as<T>(), e->B, e->cfg.max_nodes, e->cfg.hidden);
 }
+template <int NP, int HD>
+static void launch_attn_mfma_t(DitEngine *e, const std::string &p, hipStream_t st) {
+    const size_t lds = attn_mfma_lds_bytes<NP, HD>();
+    hipLaunchKernelGGL((attn_mfma_kernel<NP, HD>), dim3(cdiv(e->cfg.heads, 4), 2 * e->B), dim3(256), lds, st, e->qkv.as<bf16_t>(), e->attn_o.as<bf16_t>(),
+                       e->pfs(p + "q_norm.weight"), e->pfs(p + "q_norm.bias"), e->pfs(p + "k_norm.weight"),
+                       e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, e->cfg.max_nodes, e->cfg.hidden,
+                       e->cfg.heads);
+}
 template <typename T> static void launch_attn(DitEngine *e, int layer, hipStream_t st) {
     const int N = e->cfg.max_nodes, hd = e->hd;
     const std::string p = "blocks." + std::to_string(layer) + ".attn.";
+    if (sizeof(T) == 2 && (hd == 32 || hd == 64) && !e->force_generic_attn) {
+        const int NP = N <= 32 ? 32 : 64;
+        if (NP == 32 && hd == 32) launch_attn_mfma_t<32, 32>(e, p, st);
+        else if (NP == 32 && hd == 64) launch_attn_mfma_t<32, 64>(e, p, st);
+        else if (NP == 64 && hd == 32) launch_attn_mfma_t<64, 32>(e, p, st);
+        else launch_attn_mfma_t<64, 64>(e, p, st);
+        return;
+    }
     const size_t lds = (size_t)(3 * N * (hd + 1) + N * (N + 1)) * 4;
     hipLaunchKernelGGL((attn_generic_kernel<T>), dim3(e->cfg.heads, 2 * e->B), dim3(256), lds, st, e->qkv.as<T>(),
                        e->attn_o.as<T>(), e->pfs(p + "q_norm.weight"), e->pfs(p + "q_norm.bias"),
@@ -201,9 +219,19 @@ template <typename T> static void launch_attn(DitEngine *e, int layer, hipStream
 }
 template <typename T>
 static void launch_lnmod(DitEngine *e, int layer, int sel, int nslab, const float *bias, hipStream_t st) {
-    hipLaunchKernelGGL((ln_mod_res_kernel<T>), dim3(cdiv(e->M2, 4)), dim3(256), 0, st, e->ybuf.as<float>(), nslab,
-                       (int64_t)e->M2p * e->cfg.hidden, bias, e->x32.as<float>(), e->xa.as<T>(), e->modtab.as<float>(),
-                       e->step_ptr(), layer, sel, e->B, e->cfg.max_nodes, e->cfg.hidden, e->cfg.depth, e->M2);
+    const dim3 grid(cdiv(e->M2, 4)), blk(256);
+    const int64_t ss = (int64_t)e->M2p * e->cfg.hidden;
+#define LL_LNMOD(NS)                                                                                                   \
+    hipLaunchKernelGGL((ln_mod_res_kernel<T, NS>), grid, blk, 0, st, e->ybuf.as<float>(), ss, bias, e->x32.as<float>(), \
+                       e->xa.as<T>(), e->modtab.as<float>(), e->step_ptr(), layer, sel, e->B, e->cfg.max_nodes,        \
+                       e->cfg.hidden, e->cfg.depth, e->M2)
+    switch (nslab) {
+        case 1: LL_LNMOD(1); break;
+        case 2: LL_LNMOD(2); break;
+        case 4: LL_LNMOD(4); break;
+        default: LL_LNMOD(8); break;
+    }
+#undef LL_LNMOD
 }
 
 static int pick_splits(int M2, int H, int K) {
@@ -376,6 +404,11 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
     // the generic attention kernel may need > 64 KiB of dynamic LDS (N=64, hd>=64)
     CRH(hipFuncSetAttribute((const void *)attn_generic_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CRH(hipFuncSetAttribute((const void *)attn_generic_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<32, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    e->force_generic_attn = getenv("LL_GENERIC_ATTN") != nullptr;
     CRH(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
     CRH(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
     CRH(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
