@@ -46,6 +46,10 @@ const char *ll_last_error(void);
 int ll_linear(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
               int M, int N, int K, int epi, int out_f32, void *stream);
 
+/* Tuning utility: average ms of `iters` launches of pipelined-GEMM configuration `cfg` (-1 = the production
+ * dispatch) on an [M,K]x[N,K]^T bf16 problem, cycling over `nweights` weight matrices (HBM-resident stream). */
+int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f32, int iters, int nweights, float *ms);
+
 /* ------------------------------------------------------------------ GraphDiT sampler
  * Replaces reference GraphDiT.generate / sample_p_zs_given_zt / Transformer.forward
  * (src/model/graph_decoder/diffusion_model.py:252-399, transformer.py:93-187,

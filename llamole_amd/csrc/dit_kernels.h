@@ -206,8 +206,6 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t *__restrict
                                                          const float *__restrict__ kw, const float *__restrict__ kb,
                                                          const int *__restrict__ n_nodes, int B, int N, int H,
                                                          int heads) {
-    constexpr int LPR = 64 / NP;          // lanes per row in the load/LayerNorm phase (2 or 1)
-    constexpr int EPL = HD / LPR;         // elements per lane
     constexpr int QLD = HD + 8;           // padded row strides (elements)
     constexpr int PLD = NP + 8;
     constexpr int QK_ELEMS = NP * QLD;
@@ -225,66 +223,79 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t *__restrict
     bf16_t *Vt = Ks + QK_ELEMS;
     bf16_t *Ps = Qs;
 
-    // ---- load + LayerNorm (q, k), transpose (v)
+    // ---- load + LayerNorm (q, k), transpose (v).  HD/8 lanes cover one row with 16-B loads (full 128-B
+    //      lines for hd = 64); every global load of the wave (3 tensors x PASSES + LN parameters) is issued
+    //      before the first use, so the phase costs one memory round trip.
     {
-        const int row = lane / LPR;
-        const int d0 = (lane % LPR) * EPL;
-        const bool live = row < N;
-        const bf16_t *src = qkv + ((int64_t)seq * N + (live ? row : 0)) * (3 * (int64_t)H) + head * HD + d0;
-        uint4 rq[EPL / 8], rk[EPL / 8], rv[EPL / 8];
+        constexpr int LPR8 = HD / 8;            // lanes per row
+        constexpr int RPP = 64 / LPR8;          // rows per pass
+        constexpr int PASSES = NP / RPP;
+        const int sub = lane % LPR8, rin = lane / LPR8;
+        const int d0 = sub * 8;
+        uint4 rq[PASSES], rk[PASSES], rv[PASSES];
 #pragma unroll
-        for (int c = 0; c < EPL / 8; ++c) {
-            rq[c] = *reinterpret_cast<const uint4 *>(src + c * 8);
-            rk[c] = *reinterpret_cast<const uint4 *>(src + H + c * 8);
-            rv[c] = *reinterpret_cast<const uint4 *>(src + 2 * H + c * 8);
+        for (int p = 0; p < PASSES; ++p) {
+            const int row = p * RPP + rin;
+            const bf16_t *src = qkv + ((int64_t)seq * N + (row < N ? row : 0)) * (3 * (int64_t)H) + head * HD + d0;
+            rq[p] = *reinterpret_cast<const uint4 *>(src);
+            rk[p] = *reinterpret_cast<const uint4 *>(src + H);
+            rv[p] = *reinterpret_cast<const uint4 *>(src + 2 * H);
         }
-        auto norm_store = [&](const uint4 *r, const float *w, const float *bvec, bf16_t *dst) {
-            float f[EPL];
+        float wq[8], bq[8], wk[8], bk[8];
+        {
+            const float4 a0 = *reinterpret_cast<const float4 *>(qw + d0), a1 = *reinterpret_cast<const float4 *>(qw + d0 + 4);
+            const float4 b0 = *reinterpret_cast<const float4 *>(qb + d0), b1 = *reinterpret_cast<const float4 *>(qb + d0 + 4);
+            const float4 c0 = *reinterpret_cast<const float4 *>(kw + d0), c1 = *reinterpret_cast<const float4 *>(kw + d0 + 4);
+            const float4 e0 = *reinterpret_cast<const float4 *>(kb + d0), e1 = *reinterpret_cast<const float4 *>(kb + d0 + 4);
+            wq[0] = a0.x; wq[1] = a0.y; wq[2] = a0.z; wq[3] = a0.w; wq[4] = a1.x; wq[5] = a1.y; wq[6] = a1.z; wq[7] = a1.w;
+            bq[0] = b0.x; bq[1] = b0.y; bq[2] = b0.z; bq[3] = b0.w; bq[4] = b1.x; bq[5] = b1.y; bq[6] = b1.z; bq[7] = b1.w;
+            wk[0] = c0.x; wk[1] = c0.y; wk[2] = c0.z; wk[3] = c0.w; wk[4] = c1.x; wk[5] = c1.y; wk[6] = c1.z; wk[7] = c1.w;
+            bk[0] = e0.x; bk[1] = e0.y; bk[2] = e0.z; bk[3] = e0.w; bk[4] = e1.x; bk[5] = e1.y; bk[6] = e1.z; bk[7] = e1.w;
+        }
+        auto norm_store = [&](const uint4 r, const float *w, const float *bvec, bf16_t *dst, int row) {
+            const bool live = row < N;
+            float f[8];
+            const uint32_t u[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-            for (int c = 0; c < EPL / 8; ++c) {
-                const uint32_t u[4] = {r[c].x, r[c].y, r[c].z, r[c].w};
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    f[c * 8 + 2 * t] = __uint_as_float(u[t] << 16);
-                    f[c * 8 + 2 * t + 1] = __uint_as_float(u[t] & 0xffff0000u);
-                }
+            for (int t = 0; t < 4; ++t) {
+                f[2 * t] = __uint_as_float(u[t] << 16);
+                f[2 * t + 1] = __uint_as_float(u[t] & 0xffff0000u);
             }
             float sm = 0.f;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) sm += f[e];
-            if (LPR == 2) sm += __shfl_xor(sm, 1, 64);
+            for (int e = 0; e < 8; ++e) sm += f[e];
+#pragma unroll
+            for (int off = 1; off < LPR8; off <<= 1) sm += __shfl_xor(sm, off, 64);
             const float mean = sm / (float)HD;
             float vr = 0.f;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
+            for (int e = 0; e < 8; ++e) {
                 const float d = f[e] - mean;
                 vr += d * d;
             }
-            if (LPR == 2) vr += __shfl_xor(vr, 1, 64);
+#pragma unroll
+            for (int off = 1; off < LPR8; off <<= 1) vr += __shfl_xor(vr, off, 64);
             const float rstd = rsqrtf(vr / (float)HD + 1e-5f);
-#pragma unroll
-            for (int c = 0; c < EPL / 8; ++c) {
-                uint32_t pk[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int e0 = c * 8 + 2 * t;
-                    const float a0 = live ? (f[e0] - mean) * rstd * w[d0 + e0] + bvec[d0 + e0] : 0.f;
-                    const float a1 = live ? (f[e0 + 1] - mean) * rstd * w[d0 + e0 + 1] + bvec[d0 + e0 + 1] : 0.f;
-                    pk[t] = (uint32_t)f32_to_bf16(a0) | ((uint32_t)f32_to_bf16(a1) << 16);
-                }
-                *reinterpret_cast<uint4 *>(dst + row * QLD + d0 + c * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            }
-        };
-        norm_store(rq, qw, qb, Qs);
-        norm_store(rk, kw, kb, Ks);
-#pragma unroll
-        for (int c = 0; c < EPL / 8; ++c) {
-            const uint32_t u[4] = {rv[c].x, rv[c].y, rv[c].z, rv[c].w};
+            uint32_t pk[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int d = d0 + c * 8 + 2 * t;
-                Vt[d * PLD + row] = live ? (bf16_t)(u[t] & 0xffffu) : (bf16_t)0;
-                Vt[(d + 1) * PLD + row] = live ? (bf16_t)(u[t] >> 16) : (bf16_t)0;
+                const float a0 = live ? (f[2 * t] - mean) * rstd * w[2 * t] + bvec[2 * t] : 0.f;
+                const float a1 = live ? (f[2 * t + 1] - mean) * rstd * w[2 * t + 1] + bvec[2 * t + 1] : 0.f;
+                pk[t] = (uint32_t)f32_to_bf16(a0) | ((uint32_t)f32_to_bf16(a1) << 16);
+            }
+            *reinterpret_cast<uint4 *>(dst + row * QLD + d0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        };
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int row = p * RPP + rin;
+            norm_store(rq[p], wq, bq, Qs, row);
+            norm_store(rk[p], wk, bk, Ks, row);
+            const bool live = row < N;
+            const uint32_t u[4] = {rv[p].x, rv[p].y, rv[p].z, rv[p].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                Vt[(d0 + 2 * t) * PLD + row] = live ? (bf16_t)(u[t] & 0xffffu) : (bf16_t)0;
+                Vt[(d0 + 2 * t + 1) * PLD + row] = live ? (bf16_t)(u[t] >> 16) : (bf16_t)0;
             }
         }
     }
@@ -393,7 +404,7 @@ template <int NP, int HD> static constexpr size_t attn_mfma_lds_bytes() {
 // x += gate * (LN0(y) * (1 + scale) + shift)       (transformer.py:142-143; LN0 = no affine, eps 1e-5)
 // y = sum of `nslab` split-K partial slabs (+ bias), summed in slab order (deterministic).
 // One wave per token row; modulation rows come from the hoisted table mod[T][B+1][L][6H].
-template <typename T, int NS>
+template <typename T, int NS, int MAXE>
 __global__ __launch_bounds__(256) void ln_mod_res_kernel(const float *__restrict__ y, int64_t slab_stride,
                                                           const float *__restrict__ bias, float *__restrict__ x32,
                                                           T *__restrict__ xa, const float *__restrict__ modtab,
@@ -406,9 +417,9 @@ __global__ __launch_bounds__(256) void ln_mod_res_kernel(const float *__restrict
     const int seq = row / N;
     const int ci = (seq < B) ? seq : B;  // unconditional pass shares one row
     const float *mod = modtab + (((int64_t)s * (B + 1) + ci) * L + layer) * (6 * (int64_t)H) + (int64_t)sel * 3 * H;
-    constexpr int MAXE = 8;  // float4 chunks per lane: H <= 2048
-    float4 v[MAXE], xr[MAXE];
-    // issue every load of the row up front (slabs, bias, residual): one memory round trip
+    // MAXE float4 chunks per lane (H <= 256*MAXE).  Every load of the row -- split-K slabs, bias, residual
+    // and the three modulation vectors -- is issued up front: one memory round trip after the step index.
+    float4 v[MAXE], xr[MAXE], sh[MAXE], sc[MAXE], ga[MAXE];
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
         const int h = (lane + e * 64) * 4;
@@ -419,6 +430,9 @@ __global__ __launch_bounds__(256) void ln_mod_res_kernel(const float *__restrict
             for (int z = 0; z < NS; ++z) t[z] = *reinterpret_cast<const float4 *>(y + z * slab_stride + (int64_t)row * H + h);
             const float4 bb = *reinterpret_cast<const float4 *>(bias + h);
             xr[e] = *reinterpret_cast<const float4 *>(x32 + (int64_t)row * H + h);
+            sh[e] = *reinterpret_cast<const float4 *>(mod + h);
+            sc[e] = *reinterpret_cast<const float4 *>(mod + H + h);
+            ga[e] = *reinterpret_cast<const float4 *>(mod + 2 * H + h);
 #pragma unroll
             for (int z = 0; z < NS; ++z) { a.x += t[z].x; a.y += t[z].y; a.z += t[z].z; a.w += t[z].w; }
             a.x += bb.x; a.y += bb.y; a.z += bb.z; a.w += bb.w;
@@ -442,14 +456,11 @@ __global__ __launch_bounds__(256) void ln_mod_res_kernel(const float *__restrict
     for (int e = 0; e < MAXE; ++e) {
         const int h = (lane + e * 64) * 4;
         if (h < H) {
-            const float4 sh = *reinterpret_cast<const float4 *>(mod + h);
-            const float4 sc = *reinterpret_cast<const float4 *>(mod + H + h);
-            const float4 ga = *reinterpret_cast<const float4 *>(mod + 2 * H + h);
             float4 o;
-            o.x = xr[e].x + ga.x * ((v[e].x - mean) * rstd * (1.f + sc.x) + sh.x);
-            o.y = xr[e].y + ga.y * ((v[e].y - mean) * rstd * (1.f + sc.y) + sh.y);
-            o.z = xr[e].z + ga.z * ((v[e].z - mean) * rstd * (1.f + sc.z) + sh.z);
-            o.w = xr[e].w + ga.w * ((v[e].w - mean) * rstd * (1.f + sc.w) + sh.w);
+            o.x = xr[e].x + ga[e].x * ((v[e].x - mean) * rstd * (1.f + sc[e].x) + sh[e].x);
+            o.y = xr[e].y + ga[e].y * ((v[e].y - mean) * rstd * (1.f + sc[e].y) + sh[e].y);
+            o.z = xr[e].z + ga[e].z * ((v[e].z - mean) * rstd * (1.f + sc[e].z) + sh[e].z);
+            o.w = xr[e].w + ga[e].w * ((v[e].w - mean) * rstd * (1.f + sc[e].w) + sh[e].w);
             *reinterpret_cast<float4 *>(x32 + (int64_t)row * H + h) = o;
             store4<T>(xa + (int64_t)row * H + h, o);
         }

@@ -409,7 +409,7 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
             // pipelined kernels: prefer the largest tile that still gives >= ~1 workgroup per CU
             const long w12864 = (long)cdiv(M, 128) * cdiv(N, 64) * splits;
             const long w6464 = (long)cdiv(M, 64) * cdiv(N, 64) * splits;
-            if (w12864 >= 224)
+            if (w12864 >= 512)
                 LL_TRY((launch_pipe<128, 64, 2, 2, 4>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
             else if (w6464 >= 200 || (N % 32 != 0 && N < 64))
                 LL_TRY((launch_pipe<64, 64, 2, 2, 4>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
@@ -470,6 +470,77 @@ int convert_f32_to_bf16(const float *src, bf16_t *dst, int64_t n, hipStream_t st
 }
 
 }  // namespace ll
+
+// ------------------------------------------------------------------------------------------ tuning harness
+namespace ll {
+typedef int (*pipe_fn)(const bf16_t *, int, const bf16_t *, int, void *, int, const float *, int, int, int, int, int64_t,
+                       int, int, hipStream_t);
+struct PipeCfg {
+    int bm, bn, stages;
+    pipe_fn fn;
+};
+static const PipeCfg g_pipe_cfgs[] = {
+    {128, 64, 4, launch_pipe<128, 64, 2, 2, 4>},   // 0
+    {64, 64, 4, launch_pipe<64, 64, 2, 2, 4>},     // 1
+    {64, 32, 4, launch_pipe<64, 32, 4, 1, 4>},     // 2
+    {64, 32, 8, launch_pipe<64, 32, 4, 1, 8>},     // 3
+    {64, 64, 8, launch_pipe<64, 64, 2, 2, 8>},     // 4
+    {128, 64, 6, launch_pipe<128, 64, 2, 2, 6>},   // 5
+    {128, 128, 3, launch_pipe<128, 128, 2, 2, 3>}, // 6
+    {128, 128, 4, launch_pipe<128, 128, 2, 2, 4>}, // 7
+    {64, 128, 4, launch_pipe<64, 128, 2, 2, 4>},   // 8
+    {256, 64, 3, launch_pipe<256, 64, 4, 1, 3>},   // 9
+    {64, 64, 2, launch_pipe<64, 64, 2, 2, 2>},     // 10
+    {64, 128, 6, launch_pipe<64, 128, 2, 2, 6>},   // 11
+};
+}  // namespace ll
+
+// Times `iters` back-to-back launches of one pipelined-GEMM configuration (HIP events on a private stream),
+// cycling over `nweights` distinct weight matrices so that the weights stream from HBM as in the sampler.
+extern "C" int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f32, int iters, int nweights, float *ms) {
+    using namespace ll;
+    const int ncfg = (int)(sizeof(g_pipe_cfgs) / sizeof(g_pipe_cfgs[0]));
+    LL_CHECK(cfg >= -1 && cfg < ncfg, "cfg %d out of range [-1,%d)", cfg, ncfg);
+    LL_CHECK(ms && iters > 0 && nweights > 0 && splits >= 1 && K % (64 * splits) == 0, "bad argument");
+    const int Mp = round_up(M, 256);
+    bf16_t *A = nullptr, *W = nullptr;
+    void *C = nullptr;
+    LL_HIP(hipMalloc(&A, (size_t)Mp * K * 2));
+    LL_HIP(hipMalloc(&W, (size_t)nweights * N * K * 2));
+    LL_HIP(hipMalloc(&C, (size_t)splits * Mp * N * 4));
+    LL_HIP(hipMemset(A, 0x11, (size_t)Mp * K * 2));
+    LL_HIP(hipMemset(W, 0x11, (size_t)nweights * N * K * 2));
+    hipStream_t st;
+    LL_HIP(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    LL_HIP(hipEventCreate(&e0));
+    LL_HIP(hipEventCreate(&e1));
+    int rc = LL_OK;
+    for (int pass = 0; pass < 2 && rc == LL_OK; ++pass) {
+        if (pass == 1) (void)hipEventRecord(e0, st);
+        for (int i = 0; i < (pass ? iters : nweights) && rc == LL_OK; ++i) {
+            const bf16_t *w = W + (size_t)(i % nweights) * N * K;
+            if (cfg < 0)
+                rc = gemm_dispatch(LL_BF16, A, K, w, K, nullptr, C, N, M, N, K, splits, (int64_t)Mp * N, 0, splits > 1 ? 1 : out_f32, st);
+            else
+                rc = g_pipe_cfgs[cfg].fn(A, K, w, K, C, N, nullptr, M, N, K, splits, (int64_t)Mp * N, 0, splits > 1 ? 1 : out_f32, st);
+        }
+    }
+    (void)hipEventRecord(e1, st);
+    hipError_t he = hipEventSynchronize(e1);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    *ms = t / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(st);
+    (void)hipFree(A);
+    (void)hipFree(W);
+    (void)hipFree(C);
+    if (rc != LL_OK) return rc;
+    LL_HIP(he);
+    return LL_OK;
+}
 
 extern "C" int ll_linear(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
                          int M, int N, int K, int epi, int out_f32, void *stream) {

@@ -221,16 +221,24 @@ template <typename T>
 static void launch_lnmod(DitEngine *e, int layer, int sel, int nslab, const float *bias, hipStream_t st) {
     const dim3 grid(cdiv(e->M2, 4)), blk(256);
     const int64_t ss = (int64_t)e->M2p * e->cfg.hidden;
+#define LL_LNMOD2(NS, ME)                                                                                              \
+    hipLaunchKernelGGL((ln_mod_res_kernel<T, NS, ME>), grid, blk, 0, st, e->ybuf.as<float>(), ss, bias,                 \
+                       e->x32.as<float>(), e->xa.as<T>(), e->modtab.as<float>(), e->step_ptr(), layer, sel, e->B,      \
+                       e->cfg.max_nodes, e->cfg.hidden, e->cfg.depth, e->M2)
 #define LL_LNMOD(NS)                                                                                                   \
-    hipLaunchKernelGGL((ln_mod_res_kernel<T, NS>), grid, blk, 0, st, e->ybuf.as<float>(), ss, bias, e->x32.as<float>(), \
-                       e->xa.as<T>(), e->modtab.as<float>(), e->step_ptr(), layer, sel, e->B, e->cfg.max_nodes,        \
-                       e->cfg.hidden, e->cfg.depth, e->M2)
+    do {                                                                                                               \
+        if (e->cfg.hidden <= 256) LL_LNMOD2(NS, 1);                                                                    \
+        else if (e->cfg.hidden <= 512) LL_LNMOD2(NS, 2);                                                               \
+        else if (e->cfg.hidden <= 1024) LL_LNMOD2(NS, 4);                                                              \
+        else LL_LNMOD2(NS, 8);                                                                                         \
+    } while (0)
     switch (nslab) {
         case 1: LL_LNMOD(1); break;
         case 2: LL_LNMOD(2); break;
         case 4: LL_LNMOD(4); break;
         default: LL_LNMOD(8); break;
     }
+#undef LL_LNMOD2
 #undef LL_LNMOD
 }
 

@@ -1,0 +1,163 @@
+"""GraphCLIP (GIN encoder + projection head) on MI355X: drop-in for reference
+``src/model/graph_encoder/model.py:GraphCLIP``.
+
+``GraphCLIP(graph_num_layer, graph_hidden_size, dropout, model_config)``; ``.hidden_size``;
+``forward(x, edge_index, edge_attr, batch) -> [G, H]`` unit-norm embeddings; ``init_model(path)``
+loads ``model.pt`` (GNNEncoder keys) and ``model_proj.pt`` (ProjectionHead keys);
+``save_pretrained`` writes the same three files.  The forward runs in the HIP engine (ll_gin_forward).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .synth import gin_weight_shapes, proj_weight_shapes
+from .weights import WeightBag, engine_dtype, pack_arena
+
+
+def graph_csr(x, edge_index, edge_attr, batch):
+    """PyG-style (edge_index [2,E], edge_attr [E], batch [n]) -> the int32 CSR-by-destination arrays the C ABI takes.
+    Stable sort by destination keeps the reference's per-destination summation order."""
+    dev = x.device
+    n = x.shape[0]
+    dst = edge_index[1].long()
+    order = torch.argsort(dst, stable=True)
+    src = edge_index[0].long()[order].to(torch.int32).contiguous()
+    attr = edge_attr.long()[order].to(torch.int32).contiguous()
+    deg = torch.bincount(dst, minlength=n)
+    rowptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    rowptr[1:] = torch.cumsum(deg, 0).to(torch.int32)
+    b = batch.long()
+    G = int(b[-1].item()) + 1
+    if bool((b[1:] < b[:-1]).any()):
+        raise ValueError("`batch` must be sorted (PyG Batch convention)")
+    gptr = torch.zeros(G + 1, dtype=torch.int32, device=dev)
+    gptr[1:] = torch.cumsum(torch.bincount(b, minlength=G), 0).to(torch.int32)
+    return (x.to(torch.int32).contiguous(), rowptr.contiguous(), src, attr, b.to(torch.int32).contiguous(),
+            gptr.contiguous(), n, int(src.numel()), G)
+
+
+class _GinModule(nn.Module):
+    """Shared engine plumbing of the encoder and the predictor."""
+
+    _kind = 0
+
+    def _gin_cfg(self, code):
+        raise NotImplementedError
+
+    def _named_for_arena(self):
+        raise NotImplementedError
+
+    def _bags(self):
+        raise NotImplementedError
+
+    def _device(self):
+        p = next(self.parameters())
+        if p.device.type != "cuda":
+            raise RuntimeError(f"{type(self).__name__} runs on the HIP device only: call .to('cuda') first (no CPU path)")
+        return p.device
+
+    def _ensure_engine(self):
+        dev = self._device()
+        fp = tuple(b.fingerprint() for b in self._bags())
+        if getattr(self, "_handle", None) is not None and fp == self._fingerprint:
+            return
+        self._release()
+        lib = _lib.load()
+        p0 = next(self.parameters())
+        code = engine_dtype(p0.dtype)
+        cfg = self._gin_cfg(code)
+        with torch.cuda.device(dev):
+            self._arena = pack_arena("gin", cfg, self._named_for_arena(), dev)
+            torch.cuda.synchronize(dev)
+            h = C.c_void_p()
+            _lib.check(lib.ll_gin_create(C.byref(cfg), _lib.dptr(self._arena), C.byref(h)), "ll_gin_create")
+        self._handle, self._fingerprint = h, fp
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None:
+            _lib.load().ll_gin_destroy(self._handle)
+        self._handle = None
+        self._arena = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _run(self, x, edge_index, edge_attr, batch, c, out_cols, want_pooled=False):
+        self._ensure_engine()
+        dev = self._device()
+        xs, rowptr, src, attr, b, gptr, n, ne, G = graph_csr(x.to(dev), edge_index.to(dev), edge_attr.to(dev), batch.to(dev))
+        out = torch.empty(G, out_cols, device=dev, dtype=torch.float32)
+        pooled = torch.empty(G, self.hidden_size, device=dev, dtype=torch.float32) if want_pooled else None
+        if c is not None:
+            c = c.detach().to(device=dev, dtype=torch.float32).contiguous()
+            if c.shape[0] != G:
+                raise ValueError(f"condition rows {c.shape[0]} != number of graphs {G}")
+        _lib.check(_lib.load().ll_gin_forward(self._handle, _lib.dptr(xs), _lib.dptr(rowptr), _lib.dptr(src), _lib.dptr(attr),
+                                              _lib.dptr(b), _lib.dptr(gptr), n, ne, G, _lib.dptr(c), _lib.dptr(out),
+                                              _lib.dptr(pooled), _lib.current_stream_ptr()), "ll_gin_forward")
+        torch.cuda.current_stream().synchronize()   # temporaries above must outlive the async launch
+        return (out, pooled) if want_pooled else out
+
+    def disable_grads(self):
+        for p in self.parameters():
+            p.requires_grad = False
+
+
+class GraphCLIP(_GinModule):
+    def __init__(self, graph_num_layer, graph_hidden_size, dropout, model_config):
+        super().__init__()
+        if graph_num_layer < 2:
+            raise ValueError("Number of GNN layers must be greater than 1.")
+        self.model_config = model_config
+        self.hidden_size = graph_hidden_size
+        self.num_layer = graph_num_layer
+        self.molecule_encoder = WeightBag(gin_weight_shapes(graph_num_layer, graph_hidden_size, "encoder"))
+        self.molecule_projection = WeightBag(proj_weight_shapes(graph_hidden_size))
+        self._handle = None
+
+    def _bags(self):
+        return (self.molecule_encoder, self.molecule_projection)
+
+    def _gin_cfg(self, code):
+        return _lib.LLGinConfig(self.num_layer, self.hidden_size, 0, 0, 768, code)
+
+    def _named_for_arena(self):
+        d = dict(self.molecule_encoder.state_dict())
+        d.update({"proj." + k: v for k, v in self.molecule_projection.state_dict().items()})
+        return d.items()
+
+    @torch.no_grad()
+    def forward(self, x, edge_index, edge_attr, batch):
+        out = self._run(x, edge_index, edge_attr, batch, None, self.hidden_size)
+        return out.to(next(self.parameters()).dtype)
+
+    @torch.no_grad()
+    def pooled(self, x, edge_index, edge_attr, batch):
+        """Add-pooled node states before the projection head (GNNEncoder.forward output)."""
+        return self._run(x, edge_index, edge_attr, batch, None, self.hidden_size, want_pooled=True)[1]
+
+    def init_model(self, model_path, verbose=True):
+        molecule_path = os.path.join(model_path, "model.pt")
+        proj_path = os.path.join(model_path, "model_proj.pt")
+        if not os.path.exists(molecule_path):
+            raise FileNotFoundError(f"Molecule encoder file not found: {molecule_path}")
+        if not os.path.exists(proj_path):
+            raise FileNotFoundError(f"Molecule projection file not found: {proj_path}")
+        self.molecule_encoder.load_state_dict(torch.load(molecule_path, map_location="cpu", weights_only=False))
+        self.molecule_projection.load_state_dict(torch.load(proj_path, map_location="cpu", weights_only=False))
+
+    def save_pretrained(self, output_dir):
+        os.makedirs(output_dir, exist_ok=True)
+        torch.save(self.molecule_encoder.state_dict(), os.path.join(output_dir, "model.pt"))
+        torch.save(self.molecule_projection.state_dict(), os.path.join(output_dir, "model_proj.pt"))
+        with open(os.path.join(output_dir, "model_config.json"), "w") as f:
+            json.dump(self.model_config, f, indent=2)

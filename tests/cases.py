@@ -30,3 +30,18 @@ def dit_case(name):
 
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+
+
+def fake_template_runner(template: str, smiles: str):
+    """Deterministic stand-in for rdchiralRunText used to pin the host merge logic of sample_templates."""
+    i = int(template[1:])
+    if i % 7 == 0:
+        return []
+    if i % 11 == 0:
+        raise RuntimeError("template does not apply")
+    outs = [f"R{i % 4}.A{i % 3}", f"B{i % 6}"]
+    if i % 2 == 0:
+        outs.append(f"A{i % 3}.R{i % 4}")      # same reactant set, different order -> merged
+    if i % 3 == 0:
+        outs.append(f"C{i % 5}.C{i % 5}.D")
+    return outs

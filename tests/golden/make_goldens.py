@@ -289,6 +289,22 @@ def gen_gin(name):
         out["logits_none"] = net(x, ei, ea, batch, None).numpy()
         pr, idx = torch.topk(torch.softmax(lg, dim=1), k=50, dim=1)
         out["topk_p"], out["topk_i"] = pr.numpy(), idx.numpy().astype(np.int32)
+    # host tail of sample_templates with a scripted template runner (rdchiral is absent here)
+    import json
+    from tests.cases import fake_template_runner
+    pred.rdchiralRunText = fake_template_runner
+    gp = pred.GraphPredictor(L, H, 0.0, out_dim, {"num_layer": L, "hidden_size": H, "drop_ratio": 0.0, "num_task": out_dim},
+                             {i: f"T{i}" for i in range(out_dim)})
+    gp.predictor.load_state_dict(sd_r)
+    gp.eval()
+    n0 = int((batch == 0).sum())
+    e0 = (ei[0] < n0)
+    import types as _t
+    pg = _t.SimpleNamespace(x=x[:n0], edge_index=ei[:, e0], edge_attr=ea[e0])
+    with torch.no_grad():
+        r, sc, tm = gp.sample_templates(pg, c[:1], "PROD", topk=50)
+    with open(os.path.join(OUT, name + "_templates.json"), "w") as f:
+        json.dump({"reactants": r, "scores": sc, "templates": tm}, f)
     cm = pred.CostMLP(n_layers=1, fp_dim=2048, latent_dim=128, dropout_rate=0.1)
     cm.load_state_dict(synth.make_cost_weights(seed))
     cm.eval()
