@@ -1,0 +1,427 @@
+"""Interleaved-generation orchestrator: counterpart of reference
+``src/model/modeling_llamole.py:GraphLLMForCausalMLM`` for the MI355X graph engines.
+
+Host code stays Python on PyTorch-ROCm and the HuggingFace LLM is untouched (north star); this module owns
+the control flow between the LLM and the three graph engines:
+
+  generate()                      reference :1115-1287   dispatch design / retrosynthesis, assemble the info dict
+  design_molecule()               :584-663   LLM decode to the trigger -> query tokens -> GraphDiT (HIP)
+  add_special_body_tokens()       :521-582   [kept analysis][<x_start>][8 x <x_body>] left-padded with eos
+  one_step_reaction()             :784-889   GIN-encode product (HIP) -> LLM decode -> GIN predictor (HIP) -> templates
+  estimate_synthesis_complexity() :891-993   LLM-logit cost (+ optional CostMLP on HIP)
+  retrosynthesize()               :995-1093  A* over one_step_reaction / estimate_synthesis_complexity
+  connectors                      :205-222   Linear+SiLU x3, stored as connector/*.pt
+
+Reference quirks kept on purpose (drivers depend on the shapes of the results): ``design_text_list[0]`` is
+used for every batch element (:1174-1175); ``retro_plan_dict`` is keyed by SMILES (:1178).  The SFT
+``forward`` (:299-437) is outside the generation hot path and not provided.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from typing import Any, Dict, List, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from .graph_data import GraphBatch, GraphData
+from .planner import molstar
+
+IGNORE_INDEX = -100      # reference src/extras/constants.py:24
+NO_LABEL_INDEX = -200    # :25
+BOND_INDEX_BY_NAME = {"SINGLE": 1, "DOUBLE": 2, "TRIPLE": 3, "AROMATIC": 4}   # :51 (keyed by rdkit BondType there)
+
+SPECIAL_TOKENS = ["<design_start>", "<design_end>", "<design_body>", "<molecule>", "<retro_start>", "<retro_end>",
+                  "<retro_body>", "<rollback_start>", "<rollback_end>"]
+
+
+def make_connector(d_in: int, d_out: int) -> nn.Sequential:
+    return nn.Sequential(nn.Linear(d_in, d_out), nn.SiLU())
+
+
+class GraphLLMForCausalMLM(nn.Module):
+    def __init__(self, model_args, finetuning_args, data_args, language_model, graph_decoder, graph_predictor,
+                 graph_encoder, token_id_dict, tokenizer):
+        super().__init__()
+        self.language_model = language_model
+        self.graph_decoder = graph_decoder
+        self.graph_predictor = graph_predictor
+        self.graph_encoder = graph_encoder
+        self.token_id_dict = token_id_dict
+        self.num_body_tokens = getattr(data_args, "learned_query_size", 8)
+        self.model_args, self.finetuning_args, self.data_args = model_args, finetuning_args, data_args
+        self.tokenizer = tokenizer
+        self.config = getattr(language_model, "config", None)
+        hidden = self.config.hidden_size
+        self.graph_to_lm_connector = make_connector(graph_encoder.hidden_size, hidden)
+        self.lm_to_graph_decoder = make_connector(hidden, graph_decoder.text_input_size)
+        self.lm_to_graph_predictor = make_connector(hidden, graph_predictor.text_input_size)
+        self.timings: Dict[str, float] = {}
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_pretrained(cls, tokenizer, model_args, data_args, training_args, finetuning_args, load_adapter=False,
+                        add_valuehead=False, language_model=None):
+        """Reference :102-286.  The LLM itself is stock HuggingFace (+ peft adapter) on PyTorch-ROCm; pass
+        ``language_model`` to reuse an already-built one."""
+        from .loader import load_graph_decoder, load_graph_encoder, load_graph_predictor
+        compute_dtype = getattr(model_args, "compute_dtype", torch.bfloat16)
+        if load_adapter:
+            apath = getattr(model_args, "adapter_name_or_path", None)
+            if apath is None:
+                raise ValueError("Please specify the adapter_name_or_path when load_adapter is True.")
+            if len(apath) != 1:
+                raise ValueError("Only one adapter is supported at a time.")
+        if language_model is None:
+            from transformers import AutoModelForCausalLM
+            language_model = AutoModelForCausalLM.from_pretrained(model_args.model_name_or_path, torch_dtype=compute_dtype)
+            if len(tokenizer) > language_model.get_input_embeddings().weight.shape[0]:
+                language_model.resize_token_embeddings(len(tokenizer))
+            if load_adapter:
+                try:
+                    from peft import PeftModel
+                except ImportError as e:
+                    raise ImportError("load_adapter=True needs `peft` (reference requirements.txt:18)") from e
+                language_model = PeftModel.from_pretrained(language_model, model_args.adapter_name_or_path[0]).merge_and_unload()
+            language_model.to("cuda").eval()
+        device = next(language_model.parameters()).device
+        graph_decoder = load_graph_decoder(model_args, path=model_args.graph_decoder_path, device=device)
+        graph_predictor = load_graph_predictor(model_args, path=model_args.graph_predictor_path, device=device)
+        graph_encoder = load_graph_encoder(model_args, path=model_args.graph_encoder_path, device=device)
+        token_id_dict = {}
+        for elem in getattr(model_args, "new_special_tokens", None) or SPECIAL_TOKENS:
+            if isinstance(elem, str) and len(elem) != 0:
+                token_id_dict[elem] = tokenizer.encode(elem, add_special_tokens=False)[0]
+        model = cls(model_args, finetuning_args, data_args, language_model, graph_decoder, graph_predictor,
+                    graph_encoder, token_id_dict, tokenizer)
+        for conn in (model.graph_to_lm_connector, model.lm_to_graph_decoder, model.lm_to_graph_predictor):
+            for p in conn.parameters():
+                if p.dtype == torch.float32 and compute_dtype != torch.float32:
+                    p.data = p.data.to(compute_dtype)
+        if load_adapter:
+            cpath = getattr(model_args, "graph_lm_connector_path", None)
+            if not cpath:
+                raise ValueError("Connector should be downloaded with the adapter: set graph_lm_connector_path")
+            for name in ("graph_to_lm_connector", "lm_to_graph_decoder", "lm_to_graph_predictor"):
+                getattr(model, name).load_state_dict(torch.load(os.path.join(cpath, name + ".pt"), map_location=device, weights_only=True))
+        for name in ("graph_to_lm_connector", "lm_to_graph_decoder", "lm_to_graph_predictor"):
+            getattr(model, name).to(device)
+        return model
+
+    def save_pretrained(self, save_directory, **kwargs):
+        """Connectors + config (reference :490-515); the LLM adapter itself is saved by peft."""
+        os.makedirs(os.path.join(save_directory, "connector"), exist_ok=True)
+        for name in ("graph_to_lm_connector", "lm_to_graph_decoder", "lm_to_graph_predictor"):
+            torch.save(getattr(self, name).state_dict(), os.path.join(save_directory, "connector", name + ".pt"))
+        if hasattr(self.language_model, "save_pretrained") and kwargs.get("save_language_model", False):
+            self.language_model.save_pretrained(save_directory)
+        with open(os.path.join(save_directory, "graphllm_config.json"), "w") as f:
+            json.dump({"num_body_tokens": self.num_body_tokens, "token_id_dict": self.token_id_dict}, f, indent=2)
+
+    @property
+    def device(self):
+        return next(self.language_model.parameters()).device
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("SFT forward (reference :299-437) is outside the MI355X generation path")
+
+    # ------------------------------------------------------------------ helpers
+    def add_special_body_tokens(self, input_ids, body_token_id, num_body_tokens, start_token_id=None):
+        """Append ``[start?] + num_body_tokens x body`` after the (first) start token of every row -- or at the
+        end if the row has none -- keeping the rightmost context that fits, left-padded with eos (:521-582)."""
+        bsz, seq_len = input_ids.shape
+        start_len = 1 if start_token_id is not None else 0
+        if seq_len < num_body_tokens + start_len:
+            seq_len = seq_len + num_body_tokens + start_len
+        dev = input_ids.device
+        cut = [seq_len - start_len - num_body_tokens] * bsz
+        keep_budget = seq_len - num_body_tokens
+        if start_token_id is not None:
+            rows, cols = (input_ids == start_token_id).nonzero(as_tuple=True)
+            for r, c in zip(rows.tolist(), cols.tolist()):
+                cut[r] = c                      # last occurrence wins, as in the reference loop
+            keep_budget = seq_len - num_body_tokens - 1
+        out = torch.full((bsz, seq_len), self.tokenizer.eos_token_id, device=dev, dtype=input_ids.dtype)
+        body = torch.full((num_body_tokens,), body_token_id, device=dev, dtype=input_ids.dtype)
+        for i in range(bsz):
+            lo = max(0, cut[i] - keep_budget)
+            parts = [input_ids[i, lo:cut[i]]]
+            if start_token_id is not None:
+                parts.append(torch.tensor([start_token_id], device=dev, dtype=input_ids.dtype))
+            parts.append(body)
+            tail = torch.cat(parts)
+            out[i, seq_len - tail.numel():] = tail
+        return out
+
+    def _query_hidden(self, ids: torch.Tensor) -> torch.Tensor:
+        """LLM forward over ids (all-ones mask, as the reference) -> mean of the last num_body_tokens hidden states."""
+        out = self.language_model(input_ids=ids, attention_mask=torch.ones_like(ids), output_hidden_states=True,
+                                  return_dict=True)
+        return out.hidden_states[-1][:, -self.num_body_tokens:].mean(dim=1)
+
+    def _splice_molecules(self, ids: torch.Tensor, graphs) -> torch.Tensor:
+        """embed_tokens(ids) with every <molecule> position replaced by connector(GIN encoder(graph)) (:607-622)."""
+        emb_layer = self.language_model.get_input_embeddings()
+        inputs_embeds = emb_layer(ids)
+        pos = (ids == self.token_id_dict["<molecule>"]).nonzero()
+        mol = self.graph_encoder(graphs.x, graphs.edge_index, graphs.edge_attr, graphs.batch)
+        mol = self.graph_to_lm_connector(mol.to(next(self.graph_to_lm_connector.parameters()).dtype))
+        assert pos.shape[0] == mol.shape[0], \
+            f"Number of molecule tokens ({pos.shape[0]}) does not match number of molecule embeddings ({mol.shape[0]})"
+        inputs_embeds[pos[:, 0], pos[:, 1]] = mol.to(inputs_embeds.dtype)
+        return inputs_embeds
+
+    # ------------------------------------------------------------------ design
+    @torch.no_grad()
+    def design_hidden(self, input_ids, attention_mask, molecule_graphs=None, **kwargs):
+        """Steps 1-3 of design_molecule: analysis tokens and the [B,768] text condition for GraphDiT."""
+        t0 = time.perf_counter()
+        if molecule_graphs is None:
+            analysis = self.language_model.generate(inputs=input_ids, attention_mask=attention_mask, **kwargs)
+            analysis = analysis[:, input_ids.shape[1]:]
+        else:
+            embeds = self._splice_molecules(input_ids, molecule_graphs)
+            analysis = self.language_model.generate(attention_mask=attention_mask, inputs_embeds=embeds, **kwargs)
+        t1 = time.perf_counter()
+        design_ids = self.add_special_body_tokens(analysis, self.token_id_dict["<design_body>"], self.num_body_tokens,
+                                                  start_token_id=self.token_id_dict["<design_start>"])
+        design_ids = torch.cat([input_ids, design_ids], dim=1)
+        hidden = self._query_hidden(design_ids)
+        cond = self.lm_to_graph_decoder(hidden.to(next(self.lm_to_graph_decoder.parameters()).dtype))
+        self.timings.update(llm_decode_s=t1 - t0, llm_query_s=time.perf_counter() - t1)
+        return analysis, design_ids, cond
+
+    @torch.no_grad()
+    def design_molecule(self, input_ids, attention_mask, molecule_properties=None, molecule_graphs=None,
+                        rollback=False, **kwargs):
+        analysis, design_ids, cond = self.design_hidden(input_ids, attention_mask, molecule_graphs, **kwargs)
+        t0 = time.perf_counter()
+        smiles_list = self.graph_decoder.generate(molecule_properties.to(cond.dtype), cond, NO_LABEL_INDEX)
+        self.timings["graphdit_s"] = time.perf_counter() - t0
+        if rollback and None in smiles_list:
+            smiles_list = self.design_rollback(design_ids, smiles_list, **kwargs)
+        return analysis, smiles_list
+
+    def design_rollback(self, analysis_tokens, smiles_list, **kwargs):
+        """GraphDiT produced an invalid molecule: let the LLM write the SMILES itself (:665-718)."""
+        none_idx = [i for i, s in enumerate(smiles_list) if s is None]
+        if not none_idx:
+            return smiles_list
+        rb_ids = self.add_special_body_tokens(analysis_tokens[torch.tensor(none_idx)], self.token_id_dict.get("<rollback_start>"), 1)
+        if "max_new_tokens" in kwargs:
+            kwargs["max_new_tokens"] *= 2
+        new_tokens = self.language_model.generate(inputs=rb_ids, attention_mask=torch.ones_like(rb_ids), **kwargs)
+        end_text = self.tokenizer.decode([self.token_id_dict.get("<rollback_end>")])
+        for i, seq in zip(none_idx, new_tokens[:, rb_ids.shape[1]:]):
+            text = self.tokenizer.decode(seq, skip_special_tokens=False)
+            cut = text.find(end_text)
+            smiles_list[i] = text[:cut].strip() if cut != -1 else None
+        return smiles_list
+
+    # ------------------------------------------------------------------ retrosynthesis
+    def smiles_to_graph(self, smiles: str) -> Optional[GraphData]:
+        """SMILES -> integer graph (x = atomic number - 2, '*' -> 117; symmetric edges; bond classes 1..4) (:720-760)."""
+        try:
+            from rdkit import Chem
+        except ImportError as e:  # pragma: no cover
+            raise ImportError("smiles_to_graph needs `rdkit` (reference requirements.txt:22)") from e
+        mol = Chem.MolFromSmiles(smiles)
+        if mol is None:
+            return None
+        x = torch.tensor([117 if a.GetSymbol() == "*" else a.GetAtomicNum() - 2 for a in mol.GetAtoms()
+                          if a.GetAtomicNum() != 1], dtype=torch.long)
+        src, dst, typ = [], [], []
+        for b in mol.GetBonds():
+            i, j = b.GetBeginAtomIdx(), b.GetEndAtomIdx()
+            if mol.GetAtomWithIdx(i).GetAtomicNum() != 1 and mol.GetAtomWithIdx(j).GetAtomicNum() != 1:
+                src += [i, j]
+                dst += [j, i]
+                typ += [BOND_INDEX_BY_NAME.get(str(b.GetBondType()), 1)] * 2
+        if src:
+            return GraphData(x, torch.tensor([src, dst], dtype=torch.long), torch.tensor(typ, dtype=torch.long))
+        return GraphData(x, torch.empty((2, 0), dtype=torch.long), torch.empty((0,), dtype=torch.long))
+
+    def retrosynthesize_rollback(self, input_ids, design_text, smiles, **kwargs):
+        """Planning failed / invalid target: free-text synthesis by the LLM (:762-782)."""
+        ids = self.tokenizer.encode(f"{design_text} To synthesize {smiles}, follow these procedures: ",
+                                    add_special_tokens=False, return_tensors="pt").to(self.device)
+        if "max_new_tokens" in kwargs:
+            kwargs["max_new_tokens"] = 256
+        out = self.language_model.generate(inputs=ids, **kwargs)[:, ids.shape[1]:]
+        return self.tokenizer.encode(f"To synthesize {smiles}, follow these procedures: ") + out.cpu().squeeze().tolist()
+
+    def one_step_reaction(self, product_smiles, input_ids, design_text, molecule_graphs, topk, **kwargs):
+        prompt = self.tokenizer.encode(f"{design_text} To synthesize <molecule>, follow these procedures: ",
+                                       add_special_tokens=False, return_tensors="pt").to(self.device)
+        with_context = input_ids is not None and molecule_graphs is not None
+        if with_context:
+            prompt = torch.cat([input_ids.view(1, -1), prompt], dim=-1)
+        product = self.smiles_to_graph(product_smiles)
+        if product is None:
+            return {"reactants": [], "scores": [], "templates": [],
+                    "analysis": self.tokenizer.encode("Invalid product SMILES", add_special_tokens=False)}
+        product.to(self.device)
+        graphs = GraphBatch.from_data_list((molecule_graphs.to_data_list() if with_context else []) + [product])
+        embeds = self._splice_molecules(prompt, graphs)
+        if "max_new_tokens" in kwargs:
+            kwargs["max_new_tokens"] = 512
+        analysis = self.language_model.generate(attention_mask=torch.ones_like(prompt), inputs_embeds=embeds, **kwargs)
+        retro_ids = self.add_special_body_tokens(analysis, self.token_id_dict["<retro_body>"], self.num_body_tokens,
+                                                 start_token_id=self.token_id_dict["<retro_start>"])
+        hidden = self._query_hidden(retro_ids)
+        cond = self.lm_to_graph_predictor(hidden.to(next(self.lm_to_graph_predictor.parameters()).dtype))
+        reactants, scores, templates = self.graph_predictor.sample_templates(product, cond, product_smiles, topk)
+        head = self.tokenizer.encode(f"To synthesize {product_smiles}, follow these procedures: ")
+        return {"reactants": reactants, "scores": scores, "templates": templates,
+                "analysis": head + analysis.cpu().squeeze().tolist()}
+
+    _ANSWERS = ["All readily available", "Some commercial, some need 1-2 steps",
+                "Mix of commercial and multi-step synthesis", "Mostly require complex synthesis",
+                "All require extensive multi-step synthesis"]
+    _ANSWER_COSTS = [0, 1, 2.5, 4.5, 7]
+
+    @torch.no_grad()
+    def estimate_synthesis_complexity(self, smiles, input_ids=None, reaction=None, molecule_cost_weight=0,
+                                      language_cost_weight=1, reference_tokens=None):
+        cost = 0
+        if molecule_cost_weight is not None and molecule_cost_weight > 0:
+            cost += self.graph_predictor.estimate_cost(smiles) * molecule_cost_weight
+        if language_cost_weight is not None and language_cost_weight > 0:
+            if reaction is None:
+                content = f"""
+                Estimate remaining steps for the target {smiles} consider the following factors::
+                1. Intermediate complexity
+                2. Reagent availability
+                3. Side reactions
+                4. Stereochemistry challenges"""
+            else:
+                reactants = ", ".join(r.mol for r in reaction.children)
+                content = f"""
+                Estimate remaining steps for the target {smiles} given the following parameters:
+                Current step {reaction.depth + 1},
+                Current template: {reaction.template},
+                Reactants: {reactants}.
+                Consider the following factors:
+                1. Intermediate complexity
+                2. Reagent availability
+                3. Side reactions
+                4. Stereochemistry challenges"""
+            chat = self.tokenizer.apply_chat_template([{"role": "user", "content": content}], tokenize=False,
+                                                      add_generation_prompt=True)
+            answer_tokens = [self.tokenizer.encode(self.tokenizer.apply_chat_template(
+                [{"role": "user", "content": "Estimate the synthesis complexity:"}, {"role": "assistant", "content": a}],
+                tokenize=False, add_generation_prompt=False)) for a in self._ANSWERS]
+            ids = self.tokenizer.encode(chat, return_tensors="pt").to(self.device)
+            logits = self.language_model(ids).logits[:, -1, :]
+            answer_logits = torch.stack([logits[:, toks].mean(dim=1) for toks in answer_tokens])
+            probs = torch.softmax(answer_logits.float(), dim=0)
+            cost += (probs * torch.tensor(self._ANSWER_COSTS, device=probs.device)[:, None]).sum().item() * language_cost_weight
+        return cost
+
+    def _create_failure_result(self, target_smiles, generated_tokens=None) -> Dict[str, Any]:
+        return {"target": target_smiles, "success": False, "time": 0.0, "reaction_list": None, "cost": None,
+                "templates": None, "route_length": None,
+                "analysis_tokens": generated_tokens if generated_tokens is not None else "<NO ANALYSIS>"}
+
+    @torch.no_grad()
+    def retrosynthesize(self, input_ids, smiles=None, molecule_graphs=None, expansion_topk=50, iterations=100,
+                        starting_mols=None, molecule_cost_weight=0, language_cost_weight=1, max_planning_time=300,
+                        rollback=True, design_text=None, **kwargs) -> Dict[str, Any]:
+        if starting_mols is None:
+            if self.graph_predictor.available is None:
+                raise ValueError("No starting molecules provided and no available starting molecules found.")
+            starting_mols = self.graph_predictor.available["smiles"].tolist()
+        if smiles is None and rollback:
+            return self._create_failure_result(None, self.retrosynthesize_rollback(input_ids, design_text, None, **kwargs))
+        target = smiles.replace("*", "[H]") if "*" in smiles else smiles
+        if not self.graph_decoder.check_valid(target) and rollback:
+            return self._create_failure_result(target, self.retrosynthesize_rollback(input_ids, design_text, target, **kwargs))
+        t0 = time.time()
+        known = starting_mols if isinstance(starting_mols, (set, frozenset)) else set(starting_mols)
+        success, route, _ = molstar(
+            target_mol=target, target_mol_id=0, starting_mols=known,
+            expand_fn=lambda s: self.one_step_reaction(s, input_ids=input_ids, design_text=design_text,
+                                                       molecule_graphs=molecule_graphs, topk=expansion_topk, **kwargs),
+            value_fn=lambda s, r: self.estimate_synthesis_complexity(s, input_ids, r, molecule_cost_weight, language_cost_weight),
+            iterations=iterations, max_time=max_planning_time)
+        total = time.time() - t0
+        if success:
+            reactions, templates, cost, analysis = route.get_reaction_list()
+            return {"target": target, "success": True, "time": total, "reaction_list": reactions, "cost": cost,
+                    "templates": templates, "analysis_tokens": analysis, "route_length": route.length}
+        if rollback:
+            return self._create_failure_result(target, self.retrosynthesize_rollback(input_ids, design_text, target, **kwargs))
+        return {"target": target, "success": False, "time": total, "reaction_list": None, "cost": None,
+                "templates": None, "analysis_tokens": None, "route_length": None}
+
+    # ------------------------------------------------------------------ top level
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, molecule_properties=None, molecule_graphs=None,
+                 rollback=False, starting_mols=None, expansion_topk=50, iterations=100, molecule_cost_weight=0,
+                 language_cost_weight=1, do_molecular_design=True, do_retrosynthesis=True, input_smiles_list=None,
+                 max_planning_time=30, design_text_list=None, **kwargs) -> Dict:
+        if attention_mask is None:
+            attention_mask = input_ids.new_ones(input_ids.shape)
+        info: Dict[str, Any] = {"token_lists": [], "text_lists": [], "design_analysis_tokens": None,
+                                "smiles_list": None, "retro_plan_dict": None}
+        if do_molecular_design is True:
+            tokens, smiles = self.design_molecule(input_ids, attention_mask, molecule_properties, molecule_graphs,
+                                                  rollback, **kwargs)
+            info["design_analysis_tokens"] = tokens.cpu()
+            info["smiles_list"] = smiles
+        elif input_smiles_list is not None:
+            info["smiles_list"] = input_smiles_list
+        else:
+            raise ValueError("Either do_molecular_design must be True/False or input_smiles_list must be provided.")
+        if do_retrosynthesis:
+            info["retro_plan_dict"] = {}
+            for i, smiles in enumerate(info["smiles_list"]):
+                design_text = design_text_list[0] if design_text_list is not None else None
+                info["retro_plan_dict"][smiles] = self.retrosynthesize(
+                    input_ids[i] if input_ids.dim() > 1 else input_ids, smiles, molecule_graphs=molecule_graphs,
+                    starting_mols=starting_mols, expansion_topk=expansion_topk, iterations=iterations,
+                    molecule_cost_weight=molecule_cost_weight, language_cost_weight=language_cost_weight,
+                    max_planning_time=max_planning_time, design_text=design_text, **kwargs)
+        else:
+            info["retro_plan_dict"] = {s: {"success": None} for s in info["smiles_list"]}
+        available = None
+        for b, mol in enumerate(info["smiles_list"]):
+            tokens: List[int] = []
+            texts: List[str] = []
+            ignore: Dict[int, Any] = {}
+            if do_molecular_design:
+                dt = info["design_analysis_tokens"][b].tolist()
+                tokens = dt + [IGNORE_INDEX]
+                if mol is None:
+                    mol = "<NO MOLECULE>"
+                texts = [self.tokenizer.decode(dt, skip_special_tokens=True), mol + ". "]
+                ignore = {0: mol}
+            if do_retrosynthesis:
+                if available is None:
+                    available = set(self.graph_predictor.available["smiles"].tolist())
+                plan = info["retro_plan_dict"][mol]
+                if plan["success"]:
+                    for reaction, template, cost, at in zip(plan["reaction_list"], plan["templates"], plan["cost"], plan["analysis_tokens"]):
+                        at = at.tolist() if isinstance(at, torch.Tensor) else at
+                        tokens.extend(at + [IGNORE_INDEX])
+                        texts.extend([self.tokenizer.decode(at, skip_special_tokens=True),
+                                      reaction if reaction is not None else "<NO REACTION>", " with the template ",
+                                      template if template is not None else "<NO TEMPLATE>", " which requires the reactants: "])
+                        if reaction is not None:
+                            rs = reaction.split(">>")[1].split(".")
+                            texts.extend([", ".join(f"{r} (available)" if r in available else r for r in rs), ". "])
+                        else:
+                            texts.extend(["<NO REACTANTS>. "])
+                        ignore[len(tokens) - 1] = (reaction, template, cost)
+                else:
+                    at = plan["analysis_tokens"]
+                    at = at.tolist() if isinstance(at, torch.Tensor) else at
+                    tokens.extend(at)
+                    texts.extend([self.tokenizer.decode(at, skip_special_tokens=True), " <NO REACTION FOUND>"])
+            info["token_lists"].append(tokens)
+            info["text_lists"].append(texts)
+            info[f"batch_{b}_ignore_positions"] = ignore
+        info["IGNORE_INDEX"] = IGNORE_INDEX
+        return info
