@@ -135,6 +135,36 @@ def cpu_baseline(args, cfg, meta, sd, props, text, n_nodes):
             "denoise_steps_per_s": 1.0 / s_per_step}
 
 
+def cpu_baseline_e2e(args, llm, cfg, meta, sd, props, text, n_nodes):
+    """Reference CPU path of the e2e workload on this box's host cores, bounded sample: the same HF LLM moved
+    to the CPU (bf16) timed on the prompt pass + 2 decode tokens, and the GraphDiT oracle on a few reverse
+    steps; both extrapolated to the full budget (max_new_tokens decode steps, T reverse steps)."""
+    dit = cpu_baseline(args, cfg, meta, sd, props, text, n_nodes)
+    cores = dit["cores"]
+    torch.set_num_threads(cores)
+    llm_cpu = llm.to("cpu")
+    B = props.shape[0]
+    prompt = torch.randint(5, 1000, (B, args.cutoff_len))
+    kw = dict(do_sample=False, pad_token_id=0)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        llm_cpu.generate(inputs=prompt, attention_mask=torch.ones_like(prompt), max_new_tokens=1, **kw)
+        t1 = time.perf_counter()
+        llm_cpu.generate(inputs=prompt, attention_mask=torch.ones_like(prompt), max_new_tokens=3, **kw)
+        t2 = time.perf_counter()
+    prefill = t1 - t0
+    per_tok = max(1e-6, ((t2 - t1) - prefill) / 2)
+    requery = prefill * (2 * args.cutoff_len + 9) / args.cutoff_len
+    dit_s = args.T / dit["denoise_steps_per_s"]
+    total = prefill + args.new_tokens * per_tok + requery + dit_s
+    return {"value": B / total, "unit": "molecules/s", "cores": cores, "kind": "port",
+            "sample": f"HF {args.llm} (random-init, bf16) on {cores} CPU threads: prompt pass {prefill:.2f} s, "
+                      f"{per_tok:.3f} s/token over 2 decode tokens, extrapolated to {args.new_tokens} tokens + query re-forward; "
+                      f"GraphDiT oracle {dit['sample']}",
+            "llm_s": prefill + args.new_tokens * per_tok + requery, "graphdit_s": dit_s,
+            "denoise_steps_per_s": dit["denoise_steps_per_s"]}
+
+
 def time_dominant_kernel(args, device):
     """Event-bracketed loop of the dominant kernel (the MLP fc1 GEMM of one block) with the bench's own
     shapes, on the stream it is launched on.  Returns (avg_ms, bytes, flops, name)."""
@@ -192,6 +222,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--llm", default="qwen2-7b")
     ap.add_argument("--new-tokens", type=int, default=128)
+    ap.add_argument("--cutoff-len", type=int, default=128)
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 8 if args.workload == "graphdit" else 1
@@ -216,7 +247,8 @@ def main():
 
     if args.workload == "e2e":
         from llamole_amd.e2e import build_e2e_step
-        step_fn, e2e_info = build_e2e_step(args, m, device, props, rank)
+        step_fn, e2e_info, orch, llm = build_e2e_step(args, m, device, props, rank)
+        log("LLM built")
     else:
         e2e_info = {}
 
@@ -294,7 +326,11 @@ def main():
         "roofline": roof,
     }
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, cfg, meta, sd, props, text, n_nodes)
+        log("cpu baseline ...")
+        if args.workload == "e2e":
+            out["cpu_baseline"] = cpu_baseline_e2e(args, llm, cfg, meta, sd, props, text, n_nodes)
+        else:
+            out["cpu_baseline"] = cpu_baseline(args, cfg, meta, sd, props, text, n_nodes)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

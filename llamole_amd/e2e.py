@@ -1,0 +1,122 @@
+"""End-to-end synthetic workload: BASELINE.json configs[1] (Qwen2-7B + GraphDiT material design).
+
+There is no network on the GPU box, so the LLM is the *architecture* named by the config with seeded
+random-init weights (HuggingFace ``Qwen2ForCausalLM`` on PyTorch-ROCm, bf16, untouched), the prompt is a
+synthetic ``cutoff_len``-token id tensor, and generation uses the reference's sampling settings
+(config/generate/qwen_material.yaml: temperature 0.6, top_p 0.9, max_new_tokens 128; stop at eos or any of
+the 9 special tokens, eval/workflow.py:93-98).  With random weights the trigger token is (almost) never
+sampled, so every prompt pays the full max_new_tokens budget -- the worst case of the real workload.
+"""
+from __future__ import annotations
+
+import time
+import types
+
+import torch
+
+LLM_CONFIGS = {
+    # published architecture hyper-parameters of the base models named in BASELINE.json
+    "qwen2-7b": dict(cls="Qwen2", hidden_size=3584, num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4,
+                     intermediate_size=18944, vocab_size=152064, max_position_embeddings=32768, rope_theta=1000000.0,
+                     rms_norm_eps=1e-6, tie_word_embeddings=False),
+    "llama-3.1-8b": dict(cls="Llama", hidden_size=4096, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8,
+                         intermediate_size=14336, vocab_size=128256, max_position_embeddings=131072, rope_theta=500000.0,
+                         rms_norm_eps=1e-5, tie_word_embeddings=False),
+    "tiny": dict(cls="Qwen2", hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                 intermediate_size=512, vocab_size=2048, max_position_embeddings=2048, rope_theta=10000.0,
+                 rms_norm_eps=1e-6, tie_word_embeddings=False),
+}
+
+
+class SyntheticTokenizer:
+    """Just enough tokenizer for synthetic-id workloads: eos id, special-token ids, trivial decode."""
+
+    def __init__(self, vocab_size: int):
+        self.vocab_size = vocab_size
+        self.eos_token_id = vocab_size - 20
+        self.pad_token_id = self.eos_token_id
+        from .modeling_llamole import SPECIAL_TOKENS
+        self.special = {t: vocab_size - 19 + i for i, t in enumerate(SPECIAL_TOKENS)}
+
+    def __len__(self):
+        return self.vocab_size
+
+    def encode(self, text, add_special_tokens=False, return_tensors=None):
+        if text in self.special:
+            ids = [self.special[text]]
+        else:
+            ids = [5 + (hash(text[i:i + 3]) % 1000) for i in range(0, len(text), 3)]
+        return torch.tensor([ids]) if return_tensors == "pt" else ids
+
+    def decode(self, ids, skip_special_tokens=False, **k):
+        return " ".join(str(int(i)) for i in ids)
+
+
+def build_llm(name: str, device, dtype=torch.bfloat16, seed: int = 0):
+    import transformers
+    spec = dict(LLM_CONFIGS[name])
+    kind = spec.pop("cls")
+    cfg_cls = getattr(transformers, kind + "Config")
+    model_cls = getattr(transformers, kind + "ForCausalLM")
+    cfg = cfg_cls(**spec)
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        with torch.device(device):
+            model = model_cls(cfg)
+    finally:
+        torch.set_default_dtype(prev)
+    model.eval()
+    for p in model.parameters():
+        p.requires_grad = False
+    return model
+
+
+def build_orchestrator(llm, graph_decoder, device, dtype=torch.bfloat16):
+    from .modeling_llamole import GraphLLMForCausalMLM
+    tok = SyntheticTokenizer(llm.config.vocab_size)
+    enc = types.SimpleNamespace(hidden_size=512)
+    pred = types.SimpleNamespace(text_input_size=768, available=None)
+    m = GraphLLMForCausalMLM(types.SimpleNamespace(compute_dtype=dtype), types.SimpleNamespace(),
+                             types.SimpleNamespace(learned_query_size=8), llm, graph_decoder, pred, enc,
+                             dict(tok.special), tok)
+    torch.manual_seed(1)
+    for name in ("graph_to_lm_connector", "lm_to_graph_decoder", "lm_to_graph_predictor"):
+        getattr(m, name).to(device=device, dtype=dtype)
+    return m, tok
+
+
+def gen_kwargs(tok, new_tokens: int):
+    return dict(do_sample=True, temperature=0.6, top_p=0.9, max_new_tokens=new_tokens,
+                eos_token_id=[tok.eos_token_id] + list(tok.special.values()), pad_token_id=tok.pad_token_id)
+
+
+def build_e2e_step(args, graph_decoder, device, props, rank: int):
+    """Returns (step_fn, info).  step_fn(i) -> list of integer molecule graphs for the rank's batch."""
+    llm = build_llm(args.llm, device)
+    orch, tok = build_orchestrator(llm, graph_decoder, device)
+    B = props.shape[0]
+    g = torch.Generator().manual_seed(100 + rank)
+    prompt = torch.randint(5, 1000, (B, args.cutoff_len), generator=g).to(device)
+    mask = torch.ones_like(prompt)
+    kw = gen_kwargs(tok, args.new_tokens)
+    n_nodes = torch.full((B,), graph_decoder.max_n_nodes, dtype=torch.int64)
+    last = {}
+
+    def step_fn(i):
+        torch.manual_seed(1000 * rank + i)
+        t0 = time.perf_counter()
+        analysis, design_ids, cond = orch.design_hidden(prompt, mask, None, **kw)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        mols, _ = graph_decoder.generate_graphs(props, cond.float(), -200.0, n_nodes=n_nodes, seed=1000 * rank + i,
+                                                use_graph=not args.no_graph)
+        t2 = time.perf_counter()
+        last.update(llm_s=t1 - t0, graphdit_s=t2 - t1, new_tokens=int(analysis.shape[1]), **orch.timings)
+        return mols
+
+    n_params = sum(p.numel() for p in llm.parameters())
+    info = {"llm": args.llm, "llm_params": n_params, "llm_weights": "random-init (no network)", "prompt_len": args.cutoff_len,
+            "max_new_tokens": args.new_tokens, "sampling": "temperature 0.6, top_p 0.9", "timing_breakdown": last}
+    return step_fn, info, orch, llm
