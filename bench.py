@@ -209,7 +209,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="graphdit", choices=["graphdit", "e2e"])
+    ap.add_argument("--workload", default="e2e", choices=["graphdit", "e2e"])
     ap.add_argument("--batch", type=int, default=None, help="prompts per GPU per step")
     ap.add_argument("--nodes", type=int, default=32)
     ap.add_argument("--hidden", type=int, default=1024)
@@ -277,13 +277,10 @@ def main():
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        # the path's only exchange: all-gather of the generated integer graphs (fixed-size records)
-        rec = torch.full((B, N + N * N), -1, dtype=torch.int8, device=device)
-        for b, (a, e) in enumerate(mols):
-            rec[b, :a.numel()] = a.to(torch.int8).to(device)
-            rec[b, N:N + e.numel()] = e.reshape(-1).to(torch.int8).to(device)
-        allrec = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(allrec, rec)
+        # the path's only exchange: ONE all-gather of the generated integer graphs (fixed-size records)
+        from llamole_amd.distributed import all_gather_graphs
+        gathered = all_gather_graphs(mols, N, world * B, device=device)
+        assert len(gathered) == world * B
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -325,7 +322,7 @@ def main():
                           "mfma_frac": sflops / (step_ms * 1e-3) / (MFMA_BF16_PEAK_TF * 1e12)},
         "roofline": roof,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         log("cpu baseline ...")
         if args.workload == "e2e":
             out["cpu_baseline"] = cpu_baseline_e2e(args, llm, cfg, meta, sd, props, text, n_nodes)
