@@ -223,6 +223,7 @@ def main():
     ap.add_argument("--llm", default="qwen2-7b")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--cutoff-len", type=int, default=128)
+    ap.add_argument("--llm-decode", default="graph", choices=["graph", "eager", "hf"])
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 8 if args.workload == "graphdit" else 1

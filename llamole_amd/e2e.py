@@ -96,6 +96,8 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
     """Returns (step_fn, info).  step_fn(i) -> list of integer molecule graphs for the rank's batch."""
     llm = build_llm(args.llm, device)
     orch, tok = build_orchestrator(llm, graph_decoder, device)
+    if args.llm_decode != "hf":
+        orch.enable_graphed_decode(use_graph=(args.llm_decode == "graph"))
     B = props.shape[0]
     g = torch.Generator().manual_seed(100 + rank)
     prompt = torch.randint(5, 1000, (B, args.cutoff_len), generator=g).to(device)
@@ -118,5 +120,8 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
 
     n_params = sum(p.numel() for p in llm.parameters())
     info = {"llm": args.llm, "llm_params": n_params, "llm_weights": "random-init (no network)", "prompt_len": args.cutoff_len,
-            "max_new_tokens": args.new_tokens, "sampling": "temperature 0.6, top_p 0.9", "timing_breakdown": last}
+            "max_new_tokens": args.new_tokens, "sampling": "temperature 0.6, top_p 0.9",
+            "llm_decode": {"graph": "stock HF forward over StaticCache, one hipGraph replayed per token",
+                           "eager": "stock HF forward over StaticCache, eager", "hf": "HF generate()"}[args.llm_decode],
+            "timing_breakdown": last}
     return step_fn, info, orch, llm

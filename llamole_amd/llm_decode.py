@@ -1,0 +1,130 @@
+"""HIP-graph autoregressive decode around an untouched HuggingFace causal LM.
+
+Row f2 of SURVEY.md section 8 ("LLM-side hot loop"): the reference calls ``language_model.generate`` eagerly
+(modeling_llamole.py:599, :849), i.e. ~10^3 small launches per token from Python.  On MI355X the decode step
+of a 7-8 B model is launch-bound long before it is HBM-bound, so the step -- the stock HF ``forward`` over a
+``StaticCache`` -- is captured ONCE as a hipGraph (``torch.cuda.CUDAGraph``; no tracing compiler, no Triton)
+and replayed per token; sampling (temperature, top-p, multinomial) stays on the device and the only host
+sync is an EOS check every ``sync_every`` tokens.  The LLM forward itself is HF code on PyTorch-ROCm.
+
+``GraphedDecoder.generate(input_ids, attention_mask, ...)`` returns prompt + new tokens like ``generate``
+(rows that stopped are padded with ``pad_token_id``).  Greedy mode is token-identical to HF ``generate``.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+
+def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float, generator=None) -> torch.Tensor:
+    """HF TemperatureLogitsWarper + TopPLogitsWarper + multinomial, without host syncs.  logits [B,V] float."""
+    logits = logits.float()
+    logits = torch.nan_to_num(logits, nan=0.0, posinf=torch.finfo(torch.float32).max, neginf=torch.finfo(torch.float32).min)
+    if temperature is not None and temperature != 1.0:
+        logits = logits / temperature
+    if top_p is not None and top_p < 1.0:
+        sorted_logits, sorted_idx = torch.sort(logits, descending=False)
+        cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+        remove = cum <= (1 - top_p)
+        remove[..., -1:] = False                      # keep at least one token
+        remove = remove.scatter(1, sorted_idx, remove)
+        logits = logits.masked_fill(remove, float("-inf"))
+    probs = torch.softmax(logits, dim=-1)
+    return torch.multinomial(probs, 1, generator=generator).squeeze(1)
+
+
+class GraphedDecoder:
+    def __init__(self, model, use_graph: bool = True, sync_every: int = 16):
+        self.model = model
+        self.use_graph = use_graph and next(model.parameters()).is_cuda
+        self.sync_every = sync_every
+        self._key = None
+        self._graph = None
+
+    # static buffers + captured step for a (batch, max_len) shape
+    def _prepare(self, B: int, max_len: int, device, use_embeds: bool):
+        from transformers import StaticCache
+        key = (B, max_len, use_embeds)
+        if self._key == key:
+            self.cache.reset()
+            return
+        self._key = key
+        cfg = self.model.config
+        self.cache = StaticCache(config=cfg, max_cache_len=max_len)
+        self.tok = torch.zeros(B, 1, dtype=torch.long, device=device)
+        self.pos = torch.zeros(1, dtype=torch.long, device=device)
+        self.mask = torch.zeros(B, max_len, dtype=torch.long, device=device)
+        self.logits = None
+        self._graph = None
+
+    def _step(self):
+        out = self.model(input_ids=self.tok, attention_mask=self.mask, past_key_values=self.cache,
+                         cache_position=self.pos, position_ids=self.posid, use_cache=True, return_dict=True)
+        return out.logits[:, -1, :]
+
+    @torch.no_grad()
+    def generate(self, input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                 inputs_embeds: Optional[torch.Tensor] = None, max_new_tokens: int = 128, do_sample: bool = True,
+                 temperature: float = 1.0, top_p: float = 1.0, eos_token_id: Optional[Sequence[int]] = None,
+                 pad_token_id: Optional[int] = None, generator=None, **_ignored) -> torch.Tensor:
+        ref = input_ids if input_ids is not None else inputs_embeds
+        B, P = ref.shape[0], ref.shape[1]
+        device = ref.device
+        if attention_mask is None:
+            attention_mask = torch.ones(B, P, dtype=torch.long, device=device)
+        max_len = P + max_new_tokens
+        self._prepare(B, max_len, device, inputs_embeds is not None)
+        eos = torch.tensor(list(eos_token_id) if isinstance(eos_token_id, (list, tuple)) else
+                           ([] if eos_token_id is None else [eos_token_id]), dtype=torch.long, device=device)
+        pad = pad_token_id if pad_token_id is not None else (int(eos[0]) if eos.numel() else 0)
+        # ---- prefill (eager, one call)
+        self.mask.zero_()
+        self.mask[:, :P] = attention_mask
+        plen = attention_mask.long().sum(dim=1, keepdim=True)            # valid prompt tokens per row (left padding)
+        pos_ids = (attention_mask.long().cumsum(dim=1) - 1).clamp_min(0)
+        kw = dict(inputs_embeds=inputs_embeds) if inputs_embeds is not None else dict(input_ids=input_ids)
+        out = self.model(attention_mask=self.mask[:, :P], past_key_values=self.cache,
+                         cache_position=torch.arange(P, device=device), position_ids=pos_ids, use_cache=True,
+                         return_dict=True, **kw)
+        logits = out.logits[:, -1, :]
+        new_tokens = torch.full((B, max_new_tokens), pad, dtype=torch.long, device=device)
+        done = torch.zeros(B, dtype=torch.bool, device=device)
+        self.posid = plen.clone()                                        # position id of the next token, per row
+        n_done_steps = 0
+        for t in range(max_new_tokens):
+            nxt = sample_top_p(logits, temperature, top_p, generator) if do_sample else logits.argmax(dim=-1)
+            nxt = torch.where(done, torch.full_like(nxt, pad), nxt)
+            new_tokens[:, t] = nxt
+            if eos.numel():
+                done = done | torch.isin(nxt, eos)
+            n_done_steps = t + 1
+            if t + 1 == max_new_tokens:
+                break
+            if eos.numel() and (t + 1) % self.sync_every == 0 and bool(done.all()):
+                break
+            # ---- one decode step at cache position P + t
+            self.tok.copy_(nxt.view(B, 1))
+            self.pos.fill_(P + t)
+            self.mask[:, P + t] = 1
+            if t > 0:
+                self.posid.add_(1)
+            if self.use_graph:
+                if self._graph is None:
+                    # warm-up on a side stream, then capture the stock HF forward once
+                    s = torch.cuda.Stream()
+                    s.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s):
+                        self._step()
+                    torch.cuda.current_stream().wait_stream(s)
+                    self._graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph):
+                        self.logits = self._step()
+                self._graph.replay()
+                logits = self.logits
+            else:
+                logits = self._step()
+        new_tokens = new_tokens[:, :n_done_steps]
+        if input_ids is not None:
+            return torch.cat([input_ids, new_tokens], dim=1)
+        return new_tokens

@@ -59,6 +59,20 @@ class GraphLLMForCausalMLM(nn.Module):
         self.lm_to_graph_decoder = make_connector(hidden, graph_decoder.text_input_size)
         self.lm_to_graph_predictor = make_connector(hidden, graph_predictor.text_input_size)
         self.timings: Dict[str, float] = {}
+        self.decoder = None      # optional llm_decode.GraphedDecoder (HIP-graph decode step); None = HF generate
+
+    def enable_graphed_decode(self, use_graph: bool = True, sync_every: int = 16):
+        """Route every LLM decode of the path through one captured hipGraph of the stock HF forward."""
+        from .llm_decode import GraphedDecoder
+        self.decoder = GraphedDecoder(self.language_model, use_graph=use_graph, sync_every=sync_every)
+        return self
+
+    def _llm_generate(self, inputs=None, attention_mask=None, inputs_embeds=None, **kwargs):
+        if self.decoder is not None:
+            return self.decoder.generate(input_ids=inputs, attention_mask=attention_mask, inputs_embeds=inputs_embeds, **kwargs)
+        if inputs_embeds is not None:
+            return self.language_model.generate(attention_mask=attention_mask, inputs_embeds=inputs_embeds, **kwargs)
+        return self.language_model.generate(inputs=inputs, attention_mask=attention_mask, **kwargs)
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -179,11 +193,11 @@ class GraphLLMForCausalMLM(nn.Module):
         """Steps 1-3 of design_molecule: analysis tokens and the [B,768] text condition for GraphDiT."""
         t0 = time.perf_counter()
         if molecule_graphs is None:
-            analysis = self.language_model.generate(inputs=input_ids, attention_mask=attention_mask, **kwargs)
+            analysis = self._llm_generate(inputs=input_ids, attention_mask=attention_mask, **kwargs)
             analysis = analysis[:, input_ids.shape[1]:]
         else:
             embeds = self._splice_molecules(input_ids, molecule_graphs)
-            analysis = self.language_model.generate(attention_mask=attention_mask, inputs_embeds=embeds, **kwargs)
+            analysis = self._llm_generate(attention_mask=attention_mask, inputs_embeds=embeds, **kwargs)
         t1 = time.perf_counter()
         design_ids = self.add_special_body_tokens(analysis, self.token_id_dict["<design_body>"], self.num_body_tokens,
                                                   start_token_id=self.token_id_dict["<design_start>"])
@@ -212,7 +226,7 @@ class GraphLLMForCausalMLM(nn.Module):
         rb_ids = self.add_special_body_tokens(analysis_tokens[torch.tensor(none_idx)], self.token_id_dict.get("<rollback_start>"), 1)
         if "max_new_tokens" in kwargs:
             kwargs["max_new_tokens"] *= 2
-        new_tokens = self.language_model.generate(inputs=rb_ids, attention_mask=torch.ones_like(rb_ids), **kwargs)
+        new_tokens = self._llm_generate(inputs=rb_ids, attention_mask=torch.ones_like(rb_ids), **kwargs)
         end_text = self.tokenizer.decode([self.token_id_dict.get("<rollback_end>")])
         for i, seq in zip(none_idx, new_tokens[:, rb_ids.shape[1]:]):
             text = self.tokenizer.decode(seq, skip_special_tokens=False)
@@ -249,7 +263,7 @@ class GraphLLMForCausalMLM(nn.Module):
                                     add_special_tokens=False, return_tensors="pt").to(self.device)
         if "max_new_tokens" in kwargs:
             kwargs["max_new_tokens"] = 256
-        out = self.language_model.generate(inputs=ids, **kwargs)[:, ids.shape[1]:]
+        out = self._llm_generate(inputs=ids, **kwargs)[:, ids.shape[1]:]
         return self.tokenizer.encode(f"To synthesize {smiles}, follow these procedures: ") + out.cpu().squeeze().tolist()
 
     def one_step_reaction(self, product_smiles, input_ids, design_text, molecule_graphs, topk, **kwargs):
@@ -267,7 +281,7 @@ class GraphLLMForCausalMLM(nn.Module):
         embeds = self._splice_molecules(prompt, graphs)
         if "max_new_tokens" in kwargs:
             kwargs["max_new_tokens"] = 512
-        analysis = self.language_model.generate(attention_mask=torch.ones_like(prompt), inputs_embeds=embeds, **kwargs)
+        analysis = self._llm_generate(attention_mask=torch.ones_like(prompt), inputs_embeds=embeds, **kwargs)
         retro_ids = self.add_special_body_tokens(analysis, self.token_id_dict["<retro_body>"], self.num_body_tokens,
                                                  start_token_id=self.token_id_dict["<retro_start>"])
         hidden = self._query_hidden(retro_ids)
