@@ -224,6 +224,7 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--cutoff-len", type=int, default=128)
     ap.add_argument("--llm-decode", default="graph", choices=["graph", "eager", "hf"])
+    ap.add_argument("--blas", default="default", choices=["default", "hipblaslt", "hipblas"])
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 8 if args.workload == "graphdit" else 1
@@ -241,6 +242,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
+    if args.blas != "default":
+        torch.backends.cuda.preferred_blas_library(args.blas)
     m, cfg, meta, sd = build_model(args, device)
     log("model built")
     B, N, T = args.batch, args.nodes, args.T

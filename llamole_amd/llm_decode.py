@@ -55,6 +55,7 @@ class GraphedDecoder:
         self.tok = torch.zeros(B, 1, dtype=torch.long, device=device)
         self.pos = torch.zeros(1, dtype=torch.long, device=device)
         self.mask = torch.zeros(B, max_len, dtype=torch.long, device=device)
+        self.posid = torch.zeros(B, 1, dtype=torch.long, device=device)   # static: the captured graph reads it
         self.logits = None
         self._graph = None
 
@@ -79,7 +80,10 @@ class GraphedDecoder:
                            ([] if eos_token_id is None else [eos_token_id]), dtype=torch.long, device=device)
         pad = pad_token_id if pad_token_id is not None else (int(eos[0]) if eos.numel() else 0)
         # ---- prefill (eager, one call)
-        self.mask.zero_()
+        # 2-D key mask for the whole static cache: prompt padding as given, every future slot open (causality
+        # -- cache_position inside the HF mask builder -- already hides the slots not written yet), so the mask
+        # never changes between replays of the captured step.
+        self.mask.fill_(1)
         self.mask[:, :P] = attention_mask
         plen = attention_mask.long().sum(dim=1, keepdim=True)            # valid prompt tokens per row (left padding)
         pos_ids = (attention_mask.long().cumsum(dim=1) - 1).clamp_min(0)
@@ -90,7 +94,7 @@ class GraphedDecoder:
         logits = out.logits[:, -1, :]
         new_tokens = torch.full((B, max_new_tokens), pad, dtype=torch.long, device=device)
         done = torch.zeros(B, dtype=torch.bool, device=device)
-        self.posid = plen.clone()                                        # position id of the next token, per row
+        self.posid.copy_(plen)                                           # position id of the next token, per row
         n_done_steps = 0
         for t in range(max_new_tokens):
             nxt = sample_top_p(logits, temperature, top_p, generator) if do_sample else logits.argmax(dim=-1)
@@ -106,7 +110,6 @@ class GraphedDecoder:
             # ---- one decode step at cache position P + t
             self.tok.copy_(nxt.view(B, 1))
             self.pos.fill_(P + t)
-            self.mask[:, P + t] = 1
             if t > 0:
                 self.posid.add_(1)
             if self.use_graph:
@@ -116,6 +119,10 @@ class GraphedDecoder:
                     s.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(s):
                         self._step()
+                        # the warm-up advanced the cache's on-device length counters; rewind them so that the
+                        # captured step (replayed below for this same token) writes the same slot again
+                        for layer in self.cache.layers:
+                            layer.cumulative_length.sub_(self.tok.shape[1])
                     torch.cuda.current_stream().wait_stream(s)
                     self._graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self._graph):
@@ -125,6 +132,7 @@ class GraphedDecoder:
             else:
                 logits = self._step()
         new_tokens = new_tokens[:, :n_done_steps]
+        self.last_logits = logits
         if input_ids is not None:
             return torch.cat([input_ids, new_tokens], dim=1)
         return new_tokens

