@@ -50,6 +50,11 @@ int ll_linear(int dtype, const void *A, int lda, const void *W, int ldw, const f
  * dispatch) on an [M,K]x[N,K]^T bf16 problem, cycling over `nweights` weight matrices (HBM-resident stream). */
 int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f32, int iters, int nweights, float *ms);
 
+/* Launch-latency probe (tuning utility): average us per kernel over n launches of a trivial kernel
+ * (kind 0 empty, 1 load+store, 2 dependent loads, 3 1-MB copy), eager stream (graph=0) or one hipGraph (graph=1). */
+int ll_launch_bench(int kind, int n, int graph, float *us);
+int ll_launch_bench_set_buffers(void *a, void *b);   /* optional caller-provided 4 MB buffers (NULL = own) */
+
 /* ------------------------------------------------------------------ GraphDiT sampler
  * Replaces reference GraphDiT.generate / sample_p_zs_given_zt / Transformer.forward
  * (src/model/graph_decoder/diffusion_model.py:252-399, transformer.py:93-187,

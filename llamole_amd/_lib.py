@@ -38,6 +38,8 @@ SIGNATURES = {
     "ll_last_error": (C.c_char_p, []),
     "ll_linear": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ll_gemm_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
+    "ll_launch_bench": (_I, [_I, _I, _I, C.POINTER(_F)]),
+    "ll_launch_bench_set_buffers": (_I, [_P, _P]),
     "ll_dit_param_count": (_I, [C.POINTER(LLDitConfig)]),
     "ll_dit_param_info": (_I, [C.POINTER(LLDitConfig), _I, C.c_char_p, _I, C.POINTER(_I64), C.POINTER(_I64)]),
     "ll_dit_arena_elems": (_I64, [C.POINTER(LLDitConfig)]),

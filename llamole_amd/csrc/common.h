@@ -52,11 +52,10 @@ __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------- device numerics
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even through the native conversion (v_cvt_pk_bf16_f32 on gfx950): branch-free, NaN-safe
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
 }
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
@@ -69,15 +68,46 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float softsign(float x) { return x / (1.0f + fabsf(x)); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions on the VALU data path (DPP), not the LDS crossbar (ds_bpermute, ~100 cycles each):
+// quad_perm swaps for xor 1 / xor 2, then row_half_mirror / row_mirror (after the quad steps every quad, then
+// every 8-lane half, already holds one value, so the mirrors act as xor 4 / xor 8).
+#define LL_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true))
+__device__ __forceinline__ float row16_sum(float v) {
+    v += LL_DPP(v, 0xB1);
+    v += LL_DPP(v, 0x4E);
+    v += LL_DPP(v, 0x141);
+    v += LL_DPP(v, 0x140);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, LL_DPP(v, 0xB1));
+    v = fmaxf(v, LL_DPP(v, 0x4E));
+    v = fmaxf(v, LL_DPP(v, 0x141));
+    v = fmaxf(v, LL_DPP(v, 0x140));
     return v;
+}
+__device__ __forceinline__ float row8_sum(float v) {
+    v += LL_DPP(v, 0xB1);
+    v += LL_DPP(v, 0x4E);
+    v += LL_DPP(v, 0x141);
+    return v;
+}
+__device__ __forceinline__ float row4_sum(float v) {
+    v += LL_DPP(v, 0xB1);
+    v += LL_DPP(v, 0x4E);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    const int b = __builtin_bit_cast(int, v);
+    return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))),
+                 fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48))));
 }
 
 // Philox4x32-10 counter-based generator (Salmon et al. 2011); one call = 4 x 32 random bits.

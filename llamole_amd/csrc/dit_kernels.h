@@ -264,8 +264,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t *__restrict
             float sm = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) sm += f[e];
-#pragma unroll
-            for (int off = 1; off < LPR8; off <<= 1) sm += __shfl_xor(sm, off, 64);
+            sm = (LPR8 == 8) ? row8_sum(sm) : row4_sum(sm);
             const float mean = sm / (float)HD;
             float vr = 0.f;
 #pragma unroll
@@ -273,8 +272,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t *__restrict
                 const float d = f[e] - mean;
                 vr += d * d;
             }
-#pragma unroll
-            for (int off = 1; off < LPR8; off <<= 1) vr += __shfl_xor(vr, off, 64);
+            vr = (LPR8 == 8) ? row8_sum(vr) : row4_sum(vr);
             const float rstd = rsqrtf(vr / (float)HD + 1e-5f);
             uint32_t pk[4];
 #pragma unroll
@@ -342,8 +340,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t *__restrict
                 acc[mt][nt][r] = sv;
                 mx = fmaxf(mx, sv);
             }
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            mx = row16_max(mx);
             float sm = 0.f;
 #pragma unroll
             for (int nt = 0; nt < MT; ++nt) {
@@ -351,8 +348,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t *__restrict
                 acc[mt][nt][r] = ev;
                 sm += ev;
             }
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) sm += __shfl_xor(sm, off, 64);
+            sm = row16_sum(sm);
             const float inv = 1.f / sm;
 #pragma unroll
             for (int nt = 0; nt < MT; ++nt) Ps[i * PLD + nt * 16 + fr] = f32_to_bf16(acc[mt][nt][r] * inv);

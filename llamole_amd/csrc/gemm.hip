@@ -542,6 +542,124 @@ extern "C" int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f
     return LL_OK;
 }
 
+namespace ll {
+__global__ void lb_empty_kernel() {}
+__global__ void lb_load_kernel(const int *p, int *q) { q[threadIdx.x] = p[threadIdx.x] + 1; }
+__global__ void lb_dep_kernel(const int *idx, const int *tab, int *q) { q[threadIdx.x] = tab[idx[0] + threadIdx.x]; }
+typedef __attribute__((ext_vector_type(4))) float lbf4;
+__global__ __launch_bounds__(1024) void lb_wide_kernel(const lbf4 *p, lbf4 *q, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    lbf4 v = p[i];
+    v[0] += 1.f;
+    q[i] = v;
+}
+__global__ __launch_bounds__(1024) void lb_read_kernel(const lbf4 *p, lbf4 *q, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const lbf4 v = p[i];
+    if (v[0] == 12345.f) q[i] = v;   // never true: read-only traffic
+}
+__global__ __launch_bounds__(1024) void lb_read_same_kernel(const lbf4 *p, lbf4 *q, int n) {
+    const lbf4 v = p[threadIdx.x];   // every block reads the same 4 KB
+    if (v[0] == 12345.f) q[threadIdx.x] = v;
+}
+__global__ __launch_bounds__(1024) void lb_read_stride_kernel(const lbf4 *p, lbf4 *q, int stride_f4) {
+    const lbf4 v = p[(size_t)blockIdx.x * stride_f4 + threadIdx.x];
+    if (v[0] == 12345.f) q[threadIdx.x] = v;
+}
+__global__ __launch_bounds__(1024) void lb_write_kernel(lbf4 *q, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    q[i] = lbf4{1.f, 2.f, 3.f, 4.f};
+}
+}  // namespace ll
+
+// Launch-latency probe: average microseconds per kernel over `n` back-to-back launches of a trivial kernel,
+// either eagerly on a stream (graph=0) or as one captured hipGraph of n nodes (graph=1).
+// kind: 0 empty, 1 one load+store (64 threads), 2 dependent load chain, 3 1 MB streaming copy (256 blocks).
+static void *g_probe_a = nullptr, *g_probe_b = nullptr;
+extern "C" int ll_launch_bench_set_buffers(void *a, void *b) {
+    g_probe_a = a;
+    g_probe_b = b;
+    return LL_OK;
+}
+extern "C" int ll_launch_bench(int kind, int n, int graph, float *us) {
+    using namespace ll;
+    LL_CHECK(us && n > 0 && kind >= 0, "bad argument");
+    const int threads = kind >= 100000 ? 1024 : 256;                 // +100000: 1024-thread blocks
+    const int blocks = kind >= 100 ? (kind % 100000) / 100 : 256;   // kind = 100*blocks + {3,4,5,6}
+    if (kind >= 100) kind = kind % 100;
+    LL_CHECK(kind <= 8 && blocks >= 1 && blocks <= 999, "bad kind");
+    int *a = nullptr, *b = nullptr;
+    char *big = nullptr;
+    const char *ev = getenv("LL_PROBE_BIG");
+    const size_t bigsz = ev ? (size_t)atol(ev) << 20 : 0;
+    const bool ext = g_probe_a != nullptr;
+    if (ext) {
+        a = (int *)g_probe_a;
+        b = (int *)g_probe_b;
+    } else if (bigsz) {
+        LL_HIP(hipMalloc(&big, bigsz));
+        a = (int *)big;
+        b = (int *)(big + bigsz / 2);
+    } else {
+        LL_HIP(hipMalloc(&a, 4 << 20));
+        LL_HIP(hipMalloc(&b, 4 << 20));
+    }
+    if (!ext) LL_HIP(hipMemset(a, 0, 4 << 20));
+    hipStream_t st;
+    LL_HIP(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    LL_HIP(hipEventCreate(&e0));
+    LL_HIP(hipEventCreate(&e1));
+    auto launch = [&]() {
+        switch (kind) {
+            case 0: hipLaunchKernelGGL(lb_empty_kernel, dim3(1), dim3(64), 0, st); break;
+            case 1: hipLaunchKernelGGL(lb_load_kernel, dim3(1), dim3(64), 0, st, a, b); break;
+            case 2: hipLaunchKernelGGL(lb_dep_kernel, dim3(1), dim3(64), 0, st, a, a + 1024, b); break;
+            case 3: hipLaunchKernelGGL(lb_wide_kernel, dim3(blocks), dim3(threads), 0, st, (const lbf4 *)a, (lbf4 *)b, blocks * threads); break;
+            case 4: hipLaunchKernelGGL(lb_read_kernel, dim3(blocks), dim3(threads), 0, st, (const lbf4 *)a, (lbf4 *)b, blocks * threads); break;
+            case 7: hipLaunchKernelGGL(lb_read_stride_kernel, dim3(blocks), dim3(threads), 0, st, (const lbf4 *)a, (lbf4 *)b, (2 << 20) / 16); break;
+            case 8: hipLaunchKernelGGL(lb_read_stride_kernel, dim3(blocks), dim3(threads), 0, st, (const lbf4 *)a, (lbf4 *)b, (64 << 10) / 16); break;
+            case 6: hipLaunchKernelGGL(lb_read_same_kernel, dim3(blocks), dim3(threads), 0, st, (const lbf4 *)a, (lbf4 *)b, blocks * threads); break;
+            default: hipLaunchKernelGGL(lb_write_kernel, dim3(blocks), dim3(threads), 0, st, (lbf4 *)b, blocks * threads); break;
+        }
+    };
+    for (int i = 0; i < 16; ++i) launch();
+    LL_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    if (graph) {
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        LL_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < n; ++i) launch();
+        LL_HIP(hipStreamEndCapture(st, &g));
+        LL_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        LL_HIP(hipGraphLaunch(ge, st));
+        LL_HIP(hipStreamSynchronize(st));
+        LL_HIP(hipEventRecord(e0, st));
+        for (int r = 0; r < 4; ++r) LL_HIP(hipGraphLaunch(ge, st));
+        LL_HIP(hipEventRecord(e1, st));
+        LL_HIP(hipEventSynchronize(e1));
+        LL_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ms /= 4.f;
+        (void)hipGraphExecDestroy(ge);
+        (void)hipGraphDestroy(g);
+    } else {
+        LL_HIP(hipEventRecord(e0, st));
+        for (int i = 0; i < n; ++i) launch();
+        LL_HIP(hipEventRecord(e1, st));
+        LL_HIP(hipEventSynchronize(e1));
+        LL_HIP(hipEventElapsedTime(&ms, e0, e1));
+    }
+    *us = ms * 1000.f / n;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(st);
+    if (ext) {}
+    else if (big) (void)hipFree(big);
+    else { (void)hipFree(a); (void)hipFree(b); }
+    return LL_OK;
+}
+
 extern "C" int ll_linear(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
                          int M, int N, int K, int epi, int out_f32, void *stream) {
     return ll::linear_launch(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, epi, out_f32, (hipStream_t)stream);
