@@ -38,7 +38,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void embed_kernel(const int8_t *__restrict__ X, const int8_t *__restrict__ E,
                                                      const float *__restrict__ WxT, const float *__restrict__ lnw,
                                                      const float *__restrict__ lnb, float *__restrict__ x32,
-                                                     T *__restrict__ xa, int B, int N, int H) {
+                                                     T *__restrict__ xa, const int *__restrict__ step_ptr, int B,
+                                                     int N, int H) {
     __shared__ float red[4];
     __shared__ int gidx[72];
     __shared__ int ng;
@@ -47,8 +48,9 @@ __global__ __launch_bounds__(256) void embed_kernel(const int8_t *__restrict__ X
     const int i = row - b * N;
     if (threadIdx.x < 64) {  // wave 0 compacts the non-zero input columns with a ballot (order-preserving)
         const int lane = threadIdx.x;
-        const int8_t *er = E + ((int64_t)b * N + i) * N;
-        const int xi = X[row];
+        const int half = (*step_ptr + 1) & 1;   // z_{s+1} lives in half (s+1)&1 of the double-buffered state
+        const int8_t *er = E + (((int64_t)half * B + b) * N + i) * N;
+        const int xi = X[(int64_t)half * B * N + row];
         const int e = (lane < N) ? (int)er[lane] : -1;
         const unsigned long long m = __ballot(e >= 0);
         const int base = (xi >= 0) ? 1 : 0;
@@ -464,11 +466,20 @@ __global__ __launch_bounds__(256) void ln_mod_res_kernel(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------ posterior + CFG + sampling
+// Two launches replace ~40 ATen launches, six dense [B,F,F] builds and six bmm per step of the reference
+// (diffusion_model.py:328-399, diffusion_utils.py:316-349, 376-413, 476-492) with O(N*F) work per graph:
+//   post_rows_kernel : one wave per decoder row (pass, graph, node): LN0 + modulate in place, atom softmax, pred_X.u_xe
+//   post_pairs_kernel: one wave per (graph, node i): bond softmax of row i, structured posterior of node i and of the
+//                      pairs (i, j>i), classifier-free guidance, clamp/renorm, Exp(1)-race sampling, state write.
+// The graph state is double-buffered (z_{s+1} in half (s+1)&1, z_s written to half s&1) so rows can be processed by
+// independent workgroups without read/write hazards on E.
 struct PostArgs {
-    const float *out;    // [2][B][N][F] decoder output (fc2 + bias), before LN0/modulate
+    float *out;          // [2][B][N][F] decoder output (fc2 + bias); normalised + modulated in place by post_rows
     const float *modo;   // [T][B+1][2F] output-layer modulation (shift | scale)
-    int8_t *X;           // [B][N]      in/out
-    int8_t *E;           // [B][N][N]   in/out
+    float *predX;        // [2][B][N][16] scratch
+    float *pxe;          // [2][B][N][8]  scratch: sum_a predX[a] u_xe[a][k]
+    int8_t *X;           // [2][B][N]      double-buffered state
+    int8_t *E;           // [2][B][N][N]
     const int *n_nodes;  // [B]
     const float *x_marg, *e_marg, *u_xe, *u_ex, *betas, *alphas_bar;
     const float *qx, *qe;          // injected Exp(1) noise or null
@@ -481,87 +492,100 @@ struct PostArgs {
     int update_state;
 };
 
-// LN0 + modulate of decoder output element f of row (p,b,i)
-struct RowNorm {
-    float mean, rstd;
-};
-
-__global__ __launch_bounds__(256) void posterior_sample_kernel(PostArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
-    const int b = blockIdx.x;
+__global__ __launch_bounds__(256) void post_rows_kernel(PostArgs a) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);  // (p*B + b)*N + i
     const int N = a.N, F = a.F, B = a.B;
-    const int tid = threadIdx.x;
+    if (row >= 2 * B * N) return;
+    const int lane = threadIdx.x & 63;
+    const int s = *a.step_ptr;
+    const int p = row / (B * N);
+    const int bi = row - p * B * N;
+    const int b = bi / N, i = bi - b * N;
+    const int ci = p == 0 ? b : B;
+    const float *ss = a.modo + ((int64_t)s * (B + 1) + ci) * (2 * F);
+    float *r = a.out + (int64_t)row * F;
+    constexpr int MAXF = 6;  // F <= 336 = 16 + 5*64
+    float v[MAXF], sh[MAXF], sc[MAXF];
+    float sm = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXF; ++e) {
+        const int f = lane + e * 64;
+        v[e] = f < F ? r[f] : 0.f;
+        sh[e] = f < F ? ss[f] : 0.f;
+        sc[e] = f < F ? ss[F + f] : 0.f;
+        sm += v[e];
+    }
+    const float mean = wave_sum(sm) / (float)F;
+    float vr = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXF; ++e) {
+        const float d = v[e] - mean;
+        vr += (lane + e * 64 < F) ? d * d : 0.f;
+    }
+    const float rstd = rsqrtf(wave_sum(vr) / (float)F + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < MAXF; ++e) {
+        const int f = lane + e * 64;
+        v[e] = (v[e] - mean) * rstd * (1.f + sc[e]) + sh[e];
+        if (f < F) r[f] = v[e];
+    }
+    // atom classes live in lanes 0..15 of chunk 0
+    const int st_in = (s + 1) & 1;
+    const int xi = a.X[((int64_t)st_in * B + b) * N + i];
+    const bool valid = i < a.n_nodes[b];
+    if (lane < 16) {
+        const float l = valid ? ((xi == lane ? 1.f : 0.f) + v[0]) : 0.f;
+        if (a.logX) a.logX[(int64_t)row * XD + lane] = l;
+        const float mx = row16_max(l);
+        const float ex = expf(l - mx);
+        const float pv = ex / row16_sum(ex);
+        a.predX[(int64_t)row * XD + lane] = pv;
+        float t[ED];
+#pragma unroll
+        for (int k = 0; k < ED; ++k) t[k] = row16_sum(pv * a.u_xe[lane * ED + k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < ED; ++k) a.pxe[(int64_t)row * 8 + k] = t[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void post_pairs_kernel(PostArgs a) {
+    const int i = blockIdx.x, b = blockIdx.y;
+    const int N = a.N, F = a.F, B = a.B;
+    const int j = threadIdx.x;  // lane = partner node
     const int s = *a.step_ptr;
     const int nv = a.n_nodes[b];
+    const int st_in = (s + 1) & 1, st_out = s & 1;
+    const int8_t *Xin = a.X + ((int64_t)st_in * B + b) * N;
+    const int8_t *Ein = a.E + ((int64_t)st_in * B + b) * N * N;
+    const bool vi = i < nv, vj = j < nv && j < N;
+    const int xi = Xin[i];
+    const int eij = j < N ? (int)Ein[i * N + j] : -1;
+    const int eji = j < N ? (int)Ein[j * N + i] : -1;
+    const float beta = a.betas[s + 1], ab_s = a.alphas_bar[s], ab_t = a.alphas_bar[s + 1];
+    const bool guided = (a.guide != 1.0f);
+    const unsigned long long seed = a.seed_ptr ? *a.seed_ptr : 0ull;
+    const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
 
-    // ---- LDS carve
-    float *shsc = reinterpret_cast<float *>(smraw);  // [2][2F]  (shift | scale) per pass
-    float *stat = shsc + 4 * F;                      // [2][N][2]
-    float *predX = stat + 4 * N;                     // [2][N][16]
-    float *SE = predX + 2 * N * XD;                  // [2][N][8]  (5 class sums, [5] = total)
-    float *PXE = SE + 2 * N * 8;                     // [2][N][8]  sum_a predX[a] u_xe[a][k]
-    float *Sx = PXE + 2 * N * 8;                     // [N][16]
-    float *Se = Sx + N * XD;                         // [N][8]
-    float *cst = Se + N * 8;                         // x_marg[16] e_marg[5->8] u_xe[80] u_ex[80]
-    int *sX = reinterpret_cast<int *>(cst + 16 + 8 + 80 + 80);  // [N]
-    int8_t *sE = reinterpret_cast<int8_t *>(sX + N);            // [N][N]
-
-    float *c_xm = cst, *c_em = cst + 16, *c_uxe = cst + 24, *c_uex = cst + 104;
-    if (tid < 16) c_xm[tid] = a.x_marg[tid];
-    if (tid < 5) c_em[tid] = a.e_marg[tid];
-    if (tid < 80) {
-        c_uxe[tid] = a.u_xe[tid];
-        c_uex[tid] = a.u_ex[tid];
-    }
-    for (int i = tid; i < N; i += 256) sX[i] = a.X[(int64_t)b * N + i];
-    for (int i = tid; i < N * N; i += 256) sE[i] = a.E[(int64_t)b * N * N + i];
-    for (int i = tid; i < 2 * F; i += 256) {
-        shsc[i] = a.modo[((int64_t)s * (B + 1) + b) * (2 * F) + i];
-        shsc[2 * F + i] = a.modo[((int64_t)s * (B + 1) + B) * (2 * F) + i];
-    }
-    // ---- phase A: LayerNorm statistics of every decoder row (wave per row)
-    {
-        const int wave = tid >> 6, lane = tid & 63;
-        for (int r = wave; r < 2 * N; r += 4) {
-            const int p = r / N, i = r - p * N;
-            const float *row = a.out + (((int64_t)p * B + b) * N + i) * F;
-            float sm = 0.f;
-            for (int f = lane; f < F; f += 64) sm += row[f];
-            const float mean = wave_sum(sm) / (float)F;
-            float vr = 0.f;
-            for (int f = lane; f < F; f += 64) {
-                const float d = row[f] - mean;
-                vr += d * d;
-            }
-            vr = wave_sum(vr) / (float)F;
-            if (lane == 0) {
-                stat[r * 2] = mean;
-                stat[r * 2 + 1] = rsqrtf(vr + 1e-5f);
-            }
-        }
-    }
-    __syncthreads();
-    auto lnmod = [&](int p, int i, int f) -> float {
-        const float v = a.out[(((int64_t)p * B + b) * N + i) * F + f];
-        const float *ss = shsc + p * 2 * F;
-        return (v - stat[(p * N + i) * 2]) * stat[(p * N + i) * 2 + 1] * (1.f + ss[F + f]) + ss[f];
-    };
-    // final (masked, symmetrised) bond logits of pair (i,j) for pass p   (transformer.py:170-185 + mask)
-    auto edge_logits = [&](int p, int i, int j, float *l) {
-        if (i >= nv || j >= nv || i == j) {
+    // ---- pred_E[i][j][:] for both passes (final masked, symmetrised logits -> softmax), SE = sum_j pred_E
+    float e5[2][ED], SE[2][ED], SEt[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        float l[ED];
+        if (vi && vj && i != j) {
+            const float *zi = a.out + ((((int64_t)p * B + b) * N + i) * F) + XD + ED * j;
+            const float *zj = a.out + ((((int64_t)p * B + b) * N + j) * F) + XD + ED * i;
+#pragma unroll
+            for (int k = 0; k < ED; ++k) l[k] = 0.5f * (((eij == k ? 1.f : 0.f) + zi[k]) + ((eji == k ? 1.f : 0.f) + zj[k]));
+        } else {
 #pragma unroll
             for (int k = 0; k < ED; ++k) l[k] = 0.f;
-            return;
         }
-        const int eij = sE[i * N + j], eji = sE[j * N + i];
+        if (a.logE && j < N) {
 #pragma unroll
-        for (int k = 0; k < ED; ++k) {
-            const float bij = (eij == k ? 1.f : 0.f) + lnmod(p, i, XD + ED * j + k);
-            const float bji = (eji == k ? 1.f : 0.f) + lnmod(p, j, XD + ED * i + k);
-            l[k] = 0.5f * (bij + bji);
+            for (int k = 0; k < ED; ++k) a.logE[((((int64_t)p * B + b) * N + i) * N + j) * ED + k] = l[k];
         }
-    };
-    auto softmax5 = [](float *l) {
         float mx = l[0];
 #pragma unroll
         for (int k = 1; k < ED; ++k) mx = fmaxf(mx, l[k]);
@@ -572,297 +596,171 @@ __global__ __launch_bounds__(256) void posterior_sample_kernel(PostArgs a) {
             sm += l[k];
         }
         const float inv = 1.f / sm;
-#pragma unroll
-        for (int k = 0; k < ED; ++k) l[k] *= inv;
-    };
-
-    // ---- phase B: pred_X = softmax(atom logits); SE = sum_j pred_E[i][j][:]; thread per (pass,node)
-    if (tid < 2 * N) {
-        const int p = tid / N, i = tid - p * N;
-        float l[XD];
-        const int xi = sX[i];
-#pragma unroll
-        for (int c = 0; c < XD; ++c) l[c] = (i < nv) ? ((xi == c ? 1.f : 0.f) + lnmod(p, i, c)) : 0.f;
-        if (a.logX) {
-#pragma unroll
-            for (int c = 0; c < XD; ++c) a.logX[(((int64_t)p * B + b) * N + i) * XD + c] = l[c];
-        }
-        float mx = l[0];
-#pragma unroll
-        for (int c = 1; c < XD; ++c) mx = fmaxf(mx, l[c]);
-        float sm = 0.f;
-#pragma unroll
-        for (int c = 0; c < XD; ++c) {
-            l[c] = expf(l[c] - mx);
-            sm += l[c];
-        }
-        const float inv = 1.f / sm;
-        float pxe[ED] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < XD; ++c) {
-            const float pv = l[c] * inv;
-            predX[(p * N + i) * XD + c] = pv;
-#pragma unroll
-            for (int k = 0; k < ED; ++k) pxe[k] = fmaf(pv, c_uxe[c * ED + k], pxe[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < ED; ++k) PXE[(p * N + i) * 8 + k] = pxe[k];
-        float se[ED] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < N; ++j) {
-            float e5[ED];
-            edge_logits(p, i, j, e5);
-            if (a.logE) {
-#pragma unroll
-                for (int k = 0; k < ED; ++k) a.logE[((((int64_t)p * B + b) * N + i) * N + j) * ED + k] = e5[k];
-            }
-            softmax5(e5);
-#pragma unroll
-            for (int k = 0; k < ED; ++k) se[k] += e5[k];
-        }
         float tot = 0.f;
 #pragma unroll
         for (int k = 0; k < ED; ++k) {
-            SE[(p * N + i) * 8 + k] = se[k];
-            tot += se[k];
+            e5[p][k] = l[k] * inv;
+            SE[p][k] = wave_sum(j < N ? e5[p][k] : 0.f);
+            tot += SE[p][k];
         }
-        SE[(p * N + i) * 8 + 5] = tot;
+        SEt[p] = tot;
     }
-    // ---- phase C0: S[i,f] = sum_g X_t[i,g] u[f,g] in its structured form (diffusion_utils.py:296-305)
-    if (tid >= 128 && tid < 128 + N) {
-        const int i = tid - 128;
-        const int xi = sX[i];
-        float cnt[ED] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < N; ++j) {
-            const int e = sE[i * N + j];
+    // ---- S[i,f] = sum_g X_t[i,g] u[f,g] in structured form (diffusion_utils.py:296-305)
+    float cnt[ED];
 #pragma unroll
-            for (int k = 0; k < ED; ++k) cnt[k] += (e == k) ? 1.f : 0.f;
-        }
-        const float xm = (xi >= 0) ? c_xm[xi] : 0.f;
+    for (int k = 0; k < ED; ++k) cnt[k] = (float)__popcll(__ballot(eij == k));
+    float emsum = 0.f;
 #pragma unroll
-        for (int c = 0; c < XD; ++c) {
-            float t = xm;
-#pragma unroll
-            for (int k = 0; k < ED; ++k) t = fmaf(cnt[k], c_uxe[c * ED + k], t);
-            Sx[i * XD + c] = t;
-        }
-        float em = 0.f;
-#pragma unroll
-        for (int k = 0; k < ED; ++k) em = fmaf(cnt[k], c_em[k], em);
-#pragma unroll
-        for (int k = 0; k < ED; ++k) Se[i * 8 + k] = ((xi >= 0) ? c_uex[k * XD + xi] : 0.f) + em;
-    }
-    __syncthreads();
+    for (int k = 0; k < ED; ++k) emsum = fmaf(cnt[k], a.e_marg[k], emsum);
 
-    const float beta = a.betas[s + 1];
-    const float ab_s = a.alphas_bar[s];
-    const float ab_t = a.alphas_bar[s + 1];
-    const bool guided = (a.guide != 1.0f);
-    const unsigned long long seed = a.seed_ptr ? *a.seed_ptr : 0ull;
-
-    // ---- phase C1: node posterior, guidance, sampling (thread per node)
+    // ---- node posterior: lanes 0..15 = atom classes
     int newX = -1;
-    if (tid < N) {
-        const int i = tid;
-        const int xi = sX[i];
-        float pf[XD];
-        if (i < nv) {
-            float pc[2][XD];
-            for (int p = 0; p < (guided ? 2 : 1); ++p) {
-                float spx = 0.f;
+    {
+        const int c = j & 15;
+        float pf = 0.f;
+        if (vi) {
+            float sx = (xi >= 0) ? a.x_marg[xi] : 0.f;
 #pragma unroll
-                for (int c = 0; c < XD; ++c) spx += predX[(p * N + i) * XD + c];
-                float sum = 0.f;
+            for (int k = 0; k < ED; ++k) sx = fmaf(cnt[k], a.u_xe[c * ED + k], sx);
+            const float xt = (xi == c) ? 1.f : 0.f;
+            const float left = (1.f - beta) * xt + beta * sx;
+            const float den = fmaxf(ab_t * xt + (1.f - ab_t) * sx, 1e-5f);
+            float pc[2];
 #pragma unroll
-                for (int c = 0; c < XD; ++c) {
-                    float r = c_xm[c] * spx;
+            for (int p = 0; p < 2; ++p) {
+                const float px = a.predX[((((int64_t)p * B + b) * N + i) * XD) + c];
+                const float spx = row16_sum(px);
+                float r = a.x_marg[c] * spx;
 #pragma unroll
-                    for (int k = 0; k < ED; ++k) r = fmaf(SE[(p * N + i) * 8 + k], c_uex[k * XD + c], r);
-                    const float right = ab_s * predX[(p * N + i) * XD + c] + (1.f - ab_s) * r;
-                    const float xt = (xi == c) ? 1.f : 0.f;
-                    const float left = (1.f - beta) * xt + beta * Sx[i * XD + c];
-                    const float den = fmaxf(ab_t * xt + (1.f - ab_t) * Sx[i * XD + c], 1e-5f);
-                    const float un = left * right / den;
-                    pc[p][c] = un;
-                    sum += un;
-                }
+                for (int k = 0; k < ED; ++k) r = fmaf(SE[p][k], a.u_ex[k * XD + c], r);
+                const float right = ab_s * px + (1.f - ab_s) * r;
+                float un = left * right / den;
+                float sum = row16_sum(un);
                 if (sum == 0.f) {
-#pragma unroll
-                    for (int c = 0; c < XD; ++c) pc[p][c] = 1e-5f;
+                    un = 1e-5f;
                     sum = XD * 1e-5f;
                 }
-#pragma unroll
-                for (int c = 0; c < XD; ++c) pc[p][c] /= sum;
+                pc[p] = un / sum;
             }
             if (guided) {
-                float sum = 0.f;
-#pragma unroll
-                for (int c = 0; c < XD; ++c) {
-                    const float u = pc[1][c];
-                    pf[c] = u * powf(pc[0][c] / fmaxf(u, 1e-5f), a.guide);
-                    sum += pf[c];
-                }
-                sum = fmaxf(sum, 1e-5f);
-#pragma unroll
-                for (int c = 0; c < XD; ++c) pf[c] /= sum;
+                const float u = pc[1];
+                pf = u * powf(pc[0] / fmaxf(u, 1e-5f), a.guide);
+                pf /= fmaxf(row16_sum(pf), 1e-5f);
             } else {
-#pragma unroll
-                for (int c = 0; c < XD; ++c) pf[c] = pc[0][c];
+                pf = pc[0];
             }
-        } else {
-#pragma unroll
-            for (int c = 0; c < XD; ++c) pf[c] = 0.f;
         }
-        if (a.pX_out) {
-#pragma unroll
-            for (int c = 0; c < XD; ++c) a.pX_out[((int64_t)b * N + i) * XD + c] = pf[c];
-        }
-        // sample_discrete_features (diffusion_utils.py:386-395)
-        if (i < nv) {
-            float sum = 0.f;
-#pragma unroll
-            for (int c = 0; c < XD; ++c) {
-                pf[c] = fmaxf(pf[c], 1e-5f);
-                sum += pf[c];
-            }
-            float best = -1.f;
-            int arg = 0;
-            float q[XD];
+        if (a.pX_out && j < 16) a.pX_out[((int64_t)b * N + i) * XD + c] = pf;
+        if (vi) {   // sample_discrete_features (diffusion_utils.py:386-395): clamp, renormalise, race
+            const float pcl = fmaxf(pf, 1e-5f);
+            const float sum = row16_sum(pcl);
+            float q;
             if (a.qx) {
-#pragma unroll
-                for (int c = 0; c < XD; ++c) q[c] = a.qx[((int64_t)b * N + i) * XD + c];
+                q = a.qx[((int64_t)b * N + i) * XD + c];
             } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint4 r = philox4x32(make_uint4((uint32_t)(b * N + i), (uint32_t)s, (uint32_t)g, 0x58u),
-                                               make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
-                    q[g * 4 + 0] = exp1_from_bits(r.x);
-                    q[g * 4 + 1] = exp1_from_bits(r.y);
-                    q[g * 4 + 2] = exp1_from_bits(r.z);
-                    q[g * 4 + 3] = exp1_from_bits(r.w);
-                }
+                const uint4 r = philox4x32(make_uint4((uint32_t)(b * N + i), (uint32_t)s, (uint32_t)(c >> 2), 0x58u), key);
+                const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+                q = exp1_from_bits(rr[c & 3]);
             }
-#pragma unroll
-            for (int c = 0; c < XD; ++c) {
-                const float v = (pf[c] / sum) / q[c];
-                if (v > best) {
-                    best = v;
-                    arg = c;
-                }
-            }
-            newX = arg;
+            const float v = (pcl / sum) / q;
+            const float best = row16_max(v);
+            const unsigned long long m = __ballot(v == best && j < 16);
+            newX = __ffsll((long long)m) - 1;      // first maximum wins, like argmax
         }
     }
-
-    // ---- phase C2: bond posterior, guidance, sampling for pairs i<j (strict upper triangle is what
-    //      the reference keeps: diffusion_utils.py:409-411)
-    if (a.pE_out) {
-        for (int idx = tid; idx < N * N * ED; idx += 256) a.pE_out[(int64_t)b * N * N * ED + idx] = 0.f;
-    }
-    __syncthreads();  // all reads of sE for logits done before anybody overwrites global state; pE_out zeroed
-    const int npairs = N * (N - 1) / 2;
-    for (int pi = tid; pi < npairs; pi += 256) {
-        // unrank pair index -> (i,j), i<j
-        int i = 0, rem = pi;
-        while (rem >= N - 1 - i) {
-            rem -= N - 1 - i;
-            ++i;
-        }
-        const int j = i + 1 + rem;
-        int val = -1;
-        if (i < nv && j < nv) {
-            const int eij = sE[i * N + j];
-            float pc[2][ED];
-            for (int p = 0; p < (guided ? 2 : 1); ++p) {
-                float e5[ED];
-                edge_logits(p, i, j, e5);
-                softmax5(e5);
-                float sum = 0.f;
-#pragma unroll
-                for (int k = 0; k < ED; ++k) {
-                    const float r = PXE[(p * N + i) * 8 + k] + c_em[k] * SE[(p * N + i) * 8 + 5];
-                    const float right = ab_s * e5[k] + (1.f - ab_s) * r;
-                    const float et = (eij == k) ? 1.f : 0.f;
-                    const float left = (1.f - beta) * et + beta * Se[i * 8 + k];
-                    const float den = fmaxf(ab_t * et + (1.f - ab_t) * Se[i * 8 + k], 1e-5f);
-                    const float un = left * right / den;
-                    pc[p][k] = un;
-                    sum += un;
-                }
-                if (sum == 0.f) {
-#pragma unroll
-                    for (int k = 0; k < ED; ++k) pc[p][k] = 1e-5f;
-                    sum = ED * 1e-5f;
-                }
-#pragma unroll
-                for (int k = 0; k < ED; ++k) pc[p][k] /= sum;
-            }
-            float pf[ED];
-            if (guided) {
-                float sum = 0.f;
-#pragma unroll
-                for (int k = 0; k < ED; ++k) {
-                    const float u = pc[1][k];
-                    pf[k] = u * powf(pc[0][k] / fmaxf(u, 1e-5f), a.guide);
-                    sum += pf[k];
-                }
-                sum = fmaxf(sum, 1e-5f);
-#pragma unroll
-                for (int k = 0; k < ED; ++k) pf[k] /= sum;
-            } else {
-#pragma unroll
-                for (int k = 0; k < ED; ++k) pf[k] = pc[0][k];
-            }
-            if (a.pE_out) {
-#pragma unroll
-                for (int k = 0; k < ED; ++k) a.pE_out[(((int64_t)b * N + i) * N + j) * ED + k] = pf[k];
-            }
+    // ---- bond posterior of the pairs (i, j > i)   (strict upper triangle: diffusion_utils.py:409-411)
+    int val = -1;
+    if (j > i && j < N && vi && vj) {
+        float se = ((xi >= 0) ? 0.f : 0.f);
+        float pc[2][ED];
+        for (int p = 0; p < (guided ? 2 : 1); ++p) {
+            const float *px = a.pxe + ((((int64_t)p * B + b) * N + i) * 8);
             float sum = 0.f;
 #pragma unroll
             for (int k = 0; k < ED; ++k) {
-                pf[k] = fmaxf(pf[k], 1e-5f);
+                const float sek = ((xi >= 0) ? a.u_ex[k * XD + xi] : 0.f) + emsum;
+                const float r = px[k] + a.e_marg[k] * SEt[p];
+                const float right = ab_s * e5[p][k] + (1.f - ab_s) * r;
+                const float et = (eij == k) ? 1.f : 0.f;
+                const float left = (1.f - beta) * et + beta * sek;
+                const float den = fmaxf(ab_t * et + (1.f - ab_t) * sek, 1e-5f);
+                const float un = left * right / den;
+                pc[p][k] = un;
+                sum += un;
+            }
+            if (sum == 0.f) {
+#pragma unroll
+                for (int k = 0; k < ED; ++k) pc[p][k] = 1e-5f;
+                sum = ED * 1e-5f;
+            }
+#pragma unroll
+            for (int k = 0; k < ED; ++k) pc[p][k] /= sum;
+        }
+        (void)se;
+        float pf[ED];
+        if (guided) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < ED; ++k) {
+                const float u = pc[1][k];
+                pf[k] = u * powf(pc[0][k] / fmaxf(u, 1e-5f), a.guide);
                 sum += pf[k];
             }
-            float q[8];
-            if (a.qe) {
+            sum = fmaxf(sum, 1e-5f);
 #pragma unroll
-                for (int k = 0; k < ED; ++k) q[k] = a.qe[(((int64_t)b * N + i) * N + j) * ED + k];
-            } else {
+            for (int k = 0; k < ED; ++k) pf[k] /= sum;
+        } else {
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const uint4 r = philox4x32(make_uint4((uint32_t)((b * N + i) * N + j), (uint32_t)s, (uint32_t)g, 0x45u),
-                                               make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
-                    q[g * 4 + 0] = exp1_from_bits(r.x);
-                    q[g * 4 + 1] = exp1_from_bits(r.y);
-                    q[g * 4 + 2] = exp1_from_bits(r.z);
-                    q[g * 4 + 3] = exp1_from_bits(r.w);
-                }
-            }
-            float best = -1.f;
-            int arg = 0;
-#pragma unroll
-            for (int k = 0; k < ED; ++k) {
-                const float v = (pf[k] / sum) / q[k];
-                if (v > best) {
-                    best = v;
-                    arg = k;
-                }
-            }
-            val = arg;
+            for (int k = 0; k < ED; ++k) pf[k] = pc[0][k];
         }
-        if (a.update_state) {
-            a.E[((int64_t)b * N + i) * N + j] = (int8_t)val;
-            a.E[((int64_t)b * N + j) * N + i] = (int8_t)val;
+        if (a.pE_out) {
+#pragma unroll
+            for (int k = 0; k < ED; ++k) a.pE_out[(((int64_t)b * N + i) * N + j) * ED + k] = pf[k];
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < ED; ++k) {
+            pf[k] = fmaxf(pf[k], 1e-5f);
+            sum += pf[k];
+        }
+        float q[8];
+        if (a.qe) {
+#pragma unroll
+            for (int k = 0; k < ED; ++k) q[k] = a.qe[(((int64_t)b * N + i) * N + j) * ED + k];
+        } else {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const uint4 r = philox4x32(make_uint4((uint32_t)((b * N + i) * N + j), (uint32_t)s, (uint32_t)g, 0x45u), key);
+                q[g * 4 + 0] = exp1_from_bits(r.x);
+                q[g * 4 + 1] = exp1_from_bits(r.y);
+                q[g * 4 + 2] = exp1_from_bits(r.z);
+                q[g * 4 + 3] = exp1_from_bits(r.w);
+            }
+        }
+        float best = -1.f;
+        int arg = 0;
+#pragma unroll
+        for (int k = 0; k < ED; ++k) {
+            const float v = (pf[k] / sum) / q[k];
+            if (v > best) {
+                best = v;
+                arg = k;
+            }
+        }
+        val = arg;
+    }
+    if (a.update_state) {
+        int8_t *Xout = a.X + ((int64_t)st_out * B + b) * N;
+        int8_t *Eout = a.E + ((int64_t)st_out * B + b) * N * N;
+        if (j > i && j < N) {
+            Eout[i * N + j] = (int8_t)val;
+            Eout[j * N + i] = (int8_t)val;
+        }
+        if (j == i) {
+            Eout[i * N + i] = vi ? (int8_t)0 : (int8_t)-1;
+            Xout[i] = (int8_t)newX;
         }
     }
-    if (a.update_state && tid < N) {
-        a.X[(int64_t)b * N + tid] = (int8_t)newX;
-        a.E[((int64_t)b * N + tid) * N + tid] = (tid < nv) ? (int8_t)0 : (int8_t)-1;
-    }
-}
-
-static inline size_t posterior_lds_bytes(int N, int F) {
-    size_t fl = 4 * (size_t)F + 4 * N + 2 * N * XD + 2 * N * 8 + 2 * N * 8 + N * XD + N * 8 + (16 + 8 + 80 + 80);
-    return fl * 4 + (size_t)N * 4 + (size_t)N * N + 16;
 }
 
 // ------------------------------------------------------------------------------------------ z_T

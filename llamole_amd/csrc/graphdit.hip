@@ -147,6 +147,9 @@ struct DitEngine {
     DevBuf n_nodes, X, E, x32, xa, qkv, attn_o, ybuf, h1, ho, outF;
     DevBuf ct_in, ct_h, ct, zy, cy, txt_op, ctxt, ynan, tnan, c32, ca, m1, modtab, modo;
     DevBuf scal;  // [0] int step, [8] u64 seed
+    DevBuf predX, pxe;
+    int state_half = 0;      // which half of X/E holds the current state
+    bool state_both = false; // both halves identical (after set_state)
     // graph
     hipStream_t own = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
@@ -190,7 +193,7 @@ static void drop_graph(DitEngine *e) {
 template <typename T> static void launch_embed(DitEngine *e, hipStream_t st) {
     hipLaunchKernelGGL((embed_kernel<T>), dim3(e->B * e->cfg.max_nodes), dim3(256), 0, st, e->X.as<int8_t>(),
                        e->E.as<int8_t>(), e->wxT.as<float>(), e->pf("x_embedder.1.weight"), e->pf("x_embedder.1.bias"),
-                       e->x32.as<float>(), e->xa.as<T>(), e->B, e->cfg.max_nodes, e->cfg.hidden);
+                       e->x32.as<float>(), e->xa.as<T>(), e->step_ptr(), e->B, e->cfg.max_nodes, e->cfg.hidden);
 }
 template <int NP, int HD>
 static void launch_attn_mfma_t(DitEngine *e, const std::string &p, hipStream_t st) {
@@ -292,6 +295,8 @@ static int posterior_launch(DitEngine *e, const float *qx, const float *qe, int 
     PostArgs a;
     a.out = e->outF.as<float>();
     a.modo = e->modo.as<float>();
+    a.predX = e->predX.as<float>();
+    a.pxe = e->pxe.as<float>();
     a.X = e->X.as<int8_t>();
     a.E = e->E.as<int8_t>();
     a.n_nodes = e->n_nodes.as<int>();
@@ -304,8 +309,21 @@ static int posterior_launch(DitEngine *e, const float *qx, const float *qe, int 
     a.guide = e->cfg.guide_scale;
     a.pX_out = pX; a.pE_out = pE; a.logX = logX; a.logE = logE;
     a.update_state = update;
-    hipLaunchKernelGGL(posterior_sample_kernel, dim3(e->B), dim3(256), posterior_lds_bytes(a.N, a.F), st, a);
+    if (pX) LL_HIP(hipMemsetAsync(pX, 0, (size_t)a.B * a.N * XD * 4, st));
+    if (pE) LL_HIP(hipMemsetAsync(pE, 0, (size_t)a.B * a.N * a.N * ED * 4, st));
+    hipLaunchKernelGGL(post_rows_kernel, dim3(cdiv(2 * a.B * a.N, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(post_pairs_kernel, dim3(a.N, a.B), dim3(64), 0, st, a);
     LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+// make half `want` of the double-buffered state hold the current state (copy from the live half if needed)
+static int ensure_state_half(DitEngine *e, int want, hipStream_t st) {
+    if (e->state_both || e->state_half == want) return LL_OK;
+    const size_t nx = (size_t)e->B * e->cfg.max_nodes, ne = nx * e->cfg.max_nodes;
+    LL_HIP(hipMemcpyAsync(e->X.as<int8_t>() + want * nx, e->X.as<int8_t>() + e->state_half * nx, nx, hipMemcpyDeviceToDevice, st));
+    LL_HIP(hipMemcpyAsync(e->E.as<int8_t>() + want * ne, e->E.as<int8_t>() + e->state_half * ne, ne, hipMemcpyDeviceToDevice, st));
+    e->state_both = true;
     return LL_OK;
 }
 
@@ -437,7 +455,7 @@ int ll_dit_destroy(void *handle) {
     DevBuf *bufs[] = {&e->wop, &e->wxT, &e->wycat, &e->yw0, &e->yb0, &e->tables, &e->n_nodes, &e->X, &e->E, &e->x32,
                       &e->xa, &e->qkv, &e->attn_o, &e->ybuf, &e->h1, &e->ho, &e->outF, &e->ct_in, &e->ct_h, &e->ct,
                       &e->zy, &e->cy, &e->txt_op, &e->ctxt, &e->ynan, &e->tnan, &e->c32, &e->ca, &e->m1, &e->modtab,
-                      &e->modo, &e->scal};
+                      &e->modo, &e->scal, &e->predX, &e->pxe};
     for (DevBuf *b : bufs) b->release();
     if (e->own) (void)hipStreamDestroy(e->own);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -468,8 +486,10 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
     const size_t M2p = e->M2p;
     void *oldp[] = {e->x32.p, e->xa.p, e->qkv.p, e->attn_o.p, e->ybuf.p, e->h1.p, e->ho.p, e->outF.p, e->modtab.p, e->modo.p, e->X.p, e->E.p, e->n_nodes.p};
     LL_TRY(e->n_nodes.ensure((size_t)B * 4));
-    LL_TRY(e->X.ensure((size_t)B * N));
-    LL_TRY(e->E.ensure((size_t)B * N * N));
+    LL_TRY(e->X.ensure((size_t)2 * B * N));
+    LL_TRY(e->E.ensure((size_t)2 * B * N * N));
+    LL_TRY(e->predX.ensure((size_t)2 * B * N * XD * 4));
+    LL_TRY(e->pxe.ensure((size_t)2 * B * N * 8 * 4));
     LL_TRY(e->x32.ensure(M2p * H * 4));
     LL_TRY(e->xa.ensure(M2p * H * es));
     LL_TRY(e->qkv.ensure(M2p * 3 * H * es));
@@ -536,8 +556,14 @@ int ll_dit_init_state(void *handle, const float *qx, const float *qe, uint64_t s
     LL_CHECK((qx == nullptr) == (qe == nullptr), "qx and qe must both be given or both be null");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), e->cfg.T - 1, e->seed_ptr(), (unsigned long long)seed);
-    hipLaunchKernelGGL(init_state_kernel, dim3(e->B), dim3(256), 0, st, e->X.as<int8_t>(), e->E.as<int8_t>(), e->n_nodes.as<int>(),
-                       e->t_xm(), e->t_em(), qx, qe, e->seed_ptr(), e->B, e->cfg.max_nodes, e->cfg.T);
+    {
+        const int half = e->cfg.T & 1;
+        const size_t nx = (size_t)e->B * e->cfg.max_nodes, ne = nx * e->cfg.max_nodes;
+        hipLaunchKernelGGL(init_state_kernel, dim3(e->B), dim3(256), 0, st, e->X.as<int8_t>() + half * nx, e->E.as<int8_t>() + half * ne,
+                           e->n_nodes.as<int>(), e->t_xm(), e->t_em(), qx, qe, e->seed_ptr(), e->B, e->cfg.max_nodes, e->cfg.T);
+        e->state_half = half;
+        e->state_both = false;
+    }
     LL_LAUNCH_CHECK();
     e->state_set = true;
     return LL_OK;
@@ -548,8 +574,12 @@ int ll_dit_set_state(void *handle, const int8_t *X, const int8_t *E, void *strea
     LL_TRY(check_ready(e, false));
     LL_CHECK(X && E, "null state");
     const int N = e->cfg.max_nodes;
-    LL_HIP(hipMemcpyAsync(e->X.p, X, (size_t)e->B * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    LL_HIP(hipMemcpyAsync(e->E.p, E, (size_t)e->B * N * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    for (int h = 0; h < 2; ++h) {
+        LL_HIP(hipMemcpyAsync(e->X.as<int8_t>() + (size_t)h * e->B * N, X, (size_t)e->B * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        LL_HIP(hipMemcpyAsync(e->E.as<int8_t>() + (size_t)h * e->B * N * N, E, (size_t)e->B * N * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    e->state_half = 0;
+    e->state_both = true;
     e->state_set = true;
     return LL_OK;
 }
@@ -558,8 +588,9 @@ int ll_dit_get_state(void *handle, int8_t *X, int8_t *E, void *stream) {
     DitEngine *e = (DitEngine *)handle;
     LL_TRY(check_ready(e, true));
     const int N = e->cfg.max_nodes;
-    if (X) LL_HIP(hipMemcpyAsync(X, e->X.p, (size_t)e->B * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    if (E) LL_HIP(hipMemcpyAsync(E, e->E.p, (size_t)e->B * N * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    const size_t hx = (size_t)e->state_half * e->B * N, he = hx * N;
+    if (X) LL_HIP(hipMemcpyAsync(X, e->X.as<int8_t>() + hx, (size_t)e->B * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (E) LL_HIP(hipMemcpyAsync(E, e->E.as<int8_t>() + he, (size_t)e->B * N * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return LL_OK;
 }
 
@@ -569,10 +600,14 @@ int ll_dit_step(void *handle, int s, const float *qx, const float *qe, uint64_t 
     LL_CHECK(s >= 0 && s < e->cfg.T, "step %d out of range [0,%d)", s, e->cfg.T);
     LL_CHECK((qx == nullptr) == (qe == nullptr), "qx and qe must both be given or both be null");
     hipStream_t st = (hipStream_t)stream;
+    LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), s, e->seed_ptr(), (unsigned long long)seed);
     LL_LAUNCH_CHECK();
     LL_TRY(denoise_body(e, st, nullptr, -1));
-    return posterior_launch(e, qx, qe, 1, nullptr, nullptr, nullptr, nullptr, st);
+    LL_TRY(posterior_launch(e, qx, qe, 1, nullptr, nullptr, nullptr, nullptr, st));
+    e->state_half = s & 1;
+    e->state_both = false;
+    return LL_OK;
 }
 
 int ll_dit_denoise(void *handle, int s, float *logX, float *logE, float *hidden, int tap_layer, void *stream) {
@@ -580,6 +615,7 @@ int ll_dit_denoise(void *handle, int s, float *logX, float *logE, float *hidden,
     LL_TRY(check_ready(e, true));
     LL_CHECK(s >= 0 && s < e->cfg.T, "step %d out of range", s);
     hipStream_t st = (hipStream_t)stream;
+    LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), s, e->seed_ptr(), 0ull);
     LL_TRY(denoise_body(e, st, hidden, tap_layer));
     return posterior_launch(e, nullptr, nullptr, 0, nullptr, nullptr, logX, logE, st);
@@ -590,6 +626,7 @@ int ll_dit_step_probs(void *handle, int s, float *pX, float *pE, void *stream) {
     LL_TRY(check_ready(e, true));
     LL_CHECK(s >= 0 && s < e->cfg.T, "step %d out of range", s);
     hipStream_t st = (hipStream_t)stream;
+    LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), s, e->seed_ptr(), 0ull);
     LL_TRY(denoise_body(e, st, nullptr, -1));
     return posterior_launch(e, nullptr, nullptr, 0, pX, pE, nullptr, nullptr, st);
@@ -612,6 +649,7 @@ int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream) {
     const int T = e->cfg.T;
     LL_HIP(hipEventRecord(e->ev_in, caller));
     LL_HIP(hipStreamWaitEvent(st, e->ev_in, 0));
+    LL_TRY(ensure_state_half(e, T & 1, st));
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), T - 1, e->seed_ptr(), (unsigned long long)seed);
     LL_LAUNCH_CHECK();
     if (use_graph) {
@@ -641,6 +679,8 @@ int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream) {
     }
     e->last_steps = T;
     e->timed = true;
+    e->state_half = 0;      // z_0 lands in half 0
+    e->state_both = false;
     LL_HIP(hipEventRecord(e->ev_out, st));
     LL_HIP(hipStreamWaitEvent(caller, e->ev_out, 0));
     return LL_OK;
