@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const T *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------ attention (MFMA, bf16)
-// One 64-lane wave per (sequence, head); 4 heads per workgroup.  The whole graph (N <= 64 nodes) is one tile:
+// One 64-lane wave (= one workgroup) per (sequence, head).  The whole graph (N <= 64 nodes) is one tile:
 //   q,k rows -> f32 LayerNorm(hd) in registers -> bf16 in LDS;  V stored transposed in LDS;
 //   S = Q K^T on v_mfma_f32_16x16x32_bf16, mask + softmax in the MFMA C layout (row reductions are
 //   4-step xor-shuffles inside 16-lane groups), P -> bf16 via LDS, O = P V on MFMA.   (layers.py:56-87)
@@ -203,7 +203,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
 typedef __attribute__((ext_vector_type(4))) float af32x4;
 
 template <int NP, int HD>
-__global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ o,
+__global__ __launch_bounds__(64) void attn_mfma_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ o,
                                                          const float *__restrict__ qw, const float *__restrict__ qb,
                                                          const float *__restrict__ kw, const float *__restrict__ kb,
                                                          const int *__restrict__ n_nodes, int B, int N, int H,
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t *__restrict
     constexpr int R0 = QK_ELEMS > P_ELEMS ? QK_ELEMS : P_ELEMS;   // region 0: Q, later P
     constexpr int WAVE_ELEMS = R0 + QK_ELEMS + HD * PLD;          // + K + V^T
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw_attn[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int head = blockIdx.x * 4 + wave;
+    const int wave = 0, lane = threadIdx.x & 63;   // one wave per workgroup (spreads the tiny tiles over more CUs)
+    const int head = blockIdx.x;
     if (head >= heads) return;
     const int seq = blockIdx.y;
     const int nv = n_nodes[seq % B];
@@ -395,7 +395,7 @@ template <int NP, int HD> static constexpr size_t attn_mfma_lds_bytes() {
     constexpr int QLD = HD + 8, PLD = NP + 8;
     constexpr int QK = NP * QLD, P = NP * PLD;
     constexpr int R0 = QK > P ? QK : P;
-    return (size_t)4 * (R0 + QK + HD * PLD) * 2;
+    return (size_t)(R0 + QK + HD * PLD) * 2;
 }
 
 // ------------------------------------------------------------------------------------------ AdaLN epilogue
@@ -403,12 +403,14 @@ template <int NP, int HD> static constexpr size_t attn_mfma_lds_bytes() {
 // y = sum of `nslab` split-K partial slabs (+ bias), summed in slab order (deterministic).
 // One wave per token row; modulation rows come from the hoisted table mod[T][B+1][L][6H].
 template <typename T, int NS, int MAXE>
-__global__ __launch_bounds__(256) void ln_mod_res_kernel(const float *__restrict__ y, int64_t slab_stride,
+__global__ __launch_bounds__(64) void ln_mod_res_kernel(const float *__restrict__ y, int64_t slab_stride,
                                                           const float *__restrict__ bias, float *__restrict__ x32,
                                                           T *__restrict__ xa, const float *__restrict__ modtab,
                                                           const int *__restrict__ step_ptr, int layer, int sel, int B,
                                                           int N, int H, int L, int M2) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // one 64-lane wave = one token row = one workgroup: rows spread over as many CUs as possible, because the
+    // per-CU load path (~25-40 GB/s), not HBM, bounds these small row kernels
+    const int row = blockIdx.x;
     if (row >= M2) return;
     const int lane = threadIdx.x & 63;
     const int s = *step_ptr;

@@ -297,6 +297,127 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipe_kernel(const bf16_
     }
 }
 
+// ------------------------------------------------------------------------------------------ bf16 MFMA, skinny M
+// M <= 64 rows per workgroup (the sampler at B = 1: M2 = 2*N tokens).  A k-loop of 16-64 tiles serialised behind
+// barriers is latency-bound here, so the K dimension is split across the NW waves of the workgroup instead:
+// each wave streams its own k-tiles of A and W straight from global memory into MFMA fragments (no LDS, no
+// barrier, next tile prefetched in registers), and the NW partial 64 x BN accumulators are reduced once through
+// LDS in a fixed order (deterministic), followed by the fused bias / activation epilogue.
+template <int BN, int NW, typename OutT>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t *__restrict__ A, int lda,
+                                                               const bf16_t *__restrict__ W, int ldw,
+                                                               OutT *__restrict__ C, int ldc,
+                                                               const float *__restrict__ bias, int M, int N, int K,
+                                                               int epi) {
+    constexpr int MT = 4, NTL = BN / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sk[];
+    float *red = reinterpret_cast<float *>(smem_sk);  // [NW][64][BN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
+    const int nk = K / 64;
+    const int frow = lane & 15, fk = lane >> 4;
+
+    const bf16_t *pa[MT];
+    const bf16_t *pb[NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) pa[i] = A + (int64_t)(m0 + i * 16 + frow) * lda + fk * 8;
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+        int gr = n0 + j * 16 + frow;
+        gr = gr < N ? gr : N - 1;
+        pb[j] = W + (int64_t)gr * ldw + fk * 8;
+    }
+    f32x4 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[2][2][MT], rb[2][2][NTL];   // [buffer][kk][tile]
+    auto load = [&](int buf, int kt) {
+        const int k0 = kt * 64;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) ra[buf][kk][i] = *reinterpret_cast<const uint4 *>(pa[i] + k0 + kk * 32);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) rb[buf][kk][j] = *reinterpret_cast<const uint4 *>(pb[j] + k0 + kk * 32);
+        }
+    };
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ra[buf][kk][i]),
+                                                                        __builtin_bit_cast(bf16x8, rb[buf][kk][j]), acc[i][j], 0, 0, 0);
+    };
+    // this wave's k-tiles: wave, wave + NW, ...   (two-deep register pipeline, statically indexed)
+    int kt = wave;
+    if (kt < nk) load(0, kt);
+    while (kt < nk) {
+        if (kt + NW < nk) load(1, kt + NW);
+        compute(0);
+        kt += NW;
+        if (kt >= nk) break;
+        if (kt + NW < nk) load(0, kt + NW);
+        compute(1);
+        kt += NW;
+    }
+    // cross-wave reduction through LDS
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[(wave * 64 + i * 16 + fk * 4 + r) * BN + j * 16 + frow] = acc[i][j][r];
+    __syncthreads();
+    constexpr int OUT4 = 64 * BN / 4;   // float4 outputs per workgroup
+    for (int o = tid; o < OUT4; o += NW * 64) {
+        const int row = o / (BN / 4), c4 = (o - row * (BN / 4)) * 4;
+        float4 sum = *reinterpret_cast<const float4 *>(red + row * BN + c4);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const float4 t = *reinterpret_cast<const float4 *>(red + (w * 64 + row) * BN + c4);
+            sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+        }
+        const int grow = m0 + row, gcol = n0 + c4;
+        if (grow >= M) continue;
+        float vv[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (gcol + q < N) {
+                float v = vv[q] + (bias ? bias[gcol + q] : 0.f);
+                v = apply_epi(v, epi);
+                C[(int64_t)grow * ldc + gcol + q] = from_f32<OutT>(v);
+            }
+        }
+    }
+}
+
+template <int BN, int NW>
+static int launch_skinny(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M,
+                         int N, int K, int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
+    (void)splits;
+    (void)slab_stride;
+    constexpr size_t lds = (size_t)NW * 64 * BN * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_skinny_kernel<BN, NW, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_skinny_kernel<BN, NW, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(N, BN), cdiv(M, 64), 1);
+    if (out_f32)
+        hipLaunchKernelGGL((gemm_skinny_kernel<BN, NW, float>), grid, dim3(NW * 64), lds, s, A, lda, W, ldw, (float *)C, ldc, bias, M, N, K, epi);
+    else
+        hipLaunchKernelGGL((gemm_skinny_kernel<BN, NW, bf16_t>), grid, dim3(NW * 64), lds, s, A, lda, W, ldw, (bf16_t *)C, ldc, bias, M, N, K, epi);
+    return LL_OK;
+}
+
 // ------------------------------------------------------------------------------------------ f32 VALU
 // 64x64 tile, BK=16, 256 threads, 4x4 outputs per thread; k-ordered fmaf chain per output.
 template <typename OutT>
@@ -409,10 +530,11 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
             // pipelined kernels: prefer the largest tile that still gives >= ~1 workgroup per CU
             const long w12864 = (long)cdiv(M, 128) * cdiv(N, 64) * splits;
             const long w6464 = (long)cdiv(M, 64) * cdiv(N, 64) * splits;
-            if (w12864 >= 512)
-                LL_TRY((launch_pipe<128, 64, 2, 2, 4>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
+            // 8-wave workgroups: more waves issuing LDS-DMA per CU lifts the per-CU ingest rate (~26 -> ~43 GB/s)
+            if (w12864 >= 1024)
+                LL_TRY((launch_pipe<128, 64, 4, 2, 4>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
             else if (w6464 >= 200 || (N % 32 != 0 && N < 64))
-                LL_TRY((launch_pipe<64, 64, 2, 2, 4>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
+                LL_TRY((launch_pipe<64, 64, 4, 2, 4>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
             else
                 LL_TRY((launch_pipe<64, 32, 4, 1, 4>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
             LL_LAUNCH_CHECK();
@@ -492,6 +614,17 @@ static const PipeCfg g_pipe_cfgs[] = {
     {256, 64, 3, launch_pipe<256, 64, 4, 1, 3>},   // 9
     {64, 64, 2, launch_pipe<64, 64, 2, 2, 2>},     // 10
     {64, 128, 6, launch_pipe<64, 128, 2, 2, 6>},   // 11
+    {64, 32, 108, launch_skinny<32, 8>},           // 12  skinny: 8 waves split K
+    {64, 16, 108, launch_skinny<16, 8>},           // 13
+    {64, 32, 104, launch_skinny<32, 4>},           // 14
+    {64, 16, 116, launch_skinny<16, 16>},          // 15
+    {64, 64, 108, launch_skinny<64, 8>},           // 16
+    {128, 64, 4, launch_pipe<128, 64, 4, 2, 4>},   // 17  8-wave workgroups
+    {128, 128, 3, launch_pipe<128, 128, 4, 2, 3>}, // 18
+    {128, 128, 4, launch_pipe<128, 128, 4, 2, 4>}, // 19
+    {64, 64, 4, launch_pipe<64, 64, 4, 2, 4>},     // 20
+    {256, 64, 3, launch_pipe<256, 64, 4, 2, 3>},   // 21
+    {128, 64, 6, launch_pipe<128, 64, 4, 2, 6>},   // 22
 };
 }  // namespace ll
 

@@ -198,7 +198,7 @@ template <typename T> static void launch_embed(DitEngine *e, hipStream_t st) {
 template <int NP, int HD>
 static void launch_attn_mfma_t(DitEngine *e, const std::string &p, hipStream_t st) {
     const size_t lds = attn_mfma_lds_bytes<NP, HD>();
-    hipLaunchKernelGGL((attn_mfma_kernel<NP, HD>), dim3(cdiv(e->cfg.heads, 4), 2 * e->B), dim3(256), lds, st, e->qkv.as<bf16_t>(), e->attn_o.as<bf16_t>(),
+    hipLaunchKernelGGL((attn_mfma_kernel<NP, HD>), dim3(e->cfg.heads, 2 * e->B), dim3(64), lds, st, e->qkv.as<bf16_t>(), e->attn_o.as<bf16_t>(),
                        e->pfs(p + "q_norm.weight"), e->pfs(p + "q_norm.bias"), e->pfs(p + "k_norm.weight"),
                        e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, e->cfg.max_nodes, e->cfg.hidden,
                        e->cfg.heads);
@@ -222,7 +222,7 @@ template <typename T> static void launch_attn(DitEngine *e, int layer, hipStream
 }
 template <typename T>
 static void launch_lnmod(DitEngine *e, int layer, int sel, int nslab, const float *bias, hipStream_t st) {
-    const dim3 grid(cdiv(e->M2, 4)), blk(256);
+    const dim3 grid(e->M2), blk(64);
     const int64_t ss = (int64_t)e->M2p * e->cfg.hidden;
 #define LL_LNMOD2(NS, ME)                                                                                              \
     hipLaunchKernelGGL((ln_mod_res_kernel<T, NS, ME>), grid, blk, 0, st, e->ybuf.as<float>(), ss, bias,                 \
@@ -248,7 +248,8 @@ static void launch_lnmod(DitEngine *e, int layer, int sel, int nslab, const floa
 static int pick_splits(int M2, int H, int K) {
     const long tiles = (long)cdiv(M2, 64) * cdiv(H, 64);
     int s = 1;
-    while (s < 8 && tiles * s < 256 && (K / (s * 2)) % 64 == 0 && K / (s * 2) >= 128) s *= 2;
+    // each split costs the consumer one more f32 slab to read back: cap at 4
+    while (s < 4 && tiles * s < 256 && (K / (s * 2)) % 64 == 0 && K / (s * 2) >= 128) s *= 2;
     return s;
 }
 

@@ -7,7 +7,7 @@ from llamole_amd import _lib
 
 lib = _lib.load()
 CFG = ["128x64s4", "64x64s4", "64x32s4", "64x32s8", "64x64s8", "128x64s6", "128x128s3", "128x128s4", "64x128s4",
-       "256x64s3", "64x64s2", "64x128s6"]
+       "256x64s3", "64x64s2", "64x128s6", "sk32w8", "sk16w8", "sk32w4", "sk16w16", "sk64w8"]
 shapes = {"qkv": (3072, 1024), "proj": (1024, 1024), "fc1": (4096, 1024), "fc2": (1024, 4096)}
 for M in [int(a) for a in sys.argv[1:]] or [64, 512]:
     for name, (N, K) in shapes.items():
@@ -15,6 +15,8 @@ for M in [int(a) for a in sys.argv[1:]] or [64, 512]:
         for cfg in range(-1, len(CFG)):
             for sp in (1, 2, 4, 8):
                 if K % (64 * sp) or (K // sp) < 128:
+                    continue
+                if cfg >= 12 and sp > 1:
                     continue
                 ms = C.c_float()
                 nw = max(2, int(400e6 // (N * K * 2)))
