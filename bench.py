@@ -306,6 +306,15 @@ def main():
         roof = {"bound": "mfma", "achieved": kflops / (kms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["traffic"] = None
+    try:   # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same shape)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        key = "fc1_m%d" % (2 * B * N)
+        if key in pmc and args.hidden == 1024 and args.dtype == "bf16":
+            roof["traffic"] = pmc[key]["hbm_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
+    except Exception:
+        pass
+    roof["algorithmic_bytes"] = kbytes
     roof["kernel"] = kname
     roof["kernel_ms"] = kms
     out = {
