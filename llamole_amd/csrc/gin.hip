@@ -104,86 +104,159 @@ __global__ __launch_bounds__(256) void gin_embed_kernel(const int *__restrict__ 
 //   h_in[v] = h[v] + vn[batch[v]]
 //   z0[v]   = (1+eps) h_in[v] + sum_{e: dst(e)=v} GELU(h_in[src(e)] + bond_emb[attr(e)])
 // (graph_encoder/model.py:133-134,167-173).  Edges of a graph never cross graphs, so vn[batch[src]] == vn[batch[v]].
+template <typename T> __device__ __forceinline__ void gin_store4(T *p, float4 o);
+template <> __device__ __forceinline__ void gin_store4<float>(float *p, float4 o) { *reinterpret_cast<float4 *>(p) = o; }
+template <> __device__ __forceinline__ void gin_store4<bf16_t>(bf16_t *p, float4 o) {
+    uint2 u;
+    u.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
+    u.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
+    *reinterpret_cast<uint2 *>(p) = u;
+}
+__device__ __forceinline__ float4 gelu4(float4 v) { return make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)); }
+
 template <typename T>
-__global__ __launch_bounds__(256) void gin_aggregate_kernel(const float *__restrict__ h, const float *__restrict__ vn,
-                                                             const int *__restrict__ batch,
-                                                             const int *__restrict__ rowptr, const int *__restrict__ src,
-                                                             const int *__restrict__ attr, const float *__restrict__ bond,
-                                                             const float *__restrict__ eps, float *__restrict__ h_in,
-                                                             T *__restrict__ z0, int n, int H) {
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(64) void gin_aggregate_kernel(const float *__restrict__ h, const float *__restrict__ vn,
+                                                            const int *__restrict__ batch,
+                                                            const int *__restrict__ rowptr, const int *__restrict__ src,
+                                                            const int *__restrict__ attr, const float *__restrict__ bond,
+                                                            const float *__restrict__ eps, float *__restrict__ h_in,
+                                                            T *__restrict__ z0, int n, int H) {
+    const int v = blockIdx.x;   // one wave = one destination node = one workgroup
     if (v >= n) return;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     const float *vr = vn + (int64_t)batch[v] * H;
     const float e1 = 1.f + eps[0];
     const int e0 = rowptr[v], e_end = rowptr[v + 1];
-    for (int k = lane; k < H; k += 64) {
-        const float vk = vr[k];
-        const float hv = h[(int64_t)v * H + k] + vk;
-        float agg = 0.f;
-        for (int e = e0; e < e_end; ++e) agg += gelu_erf(h[(int64_t)src[e] * H + k] + vk + bond[(int64_t)attr[e] * H + k]);
-        h_in[(int64_t)v * H + k] = hv;
-        z0[(int64_t)v * H + k] = from_f32<T>(e1 * hv + agg);
+    // the wave's edge list (molecular graphs: degree <= ~6) is read once by the first lanes and broadcast
+    const int my_e = e0 + lane;
+    const int my_src = my_e < e_end ? src[my_e] : 0;
+    const int my_att = my_e < e_end ? attr[my_e] : 0;
+    for (int k = lane * 4; k < H; k += 256) {
+        const float4 vk = *reinterpret_cast<const float4 *>(vr + k);
+        float4 hv = *reinterpret_cast<const float4 *>(h + (int64_t)v * H + k);
+        hv.x += vk.x; hv.y += vk.y; hv.z += vk.z; hv.w += vk.w;
+        float4 agg = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int eb = e0; eb < e_end; eb += 4) {       // 4 neighbour rows in flight
+            float4 hn[4], bn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = eb + u;
+                const bool ok = e < e_end;
+                const int sidx = __builtin_amdgcn_readlane(my_src, ok ? (e - e0) & 63 : 0);   // uniform index
+                const int aidx = __builtin_amdgcn_readlane(my_att, ok ? (e - e0) & 63 : 0);
+                const int sv = (e - e0) < 64 ? sidx : src[ok ? e : e0];
+                const int av = (e - e0) < 64 ? aidx : attr[ok ? e : e0];
+                hn[u] = ok ? *reinterpret_cast<const float4 *>(h + (int64_t)sv * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bn[u] = ok ? *reinterpret_cast<const float4 *>(bond + (int64_t)av * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (eb + u < e_end) {
+                    const float4 m = gelu4(make_float4(hn[u].x + vk.x + bn[u].x, hn[u].y + vk.y + bn[u].y,
+                                                       hn[u].z + vk.z + bn[u].z, hn[u].w + vk.w + bn[u].w));
+                    agg.x += m.x; agg.y += m.y; agg.z += m.z; agg.w += m.w;
+                }
+            }
+        }
+        *reinterpret_cast<float4 *>(h_in + (int64_t)v * H + k) = hv;
+        gin_store4<T>(z0 + (int64_t)v * H + k, make_float4(e1 * hv.x + agg.x, e1 * hv.y + agg.y, e1 * hv.z + agg.z, e1 * hv.w + agg.w));
     }
 }
 
 // out[r] = act(LayerNorm_affine(in[r]))  -> operand dtype.  One wave per row, any C.
 template <typename T>
-__global__ __launch_bounds__(256) void rows_ln_act_kernel(const float *__restrict__ in, const float *__restrict__ w,
-                                                           const float *__restrict__ b, T *__restrict__ out, int R,
-                                                           int C, int gelu) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(64) void rows_ln_act_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                          const float *__restrict__ b, T *__restrict__ out, int R,
+                                                          int C, int gelu) {
+    const int r = blockIdx.x;   // one wave = one row = one workgroup
     if (r >= R) return;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     const float *x = in + (int64_t)r * C;
+    constexpr int MAXE = 32;   // float4 chunks per lane: C <= 8192
+    float4 v[MAXE];
     float s = 0.f;
-    for (int k = lane; k < C; k += 64) s += x[k];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int k = (lane + e * 64) * 4;
+        v[e] = k < C ? *reinterpret_cast<const float4 *>(x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += v[e].x + v[e].y + v[e].z + v[e].w;
+    }
     const float mean = wave_sum(s) / (float)C;
     float vr = 0.f;
-    for (int k = lane; k < C; k += 64) {
-        const float d = x[k] - mean;
-        vr += d * d;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        if ((lane + e * 64) * 4 < C) {
+            const float d0 = v[e].x - mean, d1 = v[e].y - mean, d2 = v[e].z - mean, d3 = v[e].w - mean;
+            vr += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
     }
     const float rstd = rsqrtf(wave_sum(vr) / (float)C + 1e-5f);
-    for (int k = lane; k < C; k += 64) {
-        float y = (x[k] - mean) * rstd * w[k] + b[k];
-        if (gelu) y = gelu_erf(y);
-        out[(int64_t)r * C + k] = from_f32<T>(y);
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int k = (lane + e * 64) * 4;
+        if (k < C) {
+            const float4 ww = *reinterpret_cast<const float4 *>(w + k);
+            const float4 bb = *reinterpret_cast<const float4 *>(b + k);
+            float4 y = make_float4((v[e].x - mean) * rstd * ww.x + bb.x, (v[e].y - mean) * rstd * ww.y + bb.y,
+                                   (v[e].z - mean) * rstd * ww.z + bb.z, (v[e].w - mean) * rstd * ww.w + bb.w);
+            if (gelu) y = gelu4(y);
+            gin_store4<T>(out + (int64_t)r * C + k, y);
+        }
     }
 }
 
 // Layer tail.  Encoder: z = LN_affine(z); predictor: z = LN0(z) * (1 + scale) + shift, residual gated.
 //   if not last: z = GELU(z);  h = (gate *) z + h_in         (model.py:137-145 / predictor :331-340)
-__global__ __launch_bounds__(256) void gin_post_kernel(const float *__restrict__ z, const float *__restrict__ h_in,
-                                                        const float *__restrict__ lnw, const float *__restrict__ lnb,
-                                                        const float *__restrict__ mod /*[G][3H] or null*/,
-                                                        const int *__restrict__ batch, float *__restrict__ h, int n,
-                                                        int H, int gelu) {
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(64) void gin_post_kernel(const float *__restrict__ z, const float *__restrict__ h_in,
+                                                       const float *__restrict__ lnw, const float *__restrict__ lnb,
+                                                       const float *__restrict__ mod /*[G][3H] or null*/,
+                                                       const int *__restrict__ batch, float *__restrict__ h, int n,
+                                                       int H, int gelu) {
+    const int v = blockIdx.x;
     if (v >= n) return;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     const float *x = z + (int64_t)v * H;
+    constexpr int MAXE = 8;   // H <= 2048
+    float4 t[MAXE], hi[MAXE];
     float s = 0.f;
-    for (int k = lane; k < H; k += 64) s += x[k];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int k = (lane + e * 64) * 4;
+        t[e] = k < H ? *reinterpret_cast<const float4 *>(x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        hi[e] = k < H ? *reinterpret_cast<const float4 *>(h_in + (int64_t)v * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += t[e].x + t[e].y + t[e].z + t[e].w;
+    }
     const float mean = wave_sum(s) / (float)H;
     float vr = 0.f;
-    for (int k = lane; k < H; k += 64) {
-        const float d = x[k] - mean;
-        vr += d * d;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        if ((lane + e * 64) * 4 < H) {
+            const float d0 = t[e].x - mean, d1 = t[e].y - mean, d2 = t[e].z - mean, d3 = t[e].w - mean;
+            vr += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
     }
     const float rstd = rsqrtf(wave_sum(vr) / (float)H + 1e-5f);
     const float *m = mod ? mod + (int64_t)batch[v] * 3 * H : nullptr;
-    for (int k = lane; k < H; k += 64) {
-        float y = (x[k] - mean) * rstd;
-        float gate = 1.f;
-        if (m) {
-            y = y * (1.f + m[H + k]) + m[k];
-            gate = m[2 * H + k];
-        } else {
-            y = y * lnw[k] + lnb[k];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int k = (lane + e * 64) * 4;
+        if (k < H) {
+            float4 y = make_float4((t[e].x - mean) * rstd, (t[e].y - mean) * rstd, (t[e].z - mean) * rstd, (t[e].w - mean) * rstd);
+            float4 gate = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (m) {
+                const float4 sh = *reinterpret_cast<const float4 *>(m + k);
+                const float4 sc = *reinterpret_cast<const float4 *>(m + H + k);
+                gate = *reinterpret_cast<const float4 *>(m + 2 * H + k);
+                y = make_float4(y.x * (1.f + sc.x) + sh.x, y.y * (1.f + sc.y) + sh.y, y.z * (1.f + sc.z) + sh.z, y.w * (1.f + sc.w) + sh.w);
+            } else {
+                const float4 ww = *reinterpret_cast<const float4 *>(lnw + k);
+                const float4 bb = *reinterpret_cast<const float4 *>(lnb + k);
+                y = make_float4(y.x * ww.x + bb.x, y.y * ww.y + bb.y, y.z * ww.z + bb.z, y.w * ww.w + bb.w);
+            }
+            if (gelu) y = gelu4(y);
+            *reinterpret_cast<float4 *>(h + (int64_t)v * H + k) =
+                make_float4(gate.x * y.x + hi[e].x, gate.y * y.y + hi[e].y, gate.z * y.z + hi[e].z, gate.w * y.w + hi[e].w);
         }
-        if (gelu) y = gelu_erf(y);
-        h[(int64_t)v * H + k] = gate * y + h_in[(int64_t)v * H + k];
     }
 }
 
@@ -193,14 +266,22 @@ __global__ __launch_bounds__(256) void segment_pool_kernel(const float *__restri
                                                             float *__restrict__ out32, T *__restrict__ outa, int H) {
     const int g = blockIdx.x;
     const int v0 = gptr[g], v1 = gptr[g + 1];
-    for (int k = threadIdx.x; k < H; k += 256) {
-        float acc = MAX ? -INFINITY : 0.f;
-        for (int v = v0; v < v1; ++v) {
-            const float x = h[(int64_t)v * H + k];
-            acc = MAX ? fmaxf(acc, x) : acc + x;
+    for (int k = (blockIdx.y * 256 + threadIdx.x) * 4; k < H; k += gridDim.y * 1024) {
+        float4 acc = MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int vb = v0; vb < v1; vb += 8) {   // 8 node rows in flight
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                t[u] = (vb + u < v1) ? *reinterpret_cast<const float4 *>(h + (int64_t)(vb + u) * H + k)
+                                     : (MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0.f, 0.f, 0.f, 0.f));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (MAX) { acc.x = fmaxf(acc.x, t[u].x); acc.y = fmaxf(acc.y, t[u].y); acc.z = fmaxf(acc.z, t[u].z); acc.w = fmaxf(acc.w, t[u].w); }
+                else { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
+            }
         }
-        if (out32) out32[(int64_t)g * H + k] = acc;
-        if (outa) outa[(int64_t)g * H + k] = from_f32<T>(acc);
+        if (out32) *reinterpret_cast<float4 *>(out32 + (int64_t)g * H + k) = acc;
+        if (outa) gin_store4<T>(outa + (int64_t)g * H + k, acc);
     }
 }
 
@@ -239,26 +320,52 @@ __device__ __forceinline__ uint32_t f2key(float f) {
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+// Row scan helper: 4 x float4 per thread in flight (the row is L2-resident after the first pass; a scalar strided
+// loop would serialise ~D/1024 dependent round trips per pass).  f(value, index) is called for every element.
+template <typename F>
+__device__ __forceinline__ void topk_scan_row(const float *__restrict__ x, int D, int tid, F f) {
+    const int D4 = (D % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? D / 4 : 0;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    for (int i0 = tid; i0 < D4; i0 += 4 * 1024) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (i0 + u * 1024 < D4) ? x4[i0 + u * 1024] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 1024;
+            if (i < D4) {
+                f(v[u].x, 4 * i);
+                f(v[u].y, 4 * i + 1);
+                f(v[u].z, 4 * i + 2);
+                f(v[u].w, 4 * i + 3);
+            }
+        }
+    }
+    for (int i = 4 * D4 + tid; i < D; i += 1024) f(x[i], i);
+}
+
 __global__ __launch_bounds__(1024) void softmax_topk_kernel(const float *__restrict__ logits, int D, int k,
                                                              float *__restrict__ probs, int *__restrict__ idx) {
     __shared__ unsigned int hist[256];
+    __shared__ unsigned int whist[16][256];   // one histogram per wave: the top radix byte (sign + exponent) puts most keys
+                                              // into a handful of bins, so a single LDS histogram serialises on atomics
     __shared__ float redm[16], reds[16];
-    __shared__ unsigned int s_prefix, s_need, s_cnt;
+    __shared__ unsigned int s_prefix, s_need, s_cnt, s_ties;
+    __shared__ int tie_idx[64];
     __shared__ float selv[64];
     __shared__ int seli[64];
     const float *x = logits + (int64_t)blockIdx.x * D;
     const int tid = threadIdx.x;
-    // pass 0: max and sum(exp)
+    // pass 0: max and sum(exp)  (online softmax)
     float m = -INFINITY, s = 0.f;
-    for (int i = tid; i < D; i += 1024) {
-        const float v = x[i];
+    topk_scan_row(x, D, tid, [&](float v, int) {
         if (v > m) {
             s = s * expf(m - v) + 1.f;
             m = v;
         } else {
             s += expf(v - m);
         }
-    }
+    });
     for (int o = 32; o > 0; o >>= 1) {
         const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
         const float mn = fmaxf(m, m2);
@@ -274,7 +381,7 @@ __global__ __launch_bounds__(1024) void softmax_topk_kernel(const float *__restr
     for (int w = 0; w < 16; ++w) gm = fmaxf(gm, redm[w]);
     float gs = 0.f;
     for (int w = 0; w < 16; ++w) gs += (redm[w] == -INFINITY) ? 0.f : reds[w] * expf(redm[w] - gm);
-    // radix select
+    // radix select, most significant byte first
     if (tid == 0) {
         s_prefix = 0;
         s_need = (unsigned)k;
@@ -282,49 +389,78 @@ __global__ __launch_bounds__(1024) void softmax_topk_kernel(const float *__restr
     __syncthreads();
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        if (tid < 256) hist[tid] = 0;
+        for (int i = tid; i < 16 * 256; i += 1024) (&whist[0][0])[i] = 0;
         __syncthreads();
         const unsigned prefix = s_prefix;
         const unsigned pmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (int i = tid; i < D; i += 1024) {
-            const unsigned key = f2key(x[i]);
-            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        unsigned int *myh = whist[tid >> 6];
+        topk_scan_row(x, D, tid, [&](float v, int) {
+            const unsigned key = f2key(v);
+            if ((key & pmask) == prefix) atomicAdd(&myh[(key >> shift) & 255u], 1u);
+        });
+        __syncthreads();
+        if (tid < 256) {
+            unsigned t = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) t += whist[w][tid];
+            hist[tid] = t;
         }
         __syncthreads();
         if (tid == 0) {
             unsigned need = s_need, acc = 0;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (acc + hist[b] >= need) break;
-                acc += hist[b];
+            int bsel = 255;
+            for (; bsel > 0; --bsel) {
+                if (acc + hist[bsel] >= need) break;
+                acc += hist[bsel];
             }
             s_need = need - acc;
-            s_prefix = prefix | ((unsigned)b << shift);
+            s_prefix = prefix | ((unsigned)bsel << shift);
         }
         __syncthreads();
     }
     const unsigned kth = s_prefix;   // key of the k-th largest element
     const unsigned need_eq = s_need;  // how many elements equal to kth belong to the top-k
-    if (tid == 0) s_cnt = 0;
+    if (tid == 0) {
+        s_cnt = 0;
+        s_ties = 0;
+    }
     __syncthreads();
-    for (int i = tid; i < D; i += 1024) {
-        const float v = x[i];
-        if (f2key(v) > kth) {
+    // gather: everything above the threshold, plus (normally exactly one) element equal to it
+    topk_scan_row(x, D, tid, [&](float v, int i) {
+        const unsigned key = f2key(v);
+        if (key > kth) {
             const unsigned p = atomicAdd(&s_cnt, 1u);
             selv[p] = v;
             seli[p] = i;
+        } else if (key == kth) {
+            const unsigned p = atomicAdd(&s_ties, 1u);
+            if (p < 64) tie_idx[p] = i;
         }
-    }
+    });
     __syncthreads();
-    if (tid == 0) {  // ties at the threshold: lowest indices first (rare; serial scan keeps it deterministic)
-        unsigned p = s_cnt, taken = 0;
-        for (int i = 0; i < D && taken < need_eq; ++i)
-            if (f2key(x[i]) == kth) {
-                selv[p] = x[i];
-                seli[p] = i;
+    // ties at the threshold: keep the `need_eq` lowest indices (deterministic); > 64 exact ties -> serial scan
+    if (tid == 0) {
+        unsigned p = s_cnt;
+        if (s_ties <= 64) {
+            const unsigned nt = s_ties;
+            for (unsigned a2 = 0; a2 < nt; ++a2)
+                for (unsigned b2 = a2 + 1; b2 < nt; ++b2)
+                    if (tie_idx[b2] < tie_idx[a2]) { const int t2 = tie_idx[a2]; tie_idx[a2] = tie_idx[b2]; tie_idx[b2] = t2; }
+            for (unsigned a2 = 0; a2 < need_eq && a2 < nt; ++a2) {
+                selv[p] = x[tie_idx[a2]];
+                seli[p] = tie_idx[a2];
                 ++p;
-                ++taken;
             }
+        } else {
+            unsigned taken = 0;
+            for (int i = 0; i < D && taken < need_eq; ++i)
+                if (f2key(x[i]) == kth) {
+                    selv[p] = x[i];
+                    seli[p] = i;
+                    ++p;
+                    ++taken;
+                }
+        }
     }
     __syncthreads();
     if (tid < k) {
@@ -418,7 +554,7 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
     LL_TRY(e->vt1.ensure((size_t)Gp * 4 * H * 4));
     LL_TRY(e->vt1a.ensure((size_t)Gp * 4 * H * es));
     LL_TRY(e->vt2.ensure((size_t)Gp * H * 4));
-    const dim3 rows_n(cdiv(n, 4)), rows_g(cdiv(G, 4)), blk(256);
+    const dim3 rows_n(cdiv(n, 4)), rows_g(cdiv(G, 4)), blk(256), w_n(n), w_g(G), wblk(64);
 
     hipLaunchKernelGGL(gin_embed_kernel, rows_n, blk, 0, st, x, e->pf("atom_encoder.weight"), e->h.as<float>(), n, H);
     hipLaunchKernelGGL(bcast_rows_kernel, dim3(cdiv(G * H, 256)), blk, 0, st, e->vn.as<float>(), e->pf("virtualnode_embedding.weight"), G, H);
@@ -437,31 +573,31 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
     for (int l = 0; l < L; ++l) {
         const std::string p = "convs." + std::to_string(l) + ".";
         const bool last = (l == L - 1);
-        hipLaunchKernelGGL((gin_aggregate_kernel<T>), rows_n, blk, 0, st, e->h.as<float>(), e->vn.as<float>(), batch, rowptr, src, attr,
+        hipLaunchKernelGGL((gin_aggregate_kernel<T>), w_n, wblk, 0, st, e->h.as<float>(), e->vn.as<float>(), batch, rowptr, src, attr,
                            e->pf(p + "bond_encoder.weight"), e->pf(p + "eps"), e->h_in.as<float>(), e->z0.as<T>(), n, H);
         LL_LAUNCH_CHECK();
         LL_TRY(linear_launch(dt, e->z0.p, H, e->pw(p + "mlp.0.weight"), H, e->pf(p + "mlp.0.bias"), e->t1.p, 4 * H, n, 4 * H, H, 0, 1, st));
-        hipLaunchKernelGGL((rows_ln_act_kernel<T>), rows_n, blk, 0, st, e->t1.as<float>(), e->pf(p + "mlp.1.weight"), e->pf(p + "mlp.1.bias"), e->t1a.as<T>(), n, 4 * H, 1);
+        hipLaunchKernelGGL((rows_ln_act_kernel<T>), w_n, wblk, 0, st, e->t1.as<float>(), e->pf(p + "mlp.1.weight"), e->pf(p + "mlp.1.bias"), e->t1a.as<T>(), n, 4 * H, 1);
         LL_LAUNCH_CHECK();
         LL_TRY(linear_launch(dt, e->t1a.p, 4 * H, e->pw(p + "mlp.4.weight"), 4 * H, e->pf(p + "mlp.4.bias"), e->z.p, H, n, H, 4 * H, 0, 1, st));
         const float *lnw = cf.kind == 0 ? e->pf("norms." + std::to_string(l) + ".weight") : nullptr;
         const float *lnb = cf.kind == 0 ? e->pf("norms." + std::to_string(l) + ".bias") : nullptr;
         const float *mod = cf.kind == 1 ? e->mod.as<float>() + (size_t)l * Gp * 3 * H : nullptr;
-        hipLaunchKernelGGL(gin_post_kernel, rows_n, blk, 0, st, e->z.as<float>(), e->h_in.as<float>(), lnw, lnb, mod, batch, e->h.as<float>(), n, H, last ? 0 : 1);
+        hipLaunchKernelGGL(gin_post_kernel, w_n, wblk, 0, st, e->z.as<float>(), e->h_in.as<float>(), lnw, lnb, mod, batch, e->h.as<float>(), n, H, last ? 0 : 1);
         LL_LAUNCH_CHECK();
         if (!last) {  // virtual node update from max-pooled h_in (model.py:147-150)
             const std::string q = "mlp_virtualnode_list." + std::to_string(l) + ".";
-            hipLaunchKernelGGL((segment_pool_kernel<T, true>), dim3(G), blk, 0, st, e->h_in.as<float>(), gptr, (float *)nullptr, e->poola.as<T>(), H);
+            hipLaunchKernelGGL((segment_pool_kernel<T, true>), dim3(G, cdiv(H, 1024)), blk, 0, st, e->h_in.as<float>(), gptr, (float *)nullptr, e->poola.as<T>(), H);
             LL_LAUNCH_CHECK();
             LL_TRY(linear_launch(dt, e->poola.p, H, e->pw(q + "0.weight"), H, e->pf(q + "0.bias"), e->vt1.p, 4 * H, G, 4 * H, H, 0, 1, st));
-            hipLaunchKernelGGL((rows_ln_act_kernel<T>), rows_g, blk, 0, st, e->vt1.as<float>(), e->pf(q + "1.weight"), e->pf(q + "1.bias"), e->vt1a.as<T>(), G, 4 * H, 1);
+            hipLaunchKernelGGL((rows_ln_act_kernel<T>), w_g, wblk, 0, st, e->vt1.as<float>(), e->pf(q + "1.weight"), e->pf(q + "1.bias"), e->vt1a.as<T>(), G, 4 * H, 1);
             LL_LAUNCH_CHECK();
             LL_TRY(linear_launch(dt, e->vt1a.p, 4 * H, e->pw(q + "4.weight"), 4 * H, e->pf(q + "4.bias"), e->vt2.p, H, G, H, 4 * H, 0, 1, st));
             hipLaunchKernelGGL(add_rows_kernel, dim3(cdiv(G * H, 256)), blk, 0, st, e->vn.as<float>(), e->vt2.as<float>(), (int64_t)G * H);
             LL_LAUNCH_CHECK();
         }
     }
-    hipLaunchKernelGGL((segment_pool_kernel<T, false>), dim3(G), blk, 0, st, e->h.as<float>(), gptr, e->pool32.as<float>(), e->poola.as<T>(), H);
+    hipLaunchKernelGGL((segment_pool_kernel<T, false>), dim3(G, cdiv(H, 1024)), blk, 0, st, e->h.as<float>(), gptr, e->pool32.as<float>(), e->poola.as<T>(), H);
     LL_LAUNCH_CHECK();
     if (pooled) LL_HIP(hipMemcpyAsync(pooled, e->pool32.p, (size_t)G * H * 4, hipMemcpyDeviceToDevice, st));
     if (cf.kind == 0) {  // ProjectionHead + L2 normalise (model.py:37-41,198-205)
@@ -469,7 +605,7 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
         LL_TRY(e->head1a.ensure((size_t)Gp * H * es));
         LL_TRY(e->head2.ensure((size_t)Gp * H * 4));
         LL_TRY(linear_launch(dt, e->poola.p, H, e->pw("proj.fc1.weight"), H, e->pf("proj.fc1.bias"), e->head1.p, H, G, H, H, 0, 1, st));
-        hipLaunchKernelGGL((rows_ln_act_kernel<T>), rows_g, blk, 0, st, e->head1.as<float>(), e->pf("proj.norm1.weight"), e->pf("proj.norm1.bias"), e->head1a.as<T>(), G, H, 1);
+        hipLaunchKernelGGL((rows_ln_act_kernel<T>), w_g, wblk, 0, st, e->head1.as<float>(), e->pf("proj.norm1.weight"), e->pf("proj.norm1.bias"), e->head1a.as<T>(), G, H, 1);
         LL_LAUNCH_CHECK();
         LL_TRY(linear_launch(dt, e->head1a.p, H, e->pw("proj.fc2.weight"), H, e->pf("proj.fc2.bias"), e->head2.p, H, G, H, H, 0, 1, st));
         hipLaunchKernelGGL(l2norm_rows_kernel, rows_g, blk, 0, st, e->head2.as<float>(), out, G, H);
@@ -478,7 +614,7 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
         LL_TRY(e->head1.ensure((size_t)Gp * 4 * H * 4));
         LL_TRY(e->head1a.ensure((size_t)Gp * 4 * H * es));
         LL_TRY(linear_launch(dt, e->poola.p, H, e->pw("decoder.0.weight"), H, e->pf("decoder.0.bias"), e->head1.p, 4 * H, G, 4 * H, H, 0, 1, st));
-        hipLaunchKernelGGL((rows_ln_act_kernel<T>), rows_g, blk, 0, st, e->head1.as<float>(), e->pf("decoder.1.weight"), e->pf("decoder.1.bias"), e->head1a.as<T>(), G, 4 * H, 1);
+        hipLaunchKernelGGL((rows_ln_act_kernel<T>), w_g, wblk, 0, st, e->head1.as<float>(), e->pf("decoder.1.weight"), e->pf("decoder.1.bias"), e->head1a.as<T>(), G, 4 * H, 1);
         LL_LAUNCH_CHECK();
         LL_TRY(linear_launch(dt, e->head1a.p, 4 * H, e->pw("decoder.4.weight"), 4 * H, e->pf("decoder.4.bias"), out, cf.out_dim, G, cf.out_dim, 4 * H, 0, 1, st));
     }

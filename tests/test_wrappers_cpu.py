@@ -1,0 +1,140 @@
+"""CPU tests of the drop-in wrapper classes: file formats, state-dict keys, table construction, error behaviour.
+(The arithmetic needs a HIP device and is covered by the -m gpu tests; here nothing is computed on the engine.)"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from llamole_amd import synth
+from tests.cases import DIT_CASES, GIN_CASES, dit_case, load_golden
+
+
+@pytest.fixture()
+def dit_dir(tmp_path):
+    cfg, meta, sd, B, seed = dit_case("dit_n32_h128")
+    synth.write_dit_dir(str(tmp_path), cfg, meta, sd)
+    return str(tmp_path), cfg, meta, sd
+
+
+def test_graphdit_tables_match_reference_goldens(dit_dir):
+    from llamole_amd.graph_decoder import GraphDiT
+    d, cfg, meta, sd = dit_dir
+    m = GraphDiT(os.path.join(d, "config.yaml"), os.path.join(d, "data.meta.json"), torch.float32)
+    g = load_golden("dit_n32_h128")
+    np.testing.assert_allclose(m.tables["betas"].numpy(), g["betas"], rtol=1e-6)
+    np.testing.assert_allclose(m.tables["alphas_bar"].numpy(), g["alphas_bar"], rtol=1e-6)
+    np.testing.assert_allclose(m.tables["x_marg"].numpy(), g["x_marg"], rtol=1e-6)
+    np.testing.assert_allclose(m.tables["e_marg"].numpy(), g["e_marg"], rtol=1e-6)
+    N = m.max_n_nodes
+    # u = [[u_x, tile(u_xe)], [tile(u_ex), tile(u_e)]]  (reference diffusion_utils.py:296-305)
+    np.testing.assert_allclose(m.tables["u_xe"].numpy(), g["u"][:16, 16:21], rtol=1e-6)
+    np.testing.assert_allclose(m.tables["u_ex"].numpy(), g["u"][16:21, :16], rtol=1e-6)
+    assert m.T == cfg["diffusion_steps"] and m.guide_scale == cfg["guide_scale"] and m.hidden_size == cfg["hidden_size"]
+    assert m.text_input_size == 768 and m.atom_decoder == meta["active_atoms"] and N == meta["max_node"]
+
+
+def test_graphdit_state_dict_roundtrip_and_errors(dit_dir, tmp_path):
+    from llamole_amd.graph_decoder import GraphDiT
+    d, cfg, meta, sd = dit_dir
+    m = GraphDiT(os.path.join(d, "config.yaml"), os.path.join(d, "data.meta.json"), torch.float32)
+    assert list(m.denoiser.state_dict().keys()) == list(sd.keys())          # reference Transformer key order
+    m.init_model(d)
+    for k, v in m.denoiser.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    out = tmp_path / "saved"
+    m.save_pretrained(str(out))
+    assert sorted(os.listdir(out)) == ["data.meta.json", "model.pt", "model_config.yaml"]
+    assert json.load(open(out / "data.meta.json"))["max_node"] == meta["max_node"]
+    m.disable_grads()
+    assert not any(p.requires_grad for p in m.parameters())
+    with pytest.raises(FileNotFoundError):
+        m.init_model(str(tmp_path / "missing"))
+    with pytest.raises(FileNotFoundError):
+        GraphDiT(os.path.join(d, "nope.yaml"), os.path.join(d, "data.meta.json"), torch.float32)
+    with pytest.raises(FileNotFoundError):
+        GraphDiT(os.path.join(d, "config.yaml"), os.path.join(d, "nope.json"), torch.float32)
+    props, text, n_nodes = synth.make_dit_inputs(2, 0, meta["max_node"])
+    with pytest.raises(RuntimeError, match="HIP device"):      # no CPU path in the product
+        m.generate_graphs(props, text, -200.0)
+    with pytest.raises(NotImplementedError):
+        m(None, None, None, None, None, None, None)
+    torch.manual_seed(0)
+    n = m.sample_n_nodes(1000)
+    assert int(n.min()) >= 5 and int(n.max()) <= meta["max_node"]
+
+
+def test_gin_wrappers_keys_files_and_errors(tmp_path):
+    from llamole_amd.graph_encoder import GraphCLIP
+    from llamole_amd.graph_predictor import GraphPredictor
+    L, H, out_dim, G, seed = GIN_CASES["gin_l3_h64"]
+    enc = GraphCLIP(L, H, 0.0, {"num_layer": L, "hidden_size": H, "drop_ratio": 0.0})
+    assert sorted(enc.molecule_encoder.state_dict()) == sorted(synth.gin_weight_shapes(L, H, "encoder"))
+    assert sorted(enc.molecule_projection.state_dict()) == sorted(synth.proj_weight_shapes(H))
+    enc.molecule_encoder.load_state_dict(synth.make_gin_weights(L, H, "encoder", seed=seed))
+    enc.save_pretrained(str(tmp_path / "enc"))
+    assert sorted(os.listdir(tmp_path / "enc")) == ["model.pt", "model_config.json", "model_proj.pt"]
+    enc2 = GraphCLIP(L, H, 0.0, {})
+    enc2.init_model(str(tmp_path / "enc"), verbose=False)
+    assert torch.equal(enc2.molecule_encoder.state_dict()["convs.0.eps"], enc.molecule_encoder.state_dict()["convs.0.eps"])
+    with pytest.raises(FileNotFoundError):
+        enc2.init_model(str(tmp_path / "none"))
+    with pytest.raises(ValueError, match="greater than 1"):
+        GraphCLIP(1, H, 0.0, {})
+    x, ei, ea, batch = synth.make_mol_graphs(2, 0)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        enc(x, ei, ea, batch)
+
+    import pandas as pd
+    l2t = pd.DataFrame({"rule_label": [0, 1, 2], "retro_templates": ["a>>b", "c>>d", "e>>f"]})
+    pred = GraphPredictor(L, H, 0.1, 3, {"num_layer": L, "hidden_size": H, "drop_ratio": 0.1, "num_task": 3}, l2t, available=["CCO", "CC"])
+    assert pred.label_to_template == {0: "a>>b", 1: "c>>d", 2: "e>>f"} and pred.text_input_size == 768
+    assert sorted(pred.predictor.state_dict()) == sorted(synth.gin_weight_shapes(L, H, "predictor", 3))
+    torch.save(synth.make_cost_weights(0), tmp_path / "cost_model.pt")
+    pred.init_neural_cost(str(tmp_path))
+    pred.save_pretrained(str(tmp_path / "pred"))
+    assert sorted(os.listdir(tmp_path / "pred")) == ["available.csv.gz", "cost_model.pt", "label_to_template.csv.gz", "model.pt", "model_config.json"]
+    back = pd.read_csv(tmp_path / "pred" / "label_to_template.csv.gz", compression="gzip")
+    assert list(back.columns) == ["rule_label", "retro_templates"] and len(back) == 3
+    with pytest.raises(ValueError, match="not initialized"):
+        GraphPredictor(L, H, 0.1, 3, {}, {}).estimate_cost("CCO")
+
+
+def test_loader_seam(tmp_path):
+    """load_graph_* keep the reference signatures / layouts; missing files -> FileNotFoundError (no network here)."""
+    import types
+    from llamole_amd import loader
+    cfg, meta, sd, B, seed = dit_case("dit_n32_h128")
+    d = tmp_path / "dit"
+    synth.write_dit_dir(str(d), cfg, meta, sd)
+    args = types.SimpleNamespace(compute_dtype=torch.bfloat16, disable_graph_model_gradient=True)
+    m = loader.load_graph_decoder(args, str(d), "cpu")
+    assert all(p.dtype == torch.bfloat16 and not p.requires_grad for p in m.parameters())   # reference loader.py:241-247
+    with pytest.raises(FileNotFoundError):
+        loader.load_graph_encoder(args, str(tmp_path / "no_enc"), "cpu")
+    with pytest.raises(FileNotFoundError):
+        loader.load_graph_predictor(args, str(tmp_path / "no_pred"), "cpu")
+    L, H = 3, 64
+    e = tmp_path / "enc"
+    os.makedirs(e)
+    json.dump({"num_layer": L, "hidden_size": H, "drop_ratio": 0.0}, open(e / "config.json", "w"))
+    torch.save(synth.make_gin_weights(L, H, "encoder"), e / "model.pt")
+    torch.save(synth.make_proj_weights(H), e / "model_proj.pt")
+    enc = loader.load_graph_encoder(args, str(e), "cpu")
+    assert enc.hidden_size == H and next(enc.parameters()).dtype == torch.bfloat16
+
+
+def test_graph_batch_roundtrip():
+    from llamole_amd.graph_data import GraphBatch, GraphData
+    x, ei, ea, batch = synth.make_mol_graphs(3, 1)
+    sizes = torch.bincount(batch).tolist()
+    parts, off = [], 0
+    for n in sizes:
+        sel = (ei[0] >= off) & (ei[0] < off + n)
+        parts.append(GraphData(x[off:off + n], ei[:, sel] - off, ea[sel]))
+        off += n
+    gb = GraphBatch.from_data_list(parts)
+    assert torch.equal(gb.x, x) and torch.equal(gb.batch, batch) and torch.equal(gb.edge_index, ei) and torch.equal(gb.edge_attr, ea)
+    back = gb.to_data_list()
+    assert [d.num_nodes for d in back] == sizes and torch.equal(back[1].edge_index, parts[1].edge_index)

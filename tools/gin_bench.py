@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Throughput of the GIN encoder / predictor HIP path at BASELINE.json configs[2] sizes (16 product graphs of 32 heavy
+atoms, H_gin=512, 5 layers, 180576 templates, top-50), next to the CPU oracle on the host cores.  Prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from llamole_amd import synth  # noqa: E402
+
+
+def fast_weights(shapes, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for k, shp in shapes.items():
+        if k.endswith("eps"):
+            sd[k] = torch.zeros(1, device=device)
+        elif len(shp) == 1:
+            gain = k.endswith((".1.weight", "norm1.weight")) or ".norms." in "." + k and k.endswith("weight")
+            sd[k] = (1.0 if gain else 0.0) + 0.05 * torch.randn(shp, generator=g, device=device)
+        elif "encoder.weight" in k or "embedding" in k or "text_dropping" in k:
+            sd[k] = 0.5 * torch.randn(shp, generator=g, device=device)
+        else:
+            sd[k] = (2.0 / (shp[0] + shp[1])) ** 0.5 * torch.randn(shp, generator=g, device=device)
+    return sd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--graphs", type=int, default=16)
+    ap.add_argument("--hidden", type=int, default=512)
+    ap.add_argument("--layers", type=int, default=5)
+    ap.add_argument("--out-dim", type=int, default=180576)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+    from llamole_amd.graph_encoder import GraphCLIP
+    from llamole_amd.graph_predictor import GraphPredictor
+    dev = torch.device("cuda")
+    L, H, G = a.layers, a.hidden, a.graphs
+    x, ei, ea, batch = synth.make_mol_graphs(G, 0, min_atoms=32, max_atoms=32)
+    enc = GraphCLIP(L, H, 0.0, {})
+    enc.to(dev)
+    enc.molecule_encoder.load_state_dict(fast_weights(synth.gin_weight_shapes(L, H, "encoder"), dev, 1))
+    enc.molecule_projection.load_state_dict(fast_weights(synth.proj_weight_shapes(H), dev, 2))
+    pred = GraphPredictor(L, H, 0.0, a.out_dim, {}, {})
+    pred.to(dev)
+    sdp = fast_weights(synth.gin_weight_shapes(L, H, "predictor", a.out_dim), dev, 3)
+    pred.predictor.load_state_dict(sdp)
+    for m in (enc, pred):
+        for p in m.parameters():
+            p.data = p.data.to(torch.bfloat16)
+    xs, eis, eas, bs = x.to(dev), ei.to(dev), ea.to(dev), batch.to(dev)
+    c = torch.randn(G, 768, device=dev)
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / a.iters
+
+    t_enc = timeit(lambda: enc(xs, eis, eas, bs))
+    t_pred = timeit(lambda: pred.topk_templates(xs, eis, eas, bs, c, 50))
+    dec_bytes = a.out_dim * 4 * H * 2
+    out = {"workload": f"GIN encoder + predictor(top-50 of {a.out_dim}) on {G} graphs x 32 atoms, H={H}, L={L}, bf16",
+           "encoder_ms": 1e3 * t_enc, "predictor_topk_ms": 1e3 * t_pred,
+           "expansions_per_s": G / t_pred, "decoder_weight_bytes": dec_bytes,
+           "decoder_hbm_frac_if_all_time": dec_bytes / t_pred / 8e12}
+    if not a.no_cpu:
+        from bench import usable_cores
+        from oracle import gin_oracle as go
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        sd_cpu = {k: v.float().cpu() for k, v in sdp.items()}
+        cc = c.cpu()
+        with torch.no_grad():
+            go.predictor_forward(sd_cpu, L, x, ei, ea, batch, cc)
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < 8.0 and n < 20:
+                go.template_topk(go.predictor_forward(sd_cpu, L, x, ei, ea, batch, cc), 50)
+                n += 1
+            t_cpu = (time.perf_counter() - t0) / n
+        out["cpu_baseline"] = {"predictor_topk_ms": 1e3 * t_cpu, "expansions_per_s": G / t_cpu, "cores": cores, "kind": "port",
+                               "sample": f"{n} forward+top-k calls of the fp32 oracle"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
