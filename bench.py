@@ -166,22 +166,34 @@ def cpu_baseline_e2e(args, llm, cfg, meta, sd, props, text, n_nodes):
 
 
 def time_dominant_kernel(args, device):
-    """The dominant kernel of the GraphDiT step (the bf16 MFMA GEMM at the block-MLP fc1 shape, production tile
-    dispatch) timed by HIP events on the stream it is launched on, back to back over enough distinct weight matrices
-    to defeat the 256 MiB Infinity Cache (ll_gemm_bench in the C ABI).  Returns (avg_ms, bytes, flops, name)."""
+    """The dominant hand-written kernel of the workload, timed by HIP events on the stream it is launched on, back to
+    back over enough distinct weight matrices to defeat the 256 MiB Infinity Cache (ll_gemm_bench in the C ABI):
+      e2e      : gemv_bf16_kernel -- the weight-streaming GEMV under the LLM's nn.Linear at decode (15.2 GB of bf16
+                 weights per token for Qwen2-7B); timed on the MLP up/gate projection shape [18944 x 3584], M = batch;
+      graphdit : gemm_bf16_pipe_kernel at the block-MLP fc1 shape, M = 2*B*N tokens.
+    Returns (avg_ms, algorithmic bytes, flops, name, pmc key)."""
     import ctypes as C
     from llamole_amd import _lib
     lib = _lib.load()
-    H, Hm = args.hidden, int(args.hidden * 4)
-    M2 = 2 * args.batch * args.nodes
     if args.dtype != "bf16":
         return None
-    nw = max(2, int(600e6 // (Hm * H * 2)))
+    if args.workload == "e2e" and args.llm_linear == "hip":
+        from llamole_amd.e2e import LLM_CONFIGS
+        spec = LLM_CONFIGS[args.llm]
+        M, N, K = args.batch, spec["intermediate_size"], spec["hidden_size"]
+        name = f"gemv_bf16_kernel, LLM MLP up-projection [{M}x{K}]x[{N}x{K}]^T bf16 (decode step)"
+        key = f"llm_gemv_m{M}_n{N}_k{K}"
+    else:
+        H, Hm = args.hidden, int(args.hidden * 4)
+        M, N, K = 2 * args.batch * args.nodes, Hm, H
+        name = f"gemm_bf16_pipe_kernel, GraphDiT block-MLP fc1 [{M}x{K}]x[{N}x{K}]^T bf16"
+        key = f"fc1_m{M}"
+    nw = max(2, int(600e6 // (N * K * 2)))
     ms = C.c_float()
-    _lib.check(lib.ll_gemm_bench(M2, Hm, H, -1, 1, 0, 4 * nw, nw, C.byref(ms)), "ll_gemm_bench")
-    nbytes = Hm * H * 2 + M2 * H * 2 + M2 * Hm * 2 + Hm * 4
-    flops = 2.0 * M2 * Hm * H
-    return ms.value, nbytes, flops, f"gemm_bf16_pipe_kernel, block-MLP fc1 [{M2}x{H}]x[{Hm}x{H}]^T bf16"
+    _lib.check(lib.ll_gemm_bench(M, N, K, -1, 1, 0, 4 * nw, nw, C.byref(ms)), "ll_gemm_bench")
+    nbytes = N * K * 2 + M * K * 2 + M * N * 2
+    flops = 2.0 * M * N * K
+    return ms.value, nbytes, flops, name, key
 
 
 def main():
@@ -205,6 +217,8 @@ def main():
     ap.add_argument("--cutoff-len", type=int, default=128)
     ap.add_argument("--llm-decode", default="graph", choices=["graph", "eager", "hf"])
     ap.add_argument("--blas", default="default", choices=["default", "hipblaslt", "hipblas"])
+    ap.add_argument("--llm-linear", default="hip", choices=["hip", "torch"],
+                    help="kernel under nn.Linear for decode-shaped LLM calls: libllamole_hip GEMV or PyTorch's BLAS")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 8 if args.workload == "graphdit" else 1
@@ -279,8 +293,8 @@ def main():
     log("timed region done", dt)
     dom = time_dominant_kernel(args, device)
     if dom is None:      # f32 parity mode has no tuned kernel to report
-        dom = (float("nan"), 0, 0.0, "n/a (f32 parity mode)")
-    kms, kbytes, kflops, kname = dom
+        dom = (float("nan"), 0, 0.0, "n/a (f32 parity mode)", "")
+    kms, kbytes, kflops, kname, kkey = dom
     log("dominant kernel timed", kms)
     hbm_t, mfma_t = kbytes / (HBM_PEAK_GBS * 1e9), kflops / (MFMA_BF16_PEAK_TF * 1e12)
     if hbm_t >= mfma_t or args.dtype != "bf16":
@@ -291,8 +305,8 @@ def main():
     roof["traffic"] = None
     try:   # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same shape)
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-        key = "fc1_m%d" % (2 * B * N)
-        if key in pmc and args.hidden == 1024 and args.dtype == "bf16":
+        key = kkey
+        if key in pmc and args.dtype == "bf16" and (not key.startswith("fc1") or args.hidden == 1024):
             roof["traffic"] = pmc[key]["hbm_bytes_per_launch"]
             roof["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
     except Exception:

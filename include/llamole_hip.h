@@ -42,7 +42,8 @@ const char *ll_last_error(void);
  * path (reference layers.py:47,53,106-109; transformer.py:116-130).  dtype selects the operand type
  * of A and W (LL_F32: exact f32 FMA chains; LL_BF16: MFMA 16x16x32 with f32 accumulation).
  * epi: 0 none, 1 GELU(erf), 2 SiLU, 3 Softsign.  out_f32 != 0 writes f32, else the operand dtype.
- * A must be readable for round_up(M,128) rows. */
+ * bf16: M <= 4 runs a weight-streaming GEMV, larger M the LDS-DMA pipelined MFMA tiles (A rows are clamped, no
+ * padding needed); f32: A must be readable for round_up(M,64) rows. */
 int ll_linear(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
               int M, int N, int K, int epi, int out_f32, void *stream);
 

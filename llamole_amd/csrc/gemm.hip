@@ -206,7 +206,9 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipe_kernel(const bf16_
     for (int it = 0; it < LA; ++it) {
         const int c = (it * NW + wave) * 64 + lane;
         const int row = c >> 3, slot = c & 7;
-        pa[it] = A + (int64_t)(m0 + row) * lda + kbeg + ((slot ^ (row & 7)) << 3);
+        int ar = m0 + row;
+        ar = ar < M ? ar : M - 1;   // M edge: re-read a valid row (result discarded), so A needs no row padding
+        pa[it] = A + (int64_t)ar * lda + kbeg + ((slot ^ (row & 7)) << 3);
     }
 #pragma unroll
     for (int it = 0; it < LB; ++it) {
@@ -418,6 +420,86 @@ static int launch_skinny(const bf16_t *A, int lda, const bf16_t *W, int ldw, voi
     return LL_OK;
 }
 
+// ------------------------------------------------------------------------------------------ bf16 GEMV (M <= 4)
+// Pure weight streaming for decode-shaped calls (LLM decode at batch 1..4, single-graph template head): no MFMA, no
+// LDS tiles.  Each wave owns R consecutive weight rows; a lane reads 16 B (8 bf16) of each row per step with UNR steps
+// in flight (R*UNR KiB per wave outstanding), multiplies with the matching 16 B of x (L1/L2 resident: x is K*2 bytes)
+// and accumulates in f32; one DPP/readlane wave reduction per output at the end.  out = epi(x W^T + b), bf16 or f32.
+template <int MROWS, int R, int UNR, typename OutT>
+__global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t *__restrict__ X, int ldx, const bf16_t *__restrict__ W,
+                                                         int ldw, OutT *__restrict__ C, int ldc,
+                                                         const float *__restrict__ bias, int N, int K, int epi) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * 4) + (threadIdx.x >> 6);
+    const int n0 = wave * R;
+    if (n0 >= N) return;
+    const bf16_t *wr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int row = n0 + r;
+        row = row < N ? row : N - 1;
+        wr[r] = W + (int64_t)row * ldw;
+    }
+    float acc[MROWS][R];
+#pragma unroll
+    for (int m = 0; m < MROWS; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
+    const int nchunk = K / 8;   // 16-byte chunks per row
+    for (int c0 = lane; c0 < nchunk; c0 += 64 * UNR) {
+        uint4 wv[UNR][R], xv[UNR][MROWS];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int c = c0 + u * 64;
+            const bool ok = c < nchunk;
+#pragma unroll
+            for (int r = 0; r < R; ++r) wv[u][r] = ok ? *reinterpret_cast<const uint4 *>(wr[r] + c * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MROWS; ++m) xv[u][m] = ok ? *reinterpret_cast<const uint4 *>(X + (int64_t)m * ldx + c * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+            for (int m = 0; m < MROWS; ++m) {
+                const uint32_t xw[4] = {xv[u][m].x, xv[u][m].y, xv[u][m].z, xv[u][m].w};
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t ww[4] = {wv[u][r].x, wv[u][r].y, wv[u][r].z, wv[u][r].w};
+                    float a = acc[m][r];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        a = fmaf(__uint_as_float(ww[t] << 16), __uint_as_float(xw[t] << 16), a);
+                        a = fmaf(__uint_as_float(ww[t] & 0xffff0000u), __uint_as_float(xw[t] & 0xffff0000u), a);
+                    }
+                    acc[m][r] = a;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MROWS; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float v = wave_sum(acc[m][r]);
+            if (lane == 0 && n0 + r < N) {
+                float o = v + (bias ? bias[n0 + r] : 0.f);
+                o = apply_epi(o, epi);
+                C[(int64_t)m * ldc + n0 + r] = from_f32<OutT>(o);
+            }
+        }
+}
+
+template <int MROWS>
+static void launch_gemv(const bf16_t *X, int ldx, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int N, int K,
+                        int epi, int out_f32, hipStream_t s) {
+    constexpr int R = MROWS <= 2 ? 4 : 2, UNR = 4;
+    dim3 grid(cdiv(N, 4 * R)), block(256);
+    if (out_f32)
+        hipLaunchKernelGGL((gemv_bf16_kernel<MROWS, R, UNR, float>), grid, block, 0, s, X, ldx, W, ldw, (float *)C, ldc, bias, N, K, epi);
+    else
+        hipLaunchKernelGGL((gemv_bf16_kernel<MROWS, R, UNR, bf16_t>), grid, block, 0, s, X, ldx, W, ldw, (bf16_t *)C, ldc, bias, N, K, epi);
+}
+
 // ------------------------------------------------------------------------------------------ f32 VALU
 // 64x64 tile, BK=16, 256 threads, 4x4 outputs per thread; k-ordered fmaf chain per output.
 template <typename OutT>
@@ -518,13 +600,24 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
     LL_CHECK(splits >= 1 && K % splits == 0, "ll_linear: K=%d not divisible by splits=%d", K, splits);
     const int kchunk = K / splits;
     if (dtype == LL_BF16) {
-        LL_CHECK(kchunk % 64 == 0, "ll_linear(bf16): K per split (%d) must be a multiple of 64", kchunk);
+        LL_CHECK(kchunk % 64 == 0 || (M <= 4 && splits == 1 && K % 8 == 0),
+                 "ll_linear(bf16): K per split (%d) must be a multiple of 64", kchunk);
         LL_CHECK(lda % 8 == 0 && ldw % 8 == 0, "ll_linear(bf16): lda/ldw must be multiples of 8 elements");
         const bf16_t *a = (const bf16_t *)A;
         const bf16_t *w = (const bf16_t *)W;
         if (g_gemm_variant < 0) {
             const char *ev = getenv("LL_GEMM_VARIANT");
             g_gemm_variant = ev ? atoi(ev) : 1;
+        }
+        if (g_gemm_variant != 0 && M <= 4 && splits == 1 && K % 8 == 0) {
+            switch (M) {
+                case 1: launch_gemv<1>(a, lda, w, ldw, C, ldc, bias, N, K, epi, out_f32, s); break;
+                case 2: launch_gemv<2>(a, lda, w, ldw, C, ldc, bias, N, K, epi, out_f32, s); break;
+                case 3: launch_gemv<3>(a, lda, w, ldw, C, ldc, bias, N, K, epi, out_f32, s); break;
+                default: launch_gemv<4>(a, lda, w, ldw, C, ldc, bias, N, K, epi, out_f32, s); break;
+            }
+            LL_LAUNCH_CHECK();
+            return LL_OK;
         }
         if (g_gemm_variant != 0) {
             // pipelined kernels: prefer the largest tile that still gives >= ~1 workgroup per CU

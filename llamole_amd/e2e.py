@@ -96,6 +96,10 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
     """Returns (step_fn, info).  step_fn(i) -> list of integer molecule graphs for the rank's batch."""
     llm = build_llm(args.llm, device)
     orch, tok = build_orchestrator(llm, graph_decoder, device)
+    n_accel = 0
+    if args.llm_linear == "hip":
+        from .llm_accel import accelerate_linears
+        n_accel = accelerate_linears(llm)
     if args.llm_decode != "hf":
         orch.enable_graphed_decode(use_graph=(args.llm_decode == "graph"))
     B = props.shape[0]
@@ -123,5 +127,7 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
             "max_new_tokens": args.new_tokens, "sampling": "temperature 0.6, top_p 0.9",
             "llm_decode": {"graph": "stock HF forward over StaticCache, one hipGraph replayed per token",
                            "eager": "stock HF forward over StaticCache, eager", "hf": "HF generate()"}[args.llm_decode],
+            "llm_linear": ("ll_linear (HIP weight-streaming GEMV) under %d nn.Linear modules for decode-shaped calls" % n_accel)
+                          if n_accel else "PyTorch-ROCm default (hipBLASLt)",
             "timing_breakdown": last}
     return step_fn, info, orch, llm
