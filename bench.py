@@ -215,6 +215,8 @@ def main():
     ap.add_argument("--llm", default="qwen2-7b")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--cutoff-len", type=int, default=128)
+    ap.add_argument("--no-llm-fuse", dest="llm_fuse", action="store_false",
+                    help="keep HF's op-by-op RMSNorm / rotary / SiLU*mul at decode instead of the fused HIP kernels")
     ap.add_argument("--llm-decode", default="graph", choices=["graph", "eager", "hf"])
     ap.add_argument("--blas", default="default", choices=["default", "hipblaslt", "hipblas"])
     ap.add_argument("--llm-linear", default="hip", choices=["hip", "torch"],

@@ -163,6 +163,18 @@ int ll_softmax_topk(const float *logits, int rows, int out_dim, int k, float *pr
  * weights: device f32 arena = [layers.0.weight 128x2048 | layers.0.bias 128 | layers.3.weight 1x128 | layers.3.bias 1]. */
 int ll_cost_mlp(const float *weights, const float *fps, int n, float *out, void *stream);
 
+/* ------------------------------------------------------------------ fused LLM decode helpers (optional, section 8 f2)
+ * Same arithmetic as the HuggingFace modules they stand in for, including the intermediate bf16 roundings of PyTorch's
+ * op-by-op evaluation (results are bit-identical); all tensors bf16.
+ * ll_rmsnorm_bf16 : Qwen2RMSNorm/LlamaRMSNorm.forward on [rows,H].
+ * ll_rope_bf16    : apply_rotary_pos_emb on q [B,nh,S,D] / k [B,nkv,S,D] given by element strides of dims 0..2 (last dim
+ *                   contiguous) and cos/sin [B or 1,S,D] strides of dims 0..1; outputs contiguous.
+ * ll_silu_mul_bf16: silu(gate) * up over n elements (n % 8 == 0). */
+int ll_rmsnorm_bf16(const void *x, const void *w, void *out, int rows, int H, float eps, void *stream);
+int ll_rope_bf16(const void *q, const void *k, const void *cos, const void *sin, void *qo, void *ko, int B, int nh, int nkv,
+                 int S, int D, const int64_t *qstr, const int64_t *kstr, const int64_t *cstr, void *stream);
+int ll_silu_mul_bf16(const void *gate, const void *up, void *out, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,9 +97,12 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
     llm = build_llm(args.llm, device)
     orch, tok = build_orchestrator(llm, graph_decoder, device)
     n_accel = 0
+    fused = {}
     if args.llm_linear == "hip":
-        from .llm_accel import accelerate_linears
+        from .llm_accel import accelerate_elementwise, accelerate_linears
         n_accel = accelerate_linears(llm)
+        if args.llm_fuse:
+            fused = accelerate_elementwise(llm)
     if args.llm_decode != "hf":
         orch.enable_graphed_decode(use_graph=(args.llm_decode == "graph"))
     B = props.shape[0]
@@ -129,5 +132,6 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
                            "eager": "stock HF forward over StaticCache, eager", "hf": "HF generate()"}[args.llm_decode],
             "llm_linear": ("ll_linear (HIP weight-streaming GEMV) under %d nn.Linear modules for decode-shaped calls" % n_accel)
                           if n_accel else "PyTorch-ROCm default (hipBLASLt)",
+            "llm_fused_elementwise": fused,
             "timing_breakdown": last}
     return step_fn, info, orch, llm

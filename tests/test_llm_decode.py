@@ -87,3 +87,44 @@ def test_accelerated_linears_match_blas_and_compose_with_graph():
     with torch.no_grad():
         again = llm(input_ids=tok).logits.float()
     assert torch.equal(again, ref)
+
+
+@pytest.mark.gpu
+def test_fused_elementwise_matches_hf_modules():
+    """Fused RMSNorm / rotary / SiLU*mul vs the HF op-by-op code on the same tensors: identical up to the f32 reduction
+    order of the variance and the device expf (<= 1 bf16 ulp on a tiny fraction of elements)."""
+    from llamole_amd.llm_accel import accelerate_elementwise, restore_elementwise
+    from transformers.models.qwen2 import modeling_qwen2 as mq
+    llm, prompt, mask = _case("cuda", torch.bfloat16)
+    torch.manual_seed(0)
+    norm = llm.model.layers[0].input_layernorm
+    mlp = llm.model.layers[0].mlp
+    x = torch.randn(2, 1, llm.config.hidden_size, device="cuda", dtype=torch.bfloat16) * 3
+    q = torch.randn(2, 1, 4, 64, device="cuda", dtype=torch.bfloat16).transpose(1, 2)     # strided [B,h,S,d] view like HF
+    k = torch.randn(2, 1, 2, 64, device="cuda", dtype=torch.bfloat16).transpose(1, 2)
+    cos = torch.randn(2, 1, 64, device="cuda", dtype=torch.bfloat16)
+    sin = torch.randn(2, 1, 64, device="cuda", dtype=torch.bfloat16)
+    with torch.no_grad():
+        ref_n, ref_m = norm(x), mlp(x)
+        ref_q, ref_k = mq.apply_rotary_pos_emb(q, k, cos, sin)
+        tok = prompt[:, -1:]
+        ref_logits = llm(input_ids=tok).logits.float()
+        info = accelerate_elementwise(llm)
+        assert info["rmsnorm"] == 2 * llm.config.num_hidden_layers + 1 and info["mlp"] == llm.config.num_hidden_layers and info["rope"] == 1
+        got_n, got_m = norm(x), mlp(x)
+        got_q, got_k = mq.apply_rotary_pos_emb(q, k, cos, sin)
+        got_logits = llm(input_ids=tok).logits.float()
+        long_ok = llm(input_ids=prompt.repeat(8, 1)).logits      # 96 rows > MAX_ROWS: original HF path
+    assert long_ok.shape[0] == 16
+    assert torch.equal(got_q, ref_q) and torch.equal(got_k, ref_k)                 # rotary: exact
+    for got, ref in ((got_n, ref_n), (got_m, ref_m)):
+        diff = (got.float() - ref.float()).abs()
+        assert (diff > 0).float().mean() < 0.02 and (diff <= 2 ** -7 * ref.float().abs() + 1e-6).all()
+    assert (got_logits - ref_logits).abs().max() <= 2e-2 * ref_logits.abs().max()
+    kw = dict(max_new_tokens=8, do_sample=False, pad_token_id=0, eos_token_id=[2047])
+    eager = GraphedDecoder(llm, use_graph=False).generate(prompt, mask, **kw)
+    graph = GraphedDecoder(llm, use_graph=True).generate(prompt, mask, **kw)
+    assert torch.equal(eager, graph)
+    restore_elementwise(llm)
+    with torch.no_grad():
+        assert torch.equal(llm(input_ids=tok).logits.float(), ref_logits)
