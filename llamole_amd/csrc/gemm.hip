@@ -489,10 +489,23 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t *__restrict
         }
 }
 
+template <int R, int UNR>
+static int launch_gemv_cfg(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M,
+                           int N, int K, int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
+    (void)splits; (void)slab_stride; (void)M;
+    dim3 grid(cdiv(N, 4 * R)), block(256);
+    if (out_f32)
+        hipLaunchKernelGGL((gemv_bf16_kernel<1, R, UNR, float>), grid, block, 0, s, A, lda, W, ldw, (float *)C, ldc, bias, N, K, epi);
+    else
+        hipLaunchKernelGGL((gemv_bf16_kernel<1, R, UNR, bf16_t>), grid, block, 0, s, A, lda, W, ldw, (bf16_t *)C, ldc, bias, N, K, epi);
+    return LL_OK;
+}
+
 template <int MROWS>
 static void launch_gemv(const bf16_t *X, int ldx, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int N, int K,
                         int epi, int out_f32, hipStream_t s) {
-    constexpr int R = MROWS <= 2 ? 4 : 2, UNR = 4;
+    // sweep over the Qwen2-7B / template-head shapes (tools/gemv_sweep.py): 2 rows per wave, 8 x 16 B per row in flight
+    constexpr int R = 2, UNR = MROWS == 1 ? 8 : 4;
     dim3 grid(cdiv(N, 4 * R)), block(256);
     if (out_f32)
         hipLaunchKernelGGL((gemv_bf16_kernel<MROWS, R, UNR, float>), grid, block, 0, s, X, ldx, W, ldw, (float *)C, ldc, bias, N, K, epi);
@@ -722,6 +735,14 @@ static const PipeCfg g_pipe_cfgs[] = {
     {64, 64, 4, launch_pipe<64, 64, 4, 2, 4>},     // 20
     {256, 64, 3, launch_pipe<256, 64, 4, 2, 3>},   // 21
     {128, 64, 6, launch_pipe<128, 64, 4, 2, 6>},   // 22
+    {1, 4, 204, launch_gemv_cfg<4, 4>},            // 23  GEMV (M = 1): R rows per wave, UNR 16-B loads per row in flight
+    {1, 2, 204, launch_gemv_cfg<2, 4>},            // 24
+    {1, 8, 202, launch_gemv_cfg<8, 2>},            // 25
+    {1, 4, 208, launch_gemv_cfg<4, 8>},            // 26
+    {1, 2, 208, launch_gemv_cfg<2, 8>},            // 27
+    {1, 1, 208, launch_gemv_cfg<1, 8>},            // 28
+    {1, 8, 204, launch_gemv_cfg<8, 4>},            // 29
+    {1, 1, 216, launch_gemv_cfg<1, 16>},           // 30
 };
 }  // namespace ll
 
