@@ -230,13 +230,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()    # == local_rank on a real node (one process per GPU)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("LLAMOLE_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" only for single-GPU dry runs
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     if args.blas != "default":
         torch.backends.cuda.preferred_blas_library(args.blas)
@@ -274,12 +279,12 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         # the path's only exchange: ONE all-gather of the generated integer graphs (fixed-size records)
         from llamole_amd.distributed import all_gather_graphs
-        gathered = all_gather_graphs(mols, N, world * B, device=device)
+        gathered = all_gather_graphs(mols, N, world * B, device=device if dist.get_backend() == "nccl" else None)
         assert len(gathered) == world * B
     if rank != 0:
         if dist is not None:

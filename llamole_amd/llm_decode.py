@@ -125,7 +125,8 @@ class GraphedDecoder:
                             layer.cumulative_length.sub_(self.tok.shape[1])
                     torch.cuda.current_stream().wait_stream(s)
                     self._graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self._graph):
+                    # thread-local capture: a RCCL watchdog thread polling events must not invalidate the capture
+                    with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                         self.logits = self._step()
                 self._graph.replay()
                 logits = self.logits
