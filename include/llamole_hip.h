@@ -174,6 +174,14 @@ int ll_rmsnorm_bf16(const void *x, const void *w, void *out, int rows, int H, fl
 int ll_rope_bf16(const void *q, const void *k, const void *cos, const void *sin, void *qo, void *ko, int B, int nh, int nkv,
                  int S, int D, const int64_t *qstr, const int64_t *kstr, const int64_t *cstr, void *stream);
 int ll_silu_mul_bf16(const void *gate, const void *up, void *out, int64_t n, void *stream);
+/* ll_kv_append_bf16 : StaticCache layer update at decode: write k_new/v_new [B,nkv,S,D] (element strides of dims 0..2) into
+ *                     keys/values [B,nkv,maxlen,D] at positions *pos .. *pos+S-1 (pos: device int64).
+ * ll_decode_attn_bf16: softmax(q K^T * scale + mask) V over the static cache with grouped-query heads; q [B,nh,S,D] strided,
+ *                     mask bool [B,1,S,maxlen] (strides of dims 0 and 2), out [B,S,nh,D] contiguous; D in {64,128}. */
+int ll_kv_append_bf16(void *K, void *V, const void *k_new, const void *v_new, const int64_t *pos, int B, int nkv, int S,
+                      int maxlen, int D, const int64_t *kstr, const int64_t *vstr, void *stream);
+int ll_decode_attn_bf16(const void *q, const void *K, const void *V, const void *mask, void *out, int B, int nh, int nkv, int S,
+                        int maxlen, int D, float scale, const int64_t *qstr, const int64_t *mstr, void *stream);
 
 #ifdef __cplusplus
 }

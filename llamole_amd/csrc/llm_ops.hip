@@ -102,6 +102,133 @@ __global__ __launch_bounds__(256) void silu_mul_bf16_kernel(const bf16_t *__rest
     }
 }
 
+// KV-cache append for a StaticCache layer: keys/values [B,nkv,maxlen,D] (contiguous) get the S new rows of
+// k_new/v_new ([B,nkv,S,D] views given by element strides) at positions *pos .. *pos+S-1.  Replaces the per-layer
+// arange + add + add_ + 2 x index_copy_ launches of transformers' StaticLayer.update at decode.
+__global__ __launch_bounds__(64) void kv_append_bf16_kernel(bf16_t *__restrict__ K, bf16_t *__restrict__ V,
+                                                             const bf16_t *__restrict__ kn, const bf16_t *__restrict__ vn,
+                                                             const long long *__restrict__ pos, int nkv, int S, int maxlen,
+                                                             int D, int64_t ks0, int64_t ks1, int64_t ks2, int64_t vs0,
+                                                             int64_t vs1, int64_t vs2) {
+    const int r = blockIdx.x;            // (b*nkv + h)*S + s
+    const int s = r % S, h = (r / S) % nkv, b = r / (S * nkv);
+    const long long p = *pos + s;
+    if (p < 0 || p >= maxlen) return;
+    const bf16_t *ksrc = kn + b * ks0 + h * ks1 + s * ks2;
+    const bf16_t *vsrc = vn + b * vs0 + h * vs1 + s * vs2;
+    const int64_t dst = (((int64_t)b * nkv + h) * maxlen + p) * D;
+    for (int d = threadIdx.x * 2; d < D; d += 128) {
+        *reinterpret_cast<uint32_t *>(K + dst + d) = *reinterpret_cast<const uint32_t *>(ksrc + d);
+        *reinterpret_cast<uint32_t *>(V + dst + d) = *reinterpret_cast<const uint32_t *>(vsrc + d);
+    }
+}
+
+// Decode attention over a static KV cache (GQA): one workgroup per (query head, batch*query position).
+//   scores_j = q . K[j] * scale for keys with mask[b,0,s,j] true; softmax in f32; out = sum_j p_j V[j].
+// Replaces repeat_kv (two full-cache copies) + SDPA + mask fills of the HF sdpa path at decode.  D in {64, 128}.
+template <int D>
+__global__ __launch_bounds__(256) void decode_attn_bf16_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ K,
+                                                               const bf16_t *__restrict__ V, const unsigned char *__restrict__ mask,
+                                                               bf16_t *__restrict__ out, int nh, int nkv, int S, int maxlen,
+                                                               float scale, int64_t qs0, int64_t qs1, int64_t qs2,
+                                                               int64_t ms0, int64_t ms2) {
+    extern __shared__ __attribute__((aligned(16))) float sm_attn[];
+    float *sc = sm_attn;                 // [maxlen]
+    float *part = sm_attn + maxlen;      // [4][D]
+    __shared__ float red[8];
+    const int h = blockIdx.x, bs = blockIdx.y;
+    const int b = bs / S, s = bs - b * S;
+    const int kvh = h / (nh / nkv);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int LPK = D / 8;           // lanes per key (16-byte slice each)
+    constexpr int KPW = 64 / LPK;        // keys per wave-iteration
+    const int sub = lane % LPK, kin = lane / LPK;
+    const bf16_t *qp = q + b * qs0 + h * qs1 + s * qs2 + sub * 8;
+    const uint4 qv = *reinterpret_cast<const uint4 *>(qp);
+    float qf[8];
+    {
+        const uint32_t u[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            qf[2 * t] = __uint_as_float(u[t] << 16);
+            qf[2 * t + 1] = __uint_as_float(u[t] & 0xffff0000u);
+        }
+    }
+    const bf16_t *Kb = K + ((int64_t)b * nkv + kvh) * maxlen * D;
+    const bf16_t *Vb = V + ((int64_t)b * nkv + kvh) * maxlen * D;
+    const unsigned char *mrow = mask + b * ms0 + s * ms2;
+    // ---- scores
+    for (int j0 = wave * KPW; j0 < maxlen; j0 += 4 * KPW) {
+        const int j = j0 + kin;
+        const bool ok = j < maxlen && mrow[j] != 0;
+        float dsum = 0.f;
+        if (ok) {
+            const uint4 kv = *reinterpret_cast<const uint4 *>(Kb + (int64_t)j * D + sub * 8);
+            const uint32_t u[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                dsum = fmaf(qf[2 * t], __uint_as_float(u[t] << 16), dsum);
+                dsum = fmaf(qf[2 * t + 1], __uint_as_float(u[t] & 0xffff0000u), dsum);
+            }
+        }
+        dsum = (LPK == 16) ? row16_sum(dsum) : row8_sum(dsum);
+        if (sub == 0 && j < maxlen) sc[j] = ok ? dsum * scale : -INFINITY;
+    }
+    __syncthreads();
+    // ---- softmax statistics
+    float mx = -INFINITY;
+    for (int j = tid; j < maxlen; j += 256) mx = fmaxf(mx, sc[j]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < maxlen; j += 256) {
+        const float e = (sc[j] == -INFINITY) ? 0.f : expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    // ---- out = P V : wave w takes keys j = w, w+4, ...; lane covers D/64 consecutive elements
+    constexpr int EPL = D / 64;
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    for (int j0 = wave; j0 < maxlen; j0 += 16) {
+        float pj[4];
+        uint32_t vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u;
+            pj[u] = j < maxlen ? sc[j] : 0.f;
+            vv[u] = 0;
+            if (pj[u] != 0.f) {
+                if (EPL == 2) vv[u] = *reinterpret_cast<const uint32_t *>(Vb + (int64_t)j * D + lane * 2);
+                else vv[u] = *reinterpret_cast<const unsigned short *>(Vb + (int64_t)j * D + lane);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (EPL == 2) {
+                acc[0] = fmaf(pj[u], __uint_as_float(vv[u] << 16), acc[0]);
+                acc[EPL - 1] = fmaf(pj[u], __uint_as_float(vv[u] & 0xffff0000u), acc[EPL - 1]);
+            } else {
+                acc[0] = fmaf(pj[u], __uint_as_float(vv[u] << 16), acc[0]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) part[wave * D + lane * EPL + e] = acc[e];
+    __syncthreads();
+    if (tid < D) {
+        const float o = (part[tid] + part[D + tid] + part[2 * D + tid] + part[3 * D + tid]) * inv;
+        out[(((int64_t)b * S + s) * nh + h) * D + tid] = f32_to_bf16(o);
+    }
+}
+
 }  // namespace ll
 
 using namespace ll;
@@ -135,6 +262,35 @@ int ll_silu_mul_bf16(const void *gate, const void *up, void *out, int64_t n, voi
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(silu_mul_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)gate,
                        (const bf16_t *)up, (bf16_t *)out, n / 8);
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+int ll_kv_append_bf16(void *K, void *V, const void *k_new, const void *v_new, const int64_t *pos, int B, int nkv, int S,
+                      int maxlen, int D, const int64_t *kstr, const int64_t *vstr, void *stream) {
+    LL_CHECK(K && V && k_new && v_new && pos && kstr && vstr, "null argument");
+    LL_CHECK(D % 2 == 0 && B >= 1 && nkv >= 1 && S >= 1, "bad shape");
+    hipLaunchKernelGGL(kv_append_bf16_kernel, dim3(B * nkv * S), dim3(64), 0, (hipStream_t)stream, (bf16_t *)K, (bf16_t *)V,
+                       (const bf16_t *)k_new, (const bf16_t *)v_new, (const long long *)pos, nkv, S, maxlen, D, kstr[0], kstr[1],
+                       kstr[2], vstr[0], vstr[1], vstr[2]);
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+int ll_decode_attn_bf16(const void *q, const void *K, const void *V, const void *mask, void *out, int B, int nh, int nkv, int S,
+                        int maxlen, int D, float scale, const int64_t *qstr, const int64_t *mstr, void *stream) {
+    LL_CHECK(q && K && V && mask && out && qstr && mstr, "null argument");
+    LL_CHECK((D == 64 || D == 128) && nh % nkv == 0 && maxlen >= 1 && maxlen <= 16384, "ll_decode_attn_bf16: unsupported shape");
+    const size_t lds = ((size_t)maxlen + 4 * D) * 4;
+    dim3 grid(nh, B * S);
+    if (D == 128)
+        hipLaunchKernelGGL((decode_attn_bf16_kernel<128>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t *)q,
+                           (const bf16_t *)K, (const bf16_t *)V, (const unsigned char *)mask, (bf16_t *)out, nh, nkv, S, maxlen,
+                           scale, qstr[0], qstr[1], qstr[2], mstr[0], mstr[1]);
+    else
+        hipLaunchKernelGGL((decode_attn_bf16_kernel<64>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t *)q,
+                           (const bf16_t *)K, (const bf16_t *)V, (const unsigned char *)mask, (bf16_t *)out, nh, nkv, S, maxlen,
+                           scale, qstr[0], qstr[1], qstr[2], mstr[0], mstr[1]);
     LL_LAUNCH_CHECK();
     return LL_OK;
 }

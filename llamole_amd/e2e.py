@@ -102,9 +102,12 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
         from .llm_accel import accelerate_elementwise, accelerate_linears
         n_accel = accelerate_linears(llm)
         if args.llm_fuse:
+            from .llm_accel import use_decode_attention
             fused = accelerate_elementwise(llm)
+            fused["decode_attention"] = bool(use_decode_attention(llm))
     if args.llm_decode != "hf":
-        orch.enable_graphed_decode(use_graph=(args.llm_decode == "graph"))
+        orch.enable_graphed_decode(use_graph=(args.llm_decode == "graph"), fused_cache=bool(fused))
+        fused["kv_append"] = bool(fused)
     B = props.shape[0]
     g = torch.Generator().manual_seed(100 + rank)
     prompt = torch.randint(5, 1000, (B, args.cutoff_len), generator=g).to(device)

@@ -165,3 +165,90 @@ def restore_elementwise(model: nn.Module) -> None:
     m = sys.modules.get(type(base).__module__)
     if m is not None and hasattr(getattr(m, "apply_rotary_pos_emb", None), "_ll_orig"):
         m.apply_rotary_pos_emb = m.apply_rotary_pos_emb._ll_orig
+
+
+# ------------------------------------------------------------------------------------------ decode attention + KV append
+ATTN_NAME = "llamole_decode"
+
+
+def _decode_attention_forward(module, query, key, value, attention_mask, dropout=0.0, scaling=None, **kwargs):
+    """AttentionInterface entry: softmax(q K^T * scaling + mask) V with grouped-query heads straight from the static cache
+    (no repeat_kv copies); anything that is not a small bf16 decode call with a boolean mask goes to HF's sdpa path."""
+    import ctypes as C
+    from transformers.integrations.sdpa_attention import sdpa_attention_forward
+    B, nh, S, D = query.shape
+    if (query.is_cuda and query.dtype == torch.bfloat16 and key.dtype == torch.bfloat16 and S <= 4 and D in (64, 128)
+            and attention_mask is not None and attention_mask.dtype == torch.bool and attention_mask.dim() == 4
+            and attention_mask.shape[1] == 1 and attention_mask.shape[-1] == key.shape[2] and attention_mask.stride(3) == 1
+            and key.is_contiguous() and value.is_contiguous() and query.stride(3) == 1 and dropout == 0.0
+            and not torch.is_grad_enabled() and nh % key.shape[1] == 0):
+        nkv, maxlen = key.shape[1], key.shape[2]
+        out = torch.empty((B, S, nh, D), dtype=query.dtype, device=query.device)
+        scale = float(scaling) if scaling is not None else D ** -0.5
+        I64x3, I64x2 = C.c_int64 * 3, C.c_int64 * 2
+        rc = _lib.load().ll_decode_attn_bf16(query.data_ptr(), key.data_ptr(), value.data_ptr(), attention_mask.data_ptr(),
+                                             out.data_ptr(), B, nh, nkv, S, maxlen, D, scale,
+                                             I64x3(query.stride(0), query.stride(1), query.stride(2)),
+                                             I64x2(attention_mask.stride(0), attention_mask.stride(2)),
+                                             torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "ll_decode_attn_bf16")
+        return out, None
+    return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
+
+
+def use_decode_attention(model: nn.Module) -> bool:
+    """Register the fused decode attention with transformers' AttentionInterface (boolean sdpa-style masks) and select it
+    on ``model``.  Returns False (and changes nothing) if this transformers build has no such registry."""
+    try:
+        from transformers import AttentionInterface
+        from transformers.masking_utils import AttentionMaskInterface, sdpa_mask
+    except ImportError:
+        return False
+    AttentionInterface.register(ATTN_NAME, _decode_attention_forward)
+    AttentionMaskInterface.register(ATTN_NAME, sdpa_mask)
+    model.config._attn_implementation = ATTN_NAME
+    for mod in model.modules():
+        cfg = getattr(mod, "config", None)
+        if cfg is not None and hasattr(cfg, "_attn_implementation"):
+            cfg._attn_implementation = ATTN_NAME
+    return True
+
+
+def fuse_cache_update(cache) -> int:
+    """Replace StaticLayer.update of an (already initialised) StaticCache by one fused append launch per layer for decode-
+    shaped calls.  All layers write at the position held by layer 0's on-device counter; the caller advances that counter
+    once per forward (GraphedDecoder does).  Returns the number of patched layers."""
+    import ctypes as C
+    lib = _lib.load()
+    layers = list(cache.layers)
+    if not layers or not all(getattr(l, "is_initialized", False) and hasattr(l, "cumulative_length") for l in layers):
+        return 0
+    pos = layers[0].cumulative_length
+    I64x3 = C.c_int64 * 3
+
+    def make(layer):
+        orig = layer.update
+
+        def update(key_states, value_states, *a, **k):
+            S = key_states.shape[-2]
+            if (S <= 4 and key_states.dtype == torch.bfloat16 and layer.keys.dtype == torch.bfloat16 and key_states.is_cuda
+                    and key_states.stride(3) == 1 and value_states.stride(3) == 1 and not torch.is_grad_enabled()):
+                B, nkv, _, D = key_states.shape
+                rc = lib.ll_kv_append_bf16(layer.keys.data_ptr(), layer.values.data_ptr(), key_states.data_ptr(),
+                                           value_states.data_ptr(), pos.data_ptr(), B, nkv, S, layer.keys.shape[2], D,
+                                           I64x3(key_states.stride(0), key_states.stride(1), key_states.stride(2)),
+                                           I64x3(value_states.stride(0), value_states.stride(1), value_states.stride(2)),
+                                           torch.cuda.current_stream().cuda_stream)
+                if rc != 0:
+                    _lib.check(rc, "ll_kv_append_bf16")
+                return layer.keys, layer.values
+            return orig(key_states, value_states, *a, **k)
+
+        layer.update = update
+        layer._ll_fused_update = True
+
+    for l in layers:
+        if not getattr(l, "_ll_fused_update", False):
+            make(l)
+    return len(layers)

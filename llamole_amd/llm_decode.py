@@ -35,10 +35,12 @@ def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float, generat
 
 
 class GraphedDecoder:
-    def __init__(self, model, use_graph: bool = True, sync_every: int = 16):
+    def __init__(self, model, use_graph: bool = True, sync_every: int = 16, fused_cache: bool = False):
         self.model = model
         self.use_graph = use_graph and next(model.parameters()).is_cuda
         self.sync_every = sync_every
+        self.fused_cache = fused_cache    # one fused KV-append launch per layer (llm_accel.fuse_cache_update)
+        self._cache_fused = False
         self._key = None
         self._graph = None
 
@@ -58,11 +60,19 @@ class GraphedDecoder:
         self.posid = torch.zeros(B, 1, dtype=torch.long, device=device)   # static: the captured graph reads it
         self.logits = None
         self._graph = None
+        self._cache_fused = False
 
     def _step(self):
         out = self.model(input_ids=self.tok, attention_mask=self.mask, past_key_values=self.cache,
                          cache_position=self.pos, position_ids=self.posid, use_cache=True, return_dict=True)
+        if self._cache_fused:   # the fused per-layer appends all used layer 0's counter; advance it once per forward
+            self.cache.layers[0].cumulative_length.add_(self.tok.shape[1])
         return out.logits[:, -1, :]
+
+    def _rewind(self, n: int):
+        layers = self.cache.layers[:1] if self._cache_fused else self.cache.layers
+        for layer in layers:
+            layer.cumulative_length.sub_(n)
 
     @torch.no_grad()
     def generate(self, input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
@@ -92,6 +102,9 @@ class GraphedDecoder:
                          cache_position=torch.arange(P, device=device), position_ids=pos_ids, use_cache=True,
                          return_dict=True, **kw)
         logits = out.logits[:, -1, :]
+        if self.fused_cache and not self._cache_fused and device.type == "cuda":
+            from .llm_accel import fuse_cache_update
+            self._cache_fused = fuse_cache_update(self.cache) > 0
         new_tokens = torch.full((B, max_new_tokens), pad, dtype=torch.long, device=device)
         done = torch.zeros(B, dtype=torch.bool, device=device)
         self.posid.copy_(plen)                                           # position id of the next token, per row
@@ -121,8 +134,7 @@ class GraphedDecoder:
                         self._step()
                         # the warm-up advanced the cache's on-device length counters; rewind them so that the
                         # captured step (replayed below for this same token) writes the same slot again
-                        for layer in self.cache.layers:
-                            layer.cumulative_length.sub_(self.tok.shape[1])
+                        self._rewind(self.tok.shape[1])
                     torch.cuda.current_stream().wait_stream(s)
                     self._graph = torch.cuda.CUDAGraph()
                     # thread-local capture: a RCCL watchdog thread polling events must not invalidate the capture

@@ -61,10 +61,10 @@ class GraphLLMForCausalMLM(nn.Module):
         self.timings: Dict[str, float] = {}
         self.decoder = None      # optional llm_decode.GraphedDecoder (HIP-graph decode step); None = HF generate
 
-    def enable_graphed_decode(self, use_graph: bool = True, sync_every: int = 16):
+    def enable_graphed_decode(self, use_graph: bool = True, sync_every: int = 16, fused_cache: bool = False):
         """Route every LLM decode of the path through one captured hipGraph of the stock HF forward."""
         from .llm_decode import GraphedDecoder
-        self.decoder = GraphedDecoder(self.language_model, use_graph=use_graph, sync_every=sync_every)
+        self.decoder = GraphedDecoder(self.language_model, use_graph=use_graph, sync_every=sync_every, fused_cache=fused_cache)
         return self
 
     def _llm_generate(self, inputs=None, attention_mask=None, inputs_embeds=None, **kwargs):
