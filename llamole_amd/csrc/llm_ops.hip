@@ -133,46 +133,42 @@ __global__ __launch_bounds__(256) void decode_attn_bf16_kernel(const bf16_t *__r
                                                                float scale, int64_t qs0, int64_t qs1, int64_t qs2,
                                                                int64_t ms0, int64_t ms2) {
     extern __shared__ __attribute__((aligned(16))) float sm_attn[];
-    float *sc = sm_attn;                 // [maxlen]
-    float *part = sm_attn + maxlen;      // [4][D]
+    float *qs = sm_attn;                 // [D]     query in f32 (16-B aligned LDS broadcast reads)
+    float *part = qs + D;                // [4][D]  per-wave partial outputs
+    float *sc = part + 4 * D;            // [maxlen] scores -> probabilities
     __shared__ float red[8];
     const int h = blockIdx.x, bs = blockIdx.y;
     const int b = bs / S, s = bs - b * S;
     const int kvh = h / (nh / nkv);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int LPK = D / 8;           // lanes per key (16-byte slice each)
-    constexpr int KPW = 64 / LPK;        // keys per wave-iteration
-    const int sub = lane % LPK, kin = lane / LPK;
-    const bf16_t *qp = q + b * qs0 + h * qs1 + s * qs2 + sub * 8;
-    const uint4 qv = *reinterpret_cast<const uint4 *>(qp);
-    float qf[8];
-    {
-        const uint32_t u[4] = {qv.x, qv.y, qv.z, qv.w};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            qf[2 * t] = __uint_as_float(u[t] << 16);
-            qf[2 * t + 1] = __uint_as_float(u[t] & 0xffff0000u);
-        }
-    }
+    if (tid < D) qs[tid] = bf16_to_f32(q[b * qs0 + h * qs1 + s * qs2 + tid]);
     const bf16_t *Kb = K + ((int64_t)b * nkv + kvh) * maxlen * D;
     const bf16_t *Vb = V + ((int64_t)b * nkv + kvh) * maxlen * D;
     const unsigned char *mrow = mask + b * ms0 + s * ms2;
-    // ---- scores
-    for (int j0 = wave * KPW; j0 < maxlen; j0 += 4 * KPW) {
-        const int j = j0 + kin;
-        const bool ok = j < maxlen && mrow[j] != 0;
+    __syncthreads();
+    // ---- scores: one key per thread, the whole key row (D/8 x 16 B) in flight -> one memory round trip per 256 keys
+    for (int j = tid; j < maxlen; j += 256) {
+        const bool ok = mrow[j] != 0;
         float dsum = 0.f;
         if (ok) {
-            const uint4 kv = *reinterpret_cast<const uint4 *>(Kb + (int64_t)j * D + sub * 8);
-            const uint32_t u[4] = {kv.x, kv.y, kv.z, kv.w};
+            uint4 kv[D / 8];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                dsum = fmaf(qf[2 * t], __uint_as_float(u[t] << 16), dsum);
-                dsum = fmaf(qf[2 * t + 1], __uint_as_float(u[t] & 0xffff0000u), dsum);
+            for (int c = 0; c < D / 8; ++c) kv[c] = *reinterpret_cast<const uint4 *>(Kb + (int64_t)j * D + c * 8);
+#pragma unroll
+            for (int c = 0; c < D / 8; ++c) {
+                const float4 q0 = *reinterpret_cast<const float4 *>(qs + c * 8);
+                const float4 q1 = *reinterpret_cast<const float4 *>(qs + c * 8 + 4);
+                dsum = fmaf(q0.x, __uint_as_float(kv[c].x << 16), dsum);
+                dsum = fmaf(q0.y, __uint_as_float(kv[c].x & 0xffff0000u), dsum);
+                dsum = fmaf(q0.z, __uint_as_float(kv[c].y << 16), dsum);
+                dsum = fmaf(q0.w, __uint_as_float(kv[c].y & 0xffff0000u), dsum);
+                dsum = fmaf(q1.x, __uint_as_float(kv[c].z << 16), dsum);
+                dsum = fmaf(q1.y, __uint_as_float(kv[c].z & 0xffff0000u), dsum);
+                dsum = fmaf(q1.z, __uint_as_float(kv[c].w << 16), dsum);
+                dsum = fmaf(q1.w, __uint_as_float(kv[c].w & 0xffff0000u), dsum);
             }
         }
-        dsum = (LPK == 16) ? row16_sum(dsum) : row8_sum(dsum);
-        if (sub == 0 && j < maxlen) sc[j] = ok ? dsum * scale : -INFINITY;
+        sc[j] = ok ? dsum * scale : -INFINITY;
     }
     __syncthreads();
     // ---- softmax statistics
@@ -197,11 +193,11 @@ __global__ __launch_bounds__(256) void decode_attn_bf16_kernel(const bf16_t *__r
     float acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-    for (int j0 = wave; j0 < maxlen; j0 += 16) {
-        float pj[4];
-        uint32_t vv[4];
+    for (int j0 = wave; j0 < maxlen; j0 += 32) {     // 8 keys (rows of 2*D bytes, coalesced) in flight per wave
+        float pj[8];
+        uint32_t vv[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int j = j0 + 4 * u;
             pj[u] = j < maxlen ? sc[j] : 0.f;
             vv[u] = 0;
@@ -211,13 +207,9 @@ __global__ __launch_bounds__(256) void decode_attn_bf16_kernel(const bf16_t *__r
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (EPL == 2) {
-                acc[0] = fmaf(pj[u], __uint_as_float(vv[u] << 16), acc[0]);
-                acc[EPL - 1] = fmaf(pj[u], __uint_as_float(vv[u] & 0xffff0000u), acc[EPL - 1]);
-            } else {
-                acc[0] = fmaf(pj[u], __uint_as_float(vv[u] << 16), acc[0]);
-            }
+        for (int u = 0; u < 8; ++u) {
+            acc[0] = fmaf(pj[u], __uint_as_float(vv[u] << 16), acc[0]);
+            if (EPL == 2) acc[EPL - 1] = fmaf(pj[u], __uint_as_float(vv[u] & 0xffff0000u), acc[EPL - 1]);
         }
     }
 #pragma unroll
@@ -281,7 +273,7 @@ int ll_decode_attn_bf16(const void *q, const void *K, const void *V, const void 
                         int maxlen, int D, float scale, const int64_t *qstr, const int64_t *mstr, void *stream) {
     LL_CHECK(q && K && V && mask && out && qstr && mstr, "null argument");
     LL_CHECK((D == 64 || D == 128) && nh % nkv == 0 && maxlen >= 1 && maxlen <= 16384, "ll_decode_attn_bf16: unsupported shape");
-    const size_t lds = ((size_t)maxlen + 4 * D) * 4;
+    const size_t lds = ((size_t)maxlen + 5 * D) * 4;
     dim3 grid(nh, B * S);
     if (D == 128)
         hipLaunchKernelGGL((decode_attn_bf16_kernel<128>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t *)q,
