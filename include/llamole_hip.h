@@ -169,11 +169,11 @@ int ll_cost_mlp(const float *weights, const float *fps, int n, float *out, void 
  * ll_rmsnorm_bf16 : Qwen2RMSNorm/LlamaRMSNorm.forward on [rows,H].
  * ll_rope_bf16    : apply_rotary_pos_emb on q [B,nh,S,D] / k [B,nkv,S,D] given by element strides of dims 0..2 (last dim
  *                   contiguous) and cos/sin [B or 1,S,D] strides of dims 0..1; outputs contiguous.
- * ll_silu_mul_bf16: silu(gate) * up over n elements (n % 8 == 0). */
+ * ll_silu_mul_bf16: silu(gate) * up on [rows, cols] views with input row stride ld_in (elements), contiguous output. */
 int ll_rmsnorm_bf16(const void *x, const void *w, void *out, int rows, int H, float eps, void *stream);
 int ll_rope_bf16(const void *q, const void *k, const void *cos, const void *sin, void *qo, void *ko, int B, int nh, int nkv,
                  int S, int D, const int64_t *qstr, const int64_t *kstr, const int64_t *cstr, void *stream);
-int ll_silu_mul_bf16(const void *gate, const void *up, void *out, int64_t n, void *stream);
+int ll_silu_mul_bf16(const void *gate, const void *up, void *out, int rows, int cols, int64_t ld_in, void *stream);
 /* ll_kv_append_bf16 : StaticCache layer update at decode: write k_new/v_new [B,nkv,S,D] (element strides of dims 0..2) into
  *                     keys/values [B,nkv,maxlen,D] at positions *pos .. *pos+S-1 (pos: device int64).
  * ll_decode_attn_bf16: softmax(q K^T * scale + mask) V over the static cache with grouped-query heads; q [B,nh,S,D] strided,

@@ -65,7 +65,7 @@ SIGNATURES = {
     "ll_cost_mlp": (_I, [_P, _P, _I, _P, _P]),
     "ll_rmsnorm_bf16": (_I, [_P, _P, _P, _I, _I, _F, _P]),
     "ll_rope_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), _P]),
-    "ll_silu_mul_bf16": (_I, [_P, _P, _P, _I64, _P]),
+    "ll_silu_mul_bf16": (_I, [_P, _P, _P, _I, _I, _I64, _P]),
     "ll_kv_append_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(_I64), C.POINTER(_I64), _P]),
     "ll_decode_attn_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, C.POINTER(_I64), C.POINTER(_I64), _P]),
 }

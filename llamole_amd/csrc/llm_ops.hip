@@ -87,9 +87,11 @@ __global__ __launch_bounds__(64) void rope_bf16_kernel(const bf16_t *__restrict_
 }
 
 __global__ __launch_bounds__(256) void silu_mul_bf16_kernel(const bf16_t *__restrict__ g, const bf16_t *__restrict__ u,
-                                                             bf16_t *__restrict__ out, int64_t n8) {
+                                                             bf16_t *__restrict__ out, int rows, int cols8, int64_t ld_in) {
+    const int64_t n8 = (int64_t)rows * cols8;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-        const uint4 gv = reinterpret_cast<const uint4 *>(g)[i], uv = reinterpret_cast<const uint4 *>(u)[i];
+        const int r = (int)(i / cols8), c = (int)(i - (int64_t)r * cols8);
+        const uint4 gv = *reinterpret_cast<const uint4 *>(g + r * ld_in + c * 8), uv = *reinterpret_cast<const uint4 *>(u + r * ld_in + c * 8);
         const uint32_t gg[4] = {gv.x, gv.y, gv.z, gv.w}, uu[4] = {uv.x, uv.y, uv.z, uv.w};
         uint32_t o[4];
 #pragma unroll
@@ -248,12 +250,14 @@ int ll_rope_bf16(const void *q, const void *k, const void *cos, const void *sin,
     return LL_OK;
 }
 
-int ll_silu_mul_bf16(const void *gate, const void *up, void *out, int64_t n, void *stream) {
-    LL_CHECK(gate && up && out && n >= 8 && n % 8 == 0, "ll_silu_mul_bf16: n must be a positive multiple of 8");
-    int blocks = (int)((n / 8 + 255) / 256);
+int ll_silu_mul_bf16(const void *gate, const void *up, void *out, int rows, int cols, int64_t ld_in, void *stream) {
+    LL_CHECK(gate && up && out && rows >= 1 && cols >= 8 && cols % 8 == 0 && ld_in % 8 == 0,
+             "ll_silu_mul_bf16: cols and ld_in must be positive multiples of 8");
+    const int64_t n8 = (int64_t)rows * (cols / 8);
+    int blocks = (int)((n8 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(silu_mul_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)gate,
-                       (const bf16_t *)up, (bf16_t *)out, n / 8);
+                       (const bf16_t *)up, (bf16_t *)out, rows, cols / 8, ld_in);
     LL_LAUNCH_CHECK();
     return LL_OK;
 }

@@ -84,18 +84,107 @@ def _rmsnorm_forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
     return self._ll_orig_forward(hidden_states)
 
 
+def _gemv(lib, x2: torch.Tensor, w: torch.Tensor, bias, N: int) -> torch.Tensor:
+    M, K = x2.shape
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device)
+    rc = lib.ll_linear(_lib.LL_BF16, x2.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
+                       out.data_ptr(), N, M, N, K, 0, 0, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        _lib.check(rc, "ll_linear")
+    return out
+
+
 def _mlp_forward(self, x: torch.Tensor) -> torch.Tensor:
-    if _decode_shaped(x, self.gate_proj.in_features) and self.gate_proj.out_features % 8 == 0:
-        g, u = self.gate_proj(x), self.up_proj(x)
-        if g.dtype == torch.bfloat16 and g.is_contiguous() and u.is_contiguous():
-            h = torch.empty_like(g)
-            rc = self._ll_lib.ll_silu_mul_bf16(g.data_ptr(), u.data_ptr(), h.data_ptr(), g.numel(),
-                                               torch.cuda.current_stream().cuda_stream)
-            if rc != 0:
-                _lib.check(rc, "ll_silu_mul_bf16")
-            return self.down_proj(h)
-        return self.down_proj(self.act_fn(g) * u)
+    K, I = self.gate_proj.in_features, self.gate_proj.out_features
+    if (_decode_shaped(x, K) and I % 8 == 0 and self.gate_proj.weight.dtype == torch.bfloat16 and self.gate_proj.bias is None
+            and self.up_proj.bias is None):
+        w = getattr(self, "_ll_gate_up", None)
+        if w is None:   # gate and up share the input: one [2I, K] weight, one weight-streaming launch
+            w = torch.cat([self.gate_proj.weight.detach(), self.up_proj.weight.detach()], dim=0).contiguous()
+            self._ll_gate_up = w
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        gu = _gemv(self._ll_lib, x2, w, None, 2 * I)
+        h = torch.empty(x2.shape[0], I, dtype=torch.bfloat16, device=x.device)
+        rc = self._ll_lib.ll_silu_mul_bf16(gu.data_ptr(), gu.data_ptr() + 2 * I, h.data_ptr(), x2.shape[0], I, 2 * I,
+                                           torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "ll_silu_mul_bf16")
+        return self.down_proj(h.reshape(*x.shape[:-1], I))
     return self._ll_orig_forward(x)
+
+
+class _QKVGroup:
+    """q_proj / k_proj / v_proj of one attention block share their input: the q_proj call runs ONE fused GEMV over the
+    concatenated [q|k|v] weight and the k_proj / v_proj calls that follow on the same tensor return views of its result."""
+
+    def __init__(self, lib, q, k, v):
+        self.lib = lib
+        self.nq, self.nk, self.nv = q.out_features, k.out_features, v.out_features
+        self.K = q.in_features
+        self.w = torch.cat([q.weight.detach(), k.weight.detach(), v.weight.detach()], dim=0).contiguous()
+        biases = [m.bias for m in (q, k, v)]
+        self.bias = None
+        if any(b is not None for b in biases):
+            self.bias = torch.cat([(b.detach().float() if b is not None else torch.zeros(m.out_features, device=q.weight.device))
+                                   for b, m in zip(biases, (q, k, v))]).contiguous()
+        self.x = None
+        self.buf = None
+
+    def run(self, x):
+        x2 = x.reshape(-1, self.K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        self.buf = _gemv(self.lib, x2, self.w, self.bias, self.nq + self.nk + self.nv)
+        self.x = x
+
+    def part(self, x, lo, n):
+        return self.buf[:, lo:lo + n].reshape(*x.shape[:-1], n) if x.dim() == 2 else self.buf.view(*x.shape[:-1], -1)[..., lo:lo + n]
+
+
+def _q_forward(self, x):
+    g = self._ll_qkv
+    if _decode_shaped(x, g.K):
+        g.run(x)
+        return g.part(x, 0, g.nq)
+    g.x = None
+    return self._ll_orig_forward(x)
+
+
+def _k_forward(self, x):
+    g = self._ll_qkv
+    if g.x is x and g.buf is not None:
+        return g.part(x, g.nq, g.nk)
+    return self._ll_orig_forward(x)
+
+
+def _v_forward(self, x):
+    g = self._ll_qkv
+    if g.x is x and g.buf is not None:
+        out = g.part(x, g.nq + g.nk, g.nv)
+        g.x = None          # one use per attention call
+        return out
+    return self._ll_orig_forward(x)
+
+
+def fuse_qkv(model: nn.Module) -> int:
+    """Fuse the q/k/v projections of every attention block (modules with q_proj, k_proj, v_proj Linears) for decode-shaped
+    calls.  Call after accelerate_linears (the non-decode path keeps whatever forward the Linears had)."""
+    lib = _lib.load()
+    n = 0
+    for mod in model.modules():
+        if all(type(getattr(mod, a, None)) is nn.Linear for a in ("q_proj", "k_proj", "v_proj")):
+            q, k, v = mod.q_proj, mod.k_proj, mod.v_proj
+            if q.weight.dtype != torch.bfloat16 or not q.weight.is_cuda or hasattr(q, "_ll_qkv"):
+                continue
+            grp = _QKVGroup(lib, q, k, v)
+            for m, f in ((q, _q_forward), (k, _k_forward), (v, _v_forward)):
+                m._ll_qkv = grp
+                m._ll_orig_forward = m.forward
+                m.forward = types.MethodType(f, m)
+            n += 1
+    return n
 
 
 def _make_rope(orig, lib):
@@ -135,6 +224,7 @@ def accelerate_elementwise(model: nn.Module) -> dict:
     import sys
     lib = _lib.load()
     n_norm = n_mlp = 0
+    n_qkv = fuse_qkv(model)
     for mod in model.modules():
         cls = type(mod).__name__
         if cls.endswith("RMSNorm") and hasattr(mod, "variance_epsilon") and hasattr(mod, "weight") and "forward" not in mod.__dict__:
@@ -152,7 +242,7 @@ def accelerate_elementwise(model: nn.Module) -> dict:
     if m is not None and hasattr(m, "apply_rotary_pos_emb") and not hasattr(m.apply_rotary_pos_emb, "_ll_orig"):
         m.apply_rotary_pos_emb = _make_rope(m.apply_rotary_pos_emb, lib)
         rope = 1
-    return {"rmsnorm": n_norm, "mlp": n_mlp, "rope": rope}
+    return {"rmsnorm": n_norm, "mlp": n_mlp, "rope": rope, "qkv": n_qkv}
 
 
 def restore_elementwise(model: nn.Module) -> None:

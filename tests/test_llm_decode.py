@@ -111,6 +111,7 @@ def test_fused_elementwise_matches_hf_modules():
         ref_logits = llm(input_ids=tok).logits.float()
         info = accelerate_elementwise(llm)
         assert info["rmsnorm"] == 2 * llm.config.num_hidden_layers + 1 and info["mlp"] == llm.config.num_hidden_layers and info["rope"] == 1
+        assert info["qkv"] == llm.config.num_hidden_layers
         got_n, got_m = norm(x), mlp(x)
         got_q, got_k = mq.apply_rotary_pos_emb(q, k, cos, sin)
         got_logits = llm(input_ids=tok).logits.float()
