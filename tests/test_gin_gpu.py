@@ -128,3 +128,36 @@ def test_bf16_engine(name):
     got = i.cpu().numpy()
     hits = np.mean([len(set(ref5[r]) & set(got[r][:10])) / 5.0 for r in range(G)])
     assert hits >= 0.8, hits
+
+
+def test_gin_edge_cases_vs_oracle():
+    """Isolated atoms / a bond-free graph / a single-graph batch / a high-degree hub, f32 engine vs the CPU oracle."""
+    from oracle import gin_oracle as go
+    L, H, out_dim, _, seed = GIN_CASES["gin_l3_h64"]
+    enc = _encoder("gin_l3_h64")
+    pred = _predictor("gin_l3_h64")
+    sd_e = synth.make_gin_weights(L, H, "encoder", seed=seed)
+    sd_p = synth.make_proj_weights(H, seed)
+    sd_r = synth.make_gin_weights(L, H, "predictor", out_dim, seed)
+    # graph 0: one atom, no bonds; graph 1: 3 atoms, one bond, one isolated atom; graph 2: hub with 9 neighbours
+    x = torch.tensor([5, 7, 8, 100, 6] + [1] * 9, dtype=torch.long)
+    hub = 4
+    src = [1, 2] + sum(([hub, hub + 1 + i] for i in range(9)), [])
+    dst = [2, 1] + sum(([hub + 1 + i, hub] for i in range(9)), [])
+    ei = torch.tensor([src, dst], dtype=torch.long)
+    ea = torch.tensor([2, 2] + [1 + (i % 4) for i in range(9) for _ in (0, 1)], dtype=torch.long)
+    batch = torch.tensor([0, 1, 1, 1] + [2] * 10, dtype=torch.long)
+    ref = go.graphclip_forward(sd_e, sd_p, L, x, ei, ea, batch).numpy()
+    got = enc(x.cuda(), ei.cuda(), ea.cuda(), batch.cuda()).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=5e-4)
+    c = torch.randn(3, 768, generator=torch.Generator().manual_seed(0))
+    refl = go.predictor_forward(sd_r, L, x, ei, ea, batch, c).numpy()
+    gotl = pred(x.cuda(), ei.cuda(), ea.cuda(), batch.cuda(), c.cuda()).cpu().numpy()
+    np.testing.assert_allclose(gotl, refl, rtol=3e-3, atol=2e-3)
+    # a batch that is one bond-free single atom
+    x1, e1, a1, b1 = torch.tensor([42]), torch.empty((2, 0), dtype=torch.long), torch.empty((0,), dtype=torch.long), torch.tensor([0])
+    ref1 = go.graphclip_forward(sd_e, sd_p, L, x1, e1, a1, b1).numpy()
+    got1 = enc(x1.cuda(), e1.cuda(), a1.cuda(), b1.cuda()).cpu().numpy()
+    np.testing.assert_allclose(got1, ref1, rtol=2e-3, atol=5e-4)
+    with pytest.raises(ValueError, match="condition rows"):
+        pred(x.cuda(), ei.cuda(), ea.cuda(), batch.cuda(), c[:2].cuda())
