@@ -181,6 +181,16 @@ def time_dominant_kernel(args, device):
         from llamole_amd.e2e import LLM_CONFIGS
         spec = LLM_CONFIGS[args.llm]
         M, N, K = args.batch, spec["intermediate_size"], spec["hidden_size"]
+        ms = C.c_float()
+        if args.llm_fuse and args.llm_layer_fuse and args.llm_decode != "hf" and M <= 4:
+            # the fused layer's gated-MLP kernel: RMSNorm prologue, gate|up rows streamed once, SiLU*mul epilogue
+            rows = 2 * N
+            nw = max(2, int(600e6 // (rows * K * 2)))
+            _lib.check(lib.ll_gemv_fused_bench(M, N, K, 2, 1, 1, 8 * nw, nw, C.byref(ms)), "ll_gemv_fused_bench")
+            name = (f"gemv_fused_kernel<{M},norm,silu_mul,nt>, LLM gated-MLP gate|up projection "
+                    f"[{M}x{K}]x[{rows}x{K}]^T bf16 + RMSNorm prologue + SiLU*mul epilogue (decode step)")
+            nbytes = rows * K * 2 + M * K * 2 + K * 2 + M * N * 2
+            return ms.value, nbytes, 2.0 * M * rows * K, name, f"llm_gemv_fused_m{M}_n{rows}_k{K}"
         name = f"gemv_bf16_kernel, LLM MLP up-projection [{M}x{K}]x[{N}x{K}]^T bf16 (decode step)"
         key = f"llm_gemv_m{M}_n{N}_k{K}"
     else:
@@ -215,6 +225,8 @@ def main():
     ap.add_argument("--llm", default="qwen2-7b")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--cutoff-len", type=int, default=128)
+    ap.add_argument("--no-llm-layer-fuse", dest="llm_layer_fuse", action="store_false",
+                    help="e2e: keep one launch per op inside a decoder layer (12 per layer) instead of the 5-launch fused layer")
     ap.add_argument("--no-llm-fuse", dest="llm_fuse", action="store_false",
                     help="keep HF's op-by-op RMSNorm / rotary / SiLU*mul at decode instead of the fused HIP kernels")
     ap.add_argument("--llm-decode", default="graph", choices=["graph", "eager", "hf"])

@@ -183,6 +183,31 @@ int ll_kv_append_bf16(void *K, void *V, const void *k_new, const void *v_new, co
 int ll_decode_attn_bf16(const void *q, const void *K, const void *V, const void *mask, void *out, int B, int nh, int nkv, int S,
                         int maxlen, int D, float scale, const int64_t *qstr, const int64_t *mstr, void *stream);
 
+/* ---- decode-step layer fusion (one decoder layer of the HF LLM at batch <= 4 = five launches) ----------------------------
+ * ll_gemv_fused_bf16 : out[M,N] = epilogue( rmsnorm?(x)[M,K] . W^T + bias ), M in 1..4, bf16 operands, f32 accumulation.
+ *     norm_w != NULL : x is first normalised like Qwen2RMSNorm/LlamaRMSNorm (K <= 8192, M*K <= 32768), eps as given;
+ *     epi LL_GEMV_PLAIN    : bf16(acc + bias)                                 (nn.Linear; fused q/k/v; lm_head)
+ *         LL_GEMV_RESIDUAL : bf16(residual + bf16(acc + bias))                (o_proj / down_proj + the layer's residual add)
+ *         LL_GEMV_SILU_MUL : W has 2N rows (gate rows [0,N), up rows [N,2N)): bf16(bf16(silu(gate)) * up)   (gated MLP)
+ *     Replaces <Model>RMSNorm.forward + nn.Linear.forward + the residual add / act_fn(gate)*up of
+ *     transformers modeling_qwen2.py Qwen2DecoderLayer.forward / Qwen2MLP.forward (bit-identical arithmetic).
+ * ll_decode_attn_rope_bf16 : apply_rotary_pos_emb + StaticLayer.update + attention for ONE new position per sequence.
+ *     qkv [B, (nh+2*nkv)*D] rows (stride ld_qkv) = fused q|k|v projection; cos/sin [B or 1, D] (batch stride cs_stride, 0 to
+ *     broadcast); Kc/Vc [B,nkv,maxlen,D] static cache, appended at *pos (device int64); mask bool [B,maxlen] rows
+ *     (stride mask_stride) for the new query; out [B, nh*D].  D in {64,128}.
+ * ll_gemv_fused_bench : timing utility (HIP events, `nweights` distinct weight matrices); ll_set_gemv_nt: toggle
+ *     non-temporal weight loads of ll_gemv_fused_bf16 (returns the previous setting). */
+#define LL_GEMV_PLAIN 0
+#define LL_GEMV_RESIDUAL 1
+#define LL_GEMV_SILU_MUL 2
+int ll_gemv_fused_bf16(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *norm_w, float eps,
+                       const void *residual, int ldr, void *out, int ldc, int M, int N, int K, int epi, void *stream);
+int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, const void *sin, int64_t cs_stride, void *Kc,
+                             void *Vc, const int64_t *pos, const void *mask, int64_t mask_stride, void *out, int B, int nh,
+                             int nkv, int maxlen, int D, float scale, void *stream);
+int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iters, int nweights, float *ms);
+int ll_set_gemv_nt(int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,458 @@
+// Decode-step layer kernels for an untouched HuggingFace Llama-family LLM: the twelve launches
+// of one decoder layer at batch <= 4 (RMSNorm, q/k/v GEMV, rotary, KV append, attention, o_proj GEMV, add, RMSNorm,
+// gate/up GEMV, SiLU*mul, down GEMV, add) become five:
+//   ll_gemv_fused_bf16       x W^T with an optional RMSNorm prologue on x and an epilogue: bias | residual add | SiLU(gate)*up
+//   ll_decode_attn_rope_bf16 rotary embedding of q and the new k, KV-cache append, GQA attention over the static cache
+// The arithmetic -- f32 accumulation order, every intermediate bf16 rounding PyTorch's op-by-op evaluation implies --
+// is the one of the unfused kernels (gemv_bf16_kernel, rmsnorm/rope/silu_mul/kv_append/decode_attn in llm_ops.hip),
+// so results are bit-identical to them; what goes away is seven launch boundaries and seven HBM/L2 round trips of
+// [B, hidden]-sized vectors per layer.
+#include "common.h"
+
+namespace ll {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bfr2(float v) { return bf16_to_f32(f32_to_bf16(v)); }   // round through bf16
+
+enum { GEMV_PLAIN = 0, GEMV_RESIDUAL = 1, GEMV_SILU_MUL = 2 };
+
+template <bool NT> __device__ __forceinline__ u32x4 ldw16(const bf16_t *p) {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return *reinterpret_cast<const u32x4 *>(p);
+}
+
+template <int UNR, bool NT>
+__device__ __forceinline__ void gemv_load_w(u32x4 (&wv)[UNR][2], const bf16_t *const (&wr)[2], int c0, int nchunk, bool active) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const int c = c0 + u * 64;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) wv[u][r] = (active && c < nchunk) ? ldw16<NT>(wr[r] + c * 8) : (u32x4)(0);
+    }
+}
+
+// acc += w . x over UNR 16-byte chunks per lane; x rows at xp + m*ldx (LDS when XLDS)
+template <int MROWS, int UNR, bool XLDS>
+__device__ __forceinline__ void gemv_fma(float (&acc)[MROWS][2], const u32x4 (&wv)[UNR][2], const bf16_t *xp, int64_t ldx, int c0,
+                                         int nchunk) {
+    u32x4 xv[UNR][MROWS];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const int c = c0 + u * 64;
+#pragma unroll
+        for (int m = 0; m < MROWS; ++m) xv[u][m] = c < nchunk ? *reinterpret_cast<const u32x4 *>(xp + (int64_t)m * ldx + c * 8) : (u32x4)(0);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+        for (int m = 0; m < MROWS; ++m) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                float a = acc[m][r];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    a = fmaf(__uint_as_float(wv[u][r][t] << 16), __uint_as_float(xv[u][m][t] << 16), a);
+                    a = fmaf(__uint_as_float(wv[u][r][t] & 0xffff0000u), __uint_as_float(xv[u][m][t] & 0xffff0000u), a);
+                }
+                acc[m][r] = a;
+            }
+        }
+    }
+}
+
+// Each wave owns two weight rows (GEMV_SILU_MUL: gate row n and up row n + N; otherwise rows 2w, 2w+1); a lane reads
+// 16 B of each row per step with UNR steps in flight, x comes from LDS (NORM: the workgroup normalises x once, with
+// the first weight loads already in flight) or from L1/L2.  f32 FMA chains in the lane/chunk order of gemv_bf16_kernel.
+template <int MROWS, bool NORM, int EPI, bool NT>
+__global__ __launch_bounds__(256) void gemv_fused_kernel(const bf16_t *__restrict__ X, int ldx, const bf16_t *__restrict__ W,
+                                                         int ldw, const float *__restrict__ bias,
+                                                         const bf16_t *__restrict__ normw, float eps,
+                                                         const bf16_t *__restrict__ res, int ldr, bf16_t *__restrict__ C,
+                                                         int ldc, int N, int K) {
+    constexpr int R = 2, UNR = MROWS == 1 ? 8 : 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_gemv[];
+    bf16_t *xs = reinterpret_cast<bf16_t *>(sm_gemv);   // NORM: [MROWS][K] normalised x
+    __shared__ float red[MROWS][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = blockIdx.x * 4 + (tid >> 6);
+    const int n0 = EPI == GEMV_SILU_MUL ? wave : wave * R;
+    const bool active = n0 < N;     // whole waves; inactive waves still take part in the NORM barriers
+    const bf16_t *wr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = EPI == GEMV_SILU_MUL ? (int64_t)(n0 < N ? n0 : N - 1) + (int64_t)r * N : (n0 + r < N ? n0 + r : N - 1);
+        wr[r] = W + row * ldw;
+    }
+    const int nchunk = K / 8;
+    u32x4 xv0[MROWS][4], nw0[4];
+    if (NORM) {   // x (and the norm weight) first: vmcnt retires in order, the weight loads below stay in flight
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ch = tid + c * 256;
+            const bool ok = ch < nchunk;
+#pragma unroll
+            for (int m = 0; m < MROWS; ++m) xv0[m][c] = ok ? *reinterpret_cast<const u32x4 *>(X + (int64_t)m * ldx + ch * 8) : (u32x4)(0);
+            nw0[c] = ok ? *reinterpret_cast<const u32x4 *>(normw + ch * 8) : (u32x4)(0);
+        }
+    }
+    u32x4 wv[UNR][R];
+    if (NORM) gemv_load_w<UNR, NT>(wv, wr, lane, nchunk, active);
+    if (NORM) {
+        // same summation order as rmsnorm_bf16_kernel: per-thread fmaf chain over its chunks, wave_sum, 4 partials
+#pragma unroll
+        for (int m = 0; m < MROWS; ++m) {
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float a = __uint_as_float(xv0[m][c][t] << 16), b = __uint_as_float(xv0[m][c][t] & 0xffff0000u);
+                    ss = fmaf(a, a, ss);
+                    ss = fmaf(b, b, ss);
+                }
+            ss = wave_sum(ss);
+            if (lane == 0) red[m][tid >> 6] = ss;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MROWS; ++m) {
+            const float var = (red[m][0] + red[m][1] + red[m][2] + red[m][3]) / (float)K;
+            const float rstd = rsqrtf(var + eps);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ch = tid + c * 256;
+                if (ch < nchunk) {
+                    u32x4 o;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float a = bfr2(__uint_as_float(xv0[m][c][t] << 16) * rstd) * __uint_as_float(nw0[c][t] << 16);
+                        const float b = bfr2(__uint_as_float(xv0[m][c][t] & 0xffff0000u) * rstd) * __uint_as_float(nw0[c][t] & 0xffff0000u);
+                        o[t] = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+                    }
+                    *reinterpret_cast<u32x4 *>(xs + (int64_t)m * K + ch * 8) = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    float acc[MROWS][R];
+#pragma unroll
+    for (int m = 0; m < MROWS; ++m)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
+    int cbeg = lane;
+    if (NORM) {   // first block: its weights were requested before the normalisation
+        gemv_fma<MROWS, UNR, true>(acc, wv, xs, K, lane, nchunk);
+        cbeg += 64 * UNR;
+    }
+    for (int c0 = cbeg; c0 < nchunk; c0 += 64 * UNR) {
+        gemv_load_w<UNR, NT>(wv, wr, c0, nchunk, true);
+        if (NORM) gemv_fma<MROWS, UNR, true>(acc, wv, xs, K, c0, nchunk);
+        else gemv_fma<MROWS, UNR, false>(acc, wv, X, ldx, c0, nchunk);
+    }
+#pragma unroll
+    for (int m = 0; m < MROWS; ++m) {
+        float v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = wave_sum(acc[m][r]);
+        if (lane == 0) {
+            if (EPI == GEMV_SILU_MUL) {
+                const float g = bfr2(v[0] + (bias ? bias[n0] : 0.f)), up = bfr2(v[1] + (bias ? bias[n0 + N] : 0.f));
+                C[(int64_t)m * ldc + n0] = f32_to_bf16(bfr2(silu(g)) * up);
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (n0 + r < N) {
+                        float o = v[r] + (bias ? bias[n0 + r] : 0.f);
+                        if (EPI == GEMV_RESIDUAL) o = bf16_to_f32(res[(int64_t)m * ldr + n0 + r]) + bfr2(o);
+                        C[(int64_t)m * ldc + n0 + r] = f32_to_bf16(o);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Rotary embedding + KV append + GQA decode attention for ONE new position per sequence.
+// grid (nh, B).  qkv row b = [q: nh*D | k: nkv*D | v: nkv*D] (output of the fused q/k/v GEMV).  The new key / value of
+// the head's KV group is rotated in LDS and used from there; the first query head of each group also stores it to the
+// cache at *pos.  Nobody reads cache slot *pos in this launch, so there is no cross-workgroup dependency.
+template <int D>
+__global__ __launch_bounds__(256) void decode_attn_rope_kernel(const bf16_t *__restrict__ qkv, int64_t ld_qkv,
+                                                               const bf16_t *__restrict__ cs, const bf16_t *__restrict__ sn,
+                                                               int64_t cs0, bf16_t *__restrict__ K, bf16_t *__restrict__ V,
+                                                               const long long *__restrict__ pos_ptr,
+                                                               const unsigned char *__restrict__ mask, int64_t ms0,
+                                                               bf16_t *__restrict__ out, int nh, int nkv, int maxlen, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm_attn2[];
+    float *qs = sm_attn2;                 // [D]     rotated query, f32 of its bf16 value
+    float *part = qs + D;                 // [4][D]  per-wave partial outputs
+    bf16_t *kn = reinterpret_cast<bf16_t *>(part + 4 * D);   // [D] rotated new key (bf16)
+    bf16_t *vn = kn + D;                  // [D] new value
+    float *sc = reinterpret_cast<float *>(vn + D);           // [maxlen] scores -> probabilities
+    __shared__ float red[8];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int group = nh / nkv, kvh = h / group;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long p = *pos_ptr;
+    const bool pvalid = p >= 0 && p < maxlen;
+    const bf16_t *row = qkv + b * ld_qkv;
+    const bf16_t *c = cs + b * cs0, *sv = sn + b * cs0;
+    constexpr int half = D / 2;
+    bf16_t *Kb = K + ((int64_t)b * nkv + kvh) * maxlen * D;
+    bf16_t *Vb = V + ((int64_t)b * nkv + kvh) * maxlen * D;
+    if (wave == 0) {
+        if (lane < half) {
+            const bf16_t *src = row + h * D;
+            const float x1 = bf16_to_f32(src[lane]), x2 = bf16_to_f32(src[lane + half]);
+            const float c1 = bf16_to_f32(c[lane]), c2 = bf16_to_f32(c[lane + half]);
+            const float s1 = bf16_to_f32(sv[lane]), s2 = bf16_to_f32(sv[lane + half]);
+            qs[lane] = bfr2(bfr2(x1 * c1) + bfr2(-x2 * s1));
+            qs[lane + half] = bfr2(bfr2(x2 * c2) + bfr2(x1 * s2));
+        }
+    } else if (wave == 1) {
+        if (lane < half) {
+            const bf16_t *src = row + (nh + kvh) * D;
+            const float x1 = bf16_to_f32(src[lane]), x2 = bf16_to_f32(src[lane + half]);
+            const float c1 = bf16_to_f32(c[lane]), c2 = bf16_to_f32(c[lane + half]);
+            const float s1 = bf16_to_f32(sv[lane]), s2 = bf16_to_f32(sv[lane + half]);
+            const bf16_t k1 = f32_to_bf16(bfr2(x1 * c1) + bfr2(-x2 * s1)), k2 = f32_to_bf16(bfr2(x2 * c2) + bfr2(x1 * s2));
+            kn[lane] = k1;
+            kn[lane + half] = k2;
+            if (pvalid && h % group == 0) {
+                Kb[p * D + lane] = k1;
+                Kb[p * D + lane + half] = k2;
+            }
+        }
+    } else if (wave == 2) {
+        if (lane < half) {
+            const bf16_t *src = row + (nh + nkv + kvh) * D;
+            const uint32_t v2 = *reinterpret_cast<const uint32_t *>(src + lane * 2);
+            *reinterpret_cast<uint32_t *>(vn + lane * 2) = v2;
+            if (pvalid && h % group == 0) *reinterpret_cast<uint32_t *>(Vb + p * D + lane * 2) = v2;
+        }
+    }
+    const unsigned char *mrow = mask + b * ms0;
+    __syncthreads();
+    for (int j = tid; j < maxlen; j += 256) {
+        const bool ok = mrow[j] != 0;
+        float dsum = 0.f;
+        if (ok) {
+            u32x4 kv[D / 8];
+            if (pvalid && j == p) {
+#pragma unroll
+                for (int ch = 0; ch < D / 8; ++ch) kv[ch] = *reinterpret_cast<const u32x4 *>(kn + ch * 8);
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < D / 8; ++ch) kv[ch] = *reinterpret_cast<const u32x4 *>(Kb + (int64_t)j * D + ch * 8);
+            }
+#pragma unroll
+            for (int ch = 0; ch < D / 8; ++ch) {
+                const float4 q0 = *reinterpret_cast<const float4 *>(qs + ch * 8);
+                const float4 q1 = *reinterpret_cast<const float4 *>(qs + ch * 8 + 4);
+                dsum = fmaf(q0.x, __uint_as_float(kv[ch][0] << 16), dsum);
+                dsum = fmaf(q0.y, __uint_as_float(kv[ch][0] & 0xffff0000u), dsum);
+                dsum = fmaf(q0.z, __uint_as_float(kv[ch][1] << 16), dsum);
+                dsum = fmaf(q0.w, __uint_as_float(kv[ch][1] & 0xffff0000u), dsum);
+                dsum = fmaf(q1.x, __uint_as_float(kv[ch][2] << 16), dsum);
+                dsum = fmaf(q1.y, __uint_as_float(kv[ch][2] & 0xffff0000u), dsum);
+                dsum = fmaf(q1.z, __uint_as_float(kv[ch][3] << 16), dsum);
+                dsum = fmaf(q1.w, __uint_as_float(kv[ch][3] & 0xffff0000u), dsum);
+            }
+        }
+        sc[j] = ok ? dsum * scale : -INFINITY;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = tid; j < maxlen; j += 256) mx = fmaxf(mx, sc[j]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < maxlen; j += 256) {
+        const float e = (sc[j] == -INFINITY) ? 0.f : expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    constexpr int EPL = D / 64;
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    for (int j0 = wave; j0 < maxlen; j0 += 32) {
+        float pj[8];
+        uint32_t vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + 4 * u;
+            pj[u] = j < maxlen ? sc[j] : 0.f;
+            vv[u] = 0;
+            if (pj[u] != 0.f) {
+                const bf16_t *vrow = (pvalid && j == p) ? nullptr : Vb + (int64_t)j * D;
+                if (vrow) {
+                    if (EPL == 2) vv[u] = *reinterpret_cast<const uint32_t *>(vrow + lane * 2);
+                    else vv[u] = *reinterpret_cast<const unsigned short *>(vrow + lane);
+                } else {
+                    if (EPL == 2) vv[u] = *reinterpret_cast<const uint32_t *>(vn + lane * 2);
+                    else vv[u] = vn[lane];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc[0] = fmaf(pj[u], __uint_as_float(vv[u] << 16), acc[0]);
+            if (EPL == 2) acc[EPL - 1] = fmaf(pj[u], __uint_as_float(vv[u] & 0xffff0000u), acc[EPL - 1]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) part[wave * D + lane * EPL + e] = acc[e];
+    __syncthreads();
+    if (tid < D) {
+        const float o = (part[tid] + part[D + tid] + part[2 * D + tid] + part[3 * D + tid]) * inv;
+        out[((int64_t)b * nh + h) * D + tid] = f32_to_bf16(o);
+    }
+}
+
+static int g_gemv_nt = 1;   // non-temporal weight loads (tools/gemv_fused_sweep.py)
+
+template <int MROWS, bool NORM, int EPI>
+static void launch_fused(bool nt, dim3 grid, size_t lds, hipStream_t s, const bf16_t *X, int ldx, const bf16_t *W, int ldw,
+                         const float *bias, const bf16_t *normw, float eps, const bf16_t *res, int ldr, bf16_t *C, int ldc, int N,
+                         int K) {
+    if (nt)
+        hipLaunchKernelGGL((gemv_fused_kernel<MROWS, NORM, EPI, true>), grid, dim3(256), lds, s, X, ldx, W, ldw, bias, normw, eps, res,
+                           ldr, C, ldc, N, K);
+    else
+        hipLaunchKernelGGL((gemv_fused_kernel<MROWS, NORM, EPI, false>), grid, dim3(256), lds, s, X, ldx, W, ldw, bias, normw, eps, res,
+                           ldr, C, ldc, N, K);
+}
+
+template <int MROWS>
+static int dispatch_fused(bool nt, hipStream_t s, const bf16_t *X, int ldx, const bf16_t *W, int ldw, const float *bias,
+                          const bf16_t *normw, float eps, const bf16_t *res, int ldr, bf16_t *C, int ldc, int N, int K, int epi) {
+    const bool norm = normw != nullptr;
+    const size_t lds = norm ? (size_t)MROWS * K * 2 : 0;
+    const dim3 grid(epi == GEMV_SILU_MUL ? cdiv(N, 4) : cdiv(N, 8));
+#define LL_FUSED_CASE(NORM_, EPI_)                                                                                          \
+    launch_fused<MROWS, NORM_, EPI_>(nt, grid, lds, s, X, ldx, W, ldw, bias, normw, eps, res, ldr, C, ldc, N, K)
+    if (norm) {
+        if (epi == GEMV_PLAIN) LL_FUSED_CASE(true, GEMV_PLAIN);
+        else if (epi == GEMV_RESIDUAL) LL_FUSED_CASE(true, GEMV_RESIDUAL);
+        else LL_FUSED_CASE(true, GEMV_SILU_MUL);
+    } else {
+        if (epi == GEMV_PLAIN) LL_FUSED_CASE(false, GEMV_PLAIN);
+        else if (epi == GEMV_RESIDUAL) LL_FUSED_CASE(false, GEMV_RESIDUAL);
+        else LL_FUSED_CASE(false, GEMV_SILU_MUL);
+    }
+#undef LL_FUSED_CASE
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+static int gemv_fused(bool nt, const void *x, int ldx, const void *W, int ldw, const float *bias, const void *norm_w, float eps,
+                      const void *residual, int ldr, void *out, int ldc, int M, int N, int K, int epi, hipStream_t s) {
+    LL_CHECK(x && W && out, "ll_gemv_fused_bf16: null argument");
+    LL_CHECK(M >= 1 && M <= 4, "ll_gemv_fused_bf16: M=%d rows (decode shapes only, 1..4)", M);
+    LL_CHECK(N >= 1 && K >= 8 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "ll_gemv_fused_bf16: K, ldx, ldw must be multiples of 8");
+    LL_CHECK(epi >= GEMV_PLAIN && epi <= GEMV_SILU_MUL, "ll_gemv_fused_bf16: epilogue %d", epi);
+    LL_CHECK(epi != GEMV_RESIDUAL || residual, "ll_gemv_fused_bf16: residual epilogue without a residual");
+    LL_CHECK(!norm_w || (K <= 8192 && (size_t)M * K * 2 <= 65536), "ll_gemv_fused_bf16: RMSNorm prologue needs K <= 8192 and M*K <= 32768");
+    const bf16_t *X = (const bf16_t *)x, *Wt = (const bf16_t *)W, *nw = (const bf16_t *)norm_w, *rs = (const bf16_t *)residual;
+    bf16_t *C = (bf16_t *)out;
+    switch (M) {
+        case 1: return dispatch_fused<1>(nt, s, X, ldx, Wt, ldw, bias, nw, eps, rs, ldr, C, ldc, N, K, epi);
+        case 2: return dispatch_fused<2>(nt, s, X, ldx, Wt, ldw, bias, nw, eps, rs, ldr, C, ldc, N, K, epi);
+        case 3: return dispatch_fused<3>(nt, s, X, ldx, Wt, ldw, bias, nw, eps, rs, ldr, C, ldc, N, K, epi);
+        default: return dispatch_fused<4>(nt, s, X, ldx, Wt, ldw, bias, nw, eps, rs, ldr, C, ldc, N, K, epi);
+    }
+}
+
+}  // namespace ll
+
+using namespace ll;
+
+extern "C" {
+
+int ll_gemv_fused_bf16(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *norm_w, float eps,
+                       const void *residual, int ldr, void *out, int ldc, int M, int N, int K, int epi, void *stream) {
+    return gemv_fused(g_gemv_nt != 0, x, ldx, W, ldw, bias, norm_w, eps, residual, ldr, out, ldc, M, N, K, epi, (hipStream_t)stream);
+}
+
+int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, const void *sin, int64_t cs_stride, void *Kc,
+                             void *Vc, const int64_t *pos, const void *mask, int64_t mask_stride, void *out, int B, int nh,
+                             int nkv, int maxlen, int D, float scale, void *stream) {
+    LL_CHECK(qkv && cos && sin && Kc && Vc && pos && mask && out, "ll_decode_attn_rope_bf16: null argument");
+    LL_CHECK((D == 64 || D == 128) && B >= 1 && nkv >= 1 && nh % nkv == 0 && maxlen >= 1 && maxlen <= 16384 && ld_qkv % 8 == 0,
+             "ll_decode_attn_rope_bf16: unsupported shape");
+    const size_t lds = (size_t)5 * D * 4 + (size_t)2 * D * 2 + (size_t)maxlen * 4;
+    dim3 grid(nh, B);
+    if (D == 128)
+        hipLaunchKernelGGL((decode_attn_rope_kernel<128>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t *)qkv, ld_qkv,
+                           (const bf16_t *)cos, (const bf16_t *)sin, cs_stride, (bf16_t *)Kc, (bf16_t *)Vc, (const long long *)pos,
+                           (const unsigned char *)mask, mask_stride, (bf16_t *)out, nh, nkv, maxlen, scale);
+    else
+        hipLaunchKernelGGL((decode_attn_rope_kernel<64>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t *)qkv, ld_qkv,
+                           (const bf16_t *)cos, (const bf16_t *)sin, cs_stride, (bf16_t *)Kc, (bf16_t *)Vc, (const long long *)pos,
+                           (const unsigned char *)mask, mask_stride, (bf16_t *)out, nh, nkv, maxlen, scale);
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+// Times ll_gemv_fused_bf16 on synthetic operands, cycling through `nweights` distinct weight matrices (defeats the
+// 256 MiB Infinity Cache).  norm != 0 adds the RMSNorm prologue; nt selects non-temporal weight loads.
+int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iters, int nweights, float *ms) {
+    LL_CHECK(ms && iters > 0 && nweights > 0 && M >= 1 && M <= 4, "bad argument");
+    const int rowsW = epi == GEMV_SILU_MUL ? 2 * N : N;
+    bf16_t *X = nullptr, *W = nullptr, *C = nullptr, *R = nullptr, *NW = nullptr;
+    LL_HIP(hipMalloc(&X, (size_t)4 * K * 2));
+    LL_HIP(hipMalloc(&NW, (size_t)K * 2));
+    LL_HIP(hipMalloc(&W, (size_t)nweights * rowsW * K * 2));
+    LL_HIP(hipMalloc(&C, (size_t)4 * N * 2));
+    LL_HIP(hipMalloc(&R, (size_t)4 * N * 2));
+    LL_HIP(hipMemset(X, 0x11, (size_t)4 * K * 2));
+    LL_HIP(hipMemset(NW, 0x11, (size_t)K * 2));
+    LL_HIP(hipMemset(R, 0x11, (size_t)4 * N * 2));
+    LL_HIP(hipMemset(W, 0x11, (size_t)nweights * rowsW * K * 2));
+    hipStream_t st;
+    LL_HIP(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    LL_HIP(hipEventCreate(&e0));
+    LL_HIP(hipEventCreate(&e1));
+    int rc = LL_OK;
+    for (int pass = 0; pass < 2 && rc == LL_OK; ++pass) {
+        if (pass == 1) (void)hipEventRecord(e0, st);
+        for (int i = 0; i < (pass ? iters : nweights) && rc == LL_OK; ++i)
+            rc = gemv_fused(nt != 0, X, K, W + (size_t)(i % nweights) * rowsW * K, K, nullptr, norm ? NW : nullptr, 1e-6f, R, N, C, N, M,
+                            N, K, epi, st);
+    }
+    (void)hipEventRecord(e1, st);
+    hipError_t he = hipEventSynchronize(e1);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    *ms = t / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(st);
+    (void)hipFree(X);
+    (void)hipFree(NW);
+    (void)hipFree(W);
+    (void)hipFree(C);
+    (void)hipFree(R);
+    if (rc != LL_OK) return rc;
+    LL_HIP(he);
+    return LL_OK;
+}
+
+int ll_set_gemv_nt(int on) {
+    const int old = g_gemv_nt;
+    g_gemv_nt = on ? 1 : 0;
+    return old;
+}
+
+}  // extern "C"

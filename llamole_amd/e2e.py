@@ -105,6 +105,9 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
             from .llm_accel import use_decode_attention
             fused = accelerate_elementwise(llm)
             fused["decode_attention"] = bool(use_decode_attention(llm))
+            if fused["decode_attention"] and args.llm_decode != "hf" and getattr(args, "llm_layer_fuse", True):
+                from .llm_accel import fuse_decoder_layers
+                fused["decoder_layers_5_launches"] = fuse_decoder_layers(llm)
     if args.llm_decode != "hf":
         orch.enable_graphed_decode(use_graph=(args.llm_decode == "graph"), fused_cache=bool(fused))
         fused["kv_append"] = bool(fused)

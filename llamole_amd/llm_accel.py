@@ -342,3 +342,135 @@ def fuse_cache_update(cache) -> int:
         if not getattr(l, "_ll_fused_update", False):
             make(l)
     return len(layers)
+
+
+# ------------------------------------------------------------------------------------------ whole decoder layer = 5 launches
+class _FusedLayer:
+    """Decode-step state of one HF decoder layer (Qwen2 / Llama / Mistral layout): concatenated q|k|v and gate|up weights
+    (shared with fuse_qkv / the MLP fusion when those ran first), f32 biases, norm weights.  ``run`` is
+    Qwen2DecoderLayer.forward (transformers modeling_qwen2.py) for ONE new token per sequence, batch <= 4:
+      qkv  = gemv(rmsnorm(h), Wqkv) ; a = rope+append+attention(qkv) ; h = h + gemv(a, Wo)
+      act  = silu(gate)*up of gemv(rmsnorm(h), Wgate|up) ; h = h + gemv(act, Wdown)"""
+
+    def __init__(self, lib, layer):
+        att, mlp = layer.self_attn, layer.mlp
+        self.lib = lib
+        self.layer_idx = att.layer_idx
+        q, k, v, o = att.q_proj, att.k_proj, att.v_proj, att.o_proj
+        grp = getattr(q, "_ll_qkv", None) or _QKVGroup(lib, q, k, v)
+        self.wqkv, self.bqkv = grp.w, grp.bias
+        self.nq, self.nkv_dim = q.out_features, k.out_features
+        self.D = att.head_dim
+        self.nh, self.nkv = self.nq // self.D, self.nkv_dim // self.D
+        self.H = q.in_features
+        self.scaling = float(att.scaling)
+        self.wo = o.weight.detach()
+        self.bo = o.bias.detach().float().contiguous() if o.bias is not None else None
+        wgu = getattr(mlp, "_ll_gate_up", None)
+        if wgu is None:
+            wgu = torch.cat([mlp.gate_proj.weight.detach(), mlp.up_proj.weight.detach()], dim=0).contiguous()
+            mlp._ll_gate_up = wgu
+        self.wgu = wgu
+        self.I = mlp.gate_proj.out_features
+        self.wdown = mlp.down_proj.weight.detach()
+        self.n1, self.n2 = layer.input_layernorm, layer.post_attention_layernorm
+        self.eps1, self.eps2 = float(self.n1.variance_epsilon), float(self.n2.variance_epsilon)
+
+    def eligible(self, h, mask, cache, pe) -> bool:
+        if not (h.is_cuda and h.dtype == torch.bfloat16 and h.dim() == 3 and h.shape[1] == 1 and h.shape[0] <= 4
+                and not torch.is_grad_enabled() and cache is not None and pe is not None and mask is not None):
+            return False
+        layers = getattr(cache, "layers", None)
+        if layers is None or self.layer_idx >= len(layers):
+            return False
+        cl = layers[self.layer_idx]
+        if not (getattr(cl, "_ll_fused_update", False) and cl.keys.dtype == torch.bfloat16 and cl.keys.is_contiguous()
+                and cl.values.is_contiguous()):
+            return False
+        cos = pe[0]
+        return (mask.dtype == torch.bool and mask.dim() == 4 and mask.shape[1] == 1 and mask.shape[2] == 1
+                and mask.shape[3] == cl.keys.shape[2] and mask.stride(3) == 1 and cos.dtype == torch.bfloat16
+                and cos.dim() == 3 and cos.shape[1] == 1 and cos.shape[2] == self.D and cos.stride(2) == 1
+                and pe[1].stride() == cos.stride() and h.is_contiguous())
+
+    def _gemv(self, x, w, bias, norm_w, eps, res, N, K, epi):
+        M = x.shape[0]
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+        rc = self.lib.ll_gemv_fused_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
+                                         norm_w.data_ptr() if norm_w is not None else None, eps,
+                                         res.data_ptr() if res is not None else None, res.stride(0) if res is not None else 0,
+                                         out.data_ptr(), N, M, N, K, epi, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "ll_gemv_fused_bf16")
+        return out
+
+    def run(self, h, mask, cache, pe):
+        B, H = h.shape[0], self.H
+        x = h.view(B, H)
+        cl = cache.layers[self.layer_idx]
+        pos = cache.layers[0].cumulative_length
+        cos, sin = pe
+        nqkv = self.nq + 2 * self.nkv_dim
+        qkv = self._gemv(x, self.wqkv, self.bqkv, self.n1.weight, self.eps1, None, nqkv, H, 0)
+        att = torch.empty(B, self.nq, dtype=torch.bfloat16, device=h.device)
+        rc = self.lib.ll_decode_attn_rope_bf16(qkv.data_ptr(), nqkv, cos.data_ptr(), sin.data_ptr(),
+                                               0 if cos.shape[0] == 1 else cos.stride(0), cl.keys.data_ptr(), cl.values.data_ptr(),
+                                               pos.data_ptr(), mask.data_ptr(), mask.stride(0), att.data_ptr(), B, self.nh, self.nkv,
+                                               cl.keys.shape[2], self.D, self.scaling, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "ll_decode_attn_rope_bf16")
+        h1 = self._gemv(att, self.wo, self.bo, None, 0.0, x, H, self.nq, 1)
+        act = self._gemv(h1, self.wgu, None, self.n2.weight, self.eps2, None, self.I, H, 2)
+        h2 = self._gemv(act, self.wdown, None, None, 0.0, h1, H, self.I, 1)
+        return h2.view(B, 1, H)
+
+
+def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
+                   position_embeddings=None, **kwargs):
+    st = self._ll_fused
+    if st.eligible(hidden_states, attention_mask, past_key_values, position_embeddings):
+        return st.run(hidden_states, attention_mask, past_key_values, position_embeddings)
+    return self._ll_layer_orig(hidden_states, attention_mask=attention_mask, position_ids=position_ids,
+                               past_key_values=past_key_values, use_cache=use_cache, position_embeddings=position_embeddings,
+                               **kwargs)
+
+
+def fuse_decoder_layers(model: nn.Module) -> int:
+    """Run every decoder layer of a Qwen2 / Llama / Mistral-layout HF model as five launches at decode (batch <= 4, static
+    cache with the fused append of ``fuse_cache_update``, boolean sdpa-style mask).  Any other call -- prefill, larger
+    batches, a dynamic cache -- takes the layer's previous forward.  Returns the number of patched layers."""
+    lib = _lib.load()
+    base = getattr(model, "model", model)
+    layers = getattr(base, "layers", None)
+    if layers is None:
+        return 0
+    n = 0
+    for layer in layers:
+        att, mlp = getattr(layer, "self_attn", None), getattr(layer, "mlp", None)
+        if att is None or mlp is None or hasattr(layer, "_ll_fused"):
+            continue
+        ok = (all(type(getattr(att, a, None)) is nn.Linear for a in ("q_proj", "k_proj", "v_proj", "o_proj"))
+              and all(type(getattr(mlp, a, None)) is nn.Linear for a in ("gate_proj", "up_proj", "down_proj"))
+              and _is_silu(getattr(mlp, "act_fn", None)) and hasattr(layer, "input_layernorm")
+              and hasattr(layer, "post_attention_layernorm") and hasattr(layer.input_layernorm, "variance_epsilon")
+              and att.q_proj.weight.dtype == torch.bfloat16 and att.q_proj.weight.is_cuda
+              and getattr(att, "head_dim", 0) in (64, 128) and att.q_proj.in_features % 8 == 0
+              and att.q_proj.in_features <= 8192 and mlp.gate_proj.bias is None and mlp.up_proj.bias is None
+              and mlp.down_proj.bias is None and getattr(att, "sliding_window", None) is None
+              and not hasattr(att, "q_norm"))
+        if not ok:
+            continue
+        layer._ll_fused = _FusedLayer(lib, layer)
+        layer._ll_layer_orig = layer.forward
+        layer.forward = types.MethodType(_layer_forward, layer)
+        n += 1
+    return n
+
+
+def restore_decoder_layers(model: nn.Module) -> None:
+    base = getattr(model, "model", model)
+    for layer in getattr(base, "layers", []):
+        if "_ll_fused" in layer.__dict__:
+            del layer.__dict__["forward"]
+            del layer.__dict__["_ll_fused"]
+            del layer.__dict__["_ll_layer_orig"]

@@ -155,3 +155,92 @@ def test_decode_attention_and_fused_cache():
     got_g = g.generate(prompt, mask, **kw)
     assert torch.equal(got_g, got)
     assert torch.equal(g.generate(prompt, mask, **kw), got)     # graph + cache reuse after reset
+
+
+@pytest.mark.gpu
+def test_fused_decoder_layers_bit_identical():
+    """The 5-launch decoder layer (RMSNorm-prologue GEMVs, rope+append+attention, residual / SiLU*mul epilogues) against the
+    one-launch-per-op accelerated path: same kernels' arithmetic in the same order -> identical tokens, logits and cache."""
+    from llamole_amd.llm_accel import (accelerate_elementwise, accelerate_linears, fuse_decoder_layers, restore_decoder_layers,
+                                       restore_elementwise, restore_linears, use_decode_attention)
+    for rows in (2, 1):
+        llm, prompt, mask = _case("cuda", torch.bfloat16)
+        prompt, mask = prompt[:rows], mask[:rows]
+        kw = dict(max_new_tokens=12, do_sample=False, pad_token_id=0, eos_token_id=[2047])
+        assert accelerate_linears(llm, min_weight_elems=1) > 0
+        accelerate_elementwise(llm)
+        assert use_decode_attention(llm)
+        base = GraphedDecoder(llm, use_graph=False, fused_cache=True)
+        ref = base.generate(prompt, mask, **kw)
+        ref_logits = base.last_logits.clone()
+        ref_kv = [(l.keys.clone(), l.values.clone()) for l in base.cache.layers]
+        try:
+            assert fuse_decoder_layers(llm) == llm.config.num_hidden_layers
+            dec = GraphedDecoder(llm, use_graph=False, fused_cache=True)
+            got = dec.generate(prompt, mask, **kw)
+            assert torch.equal(got, ref)
+            assert torch.equal(dec.last_logits, ref_logits)
+            for (k, v), l in zip(ref_kv, dec.cache.layers):
+                assert torch.equal(l.keys, k) and torch.equal(l.values, v)
+            g = GraphedDecoder(llm, use_graph=True, fused_cache=True)
+            assert torch.equal(g.generate(prompt, mask, **kw), ref)
+            assert torch.equal(g.last_logits, ref_logits)
+            assert torch.equal(g.generate(prompt, mask, **kw), ref)
+            # sampling path runs too and is reproducible
+            gen = torch.Generator(device="cuda").manual_seed(3)
+            s1 = g.generate(prompt, mask, max_new_tokens=12, do_sample=True, temperature=0.6, top_p=0.9, pad_token_id=0, generator=gen)
+            gen.manual_seed(3)
+            s2 = g.generate(prompt, mask, max_new_tokens=12, do_sample=True, temperature=0.6, top_p=0.9, pad_token_id=0, generator=gen)
+            assert torch.equal(s1, s2)
+            restore_decoder_layers(llm)
+            assert torch.equal(GraphedDecoder(llm, use_graph=False, fused_cache=True).generate(prompt, mask, **kw), ref)
+        finally:
+            restore_decoder_layers(llm)
+            restore_elementwise(llm)
+            restore_linears(llm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+def test_gemv_fused_epilogues_vs_torch(M):
+    """ll_gemv_fused_bf16 through the C ABI against op-by-op PyTorch (RMSNorm as HF writes it, F.linear in f32 accumulate,
+    residual add / silu*mul with bf16 roundings).  N not a multiple of the 8 rows a workgroup owns; K spans two blocks."""
+    import torch.nn.functional as F
+    from llamole_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M)
+    K, N = 4608, 1003
+    x = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(2 * N, K, generator=g) * 0.02).bfloat16().cuda()
+    bias = torch.randn(2 * N, generator=g).float().cuda()
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().cuda()
+    res = torch.randn(M, N, generator=g).bfloat16().cuda()
+    eps = 1e-6
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(epi, norm, use_bias):
+        out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.ll_gemv_fused_bf16(x.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if use_bias else None,
+                                          nw.data_ptr() if norm else None, eps, res.data_ptr() if epi == 1 else None, N,
+                                          out.data_ptr(), N, M, N, K, epi, s), "ll_gemv_fused_bf16")
+        return out
+
+    def rms(v):
+        f = v.float()
+        f = f * torch.rsqrt(f.pow(2).mean(-1, keepdim=True) + eps)
+        return nw * f.to(torch.bfloat16)
+
+    for norm in (False, True):
+        xin = rms(x) if norm else x
+        for use_bias in (False, True):
+            b = bias if use_bias else torch.zeros_like(bias)
+            full = (xin.float() @ w.float().t() + b).to(torch.bfloat16)           # [M, 2N] as nn.Linear would round it
+            got = run(0, norm, use_bias)
+            torch.testing.assert_close(got.float(), full[:, :N].float(), rtol=2e-2, atol=2e-2)
+            got = run(1, norm, use_bias)
+            torch.testing.assert_close(got.float(), (res + full[:, :N]).float(), rtol=2e-2, atol=3e-2)
+            got = run(2, norm, use_bias)
+            torch.testing.assert_close(got.float(), (F.silu(full[:, :N]) * full[:, N:]).float(), rtol=3e-2, atol=3e-2)
+    # error behaviour: shapes outside the decode envelope are refused, not silently mis-computed
+    assert lib.ll_gemv_fused_bf16(x.data_ptr(), K, w.data_ptr(), K, None, None, eps, None, 0, res.data_ptr(), N, 5, N, K, 0, s) == -1   # LL_EINVAL
+    assert lib.ll_gemv_fused_bf16(x.data_ptr(), K, w.data_ptr(), K, None, None, eps, None, 0, res.data_ptr(), N, M, N, K, 1, s) == -1   # LL_EINVAL

@@ -1,15 +1,23 @@
-"""Run only the dominant GEMM (block MLP fc1 at the bench's token count) a few times: target for rocprofv3 --pmc.
-usage: gemm_one.py M [N K]   (no torch import: keeps the profiled process minimal)"""
+"""Run only one dominant kernel a few times: target for rocprofv3 --pmc (no torch import: keeps the profiled process minimal).
+usage: gemm_one.py M [N K]                     ll_linear dispatch (GraphDiT fc1 GEMM / unfused LLM GEMV)
+       gemm_one.py fused M N K EPI NORM        ll_gemv_fused_bf16 (EPI 0 plain | 1 residual | 2 silu_mul over 2N rows)"""
 import ctypes as C
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llamole_amd import _lib
 lib = _lib.load()
-M = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-K = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 ms = C.c_float()
-nw = 48   # 48 x 8 MB of weights: > 256 MiB Infinity Cache, so every launch streams its weights from HBM
-_lib.check(lib.ll_gemm_bench(M, N, K, -1, 1, 0, 2 * nw, nw, C.byref(ms)))
-print(f"M={M} N={N} K={K} avg {ms.value*1e3:.2f} us")
+if len(sys.argv) > 1 and sys.argv[1] == "fused":
+    M, N, K, epi, norm = (int(a) for a in sys.argv[2:7])
+    rows = 2 * N if epi == 2 else N
+    nw = max(2, int(600e6 // (rows * K * 2)))   # > 256 MiB Infinity Cache: every launch streams its weights from HBM
+    _lib.check(lib.ll_gemv_fused_bench(M, N, K, epi, norm, 1, 8 * nw, nw, C.byref(ms)))
+    print(f"fused M={M} N={N} K={K} epi={epi} norm={norm} avg {ms.value*1e3:.2f} us")
+else:
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    K = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    nw = 48   # 48 x 8 MB of weights: > 256 MiB Infinity Cache, so every launch streams its weights from HBM
+    _lib.check(lib.ll_gemm_bench(M, N, K, -1, 1, 0, 2 * nw, nw, C.byref(ms)))
+    print(f"M={M} N={N} K={K} avg {ms.value*1e3:.2f} us")
