@@ -208,6 +208,20 @@ int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, c
 int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iters, int nweights, float *ms);
 int ll_set_gemv_nt(int on);
 
+/* ll_sample_token_bf16 : one decode-loop sampling step per row in ONE launch -- HF TemperatureLogitsWarper + TopPLogitsWarper
+ *     + softmax + multinomial (transformers generation/logits_process.py, generation/utils.py _sample; the reference reaches
+ *     them through language_model.generate(do_sample, temperature, top_p), modeling_llamole.py:599/:849) and the loop's
+ *     bookkeeping.  logits bf16 [B,V] (row stride ld, V % 8 == 0, V <= 163840); inv_temp = 1/temperature; greedy != 0
+ *     = argmax (lowest index on ties).  A value is kept iff the probability mass strictly above it is < top_p; ties with
+ *     the boundary value are all kept.  Randomness: Philox4x32-10 keyed by *seed (device int64), counter (step[b], b).
+ *     Per row b: t = step[b]; token = done[b] ? pad : sampled; out_tokens[b*ld_out + t] = tok[b] = token;
+ *     done[b] |= token in eos[0..n_eos); step[b] = t+1; if advance: posid[b] += 1, pos[0] += 1 (either may be NULL).
+ *     dbg (optional, [B,4] uint64): Z, kept mass (2^-40 fixed point), boundary key, sampled key -- parity taps. */
+int ll_sample_token_bf16(const void *logits, int64_t ld, int B, int V, float inv_temp, float top_p, int greedy,
+                         const int64_t *seed, const int64_t *eos, int n_eos, int64_t pad, void *done, int64_t *tok,
+                         int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid, int64_t *pos,
+                         int advance, uint64_t *dbg, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,332 @@
+// Next-token sampler of the LLM decode loop as ONE launch: HF TemperatureLogitsWarper +
+// TopPLogitsWarper + softmax + multinomial (transformers generation/logits_process.py; the reference calls them through
+// language_model.generate(do_sample, temperature, top_p), modeling_llamole.py:599/:849) plus the loop's bookkeeping
+// (pad rows that already stopped, EOS test, write the token into the output buffer and the next step's input, advance the
+// position counters).  The op-by-op PyTorch version is ~25 launches per token incl. a full sort of the vocabulary
+// (~0.2 ms at V = 152 k); here one workgroup per row keeps the whole row of bf16 logits in registers:
+//   1. order-preserving 16-bit keys, row maximum;
+//   2. an EXACT count histogram in LDS over the 36 864 keys below the maximum (bf16 logits take few distinct values: one
+//      bin per value; integer atomics, so the result is deterministic and order-independent); keys further down (more than
+//      288 binades away: mass 0 for any practical temperature) are summed into one tail mass;
+//   3. per non-empty bin mass = count * exp(l/T - max) in 2^-40 fixed point; descending scan -> the lowest value whose
+//      mass-above is < top_p * Z = the nucleus boundary, and the kept mass M;
+//   4. one Philox draw R in [0, M) -> the sampled VALUE and a rank among the tokens sharing it (equal logits = equal
+//      probability);  5. the rank-th such token.
+// exp is evaluated per distinct value (a few thousand), not per token; the per-token work is integer compares.
+// Nucleus semantics: a value v is kept iff the probability mass strictly above v is < top_p (HF: ascending cumulative sum
+// > 1 - top_p); tokens tied with the boundary value are all kept (torch.sort leaves their order unspecified).
+#include "common.h"
+
+namespace ll {
+
+struct SampleArgs {
+    const bf16_t *logits;      // [B, V] bf16, row stride ld
+    int64_t ld;
+    int V;
+    float inv_temp;            // 1 / temperature (f32, as PyTorch's tensor / python-scalar computes it)
+    float top_p;
+    int greedy;
+    const long long *seed;     // device, [1]
+    const long long *eos;      // device, [n_eos] (-1 = unused slot)
+    int n_eos;
+    long long pad;
+    unsigned char *done;       // [B]
+    long long *tok;            // [B]   next step's input ids
+    long long *out_tokens;     // [B, max_new], row stride ld_out, column step[b]
+    int64_t ld_out;
+    int max_new;
+    long long *step;           // [B]
+    long long *posid;          // [B] or null
+    long long *pos;            // [1] or null
+    int advance;               // also advance posid / pos (decode-loop use)
+    unsigned long long *dbg;   // optional [B,4]: Z, kept mass, boundary key, sampled key
+};
+
+__device__ __forceinline__ uint32_t key_of(uint32_t x) {   // x: raw bf16 bits (16 low bits), NaN -> 0, inf -> +-max
+    const uint32_t ex = (x >> 7) & 0xffu;
+    if (ex == 0xffu) x = (x & 0x7fu) ? 0u : ((x & 0x8000u) | 0x7f7fu);
+    return (x & 0x8000u) ? (~x & 0xffffu) : (x | 0x8000u);
+}
+// both halves of a packed pair of bf16 -> packed pair of keys
+__device__ __forceinline__ uint32_t keys_of_pair(uint32_t wv) {
+    uint32_t lo = wv & 0xffffu, hi = wv >> 16;
+    const uint32_t alo = lo & 0x7fffu, ahi = hi & 0x7fffu;
+    lo = alo > 0x7f80u ? 0u : (alo == 0x7f80u ? lo - 1u : lo);       // NaN -> 0, +-inf -> +-max finite
+    hi = ahi > 0x7f80u ? 0u : (ahi == 0x7f80u ? hi - 1u : hi);
+    const uint32_t x = lo | (hi << 16);
+    const uint32_t msk = (((x >> 15) & 0x00010001u) * 0xffffu) | 0x80008000u;   // negative: flip all bits; else set the sign bit
+    return x ^ msk;
+}
+__device__ __forceinline__ float val_of(uint32_t k) {
+    const uint32_t x = (k & 0x8000u) ? (k & 0x7fffu) : (~k & 0xffffu);
+    return __uint_as_float(x << 16);
+}
+__device__ __forceinline__ float scaled(uint32_t k, float inv_temp) {
+    return fminf(fmaxf(val_of(k) * inv_temp, -3.0e38f), 3.0e38f);
+}
+__device__ __forceinline__ unsigned long long mass_of(uint32_t k, float inv_temp, float m) {
+    return (unsigned long long)(__expf(scaled(k, inv_temp) - m) * 1099511627776.0f);   // 2^40 fixed point
+}
+
+// Opaque to the optimiser: stops it from unpacking all keys once and keeping 2x the registers live across the passes.
+template <int CH> __device__ __forceinline__ void reg_fence(uint32_t (&w)[CH][4]) {
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(w[k][t]));
+}
+
+constexpr int SAMPLE_BPT = 36;                      // histogram bins per thread
+constexpr int SAMPLE_W = SAMPLE_BPT * 1024;         // key window below the row maximum held in LDS (147 KB of counters)
+
+template <int CH>
+__global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
+    __shared__ uint32_t cnt[SAMPLE_W];              // cnt[d] = number of tokens whose key is kmax - d
+    __shared__ unsigned long long wsum[16];
+    __shared__ float redf[16];
+    __shared__ unsigned int redu[16];
+    __shared__ unsigned long long sh_tail, sh_R;
+    __shared__ unsigned int sh_d, sh_key, sh_rank, sh_tok;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bf16_t *row = a.logits + (int64_t)b * a.ld;
+    const int nchunk = a.V / 8;
+    uint32_t w[CH][4];   // two 16-bit keys per word; key 0 = no element
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int c = tid + k * 1024;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c < nchunk) v = *reinterpret_cast<const uint4 *>(row + (int64_t)c * 8);
+        w[k][0] = v.x; w[k][1] = v.y; w[k][2] = v.z; w[k][3] = v.w;
+    }
+    if (!a.greedy) {
+#pragma unroll
+        for (int i = 0; i < SAMPLE_BPT; ++i) cnt[i * 1024 + tid] = 0;
+    }
+    if (tid == 0) { sh_tail = 0; sh_d = 0; sh_tok = 0; }
+    reg_fence<CH>(w);
+    uint32_t kmaxi = 0;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const bool ok = tid + k * 1024 < nchunk;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t kk = ok ? keys_of_pair(w[k][t]) : 0u;
+            w[k][t] = kk;
+            kmaxi = max(kmaxi, max(kk & 0xffffu, kk >> 16));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float kmaxf = wave_max((float)kmaxi);
+    if (lane == 0) redf[wave] = kmaxf;
+    __syncthreads();
+    float km = redf[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) km = fmaxf(km, redf[i]);
+    const uint32_t kmax = (uint32_t)km;
+    const float m = scaled(kmax, a.inv_temp);
+    uint32_t k2 = kmax;      // the value to pick a token of
+    uint32_t rank = 0;
+    if (!a.greedy) {
+        // ---- 2. exact count histogram over the key window [kmax - W + 1, kmax]; anything below goes to one tail mass
+        reg_fence<CH>(w);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const uint32_t key = hh ? (w[k][t] >> 16) : (w[k][t] & 0xffffu);
+                    const uint32_t d = kmax - key;
+                    if (key) {
+                        if (d < (uint32_t)SAMPLE_W) atomicAdd(&cnt[d], 1u);
+                        else {
+                            const unsigned long long q = mass_of(key, a.inv_temp, m);
+                            if (q) atomicAdd(&sh_tail, q);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        // ---- 3. thread t owns d in [36 t, 36 t + 36), descending values: masses = count * 2^-40 fixed-point exp
+        const int d0 = tid * SAMPLE_BPT;
+        unsigned long long lsum = 0;
+        for (int i = 0; i < SAMPLE_BPT; ++i) {
+            const uint32_t c = cnt[d0 + i];
+            if (c && (uint32_t)(d0 + i) < kmax) lsum += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
+        }
+        unsigned long long inc = lsum;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const unsigned long long o = __shfl_up(inc, dd, 64);
+            if (lane >= dd) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned long long base = 0, Z = sh_tail;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i < wave) base += wsum[i];
+            Z += wsum[i];
+        }
+        const unsigned long long excl = base + inc - lsum;
+        const unsigned long long Tq = a.top_p >= 1.f ? ~0ull : (unsigned long long)((double)a.top_p * (double)Z);
+        // boundary: the lowest value whose mass-above is still < Tq (mass-above is non-decreasing in d)
+        {
+            unsigned long long A = excl;
+            int last = -1;
+            for (int i = 0; i < SAMPLE_BPT; ++i) {
+                const uint32_t c = cnt[d0 + i];
+                if (c && (uint32_t)(d0 + i) < kmax) {
+                    if (A < Tq) last = d0 + i;
+                    A += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
+                }
+            }
+            if (last >= 0) atomicMax(&sh_d, (unsigned int)last);
+        }
+        __syncthreads();
+        const uint32_t dtau = sh_d;      // 0 when nothing else qualifies: the top value is always kept
+        if (dtau >= (uint32_t)d0 && dtau < (uint32_t)(d0 + SAMPLE_BPT)) {
+            unsigned long long A = excl;
+            for (int i = 0; i < SAMPLE_BPT; ++i) {
+                const uint32_t c = cnt[d0 + i];
+                if (c && (uint32_t)(d0 + i) < kmax) {
+                    A += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
+                    if ((uint32_t)(d0 + i) == dtau) break;
+                }
+            }
+            unsigned long long M = A;    // kept mass: everything down to and including the boundary value
+            if (a.top_p >= 1.f) M = Z;   // tail included when nothing is filtered
+            const unsigned long long sd = (unsigned long long)*a.seed;
+            const unsigned long long st = (unsigned long long)a.step[b];
+            const uint4 rnd = philox4x32(make_uint4((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)b, 0x5A17u),
+                                         make_uint2((uint32_t)sd, (uint32_t)(sd >> 32)));
+            const unsigned long long r64 = ((unsigned long long)rnd.x << 32) | rnd.y;
+            sh_R = __umul64hi(r64, M);
+            if (a.dbg) { a.dbg[b * 4 + 0] = Z; a.dbg[b * 4 + 1] = M; a.dbg[b * 4 + 2] = kmax - dtau; }
+        }
+        if (tid == 0) { sh_key = kmax; sh_rank = 0; }
+        __syncthreads();
+        // ---- 4. the value whose mass interval contains R, and the rank among the tokens sharing it
+        const unsigned long long R = sh_R;
+        if (R >= excl && R < excl + lsum) {
+            unsigned long long A = excl;
+            for (int i = 0; i < SAMPLE_BPT; ++i) {
+                const uint32_t c = cnt[d0 + i];
+                if (c && (uint32_t)(d0 + i) < kmax) {
+                    const unsigned long long q = mass_of(kmax - (d0 + i), a.inv_temp, m);
+                    const unsigned long long ms = (unsigned long long)c * q;
+                    if (R < A + ms) {
+                        unsigned long long r = q ? (R - A) / q : 0;
+                        if (r >= c) r = c - 1;
+                        sh_key = kmax - (d0 + i);
+                        sh_rank = (uint32_t)r;
+                        break;
+                    }
+                    A += ms;
+                }
+            }
+        }
+        __syncthreads();
+        k2 = sh_key;      // (R in the tail mass, possible only with top_p >= 1 and a > 288-binade spread: the top value)
+        rank = sh_rank;
+        if (a.dbg && tid == 0) a.dbg[b * 4 + 3] = k2;
+    }
+    // ---- 5. the rank-th token whose key is k2 (greedy: the lowest index holding the maximum, like torch.argmax)
+    reg_fence<CH>(w);
+    uint32_t cntm = 0, minidx = 0xffffffffu;
+    uint32_t tid_a = tid;                       // opaque copies: keep the 4*CH token indices from being hoisted and
+    asm volatile("" : "+v"(tid_a));             // held live across the two passes below
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t base_idx = (tid_a + k * 1024) * 8 + t * 2;
+            if ((w[k][t] & 0xffffu) == k2) { ++cntm; minidx = min(minidx, base_idx); }
+            if ((w[k][t] >> 16) == k2) { ++cntm; minidx = min(minidx, base_idx + 1); }
+        }
+    if (a.greedy) {
+        float mi = -(float)minidx;            // indices < 2^24: exact in f32
+        mi = wave_max(mi);
+        if (lane == 0) redf[wave] = mi;
+        __syncthreads();
+        if (tid == 0) {
+            float best = redf[0];
+            for (int i = 1; i < 16; ++i) best = fmaxf(best, redf[i]);
+            sh_tok = (uint32_t)(-best);
+        }
+    } else {
+        uint32_t inc = cntm;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t o = __shfl_up(inc, dd, 64);
+            if (lane >= dd) inc += o;
+        }
+        if (lane == 63) redu[wave] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < wave) base += redu[i];
+        const uint32_t excl = base + inc - cntm;
+        if (cntm && rank >= excl && rank < excl + cntm) {
+            uint32_t left = rank - excl, found = 0xffffffffu;
+            reg_fence<CH>(w);
+            uint32_t tid_b = tid;
+            asm volatile("" : "+v"(tid_b));
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t base_idx = (tid_b + k * 1024) * 8 + t * 2;
+                    if ((w[k][t] & 0xffffu) == k2) { if (left == 0 && found == 0xffffffffu) found = base_idx; --left; }
+                    if ((w[k][t] >> 16) == k2) { if (left == 0 && found == 0xffffffffu) found = base_idx + 1; --left; }
+                }
+            sh_tok = found;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const long long t = a.step[b];
+        long long nxt = a.done[b] ? a.pad : (long long)sh_tok;
+        if (t >= 0 && t < a.max_new) a.out_tokens[(int64_t)b * a.ld_out + t] = nxt;
+        a.tok[b] = nxt;
+        bool stop = false;
+        for (int i = 0; i < a.n_eos; ++i) stop = stop || (a.eos[i] == nxt);
+        if (stop) a.done[b] = 1;
+        a.step[b] = t + 1;
+        if (a.advance) {
+            if (a.posid) a.posid[b] += 1;
+            if (a.pos && b == 0) a.pos[0] += 1;
+        }
+    }
+}
+
+}  // namespace ll
+
+using namespace ll;
+
+extern "C" int ll_sample_token_bf16(const void *logits, int64_t ld, int B, int V, float inv_temp, float top_p, int greedy,
+                                    const int64_t *seed, const int64_t *eos, int n_eos, int64_t pad, void *done, int64_t *tok,
+                                    int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid,
+                                    int64_t *pos, int advance, uint64_t *dbg, void *stream) {
+    LL_CHECK(logits && seed && done && tok && out_tokens && step && (n_eos == 0 || eos), "ll_sample_token_bf16: null argument");
+    LL_CHECK(B >= 1 && V >= 8 && V % 8 == 0 && V <= 1024 * 8 * 20 && ld % 8 == 0,
+             "ll_sample_token_bf16: vocabulary %d must be a multiple of 8 and <= 163840", V);
+    LL_CHECK(greedy || (inv_temp > 0.f && top_p >= 0.f), "ll_sample_token_bf16: temperature and top_p must be positive");
+    SampleArgs a;
+    a.logits = (const bf16_t *)logits; a.ld = ld; a.V = V; a.inv_temp = inv_temp; a.top_p = top_p; a.greedy = greedy;
+    a.seed = (const long long *)seed; a.eos = (const long long *)eos; a.n_eos = n_eos; a.pad = pad;
+    a.done = (unsigned char *)done; a.tok = (long long *)tok; a.out_tokens = (long long *)out_tokens; a.ld_out = ld_out;
+    a.max_new = max_new; a.step = (long long *)step; a.posid = (long long *)posid; a.pos = (long long *)pos;
+    a.advance = advance; a.dbg = (unsigned long long *)dbg;
+    hipStream_t s = (hipStream_t)stream;
+    const int per = cdiv(V, 8 * 1024);
+    if (per <= 2) hipLaunchKernelGGL((sample_token_kernel<2>), dim3(B), dim3(1024), 0, s, a);
+    else if (per <= 8) hipLaunchKernelGGL((sample_token_kernel<8>), dim3(B), dim3(1024), 0, s, a);
+    else if (per <= 16) hipLaunchKernelGGL((sample_token_kernel<16>), dim3(B), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL((sample_token_kernel<20>), dim3(B), dim3(1024), 0, s, a);
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}

@@ -34,12 +34,20 @@ def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float, generat
     return torch.multinomial(probs, 1, generator=generator).squeeze(1)
 
 
+MAX_HIP_VOCAB = 163840   # ll_sample_token_bf16 keeps a whole row of logits in one workgroup's registers
+N_EOS_SLOTS = 32
+
+
 class GraphedDecoder:
-    def __init__(self, model, use_graph: bool = True, sync_every: int = 16, fused_cache: bool = False):
+    def __init__(self, model, use_graph: bool = True, sync_every: int = 16, fused_cache: bool = False, sampler: str = "hip"):
         self.model = model
         self.use_graph = use_graph and next(model.parameters()).is_cuda
         self.sync_every = sync_every
         self.fused_cache = fused_cache    # one fused KV-append launch per layer (llm_accel.fuse_cache_update)
+        # "hip": on a HIP device with bf16 logits the sampler (temperature / top-p / multinomial, or argmax) and the loop
+        # bookkeeping are ONE launch inside the captured step (ll_sample_token_bf16); "torch": op-by-op PyTorch sampler
+        self.sampler = sampler
+        self._sample_key = None
         self._cache_fused = False
         self._key = None
         self._graph = None
@@ -58,6 +66,11 @@ class GraphedDecoder:
         self.pos = torch.zeros(1, dtype=torch.long, device=device)
         self.mask = torch.zeros(B, max_len, dtype=torch.long, device=device)
         self.posid = torch.zeros(B, 1, dtype=torch.long, device=device)   # static: the captured graph reads it
+        self.out_buf = torch.zeros(B, max_len, dtype=torch.long, device=device)
+        self.done = torch.zeros(B, dtype=torch.uint8, device=device)
+        self.stepc = torch.zeros(B, dtype=torch.long, device=device)
+        self.seed_buf = torch.zeros(1, dtype=torch.long, device=device)
+        self.eos_buf = torch.full((N_EOS_SLOTS,), -1, dtype=torch.long, device=device)
         self.logits = None
         self._graph = None
         self._cache_fused = False
@@ -73,6 +86,62 @@ class GraphedDecoder:
         layers = self.cache.layers[:1] if self._cache_fused else self.cache.layers
         for layer in layers:
             layer.cumulative_length.sub_(n)
+
+    def _hip_sample(self, logits: torch.Tensor, sp, advance: int):
+        """One launch: sample (or argmax) from bf16 logits [B,V], write tok / out_buf[:, step], update done / step and,
+        with ``advance``, the position counters the next forward reads."""
+        from . import _lib
+        greedy, inv_temp, top_p, pad = sp
+        B, V = logits.shape
+        rc = _lib.load().ll_sample_token_bf16(logits.data_ptr(), logits.stride(0), B, V, inv_temp, top_p, int(greedy),
+                                              self.seed_buf.data_ptr(), self.eos_buf.data_ptr(), N_EOS_SLOTS, pad,
+                                              self.done.data_ptr(), self.tok.data_ptr(), self.out_buf.data_ptr(),
+                                              self.out_buf.stride(0), self.out_buf.shape[1], self.stepc.data_ptr(),
+                                              self.posid.data_ptr(), self.pos.data_ptr(), advance, None,
+                                              torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "ll_sample_token_bf16")
+
+    def _generate_hip(self, logits, sp, P, plen, eos_list, max_new_tokens, generator, device):
+        """Decode loop with the fused sampler: per token the host only replays ONE graph (forward + sampler)."""
+        self.done.zero_()
+        self.stepc.zero_()
+        self.out_buf.fill_(sp[3])
+        self.eos_buf.fill_(-1)
+        if eos_list:
+            self.eos_buf[:len(eos_list)] = torch.tensor(eos_list, dtype=torch.long, device=device)
+        gen_dev = generator.device.type if generator is not None else device.type
+        self.seed_buf.copy_(torch.randint(0, 2 ** 62, (1,), device=gen_dev, generator=generator))
+        self.posid.copy_(plen)
+        self.pos.fill_(P)
+        if self._sample_key != sp:          # sampler parameters are baked into the captured launch
+            self._sample_key = sp
+            self._graph = None
+        self._hip_sample(logits, sp, 0)
+        n = 1
+        for t in range(1, max_new_tokens):
+            if eos_list and t % self.sync_every == 0 and bool(self.done.all()):
+                break
+            if self.use_graph:
+                if self._graph is None:
+                    s = torch.cuda.Stream()
+                    s.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s):
+                        self._step()                              # warm-up of the forward only; state rewound below
+                        self._rewind(self.tok.shape[1])
+                    torch.cuda.current_stream().wait_stream(s)
+                    self._graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+                        self.logits = self._step()
+                        self._hip_sample(self.logits, sp, 1)
+                self._graph.replay()
+                logits = self.logits
+            else:
+                logits = self._step()
+                self._hip_sample(logits, sp, 1)
+            n = t + 1
+        self.last_logits = logits
+        return self.out_buf[:, :n].clone()
 
     @torch.no_grad()
     def generate(self, input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
@@ -105,6 +174,17 @@ class GraphedDecoder:
         if self.fused_cache and not self._cache_fused and device.type == "cuda":
             from .llm_accel import fuse_cache_update
             self._cache_fused = fuse_cache_update(self.cache) > 0
+        if (self.sampler == "hip" and logits.is_cuda and logits.dtype == torch.bfloat16 and logits.shape[1] % 8 == 0
+                and logits.shape[1] <= MAX_HIP_VOCAB and logits.stride(1) == 1 and eos.numel() <= N_EOS_SLOTS
+                and (not do_sample or (temperature or 1.0) > 0)):
+            import numpy as np
+            temp = 1.0 if temperature is None else float(temperature)
+            sp = (not do_sample, float(np.float32(1.0) / np.float32(temp)), 1.0 if top_p is None else float(top_p), int(pad))
+            new_tokens = self._generate_hip(logits, sp, P, plen, eos.tolist(), max_new_tokens, generator, device)
+            return torch.cat([input_ids, new_tokens], dim=1) if input_ids is not None else new_tokens
+        if self._sample_key is not None:     # a graph captured with the fused sampler does not fit the torch-sampler loop
+            self._sample_key = None
+            self._graph = None
         new_tokens = torch.full((B, max_new_tokens), pad, dtype=torch.long, device=device)
         done = torch.zeros(B, dtype=torch.bool, device=device)
         self.posid.copy_(plen)                                           # position id of the next token, per row

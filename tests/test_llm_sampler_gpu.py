@@ -1,0 +1,174 @@
+"""ll_sample_token_bf16 (fused temperature / top-p / multinomial sampler + decode-loop bookkeeping) through the C ABI
+against PyTorch: argmax, nucleus boundary, sampled distribution, NaN/inf sanitisation, stop/pad/position bookkeeping."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _key_to_value(key: int) -> float:
+    x = (key & 0x7fff) if (key & 0x8000) else (~key & 0xffff)
+    return float(torch.tensor([x], dtype=torch.int32).to(torch.int16).view(torch.bfloat16).float()) if x < 0x8000 else \
+        float(torch.tensor([x - 0x10000], dtype=torch.int32).to(torch.int16).view(torch.bfloat16).float())
+
+
+class Sampler:
+    def __init__(self, B, V, max_new=64, eos=(), pad=0):
+        from llamole_amd import _lib
+        self.lib, self._lib = _lib.load(), _lib
+        d = "cuda"
+        self.B, self.V = B, V
+        self.seed = torch.zeros(1, dtype=torch.long, device=d)
+        self.eos = torch.full((8,), -1, dtype=torch.long, device=d)
+        if eos:
+            self.eos[:len(eos)] = torch.tensor(eos, device=d)
+        self.pad = pad
+        self.done = torch.zeros(B, dtype=torch.uint8, device=d)
+        self.tok = torch.zeros(B, dtype=torch.long, device=d)
+        self.out = torch.full((B, max_new), -7, dtype=torch.long, device=d)
+        self.step = torch.zeros(B, dtype=torch.long, device=d)
+        self.posid = torch.zeros(B, dtype=torch.long, device=d)
+        self.pos = torch.zeros(1, dtype=torch.long, device=d)
+        self.dbg = torch.zeros(B, 4, dtype=torch.int64, device=d)
+
+    def __call__(self, logits, temperature=1.0, top_p=1.0, greedy=False, advance=1):
+        inv = float(np.float32(1.0) / np.float32(temperature))
+        rc = self.lib.ll_sample_token_bf16(logits.data_ptr(), logits.stride(0), self.B, self.V, inv, top_p, int(greedy),
+                                           self.seed.data_ptr(), self.eos.data_ptr(), 8, self.pad, self.done.data_ptr(),
+                                           self.tok.data_ptr(), self.out.data_ptr(), self.out.stride(0), self.out.shape[1],
+                                           self.step.data_ptr(), self.posid.data_ptr(), self.pos.data_ptr(), advance,
+                                           self.dbg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        self._lib.check(rc, "ll_sample_token_bf16")
+        return self.tok.clone()
+
+
+@pytest.mark.parametrize("V", [2048, 32000, 128256, 152064])
+def test_greedy_is_argmax_lowest_index(V):
+    g = torch.Generator().manual_seed(V)
+    logits = torch.randn(3, V, generator=g).bfloat16()
+    mx = logits.float().max(dim=1).values
+    for b, idxs in enumerate([(5, V - 3), (V // 2, V // 2 + 1), (V - 1,)]):   # ties on the maximum
+        for i in idxs:
+            logits[b, i] = mx[b] + 1
+    logits = logits.cuda()
+    s = Sampler(3, V)
+    tok = s(logits, greedy=True)
+    assert tok.tolist() == [5, V // 2, V - 1]
+    assert tok.tolist() == logits.float().argmax(dim=1).tolist()
+    assert s.out[:, 0].tolist() == tok.tolist() and s.step.tolist() == [1, 1, 1]
+    assert s.posid.tolist() == [1, 1, 1] and s.pos.item() == 1
+
+
+@pytest.mark.parametrize("V,scale,temperature,top_p", [(2048, 3.0, 0.6, 0.9), (152064, 0.5, 0.6, 0.9), (152064, 4.0, 1.0, 0.5),
+                                                       (128256, 2.0, 0.7, 0.95), (32000, 1.0, 1.3, 1.0)])
+def test_nucleus_boundary_matches_reference(V, scale, temperature, top_p):
+    """Boundary value and kept mass against an f64 PyTorch evaluation of the same rule, and against the HF warper's kept
+    set (ascending cumulative sum > 1 - top_p): HF's set is contained in ours, the extras are tied with the boundary."""
+    g = torch.Generator().manual_seed(int(V + 100 * scale))
+    B = 2
+    logits = (torch.randn(B, V, generator=g) * scale).bfloat16().cuda()
+    s = Sampler(B, V)
+    s.seed.fill_(1234)
+    tok = s(logits, temperature=temperature, top_p=top_p)
+    dbg = s.dbg.cpu()
+    inv = float(np.float32(1.0) / np.float32(temperature))
+    for b in range(B):
+        sc = (logits[b].float() * inv).double().cpu()
+        p = torch.softmax(sc, dim=0)
+        vals, inverse = torch.unique(sc, return_inverse=True)           # ascending distinct values
+        mass = torch.zeros_like(vals).scatter_add_(0, inverse, p)
+        above = mass.flip(0).cumsum(0).flip(0) - mass                   # mass strictly above each distinct value
+        kept_vals = vals[above < top_p] if top_p < 1.0 else vals
+        tau_ref = kept_vals.min().item()
+        if top_p < 1.0:
+            tau = _key_to_value(int(dbg[b, 2])) * inv
+            assert abs(tau - tau_ref) <= 1e-6 * max(1.0, abs(tau_ref)), (tau, tau_ref)
+        else:
+            assert int(dbg[b, 0]) == int(dbg[b, 1])                     # no filtering: kept mass is all of Z
+        kept = sc >= tau_ref - 1e-9
+        Z, M = float(dbg[b, 0]), float(dbg[b, 1])
+        assert abs(M / Z - p[kept].sum().item()) < 2e-5
+        assert bool(kept[tok[b]])                                       # the sampled token is in the nucleus
+        assert abs(_key_to_value(int(dbg[b, 3])) - logits[b, tok[b]].float().item()) == 0.0
+        if top_p < 1.0:                                                 # HF TopPLogitsWarper on the same scores
+            srt, idx = torch.sort(sc, descending=False)
+            cum = torch.softmax(srt, dim=0).cumsum(0)
+            remove = cum <= (1 - top_p)
+            remove[-1] = False
+            kept_hf = torch.ones(V, dtype=torch.bool)
+            kept_hf[idx[remove]] = False
+            assert bool((kept | ~kept_hf).all())                        # HF's nucleus is a subset of ours
+            extra = kept & ~kept_hf
+            assert bool((sc[extra] <= tau_ref + 1e-9).all())            # extras are ties of the boundary value
+
+
+def test_sampled_distribution_matches_softmax():
+    """8000 draws from a peaked 2048-token row: chi-square of the head tokens against softmax of the nucleus."""
+    V, B, steps = 2048, 4, 2000
+    g = torch.Generator().manual_seed(3)
+    base = (torch.randn(V, generator=g) * 2.5).bfloat16()
+    logits = base.repeat(B, 1).cuda()
+    s = Sampler(B, V, max_new=steps)
+    s.seed.fill_(99)
+    for _ in range(steps):
+        s(logits, temperature=0.8, top_p=0.9)
+    draws = s.out.flatten().cpu()
+    assert (draws >= 0).all()
+    inv = float(np.float32(1.0) / np.float32(0.8))
+    sc = (base.float() * inv).double()
+    p = torch.softmax(sc, dim=0)
+    vals, inverse = torch.unique(sc, return_inverse=True)
+    mass = torch.zeros_like(vals).scatter_add_(0, inverse, p)
+    above = mass.flip(0).cumsum(0).flip(0) - mass
+    tau = vals[above < 0.9].min()
+    kept = sc >= tau
+    q = torch.where(kept, p, torch.zeros_like(p))
+    q = q / q.sum()
+    counts = torch.bincount(draws, minlength=V).double()
+    assert counts[~kept].sum() == 0                                    # nothing outside the nucleus is ever drawn
+    n = counts.sum()
+    big = q * n >= 20
+    chi2 = (((counts[big] - q[big] * n) ** 2) / (q[big] * n)).sum().item() + \
+        ((counts[~big & kept].sum() - q[~big & kept].sum() * n) ** 2 / max(q[~big & kept].sum().item() * n, 1e-9)).item()
+    dof = int(big.sum())
+    assert chi2 < dof + 6 * (2 * dof) ** 0.5, (chi2, dof)
+    # reproducible: same seed, same steps -> same stream; another seed -> a different one
+    s2 = Sampler(B, V, max_new=steps)
+    s2.seed.fill_(99)
+    for _ in range(50):
+        s2(logits, temperature=0.8, top_p=0.9)
+    assert torch.equal(s2.out[:, :50], s.out[:, :50])
+    s3 = Sampler(B, V, max_new=steps)
+    s3.seed.fill_(100)
+    for _ in range(50):
+        s3(logits, temperature=0.8, top_p=0.9)
+    assert not torch.equal(s3.out[:, :50], s.out[:, :50])
+
+
+def test_sanitisation_and_bookkeeping():
+    V = 2048
+    logits = torch.zeros(3, V).bfloat16()
+    logits[0, 7] = float("nan")          # NaN counts as 0.0 (torch.nan_to_num in the HF path)
+    logits[0, 11] = float("inf")         # +inf wins
+    logits[1, :] = float("-inf")
+    logits[1, 100] = -3.0                # everything else is -inf -> only token 100 has mass
+    logits[2, 5] = 30.0
+    logits = logits.cuda()
+    s = Sampler(3, V, eos=(5, 9), pad=1)
+    tok = s(logits, temperature=0.6, top_p=0.9, advance=0)
+    assert tok.tolist() == [11, 100, 5]
+    assert s.done.tolist() == [0, 0, 1]                  # row 2 sampled an EOS id
+    assert s.posid.tolist() == [0, 0, 0] and s.pos.item() == 0 and s.step.tolist() == [1, 1, 1]
+    tok = s(logits, temperature=0.6, top_p=0.9, advance=1)
+    assert tok.tolist() == [11, 100, 1]                  # a stopped row emits pad from now on
+    assert s.out[:, :3].tolist() == [[11, 11, -7], [100, 100, -7], [5, 1, -7]]
+    assert s.posid.tolist() == [1, 1, 1] and s.pos.item() == 1
+    # C-ABI error behaviour
+    lib = s.lib
+    assert lib.ll_sample_token_bf16(logits.data_ptr(), V, 3, 2047, 1.0, 0.9, 0, s.seed.data_ptr(), s.eos.data_ptr(), 8, 0,
+                                    s.done.data_ptr(), s.tok.data_ptr(), s.out.data_ptr(), 64, 64, s.step.data_ptr(), None,
+                                    None, 0, None, None) == -1
+    assert b"multiple of 8" in lib.ll_last_error()
