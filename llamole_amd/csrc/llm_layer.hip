@@ -8,6 +8,7 @@
 // so results are bit-identical to them; what goes away is seven launch boundaries and seven HBM/L2 round trips of
 // [B, hidden]-sized vectors per layer.
 #include "common.h"
+#include "attn_decode.h"
 
 namespace ll {
 
@@ -203,6 +204,9 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const bf16_t *__r
     constexpr int half = D / 2;
     bf16_t *Kb = K + ((int64_t)b * nkv + kvh) * maxlen * D;
     bf16_t *Vb = V + ((int64_t)b * nkv + kvh) * maxlen * D;
+    const unsigned char *mrow = mask + b * ms0;
+    AttnTile0<D> t0;      // first 256 keys / values / mask bytes: requested before the rotary arithmetic
+    attn_prefetch<D>(t0, Kb, Vb, mrow, maxlen, tid, lane, wave);
     if (wave == 0) {
         if (lane < half) {
             const bf16_t *src = row + h * D;
@@ -234,89 +238,9 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const bf16_t *__r
             if (pvalid && h % group == 0) *reinterpret_cast<uint32_t *>(Vb + p * D + lane * 2) = v2;
         }
     }
-    const unsigned char *mrow = mask + b * ms0;
     __syncthreads();
-    for (int j = tid; j < maxlen; j += 256) {
-        const bool ok = mrow[j] != 0;
-        float dsum = 0.f;
-        if (ok) {
-            u32x4 kv[D / 8];
-            if (pvalid && j == p) {
-#pragma unroll
-                for (int ch = 0; ch < D / 8; ++ch) kv[ch] = *reinterpret_cast<const u32x4 *>(kn + ch * 8);
-            } else {
-#pragma unroll
-                for (int ch = 0; ch < D / 8; ++ch) kv[ch] = *reinterpret_cast<const u32x4 *>(Kb + (int64_t)j * D + ch * 8);
-            }
-#pragma unroll
-            for (int ch = 0; ch < D / 8; ++ch) {
-                const float4 q0 = *reinterpret_cast<const float4 *>(qs + ch * 8);
-                const float4 q1 = *reinterpret_cast<const float4 *>(qs + ch * 8 + 4);
-                dsum = fmaf(q0.x, __uint_as_float(kv[ch][0] << 16), dsum);
-                dsum = fmaf(q0.y, __uint_as_float(kv[ch][0] & 0xffff0000u), dsum);
-                dsum = fmaf(q0.z, __uint_as_float(kv[ch][1] << 16), dsum);
-                dsum = fmaf(q0.w, __uint_as_float(kv[ch][1] & 0xffff0000u), dsum);
-                dsum = fmaf(q1.x, __uint_as_float(kv[ch][2] << 16), dsum);
-                dsum = fmaf(q1.y, __uint_as_float(kv[ch][2] & 0xffff0000u), dsum);
-                dsum = fmaf(q1.z, __uint_as_float(kv[ch][3] << 16), dsum);
-                dsum = fmaf(q1.w, __uint_as_float(kv[ch][3] & 0xffff0000u), dsum);
-            }
-        }
-        sc[j] = ok ? dsum * scale : -INFINITY;
-    }
-    __syncthreads();
-    float mx = -INFINITY;
-    for (int j = tid; j < maxlen; j += 256) mx = fmaxf(mx, sc[j]);
-    mx = wave_max(mx);
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float sum = 0.f;
-    for (int j = tid; j < maxlen; j += 256) {
-        const float e = (sc[j] == -INFINITY) ? 0.f : expf(sc[j] - mx);
-        sc[j] = e;
-        sum += e;
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) red[4 + wave] = sum;
-    __syncthreads();
-    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
-    constexpr int EPL = D / 64;
-    float acc[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-    for (int j0 = wave; j0 < maxlen; j0 += 32) {
-        float pj[8];
-        uint32_t vv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = j0 + 4 * u;
-            pj[u] = j < maxlen ? sc[j] : 0.f;
-            vv[u] = 0;
-            if (pj[u] != 0.f) {
-                const bf16_t *vrow = (pvalid && j == p) ? nullptr : Vb + (int64_t)j * D;
-                if (vrow) {
-                    if (EPL == 2) vv[u] = *reinterpret_cast<const uint32_t *>(vrow + lane * 2);
-                    else vv[u] = *reinterpret_cast<const unsigned short *>(vrow + lane);
-                } else {
-                    if (EPL == 2) vv[u] = *reinterpret_cast<const uint32_t *>(vn + lane * 2);
-                    else vv[u] = vn[lane];
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            acc[0] = fmaf(pj[u], __uint_as_float(vv[u] << 16), acc[0]);
-            if (EPL == 2) acc[EPL - 1] = fmaf(pj[u], __uint_as_float(vv[u] & 0xffff0000u), acc[EPL - 1]);
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) part[wave * D + lane * EPL + e] = acc[e];
-    __syncthreads();
-    if (tid < D) {
-        const float o = (part[tid] + part[D + tid] + part[2 * D + tid] + part[3 * D + tid]) * inv;
-        out[((int64_t)b * nh + h) * D + tid] = f32_to_bf16(o);
-    }
+    attn_finish<D, true>(t0, qs, part, sc, red, Kb, Vb, mrow, maxlen, pvalid ? p : -1, kn, vn, scale,
+                         out + ((int64_t)b * nh + h) * D, tid, lane, wave);
 }
 
 static int g_gemv_nt = 1;   // non-temporal weight loads (tools/gemv_fused_sweep.py)

@@ -9,6 +9,7 @@
 //   ll_rope_bf16      apply_rotary_pos_emb: q*cos + rotate_half(q)*sin for q and k (strided [B,h,S,d] views)
 //   ll_silu_mul_bf16  act_fn(gate) * up of the gated MLP
 #include "common.h"
+#include "attn_decode.h"
 
 namespace ll {
 
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(64) void kv_append_bf16_kernel(bf16_t *__restrict__
 // Decode attention over a static KV cache (GQA): one workgroup per (query head, batch*query position).
 //   scores_j = q . K[j] * scale for keys with mask[b,0,s,j] true; softmax in f32; out = sum_j p_j V[j].
 // Replaces repeat_kv (two full-cache copies) + SDPA + mask fills of the HF sdpa path at decode.  D in {64, 128}.
+// Body in attn_decode.h (shared with the fused rope + append + attention kernel of llm_layer.hip).
 template <int D>
 __global__ __launch_bounds__(256) void decode_attn_bf16_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ K,
                                                                const bf16_t *__restrict__ V, const unsigned char *__restrict__ mask,
@@ -143,84 +145,15 @@ __global__ __launch_bounds__(256) void decode_attn_bf16_kernel(const bf16_t *__r
     const int b = bs / S, s = bs - b * S;
     const int kvh = h / (nh / nkv);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < D) qs[tid] = bf16_to_f32(q[b * qs0 + h * qs1 + s * qs2 + tid]);
     const bf16_t *Kb = K + ((int64_t)b * nkv + kvh) * maxlen * D;
     const bf16_t *Vb = V + ((int64_t)b * nkv + kvh) * maxlen * D;
     const unsigned char *mrow = mask + b * ms0 + s * ms2;
+    AttnTile0<D> t0;
+    attn_prefetch<D>(t0, Kb, Vb, mrow, maxlen, tid, lane, wave);
+    if (tid < D) qs[tid] = bf16_to_f32(q[b * qs0 + h * qs1 + s * qs2 + tid]);
     __syncthreads();
-    // ---- scores: one key per thread, the whole key row (D/8 x 16 B) in flight -> one memory round trip per 256 keys
-    for (int j = tid; j < maxlen; j += 256) {
-        const bool ok = mrow[j] != 0;
-        float dsum = 0.f;
-        if (ok) {
-            uint4 kv[D / 8];
-#pragma unroll
-            for (int c = 0; c < D / 8; ++c) kv[c] = *reinterpret_cast<const uint4 *>(Kb + (int64_t)j * D + c * 8);
-#pragma unroll
-            for (int c = 0; c < D / 8; ++c) {
-                const float4 q0 = *reinterpret_cast<const float4 *>(qs + c * 8);
-                const float4 q1 = *reinterpret_cast<const float4 *>(qs + c * 8 + 4);
-                dsum = fmaf(q0.x, __uint_as_float(kv[c].x << 16), dsum);
-                dsum = fmaf(q0.y, __uint_as_float(kv[c].x & 0xffff0000u), dsum);
-                dsum = fmaf(q0.z, __uint_as_float(kv[c].y << 16), dsum);
-                dsum = fmaf(q0.w, __uint_as_float(kv[c].y & 0xffff0000u), dsum);
-                dsum = fmaf(q1.x, __uint_as_float(kv[c].z << 16), dsum);
-                dsum = fmaf(q1.y, __uint_as_float(kv[c].z & 0xffff0000u), dsum);
-                dsum = fmaf(q1.z, __uint_as_float(kv[c].w << 16), dsum);
-                dsum = fmaf(q1.w, __uint_as_float(kv[c].w & 0xffff0000u), dsum);
-            }
-        }
-        sc[j] = ok ? dsum * scale : -INFINITY;
-    }
-    __syncthreads();
-    // ---- softmax statistics
-    float mx = -INFINITY;
-    for (int j = tid; j < maxlen; j += 256) mx = fmaxf(mx, sc[j]);
-    mx = wave_max(mx);
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float sum = 0.f;
-    for (int j = tid; j < maxlen; j += 256) {
-        const float e = (sc[j] == -INFINITY) ? 0.f : expf(sc[j] - mx);
-        sc[j] = e;
-        sum += e;
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) red[4 + wave] = sum;
-    __syncthreads();
-    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
-    // ---- out = P V : wave w takes keys j = w, w+4, ...; lane covers D/64 consecutive elements
-    constexpr int EPL = D / 64;
-    float acc[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-    for (int j0 = wave; j0 < maxlen; j0 += 32) {     // 8 keys (rows of 2*D bytes, coalesced) in flight per wave
-        float pj[8];
-        uint32_t vv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = j0 + 4 * u;
-            pj[u] = j < maxlen ? sc[j] : 0.f;
-            vv[u] = 0;
-            if (pj[u] != 0.f) {
-                if (EPL == 2) vv[u] = *reinterpret_cast<const uint32_t *>(Vb + (int64_t)j * D + lane * 2);
-                else vv[u] = *reinterpret_cast<const unsigned short *>(Vb + (int64_t)j * D + lane);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            acc[0] = fmaf(pj[u], __uint_as_float(vv[u] << 16), acc[0]);
-            if (EPL == 2) acc[EPL - 1] = fmaf(pj[u], __uint_as_float(vv[u] & 0xffff0000u), acc[EPL - 1]);
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) part[wave * D + lane * EPL + e] = acc[e];
-    __syncthreads();
-    if (tid < D) {
-        const float o = (part[tid] + part[D + tid] + part[2 * D + tid] + part[3 * D + tid]) * inv;
-        out[(((int64_t)b * S + s) * nh + h) * D + tid] = f32_to_bf16(o);
-    }
+    attn_finish<D, false>(t0, qs, part, sc, red, Kb, Vb, mrow, maxlen, -1, nullptr, nullptr, scale,
+                          out + (((int64_t)b * S + s) * nh + h) * D, tid, lane, wave);
 }
 
 }  // namespace ll

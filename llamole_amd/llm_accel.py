@@ -16,7 +16,8 @@ import torch.nn.functional as F
 
 from . import _lib
 
-MAX_ROWS = 64
+MAX_ROWS = 64            # GEMV / skinny-GEMM path under nn.Linear
+MAX_EW_ROWS = 16384      # row-parallel elementwise kernels (RMSNorm, rotary, SiLU*mul) also serve prefill-sized calls
 
 
 def _hip_linear_forward(self: nn.Linear, x: torch.Tensor) -> torch.Tensor:
@@ -64,14 +65,14 @@ def restore_linears(model: nn.Module) -> None:
 
 
 # ------------------------------------------------------------------------------------------ fused elementwise ops
-def _decode_shaped(x: torch.Tensor, width: int) -> bool:
+def _decode_shaped(x: torch.Tensor, width: int, max_rows: int = MAX_ROWS) -> bool:
     return (x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.shape[-1] == width
-            and x.numel() // width <= MAX_ROWS)
+            and x.numel() // width <= max_rows)
 
 
 def _rmsnorm_forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
     H = self.weight.shape[0]
-    if _decode_shaped(hidden_states, H) and self.weight.dtype == torch.bfloat16 and H % 8 == 0 and H <= 8192:
+    if _decode_shaped(hidden_states, H, MAX_EW_ROWS) and self.weight.dtype == torch.bfloat16 and H % 8 == 0 and H <= 8192:
         x = hidden_states.reshape(-1, H)
         if not x.is_contiguous():
             x = x.contiguous()
@@ -112,6 +113,18 @@ def _mlp_forward(self, x: torch.Tensor) -> torch.Tensor:
         if rc != 0:
             _lib.check(rc, "ll_silu_mul_bf16")
         return self.down_proj(h.reshape(*x.shape[:-1], I))
+    if (_decode_shaped(x, K, MAX_EW_ROWS) and I % 8 == 0 and self.gate_proj.weight.dtype == torch.bfloat16):
+        # prefill-sized call: BLAS projections, act_fn(gate) * up as one launch
+        g, u = self.gate_proj(x), self.up_proj(x)
+        g2, u2 = g.reshape(-1, I), u.reshape(-1, I)
+        if g2.is_contiguous() and u2.is_contiguous():
+            h = torch.empty_like(g2)
+            rc = self._ll_lib.ll_silu_mul_bf16(g2.data_ptr(), u2.data_ptr(), h.data_ptr(), g2.shape[0], I, I,
+                                               torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                _lib.check(rc, "ll_silu_mul_bf16")
+            return self.down_proj(h.reshape(g.shape))
+        return self.down_proj(self.act_fn(g) * u)
     return self._ll_orig_forward(x)
 
 
@@ -193,7 +206,7 @@ def _make_rope(orig, lib):
 
     def apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=1, **kw):
         if (unsqueeze_dim == 1 and q.dim() == 4 and q.is_cuda and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16
-                and cos.dtype == torch.bfloat16 and cos.dim() == 3 and not torch.is_grad_enabled() and q.shape[2] <= MAX_ROWS
+                and cos.dtype == torch.bfloat16 and cos.dim() == 3 and not torch.is_grad_enabled() and q.shape[2] <= MAX_EW_ROWS
                 and q.stride(3) == 1 and k.stride(3) == 1 and cos.stride(2) == 1 and sin.stride() == cos.stride()
                 and q.shape[3] % 2 == 0 and q.shape[3] <= 128 and cos.shape[-1] == q.shape[3]):
             B, nh, S, D = q.shape

@@ -169,7 +169,7 @@ class GraphedDecoder:
         kw = dict(inputs_embeds=inputs_embeds) if inputs_embeds is not None else dict(input_ids=input_ids)
         out = self.model(attention_mask=self.mask[:, :P], past_key_values=self.cache,
                          cache_position=torch.arange(P, device=device), position_ids=pos_ids, use_cache=True,
-                         return_dict=True, **kw)
+                         return_dict=True, logits_to_keep=1, **kw)      # only the last position's logits are used
         logits = out.logits[:, -1, :]
         if self.fused_cache and not self._cache_fused and device.type == "cuda":
             from .llm_accel import fuse_cache_update

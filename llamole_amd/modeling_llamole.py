@@ -171,8 +171,11 @@ class GraphLLMForCausalMLM(nn.Module):
 
     def _query_hidden(self, ids: torch.Tensor) -> torch.Tensor:
         """LLM forward over ids (all-ones mask, as the reference) -> mean of the last num_body_tokens hidden states."""
-        out = self.language_model(input_ids=ids, attention_mask=torch.ones_like(ids), output_hidden_states=True,
-                                  return_dict=True)
+        kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), output_hidden_states=True, return_dict=True)
+        try:      # only hidden states are used: skip the [B, L, vocab] lm_head product where the model allows it
+            out = self.language_model(logits_to_keep=1, **kw)
+        except TypeError:
+            out = self.language_model(**kw)
         return out.hidden_states[-1][:, -self.num_body_tokens:].mean(dim=1)
 
     def _splice_molecules(self, ids: torch.Tensor, graphs) -> torch.Tensor:
