@@ -111,7 +111,8 @@ __device__ __forceinline__ void attn_finish(AttnTile0<D> &t, const float *qs, fl
     sum = wave_sum(sum);
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
-    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    const float den = red[4] + red[5] + red[6] + red[7];
+    const float inv = den > 0.f ? 1.f / den : 0.f;      // a fully masked query row (left padding) yields zeros, not NaN
     // ---- out = P V: wave w takes keys 64w..64w+63 of tile 0 (registers), then keys 256 + w + 4u + 32 it
     float acc[EPL];
 #pragma unroll
@@ -120,7 +121,7 @@ __device__ __forceinline__ void attn_finish(AttnTile0<D> &t, const float *qs, fl
     for (int i = 0; i < 64; ++i) {
         const int j = wave * 64 + i;
         const float pj = j < maxlen ? sc[j] : 0.f;
-        uint32_t x = t.v[i];
+        uint32_t x = pj != 0.f ? t.v[i] : 0u;      // masked rows may hold anything (NaN from padded positions): never multiply them
         if (NEWKV && j == p) x = EPL == 2 ? *reinterpret_cast<const uint32_t *>(vn + lane * 2) : (uint32_t)vn[lane];
         acc[0] = fmaf(pj, __uint_as_float(x << 16), acc[0]);
         if (EPL == 2) acc[EPL - 1] = fmaf(pj, __uint_as_float(x & 0xffff0000u), acc[EPL - 1]);

@@ -109,8 +109,10 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
                 from .llm_accel import fuse_decoder_layers
                 fused["decoder_layers_5_launches"] = fuse_decoder_layers(llm)
     if args.llm_decode != "hf":
-        orch.enable_graphed_decode(use_graph=(args.llm_decode == "graph"), fused_cache=bool(fused))
+        reuse = getattr(args, "query_kv_reuse", True)
+        orch.enable_graphed_decode(use_graph=(args.llm_decode == "graph"), fused_cache=bool(fused), reuse_query_kv=reuse)
         fused["kv_append"] = bool(fused)
+        fused["query_forward_reuses_decode_kv"] = bool(reuse)
     B = props.shape[0]
     g = torch.Generator().manual_seed(100 + rank)
     prompt = torch.randint(5, 1000, (B, args.cutoff_len), generator=g).to(device)

@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from . import _lib
 
 MAX_ROWS = 64            # GEMV / skinny-GEMM path under nn.Linear
+MAX_APPEND_ROWS = 16     # new positions per call served by the fused KV append / decode attention (decode, query tail)
 MAX_EW_ROWS = 16384      # row-parallel elementwise kernels (RMSNorm, rotary, SiLU*mul) also serve prefill-sized calls
 
 
@@ -280,7 +281,7 @@ def _decode_attention_forward(module, query, key, value, attention_mask, dropout
     import ctypes as C
     from transformers.integrations.sdpa_attention import sdpa_attention_forward
     B, nh, S, D = query.shape
-    if (query.is_cuda and query.dtype == torch.bfloat16 and key.dtype == torch.bfloat16 and S <= 4 and D in (64, 128)
+    if (query.is_cuda and query.dtype == torch.bfloat16 and key.dtype == torch.bfloat16 and S <= MAX_APPEND_ROWS and D in (64, 128)
             and attention_mask is not None and attention_mask.dtype == torch.bool and attention_mask.dim() == 4
             and attention_mask.shape[1] == 1 and attention_mask.shape[-1] == key.shape[2] and attention_mask.stride(3) == 1
             and key.is_contiguous() and value.is_contiguous() and query.stride(3) == 1 and dropout == 0.0
@@ -335,7 +336,7 @@ def fuse_cache_update(cache) -> int:
 
         def update(key_states, value_states, *a, **k):
             S = key_states.shape[-2]
-            if (S <= 4 and key_states.dtype == torch.bfloat16 and layer.keys.dtype == torch.bfloat16 and key_states.is_cuda
+            if (S <= MAX_APPEND_ROWS and key_states.dtype == torch.bfloat16 and layer.keys.dtype == torch.bfloat16 and key_states.is_cuda
                     and key_states.stride(3) == 1 and value_states.stride(3) == 1 and not torch.is_grad_enabled()):
                 B, nkv, _, D = key_states.shape
                 rc = lib.ll_kv_append_bf16(layer.keys.data_ptr(), layer.values.data_ptr(), key_states.data_ptr(),

@@ -87,6 +87,30 @@ class GraphedDecoder:
         for layer in layers:
             layer.cumulative_length.sub_(n)
 
+    @torch.no_grad()
+    def continue_hidden(self, tail_ids: torch.Tensor, start: int) -> torch.Tensor:
+        """Final hidden states of ``tail_ids`` [B,S] run ON TOP of the KV cache of the last ``generate`` call, at cache
+        slots ``start .. start+S-1`` (slots >= start are overwritten).  This is the reference's query-token re-forward
+        (modeling_llamole.py:641-646) without recomputing the prompt + analysis prefix."""
+        info = self._last
+        if info is None:
+            raise RuntimeError("continue_hidden needs a preceding generate() on this decoder")
+        B, S = tail_ids.shape
+        P = info["P"]
+        if start < P or start + S > self.mask.shape[1]:
+            raise ValueError(f"continuation [{start},{start + S}) outside the cache window [{P},{self.mask.shape[1]})")
+        for layer in self.cache.layers:
+            layer.cumulative_length.fill_(start)
+        device = tail_ids.device
+        pos = torch.arange(start, start + S, device=device)
+        posid = info["plen"] + (start - P) + torch.arange(S, device=device).unsqueeze(0)
+        base = getattr(self.model, "model", self.model)
+        out = base(input_ids=tail_ids, attention_mask=self.mask, past_key_values=self.cache, cache_position=pos,
+                   position_ids=posid, use_cache=True, return_dict=True)
+        if self._cache_fused:
+            self.cache.layers[0].cumulative_length.add_(S)
+        return out.last_hidden_state
+
     def _hip_sample(self, logits: torch.Tensor, sp, advance: int):
         """One launch: sample (or argmax) from bf16 logits [B,V], write tok / out_buf[:, step], update done / step and,
         with ``advance``, the position counters the next forward reads."""
@@ -141,6 +165,7 @@ class GraphedDecoder:
                 self._hip_sample(logits, sp, 1)
             n = t + 1
         self.last_logits = logits
+        self._last["n_new"] = n
         return self.out_buf[:, :n].clone()
 
     @torch.no_grad()
@@ -155,6 +180,7 @@ class GraphedDecoder:
             attention_mask = torch.ones(B, P, dtype=torch.long, device=device)
         max_len = P + max_new_tokens
         self._prepare(B, max_len, device, inputs_embeds is not None)
+        self._last = None
         eos = torch.tensor(list(eos_token_id) if isinstance(eos_token_id, (list, tuple)) else
                            ([] if eos_token_id is None else [eos_token_id]), dtype=torch.long, device=device)
         pad = pad_token_id if pad_token_id is not None else (int(eos[0]) if eos.numel() else 0)
@@ -171,6 +197,10 @@ class GraphedDecoder:
                          cache_position=torch.arange(P, device=device), position_ids=pos_ids, use_cache=True,
                          return_dict=True, logits_to_keep=1, **kw)      # only the last position's logits are used
         logits = out.logits[:, -1, :]
+        for layer in self.cache.layers:          # the next free slot is P whichever update path the prefill took (a short
+            if hasattr(layer, "cumulative_length"):   # prompt on a re-used cache goes through the fused append, which
+                layer.cumulative_length.fill_(P)      # leaves advancing layer 0's shared counter to its caller)
+        self._last = dict(P=P, plen=plen, max_new=max_new_tokens, from_ids=input_ids is not None)
         if self.fused_cache and not self._cache_fused and device.type == "cuda":
             from .llm_accel import fuse_cache_update
             self._cache_fused = fuse_cache_update(self.cache) > 0
@@ -225,6 +255,7 @@ class GraphedDecoder:
             else:
                 logits = self._step()
         new_tokens = new_tokens[:, :n_done_steps]
+        self._last["n_new"] = n_done_steps
         self.last_logits = logits
         if input_ids is not None:
             return torch.cat([input_ids, new_tokens], dim=1)

@@ -60,11 +60,15 @@ class GraphLLMForCausalMLM(nn.Module):
         self.lm_to_graph_predictor = make_connector(hidden, graph_predictor.text_input_size)
         self.timings: Dict[str, float] = {}
         self.decoder = None      # optional llm_decode.GraphedDecoder (HIP-graph decode step); None = HF generate
+        self.reuse_query_kv = False
 
-    def enable_graphed_decode(self, use_graph: bool = True, sync_every: int = 16, fused_cache: bool = False):
-        """Route every LLM decode of the path through one captured hipGraph of the stock HF forward."""
+    def enable_graphed_decode(self, use_graph: bool = True, sync_every: int = 16, fused_cache: bool = False,
+                              reuse_query_kv: bool = True):
+        """Route every LLM decode of the path through one captured hipGraph of the stock HF forward; ``reuse_query_kv``
+        runs the query-token re-forward on top of the decode's KV cache whenever that is the same computation."""
         from .llm_decode import GraphedDecoder
         self.decoder = GraphedDecoder(self.language_model, use_graph=use_graph, sync_every=sync_every, fused_cache=fused_cache)
+        self.reuse_query_kv = reuse_query_kv
         return self
 
     def _llm_generate(self, inputs=None, attention_mask=None, inputs_embeds=None, **kwargs):
@@ -178,6 +182,24 @@ class GraphLLMForCausalMLM(nn.Module):
             out = self.language_model(**kw)
         return out.hidden_states[-1][:, -self.num_body_tokens:].mean(dim=1)
 
+    def _query_hidden_from_cache(self, input_ids, attention_mask, analysis, design_ids):
+        """KV-cache reuse for the query-token re-forward.  Valid only when the token sequence of the
+        re-forward is the decoded sequence with its last tokens replaced by ``[<design_start>] + bodies``: full-length
+        analysis without a ``<design_start>`` trigger (add_special_body_tokens then keeps ``analysis[:-9]`` in place) and an
+        unpadded prompt (the re-forward uses an all-ones mask).  Returns None when the full re-forward is required."""
+        dec = self.decoder
+        info = getattr(dec, "_last", None) if dec is not None else None
+        tail = self.num_body_tokens + 1
+        L = analysis.shape[1]
+        if (info is None or not info["from_ids"] or info.get("n_new") != info["max_new"] or L != info["max_new"] or L <= tail
+                or design_ids.shape[1] != input_ids.shape[1] + L):
+            return None
+        start_id = self.token_id_dict["<design_start>"]
+        if bool((analysis == start_id).any()) or not bool(attention_mask.bool().all()):
+            return None
+        hs = dec.continue_hidden(design_ids[:, -tail:], input_ids.shape[1] + L - tail)
+        return hs[:, -self.num_body_tokens:].mean(dim=1)
+
     def _splice_molecules(self, ids: torch.Tensor, graphs) -> torch.Tensor:
         """embed_tokens(ids) with every <molecule> position replaced by connector(GIN encoder(graph)) (:607-622)."""
         emb_layer = self.language_model.get_input_embeddings()
@@ -205,7 +227,11 @@ class GraphLLMForCausalMLM(nn.Module):
         design_ids = self.add_special_body_tokens(analysis, self.token_id_dict["<design_body>"], self.num_body_tokens,
                                                   start_token_id=self.token_id_dict["<design_start>"])
         design_ids = torch.cat([input_ids, design_ids], dim=1)
-        hidden = self._query_hidden(design_ids)
+        hidden = None
+        if molecule_graphs is None and self.reuse_query_kv:
+            hidden = self._query_hidden_from_cache(input_ids, attention_mask, analysis, design_ids)
+        if hidden is None:
+            hidden = self._query_hidden(design_ids)
         cond = self.lm_to_graph_decoder(hidden.to(next(self.lm_to_graph_decoder.parameters()).dtype))
         self.timings.update(llm_decode_s=t1 - t0, llm_query_s=time.perf_counter() - t1)
         return analysis, design_ids, cond
