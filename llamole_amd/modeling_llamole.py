@@ -61,6 +61,7 @@ class GraphLLMForCausalMLM(nn.Module):
         self.timings: Dict[str, float] = {}
         self.decoder = None      # optional llm_decode.GraphedDecoder (HIP-graph decode step); None = HF generate
         self.reuse_query_kv = False
+        self.batch_values = True   # A* value estimates of one expansion in one LLM forward (estimate_synthesis_complexity_batch)
 
     def enable_graphed_decode(self, use_graph: bool = True, sync_every: int = 16, fused_cache: bool = False,
                               reuse_query_kv: bool = True):
@@ -325,23 +326,16 @@ class GraphLLMForCausalMLM(nn.Module):
                 "All require extensive multi-step synthesis"]
     _ANSWER_COSTS = [0, 1, 2.5, 4.5, 7]
 
-    @torch.no_grad()
-    def estimate_synthesis_complexity(self, smiles, input_ids=None, reaction=None, molecule_cost_weight=0,
-                                      language_cost_weight=1, reference_tokens=None):
-        cost = 0
-        if molecule_cost_weight is not None and molecule_cost_weight > 0:
-            cost += self.graph_predictor.estimate_cost(smiles) * molecule_cost_weight
-        if language_cost_weight is not None and language_cost_weight > 0:
-            if reaction is None:
-                content = f"""
+    def _complexity_prompt(self, smiles, reaction) -> str:
+        if reaction is None:
+            return f"""
                 Estimate remaining steps for the target {smiles} consider the following factors::
                 1. Intermediate complexity
                 2. Reagent availability
                 3. Side reactions
                 4. Stereochemistry challenges"""
-            else:
-                reactants = ", ".join(r.mol for r in reaction.children)
-                content = f"""
+        reactants = ", ".join(r.mol for r in reaction.children)
+        return f"""
                 Estimate remaining steps for the target {smiles} given the following parameters:
                 Current step {reaction.depth + 1},
                 Current template: {reaction.template},
@@ -351,17 +345,71 @@ class GraphLLMForCausalMLM(nn.Module):
                 2. Reagent availability
                 3. Side reactions
                 4. Stereochemistry challenges"""
-            chat = self.tokenizer.apply_chat_template([{"role": "user", "content": content}], tokenize=False,
-                                                      add_generation_prompt=True)
-            answer_tokens = [self.tokenizer.encode(self.tokenizer.apply_chat_template(
-                [{"role": "user", "content": "Estimate the synthesis complexity:"}, {"role": "assistant", "content": a}],
-                tokenize=False, add_generation_prompt=False)) for a in self._ANSWERS]
+
+    def _answer_tokens(self):
+        return [self.tokenizer.encode(self.tokenizer.apply_chat_template(
+            [{"role": "user", "content": "Estimate the synthesis complexity:"}, {"role": "assistant", "content": a}],
+            tokenize=False, add_generation_prompt=False)) for a in self._ANSWERS]
+
+    def _cost_from_logits(self, logits, answer_tokens):
+        """logits [n, vocab] of the last prompt position -> expected remaining-step cost per row (:976-993)."""
+        answer_logits = torch.stack([logits[:, toks].mean(dim=1) for toks in answer_tokens])        # [5, n]
+        probs = torch.softmax(answer_logits.float(), dim=0)
+        return (probs * torch.tensor(self._ANSWER_COSTS, device=probs.device)[:, None]).sum(dim=0)  # [n]
+
+    @torch.no_grad()
+    def estimate_synthesis_complexity(self, smiles, input_ids=None, reaction=None, molecule_cost_weight=0,
+                                      language_cost_weight=1, reference_tokens=None):
+        cost = 0
+        if molecule_cost_weight is not None and molecule_cost_weight > 0:
+            cost += self.graph_predictor.estimate_cost(smiles) * molecule_cost_weight
+        if language_cost_weight is not None and language_cost_weight > 0:
+            chat = self.tokenizer.apply_chat_template([{"role": "user", "content": self._complexity_prompt(smiles, reaction)}],
+                                                      tokenize=False, add_generation_prompt=True)
             ids = self.tokenizer.encode(chat, return_tensors="pt").to(self.device)
             logits = self.language_model(ids).logits[:, -1, :]
-            answer_logits = torch.stack([logits[:, toks].mean(dim=1) for toks in answer_tokens])
-            probs = torch.softmax(answer_logits.float(), dim=0)
-            cost += (probs * torch.tensor(self._ANSWER_COSTS, device=probs.device)[:, None]).sum().item() * language_cost_weight
+            cost += self._cost_from_logits(logits, self._answer_tokens()).sum().item() * language_cost_weight
         return cost
+
+    @torch.no_grad()
+    def estimate_synthesis_complexity_batch(self, items, input_ids=None, molecule_cost_weight=0, language_cost_weight=1,
+                                            max_batch: int = 64) -> List[float]:
+        """``estimate_synthesis_complexity`` for many ``(smiles, reaction)`` pairs with ONE LLM forward per ``max_batch``
+        prompts instead of one per new tree node: prompts are left-padded, padding is masked and position
+        ids count real tokens only, so every row computes exactly what its own unpadded forward computes."""
+        n = len(items)
+        costs = [0.0] * n
+        if n == 0:
+            return costs
+        if molecule_cost_weight is not None and molecule_cost_weight > 0:
+            for i, (smiles, _) in enumerate(items):
+                costs[i] += self.graph_predictor.estimate_cost(smiles) * molecule_cost_weight
+        if language_cost_weight is not None and language_cost_weight > 0:
+            answer_tokens = self._answer_tokens()
+            rows = [self.tokenizer.encode(self.tokenizer.apply_chat_template(
+                [{"role": "user", "content": self._complexity_prompt(smiles, reaction)}], tokenize=False,
+                add_generation_prompt=True)) for smiles, reaction in items]
+            pad = getattr(self.tokenizer, "pad_token_id", None)
+            pad = self.tokenizer.eos_token_id if pad is None else pad
+            for lo in range(0, n, max_batch):
+                chunk = rows[lo:lo + max_batch]
+                L = max(len(r) for r in chunk)
+                ids = torch.full((len(chunk), L), pad, dtype=torch.long)
+                mask = torch.zeros((len(chunk), L), dtype=torch.long)
+                for j, r in enumerate(chunk):
+                    ids[j, L - len(r):] = torch.tensor(r, dtype=torch.long)
+                    mask[j, L - len(r):] = 1
+                ids, mask = ids.to(self.device), mask.to(self.device)
+                posid = (mask.cumsum(dim=1) - 1).clamp_min(0)
+                kw = dict(input_ids=ids, attention_mask=mask, position_ids=posid)
+                try:
+                    logits = self.language_model(logits_to_keep=1, **kw).logits[:, -1, :]
+                except TypeError:
+                    logits = self.language_model(**kw).logits[:, -1, :]
+                c = self._cost_from_logits(logits, answer_tokens) * language_cost_weight
+                for j, v in enumerate(c.tolist()):
+                    costs[lo + j] += v
+        return costs
 
     def _create_failure_result(self, target_smiles, generated_tokens=None) -> Dict[str, Any]:
         return {"target": target_smiles, "success": False, "time": 0.0, "reaction_list": None, "cost": None,
@@ -388,7 +436,10 @@ class GraphLLMForCausalMLM(nn.Module):
             expand_fn=lambda s: self.one_step_reaction(s, input_ids=input_ids, design_text=design_text,
                                                        molecule_graphs=molecule_graphs, topk=expansion_topk, **kwargs),
             value_fn=lambda s, r: self.estimate_synthesis_complexity(s, input_ids, r, molecule_cost_weight, language_cost_weight),
-            iterations=iterations, max_time=max_planning_time)
+            iterations=iterations, max_time=max_planning_time,
+            value_batch_fn=(lambda items: self.estimate_synthesis_complexity_batch(items, input_ids, molecule_cost_weight,
+                                                                                     language_cost_weight))
+            if self.batch_values else None)
         total = time.time() - t0
         if success:
             reactions, templates, cost, analysis = route.get_reaction_list()

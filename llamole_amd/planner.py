@@ -206,19 +206,44 @@ class Route:
         return self.templates
 
 
+class _MolView:
+    __slots__ = ("mol",)
+
+    def __init__(self, mol: str):
+        self.mol = mol
+
+
+class ReactionView:
+    """What ``value_fn`` may read of a parent reaction (``depth``, ``template``, ``children[i].mol``) at the moment the
+    reference evaluates a new reactant: the reaction exists and holds only the reactants attached BEFORE this one
+    (mol_tree.py:25-33 evaluates, then MolNode.__init__ appends).  Lets a whole expansion be evaluated in one batch."""
+    __slots__ = ("depth", "template", "children")
+
+    def __init__(self, depth: int, template, earlier_reactants: Sequence[str]):
+        self.depth = depth
+        self.template = template
+        self.children = [_MolView(m) for m in earlier_reactants]
+
+
 class SearchTree:
-    def __init__(self, target_mol: str, known_mols: Iterable[str], value_fn: Callable):
+    def __init__(self, target_mol: str, known_mols: Iterable[str], value_fn: Callable,
+                 value_batch_fn: Optional[Callable] = None):
         self.target_mol = target_mol
         self.known = known_mols if isinstance(known_mols, (set, frozenset)) else set(known_mols)
         self.value_fn = value_fn
+        # optional: value_batch_fn([(mol, ReactionView), ...]) -> [float, ...] evaluates every new, non-purchasable
+        # reactant of one expansion in ONE call (SURVEY.md 8 f2; the reference pays one LLM forward per node).  The
+        # estimate of a purchasable molecule is never read (its value is 0), so those are not requested.
+        self.value_batch_fn = value_batch_fn
         self.mol_nodes: List[Molecule] = []
         self.reaction_nodes: List[Reaction] = []
         self.root = self._new_mol(target_mol, None)
         self.succ = False
         self.search_status = 0
 
-    def _new_mol(self, mol: str, parent: Optional[Reaction]) -> Molecule:
-        estimate = self.value_fn(mol, parent)       # one LLM forward per new tree node in Llamole
+    def _new_mol(self, mol: str, parent: Optional[Reaction], estimate: Optional[float] = None) -> Molecule:
+        if estimate is None:
+            estimate = self.value_fn(mol, parent)   # one LLM forward per new tree node in Llamole
         node = Molecule(mol, estimate, parent, mol in self.known)
         self.mol_nodes.append(node)
         node.id = len(self.mol_nodes)
@@ -236,13 +261,26 @@ class SearchTree:
             return self._dead_end(node)
         assert node.open
         lineage = node.ancestors()
+        estimates = None
+        if self.value_batch_fn is not None:
+            requests = []
+            for i in range(len(costs)):
+                if any(m in lineage for m in reactant_lists[i]):
+                    continue
+                for k, m in enumerate(reactant_lists[i]):
+                    if m not in self.known:
+                        requests.append((m, ReactionView(node.depth + 1, templates[i], reactant_lists[i][:k])))
+            estimates = iter(self.value_batch_fn(requests)) if requests else iter(())
         for i in range(len(costs)):
             assert costs[i] >= 0
             if any(m in lineage for m in reactant_lists[i]):
                 continue                                   # would re-introduce an ancestor: cycle
             rxn = Reaction(node, costs[i], templates[i], analysis_tokens)
             for m in reactant_lists[i]:
-                self._new_mol(m, rxn)
+                if estimates is None:
+                    self._new_mol(m, rxn)
+                else:
+                    self._new_mol(m, rxn, 0.0 if m in self.known else float(next(estimates)))
             rxn.close()
             self.reaction_nodes.append(rxn)
             rxn.id = len(self.reaction_nodes)
@@ -277,8 +315,8 @@ class SearchTree:
 
 
 def molstar(target_mol, target_mol_id, starting_mols, expand_fn, value_fn, iterations, viz=False, viz_dir=None,
-            max_time=300) -> Tuple[bool, Optional[Route], int]:
-    tree = SearchTree(target_mol, starting_mols, value_fn)
+            max_time=300, value_batch_fn=None) -> Tuple[bool, Optional[Route], int]:
+    tree = SearchTree(target_mol, starting_mols, value_fn, value_batch_fn)
     done = -1
     t0 = time.time()
     if not tree.succ:
