@@ -132,6 +132,22 @@ class GraphPredictor(_GinModule):
         run = self.template_runner or _default_template_runner()
         return merge_template_outcomes(topk_probs, templates, product_smiles, run)
 
+    @torch.no_grad()
+    def sample_templates_batch(self, product_graphs, c, product_smiles_list, topk=10):
+        """``sample_templates`` for several products with ONE GIN forward + one top-k launch (batched
+        expansions of concurrent A* searches); the host tail (template application, merge) runs per product.
+        product_graphs: list of GraphData; c [G, text_input_size]; returns a list of (reactants, scores, templates)."""
+        from .graph_data import GraphBatch
+        gb = GraphBatch.from_data_list(list(product_graphs))
+        probs, idx = self.topk_templates(gb.x, gb.edge_index, gb.edge_attr, gb.batch, c, topk)
+        probs, idx = probs.float().cpu().numpy(), idx.cpu().numpy()
+        run = self.template_runner or _default_template_runner()
+        out = []
+        for g, smiles in enumerate(product_smiles_list):
+            templates = [self.label_to_template[int(i)] for i in idx[g]]
+            out.append(merge_template_outcomes(probs[g], templates, smiles, run))
+        return out
+
     # cost model ------------------------------------------------------------------------------
     def init_neural_cost(self, model_path, verbose=False):
         model_file = os.path.join(model_path, "cost_model.pt")

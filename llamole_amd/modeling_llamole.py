@@ -61,6 +61,7 @@ class GraphLLMForCausalMLM(nn.Module):
         self.timings: Dict[str, float] = {}
         self.decoder = None      # optional llm_decode.GraphedDecoder (HIP-graph decode step); None = HF generate
         self.reuse_query_kv = False
+        self.batch_retro = False   # lock-step A* searches of one batch with batched expansions (retrosynthesize_many)
         self.batch_values = True   # A* value estimates of one expansion in one LLM forward (estimate_synthesis_complexity_batch)
 
     def enable_graphed_decode(self, use_graph: bool = True, sync_every: int = 16, fused_cache: bool = False,
@@ -321,6 +322,73 @@ class GraphLLMForCausalMLM(nn.Module):
         return {"reactants": reactants, "scores": scores, "templates": templates,
                 "analysis": head + analysis.cpu().squeeze().tolist()}
 
+    @torch.no_grad()
+    def one_step_reaction_batch(self, requests, topk, **kwargs):
+        """``one_step_reaction`` for several products at once: one GIN-encoder forward over every spliced
+        graph, ONE batched LLM decode over the left-padded prompts, one query-token forward, one predictor forward + top-k.
+        requests: dicts with product_smiles, input_ids (1-D or None), design_text, molecule_graphs (or None).  Returns one
+        result dict per request, as ``one_step_reaction`` would."""
+        results: List[Optional[Dict[str, Any]]] = [None] * len(requests)
+        prompts, graph_lists, products, live = [], [], [], []
+        for i, rq in enumerate(requests):
+            prompt = self.tokenizer.encode(f"{rq.get('design_text')} To synthesize <molecule>, follow these procedures: ",
+                                           add_special_tokens=False, return_tensors="pt").to(self.device)
+            ctx_ids, ctx_graphs = rq.get("input_ids"), rq.get("molecule_graphs")
+            with_context = ctx_ids is not None and ctx_graphs is not None
+            if with_context:
+                prompt = torch.cat([ctx_ids.view(1, -1), prompt], dim=-1)
+            product = self.smiles_to_graph(rq["product_smiles"])
+            if product is None:
+                results[i] = {"reactants": [], "scores": [], "templates": [],
+                              "analysis": self.tokenizer.encode("Invalid product SMILES", add_special_tokens=False)}
+                continue
+            product.to(self.device)
+            prompts.append(prompt)
+            graph_lists.append((ctx_graphs.to_data_list() if with_context else []) + [product])
+            products.append(product)
+            live.append(i)
+        if not live:
+            return results
+        # ---- one encoder forward for every <molecule> slot of every prompt
+        emb_layer = self.language_model.get_input_embeddings()
+        all_graphs = GraphBatch.from_data_list([g for gl in graph_lists for g in gl])
+        mol = self.graph_encoder(all_graphs.x, all_graphs.edge_index, all_graphs.edge_attr, all_graphs.batch)
+        mol = self.graph_to_lm_connector(mol.to(next(self.graph_to_lm_connector.parameters()).dtype))
+        L = max(p.shape[1] for p in prompts)
+        embeds, mask, off = [], torch.zeros((len(prompts), L), dtype=torch.long, device=self.device), 0
+        pad_id = self.tokenizer.eos_token_id
+        for j, (p, gl) in enumerate(zip(prompts, graph_lists)):
+            e = emb_layer(p)
+            pos = (p == self.token_id_dict["<molecule>"]).nonzero()
+            assert pos.shape[0] == len(gl), \
+                f"Number of molecule tokens ({pos.shape[0]}) does not match number of molecule embeddings ({len(gl)})"
+            e[pos[:, 0], pos[:, 1]] = mol[off:off + len(gl)].to(e.dtype)
+            off += len(gl)
+            if p.shape[1] < L:
+                padding = emb_layer(torch.full((1, L - p.shape[1]), pad_id, dtype=torch.long, device=self.device))
+                e = torch.cat([padding, e], dim=1)
+            mask[j, L - p.shape[1]:] = 1
+            embeds.append(e)
+        embeds = torch.cat(embeds, dim=0)
+        if "max_new_tokens" in kwargs:
+            kwargs["max_new_tokens"] = 512
+        analysis = self._llm_generate(attention_mask=mask, inputs_embeds=embeds, **kwargs)
+        retro_ids = self.add_special_body_tokens(analysis, self.token_id_dict["<retro_body>"], self.num_body_tokens,
+                                                 start_token_id=self.token_id_dict["<retro_start>"])
+        hidden = self._query_hidden(retro_ids)
+        cond = self.lm_to_graph_predictor(hidden.to(next(self.lm_to_graph_predictor.parameters()).dtype))
+        smiles = [requests[i]["product_smiles"] for i in live]
+        if hasattr(self.graph_predictor, "sample_templates_batch"):
+            triples = self.graph_predictor.sample_templates_batch(products, cond, smiles, topk)
+        else:
+            triples = [self.graph_predictor.sample_templates(g, cond[j:j + 1], s, topk) for j, (g, s) in enumerate(zip(products, smiles))]
+        for j, i in enumerate(live):
+            reactants, scores, templates = triples[j]
+            head = self.tokenizer.encode(f"To synthesize {smiles[j]}, follow these procedures: ")
+            results[i] = {"reactants": reactants, "scores": scores, "templates": templates,
+                          "analysis": head + analysis[j].cpu().tolist()}
+        return results
+
     _ANSWERS = ["All readily available", "Some commercial, some need 1-2 steps",
                 "Mix of commercial and multi-step synthesis", "Mostly require complex synthesis",
                 "All require extensive multi-step synthesis"]
@@ -450,6 +518,61 @@ class GraphLLMForCausalMLM(nn.Module):
         return {"target": target, "success": False, "time": total, "reaction_list": None, "cost": None,
                 "templates": None, "analysis_tokens": None, "route_length": None}
 
+    @torch.no_grad()
+    def retrosynthesize_many(self, input_ids_list, smiles_list, molecule_graphs=None, expansion_topk=50, iterations=100,
+                             starting_mols=None, molecule_cost_weight=0, language_cost_weight=1, max_planning_time=300,
+                             rollback=True, design_text=None, **kwargs) -> List[Dict[str, Any]]:
+        """``retrosynthesize`` for several targets with their A* searches advanced in lock step (planner.molstar_many):
+        each round's expansions share one batched LLM decode / GIN forward (one_step_reaction_batch) and each expansion's
+        new nodes share one value forward.  Pre-checks, rollbacks and result dicts are those of ``retrosynthesize``;
+        ``max_planning_time`` is measured on the shared clock."""
+        from .planner import molstar_many
+        if starting_mols is None:
+            if self.graph_predictor.available is None:
+                raise ValueError("No starting molecules provided and no available starting molecules found.")
+            starting_mols = self.graph_predictor.available["smiles"].tolist()
+        known = starting_mols if isinstance(starting_mols, (set, frozenset)) else set(starting_mols)
+        out: List[Optional[Dict[str, Any]]] = [None] * len(smiles_list)
+        targets, where = [], []
+        for i, smiles in enumerate(smiles_list):
+            ids = input_ids_list[i]
+            if smiles is None and rollback:
+                out[i] = self._create_failure_result(None, self.retrosynthesize_rollback(ids, design_text, None, **kwargs))
+                continue
+            target = smiles.replace("*", "[H]") if "*" in smiles else smiles
+            if not self.graph_decoder.check_valid(target) and rollback:
+                out[i] = self._create_failure_result(target, self.retrosynthesize_rollback(ids, design_text, target, **kwargs))
+                continue
+            targets.append(target)
+            where.append(i)
+        if targets:
+            t0 = time.time()
+
+            def expand_batch(picks):
+                reqs = [dict(product_smiles=mol, input_ids=input_ids_list[where[k]], design_text=design_text,
+                             molecule_graphs=molecule_graphs) for k, mol in picks]
+                return self.one_step_reaction_batch(reqs, expansion_topk, **kwargs)
+            outcomes = molstar_many(
+                targets, known, expand_batch,
+                value_fn=lambda s, r: self.estimate_synthesis_complexity(s, None, r, molecule_cost_weight, language_cost_weight),
+                iterations=iterations, max_time=max_planning_time,
+                value_batch_fn=lambda items: self.estimate_synthesis_complexity_batch(items, None, molecule_cost_weight,
+                                                                                      language_cost_weight))
+            total = time.time() - t0
+            for k, (success, route, _) in enumerate(outcomes):
+                i, target = where[k], targets[k]
+                if success:
+                    reactions, templates, cost, analysis = route.get_reaction_list()
+                    out[i] = {"target": target, "success": True, "time": total, "reaction_list": reactions, "cost": cost,
+                              "templates": templates, "analysis_tokens": analysis, "route_length": route.length}
+                elif rollback:
+                    out[i] = self._create_failure_result(target, self.retrosynthesize_rollback(input_ids_list[i], design_text,
+                                                                                                  target, **kwargs))
+                else:
+                    out[i] = {"target": target, "success": False, "time": total, "reaction_list": None, "cost": None,
+                              "templates": None, "analysis_tokens": None, "route_length": None}
+        return out
+
     # ------------------------------------------------------------------ top level
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, molecule_properties=None, molecule_graphs=None,
@@ -471,8 +594,17 @@ class GraphLLMForCausalMLM(nn.Module):
             raise ValueError("Either do_molecular_design must be True/False or input_smiles_list must be provided.")
         if do_retrosynthesis:
             info["retro_plan_dict"] = {}
-            for i, smiles in enumerate(info["smiles_list"]):
-                design_text = design_text_list[0] if design_text_list is not None else None
+            design_text = design_text_list[0] if design_text_list is not None else None
+            if self.batch_retro and len(info["smiles_list"]) > 1:
+                ids_list = [input_ids[i] if input_ids.dim() > 1 else input_ids for i in range(len(info["smiles_list"]))]
+                plans = self.retrosynthesize_many(
+                    ids_list, info["smiles_list"], molecule_graphs=molecule_graphs, starting_mols=starting_mols,
+                    expansion_topk=expansion_topk, iterations=iterations, molecule_cost_weight=molecule_cost_weight,
+                    language_cost_weight=language_cost_weight, max_planning_time=max_planning_time, design_text=design_text,
+                    **kwargs)
+                for smiles, plan in zip(info["smiles_list"], plans):
+                    info["retro_plan_dict"][smiles] = plan
+            for i, smiles in enumerate(info["smiles_list"] if not (self.batch_retro and len(info["smiles_list"]) > 1) else []):
                 info["retro_plan_dict"][smiles] = self.retrosynthesize(
                     input_ids[i] if input_ids.dim() > 1 else input_ids, smiles, molecule_graphs=molecule_graphs,
                     starting_mols=starting_mols, expansion_topk=expansion_topk, iterations=iterations,

@@ -314,34 +314,88 @@ class SearchTree:
         return route
 
 
+class MolStarSearch:
+    """One A* search as an explicit state machine: ``select()`` -> the open molecule to expand (or None when the search
+    is over), ``apply(result)`` -> feed the expansion back.  ``molstar`` drives one of these; ``molstar_many`` drives
+    several in lock step so that their expansions can share one batched LLM decode / GIN forward."""
+
+    def __init__(self, target_mol, starting_mols, value_fn, iterations, max_time=300, value_batch_fn=None):
+        self.tree = SearchTree(target_mol, starting_mols, value_fn, value_batch_fn)
+        self.iterations = iterations
+        self.max_time = max_time
+        self.t0 = time.time()
+        self.done_iters = 0
+        self.finished = self.tree.succ
+        self._node = None
+
+    def select(self) -> Optional[Molecule]:
+        if self.finished:
+            return None
+        if self.done_iters >= self.iterations:
+            self.finished = True
+            return None
+        self.done_iters += 1          # iterations ENTERED, like the reference's `for done in range(iterations)` + 1
+        if time.time() - self.t0 > self.max_time:
+            self.finished = True
+            return None
+        best_node, best_score = None, INF
+        for m in self.tree.mol_nodes:                     # first minimum wins, like np.argmin
+            if m.open:
+                score = m.target_value()
+                if score < best_score:
+                    best_node, best_score = m, score
+        if best_node is None:
+            self.finished = True
+            return None
+        self.tree.search_status = best_score
+        self._node = best_node
+        return best_node
+
+    def apply(self, result) -> None:
+        node, tree = self._node, self.tree
+        self._node = None
+        if result is not None and len(result["scores"]) > 0:
+            scores = result["scores"]
+            costs = [-math.log(min(max(float(s), 1e-3), 1.0)) for s in scores]
+            reactant_lists = [list(dict.fromkeys(result["reactants"][j].split("."))) for j in range(len(scores))]
+            if tree.expand(node, reactant_lists, costs, result["templates"], result["analysis"]):
+                self.finished = True
+            elif tree.root.succ_value <= tree.search_status:
+                self.finished = True
+        else:
+            tree.expand(node, None, None, None, None)
+
+    def outcome(self) -> Tuple[bool, Optional[Route], int]:
+        route = self.tree.best_route() if self.tree.succ else None
+        return self.tree.succ, route, self.done_iters
+
+
 def molstar(target_mol, target_mol_id, starting_mols, expand_fn, value_fn, iterations, viz=False, viz_dir=None,
             max_time=300, value_batch_fn=None) -> Tuple[bool, Optional[Route], int]:
-    tree = SearchTree(target_mol, starting_mols, value_fn, value_batch_fn)
-    done = -1
-    t0 = time.time()
-    if not tree.succ:
-        for done in range(iterations):
-            if time.time() - t0 > max_time:
-                break
-            best_node, best_score = None, INF
-            for m in tree.mol_nodes:                      # first minimum wins, like np.argmin
-                if m.open:
-                    score = m.target_value()
-                    if score < best_score:
-                        best_node, best_score = m, score
-            if best_node is None:
-                break
-            tree.search_status = best_score
-            result = expand_fn(best_node.mol)
-            if result is not None and len(result["scores"]) > 0:
-                scores = result["scores"]
-                costs = [-math.log(min(max(float(s), 1e-3), 1.0)) for s in scores]
-                reactant_lists = [list(dict.fromkeys(result["reactants"][j].split("."))) for j in range(len(scores))]
-                if tree.expand(best_node, reactant_lists, costs, result["templates"], result["analysis"]):
-                    break
-                if tree.root.succ_value <= tree.search_status:
-                    break
-            else:
-                tree.expand(best_node, None, None, None, None)
-    route = tree.best_route() if tree.succ else None
-    return tree.succ, route, done + 1
+    search = MolStarSearch(target_mol, starting_mols, value_fn, iterations, max_time, value_batch_fn)
+    while True:
+        node = search.select()
+        if node is None:
+            break
+        search.apply(expand_fn(node.mol))
+    return search.outcome()
+
+
+def molstar_many(target_mols: Sequence[str], starting_mols, expand_batch_fn, value_fn, iterations, max_time=300,
+                 value_batch_fn=None) -> List[Tuple[bool, Optional[Route], int]]:
+    """Independent A* searches advanced in lock step: each round every unfinished search nominates its best open
+    molecule and ``expand_batch_fn([(search_index, mol), ...]) -> [result, ...]`` expands them together.  Every search
+    sees exactly the calls a solo ``molstar`` would make, so with deterministic callbacks the routes are the same;
+    ``max_time`` is measured on the shared wall clock."""
+    known = starting_mols if isinstance(starting_mols, (set, frozenset)) else set(starting_mols)
+    searches = [MolStarSearch(t, known, value_fn, iterations, max_time, value_batch_fn) for t in target_mols]
+    while True:
+        picks = [(i, s.select()) for i, s in enumerate(searches)]
+        picks = [(i, n) for i, n in picks if n is not None]
+        if not picks:
+            break
+        results = expand_batch_fn([(i, n.mol) for i, n in picks])
+        assert len(results) == len(picks)
+        for (i, _), res in zip(picks, results):
+            searches[i].apply(res)
+    return [s.outcome() for s in searches]

@@ -161,3 +161,24 @@ def test_gin_edge_cases_vs_oracle():
     np.testing.assert_allclose(got1, ref1, rtol=2e-3, atol=5e-4)
     with pytest.raises(ValueError, match="condition rows"):
         pred(x.cuda(), ei.cuda(), ea.cuda(), batch.cuda(), c[:2].cuda())
+
+
+def test_sample_templates_batch_equals_per_product():
+    """One GIN forward + one top-k launch for several products == sample_templates product by product."""
+    from llamole_amd.graph_data import GraphBatch
+    name = "gin_l3_h64"
+    L, H, out_dim, G, seed = GIN_CASES[name]
+    x, ei, ea, batch = [t.cuda() for t in synth.make_mol_graphs(G, seed)]
+    gb = GraphBatch(x, ei, ea, batch, [int((batch == g).sum()) for g in range(G)])
+    graphs = gb.to_data_list()
+    m = _predictor(name)
+    m.template_runner = fake_template_runner
+    c = torch.randn(G, 768, generator=torch.Generator().manual_seed(1)).cuda()
+    smiles = [f"PROD{g}" for g in range(G)]
+    together = m.sample_templates_batch(graphs, c, smiles, topk=20)
+    assert len(together) == G
+    for g in range(G):
+        r, s, t = m.sample_templates(graphs[g], c[g:g + 1], smiles[g], topk=20)
+        rb, sb, tb = together[g]
+        assert rb == r and tb == t
+        np.testing.assert_allclose(sb, s, rtol=1e-4, atol=1e-7)
