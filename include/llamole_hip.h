@@ -155,6 +155,20 @@ int ll_gin_forward(void *handle, const int32_t *x, const int32_t *rowptr, const 
                    const int32_t *batch, const int32_t *gptr, int n_nodes, int n_edges, int n_graphs, const float *c,
                    float *out, float *pooled, void *stream);
 
+/* Training path of the predictor (reference modeling_llamole.py:385-419: the retro cross-entropy
+ * reaches the LLM through c = lm_to_graph_predictor(hidden); the predictor's own weights are frozen):
+ * ll_gin_forward_train = ll_gin_forward (predictor, c != NULL) that also keeps the per-layer activations;
+ * ll_gin_backward_c    = d loss / d c [G,text_dim] from d loss / d logits [G,out_dim] for the batch of the last
+ *                        ll_gin_forward_train call (LL_ESTATE otherwise).  Edges here in CSR-by-SOURCE form: rowptr_src [n+1],
+ *                        and for e in [rowptr_src[v], rowptr_src[v+1]) the message destination dst[e] and bond class attr[e].
+ * Replaces torch.autograd through GNNRetrosynthsizer.forward (graph_predictor/model.py:306-353). */
+int ll_gin_forward_train(void *handle, const int32_t *x, const int32_t *rowptr, const int32_t *src, const int32_t *attr,
+                         const int32_t *batch, const int32_t *gptr, int n_nodes, int n_edges, int n_graphs, const float *c,
+                         float *out, void *stream);
+int ll_gin_backward_c(void *handle, const int32_t *rowptr_src, const int32_t *dst, const int32_t *attr, const int32_t *batch,
+                      const int32_t *gptr, int n_nodes, int n_edges, int n_graphs, const float *c, const float *dlogits, float *dc,
+                      void *stream);
+
 /* softmax over out_dim then top-k (GraphPredictor.sample_templates, graph_predictor/model.py:174-179).
  * probs [rows,k] descending, idx [rows,k]. k <= 64. */
 int ll_softmax_topk(const float *logits, int rows, int out_dim, int k, float *probs, int32_t *idx, void *stream);

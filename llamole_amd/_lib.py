@@ -72,6 +72,8 @@ SIGNATURES = {
     "ll_decode_attn_rope_bf16": (_I, [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _I, _F, _P]),
     "ll_gemv_fused_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "ll_set_gemv_nt": (_I, [_I]),
+    "ll_gin_forward_train": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "ll_gin_backward_c": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "ll_sample_token_bf16": (_I, [_P, _I64, _I, _I, _F, _F, _I, _P, _P, _I, _I64, _P, _P, _P, _I64, _I, _P, _P, _P, _I, _P, _P]),
 }
 

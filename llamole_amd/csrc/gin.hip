@@ -9,6 +9,7 @@
 // (degree <= ~6) incoming edges and accumulates in registers -- no atomics, deterministic summation order,
 // feature rows read as coalesced 256-B segments.  Virtual-node max-pool / add-pool are segment reductions
 // over the sorted `batch` vector (one workgroup per graph).  All Linears go through the shared MFMA GEMM.
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -523,6 +524,13 @@ struct GinEngine {
     const float *w32 = nullptr;
     GBuf wop;
     GBuf h, h_in, z0, t1, t1a, z, vn, pool32, poola, vt1, vt1a, vt2, mod, csilu, head1, head1a, head2;
+    // ---- training (ll_gin_forward keep=1 + ll_gin_backward_c): per-layer activations, transposed weights, gradients
+    bool keep = false;
+    int kept_n = -1, kept_G = -1;
+    std::vector<GBuf> sv_hin, sv_t1, sv_z, sv_vt1;
+    GBuf sv_head1, wT, adT;
+    GBuf g_dh, g_dz, g_dt1a, g_dt1, g_dz0, g_c3, g_dmod, g_dmoda, g_dvn, g_dvna, g_dvt1a, g_dvt1, g_dpool, g_tmpG, g_dhead1a,
+        g_dhead1, g_dlog, g_slabs, g_dcs;
     const float *pf(const std::string &n) const {
         for (auto &p : layout)
             if (p.name == n) return w32 + p.offset;
@@ -585,6 +593,14 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
         const float *mod = cf.kind == 1 ? e->mod.as<float>() + (size_t)l * Gp * 3 * H : nullptr;
         hipLaunchKernelGGL(gin_post_kernel, w_n, wblk, 0, st, e->z.as<float>(), e->h_in.as<float>(), lnw, lnb, mod, batch, e->h.as<float>(), n, H, last ? 0 : 1);
         LL_LAUNCH_CHECK();
+        if (e->keep) {
+            LL_TRY(e->sv_hin[l].ensure((size_t)np * H * 4));
+            LL_TRY(e->sv_t1[l].ensure((size_t)np * 4 * H * 4));
+            LL_TRY(e->sv_z[l].ensure((size_t)np * H * 4));
+            LL_HIP(hipMemcpyAsync(e->sv_hin[l].p, e->h_in.p, (size_t)n * H * 4, hipMemcpyDeviceToDevice, st));
+            LL_HIP(hipMemcpyAsync(e->sv_t1[l].p, e->t1.p, (size_t)n * 4 * H * 4, hipMemcpyDeviceToDevice, st));
+            LL_HIP(hipMemcpyAsync(e->sv_z[l].p, e->z.p, (size_t)n * H * 4, hipMemcpyDeviceToDevice, st));
+        }
         if (!last) {  // virtual node update from max-pooled h_in (model.py:147-150)
             const std::string q = "mlp_virtualnode_list." + std::to_string(l) + ".";
             hipLaunchKernelGGL((segment_pool_kernel<T, true>), dim3(G, cdiv(H, 1024)), blk, 0, st, e->h_in.as<float>(), gptr, (float *)nullptr, e->poola.as<T>(), H);
@@ -592,6 +608,10 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
             LL_TRY(linear_launch(dt, e->poola.p, H, e->pw(q + "0.weight"), H, e->pf(q + "0.bias"), e->vt1.p, 4 * H, G, 4 * H, H, 0, 1, st));
             hipLaunchKernelGGL((rows_ln_act_kernel<T>), w_g, wblk, 0, st, e->vt1.as<float>(), e->pf(q + "1.weight"), e->pf(q + "1.bias"), e->vt1a.as<T>(), G, 4 * H, 1);
             LL_LAUNCH_CHECK();
+            if (e->keep) {
+                LL_TRY(e->sv_vt1[l].ensure((size_t)Gp * 4 * H * 4));
+                LL_HIP(hipMemcpyAsync(e->sv_vt1[l].p, e->vt1.p, (size_t)G * 4 * H * 4, hipMemcpyDeviceToDevice, st));
+            }
             LL_TRY(linear_launch(dt, e->vt1a.p, 4 * H, e->pw(q + "4.weight"), 4 * H, e->pf(q + "4.bias"), e->vt2.p, H, G, H, 4 * H, 0, 1, st));
             hipLaunchKernelGGL(add_rows_kernel, dim3(cdiv(G * H, 256)), blk, 0, st, e->vn.as<float>(), e->vt2.as<float>(), (int64_t)G * H);
             LL_LAUNCH_CHECK();
@@ -616,8 +636,391 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
         LL_TRY(linear_launch(dt, e->poola.p, H, e->pw("decoder.0.weight"), H, e->pf("decoder.0.bias"), e->head1.p, 4 * H, G, 4 * H, H, 0, 1, st));
         hipLaunchKernelGGL((rows_ln_act_kernel<T>), w_g, wblk, 0, st, e->head1.as<float>(), e->pf("decoder.1.weight"), e->pf("decoder.1.bias"), e->head1a.as<T>(), G, 4 * H, 1);
         LL_LAUNCH_CHECK();
+        if (e->keep) {
+            LL_TRY(e->sv_head1.ensure((size_t)Gp * 4 * H * 4));
+            LL_HIP(hipMemcpyAsync(e->sv_head1.p, e->head1.p, (size_t)G * 4 * H * 4, hipMemcpyDeviceToDevice, st));
+            e->kept_n = n;
+            e->kept_G = G;
+        }
         LL_TRY(linear_launch(dt, e->head1a.p, 4 * H, e->pw("decoder.4.weight"), 4 * H, e->pf("decoder.4.bias"), out, cf.out_dim, G, cf.out_dim, 4 * H, 0, 1, st));
     }
+    return LL_OK;
+}
+
+
+// ================================================================================================ training: d logits -> d c
+// Backward of the predictor forward w.r.t. the text condition c only (weights are frozen in Llamole's SFT: the retro
+// cross-entropy reaches the LLM through c = lm_to_graph_predictor(hidden), reference modeling_llamole.py:385-419).
+// It is still a full reverse sweep over the node features: c enters every layer through (shift, scale, gate).
+
+__device__ __forceinline__ float gelu_grad(float u) {
+    return 0.5f * (1.f + erff(u * 0.70710678118654752440f)) + u * 0.39894228040143267794f * expf(-0.5f * u * u);
+}
+
+// dt = d/dt [ GELU(LN_affine(t)) ] . g   (rows of C <= 8192), one wave per row; dt in operand dtype (next GEMM's A)
+template <typename T>
+__global__ __launch_bounds__(64) void ln_gelu_bwd_kernel(const float *__restrict__ t, const float *__restrict__ w,
+                                                          const float *__restrict__ b, const float *__restrict__ g,
+                                                          T *__restrict__ dt, int R, int C) {
+    const int r = blockIdx.x;
+    if (r >= R) return;
+    const int lane = threadIdx.x;
+    const float *x = t + (int64_t)r * C, *gr = g + (int64_t)r * C;
+    constexpr int MAXE = 32;
+    float4 v[MAXE];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int k = (lane + e * 64) * 4;
+        v[e] = k < C ? *reinterpret_cast<const float4 *>(x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += v[e].x + v[e].y + v[e].z + v[e].w;
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float vr = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        if ((lane + e * 64) * 4 < C) {
+            const float d0 = v[e].x - mean, d1 = v[e].y - mean, d2 = v[e].z - mean, d3 = v[e].w - mean;
+            vr += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(vr) / (float)C + 1e-5f);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {     // v[e] <- xhat; accumulate mean(dxhat), mean(dxhat * xhat)
+        const int k = (lane + e * 64) * 4;
+        if (k < C) {
+            const float4 ww = *reinterpret_cast<const float4 *>(w + k), bb = *reinterpret_cast<const float4 *>(b + k);
+            const float4 gg = *reinterpret_cast<const float4 *>(gr + k);
+            float xh[4] = {(v[e].x - mean) * rstd, (v[e].y - mean) * rstd, (v[e].z - mean) * rstd, (v[e].w - mean) * rstd};
+            const float wv[4] = {ww.x, ww.y, ww.z, ww.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w}, gv[4] = {gg.x, gg.y, gg.z, gg.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float dx = gv[q] * gelu_grad(xh[q] * wv[q] + bv[q]) * wv[q];
+                m1 += dx;
+                m2 += dx * xh[q];
+            }
+            v[e] = make_float4(xh[0], xh[1], xh[2], xh[3]);
+        }
+    }
+    m1 = wave_sum(m1) / (float)C;
+    m2 = wave_sum(m2) / (float)C;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int k = (lane + e * 64) * 4;
+        if (k < C) {
+            const float4 ww = *reinterpret_cast<const float4 *>(w + k), bb = *reinterpret_cast<const float4 *>(b + k);
+            const float4 gg = *reinterpret_cast<const float4 *>(gr + k);
+            const float xh[4] = {v[e].x, v[e].y, v[e].z, v[e].w};
+            const float wv[4] = {ww.x, ww.y, ww.z, ww.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w}, gv[4] = {gg.x, gg.y, gg.z, gg.w};
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float dx = gv[q] * gelu_grad(xh[q] * wv[q] + bv[q]) * wv[q];
+                o[q] = rstd * (dx - m1 - xh[q] * m2);
+            }
+            gin_store4<T>(dt + (int64_t)r * C + k, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+}
+
+// Layer tail backward (predictor): h = gate * act(LN0(z) (1 + scale) + shift) + h_in.  One wave per node.
+//   dz (operand dtype), per-node contributions to d shift / d scale / d gate (summed per graph afterwards); dh is left in
+//   place as the running d h_in (the residual path is the identity).
+template <typename T>
+__global__ __launch_bounds__(64) void gin_post_bwd_kernel(const float *__restrict__ z, const float *__restrict__ mod,
+                                                           const int *__restrict__ batch, const float *__restrict__ dh,
+                                                           T *__restrict__ dz, float *__restrict__ c3 /*[3][n][H]*/, int n,
+                                                           int H, int gelu) {
+    const int v = blockIdx.x;
+    if (v >= n) return;
+    const int lane = threadIdx.x;
+    const float *x = z + (int64_t)v * H;
+    constexpr int MAXE = 8;
+    float4 t[MAXE];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int k = (lane + e * 64) * 4;
+        t[e] = k < H ? *reinterpret_cast<const float4 *>(x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += t[e].x + t[e].y + t[e].z + t[e].w;
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float vr = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        if ((lane + e * 64) * 4 < H) {
+            const float d0 = t[e].x - mean, d1 = t[e].y - mean, d2 = t[e].z - mean, d3 = t[e].w - mean;
+            vr += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(vr) / (float)H + 1e-5f);
+    const float *m = mod + (int64_t)batch[v] * 3 * H;
+    float4 dxh[MAXE];
+    float m1 = 0.f, m2 = 0.f;
+    const int64_t plane = (int64_t)n * H;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int k = (lane + e * 64) * 4;
+        dxh[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < H) {
+            const float4 sh = *reinterpret_cast<const float4 *>(m + k), sc = *reinterpret_cast<const float4 *>(m + H + k);
+            const float4 gt = *reinterpret_cast<const float4 *>(m + 2 * H + k);
+            const float4 dd = *reinterpret_cast<const float4 *>(dh + (int64_t)v * H + k);
+            const float xh[4] = {(t[e].x - mean) * rstd, (t[e].y - mean) * rstd, (t[e].z - mean) * rstd, (t[e].w - mean) * rstd};
+            const float shv[4] = {sh.x, sh.y, sh.z, sh.w}, scv[4] = {sc.x, sc.y, sc.z, sc.w}, gtv[4] = {gt.x, gt.y, gt.z, gt.w};
+            const float dv[4] = {dd.x, dd.y, dd.z, dd.w};
+            float cs[4], csc[4], cg[4], dx[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float y0 = xh[q] * (1.f + scv[q]) + shv[q];
+                const float y = gelu ? gelu_erf(y0) : y0;
+                cg[q] = dv[q] * y;
+                const float dy0 = dv[q] * gtv[q] * (gelu ? gelu_grad(y0) : 1.f);
+                cs[q] = dy0;
+                csc[q] = dy0 * xh[q];
+                dx[q] = dy0 * (1.f + scv[q]);
+                m1 += dx[q];
+                m2 += dx[q] * xh[q];
+            }
+            t[e] = make_float4(xh[0], xh[1], xh[2], xh[3]);
+            dxh[e] = make_float4(dx[0], dx[1], dx[2], dx[3]);
+            *reinterpret_cast<float4 *>(c3 + (int64_t)v * H + k) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+            *reinterpret_cast<float4 *>(c3 + plane + (int64_t)v * H + k) = make_float4(csc[0], csc[1], csc[2], csc[3]);
+            *reinterpret_cast<float4 *>(c3 + 2 * plane + (int64_t)v * H + k) = make_float4(cg[0], cg[1], cg[2], cg[3]);
+        }
+    }
+    m1 = wave_sum(m1) / (float)H;
+    m2 = wave_sum(m2) / (float)H;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+        const int k = (lane + e * 64) * 4;
+        if (k < H)
+            gin_store4<T>(dz + (int64_t)v * H + k,
+                          make_float4(rstd * (dxh[e].x - m1 - t[e].x * m2), rstd * (dxh[e].y - m1 - t[e].y * m2),
+                                      rstd * (dxh[e].z - m1 - t[e].z * m2), rstd * (dxh[e].w - m1 - t[e].w * m2)));
+    }
+}
+
+// d h_in[v] += (1+eps) dz0[v] + sum over OUT-edges (v -> u, a): dz0[u] * GELU'(h_in[v] + bond[a]).  CSR by SOURCE node.
+__global__ __launch_bounds__(64) void gin_aggregate_bwd_kernel(const float *__restrict__ h_in, const float *__restrict__ dz0,
+                                                                const int *__restrict__ rowptr_s, const int *__restrict__ dst_s,
+                                                                const int *__restrict__ attr_s, const float *__restrict__ bond,
+                                                                const float *__restrict__ eps, float *__restrict__ dh, int n, int H) {
+    const int v = blockIdx.x;
+    if (v >= n) return;
+    const int lane = threadIdx.x;
+    const float e1 = 1.f + eps[0];
+    const int e0 = rowptr_s[v], e_end = rowptr_s[v + 1];
+    for (int k = lane * 4; k < H; k += 256) {
+        const float4 hv = *reinterpret_cast<const float4 *>(h_in + (int64_t)v * H + k);
+        const float4 dzv = *reinterpret_cast<const float4 *>(dz0 + (int64_t)v * H + k);
+        float4 acc = *reinterpret_cast<const float4 *>(dh + (int64_t)v * H + k);
+        acc.x += e1 * dzv.x; acc.y += e1 * dzv.y; acc.z += e1 * dzv.z; acc.w += e1 * dzv.w;
+        for (int e = e0; e < e_end; ++e) {
+            const float4 du = *reinterpret_cast<const float4 *>(dz0 + (int64_t)dst_s[e] * H + k);
+            const float4 bn = *reinterpret_cast<const float4 *>(bond + (int64_t)attr_s[e] * H + k);
+            acc.x += du.x * gelu_grad(hv.x + bn.x);
+            acc.y += du.y * gelu_grad(hv.y + bn.y);
+            acc.z += du.z * gelu_grad(hv.z + bn.z);
+            acc.w += du.w * gelu_grad(hv.w + bn.w);
+        }
+        *reinterpret_cast<float4 *>(dh + (int64_t)v * H + k) = acc;
+    }
+}
+
+// segment-max backward: the gradient of pool[g][k] goes to the FIRST node of graph g holding the maximum of feature k
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restrict__ h_in, const int *__restrict__ gptr,
+                                                           const float *__restrict__ dpool, float *__restrict__ dh, int H) {
+    const int g = blockIdx.x;
+    const int v0 = gptr[g], v1 = gptr[g + 1];
+    for (int k = blockIdx.y * 256 + threadIdx.x; k < H; k += gridDim.y * 256) {
+        float best = -INFINITY;
+        int arg = v0;
+        for (int v = v0; v < v1; ++v) {
+            const float x = h_in[(int64_t)v * H + k];
+            if (x > best) { best = x; arg = v; }
+        }
+        if (v1 > v0) dh[(int64_t)arg * H + k] += dpool[(int64_t)g * H + k];
+    }
+}
+
+__global__ void gather_rows_kernel(float *__restrict__ dst, const float *__restrict__ rows, const int *__restrict__ idx, int n, int H) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)n * H; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = rows[(int64_t)idx[i / H] * H + i % H];
+}
+template <typename T> __global__ void cvt_rows_kernel(const float *__restrict__ src, int64_t lds, T *__restrict__ dst, int64_t ldd, int R, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)R * C; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / C, c = i - r * C;
+        dst[r * ldd + c] = from_f32<T>(src[r * lds + c]);
+    }
+}
+// out[K][ldo] (first N columns) = in[N][K]^T, operand dtype
+template <typename T> __global__ void transpose_w_kernel(const float *__restrict__ in, T *__restrict__ out, int N, int K, int64_t ldo) {
+    __shared__ float tile[32][33];
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    for (int j = threadIdx.y; j < 32; j += 8)
+        if (n0 + j < N && k0 + threadIdx.x < K) tile[j][threadIdx.x] = in[(int64_t)(n0 + j) * K + k0 + threadIdx.x];
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8)
+        if (k0 + j < K && n0 + threadIdx.x < N) out[(int64_t)(k0 + j) * ldo + n0 + threadIdx.x] = from_f32<T>(tile[threadIdx.x][j]);
+}
+__global__ void sum_slabs_kernel(const float *__restrict__ slabs, int64_t stride, int splits, float *__restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int z = 0; z < splits; ++z) a += slabs[z * stride + i];
+        out[i] = a;
+    }
+}
+__global__ void silu_bwd_kernel(const float *__restrict__ c, const float *__restrict__ g, float *__restrict__ dc, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = c[i], sg = 1.f / (1.f + expf(-x));
+        dc[i] = g[i] * sg * (1.f + x * (1.f - sg));
+    }
+}
+
+constexpr int HEAD_SPLITS = 16;
+static int64_t head_kp(int out_dim) { return (int64_t)round_up(out_dim, 64 * HEAD_SPLITS); }
+
+// transposed operand-dtype copies of every weight the reverse sweep multiplies by (same slot offsets as the arena; the
+// template head gets a K-padded row pitch; the L adapter matrices are concatenated along K for one GEMM)
+template <typename T>
+static int gin_build_transposes(GinEngine *e, hipStream_t st) {
+    const LLGinConfig &cf = e->cfg;
+    const int H = cf.hidden, L = cf.num_layer;
+    int64_t total = 0;
+    for (auto &p : e->layout) total = std::max<int64_t>(total, p.offset + (p.numel + 63) / 64 * 64);
+    const int64_t kp = head_kp(cf.out_dim);
+    LL_TRY(e->wT.ensure((size_t)(total + (int64_t)4 * H * kp) * sizeof(T)));     // head copy appended after the arena image
+    LL_TRY(e->adT.ensure((size_t)cf.text_dim * L * 3 * H * sizeof(T)));
+    auto tr = [&](const std::string &name, int N, int K, T *dst, int64_t ldo) {
+        dim3 grid(cdiv(K, 32), cdiv(N, 32)), blk(32, 8);
+        hipLaunchKernelGGL((transpose_w_kernel<T>), grid, blk, 0, st, e->pf(name), dst, N, K, ldo);
+    };
+    auto slot = [&](const std::string &name) -> T * {
+        for (auto &p : e->layout)
+            if (p.name == name) return e->wT.as<T>() + p.offset;
+        return nullptr;
+    };
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "convs." + std::to_string(l) + ".";
+        tr(p + "mlp.0.weight", 4 * H, H, slot(p + "mlp.0.weight"), 4 * H);       // [H][4H]
+        tr(p + "mlp.4.weight", H, 4 * H, slot(p + "mlp.4.weight"), H);           // [4H][H]
+        tr("adapters." + std::to_string(l) + ".1.weight", 3 * H, cf.text_dim, e->adT.as<T>() + (int64_t)l * 3 * H, (int64_t)L * 3 * H);
+        if (l < L - 1) {
+            const std::string q = "mlp_virtualnode_list." + std::to_string(l) + ".";
+            tr(q + "0.weight", 4 * H, H, slot(q + "0.weight"), 4 * H);
+            tr(q + "4.weight", H, 4 * H, slot(q + "4.weight"), H);
+        }
+    }
+    tr("decoder.0.weight", 4 * H, H, slot("decoder.0.weight"), 4 * H);
+    LL_HIP(hipMemsetAsync(e->wT.as<T>() + total, 0, (size_t)4 * H * kp * sizeof(T), st));
+    tr("decoder.4.weight", cf.out_dim, 4 * H, e->wT.as<T>() + total, kp);        // [4H][kp], zero-padded columns
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+template <typename T>
+static int gin_backward_c_t(GinEngine *e, const int *rowptr_s, const int *dst_s, const int *attr_s, const int *batch,
+                            const int *gptr, int n, int G, const float *c, const float *dlogits, float *dc, hipStream_t st) {
+    const LLGinConfig &cf = e->cfg;
+    const int H = cf.hidden, L = cf.num_layer, dt = cf.dtype, es = sizeof(T);
+    const int np = round_up(n, 128), Gp = round_up(G, 128);
+    const int64_t kp = head_kp(cf.out_dim);
+    if (!e->wT.p) LL_TRY(gin_build_transposes<T>(e, st));
+    int64_t total = 0;
+    for (auto &p : e->layout) total = std::max<int64_t>(total, p.offset + (p.numel + 63) / 64 * 64);
+    auto wt = [&](const std::string &name) -> const void * {
+        for (auto &p : e->layout)
+            if (p.name == name) return (const void *)(e->wT.as<T>() + p.offset);
+        return nullptr;
+    };
+    LL_TRY(e->g_dh.ensure((size_t)np * H * 4));
+    LL_TRY(e->g_dz.ensure((size_t)np * H * es));
+    LL_TRY(e->g_dt1a.ensure((size_t)np * 4 * H * 4));
+    LL_TRY(e->g_dt1.ensure((size_t)np * 4 * H * es));
+    LL_TRY(e->g_dz0.ensure((size_t)np * H * 4));
+    LL_TRY(e->g_c3.ensure((size_t)3 * np * H * 4));
+    LL_TRY(e->g_dmod.ensure((size_t)Gp * L * 3 * H * 4));
+    LL_TRY(e->g_dmoda.ensure((size_t)Gp * L * 3 * H * es));
+    LL_TRY(e->g_dvn.ensure((size_t)Gp * H * 4));
+    LL_TRY(e->g_dvna.ensure((size_t)Gp * H * es));
+    LL_TRY(e->g_dvt1a.ensure((size_t)Gp * 4 * H * 4));
+    LL_TRY(e->g_dvt1.ensure((size_t)Gp * 4 * H * es));
+    LL_TRY(e->g_dpool.ensure((size_t)Gp * H * 4));
+    LL_TRY(e->g_tmpG.ensure((size_t)Gp * H * 4));
+    LL_TRY(e->g_dhead1a.ensure((size_t)Gp * 4 * H * 4));
+    LL_TRY(e->g_dhead1.ensure((size_t)Gp * 4 * H * es));
+    LL_TRY(e->g_dlog.ensure((size_t)Gp * kp * es));
+    LL_TRY(e->g_slabs.ensure((size_t)HEAD_SPLITS * Gp * 4 * H * 4));
+    LL_TRY(e->g_dcs.ensure((size_t)Gp * cf.text_dim * 4));
+    const dim3 blk(256), w_n(n), w_g(G), wblk(64);
+    auto ew = [](int64_t cnt) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((cnt + 255) / 256, 4096))); };
+
+    // ---- readout: logits = GELU(LN(pool Wd0^T + b)) Wd4^T + b4;  pool = segment_sum(h_L)
+    LL_HIP(hipMemsetAsync(e->g_dlog.p, 0, (size_t)Gp * kp * es, st));
+    hipLaunchKernelGGL((cvt_rows_kernel<T>), ew((int64_t)G * cf.out_dim), blk, 0, st, dlogits, (int64_t)cf.out_dim, e->g_dlog.as<T>(), kp, G, cf.out_dim);
+    LL_LAUNCH_CHECK();
+    LL_TRY(linear_splitk_launch(dt, e->g_dlog.p, (int)kp, e->wT.as<T>() + total, (int)kp, e->g_slabs.as<float>(), 4 * H,
+                                (int64_t)Gp * 4 * H, G, 4 * H, (int)kp, HEAD_SPLITS, st));
+    hipLaunchKernelGGL(sum_slabs_kernel, ew((int64_t)G * 4 * H), blk, 0, st, e->g_slabs.as<float>(), (int64_t)Gp * 4 * H, HEAD_SPLITS,
+                       e->g_dhead1a.as<float>(), (int64_t)G * 4 * H);
+    hipLaunchKernelGGL((ln_gelu_bwd_kernel<T>), w_g, wblk, 0, st, e->sv_head1.as<float>(), e->pf("decoder.1.weight"), e->pf("decoder.1.bias"),
+                       e->g_dhead1a.as<float>(), e->g_dhead1.as<T>(), G, 4 * H);
+    LL_LAUNCH_CHECK();
+    LL_TRY(linear_launch(dt, e->g_dhead1.p, 4 * H, wt("decoder.0.weight"), 4 * H, nullptr, e->g_dpool.p, H, G, H, 4 * H, 0, 1, st));
+    hipLaunchKernelGGL(gather_rows_kernel, ew((int64_t)n * H), blk, 0, st, e->g_dh.as<float>(), e->g_dpool.as<float>(), batch, n, H);
+    LL_HIP(hipMemsetAsync(e->g_dvn.p, 0, (size_t)Gp * H * 4, st));
+    LL_LAUNCH_CHECK();
+
+    for (int l = L - 1; l >= 0; --l) {
+        const std::string p = "convs." + std::to_string(l) + ".";
+        const bool last = (l == L - 1);
+        const float *mod = e->mod.as<float>() + (size_t)l * Gp * 3 * H;
+        // tail: h = gate * act(LN0(z)(1+scale)+shift) + h_in
+        hipLaunchKernelGGL((gin_post_bwd_kernel<T>), w_n, wblk, 0, st, e->sv_z[l].as<float>(), mod, batch, e->g_dh.as<float>(), e->g_dz.as<T>(),
+                           e->g_c3.as<float>(), n, H, last ? 0 : 1);
+        LL_LAUNCH_CHECK();
+        for (int q = 0; q < 3; ++q) {   // d(shift | scale | gate)[g] = sum over the graph's nodes
+            hipLaunchKernelGGL((segment_pool_kernel<float, false>), dim3(G, cdiv(H, 1024)), blk, 0, st, e->g_c3.as<float>() + (size_t)q * n * H, gptr,
+                               e->g_tmpG.as<float>(), (float *)nullptr, H);
+            hipLaunchKernelGGL((cvt_rows_kernel<T>), ew((int64_t)G * H), blk, 0, st, e->g_tmpG.as<float>(), (int64_t)H,
+                               e->g_dmoda.as<T>() + (size_t)l * 3 * H + (size_t)q * H, (int64_t)L * 3 * H, G, H);
+        }
+        LL_LAUNCH_CHECK();
+        // MLP: z = GELU(LN(z0 W0^T + b0)) W4^T + b4
+        LL_TRY(linear_launch(dt, e->g_dz.p, H, wt(p + "mlp.4.weight"), H, nullptr, e->g_dt1a.p, 4 * H, n, 4 * H, H, 0, 1, st));
+        hipLaunchKernelGGL((ln_gelu_bwd_kernel<T>), w_n, wblk, 0, st, e->sv_t1[l].as<float>(), e->pf(p + "mlp.1.weight"), e->pf(p + "mlp.1.bias"),
+                           e->g_dt1a.as<float>(), e->g_dt1.as<T>(), n, 4 * H);
+        LL_LAUNCH_CHECK();
+        LL_TRY(linear_launch(dt, e->g_dt1.p, 4 * H, wt(p + "mlp.0.weight"), 4 * H, nullptr, e->g_dz0.p, H, n, H, 4 * H, 0, 1, st));
+        // aggregation: z0 = (1+eps) h_in + sum GELU(h_in[src] + bond)
+        hipLaunchKernelGGL(gin_aggregate_bwd_kernel, w_n, wblk, 0, st, e->sv_hin[l].as<float>(), e->g_dz0.as<float>(), rowptr_s, dst_s, attr_s,
+                           e->pf(p + "bond_encoder.weight"), e->pf(p + "eps"), e->g_dh.as<float>(), n, H);
+        LL_LAUNCH_CHECK();
+        if (!last) {   // vn_{l+1} = vn_l + MLP_vn(segment_max(h_in_l)): d vn_{l+1} is in g_dvn
+            const std::string q = "mlp_virtualnode_list." + std::to_string(l) + ".";
+            hipLaunchKernelGGL((cvt_rows_kernel<T>), ew((int64_t)G * H), blk, 0, st, e->g_dvn.as<float>(), (int64_t)H, e->g_dvna.as<T>(), (int64_t)H, G, H);
+            LL_LAUNCH_CHECK();
+            LL_TRY(linear_launch(dt, e->g_dvna.p, H, wt(q + "4.weight"), H, nullptr, e->g_dvt1a.p, 4 * H, G, 4 * H, H, 0, 1, st));
+            hipLaunchKernelGGL((ln_gelu_bwd_kernel<T>), w_g, wblk, 0, st, e->sv_vt1[l].as<float>(), e->pf(q + "1.weight"), e->pf(q + "1.bias"),
+                               e->g_dvt1a.as<float>(), e->g_dvt1.as<T>(), G, 4 * H);
+            LL_LAUNCH_CHECK();
+            LL_TRY(linear_launch(dt, e->g_dvt1.p, 4 * H, wt(q + "0.weight"), 4 * H, nullptr, e->g_dpool.p, H, G, H, 4 * H, 0, 1, st));
+            hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(G, cdiv(H, 256)), blk, 0, st, e->sv_hin[l].as<float>(), gptr, e->g_dpool.as<float>(), e->g_dh.as<float>(), H);
+            LL_LAUNCH_CHECK();
+        }
+        if (l > 0) {   // h_in_l = h_{l-1} + vn_l[batch]: d vn_l += segment_sum(d h_in_l); d h_{l-1} = d h_in_l (in place)
+            hipLaunchKernelGGL((segment_pool_kernel<float, false>), dim3(G, cdiv(H, 1024)), blk, 0, st, e->g_dh.as<float>(), gptr, e->g_tmpG.as<float>(),
+                               (float *)nullptr, H);
+            hipLaunchKernelGGL(add_rows_kernel, dim3(cdiv(G * H, 256)), blk, 0, st, e->g_dvn.as<float>(), e->g_tmpG.as<float>(), (int64_t)G * H);
+            LL_LAUNCH_CHECK();
+        }
+    }
+    // ---- (shift, scale, gate)_l = Linear_l(SiLU(c)): one GEMM over the K-concatenated adapters, then SiLU'
+    LL_TRY(linear_launch(dt, e->g_dmoda.p, L * 3 * H, e->adT.p, L * 3 * H, nullptr, e->g_dcs.p, cf.text_dim, G, cf.text_dim, L * 3 * H, 0, 1, st));
+    hipLaunchKernelGGL(silu_bwd_kernel, ew((int64_t)G * cf.text_dim), blk, 0, st, c, e->g_dcs.as<float>(), dc, (int64_t)G * cf.text_dim);
+    LL_LAUNCH_CHECK();
     return LL_OK;
 }
 
@@ -652,6 +1055,10 @@ int ll_gin_create(const LLGinConfig *cfg, const float *d_weights_f32, void **han
     e->cfg = *cfg;
     e->layout = gin_layout(*cfg);
     e->w32 = d_weights_f32;
+    e->sv_hin.resize(cfg->num_layer);
+    e->sv_t1.resize(cfg->num_layer);
+    e->sv_z.resize(cfg->num_layer);
+    e->sv_vt1.resize(cfg->num_layer);
     if (cfg->dtype == LL_BF16) {
         const int64_t elems = ll_gin_arena_elems(cfg);
         int rc = e->wop.ensure((size_t)elems * 2);
@@ -676,6 +1083,12 @@ int ll_gin_destroy(void *handle) {
     GBuf *bufs[] = {&e->wop, &e->h, &e->h_in, &e->z0, &e->t1, &e->t1a, &e->z, &e->vn, &e->pool32, &e->poola, &e->vt1,
                     &e->vt1a, &e->vt2, &e->mod, &e->csilu, &e->head1, &e->head1a, &e->head2};
     for (GBuf *b : bufs) b->release();
+    GBuf *tb[] = {&e->sv_head1, &e->wT, &e->adT, &e->g_dh, &e->g_dz, &e->g_dt1a, &e->g_dt1, &e->g_dz0, &e->g_c3, &e->g_dmod, &e->g_dmoda,
+                  &e->g_dvn, &e->g_dvna, &e->g_dvt1a, &e->g_dvt1, &e->g_dpool, &e->g_tmpG, &e->g_dhead1a, &e->g_dhead1, &e->g_dlog,
+                  &e->g_slabs, &e->g_dcs};
+    for (GBuf *b : tb) b->release();
+    for (auto *v : {&e->sv_hin, &e->sv_t1, &e->sv_z, &e->sv_vt1})
+        for (GBuf &b : *v) b.release();
     delete e;
     return LL_OK;
 }
@@ -690,6 +1103,34 @@ int ll_gin_forward(void *handle, const int32_t *x, const int32_t *rowptr, const 
     if (e->cfg.dtype == LL_BF16)
         return gin_forward_t<bf16_t>(e, x, rowptr, src, attr, batch, gptr, n_nodes, n_edges, n_graphs, c, out, pooled, (hipStream_t)stream);
     return gin_forward_t<float>(e, x, rowptr, src, attr, batch, gptr, n_nodes, n_edges, n_graphs, c, out, pooled, (hipStream_t)stream);
+}
+
+int ll_gin_forward_train(void *handle, const int32_t *x, const int32_t *rowptr, const int32_t *src, const int32_t *attr,
+                         const int32_t *batch, const int32_t *gptr, int n_nodes, int n_edges, int n_graphs, const float *c,
+                         float *out, void *stream) {
+    GinEngine *e = (GinEngine *)handle;
+    LL_CHECK(e && e->cfg.kind == 1 && c, "ll_gin_forward_train: predictor engines with a text condition only");
+    e->keep = true;
+    const int rc = ll_gin_forward(handle, x, rowptr, src, attr, batch, gptr, n_nodes, n_edges, n_graphs, c, out, nullptr, stream);
+    e->keep = false;
+    if (rc != LL_OK) e->kept_n = e->kept_G = -1;
+    return rc;
+}
+
+int ll_gin_backward_c(void *handle, const int32_t *rowptr_src, const int32_t *dst, const int32_t *attr, const int32_t *batch,
+                      const int32_t *gptr, int n_nodes, int n_edges, int n_graphs, const float *c, const float *dlogits, float *dc,
+                      void *stream) {
+    GinEngine *e = (GinEngine *)handle;
+    LL_CHECK(e && rowptr_src && batch && gptr && c && dlogits && dc, "null argument");
+    LL_CHECK(e->cfg.kind == 1, "ll_gin_backward_c: predictor engines only");
+    LL_CHECK(n_edges == 0 || (dst && attr), "edges given without dst/attr");
+    if (e->kept_n != n_nodes || e->kept_G != n_graphs) {
+        set_error("ll_gin_backward_c: no kept activations for %d nodes / %d graphs: call ll_gin_forward_train first", n_nodes, n_graphs);
+        return LL_ESTATE;
+    }
+    if (e->cfg.dtype == LL_BF16)
+        return gin_backward_c_t<bf16_t>(e, rowptr_src, dst, attr, batch, gptr, n_nodes, n_graphs, c, dlogits, dc, (hipStream_t)stream);
+    return gin_backward_c_t<float>(e, rowptr_src, dst, attr, batch, gptr, n_nodes, n_graphs, c, dlogits, dc, (hipStream_t)stream);
 }
 
 int ll_softmax_topk(const float *logits, int rows, int out_dim, int k, float *probs, int32_t *idx, void *stream) {

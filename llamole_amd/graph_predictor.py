@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .graph_encoder import _GinModule
+from .graph_encoder import graph_csr, _GinModule
 from .synth import gin_weight_shapes
 from .weights import WeightBag
 
@@ -63,6 +63,22 @@ def merge_template_outcomes(topk_probs, templates, product_smiles, run_template)
     return reactants, [s / total for s in scores], tmpls
 
 
+class _PredictorWithGrad(torch.autograd.Function):
+    """logits = predictor(graphs, c) with d logits -> d c computed by the HIP engine (weights frozen)."""
+
+    @staticmethod
+    def forward(ctx, c, module, x, edge_index, edge_attr, batch):
+        c32 = c.detach().to(device=module._device(), dtype=torch.float32).contiguous()
+        out, saved = module._forward_train(x, edge_index, edge_attr, batch, c32)
+        ctx.module, ctx.saved, ctx.c32, ctx.c_dtype = module, saved, c32, c.dtype
+        return out.to(next(module.predictor.parameters()).dtype)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        dc = ctx.module._backward_c(ctx.saved, ctx.c32, dlogits)
+        return dc.to(ctx.c_dtype), None, None, None, None, None
+
+
 class GraphPredictor(_GinModule):
     def __init__(self, num_layer, hidden_size, drop_ratio, out_dim, model_config, label_to_template, available=None):
         super().__init__()
@@ -99,10 +115,41 @@ class GraphPredictor(_GinModule):
         return self.predictor.state_dict().items()
 
     # ------------------------------------------------------------------ reference surface
-    @torch.no_grad()
     def forward(self, x, edge_index, edge_attr, batch, c):
-        out = self._run(x, edge_index, edge_attr, batch, c, self.out_dim)
-        return out.to(next(self.predictor.parameters()).dtype)
+        """Template logits [G, out_dim].  With autograd enabled and ``c.requires_grad`` (SFT: the retro cross-entropy trains
+        the LLM through ``c``, reference modeling_llamole.py:385-419; the predictor itself is frozen) the result carries a
+        grad_fn whose backward is the HIP reverse sweep ``ll_gin_backward_c``."""
+        if c is not None and torch.is_grad_enabled() and c.requires_grad:
+            return _PredictorWithGrad.apply(c, self, x, edge_index, edge_attr, batch)
+        with torch.no_grad():
+            out = self._run(x, edge_index, edge_attr, batch, c, self.out_dim)
+            return out.to(next(self.predictor.parameters()).dtype)
+
+    def _forward_train(self, x, edge_index, edge_attr, batch, c32):
+        self._ensure_engine()
+        dev = self._device()
+        x, edge_index, edge_attr, batch = x.to(dev), edge_index.to(dev), edge_attr.to(dev), batch.to(dev)
+        xs, rowptr, src, attr, b, gptr, n, ne, G = graph_csr(x, edge_index, edge_attr, batch)
+        if c32.shape[0] != G:
+            raise ValueError(f"condition rows {c32.shape[0]} != number of graphs {G}")
+        # the reverse sweep walks OUT-edges: CSR keyed by source = graph_csr of the flipped edge list
+        _, rowptr_s, dst_s, attr_s, _, _, _, _, _ = graph_csr(x, edge_index.flip(0), edge_attr, batch)
+        out = torch.empty(G, self.out_dim, device=dev, dtype=torch.float32)
+        _lib.check(_lib.load().ll_gin_forward_train(self._handle, _lib.dptr(xs), _lib.dptr(rowptr), _lib.dptr(src), _lib.dptr(attr),
+                                                    _lib.dptr(b), _lib.dptr(gptr), n, ne, G, _lib.dptr(c32), _lib.dptr(out),
+                                                    _lib.current_stream_ptr()), "ll_gin_forward_train")
+        torch.cuda.current_stream().synchronize()
+        return out, (rowptr_s, dst_s, attr_s, b, gptr, n, ne, G)
+
+    def _backward_c(self, saved, c32, dlogits):
+        rowptr_s, dst_s, attr_s, b, gptr, n, ne, G = saved
+        dlogits = dlogits.to(torch.float32).contiguous()
+        dc = torch.empty_like(c32)
+        _lib.check(_lib.load().ll_gin_backward_c(self._handle, _lib.dptr(rowptr_s), _lib.dptr(dst_s), _lib.dptr(attr_s), _lib.dptr(b),
+                                                 _lib.dptr(gptr), n, ne, G, _lib.dptr(c32), _lib.dptr(dlogits), _lib.dptr(dc),
+                                                 _lib.current_stream_ptr()), "ll_gin_backward_c")
+        torch.cuda.current_stream().synchronize()
+        return dc
 
     @torch.no_grad()
     def topk_templates(self, x, edge_index, edge_attr, batch, c, topk: int):

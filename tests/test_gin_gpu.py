@@ -182,3 +182,48 @@ def test_sample_templates_batch_equals_per_product():
         rb, sb, tb = together[g]
         assert rb == r and tb == t
         np.testing.assert_allclose(sb, s, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("name,dtype,tol", [("gin_l3_h64", torch.float32, 2e-3), ("gin_l5_h128", torch.float32, 2e-3),
+                                            ("gin_l3_h64", torch.bfloat16, 8e-2)])
+def test_predictor_backward_wrt_condition(name, dtype, tol):
+    """d(retro cross-entropy)/d c through the frozen predictor -- the HIP reverse sweep (ll_gin_backward_c)
+    against torch.autograd through the CPU oracle (reference GNNRetrosynthsizer.forward, graph_predictor/model.py:306-353,
+    loss as modeling_llamole.py:416-419)."""
+    import torch.nn.functional as F
+    from oracle import gin_oracle as go
+    L, H, out_dim, G, seed = GIN_CASES[name]
+    x, ei, ea, batch = synth.make_mol_graphs(G, seed)
+    sd = synth.make_gin_weights(L, H, "predictor", out_dim, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    c0 = torch.randn(G, 768, generator=g)
+    labels = torch.randint(0, out_dim, (G,), generator=g)
+    # oracle gradient
+    c_ref = c0.clone().requires_grad_(True)
+    logits_ref = go.predictor_forward(sd, L, x, ei, ea, batch, c_ref)
+    loss_ref = F.cross_entropy(logits_ref, labels)
+    (dc_ref,) = torch.autograd.grad(loss_ref, c_ref)
+    # engine gradient
+    m = _predictor(name, dtype)
+    c = c0.clone().cuda().requires_grad_(True)
+    logits = m(x.cuda(), ei.cuda(), ea.cuda(), batch.cuda(), c)
+    assert logits.requires_grad and logits.shape == (G, out_dim)
+    loss = F.cross_entropy(logits.float(), labels.cuda())
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) <= (5e-4 if dtype == torch.float32 else 5e-2) * max(1.0, abs(loss_ref.item()))
+    dc = c.grad.float().cpu()
+    scale = dc_ref.abs().max().item()
+    assert scale > 0
+    err = (dc - dc_ref).abs().max().item()
+    assert err <= tol * scale, (err, scale)
+    cos = F.cosine_similarity(dc.flatten(), dc_ref.flatten(), dim=0).item()
+    assert cos > (0.9999 if dtype == torch.float32 else 0.995), cos
+    # a second backward without a new forward of that batch is refused by the C ABI (call-order contract)
+    from llamole_amd import _lib
+    rc = _lib.load().ll_gin_backward_c(m._handle, None, None, None, None, None, 1, 0, 1, None, None, None, None)
+    assert rc == -1
+    # inference path unchanged: no grad -> same logits, no grad_fn
+    with torch.no_grad():
+        l2 = m(x.cuda(), ei.cuda(), ea.cuda(), batch.cuda(), c.detach())
+    assert not l2.requires_grad
+    torch.testing.assert_close(l2.float(), logits.detach().float(), rtol=1e-5, atol=1e-5)
