@@ -13,8 +13,8 @@ the control flow between the LLM and the three graph engines:
   connectors                      :205-222   Linear+SiLU x3, stored as connector/*.pt
 
 Reference quirks kept on purpose (drivers depend on the shapes of the results): ``design_text_list[0]`` is
-used for every batch element (:1174-1175); ``retro_plan_dict`` is keyed by SMILES (:1178).  The SFT
-``forward`` (:299-437) is outside the generation hot path and not provided.
+used for every batch element (:1174-1175); ``retro_plan_dict`` is keyed by SMILES (:1178); the SFT loss adds the
+retro loss under both the design and the retro weight (:421-425).
 """
 from __future__ import annotations
 
@@ -35,6 +35,11 @@ BOND_INDEX_BY_NAME = {"SINGLE": 1, "DOUBLE": 2, "TRIPLE": 3, "AROMATIC": 4}   # 
 
 SPECIAL_TOKENS = ["<design_start>", "<design_end>", "<design_body>", "<molecule>", "<retro_start>", "<retro_end>",
                   "<retro_body>", "<rollback_start>", "<rollback_end>"]
+
+
+class GraphLMOutput(dict):
+    """Result of the SFT forward (reference GraphLMOutput, :40-48): dict with attribute access; ``loss`` carries the graph."""
+    __getattr__ = dict.get
 
 
 def make_connector(d_in: int, d_out: int) -> nn.Sequential:
@@ -144,8 +149,70 @@ class GraphLLMForCausalMLM(nn.Module):
     def device(self):
         return next(self.language_model.parameters()).device
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("SFT forward (reference :299-437) is outside the MI355X generation path")
+    def forward(self, input_ids=None, attention_mask=None, labels=None, molecule_graphs=None, molecule_properties=None,
+                design_graphs=None, retro_labels=None, retro_product_graphs=None, past_key_values=None, use_cache=None,
+                output_attentions=None, output_hidden_states=True, return_dict=None):
+        """SFT forward (reference :299-437): next-token loss of the HF LLM over the prompt with GIN-encoded
+        molecules spliced in, plus the retrosynthesis cross-entropy of the frozen GIN predictor conditioned on the mean
+        hidden state of the ``<retro_body>`` query tokens.  Gradients reach the LLM (adapter) and the connectors; through
+        the predictor they are the HIP reverse sweep (GraphPredictor.forward with ``c.requires_grad``).
+
+        ``total = w_lm * lm_loss + (w_design + w_retro) * retro_loss`` -- the reference multiplies ``loss_weight_design``
+        by the retro loss as well (:421-425) and never adds its design loss, so the GraphDiT training forward it runs
+        (:359-381) changes neither the loss nor any gradient; it is skipped here unless ``self.compute_design_loss``."""
+        emb_layer = self.language_model.get_input_embeddings()
+        inputs_embeds = emb_layer(input_ids)
+        mol_pos = (input_ids == self.token_id_dict["<molecule>"]).nonzero()
+        if molecule_graphs is not None and mol_pos.shape[0] > 0:
+            with torch.no_grad():          # the encoder is frozen and its inputs are integers
+                mol = self.graph_encoder(molecule_graphs.x, molecule_graphs.edge_index, molecule_graphs.edge_attr,
+                                         molecule_graphs.batch)
+            mol = self.graph_to_lm_connector(mol.to(next(self.graph_to_lm_connector.parameters()).dtype))
+            assert mol_pos.shape[0] == mol.shape[0], \
+                f"Number of molecule tokens ({mol_pos.shape[0]}) does not match number of molecule embeddings ({mol.shape[0]})"
+            inputs_embeds = inputs_embeds.clone()
+            inputs_embeds[mol_pos[:, 0], mol_pos[:, 1]] = mol.to(inputs_embeds.dtype)
+        lm_out = self.language_model(input_ids=None, attention_mask=attention_mask, past_key_values=past_key_values,
+                                     inputs_embeds=inputs_embeds, use_cache=use_cache, output_attentions=output_attentions,
+                                     output_hidden_states=True, return_dict=True, labels=labels)
+        lm_loss = lm_out.loss if lm_out.loss is not None else 0
+        hidden = lm_out.hidden_states[-1]
+        body = torch.arange(self.num_body_tokens, device=input_ids.device)
+
+        design_loss = 0
+        if design_graphs is not None and getattr(self, "compute_design_loss", False):
+            pos = (input_ids == self.token_id_dict["<design_start>"]).nonzero()
+            if pos.numel() > 0:
+                dh = hidden[pos[:, 0].unsqueeze(1), (pos[:, 1] + 1).unsqueeze(1) + body].mean(dim=1)
+                dh = self.lm_to_graph_decoder(dh.to(next(self.lm_to_graph_decoder.parameters()).dtype))
+                design_loss = self.graph_decoder(design_graphs.x, design_graphs.edge_index, design_graphs.edge_attr,
+                                                 design_graphs.batch, molecule_properties, dh, NO_LABEL_INDEX)
+
+        retro_loss = 0
+        if retro_labels is not None:
+            pos = (input_ids == self.token_id_dict["<retro_start>"]).nonzero()
+            flat = retro_labels[retro_labels != IGNORE_INDEX]
+            valid = flat != NO_LABEL_INDEX
+            pos, flat = pos[valid], flat[valid]
+            if len(flat) > 0:
+                rh = hidden[pos[:, 0].unsqueeze(1), (pos[:, 1] + 1).unsqueeze(1) + body].mean(dim=1)
+                graphs = retro_product_graphs.to_data_list() if hasattr(retro_product_graphs, "to_data_list") else list(retro_product_graphs)
+                keep = valid.nonzero().view(-1).tolist()
+                gb = GraphBatch.from_data_list([graphs[i] for i in keep])
+                rh = self.lm_to_graph_predictor(rh.to(next(self.lm_to_graph_predictor.parameters()).dtype))
+                pred = self.graph_predictor(gb.x, gb.edge_index, gb.edge_attr, gb.batch, rh)
+                retro_loss = torch.nn.functional.cross_entropy(pred.float(), flat.to(pred.device))
+
+        w = self.finetuning_args
+        total = (getattr(w, "loss_weight_lm", 1) * lm_loss + getattr(w, "loss_weight_design", 1) * retro_loss
+                 + getattr(w, "loss_weight_retro", 1) * retro_loss)
+        out = {"loss": total, "logits": lm_out.logits, "past_key_values": getattr(lm_out, "past_key_values", None),
+               "hidden_states": lm_out.hidden_states, "attentions": getattr(lm_out, "attentions", None),
+               "additional_log_info": {k: (v.detach() if torch.is_tensor(v) else v) for k, v in
+                                       (("lm_loss", lm_loss), ("retro_loss", retro_loss), ("design_loss", design_loss))}}
+        if return_dict is False:
+            return (total, lm_out.logits, out["past_key_values"], lm_out.hidden_states)
+        return GraphLMOutput(out)
 
     # ------------------------------------------------------------------ helpers
     def add_special_body_tokens(self, input_ids, body_token_id, num_body_tokens, start_token_id=None):

@@ -227,3 +227,78 @@ def test_predictor_backward_wrt_condition(name, dtype, tol):
         l2 = m(x.cuda(), ei.cuda(), ea.cuda(), batch.cuda(), c.detach())
     assert not l2.requires_grad
     torch.testing.assert_close(l2.float(), logits.detach().float(), rtol=1e-5, atol=1e-5)
+
+
+def test_sft_forward_with_hip_engines_matches_oracle():
+    """SURVEY 8 f4 end to end on the GPU: GraphLLMForCausalMLM.forward with the HIP GIN encoder and HIP predictor
+    (forward + reverse sweep) against the same computation on the CPU with the oracle networks under torch.autograd:
+    total loss and the gradients that reach the lm_to_graph_predictor connector and the LLM."""
+    import types
+    import torch.nn.functional as F
+    from llamole_amd import e2e
+    from llamole_amd.graph_data import GraphBatch
+    from llamole_amd.modeling_llamole import IGNORE_INDEX, NO_LABEL_INDEX, SPECIAL_TOKENS, GraphLLMForCausalMLM
+    from oracle import gin_oracle as go
+    name = "gin_l3_h64"
+    L, H, out_dim, G, seed = GIN_CASES[name]
+    x, ei, ea, batch = synth.make_mol_graphs(G, seed)
+    graphs = GraphBatch(x, ei, ea, batch, [int((batch == g).sum()) for g in range(G)]).to_data_list()
+    sd_p = synth.make_gin_weights(L, H, "predictor", out_dim, seed)
+    sd_e, sd_j = synth.make_gin_weights(L, H, "encoder", seed=seed), synth.make_proj_weights(H, seed)
+    tid = {t: 2000 + i for i, t in enumerate(SPECIAL_TOKENS)}
+    g = torch.Generator().manual_seed(0)
+    B, Lseq = 2, 40
+    ids = torch.randint(5, 1000, (B, Lseq), generator=g)
+    ids[0, 3], ids[1, 5] = tid["<molecule>"], tid["<molecule>"]
+    for b, start in ((0, 10), (0, 25), (1, 12)):
+        ids[b, start] = tid["<retro_start>"]
+        ids[b, start + 1:start + 9] = tid["<retro_body>"]
+    labels = ids.clone()
+    labels[:, :4] = IGNORE_INDEX
+    retro_labels = torch.tensor([[4, NO_LABEL_INDEX], [2, IGNORE_INDEX]])
+    mols, products = [graphs[0], graphs[1]], [graphs[2], graphs[3], graphs[0]]
+
+    def build(device, predictor, encoder):
+        llm = e2e.build_llm("tiny", device, torch.float32)
+        for p in llm.parameters():
+            p.requires_grad = True
+        m = GraphLLMForCausalMLM(types.SimpleNamespace(), types.SimpleNamespace(loss_weight_lm=1, loss_weight_design=1, loss_weight_retro=1),
+                                 types.SimpleNamespace(learned_query_size=8), llm, types.SimpleNamespace(text_input_size=768), predictor,
+                                 encoder, tid, None)
+        torch.manual_seed(1)
+        for nm in ("graph_to_lm_connector", "lm_to_graph_decoder", "lm_to_graph_predictor"):
+            for p in getattr(m, nm).parameters():
+                p.data = torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())) * 0.03
+            getattr(m, nm).to(device)
+        m.graph_encoder = encoder
+        return m, llm
+
+    class OraclePred(torch.nn.Module):
+        text_input_size, available = 768, None
+
+        def forward(self, x, ei, ea, b, c):
+            return go.predictor_forward(sd_p, L, x, ei, ea, b, c)
+    oenc = lambda x, ei, ea, b: go.graphclip_forward(sd_e, sd_j, L, x, ei, ea, b)   # noqa: E731
+    oenc.hidden_size = H
+    ref_m, ref_llm = build("cpu", OraclePred(), oenc)
+    ref = ref_m(input_ids=ids, attention_mask=torch.ones_like(ids), labels=labels, molecule_graphs=GraphBatch.from_data_list(mols),
+                retro_labels=retro_labels, retro_product_graphs=products)
+    ref.loss.backward()
+
+    pred, enc = _predictor(name), _encoder(name)
+    m, llm = build("cuda", pred, enc)
+    llm.load_state_dict(ref_llm.state_dict())        # random init differs between the CPU and the device generator
+    to_dev = lambda gl: [type(d)(d.x.cuda(), d.edge_index.cuda(), d.edge_attr.cuda()) for d in gl]   # noqa: E731
+    out = m(input_ids=ids.cuda(), attention_mask=torch.ones_like(ids).cuda(), labels=labels.cuda(),
+            molecule_graphs=GraphBatch.from_data_list(to_dev(mols)), retro_labels=retro_labels.cuda(), retro_product_graphs=to_dev(products))
+    out.loss.backward()
+    assert abs(out.loss.item() - ref.loss.item()) <= 2e-3 * abs(ref.loss.item())
+    assert abs(float(out.additional_log_info["retro_loss"]) - float(ref.additional_log_info["retro_loss"])) <= 2e-3 * float(ref.additional_log_info["retro_loss"])
+    for nm in ("lm_to_graph_predictor.0.weight", "graph_to_lm_connector.0.weight"):
+        ga = dict(m.named_parameters())[nm].grad.cpu()
+        gr = dict(ref_m.named_parameters())[nm].grad
+        assert F.cosine_similarity(ga.flatten(), gr.flatten(), dim=0) > 0.999, nm
+        assert (ga - gr).abs().max() <= 2e-2 * gr.abs().max(), nm
+    ga = llm.model.layers[1].mlp.down_proj.weight.grad.cpu()
+    gr = ref_llm.model.layers[1].mlp.down_proj.weight.grad
+    assert F.cosine_similarity(ga.flatten(), gr.flatten(), dim=0) > 0.999
