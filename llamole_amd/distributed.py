@@ -79,3 +79,45 @@ def all_gather_topk(idx: torch.Tensor, prob: torch.Tensor, group=None):
     dist.all_gather(bi, idx.contiguous(), group=group)
     dist.all_gather(bp, prob.contiguous(), group=group)
     return torch.cat(bi), torch.cat(bp)
+
+
+def allreduce_gradients(params, bucket_bytes: int = 64 << 20, group=None) -> int:
+    """Average ``p.grad`` of every parameter over the ranks (SFT data parallelism): gradients are packed
+    into flat buckets of up to ``bucket_bytes`` per dtype and each bucket is ONE all-reduce (RCCL over xGMI under backend
+    "nccl", gloo in the CPU tests).  Llamole's trainable set (LoRA adapter + connectors) is tens of MB: one or two direct
+    all-reduces, not a per-tensor stream of small ones.  Returns the number of collectives issued (0 when not distributed)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    world = dist.get_world_size(group)
+    by_dtype = {}
+    for p in params:
+        if p.grad is not None:
+            by_dtype.setdefault((p.grad.dtype, p.grad.device), []).append(p)
+    calls = 0
+    for (dtype, device), plist in by_dtype.items():
+        bucket, size = [], 0
+        itemsize = torch.empty((), dtype=dtype).element_size()
+
+        def flush(bucket=bucket):
+            nonlocal calls
+            if not bucket:
+                return
+            flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            flat.div_(world)
+            off = 0
+            for p in bucket:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+            calls += 1
+            bucket.clear()
+        for p in plist:
+            nbytes = p.grad.numel() * itemsize
+            if bucket and size + nbytes > bucket_bytes:
+                flush()
+                size = 0
+            bucket.append(p)
+            size += nbytes
+        flush()
+    return calls

@@ -1,0 +1,99 @@
+"""SFT plumbing around ``GraphLLMForCausalMLM.forward`` (BASELINE.json configs[4]).
+
+* ``GraphSFTCollator``  -- reference ``src/data/collator.py:DataCollatorForSeqGraph`` (:26-151) without PyG: pads the token
+  features, turns ``molecule_ids`` / ``retro_product_ids`` into ``GraphBatch`` objects (first molecule of a row is also its
+  design graph), pads ``retro_labels`` with the label pad id.
+* ``sft_step``          -- forward, backward, data-parallel gradient all-reduce, optimizer step.  One process per GPU
+  (``torch.distributed`` backend "nccl" = RCCL over xGMI); gradients are reduced in a few large flat buckets with a DIRECT
+  all-reduce per bucket -- the trainable set of Llamole's SFT (LoRA adapter + three connectors) is tens of MB, i.e. latency-
+  bound on point-to-point xGMI links, so bucket count, not ring bandwidth, is what matters.
+The LLM forward/backward is stock HuggingFace on PyTorch-ROCm; the graph side of the loss (GIN encoder forward, GIN
+predictor forward + reverse sweep w.r.t. the query condition) runs in the HIP engines.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+
+from .graph_data import GraphBatch
+
+IGNORE_INDEX = -100
+
+
+class GraphSFTCollator:
+    def __init__(self, pad_token_id: int, mol_id_to_graph: Dict[int, Any], label_pad_token_id: int = IGNORE_INDEX,
+                 padding_side: str = "right", pad_to_multiple_of: Optional[int] = None):
+        self.pad_token_id = pad_token_id
+        self.mol_id_to_graph = mol_id_to_graph
+        self.label_pad_token_id = label_pad_token_id
+        self.padding_side = padding_side
+        self.pad_to_multiple_of = pad_to_multiple_of
+
+    def _pad(self, rows: Sequence[Sequence[int]], value: int, length: int) -> torch.Tensor:
+        out = torch.full((len(rows), length), value, dtype=torch.long)
+        for i, r in enumerate(rows):
+            r = list(r)
+            if self.padding_side == "right":
+                out[i, :len(r)] = torch.tensor(r, dtype=torch.long)
+            else:
+                out[i, length - len(r):] = torch.tensor(r, dtype=torch.long)
+        return out
+
+    def __call__(self, features: List[Dict[str, Any]]) -> Dict[str, Any]:
+        mol_graphs, design_graphs, retro_graphs = [], [], []
+        for f in features:
+            for pos, mid in enumerate(f.get("molecule_ids") or []):
+                if pos == 0:
+                    design_graphs.append(self.mol_id_to_graph[mid])
+                if mid != self.label_pad_token_id and mid in self.mol_id_to_graph:
+                    mol_graphs.append(self.mol_id_to_graph[mid])
+            for mid in f.get("retro_product_ids") or []:
+                if mid != self.label_pad_token_id and mid in self.mol_id_to_graph:
+                    retro_graphs.append(self.mol_id_to_graph[mid])
+        L = max(len(f["input_ids"]) for f in features)
+        if self.pad_to_multiple_of:
+            L = (L + self.pad_to_multiple_of - 1) // self.pad_to_multiple_of * self.pad_to_multiple_of
+        batch: Dict[str, Any] = {
+            "input_ids": self._pad([f["input_ids"] for f in features], self.pad_token_id, L),
+            "attention_mask": self._pad([f.get("attention_mask", [1] * len(f["input_ids"])) for f in features], 0, L),
+        }
+        if all("labels" in f for f in features):
+            batch["labels"] = self._pad([f["labels"] for f in features], self.label_pad_token_id, L)
+        if "property" in features[0]:
+            batch["molecule_properties"] = torch.tensor([f["property"] for f in features], dtype=torch.float32)
+        batch["molecule_graphs"] = GraphBatch.from_data_list(mol_graphs) if mol_graphs else None
+        batch["design_graphs"] = GraphBatch.from_data_list(design_graphs) if design_graphs else None
+        batch["retro_product_graphs"] = GraphBatch.from_data_list(retro_graphs) if retro_graphs else None
+        labels = [f.get("retro_labels") for f in features]
+        if any(r is not None for r in labels):
+            R = max(len(r) for r in labels if r is not None)
+            batch["retro_labels"] = torch.tensor([(list(r) + [self.label_pad_token_id] * (R - len(r))) if r is not None
+                                                  else [self.label_pad_token_id] * R for r in labels], dtype=torch.int64)
+        else:
+            batch["retro_labels"] = None
+        return batch
+
+
+def to_device(batch: Dict[str, Any], device) -> Dict[str, Any]:
+    out = {}
+    for k, v in batch.items():
+        out[k] = v.to(device) if hasattr(v, "to") and v is not None else v
+    return out
+
+
+def sft_step(model, batch: Dict[str, Any], optimizer=None, bucket_bytes: int = 64 << 20) -> Dict[str, float]:
+    """One SFT step.  Under ``torch.distributed`` every rank calls it on its own shard; gradients are averaged."""
+    from .distributed import allreduce_gradients
+    out = model(**batch)
+    loss = out.loss
+    if optimizer is not None:
+        optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    params = [p for p in model.parameters() if p.requires_grad and p.grad is not None]
+    allreduce_gradients(params, bucket_bytes=bucket_bytes)
+    if optimizer is not None:
+        optimizer.step()
+    log = {k: float(v) for k, v in out.additional_log_info.items()}
+    log["loss"] = float(loss.detach())
+    return log

@@ -69,3 +69,97 @@ def test_all_gather_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+# ------------------------------------------------------------------------------------------ SFT data parallelism (8 f4)
+def _sft_setup():
+    """Tiny real HF LLM + differentiable stand-ins for the graph engines (the HIP predictor needs a GPU); 4 samples."""
+    import types
+    from llamole_amd import e2e
+    from llamole_amd.graph_data import GraphData
+    from llamole_amd.modeling_llamole import SPECIAL_TOKENS, GraphLLMForCausalMLM
+    from llamole_amd.sft import GraphSFTCollator
+    llm = e2e.build_llm("tiny", "cpu", torch.float32, seed=0)
+    for p in llm.parameters():
+        p.requires_grad = True
+    tid = {t: 2000 + i for i, t in enumerate(SPECIAL_TOKENS)}
+    W = torch.randn(7, 768, generator=torch.Generator().manual_seed(3)) * 0.05
+
+    class Pred(torch.nn.Module):
+        text_input_size, available = 768, None
+
+        def forward(self, x, ei, ea, batch, c):
+            return c.float() @ W.t()
+    enc = lambda x, ei, ea, b: torch.stack([x[b == g].float().mean().repeat(32) for g in range(int(b.max()) + 1)]) * 0.01  # noqa: E731
+    enc.hidden_size = 32
+    m = GraphLLMForCausalMLM(types.SimpleNamespace(), types.SimpleNamespace(loss_weight_lm=1, loss_weight_design=1, loss_weight_retro=1),
+                             types.SimpleNamespace(learned_query_size=8), llm, types.SimpleNamespace(text_input_size=768), Pred(), enc,
+                             tid, None)
+    m.graph_encoder = enc
+    for nm in ("graph_to_lm_connector", "lm_to_graph_decoder", "lm_to_graph_predictor"):
+        for p in getattr(m, nm).parameters():
+            p.data = torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())) * 0.03
+    mk = lambda n, k: GraphData(torch.arange(n) % 9 + k, torch.empty((2, 0), dtype=torch.long), torch.empty((0,), dtype=torch.long))  # noqa: E731
+    graphs = {i: mk(3 + i, i) for i in range(6)}
+    g = torch.Generator().manual_seed(5)
+    feats = []
+    for i in range(4):
+        L = 30 + 2 * i
+        ids = torch.randint(5, 1000, (L,), generator=g).tolist()
+        ids[2] = tid["<molecule>"]
+        ids[12] = tid["<retro_start>"]
+        ids[13:21] = [tid["<retro_body>"]] * 8
+        feats.append({"input_ids": ids, "labels": [-100] * 4 + ids[4:], "molecule_ids": [i], "retro_product_ids": [i + 1],
+                      "retro_labels": [i % 7]})
+    return m, GraphSFTCollator(0, graphs), feats
+
+
+def _sft_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from llamole_amd.sft import sft_step
+        torch.set_num_threads(2)
+        m, coll, feats = _sft_setup()
+        mine = [feats[i] for i in D.shard_range(len(feats), rank, world)]
+        log = sft_step(m, coll(mine), optimizer=None, bucket_bytes=1 << 20)
+        grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        q.put((rank, log["loss"], {k: grads[k].numpy() for k in ("lm_to_graph_predictor.0.weight", "language_model.model.layers.1.mlp.down_proj.weight",
+                                                          "graph_to_lm_connector.0.bias")}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sft_collator_and_data_parallel_step_world2_gloo():
+    """Collator semantics (reference data/collator.py:77-135) and the DP step: after the bucketed all-reduce both ranks hold
+    the mean of the per-shard gradients, equal to what one process computes from the two shards."""
+    from llamole_amd.sft import sft_step
+    m, coll, feats = _sft_setup()
+    b = coll(feats)
+    assert b["input_ids"].shape == (4, 36) and b["attention_mask"].sum().item() == sum(len(f["input_ids"]) for f in feats)
+    assert b["labels"][0, -1].item() == -100 and b["retro_labels"].tolist() == [[0], [1], [2], [3]]
+    assert b["molecule_graphs"].num_graphs == 4 and b["retro_product_graphs"].num_graphs == 4 and b["design_graphs"].num_graphs == 4
+    torch.set_num_threads(2)
+    ref = {}
+    for r in range(2):
+        mm, cc, ff = _sft_setup()
+        sft_step(mm, cc([ff[i] for i in D.shard_range(4, r, 2)]))
+        for n, p in mm.named_parameters():
+            if p.grad is not None:
+                ref[n] = ref.get(n, 0) + p.grad / 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sft_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for k in res[0][2]:
+        a, b2 = torch.from_numpy(res[0][2][k]), torch.from_numpy(res[1][2][k])
+        torch.testing.assert_close(a, b2, rtol=0, atol=0)                              # ranks agree bit for bit
+        torch.testing.assert_close(a, ref[k], rtol=1e-5, atol=1e-7)

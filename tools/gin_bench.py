@@ -69,10 +69,21 @@ def main():
 
     t_enc = timeit(lambda: enc(xs, eis, eas, bs))
     t_pred = timeit(lambda: pred.topk_templates(xs, eis, eas, bs, c, 50))
+    # SFT: retro cross-entropy forward + reverse sweep w.r.t. the condition (weights frozen)
+    labels = torch.randint(0, a.out_dim, (G,), device=dev)
+
+    def train_step():
+        cg = c.clone().requires_grad_(True)
+        loss = torch.nn.functional.cross_entropy(pred(xs, eis, eas, bs, cg).float(), labels)
+        loss.backward()
+        return cg.grad
+    t_train = timeit(train_step)
     dec_bytes = a.out_dim * 4 * H * 2
     out = {"workload": f"GIN encoder + predictor(top-50 of {a.out_dim}) on {G} graphs x 32 atoms, H={H}, L={L}, bf16",
            "encoder_ms": 1e3 * t_enc, "predictor_topk_ms": 1e3 * t_pred,
            "expansions_per_s": G / t_pred, "decoder_weight_bytes": dec_bytes,
+           "sft_retro_fwd_bwd_ms": 1e3 * t_train, "sft_retro_graphs_per_s": G / t_train,
+           "sft_head_hbm_frac_if_all_time": 2 * dec_bytes / t_train / 8e12,
            "decoder_hbm_frac_if_all_time": dec_bytes / t_pred / 8e12}
     if not a.no_cpu:
         from bench import usable_cores
@@ -89,8 +100,17 @@ def main():
                 go.template_topk(go.predictor_forward(sd_cpu, L, x, ei, ea, batch, cc), 50)
                 n += 1
             t_cpu = (time.perf_counter() - t0) / n
+        cg = cc.clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        n2 = 0
+        while time.perf_counter() - t0 < 8.0 and n2 < 10:
+            loss = torch.nn.functional.cross_entropy(go.predictor_forward(sd_cpu, L, x, ei, ea, batch, cg), labels.cpu())
+            torch.autograd.grad(loss, cg)
+            n2 += 1
+        t_cpu_train = (time.perf_counter() - t0) / n2
         out["cpu_baseline"] = {"predictor_topk_ms": 1e3 * t_cpu, "expansions_per_s": G / t_cpu, "cores": cores, "kind": "port",
-                               "sample": f"{n} forward+top-k calls of the fp32 oracle"}
+                               "sample": f"{n} forward+top-k calls / {n2} forward+autograd steps of the fp32 oracle",
+                               "sft_retro_fwd_bwd_ms": 1e3 * t_cpu_train, "sft_retro_graphs_per_s": G / t_cpu_train}
     print(json.dumps(out))
 
 
