@@ -1,12 +1,15 @@
 // Shared body of the two decode-attention kernels (llm_ops.hip: ll_decode_attn_bf16; llm_layer.hip: the fused
-// rope + append + attention).  One workgroup (256 threads) per (query head, sequence[, query position]).
+// rope + append + attention).  One workgroup (256 threads = 4 waves) per (query head, sequence[, query position]).
 //
-// Latency structure: the first 256 keys -- the whole context of a short prompt -- are fetched BEFORE anything else is
-// computed: thread j holds key row j (D/8 x 16 B) and wave w holds its slice of value rows 64w..64w+63 (one 2-/4-byte
-// load per row per lane), all issued back to back, so K, V and the mask cost ONE memory round trip that overlaps the
-// query preparation (rotary embedding, cache append).  Only contexts beyond 256 keys take further round trips (one per
-// 256 keys for K, one per 32 keys per wave for V).  Scores, softmax statistics and P.V accumulate in f32; both kernels
-// sum in the same order, so the fused layer stays bit-identical to the op-by-op path.
+// Access pattern: a wave-level load instruction covers RPI = 1024/(2 D) whole key (or value) rows -- LPR = D/8 lanes x 16 B
+// per row, fully coalesced -- so a tile of 256 keys is 64/RPI load instructions per wave for K and as many for V.
+//   scores: lane (r, c) holds q[8c..8c+7] in registers and dots it with its 16 B of key row 4i + r; a DPP reduction over
+//           the LPR lanes of the row finishes the dot product (no LDS traffic, no per-thread row walks);
+//   P.V   : the same lanes accumulate p[row] * v[row][8c..8c+7] over the rows they see; the RPI row groups are combined
+//           through LDS at the end.
+// The first tile -- the whole context of a short prompt -- is requested BEFORE anything else is computed (K, V and mask:
+// one memory round trip that overlaps the query preparation: rotary embedding, cache append).  Softmax statistics in f32.
+// Both kernels share this code, so the fused layer stays bit-identical to the op-by-op path.
 #pragma once
 #include "common.h"
 
@@ -14,90 +17,108 @@ namespace ll {
 
 typedef uint32_t au32x4 __attribute__((ext_vector_type(4)));
 
+template <int D> struct AttnGeom {
+    static constexpr int LPR = D / 8;          // lanes per row (16 B each)
+    static constexpr int RPI = 64 / LPR;       // rows per wave-level load instruction
+    static constexpr int NI = 64 / RPI;        // instructions per wave for its 64 keys of a 256-key tile
+};
+
 template <int D> struct AttnTile0 {
-    au32x4 k[D / 8];      // key row `tid`
-    uint32_t v[64];       // value rows 64*wave + i, this lane's D/64 elements
+    au32x4 k[AttnGeom<D>::NI];
+    au32x4 v[AttnGeom<D>::NI];
     unsigned char mk;     // mask byte of key `tid`
 };
+
+// key index handled by (wave, instruction i, lane) inside a tile starting at j0
+template <int D> __device__ __forceinline__ int attn_key(int j0, int wave, int i, int lane) {
+    return j0 + wave * 64 + i * AttnGeom<D>::RPI + lane / AttnGeom<D>::LPR;
+}
 
 template <int D>
 __device__ __forceinline__ void attn_prefetch(AttnTile0<D> &t, const bf16_t *__restrict__ Kb, const bf16_t *__restrict__ Vb,
                                               const unsigned char *__restrict__ mrow, int maxlen, int tid, int lane, int wave) {
-    constexpr int EPL = D / 64;
-    const bool in = tid < maxlen;
-    t.mk = in ? mrow[tid] : (unsigned char)0;
+    constexpr int LPR = AttnGeom<D>::LPR, NI = AttnGeom<D>::NI;
+    t.mk = tid < maxlen ? mrow[tid] : (unsigned char)0;
+    const int c = lane % LPR;
 #pragma unroll
-    for (int c = 0; c < D / 8; ++c) t.k[c] = in ? *reinterpret_cast<const au32x4 *>(Kb + (int64_t)tid * D + c * 8) : (au32x4)(0);
+    for (int i = 0; i < NI; ++i) {
+        const int j = attn_key<D>(0, wave, i, lane);
+        t.k[i] = j < maxlen ? *reinterpret_cast<const au32x4 *>(Kb + (int64_t)j * D + c * 8) : (au32x4)(0);
+    }
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-        const int j = wave * 64 + i;
-        uint32_t x = 0;
-        if (j < maxlen) {
-            if (EPL == 2) x = *reinterpret_cast<const uint32_t *>(Vb + (int64_t)j * D + lane * 2);
-            else x = *reinterpret_cast<const unsigned short *>(Vb + (int64_t)j * D + lane);
-        }
-        t.v[i] = x;
+    for (int i = 0; i < NI; ++i) {
+        const int j = attn_key<D>(0, wave, i, lane);
+        t.v[i] = j < maxlen ? *reinterpret_cast<const au32x4 *>(Vb + (int64_t)j * D + c * 8) : (au32x4)(0);
     }
 }
 
-__device__ __forceinline__ float attn_dot8(const float *qs, au32x4 kv, float dsum) {
-    const float4 q0 = *reinterpret_cast<const float4 *>(qs);
-    const float4 q1 = *reinterpret_cast<const float4 *>(qs + 4);
-    dsum = fmaf(q0.x, __uint_as_float(kv[0] << 16), dsum);
-    dsum = fmaf(q0.y, __uint_as_float(kv[0] & 0xffff0000u), dsum);
-    dsum = fmaf(q0.z, __uint_as_float(kv[1] << 16), dsum);
-    dsum = fmaf(q0.w, __uint_as_float(kv[1] & 0xffff0000u), dsum);
-    dsum = fmaf(q1.x, __uint_as_float(kv[2] << 16), dsum);
-    dsum = fmaf(q1.y, __uint_as_float(kv[2] & 0xffff0000u), dsum);
-    dsum = fmaf(q1.z, __uint_as_float(kv[3] << 16), dsum);
-    dsum = fmaf(q1.w, __uint_as_float(kv[3] & 0xffff0000u), dsum);
-    return dsum;
+template <int LPR> __device__ __forceinline__ float attn_row_sum(float v) {
+    if (LPR == 16) return row16_sum(v);
+    return row8_sum(v);
 }
 
-// qs [D] f32 query, part [4][D], sc [maxlen], red [8] in LDS; the caller has synchronised after writing qs (and kn / vn).
-// NEWKV: key / value `p` are taken from kn / vn (LDS, bf16) instead of the cache.  Writes D outputs to outp.
+__device__ __forceinline__ float attn_dot8(const float (&q)[8], au32x4 kv) {
+    float d = 0.f;
+    d = fmaf(q[0], __uint_as_float(kv[0] << 16), d);
+    d = fmaf(q[1], __uint_as_float(kv[0] & 0xffff0000u), d);
+    d = fmaf(q[2], __uint_as_float(kv[1] << 16), d);
+    d = fmaf(q[3], __uint_as_float(kv[1] & 0xffff0000u), d);
+    d = fmaf(q[4], __uint_as_float(kv[2] << 16), d);
+    d = fmaf(q[5], __uint_as_float(kv[2] & 0xffff0000u), d);
+    d = fmaf(q[6], __uint_as_float(kv[3] << 16), d);
+    d = fmaf(q[7], __uint_as_float(kv[3] & 0xffff0000u), d);
+    return d;
+}
+__device__ __forceinline__ void attn_axpy8(float (&acc)[8], float p, au32x4 vv) {
+    acc[0] = fmaf(p, __uint_as_float(vv[0] << 16), acc[0]);
+    acc[1] = fmaf(p, __uint_as_float(vv[0] & 0xffff0000u), acc[1]);
+    acc[2] = fmaf(p, __uint_as_float(vv[1] << 16), acc[2]);
+    acc[3] = fmaf(p, __uint_as_float(vv[1] & 0xffff0000u), acc[3]);
+    acc[4] = fmaf(p, __uint_as_float(vv[2] << 16), acc[4]);
+    acc[5] = fmaf(p, __uint_as_float(vv[2] & 0xffff0000u), acc[5]);
+    acc[6] = fmaf(p, __uint_as_float(vv[3] << 16), acc[6]);
+    acc[7] = fmaf(p, __uint_as_float(vv[3] & 0xffff0000u), acc[7]);
+}
+
+// qs [D] f32 query, part [4][RPI][D], sc [maxlen], red [8] in LDS; the caller has synchronised after writing qs (and kn /
+// vn).  NEWKV: key / value `p` are taken from kn / vn (LDS, bf16) instead of the cache.  Writes D outputs to outp.
 template <int D, bool NEWKV>
 __device__ __forceinline__ void attn_finish(AttnTile0<D> &t, const float *qs, float *part, float *sc, float *red,
                                             const bf16_t *__restrict__ Kb, const bf16_t *__restrict__ Vb,
                                             const unsigned char *__restrict__ mrow, int maxlen, long long p,
                                             const bf16_t *kn, const bf16_t *vn, float scale, bf16_t *__restrict__ outp,
                                             int tid, int lane, int wave) {
-    constexpr int EPL = D / 64;
-    // ---- scores: tile 0 from registers, further tiles one key per thread with the whole row in flight
-    if (tid < maxlen) {
-        const bool ok = t.mk != 0;
-        float dsum = 0.f;
-        if (ok) {
-            if (NEWKV && tid == p) {
+    constexpr int LPR = AttnGeom<D>::LPR, RPI = AttnGeom<D>::RPI, NI = AttnGeom<D>::NI;
+    const int c = lane % LPR, r = lane / LPR;
+    float q[8];
 #pragma unroll
-                for (int c = 0; c < D / 8; ++c) t.k[c] = *reinterpret_cast<const au32x4 *>(kn + c * 8);
-            }
+    for (int e = 0; e < 8; ++e) q[e] = qs[c * 8 + e];
+    // ---- scores (mask applied afterwards from the bytes fetched with the tile)
+    for (int j0 = 0; j0 < maxlen; j0 += 256) {
+        au32x4 kk[NI];
 #pragma unroll
-            for (int c = 0; c < D / 8; ++c) dsum = attn_dot8(qs + c * 8, t.k[c], dsum);
+        for (int i = 0; i < NI; ++i) {
+            const int j = attn_key<D>(j0, wave, i, lane);
+            if (j0 == 0) kk[i] = t.k[i];
+            else kk[i] = (j < maxlen && mrow[j] != 0) ? *reinterpret_cast<const au32x4 *>(Kb + (int64_t)j * D + c * 8) : (au32x4)(0);
+            if (NEWKV && j == p) kk[i] = *reinterpret_cast<const au32x4 *>(kn + c * 8);
         }
-        sc[tid] = ok ? dsum * scale : -INFINITY;
-    }
-    for (int j = tid + 256; j < maxlen; j += 256) {
-        const bool ok = mrow[j] != 0;
-        float dsum = 0.f;
-        if (ok) {
-            au32x4 kv[D / 8];
-            if (NEWKV && j == p) {
 #pragma unroll
-                for (int c = 0; c < D / 8; ++c) kv[c] = *reinterpret_cast<const au32x4 *>(kn + c * 8);
-            } else {
-#pragma unroll
-                for (int c = 0; c < D / 8; ++c) kv[c] = *reinterpret_cast<const au32x4 *>(Kb + (int64_t)j * D + c * 8);
-            }
-#pragma unroll
-            for (int c = 0; c < D / 8; ++c) dsum = attn_dot8(qs + c * 8, kv[c], dsum);
+        for (int i = 0; i < NI; ++i) {
+            const int j = attn_key<D>(j0, wave, i, lane);
+            const float d = attn_row_sum<LPR>(attn_dot8(q, kk[i]));
+            if (c == 0 && j < maxlen) sc[j] = d * scale;
         }
-        sc[j] = ok ? dsum * scale : -INFINITY;
     }
     __syncthreads();
-    // ---- softmax statistics
+    // ---- softmax statistics over the unmasked keys
     float mx = -INFINITY;
-    for (int j = tid; j < maxlen; j += 256) mx = fmaxf(mx, sc[j]);
+    for (int j = tid; j < maxlen; j += 256) {
+        const bool ok = (j == tid ? t.mk : mrow[j]) != 0;
+        const float s = ok ? sc[j] : -INFINITY;
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
@@ -113,45 +134,33 @@ __device__ __forceinline__ void attn_finish(AttnTile0<D> &t, const float *qs, fl
     __syncthreads();
     const float den = red[4] + red[5] + red[6] + red[7];
     const float inv = den > 0.f ? 1.f / den : 0.f;      // a fully masked query row (left padding) yields zeros, not NaN
-    // ---- out = P V: wave w takes keys 64w..64w+63 of tile 0 (registers), then keys 256 + w + 4u + 32 it
-    float acc[EPL];
+    // ---- out = P V: lane (r, c) accumulates columns 8c..8c+7 over the rows it sees
+    float acc[8];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int j0 = 0; j0 < maxlen; j0 += 256) {
+        au32x4 vv[NI];
+        float pj[NI];
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-        const int j = wave * 64 + i;
-        const float pj = j < maxlen ? sc[j] : 0.f;
-        uint32_t x = pj != 0.f ? t.v[i] : 0u;      // masked rows may hold anything (NaN from padded positions): never multiply them
-        if (NEWKV && j == p) x = EPL == 2 ? *reinterpret_cast<const uint32_t *>(vn + lane * 2) : (uint32_t)vn[lane];
-        acc[0] = fmaf(pj, __uint_as_float(x << 16), acc[0]);
-        if (EPL == 2) acc[EPL - 1] = fmaf(pj, __uint_as_float(x & 0xffff0000u), acc[EPL - 1]);
-    }
-    for (int j0 = 256 + wave; j0 < maxlen; j0 += 32) {     // 8 keys (rows of 2*D bytes, coalesced) in flight per wave
-        float pj[8];
-        uint32_t vv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = j0 + 4 * u;
-            pj[u] = j < maxlen ? sc[j] : 0.f;
-            vv[u] = 0;
-            if (pj[u] != 0.f) {
-                if (NEWKV && j == p) vv[u] = EPL == 2 ? *reinterpret_cast<const uint32_t *>(vn + lane * 2) : (uint32_t)vn[lane];
-                else if (EPL == 2) vv[u] = *reinterpret_cast<const uint32_t *>(Vb + (int64_t)j * D + lane * 2);
-                else vv[u] = *reinterpret_cast<const unsigned short *>(Vb + (int64_t)j * D + lane);
-            }
+        for (int i = 0; i < NI; ++i) {
+            const int j = attn_key<D>(j0, wave, i, lane);
+            pj[i] = j < maxlen ? sc[j] : 0.f;
+            if (j0 == 0) vv[i] = t.v[i];
+            else vv[i] = pj[i] != 0.f ? *reinterpret_cast<const au32x4 *>(Vb + (int64_t)j * D + c * 8) : (au32x4)(0);
+            if (NEWKV && j == p) vv[i] = *reinterpret_cast<const au32x4 *>(vn + c * 8);
+            if (pj[i] == 0.f) vv[i] = (au32x4)(0);      // masked rows may hold anything (NaN from padded positions)
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            acc[0] = fmaf(pj[u], __uint_as_float(vv[u] << 16), acc[0]);
-            if (EPL == 2) acc[EPL - 1] = fmaf(pj[u], __uint_as_float(vv[u] & 0xffff0000u), acc[EPL - 1]);
-        }
+        for (int i = 0; i < NI; ++i) attn_axpy8(acc, pj[i], vv[i]);
     }
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) part[wave * D + lane * EPL + e] = acc[e];
+    for (int e = 0; e < 8; ++e) part[(wave * RPI + r) * D + c * 8 + e] = acc[e];
     __syncthreads();
     if (tid < D) {
-        const float o = (part[tid] + part[D + tid] + part[2 * D + tid] + part[3 * D + tid]) * inv;
-        outp[tid] = f32_to_bf16(o);
+        float o = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4 * RPI; ++g) o += part[g * D + tid];
+        outp[tid] = f32_to_bf16(o * inv);
     }
 }
 

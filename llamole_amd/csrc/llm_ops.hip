@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void decode_attn_bf16_kernel(const bf16_t *__r
                                                                int64_t ms0, int64_t ms2) {
     extern __shared__ __attribute__((aligned(16))) float sm_attn[];
     float *qs = sm_attn;                 // [D]     query in f32 (16-B aligned LDS broadcast reads)
-    float *part = qs + D;                // [4][D]  per-wave partial outputs
-    float *sc = part + 4 * D;            // [maxlen] scores -> probabilities
+    float *part = qs + D;                // [4 waves][rows per load][D] partial outputs = 2048 floats for either D
+    float *sc = part + 2048;             // [maxlen] scores -> probabilities
     __shared__ float red[8];
     const int h = blockIdx.x, bs = blockIdx.y;
     const int b = bs / S, s = bs - b * S;
@@ -210,7 +210,7 @@ int ll_decode_attn_bf16(const void *q, const void *K, const void *V, const void 
                         int maxlen, int D, float scale, const int64_t *qstr, const int64_t *mstr, void *stream) {
     LL_CHECK(q && K && V && mask && out && qstr && mstr, "null argument");
     LL_CHECK((D == 64 || D == 128) && nh % nkv == 0 && maxlen >= 1 && maxlen <= 16384, "ll_decode_attn_bf16: unsupported shape");
-    const size_t lds = ((size_t)maxlen + 5 * D) * 4;
+    const size_t lds = ((size_t)maxlen + D + 2048) * 4;
     dim3 grid(nh, B * S);
     if (D == 128)
         hipLaunchKernelGGL((decode_attn_bf16_kernel<128>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t *)q,
