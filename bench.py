@@ -230,6 +230,8 @@ def main():
     ap.add_argument("--no-query-kv-reuse", dest="query_kv_reuse", action="store_false",
                     help="e2e: full re-forward of prompt + analysis + query tokens (the reference's way) instead of "
                          "running the 9 query tokens on top of the decode's KV cache")
+    ap.add_argument("--no-llm-model-fuse", dest="llm_model_fuse", action="store_false",
+                    help="e2e: keep HF's per-token rotary-table / causal-mask construction (~12 launches) in the decode step")
     ap.add_argument("--no-llm-fuse", dest="llm_fuse", action="store_false",
                     help="keep HF's op-by-op RMSNorm / rotary / SiLU*mul at decode instead of the fused HIP kernels")
     ap.add_argument("--llm-decode", default="graph", choices=["graph", "eager", "hf"])

@@ -219,6 +219,13 @@ int ll_gemv_fused_bf16(const void *x, int ldx, const void *W, int ldw, const flo
 int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, const void *sin, int64_t cs_stride, void *Kc,
                              void *Vc, const int64_t *pos, const void *mask, int64_t mask_stride, void *out, int B, int nh,
                              int nkv, int maxlen, int D, float scale, void *stream);
+/* ll_decode_prologue : per-token prologue of a decode step in one launch: cos/sin [B,D] bf16 of Qwen2RotaryEmbedding.forward
+ *     (transformers modeling_qwen2.py: inv_freq * position in f32, cos/sin, * attention_scaling, cast) for position_ids [B],
+ *     and the boolean key mask [B,maxlen] of create_causal_mask (masking_utils.py) for one new query at cache slot *pos:
+ *     key j visible iff j <= *pos and mask2d[b][j] != 0 (mask2d int64, row stride mask_stride). */
+int ll_decode_prologue(const int64_t *position_ids, const float *inv_freq, float attention_scaling, const int64_t *mask2d,
+                       int64_t mask_stride, const int64_t *pos, void *cos, void *sin, void *mask_out, int B, int D, int maxlen,
+                       void *stream);
 int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iters, int nweights, float *ms);
 int ll_set_gemv_nt(int on);
 

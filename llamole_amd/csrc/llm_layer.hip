@@ -243,6 +243,28 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const bf16_t *__r
                          out + ((int64_t)b * nh + h) * D, tid, lane, wave);
 }
 
+// Per-token prologue of the decode step: what Qwen2RotaryEmbedding.forward (freqs = inv_freq * position, cos/sin in f32,
+// * attention_scaling, cast to bf16) and create_causal_mask (key j visible iff j <= query position and not padding) compute
+// with ~12 small ATen launches, as one.  grid B.
+__global__ __launch_bounds__(256) void decode_prologue_kernel(const long long *__restrict__ posid, const float *__restrict__ inv_freq,
+                                                              float scaling, const long long *__restrict__ mask2d, int64_t ms,
+                                                              const long long *__restrict__ pos_ptr, bf16_t *__restrict__ cos_o,
+                                                              bf16_t *__restrict__ sin_o, unsigned char *__restrict__ mask_o,
+                                                              int D, int maxlen) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int half = D / 2;
+    if (tid < half) {
+        const float f = inv_freq[tid] * (float)posid[b];
+        const bf16_t c = f32_to_bf16(cosf(f) * scaling), s = f32_to_bf16(sinf(f) * scaling);
+        cos_o[(int64_t)b * D + tid] = c;
+        cos_o[(int64_t)b * D + tid + half] = c;
+        sin_o[(int64_t)b * D + tid] = s;
+        sin_o[(int64_t)b * D + tid + half] = s;
+    }
+    const long long p = *pos_ptr;
+    for (int j = tid; j < maxlen; j += 256) mask_o[(int64_t)b * maxlen + j] = (j <= p && mask2d[b * ms + j] != 0) ? 1 : 0;
+}
+
 static int g_gemv_nt = 1;   // non-temporal weight loads (tools/gemv_fused_sweep.py)
 
 template <int MROWS, bool NORM, int EPI>
@@ -324,6 +346,18 @@ int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, c
         hipLaunchKernelGGL((decode_attn_rope_kernel<64>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t *)qkv, ld_qkv,
                            (const bf16_t *)cos, (const bf16_t *)sin, cs_stride, (bf16_t *)Kc, (bf16_t *)Vc, (const long long *)pos,
                            (const unsigned char *)mask, mask_stride, (bf16_t *)out, nh, nkv, maxlen, scale);
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+int ll_decode_prologue(const int64_t *position_ids, const float *inv_freq, float attention_scaling, const int64_t *mask2d,
+                       int64_t mask_stride, const int64_t *pos, void *cos, void *sin, void *mask_out, int B, int D, int maxlen,
+                       void *stream) {
+    LL_CHECK(position_ids && inv_freq && mask2d && pos && cos && sin && mask_out, "ll_decode_prologue: null argument");
+    LL_CHECK(B >= 1 && D >= 2 && D % 2 == 0 && D <= 512 && maxlen >= 1, "ll_decode_prologue: unsupported shape");
+    hipLaunchKernelGGL(decode_prologue_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long *)position_ids, inv_freq,
+                       attention_scaling, (const long long *)mask2d, mask_stride, (const long long *)pos, (bf16_t *)cos, (bf16_t *)sin,
+                       (unsigned char *)mask_out, D, maxlen);
     LL_LAUNCH_CHECK();
     return LL_OK;
 }

@@ -108,6 +108,9 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
             if fused["decode_attention"] and args.llm_decode != "hf" and getattr(args, "llm_layer_fuse", True):
                 from .llm_accel import fuse_decoder_layers
                 fused["decoder_layers_5_launches"] = fuse_decoder_layers(llm)
+                if getattr(args, "llm_model_fuse", True):
+                    from .llm_accel import fuse_model_decode
+                    fused["decode_prologue_1_launch"] = fuse_model_decode(llm)
     if args.llm_decode != "hf":
         reuse = getattr(args, "query_kv_reuse", True)
         orch.enable_graphed_decode(use_graph=(args.llm_decode == "graph"), fused_cache=bool(fused), reuse_query_kv=reuse)

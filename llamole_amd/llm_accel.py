@@ -488,3 +488,73 @@ def restore_decoder_layers(model: nn.Module) -> None:
             del layer.__dict__["forward"]
             del layer.__dict__["_ll_fused"]
             del layer.__dict__["_ll_layer_orig"]
+
+
+# ------------------------------------------------------------------------------------------ whole decode step of the base model
+def _model_forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                   use_cache=None, **kwargs):
+    """Qwen2Model.forward / LlamaModel.forward for ONE new token per sequence on the fused layers: embedding gather, one
+    prologue launch (rotary cos/sin + causal/padding key mask, instead of ~12 ATen launches of rotary_emb and
+    create_causal_mask), the five-launch layers, final norm.  Anything else goes to the original forward."""
+    st = self._ll_decode
+    layers = self.layers[: self.config.num_hidden_layers]
+    if (input_ids is not None and inputs_embeds is None and input_ids.dim() == 2 and input_ids.shape[1] == 1
+            and input_ids.shape[0] <= 4 and input_ids.is_cuda and not torch.is_grad_enabled() and past_key_values is not None
+            and attention_mask is not None and attention_mask.dim() == 2 and attention_mask.dtype == torch.long
+            and attention_mask.stride(1) == 1 and position_ids is not None and position_ids.shape == input_ids.shape
+            and position_ids.dtype == torch.long and not kwargs.get("output_hidden_states") and not kwargs.get("output_attentions")
+            and getattr(past_key_values, "layers", None) and all(getattr(l, "_ll_fused_update", False) for l in past_key_values.layers)
+            and attention_mask.shape[1] == past_key_values.layers[0].keys.shape[2]
+            and past_key_values.layers[0].keys.dtype == torch.bfloat16):
+        B, maxlen, D = input_ids.shape[0], attention_mask.shape[1], st["D"]
+        dev = input_ids.device
+        h = self.embed_tokens(input_ids)
+        if h.dtype == torch.bfloat16 and h.is_contiguous():
+            cos = torch.empty(B, 1, D, dtype=torch.bfloat16, device=dev)
+            sin = torch.empty(B, 1, D, dtype=torch.bfloat16, device=dev)
+            mask = torch.empty(B, 1, 1, maxlen, dtype=torch.bool, device=dev)
+            inv_freq = self.rotary_emb.inv_freq
+            pos = past_key_values.layers[0].cumulative_length
+            posid = position_ids.contiguous()
+            rc = st["lib"].ll_decode_prologue(posid.data_ptr(), inv_freq.data_ptr(), float(self.rotary_emb.attention_scaling),
+                                              attention_mask.data_ptr(), attention_mask.stride(0), pos.data_ptr(), cos.data_ptr(),
+                                              sin.data_ptr(), mask.data_ptr(), B, D, maxlen, torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                _lib.check(rc, "ll_decode_prologue")
+            pe = (cos, sin)
+            if layers[0]._ll_fused.eligible(h, mask, past_key_values, pe):
+                for layer in layers:
+                    h = layer._ll_fused.run(h, mask, past_key_values, pe)
+                h = self.norm(h)
+                from transformers.modeling_outputs import BaseModelOutputWithPast
+                return BaseModelOutputWithPast(last_hidden_state=h, past_key_values=past_key_values if use_cache else None)
+    return self._ll_model_orig(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
+                               past_key_values=past_key_values, inputs_embeds=inputs_embeds, use_cache=use_cache, **kwargs)
+
+
+def fuse_model_decode(model: nn.Module) -> bool:
+    """Run the base model's decode step without HF's per-token mask / rotary-table construction (call after
+    ``fuse_decoder_layers``; needs every layer fused, default rope, f32 ``inv_freq``).  Returns whether it was installed."""
+    base = getattr(model, "model", model)
+    layers = getattr(base, "layers", None)
+    rot = getattr(base, "rotary_emb", None)
+    if (layers is None or rot is None or hasattr(base, "_ll_decode") or not all(hasattr(l, "_ll_fused") for l in layers)
+            or not hasattr(rot, "inv_freq") or rot.inv_freq.dtype != torch.float32 or not rot.inv_freq.is_cuda
+            or getattr(rot, "rope_type", "default") != "default" or not hasattr(base, "embed_tokens") or not hasattr(base, "norm")
+            or getattr(base, "has_sliding_layers", False)):
+        return False
+    D = layers[0]._ll_fused.D
+    if rot.inv_freq.numel() * 2 != D:
+        return False
+    base._ll_decode = {"lib": _lib.load(), "D": D}
+    base._ll_model_orig = base.forward
+    base.forward = types.MethodType(_model_forward, base)
+    return True
+
+
+def restore_model_decode(model: nn.Module) -> None:
+    base = getattr(model, "model", model)
+    if "_ll_decode" in base.__dict__:
+        del base.__dict__["forward"]
+        del base.__dict__["_ll_decode"]
+        del base.__dict__["_ll_model_orig"]

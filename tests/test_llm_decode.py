@@ -192,9 +192,25 @@ def test_fused_decoder_layers_bit_identical():
             gen.manual_seed(3)
             s2 = g.generate(prompt, mask, max_new_tokens=12, do_sample=True, temperature=0.6, top_p=0.9, pad_token_id=0, generator=gen)
             assert torch.equal(s1, s2)
+            # whole decode step of the base model: one prologue launch instead of HF's rotary-table / causal-mask kernels
+            from llamole_amd.llm_accel import fuse_model_decode, restore_model_decode
+            assert fuse_model_decode(llm)
+            calls = []
+            orig_run = llm.model.layers[0]._ll_fused.run
+            llm.model.layers[0]._ll_fused.run = lambda *a, **k: (calls.append(1), orig_run(*a, **k))[1]
+            d2 = GraphedDecoder(llm, use_graph=False, fused_cache=True)
+            assert torch.equal(d2.generate(prompt, mask, **kw), ref) and torch.equal(d2.last_logits, ref_logits)
+            assert len(calls) == kw["max_new_tokens"] - 1
+            for (k, v), l in zip(ref_kv, d2.cache.layers):
+                assert torch.equal(l.keys, k) and torch.equal(l.values, v)
+            g2 = GraphedDecoder(llm, use_graph=True, fused_cache=True)
+            assert torch.equal(g2.generate(prompt, mask, **kw), ref) and torch.equal(g2.last_logits, ref_logits)
+            restore_model_decode(llm)
             restore_decoder_layers(llm)
             assert torch.equal(GraphedDecoder(llm, use_graph=False, fused_cache=True).generate(prompt, mask, **kw), ref)
         finally:
+            from llamole_amd.llm_accel import restore_model_decode
+            restore_model_decode(llm)
             restore_decoder_layers(llm)
             restore_elementwise(llm)
             restore_linears(llm)
