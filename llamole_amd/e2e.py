@@ -124,17 +124,44 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
     n_nodes = torch.full((B,), graph_decoder.max_n_nodes, dtype=torch.int64)
     last = {}
 
+    pipeline = bool(getattr(args, "pipeline", True))
+    pending = {"h": None}
+    dit_ms: list = []
+
+    def collect():
+        h, pending["h"] = pending["h"], None
+        if h is None:
+            return None
+        mols, _ = h.result()
+        dit_ms.append(h.run_ms)
+        return mols
+
     def step_fn(i):
+        """One prompt batch.  Pipelined (default): the reverse diffusion of batch i is enqueued on a side stream and
+        overlaps the LLM decode of batch i+1 (independent prompts); returns the molecules of the PREVIOUS batch, the last
+        batch is collected by ``step_fn.finish()`` inside the timed region."""
         torch.manual_seed(1000 * rank + i)
         t0 = time.perf_counter()
         analysis, design_ids, cond = orch.design_hidden(prompt, mask, None, **kw)
-        torch.cuda.synchronize()
+        if not pipeline:
+            torch.cuda.synchronize()
         t1 = time.perf_counter()
+        if pipeline:
+            prev = collect()
+            pending["h"] = graph_decoder.generate_graphs_async(props, cond.float(), -200.0, n_nodes=n_nodes, seed=1000 * rank + i,
+                                                               use_graph=not args.no_graph)
+            last.update(llm_enqueue_s=t1 - t0, new_tokens=int(analysis.shape[1]), **orch.timings)
+            return prev
         mols, _ = graph_decoder.generate_graphs(props, cond.float(), -200.0, n_nodes=n_nodes, seed=1000 * rank + i,
                                                 use_graph=not args.no_graph)
         t2 = time.perf_counter()
+        dit_ms.append(graph_decoder.last_run_ms()[0])
         last.update(llm_s=t1 - t0, graphdit_s=t2 - t1, new_tokens=int(analysis.shape[1]), **orch.timings)
         return mols
+
+    step_fn.finish = collect
+    step_fn.dit_ms = dit_ms
+    step_fn.pipeline = pipeline
 
     n_params = sum(p.numel() for p in llm.parameters())
     info = {"llm": args.llm, "llm_params": n_params, "llm_weights": "random-init (no network)", "prompt_len": args.cutoff_len,
@@ -144,5 +171,7 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
             "llm_linear": ("ll_linear (HIP weight-streaming GEMV) under %d nn.Linear modules for decode-shaped calls" % n_accel)
                           if n_accel else "PyTorch-ROCm default (hipBLASLt)",
             "llm_fused_elementwise": fused,
+            "pipeline": ("GraphDiT of prompt batch i runs on a side HIP stream and overlaps the LLM decode of batch i+1"
+                         if pipeline else "none (LLM decode, then GraphDiT, per batch)"),
             "timing_breakdown": last}
     return step_fn, info, orch, llm

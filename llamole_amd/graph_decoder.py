@@ -108,6 +108,29 @@ def transition_tables(data_info: DataInfos, T: int):
                 u_ex=ex.contiguous(), betas=betas.contiguous(), alphas_bar=alphas_bar.contiguous())
 
 
+class PendingGraphs:
+    """Handle of an enqueued reverse-diffusion trajectory (GraphDiT.generate_graphs_async)."""
+
+    def __init__(self, owner, X, E, n_nodes, stream):
+        self.owner, self.X, self.E, self.n_nodes, self.stream = owner, X, E, n_nodes, stream
+        self.run_ms = None
+        self._out = None
+
+    def result(self):
+        if self._out is None:
+            self.stream.synchronize()
+            self.run_ms = self.owner.last_run_ms()[0]
+            X, E = self.X.cpu().long(), self.E.cpu().long()
+            mols = []
+            for i in range(X.shape[0]):
+                n = int(self.n_nodes[i])
+                mols.append([X[i, :n].clone(), E[i, :n, :n].clone()])
+            self._out = (mols, self.n_nodes)
+            if self.owner._pending is self:
+                self.owner._pending = None
+        return self._out
+
+
 class GraphDiT(nn.Module):
     def __init__(self, model_config_path, data_info_path, model_dtype):
         super().__init__()
@@ -344,6 +367,36 @@ class GraphDiT(nn.Module):
             n = int(n_nodes[i])
             mols.append([X[i, :n].clone(), E[i, :n, :n].clone()])
         return mols, n_nodes
+
+    @torch.no_grad()
+    def generate_graphs_async(self, properties, text_embedding, no_label_index, n_nodes=None, seed: Optional[int] = None,
+                              use_graph: bool = True) -> "PendingGraphs":
+        """``generate_graphs`` without waiting: the whole trajectory is enqueued on a side HIP stream (after the work already
+        queued on the current stream, which produced ``text_embedding``) and the caller's stream is NOT made to wait, so the
+        LLM decode of the next prompt can overlap this reverse diffusion.  ``.result()`` waits for the side stream only and
+        returns ``(molecule_list, n_nodes)``.  One trajectory at a time per engine: the previous one must be collected."""
+        if getattr(self, "_pending", None) is not None:
+            raise RuntimeError("a previous generate_graphs_async is still pending: call .result() on it first")
+        dev = self._device()
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        side = self._side_stream
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            n_nodes = self.begin(properties, text_embedding, no_label_index, n_nodes)
+            B, N = self._B, self.max_n_nodes
+            qx = torch.empty(B * N, XDIM).exponential_()
+            qe = torch.empty(B * N * N, EDIM).exponential_()
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            self.init_state(qx, qe, seed)
+            self.run(seed, use_graph)
+            X, E = self.get_state()
+        for t in (properties, text_embedding):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(side)
+        self._pending = PendingGraphs(self, X, E, n_nodes, side)
+        return self._pending
 
     @torch.no_grad()
     def generate(self, properties, text_embedding, no_label_index) -> List[Optional[str]]:

@@ -127,3 +127,26 @@ def test_c_abi_error_behaviour():
     m.step(spec.T - 1, seed=1)
     X, E = m.get_state()
     assert X.shape == (1, spec.N)
+
+
+def test_async_trajectory_equals_sync_and_overlaps_other_work():
+    """generate_graphs_async (side stream, caller not blocked) returns exactly what generate_graphs returns, while other work
+    queued on the caller's stream afterwards is free to run; a second launch before .result() is refused."""
+    import pytest as _pt
+    m, do, spec, sd, props, text, n_nodes, seed = _build("n64_hd64", torch.bfloat16)
+    torch.manual_seed(11)
+    ref, _ = m.generate_graphs(props, text, -200.0, n_nodes=n_nodes, seed=77)
+    torch.manual_seed(11)
+    h = m.generate_graphs_async(props, text, -200.0, n_nodes=n_nodes, seed=77)
+    busy = torch.randn(2048, 2048, device="cuda")
+    for _ in range(5):
+        busy = busy @ busy * 1e-3                      # unrelated work on the caller's stream
+    with _pt.raises(RuntimeError, match="pending"):
+        m.generate_graphs_async(props, text, -200.0, n_nodes=n_nodes, seed=78)
+    got, nn = h.result()
+    assert h.run_ms is not None and h.run_ms > 0 and torch.equal(nn, n_nodes)
+    for (a, e), (a0, e0) in zip(got, ref):
+        assert torch.equal(a, a0) and torch.equal(e, e0)
+    torch.cuda.synchronize()
+    h2 = m.generate_graphs_async(props, text, -200.0, n_nodes=n_nodes, seed=77)     # engine is free again
+    assert len(h2.result()[0]) == len(n_nodes)

@@ -9,6 +9,7 @@ import sys
 
 
 def short(name: str) -> str:
+    name = name.replace("(anonymous namespace)", "anon")
     name = re.sub(r"\(.*$", "", name)
     name = name.replace("void ", "").replace("ll::", "")
     return name[:110]
