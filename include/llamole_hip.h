@@ -119,6 +119,11 @@ int ll_dit_get_state(void *handle, int8_t *X, int8_t *E, void *stream);
 int ll_dit_denoise(void *handle, int s, float *logX, float *logE, float *hidden, int tap_layer, void *stream);
 /* Guided probabilities of step s as handed to sample_discrete_features: pX [B,N,16], pE [B,N,N,5]
  * (only rows of valid nodes / pairs i<j of valid nodes are defined; others are written as 0). */
+/* ll_dit_denoise_rows : the denoiser's conditional / unconditional logits for the current state (ll_dit_set_state) with a
+ * PER-GRAPH timestep t_int[b] in 0..T (device int32 [B]) instead of one shared reverse step: the training forward
+ * (GraphDiT.forward / apply_noise, diffusion_model.py:148-250) draws t independently per graph, t = 0 included.
+ * logX [2][B][N][16], logE [2][B][N][N][5] as ll_dit_denoise. */
+int ll_dit_denoise_rows(void *handle, const int32_t *t_int, float *logX, float *logE, void *stream);
 int ll_dit_step_probs(void *handle, int s, float *pX, float *pE, void *stream);
 /* Conditioning vectors c [B+1,H] at step s (rows 0..B-1 conditional, row B unconditional). */
 int ll_dit_cvec(void *handle, int s, float *c, void *stream);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "ll_dit_get_state": (_I, [_P, _P, _P, _P]),
     "ll_dit_denoise": (_I, [_P, _I, _P, _P, _P, _I, _P]),
     "ll_dit_step_probs": (_I, [_P, _I, _P, _P, _P]),
+    "ll_dit_denoise_rows": (_I, [_P, _P, _P, _P, _P]),
     "ll_dit_cvec": (_I, [_P, _I, _P, _P]),
     "ll_dit_last_run_ms": (_I, [_P, C.POINTER(_F), C.POINTER(_I)]),
     "ll_gin_param_count": (_I, [C.POINTER(LLGinConfig)]),

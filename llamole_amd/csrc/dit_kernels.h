@@ -406,15 +406,17 @@ template <typename T, int NS, int MAXE>
 __global__ __launch_bounds__(64) void ln_mod_res_kernel(const float *__restrict__ y, int64_t slab_stride,
                                                           const float *__restrict__ bias, float *__restrict__ x32,
                                                           T *__restrict__ xa, const float *__restrict__ modtab,
-                                                          const int *__restrict__ step_ptr, int layer, int sel, int B,
-                                                          int N, int H, int L, int M2) {
+                                                          const int *__restrict__ step_ptr,
+                                                          const int *__restrict__ rowvec /*[B] table rows or null*/,
+                                                          int layer, int sel, int B, int N, int H, int L, int M2) {
     // one 64-lane wave = one token row = one workgroup: rows spread over as many CUs as possible, because the
     // per-CU load path (~25-40 GB/s), not HBM, bounds these small row kernels
     const int row = blockIdx.x;
     if (row >= M2) return;
     const int lane = threadIdx.x & 63;
-    const int s = *step_ptr;
     const int seq = row / N;
+    // table row: the shared reverse step, or (training forward) a per-graph row -- t differs from graph to graph there
+    const int s = rowvec ? rowvec[seq < B ? seq : seq - B] : *step_ptr;
     const int ci = (seq < B) ? seq : B;  // unconditional pass shares one row
     const float *mod = modtab + (((int64_t)s * (B + 1) + ci) * L + layer) * (6 * (int64_t)H) + (int64_t)sel * 3 * H;
     // MAXE float4 chunks per lane (H <= 256*MAXE).  Every load of the row -- split-K slabs, bias, residual
@@ -487,6 +489,7 @@ struct PostArgs {
     const float *qx, *qe;          // injected Exp(1) noise or null
     const unsigned long long *seed_ptr;
     const int *step_ptr;
+    const int *rowvec;   // [B] per-graph table rows (training forward) or null
     int B, N, F, T;
     float guide;
     float *pX_out, *pE_out;  // optional taps
@@ -499,10 +502,10 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostArgs a) {
     const int N = a.N, F = a.F, B = a.B;
     if (row >= 2 * B * N) return;
     const int lane = threadIdx.x & 63;
-    const int s = *a.step_ptr;
     const int p = row / (B * N);
     const int bi = row - p * B * N;
     const int b = bi / N, i = bi - b * N;
+    const int s = a.rowvec ? a.rowvec[b] : *a.step_ptr;
     const int ci = p == 0 ? b : B;
     const float *ss = a.modo + ((int64_t)s * (B + 1) + ci) * (2 * F);
     float *r = a.out + (int64_t)row * F;
@@ -826,12 +829,13 @@ __global__ __launch_bounds__(256) void init_state_kernel(int8_t *X, int8_t *E, c
 }
 
 // ------------------------------------------------------------------------------------------ cold path (per batch)
-// Sinusoidal timestep features for every step s: t = (s+1)/T fractional (conditions.py:32-51).
+// Sinusoidal timestep features for every step s: t = (s+1)/T fractional (conditions.py:32-51).  Row Tsteps holds t = 0,
+// which only the training forward draws (diffusion_model.py:201-206).
 template <typename T>
 __global__ void tfreq_kernel(T *out, int Tsteps) {
     const int s = blockIdx.x;
     const int j = threadIdx.x;  // 0..127
-    const float t = (float)(s + 1) / (float)Tsteps;
+    const float t = s < Tsteps ? (float)(s + 1) / (float)Tsteps : 0.f;
     const float f = expf(-logf(10000.f) * (float)j / 128.f);
     const float arg = t * f;
     out[(int64_t)s * 256 + j] = from_f32<T>(cosf(arg));
@@ -913,6 +917,14 @@ __global__ void combine_c_kernel(const float *__restrict__ ct, const float *__re
     }
 }
 
+// training forward: timestep t in 0..T -> row of the hoisted tables (t = 0 lives in row T); out-of-range t clamps
+__global__ void t_to_row_kernel(const int *__restrict__ t_int, int *__restrict__ rows, int B, int T) {
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        int t = t_int[b];
+        t = t < 0 ? 0 : (t > T ? T : t);
+        rows[b] = t == 0 ? T : t - 1;
+    }
+}
 __global__ void set_scalars_kernel(int *step_ptr, int s, unsigned long long *seed_ptr, unsigned long long seed) {
     *step_ptr = s;
     *seed_ptr = seed;

@@ -145,7 +145,7 @@ struct DitEngine {
     int B = 0, M2 = 0, M2p = 0, splits_h = 1, splits_m = 1;
     bool begun = false, state_set = false;
     DevBuf n_nodes, X, E, x32, xa, qkv, attn_o, ybuf, h1, ho, outF;
-    DevBuf ct_in, ct_h, ct, zy, cy, txt_op, ctxt, ynan, tnan, c32, ca, m1, modtab, modo;
+    DevBuf ct_in, ct_h, ct, zy, cy, txt_op, ctxt, ynan, tnan, c32, ca, m1, modtab, modo, rows;
     DevBuf scal;  // [0] int step, [8] u64 seed
     DevBuf predX, pxe;
     int state_half = 0;      // which half of X/E holds the current state
@@ -172,6 +172,7 @@ struct DitEngine {
     }
     const float *pfs(const std::string &name) const { return pf(name.c_str()); }
     int *step_ptr() const { return scal.as<int>(); }
+    const int *rowvec = nullptr;   // per-graph table rows while ll_dit_denoise_rows runs, else null
     unsigned long long *seed_ptr() const { return reinterpret_cast<unsigned long long *>(scal.as<char>() + 8); }
     float *tab(int off) const { return tables.as<float>() + off; }
     float *t_xm() const { return tab(0); }
@@ -226,7 +227,7 @@ static void launch_lnmod(DitEngine *e, int layer, int sel, int nslab, const floa
     const int64_t ss = (int64_t)e->M2p * e->cfg.hidden;
 #define LL_LNMOD2(NS, ME)                                                                                              \
     hipLaunchKernelGGL((ln_mod_res_kernel<T, NS, ME>), grid, blk, 0, st, e->ybuf.as<float>(), ss, bias,                 \
-                       e->x32.as<float>(), e->xa.as<T>(), e->modtab.as<float>(), e->step_ptr(), layer, sel, e->B,      \
+                       e->x32.as<float>(), e->xa.as<T>(), e->modtab.as<float>(), e->step_ptr(), e->rowvec, layer, sel, e->B, \
                        e->cfg.max_nodes, e->cfg.hidden, e->cfg.depth, e->M2)
 #define LL_LNMOD(NS)                                                                                                   \
     do {                                                                                                               \
@@ -306,6 +307,7 @@ static int posterior_launch(DitEngine *e, const float *qx, const float *qe, int 
     a.qx = qx; a.qe = qe;
     a.seed_ptr = e->seed_ptr();
     a.step_ptr = e->step_ptr();
+    a.rowvec = e->rowvec;
     a.B = e->B; a.N = e->cfg.max_nodes; a.F = e->F; a.T = e->cfg.T;
     a.guide = e->cfg.guide_scale;
     a.pX_out = pX; a.pE_out = pE; a.logX = logX; a.logE = logE;
@@ -456,7 +458,7 @@ int ll_dit_destroy(void *handle) {
     DevBuf *bufs[] = {&e->wop, &e->wxT, &e->wycat, &e->yw0, &e->yb0, &e->tables, &e->n_nodes, &e->X, &e->E, &e->x32,
                       &e->xa, &e->qkv, &e->attn_o, &e->ybuf, &e->h1, &e->ho, &e->outF, &e->ct_in, &e->ct_h, &e->ct,
                       &e->zy, &e->cy, &e->txt_op, &e->ctxt, &e->ynan, &e->tnan, &e->c32, &e->ca, &e->m1, &e->modtab,
-                      &e->modo, &e->scal, &e->predX, &e->pxe};
+                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows};
     for (DevBuf *b : bufs) b->release();
     if (e->own) (void)hipStreamDestroy(e->own);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -482,8 +484,8 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
     e->splits_h = pick_splits(e->M2, H, H);
     e->splits_m = pick_splits(e->M2, H, Hm);
     const int smax = e->splits_h > e->splits_m ? e->splits_h : e->splits_m;
-    const int Mc = T * (B + 1), Mcp = round_up(Mc, 128);
-    const int Tp = round_up(T, 128), Bp = round_up(B, 128);
+    const int Mc = (T + 1) * (B + 1), Mcp = round_up(Mc, 128);   // rows 0..T-1: reverse steps (t = s+1); row T: t = 0 (training)
+    const int Tp = round_up(T + 1, 128), Bp = round_up(B, 128);
     const size_t M2p = e->M2p;
     void *oldp[] = {e->x32.p, e->xa.p, e->qkv.p, e->attn_o.p, e->ybuf.p, e->h1.p, e->ho.p, e->outF.p, e->modtab.p, e->modo.p, e->X.p, e->E.p, e->n_nodes.p};
     LL_TRY(e->n_nodes.ensure((size_t)B * 4));
@@ -519,11 +521,11 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
 
     LL_HIP(hipMemcpyAsync(e->n_nodes.p, n_nodes, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     // ---- c_t for every step: sinusoid -> Linear(256,H)+SiLU -> Linear(H,H)          (conditions.py:53-58)
-    if (bf) hipLaunchKernelGGL((tfreq_kernel<bf16_t>), dim3(T), dim3(128), 0, st, e->ct_in.as<bf16_t>(), T);
-    else hipLaunchKernelGGL((tfreq_kernel<float>), dim3(T), dim3(128), 0, st, e->ct_in.as<float>(), T);
+    if (bf) hipLaunchKernelGGL((tfreq_kernel<bf16_t>), dim3(T + 1), dim3(128), 0, st, e->ct_in.as<bf16_t>(), T);
+    else hipLaunchKernelGGL((tfreq_kernel<float>), dim3(T + 1), dim3(128), 0, st, e->ct_in.as<float>(), T);
     LL_LAUNCH_CHECK();
-    LL_TRY(linear_launch(dt, e->ct_in.p, 256, e->pw("t_embedder.mlp.0.weight"), 256, e->pf("t_embedder.mlp.0.bias"), e->ct_h.p, H, T, H, 256, 2, 0, st));
-    LL_TRY(linear_launch(dt, e->ct_h.p, H, e->pw("t_embedder.mlp.2.weight"), H, e->pf("t_embedder.mlp.2.bias"), e->ct.p, H, T, H, H, 0, 1, st));
+    LL_TRY(linear_launch(dt, e->ct_in.p, 256, e->pw("t_embedder.mlp.0.weight"), 256, e->pf("t_embedder.mlp.0.bias"), e->ct_h.p, H, T + 1, H, 256, 2, 0, st));
+    LL_TRY(linear_launch(dt, e->ct_h.p, H, e->pw("t_embedder.mlp.2.weight"), H, e->pf("t_embedder.mlp.2.bias"), e->ct.p, H, T + 1, H, H, 0, 1, st));
     // ---- c_y: softmax features -> one GEMM over the K-concatenated property MLPs      (conditions.py:60-98)
     if (bf) hipLaunchKernelGGL((yfeat_kernel<bf16_t>), dim3(B, LL_YDIM), dim3(256), 0, st, props, e->yw0.as<float>(), e->yb0.as<float>(), e->zy.as<bf16_t>(), e->ynan.as<int8_t>(), H);
     else hipLaunchKernelGGL((yfeat_kernel<float>), dim3(B, LL_YDIM), dim3(256), 0, st, props, e->yw0.as<float>(), e->yb0.as<float>(), e->zy.as<float>(), e->ynan.as<int8_t>(), H);
@@ -535,8 +537,8 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
     LL_LAUNCH_CHECK();
     LL_TRY(linear_launch(dt, e->txt_op.p, LL_TEXT_DIM, e->pw("txt_embedder.linear.weight"), LL_TEXT_DIM, e->pf("txt_embedder.linear.bias"), e->ctxt.p, H, B, H, LL_TEXT_DIM, 0, 1, st));
     // ---- c[s][ci]
-    if (bf) hipLaunchKernelGGL((combine_c_kernel<bf16_t>), dim3(T, B + 1), dim3(256), 0, st, e->ct.as<float>(), e->cy.as<float>(), e->ctxt.as<float>(), e->pf("y_embedder.embedding_drop.weight"), e->pf("txt_embedder.embedding_drop.weight"), e->ynan.as<int8_t>(), e->tnan.as<int8_t>(), e->c32.as<float>(), e->ca.as<bf16_t>(), B, H);
-    else hipLaunchKernelGGL((combine_c_kernel<float>), dim3(T, B + 1), dim3(256), 0, st, e->ct.as<float>(), e->cy.as<float>(), e->ctxt.as<float>(), e->pf("y_embedder.embedding_drop.weight"), e->pf("txt_embedder.embedding_drop.weight"), e->ynan.as<int8_t>(), e->tnan.as<int8_t>(), e->c32.as<float>(), e->ca.as<float>(), B, H);
+    if (bf) hipLaunchKernelGGL((combine_c_kernel<bf16_t>), dim3(T + 1, B + 1), dim3(256), 0, st, e->ct.as<float>(), e->cy.as<float>(), e->ctxt.as<float>(), e->pf("y_embedder.embedding_drop.weight"), e->pf("txt_embedder.embedding_drop.weight"), e->ynan.as<int8_t>(), e->tnan.as<int8_t>(), e->c32.as<float>(), e->ca.as<bf16_t>(), B, H);
+    else hipLaunchKernelGGL((combine_c_kernel<float>), dim3(T + 1, B + 1), dim3(256), 0, st, e->ct.as<float>(), e->cy.as<float>(), e->ctxt.as<float>(), e->pf("y_embedder.embedding_drop.weight"), e->pf("txt_embedder.embedding_drop.weight"), e->ynan.as<int8_t>(), e->tnan.as<int8_t>(), e->c32.as<float>(), e->ca.as<float>(), B, H);
     LL_LAUNCH_CHECK();
     // ---- all adaLN modulations for all steps: Linear(H,H)+SiLU -> Linear(H,6H)+Softsign  (transformer.py:125-130)
     for (int l = 0; l < L; ++l) {
@@ -620,6 +622,25 @@ int ll_dit_denoise(void *handle, int s, float *logX, float *logE, float *hidden,
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), s, e->seed_ptr(), 0ull);
     LL_TRY(denoise_body(e, st, hidden, tap_layer));
     return posterior_launch(e, nullptr, nullptr, 0, nullptr, nullptr, logX, logE, st);
+}
+
+int ll_dit_denoise_rows(void *handle, const int32_t *t_int, float *logX, float *logE, void *stream) {
+    DitEngine *e = (DitEngine *)handle;
+    LL_TRY(check_ready(e, true));
+    LL_CHECK(t_int && logX && logE, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int T = e->cfg.T;
+    // the state the denoiser reads is the one a reverse step s = T-1 would read (set by ll_dit_set_state)
+    LL_TRY(ensure_state_half(e, T & 1, st));
+    LL_TRY(e->rows.ensure((size_t)e->B * 4));
+    hipLaunchKernelGGL(t_to_row_kernel, dim3(1), dim3(256), 0, st, t_int, e->rows.as<int>(), e->B, T);
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), T - 1, e->seed_ptr(), 0ull);
+    LL_LAUNCH_CHECK();
+    e->rowvec = e->rows.as<int>();
+    int rc = denoise_body(e, st, nullptr, -1);
+    if (rc == LL_OK) rc = posterior_launch(e, nullptr, nullptr, 0, nullptr, nullptr, logX, logE, st);
+    e->rowvec = nullptr;
+    return rc;
 }
 
 int ll_dit_step_probs(void *handle, int s, float *pX, float *pE, void *stream) {

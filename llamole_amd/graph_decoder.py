@@ -190,10 +190,96 @@ class GraphDiT(nn.Module):
         from .molecule_utils import check_valid
         return check_valid(smiles)
 
-    def forward(self, x, edge_index, edge_attr, graph_batch, properties, text_embedding, no_label_index):
-        # SFT loss (diffusion_model.py:148-177).  The reference computes it and discards it
-        # (modeling_llamole.py:421-425); it is outside the generation hot path.
-        raise NotImplementedError("GraphDiT training loss is not part of the MI355X generation path")
+    @torch.no_grad()
+    def forward(self, x, edge_index, edge_attr, graph_batch, properties, text_embedding, no_label_index, t_int=None, noise=None):
+        """Training loss of the denoiser (reference GraphDiT.forward + apply_noise + TrainLossDiscrete,
+        diffusion_model.py:148-250, 402-438): densify, diffuse every graph to its own random timestep, ONE conditional
+        denoiser pass with per-graph timesteps on the HIP engine (ll_dit_denoise_rows), masked cross-entropies.
+
+        Returns the scalar loss WITHOUT a graph: in Llamole's SFT the decoder is frozen and the design loss is dropped from
+        the total (modeling_llamole.py:421-425), so nothing is ever back-propagated through it.  Conditioning follows the
+        deterministic (eval) branch of the embedders; the training-only label dropout and embedding noise
+        (conditions.py:84-94) are not applied.  ``t_int`` [B] / [B,1] in 0..T and ``noise`` = (qx [B*N,16], qe [B*N*N,5])
+        Exp(1) race noise may be injected (parity tests); otherwise t ~ U{lowest..T} (lowest = 0 in training mode, 1 in
+        eval, :201-206) and the state is drawn with torch.multinomial."""
+        dev = self._device()
+        N, T = self.max_n_nodes, self.T
+        x, edge_index, edge_attr, b = x.to(dev).long(), edge_index.to(dev).long(), edge_attr.to(dev).long(), graph_batch.to(dev).long()
+        B = int(b.max().item()) + 1
+        counts = torch.bincount(b, minlength=B)
+        if int(counts.max()) > N:
+            raise ValueError(f"a graph has more than max_n_nodes={N} atoms")
+        start = torch.cumsum(counts, 0) - counts
+        pos = torch.arange(x.shape[0], device=dev) - start[b]
+        lut = torch.full((118,), -1, dtype=torch.long, device=dev)
+        ai = self.active_index.to(dev).view(-1)
+        lut[ai] = torch.arange(ai.numel(), device=dev)
+        # ---- clean state, as the reference's to_dense leaves it (UNMASKED: every off-diagonal pair carries a class)
+        X = torch.zeros(B, N, XDIM, device=dev)
+        cls = lut[x]
+        ok = cls >= 0
+        X[b[ok], pos[ok], cls[ok]] = 1.0
+        mask = torch.zeros(B, N, dtype=torch.bool, device=dev)
+        mask[b, pos] = True
+        keep = edge_index[0] != edge_index[1]
+        ei, ea = edge_index[:, keep], edge_attr[keep]
+        g = b[ei[0]]
+        E = torch.zeros(B, N, N, EDIM, device=dev)
+        E.index_put_((g, ei[0] - start[g], ei[1] - start[g], ea), torch.ones(ea.shape[0], device=dev), accumulate=True)
+        E[..., 0][E.sum(dim=3) == 0] = 1
+        eye = torch.eye(N, dtype=torch.bool, device=dev).unsqueeze(0).expand(B, -1, -1)
+        E[eye] = 0
+        # ---- z_t ~ q(z_t | z_0): Q_bar_t = a_bar_t I + (1 - a_bar_t) u
+        if t_int is None:
+            t_int = torch.randint(0 if self.training else 1, T + 1, (B,), device=dev)
+        t_int = torch.as_tensor(t_int).to(dev).view(-1).long()
+        if t_int.numel() != B or int(t_int.min()) < 0 or int(t_int.max()) > T:
+            raise ValueError("t_int must hold one timestep in 0..T per graph")
+        tb = {k: v.to(dev) for k, v in self.tables.items()}
+        u_x = tb["x_marg"].unsqueeze(0).expand(XDIM, -1)
+        u_e = tb["e_marg"].unsqueeze(0).expand(EDIM, -1)
+        u = torch.cat([torch.cat([u_x, tb["u_xe"].repeat(1, N)], dim=1),
+                       torch.cat([tb["u_ex"].repeat(N, 1), u_e.repeat(N, N)], dim=1)], dim=0)
+        ab = tb["alphas_bar"][t_int].view(B, 1, 1)
+        Fd = XDIM + EDIM * N
+        Qtb = ab * torch.eye(Fd, device=dev).unsqueeze(0) + (1 - ab) * u.unsqueeze(0)
+        prob = torch.cat([X, E.reshape(B, N, -1)], dim=-1) @ Qtb
+        pX, pE = prob[:, :, :XDIM].clone(), prob[:, :, XDIM:].reshape(B, N, N, EDIM).clone()
+        pX[~mask] = 1 / XDIM
+        pX = pX.reshape(B * N, -1).clamp_min(1e-5)
+        pX = pX / pX.sum(dim=-1, keepdim=True)
+        pE[~(mask.unsqueeze(1) & mask.unsqueeze(2))] = 1 / EDIM
+        pE[eye] = 1 / EDIM
+        pE = pE.reshape(B * N * N, -1).clamp_min(1e-5)
+        pE = pE / pE.sum(dim=-1, keepdim=True)
+        if noise is not None:
+            qx, qe = (q.to(dev).float() for q in noise)
+            Xs, Es = torch.argmax(pX / qx, dim=-1), torch.argmax(pE / qe, dim=-1)
+        else:
+            Xs, Es = pX.multinomial(1).squeeze(1), pE.multinomial(1).squeeze(1)
+        Xs, Es = Xs.reshape(B, N), Es.reshape(B, N, N)
+        Es = torch.triu(Es, diagonal=1)
+        Es = Es + Es.transpose(1, 2)
+        Xs = torch.where(mask, Xs, torch.full_like(Xs, -1))
+        pair = mask.unsqueeze(1) & mask.unsqueeze(2)        # the diagonal of valid nodes keeps class 0, as in the reference
+        Es = torch.where(pair, Es, torch.full_like(Es, -1))
+        # ---- one conditional denoiser pass with per-graph timesteps on the engine
+        self.begin(properties, text_embedding, no_label_index, n_nodes=counts.cpu())
+        self.set_state(Xs.to(torch.int8), Es.to(torch.int8))
+        lx = torch.empty(2, B, N, XDIM, device=dev)
+        le = torch.empty(2, B, N, N, EDIM, device=dev)
+        t32 = t_int.to(torch.int32).contiguous()
+        _lib.check(_lib.load().ll_dit_denoise_rows(self._handle, _lib.dptr(t32), _lib.dptr(lx), _lib.dptr(le),
+                                                   _lib.current_stream_ptr()), "ll_dit_denoise_rows")
+        torch.cuda.current_stream().synchronize()
+        # ---- TrainLossDiscrete: rows whose true one-hot is all zero (padding nodes, the diagonal) do not count
+        lam = getattr(self.model_config, "lambda_train", [1, 10])
+        tX, tE = X.reshape(-1, XDIM), E.reshape(-1, EDIM)
+        mX, mE = (tX != 0).any(dim=-1), (tE != 0).any(dim=-1)
+        loss_x = torch.nn.functional.cross_entropy(lx[0].reshape(-1, XDIM)[mX], tX[mX].argmax(dim=-1))
+        loss_e = torch.nn.functional.cross_entropy(le[0].reshape(-1, EDIM)[mE], tE[mE].argmax(dim=-1))
+        self._last_train = {"X_t": Xs, "E_t": Es, "logX": lx[0], "logE": le[0], "t_int": t_int}
+        return lam[0] * loss_x + lam[1] * loss_e
 
     # ------------------------------------------------------------------ engine management
     def _device(self) -> torch.device:

@@ -324,3 +324,41 @@ def make_cost_weights(seed: int = 0):
 def make_fingerprints(n: int, seed: int = 0):
     rs = np.random.RandomState(7500 + seed)
     return torch.from_numpy((rs.uniform(size=(n, 2048)) < 0.03).astype(np.float32))
+
+
+def make_dit_train_batch(meta, B, seed, T):
+    """Synthetic SFT batch for GraphDiT.forward: B molecules as PyG-style arrays (x = atom ids among the active atoms,
+    symmetric edges with bond classes 1..4), properties with NaN / -200 slots, text rows, per-graph timesteps (t = 0, T and
+    a repeated value included).  Returns x, edge_index, edge_attr, batch, props, text, t_int [B,1]."""
+    import numpy as np
+    import torch
+    rs = np.random.RandomState(seed + 77)
+    N = int(meta["max_node"])
+    active = np.nonzero(np.asarray(meta["atom_type_dist"]) > 0)[0]
+    xs, src, dst, att, bt, off = [], [], [], [], [], 0
+    sizes = [N, max(2, N // 2), 3, 1] + [int(rs.randint(2, N + 1)) for _ in range(max(0, B - 4))]
+    sizes = sizes[:B]
+    for g, n in enumerate(sizes):
+        xs.append(rs.choice(active, size=n))
+        for i in range(1, n):                       # a random tree plus a few extra bonds
+            j = int(rs.randint(0, i))
+            a = int(rs.randint(1, 5))
+            src += [off + i, off + j]
+            dst += [off + j, off + i]
+            att += [a, a]
+        for _ in range(n // 4):
+            i, j = rs.randint(0, n, size=2)
+            if i != j and (off + i, off + j) not in set(zip(src, dst)):
+                a = int(rs.randint(1, 5))
+                src += [off + int(i), off + int(j)]
+                dst += [off + int(j), off + int(i)]
+                att += [a, a]
+        bt += [g] * n
+        off += n
+    x = torch.from_numpy(np.concatenate(xs)).long()
+    ei = torch.tensor([src, dst], dtype=torch.long).reshape(2, -1)
+    ea = torch.tensor(att, dtype=torch.long)
+    props, text, _ = make_dit_inputs(B, seed + 5, N)
+    props[0, 1] = -200.0
+    t = [0, T, 3, 3] + [int(rs.randint(1, T + 1)) for _ in range(max(0, B - 4))]
+    return x, ei, ea, torch.tensor(bt, dtype=torch.long), props, text, torch.tensor(t[:B], dtype=torch.long).view(B, 1)

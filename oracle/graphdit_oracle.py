@@ -355,3 +355,65 @@ def generate(sd, spec: DitSpec, y, txt, n_nodes, noise_fn: Callable[[int], Tuple
     Xi, Ei = collapse(X, E, mask)
     mols = [(Xi[i, :n_nodes[i]].clone(), Ei[i, :n_nodes[i], :n_nodes[i]].clone()) for i in range(B)]
     return mols, (Xi, Ei), trace
+
+
+# ----------------------------------------------------------------------------- training forward (a22 / f4)
+def to_dense(spec: DitSpec, x, edge_index, edge_attr, batch):
+    """reference diffusion_model.py:152-160 + diffusion_utils.py:111-139 (to_dense, encode_no_edge) with the published
+    semantics of torch_geometric's to_dense_batch / remove_self_loops / to_dense_adj.  Returns the UNMASKED one-hot
+    X [B,N,16], E [B,N,N,5] (no-bond class set on every non-diagonal pair, padding included) and node_mask [B,N]."""
+    N = spec.N
+    data_x = F.one_hot(x, num_classes=118).float()[:, spec.active_index]
+    data_e = F.one_hot(edge_attr, num_classes=EDIM).float()
+    B = int(batch.max().item()) + 1
+    counts = torch.bincount(batch, minlength=B)
+    start = torch.cumsum(counts, 0) - counts
+    pos = torch.arange(x.shape[0]) - start[batch]
+    X = torch.zeros(B, N, XDIM)
+    mask = torch.zeros(B, N, dtype=torch.bool)
+    X[batch, pos] = data_x
+    mask[batch, pos] = True
+    keep = edge_index[0] != edge_index[1]
+    ei, de = edge_index[:, keep], data_e[keep]
+    g = batch[ei[0]]
+    E = torch.zeros(B, N, N, EDIM)
+    E.index_put_((g, ei[0] - start[g], ei[1] - start[g]), de, accumulate=True)
+    no_edge = E.sum(dim=3) == 0
+    E[..., 0][no_edge] = 1
+    E[torch.eye(N, dtype=torch.bool).unsqueeze(0).expand(B, -1, -1)] = 0
+    return X, E, mask
+
+
+def apply_noise(spec: DitSpec, X, E, mask, t_int, qx, qe):
+    """reference diffusion_model.py:197-250: z_t ~ q(z_t | z_0) through Q_bar_t = a_bar_t I + (1 - a_bar_t) u
+    (diffusion_utils.py:332-349), sampled with the race noise qx [B*N,16], qe [B*N*N,5]; masked one-hot output."""
+    B, N, _ = X.shape
+    ab = spec.alphas_bar[t_int.view(-1).long()].view(B, 1, 1)
+    Fd = spec.F
+    Qtb = ab * torch.eye(Fd).unsqueeze(0) + (1 - ab) * spec.u.unsqueeze(0)
+    prob = torch.cat([X, E.reshape(B, N, -1)], dim=-1) @ Qtb
+    pX, pE = prob[:, :, :XDIM], prob[:, :, XDIM:].reshape(B, N, N, EDIM)
+    Xs, Es = sample_features(pX, pE, mask, qx, qe)
+    return to_onehot_masked(Xs, Es, mask)
+
+
+def train_loss(spec: DitSpec, pred_X, pred_E, true_X, true_E, lambda_train=(1, 10)):
+    """reference TrainLossDiscrete.forward, diffusion_model.py:402-438."""
+    tX, tE = true_X.reshape(-1, XDIM), true_E.reshape(-1, EDIM)
+    pX, pE = pred_X.reshape(-1, XDIM), pred_E.reshape(-1, EDIM)
+    mX, mE = (tX != 0).any(dim=-1), (tE != 0).any(dim=-1)
+    lx = F.cross_entropy(pX[mX], tX[mX].argmax(dim=-1), reduction="mean")
+    le = F.cross_entropy(pE[mE], tE[mE].argmax(dim=-1), reduction="mean")
+    return lambda_train[0] * lx + lambda_train[1] * le
+
+
+def train_forward(sd, spec: DitSpec, x, edge_index, edge_attr, batch, props, text, no_label_index, t_int, qx, qe,
+                  lambda_train=(1, 10)):
+    """reference GraphDiT.forward (diffusion_model.py:148-173) in eval mode: no condition dropout / noise
+    (conditions.py:84-94 only act when ``train``); t_int [B,1] in 0..T is what torch.randint draws there."""
+    y = torch.where(props == no_label_index, torch.tensor(float("nan")), props)
+    X, E, mask = to_dense(spec, x, edge_index, edge_attr, batch)
+    X_t, E_t = apply_noise(spec, X, E, mask, t_int, qx, qe)
+    t = t_int.float() / spec.T
+    lx, le = denoiser(sd, spec, X_t, E_t, mask, y, text, t, uncond=False)
+    return train_loss(spec, lx, le, X, E, lambda_train), (X_t, E_t, lx, le)

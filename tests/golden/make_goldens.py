@@ -38,8 +38,35 @@ def install_stubs():
 
     tg = types.ModuleType("torch_geometric")
     tgu = types.ModuleType("torch_geometric.utils")
-    for n in ("to_dense_adj", "to_dense_batch", "remove_self_loops"):
-        setattr(tgu, n, None)
+    # torch_geometric.utils used by the TRAINING forward only (diffusion_utils.py:111-124), published semantics:
+    def to_dense_batch(x, batch, max_num_nodes=None):
+        B = int(batch.max().item()) + 1
+        counts = torch.bincount(batch, minlength=B)
+        n = int(max_num_nodes if max_num_nodes is not None else counts.max())
+        start = torch.cumsum(counts, 0) - counts
+        pos = torch.arange(x.shape[0]) - start[batch]
+        out = torch.zeros(B, n, *x.shape[1:], dtype=x.dtype)
+        mask = torch.zeros(B, n, dtype=torch.bool)
+        out[batch, pos] = x
+        mask[batch, pos] = True
+        return out, mask
+
+    def remove_self_loops(edge_index, edge_attr=None):
+        keep = edge_index[0] != edge_index[1]
+        return edge_index[:, keep], (edge_attr[keep] if edge_attr is not None else None)
+
+    def to_dense_adj(edge_index, batch, edge_attr, max_num_nodes=None):
+        B = int(batch.max().item()) + 1
+        counts = torch.bincount(batch, minlength=B)
+        n = int(max_num_nodes if max_num_nodes is not None else counts.max())
+        start = torch.cumsum(counts, 0) - counts
+        g = batch[edge_index[0]]
+        i, j = edge_index[0] - start[g], edge_index[1] - start[g]
+        adj = torch.zeros(B, n, n, *edge_attr.shape[1:], dtype=edge_attr.dtype)
+        adj.index_put_((g, i, j), edge_attr, accumulate=True)      # duplicate edges add, like PyG's scatter
+        return adj
+
+    tgu.to_dense_batch, tgu.remove_self_loops, tgu.to_dense_adj = to_dense_batch, remove_self_loops, to_dense_adj
     tgn = types.ModuleType("torch_geometric.nn")
 
     class MessagePassing(nn.Module):
@@ -253,6 +280,47 @@ def gen_dit(name):
     print(name, "ok:", {k: v.shape for k, v in list(out.items())[:6]}, "...")
 
 
+def gen_dit_train(name):
+    """GraphDiT.forward (training loss, diffusion_model.py:148-250, 402-438) of the reference in eval mode (no condition
+    dropout / noise), with the per-graph timesteps and the forward-noise draws injected."""
+    from graph_decoder import diffusion_model as dm
+
+    cfg, meta, sd, B, seed = dit_case(name)
+    N, T = meta["max_node"], cfg["diffusion_steps"]
+    tmp = tempfile.mkdtemp()
+    synth.write_dit_dir(tmp, cfg, meta, sd)
+    model = dm.GraphDiT(os.path.join(tmp, "config.yaml"), os.path.join(tmp, "data.meta.json"), torch.float32)
+    model.init_model(tmp)
+    model.eval()
+    x, ei, ea, batch, props, text, t_int = synth.make_dit_train_batch(meta, B, seed, T)
+    captured = {}
+    orig_fwd = model._forward
+
+    def spy(noisy, txt, unconditioned=False):
+        captured["X_t"], captured["E_t"] = noisy["X_t"].clone(), noisy["E_t"].clone()
+        pred = orig_fwd(noisy, txt, unconditioned)
+        captured["pX"], captured["pE"] = pred.X.detach().clone(), pred.E.detach().clone()
+        return pred
+    model._forward = spy
+    orig_randint = torch.randint
+    torch.randint = lambda lo, hi, size, device=None, **k: t_int.clone().view(size)
+    try:
+        with torch.no_grad(), NoiseFeed() as feed:
+            feed.push(*synth.exp_noise(seed, T + 1, B, N))
+            loss = model(x, ei, ea, batch, props.clone(), text, -200.0)
+            assert not feed.queue
+    finally:
+        torch.randint = orig_randint
+    Xi = captured["X_t"].argmax(-1)
+    Xi[captured["X_t"].sum(-1) == 0] = -1
+    Ei = captured["E_t"].argmax(-1)
+    Ei[captured["E_t"].sum(-1) == 0] = -1
+    out = {"loss": np.float32(loss.item()), "X_t": Xi.numpy().astype(np.int8), "E_t": Ei.numpy().astype(np.int8),
+           "pX": captured["pX"].numpy(), "pE": captured["pE"].numpy(), "t_int": t_int.numpy()}
+    np.savez_compressed(os.path.join(OUT, name + "_train.npz"), **out)
+    print(name, "train ok: loss", float(loss), "t", t_int.view(-1).tolist())
+
+
 # ----------------------------------------------------------------------------- GIN goldens
 def gen_gin(name):
     from graph_encoder import model as enc
@@ -344,10 +412,13 @@ if __name__ == "__main__":
     install_stubs()
     check_multinomial_is_race()
     sys.path.insert(0, REF)
-    which = sys.argv[1:] or ["dit", "gin", "planner"]
+    which = sys.argv[1:] or ["dit", "dit_train", "gin", "planner"]
     if "dit" in which:
         for n in DIT_CASES:
             gen_dit(n)
+    if "dit_train" in which:
+        for n in DIT_CASES:
+            gen_dit_train(n)
     if "gin" in which:
         for n in GIN_CASES:
             gen_gin(n)

@@ -241,3 +241,30 @@ def test_bf16_engine_close_to_f32_oracle(name):
     for (a, e), n in zip(mols, n_nodes):
         assert a.shape == (int(n),) and (a >= 0).all() and (a < 16).all()
         assert torch.equal(e, e.t()) and (e >= 0).all() and (e < 5).all() and (e.diagonal() == 0).all()
+
+
+@pytest.mark.parametrize("name", list(DIT_CASES))
+def test_training_forward_matches_oracle_and_reference(name):
+    """GraphDiT.forward on the engine with per-graph timesteps (t = 0 and t = T included): noisy state
+    bit-exact, conditional logits and the loss against the oracle AND the reference's own loss (golden)."""
+    from llamole_amd import synth
+    m, cfg, meta, sd, B, seed = _make_model(name, torch.float32)
+    do, spec = _oracle(name)
+    g = load_golden(name + "_train")
+    x, ei, ea, batch, props, text, t_int = synth.make_dit_train_batch(meta, B, seed, spec.T)
+    qx, qe = synth.exp_noise(seed, spec.T + 1, B, spec.N)
+    loss = m(x, ei, ea, batch, props, text, -200.0, t_int=t_int, noise=(qx, qe))
+    ref_loss, (X_t, E_t, lx, le) = do.train_forward(sd, spec, x, ei, ea, batch, props, text, -200.0, t_int, qx, qe)
+    lt = m._last_train
+    assert np.array_equal(lt["X_t"].cpu().numpy().astype(np.int8), g["X_t"]) and np.array_equal(lt["E_t"].cpu().numpy().astype(np.int8), g["E_t"])
+    np.testing.assert_allclose(lt["logX"].cpu().numpy(), lx.numpy(), rtol=5e-3, atol=1e-3)
+    np.testing.assert_allclose(lt["logE"].cpu().numpy(), le.numpy(), rtol=5e-3, atol=1e-3)
+    assert abs(loss.item() - ref_loss.item()) <= 1e-3 * abs(ref_loss.item())
+    assert abs(loss.item() - float(g["loss"])) <= 1e-3 * abs(float(g["loss"]))
+    assert not loss.requires_grad
+    # without injection: timesteps are drawn in 1..T (eval) and the loss stays finite; sampling afterwards still works
+    m.eval()
+    l2 = m(x, ei, ea, batch, props, text, -200.0)
+    assert torch.isfinite(l2) and int(m._last_train["t_int"].min()) >= 1
+    mols, _ = m.generate_graphs(props, text, -200.0, seed=3)
+    assert len(mols) == B

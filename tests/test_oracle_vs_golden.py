@@ -126,3 +126,26 @@ def test_gin(name):
     _close(p, g["topk_p"], 1e-3, 1e-7)
     assert (i.numpy() == g["topk_i"]).mean() > 0.98      # near-ties may swap neighbours
     _close(go.cost_mlp(synth.make_cost_weights(seed), synth.make_fingerprints(4, seed)), g["cost_out"], 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("name", list(DIT_CASES))
+def test_training_forward_matches_reference(name):
+    """GraphDiT.forward of the reference (eval mode, injected timesteps incl. t = 0 and t = T, injected forward noise):
+    noisy state bit-exact, masked logits and the loss to rounding (tests/golden/<case>_train.npz, make_goldens.py dit_train)."""
+    from llamole_amd import synth
+    from oracle import graphdit_oracle as do
+    cfg, meta, sd, B, seed = dit_case(name)
+    g = load_golden(name + "_train")
+    spec = do.build_spec(cfg, meta)
+    x, ei, ea, batch, props, text, t_int = synth.make_dit_train_batch(meta, B, seed, spec.T)
+    assert np.array_equal(t_int.numpy(), g["t_int"])
+    qx, qe = synth.exp_noise(seed, spec.T + 1, B, spec.N)
+    loss, (X_t, E_t, lx, le) = do.train_forward(sd, spec, x, ei, ea, batch, props, text, -200.0, t_int, qx, qe)
+    Xi = X_t.argmax(-1)
+    Xi[X_t.sum(-1) == 0] = -1
+    Ei = E_t.argmax(-1)
+    Ei[E_t.sum(-1) == 0] = -1
+    assert np.array_equal(Xi.numpy().astype(np.int8), g["X_t"]) and np.array_equal(Ei.numpy().astype(np.int8), g["E_t"])
+    np.testing.assert_allclose(lx.numpy(), g["pX"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(le.numpy(), g["pE"], rtol=2e-4, atol=2e-5)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
