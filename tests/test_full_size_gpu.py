@@ -40,6 +40,8 @@ def test_qwen2_7b_decode_fused_equals_unfused_at_full_size():
     gen.manual_seed(9)
     s2 = gdec.generate(prompt, mask, max_new_tokens=8, do_sample=True, temperature=0.6, top_p=0.9, pad_token_id=0, generator=gen)
     assert torch.equal(s1, s2) and int(s1.max()) < 152064
+    from llamole_amd.llm_accel import restore_elementwise      # the rotary patch is module-global: leave HF as we found it
+    restore_elementwise(llm)
 
 
 def _last_but_one_logits(llm, seq):

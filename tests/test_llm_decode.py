@@ -323,3 +323,5 @@ def test_query_forward_reuses_decode_cache_gpu():
     assert orch.decoder._cache_fused
     # cache-based attention over bf16 K/V vs a from-scratch bf16 prefill: bf16-level agreement of the [1,768] condition
     assert (c1.float() - c0.float()).abs().max() <= 3e-2 * c0.float().abs().max()
+    from llamole_amd.llm_accel import restore_elementwise      # the rotary patch is module-global
+    restore_elementwise(llm)

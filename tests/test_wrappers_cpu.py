@@ -58,8 +58,9 @@ def test_graphdit_state_dict_roundtrip_and_errors(dit_dir, tmp_path):
     props, text, n_nodes = synth.make_dit_inputs(2, 0, meta["max_node"])
     with pytest.raises(RuntimeError, match="HIP device"):      # no CPU path in the product
         m.generate_graphs(props, text, -200.0)
-    with pytest.raises(NotImplementedError):
-        m(None, None, None, None, None, None, None)
+    with pytest.raises(RuntimeError, match="HIP device"):      # the training forward has no CPU path either
+        m(torch.zeros(2, dtype=torch.long), torch.zeros((2, 0), dtype=torch.long), torch.zeros(0, dtype=torch.long),
+          torch.zeros(2, dtype=torch.long), props[:1], text[:1], -200.0)
     torch.manual_seed(0)
     n = m.sample_n_nodes(1000)
     assert int(n.min()) >= 5 and int(n.max()) <= meta["max_node"]
