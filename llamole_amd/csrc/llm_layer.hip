@@ -65,7 +65,7 @@ __device__ __forceinline__ void gemv_fma(float (&acc)[MROWS][2], const u32x4 (&w
 // Each wave owns two weight rows (GEMV_SILU_MUL: gate row n and up row n + N; otherwise rows 2w, 2w+1); a lane reads
 // 16 B of each row per step with UNR steps in flight, x comes from LDS (NORM: the workgroup normalises x once, with
 // the first weight loads already in flight) or from L1/L2.  f32 FMA chains in the lane/chunk order of gemv_bf16_kernel.
-template <int MROWS, bool NORM, int EPI, bool NT>
+template <int MROWS, bool NORM, int EPI, bool NT, int XC>
 __global__ __launch_bounds__(256) void gemv_fused_kernel(const bf16_t *__restrict__ X, int ldx, const bf16_t *__restrict__ W,
                                                          int ldw, const float *__restrict__ bias,
                                                          const bf16_t *__restrict__ normw, float eps,
@@ -86,10 +86,12 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const bf16_t *__restric
         wr[r] = W + row * ldw;
     }
     const int nchunk = K / 8;
-    u32x4 xv0[MROWS][4], nw0[4];
+    // XC 16-byte chunks of x per thread (K <= 2048 XC): keeping it at 2 for hidden sizes <= 4096 holds the kernel at
+    // <= 128 VGPRs = 4 waves per SIMD
+    u32x4 xv0[MROWS][XC], nw0[XC];
     if (NORM) {   // x (and the norm weight) first: vmcnt retires in order, the weight loads below stay in flight
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < XC; ++c) {
             const int ch = tid + c * 256;
             const bool ok = ch < nchunk;
 #pragma unroll
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const bf16_t *__restric
         for (int m = 0; m < MROWS; ++m) {
             float ss = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < XC; ++c)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float a = __uint_as_float(xv0[m][c][t] << 16), b = __uint_as_float(xv0[m][c][t] & 0xffff0000u);
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const bf16_t *__restric
             const float var = (red[m][0] + red[m][1] + red[m][2] + red[m][3]) / (float)K;
             const float rstd = rsqrtf(var + eps);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < XC; ++c) {
                 const int ch = tid + c * 256;
                 if (ch < nchunk) {
                     u32x4 o;
@@ -149,9 +151,38 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const bf16_t *__restric
         cbeg += 64 * UNR;
     }
     for (int c0 = cbeg; c0 < nchunk; c0 += 64 * UNR) {
-        gemv_load_w<UNR, NT>(wv, wr, c0, nchunk, true);
-        if (NORM) gemv_fma<MROWS, UNR, true>(acc, wv, xs, K, c0, nchunk);
-        else gemv_fma<MROWS, UNR, false>(acc, wv, X, ldx, c0, nchunk);
+        if (NORM) {
+            gemv_load_w<UNR, NT>(wv, wr, c0, nchunk, true);
+            gemv_fma<MROWS, UNR, true>(acc, wv, xs, K, c0, nchunk);
+        } else {
+            // x chunk u right behind weight chunk u (loads retire in order: the first FMAs need not wait for all of W)
+            u32x4 xv[UNR][MROWS];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int c = c0 + u * 64;
+                const bool ok = c < nchunk;
+#pragma unroll
+                for (int r = 0; r < R; ++r) wv[u][r] = ok ? ldw16<NT>(wr[r] + c * 8) : (u32x4)(0);
+#pragma unroll
+                for (int m = 0; m < MROWS; ++m) xv[u][m] = ok ? *reinterpret_cast<const u32x4 *>(X + (int64_t)m * ldx + c * 8) : (u32x4)(0);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+                for (int m = 0; m < MROWS; ++m) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float a = acc[m][r];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            a = fmaf(__uint_as_float(wv[u][r][t] << 16), __uint_as_float(xv[u][m][t] << 16), a);
+                            a = fmaf(__uint_as_float(wv[u][r][t] & 0xffff0000u), __uint_as_float(xv[u][m][t] & 0xffff0000u), a);
+                        }
+                        acc[m][r] = a;
+                    }
+                }
+            }
+        }
     }
 #pragma unroll
     for (int m = 0; m < MROWS; ++m) {
@@ -271,12 +302,14 @@ template <int MROWS, bool NORM, int EPI>
 static void launch_fused(bool nt, dim3 grid, size_t lds, hipStream_t s, const bf16_t *X, int ldx, const bf16_t *W, int ldw,
                          const float *bias, const bf16_t *normw, float eps, const bf16_t *res, int ldr, bf16_t *C, int ldc, int N,
                          int K) {
-    if (nt)
-        hipLaunchKernelGGL((gemv_fused_kernel<MROWS, NORM, EPI, true>), grid, dim3(256), lds, s, X, ldx, W, ldw, bias, normw, eps, res,
-                           ldr, C, ldc, N, K);
-    else
-        hipLaunchKernelGGL((gemv_fused_kernel<MROWS, NORM, EPI, false>), grid, dim3(256), lds, s, X, ldx, W, ldw, bias, normw, eps, res,
-                           ldr, C, ldc, N, K);
+#define LL_GF(NT_, XC_) hipLaunchKernelGGL((gemv_fused_kernel<MROWS, NORM, EPI, NT_, XC_>), grid, dim3(256), lds, s, X, ldx, W, ldw, bias, \
+                                           normw, eps, res, ldr, C, ldc, N, K)
+    if (!NORM || K <= 4096) {
+        if (nt) LL_GF(true, 2); else LL_GF(false, 2);
+    } else {
+        if (nt) LL_GF(true, 4); else LL_GF(false, 4);
+    }
+#undef LL_GF
 }
 
 template <int MROWS>
