@@ -99,22 +99,16 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
     n_accel = 0
     fused = {}
     if args.llm_linear == "hip":
-        from .llm_accel import accelerate_elementwise, accelerate_linears
-        n_accel = accelerate_linears(llm)
-        if args.llm_fuse:
-            from .llm_accel import use_decode_attention
-            fused = accelerate_elementwise(llm)
-            fused["decode_attention"] = bool(use_decode_attention(llm))
-            if fused["decode_attention"] and args.llm_decode != "hf" and getattr(args, "llm_layer_fuse", True):
-                from .llm_accel import fuse_decoder_layers
-                fused["decoder_layers_5_launches"] = fuse_decoder_layers(llm)
-                if getattr(args, "llm_model_fuse", True):
-                    from .llm_accel import fuse_model_decode
-                    fused["decode_prologue_1_launch"] = fuse_model_decode(llm)
+        from .llm_accel import accelerate_llm
+        fused = accelerate_llm(llm, fuse=bool(args.llm_fuse),
+                               layers=args.llm_decode != "hf" and getattr(args, "llm_layer_fuse", True),
+                               model_decode=getattr(args, "llm_model_fuse", True))
+        n_accel = fused.pop("linears", 0)
     if args.llm_decode != "hf":
         reuse = getattr(args, "query_kv_reuse", True)
-        orch.enable_graphed_decode(use_graph=(args.llm_decode == "graph"), fused_cache=bool(fused), reuse_query_kv=reuse)
-        fused["kv_append"] = bool(fused)
+        orch.enable_graphed_decode(use_graph=(args.llm_decode == "graph"), fused_cache=bool(fused.get("decode_attention")),
+                                   reuse_query_kv=reuse)
+        fused["kv_append"] = bool(fused.get("decode_attention"))
         fused["query_forward_reuses_decode_kv"] = bool(reuse)
     B = props.shape[0]
     g = torch.Generator().manual_seed(100 + rank)

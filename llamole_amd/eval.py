@@ -161,7 +161,10 @@ def run_eval(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> Di
     gen_kwargs["pad_token_id"] = tokenizer.pad_token_id
     model = GraphLLMForCausalMLM.from_pretrained(tokenizer, model_args, data_args, training_args, finetuning_args, load_adapter=True)
     model.eval()
-    model.enable_graphed_decode()
+    accel = model.enable_mi355x_decode()
+    model.batch_retro = bool(getattr(generating_args, "batch_retro", False) or (overrides or {}).get("batch_retro", False))
+    if rank == 0:
+        print(json.dumps({"llm_acceleration": accel}))
     out = run_molqa(model, tokenizer, load_dataset_records(data_args), data_args.cutoff_len,
                     training_args.per_device_eval_batch_size, gen_kwargs, rank=rank, world=world)
     if rank == 0:

@@ -558,3 +558,24 @@ def restore_model_decode(model: nn.Module) -> None:
         del base.__dict__["forward"]
         del base.__dict__["_ll_decode"]
         del base.__dict__["_ll_model_orig"]
+
+
+# ------------------------------------------------------------------------------------------ one call for the whole stack
+def accelerate_llm(model: nn.Module, linears: bool = True, fuse: bool = True, layers: bool = True, model_decode: bool = True) -> dict:
+    """Apply the decode acceleration stack to an (untouched) HF Llama-family causal LM on a HIP device and report what took
+    effect: GEMV under nn.Linear -> fused RMSNorm / rotary / SiLU*mul and q|k|v, gate|up fusion -> decode attention through
+    the AttentionInterface registry -> five-launch decoder layers -> one-launch decode prologue.  Every stage falls back to
+    the HF code for shapes or architectures it does not cover; pair it with ``GraphedDecoder(..., fused_cache=True)``."""
+    info: dict = {"linears": 0}
+    if not next(model.parameters()).is_cuda:
+        return info
+    if linears:
+        info["linears"] = accelerate_linears(model)
+    if linears and fuse:
+        info.update(accelerate_elementwise(model))
+        info["decode_attention"] = bool(use_decode_attention(model))
+        if info["decode_attention"] and layers:
+            info["decoder_layers_5_launches"] = fuse_decoder_layers(model)
+            if model_decode:
+                info["decode_prologue_1_launch"] = fuse_model_decode(model)
+    return info

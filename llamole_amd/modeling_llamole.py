@@ -78,6 +78,15 @@ class GraphLLMForCausalMLM(nn.Module):
         self.reuse_query_kv = reuse_query_kv
         return self
 
+    def enable_mi355x_decode(self, use_graph: bool = True, **kw) -> dict:
+        """The whole LLM-side stack in one call (what bench.py measures): HIP kernels under the HF modules
+        (llm_accel.accelerate_llm) + hipGraph decode with the fused KV append and in-graph sampler.  Returns the report of
+        what took effect; on a CPU model it only installs the (eager) static-cache decoder."""
+        from .llm_accel import accelerate_llm
+        info = accelerate_llm(self.language_model)
+        self.enable_graphed_decode(use_graph=use_graph, fused_cache=bool(info.get("decode_attention")), **kw)
+        return info
+
     def _llm_generate(self, inputs=None, attention_mask=None, inputs_embeds=None, **kwargs):
         if self.decoder is not None:
             return self.decoder.generate(input_ids=inputs, attention_mask=attention_mask, inputs_embeds=inputs_embeds, **kwargs)

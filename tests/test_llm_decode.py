@@ -325,3 +325,30 @@ def test_query_forward_reuses_decode_cache_gpu():
     assert (c1.float() - c0.float()).abs().max() <= 3e-2 * c0.float().abs().max()
     from llamole_amd.llm_accel import restore_elementwise      # the rotary patch is module-global
     restore_elementwise(llm)
+
+
+def test_enable_mi355x_decode_on_cpu_model_is_a_plain_static_cache_decoder():
+    llm = e2e.build_llm("tiny", "cpu", torch.float32)
+    orch, tok = _orchestrator(llm, "cpu", torch.float32)
+    info = orch.enable_mi355x_decode()
+    assert info == {"linears": 0} and orch.decoder is not None and not orch.decoder.use_graph and not orch.decoder.fused_cache
+
+
+@pytest.mark.gpu
+def test_enable_mi355x_decode_reports_the_whole_stack():
+    from llamole_amd.llm_accel import restore_decoder_layers, restore_elementwise, restore_linears, restore_model_decode
+    llm = e2e.build_llm("tiny", "cuda", torch.bfloat16)
+    orch, tok = _orchestrator(llm, "cuda", torch.bfloat16)
+    try:
+        info = orch.enable_mi355x_decode()
+        assert info["linears"] > 0 and info["decode_attention"] and info["decoder_layers_5_launches"] == 2
+        assert info["decode_prologue_1_launch"] and orch.decoder.use_graph and orch.decoder.fused_cache
+        prompt = torch.randint(5, 1000, (1, 10), generator=torch.Generator().manual_seed(2)).cuda()
+        a, ids, cond = orch.design_hidden(prompt, torch.ones_like(prompt), None, do_sample=False, max_new_tokens=16,
+                                          eos_token_id=[], pad_token_id=0)
+        assert a.shape == (1, 16) and cond.shape == (1, 768) and torch.isfinite(cond.float()).all()
+    finally:
+        restore_model_decode(llm)
+        restore_decoder_layers(llm)
+        restore_elementwise(llm)
+        restore_linears(llm)
