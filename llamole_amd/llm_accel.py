@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from . import _lib
 
-MAX_ROWS = 64            # GEMV / skinny-GEMM path under nn.Linear
+MAX_ROWS = 128           # GEMV / skinny-GEMM path under nn.Linear (128-token prefill: 8.7 ms vs 10.0 ms on hipBLASLt, tools/prefill_probe.py)
 MAX_APPEND_ROWS = 16     # new positions per call served by the fused KV append / decode attention (decode, query tail)
 MAX_EW_ROWS = 16384      # row-parallel elementwise kernels (RMSNorm, rotary, SiLU*mul) also serve prefill-sized calls
 

@@ -76,7 +76,7 @@ def test_accelerated_linears_match_blas_and_compose_with_graph():
         n = accelerate_linears(llm, min_weight_elems=1)
         assert n >= 2 * 7 + 1
         got = llm(input_ids=tok).logits.float()
-        big = llm(input_ids=prompt.repeat(8, 1)).logits      # > 64 rows: falls through to F.linear
+        big = llm(input_ids=prompt.repeat(8, 1)).logits      # 192 rows > MAX_ROWS: falls through to F.linear
     assert big.shape[0] == 16
     assert (got - ref).abs().max() <= 2e-2 * ref.abs().max()
     kw = dict(max_new_tokens=8, do_sample=False, pad_token_id=0, eos_token_id=[2047])
@@ -115,7 +115,7 @@ def test_fused_elementwise_matches_hf_modules():
         got_n, got_m = norm(x), mlp(x)
         got_q, got_k = mq.apply_rotary_pos_emb(q, k, cos, sin)
         got_logits = llm(input_ids=tok).logits.float()
-        long_ok = llm(input_ids=prompt.repeat(8, 1)).logits      # 96 rows > MAX_ROWS: original HF path
+        long_ok = llm(input_ids=prompt.repeat(8, 1)).logits      # 192 rows > MAX_ROWS: original HF path
     assert long_ok.shape[0] == 16
     assert torch.equal(got_q, ref_q) and torch.equal(got_k, ref_k)                 # rotary: exact
     for got, ref in ((got_n, ref_n), (got_m, ref_m)):
