@@ -611,6 +611,112 @@ static int launch_pipe(const bf16_t *A, int lda, const bf16_t *W, int ldw, void 
     return LL_OK;
 }
 
+// ------------------------------------------------------------------------------------------ bf16 MFMA, M <= 64 rows
+// The GraphDiT sampler at batch 1 multiplies a 64-row activation panel (cond + uncond tokens of one molecule) by every
+// weight matrix.  With LDS-DMA tiles each workgroup re-ingests the whole panel through a 2-tile-deep ring and ends up
+// bound by its own load path (~33-43 GB/s per CU).  This kernel issues EVERYTHING a workgroup needs
+// up front instead -- one memory round trip:
+//   * workgroup = 16 output columns x one K chunk of KC = 128 NS elements (grid.z chunks = split-K slabs);
+//   * the A panel chunk [64 x KC] goes global -> VGPR (4 NS x 16 B per thread, all in flight) -> LDS (row pitch + 16 B:
+//     ds_read_b128 fragment reads are bank-conflict free);
+//   * each of the 4 waves takes a quarter of the chunk: its weight fragments go straight from global memory into the MFMA
+//     B-operand registers (16 B per lane = 8 consecutive k of one weight row: exactly the operand layout), NS loads;
+//   * 4 NS MFMAs per wave, the four partial 64x16 tiles are summed through LDS in wave order (deterministic).
+template <int NS, typename OutT>
+__global__ __launch_bounds__(256) void gemm_m64_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ W,
+                                                        int ldw, OutT *__restrict__ C, int ldc,
+                                                        const float *__restrict__ bias, int M, int N, int64_t slab_stride,
+                                                        int epi) {
+    constexpr int KC = NS * 128;
+    constexpr int PITCH = KC * 2 + 16;             // bytes
+    constexpr int CPR = KC / 8;                    // 16-byte chunks per row
+    constexpr int NA = 4 * NS;                     // A chunks per thread: 64 * CPR / 256
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_m64[];
+    unsigned char *As = sm_m64;                                        // [64][PITCH]
+    float *red = reinterpret_cast<float *>(sm_m64 + 64 * PITCH);       // [4 waves][4 m-tiles][64 lanes][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int kbeg = blockIdx.z * KC;
+    u4 areg[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int c = tid + i * 256;
+        const int row = c / CPR, kc = c - row * CPR;
+        areg[i] = row < M ? *reinterpret_cast<const u4 *>(A + (int64_t)row * lda + kbeg + kc * 8) : (u4)(0);
+    }
+    int wrow = n0 + (lane & 15);
+    wrow = wrow < N ? wrow : N - 1;
+    const bf16_t *wp = W + (int64_t)wrow * ldw + kbeg + wave * (NS * 32) + (lane >> 4) * 8;
+    u4 wreg[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) wreg[s] = *reinterpret_cast<const u4 *>(wp + s * 32);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int c = tid + i * 256;
+        const int row = c / CPR, kc = c - row * CPR;
+        *reinterpret_cast<u4 *>(As + row * PITCH + kc * 16) = areg[i];
+    }
+    __syncthreads();
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4)(0.f);
+    const unsigned char *ap = As + (lane & 15) * PITCH + (wave * (NS * 32) + (lane >> 4) * 8) * 2;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bf16x8 b = __builtin_bit_cast(bf16x8, wreg[s]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(ap + mt * 16 * PITCH + s * 64);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[mt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4 *>(red + ((wave * 4 + mt) * 64 + lane) * 4) = acc[mt];
+    __syncthreads();
+    // thread (mt = tid>>6, lane): C rows mt*16 + (lane>>4)*4 + r, column n0 + (lane & 15)
+    const int mt = tid >> 6;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(red + ((0 * 4 + mt) * 64 + lane) * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(red + ((w * 4 + mt) * 64 + lane) * 4);
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    const int col = n0 + (lane & 15);
+    if (col < N) {
+        const bool raw = gridDim.z > 1;
+        const float bv = (bias && !raw) ? bias[col] : 0.f;
+        OutT *Cz = C + (int64_t)blockIdx.z * slab_stride;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = mt * 16 + (lane >> 4) * 4 + r;
+            if (row < M) {
+                float o = v[r] + bv;
+                if (!raw) o = apply_epi(o, epi);
+                Cz[(int64_t)row * ldc + col] = from_f32<OutT>(o);
+            }
+        }
+    }
+}
+
+template <int NS>
+static int launch_m64(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M, int N,
+                      int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
+    constexpr size_t lds = (size_t)64 * (NS * 256 + 16) + 4 * 4 * 64 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m64_kernel<NS, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m64_kernel<NS, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(N, 16), 1, splits);
+    if (out_f32)
+        hipLaunchKernelGGL((gemm_m64_kernel<NS, float>), grid, dim3(256), lds, s, A, lda, W, ldw, (float *)C, ldc, bias, M, N, slab_stride, epi);
+    else
+        hipLaunchKernelGGL((gemm_m64_kernel<NS, bf16_t>), grid, dim3(256), lds, s, A, lda, W, ldw, (bf16_t *)C, ldc, bias, M, N, slab_stride, epi);
+    return LL_OK;
+}
+
 static int g_gemm_variant = -1;  // LL_GEMM_VARIANT=0 forces the 2-stage register-staged kernels (A/B testing)
 
 static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
@@ -635,6 +741,15 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
                 case 3: launch_gemv<3>(a, lda, w, ldw, C, ldc, bias, N, K, epi, out_f32, s); break;
                 default: launch_gemv<4>(a, lda, w, ldw, C, ldc, bias, N, K, epi, out_f32, s); break;
             }
+            LL_LAUNCH_CHECK();
+            return LL_OK;
+        }
+        if (g_gemm_variant != 0 && g_gemm_variant != 2 && M <= 64 && (kchunk == 256 || kchunk == 512 || kchunk == 1024) &&
+            (long)cdiv(N, 16) * splits >= 48) {
+            // one molecule's token panel (GraphDiT at batch 1, small GIN batches): everything in flight at once
+            if (kchunk == 1024) LL_TRY((launch_m64<8>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));
+            else if (kchunk == 512) LL_TRY((launch_m64<4>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));
+            else LL_TRY((launch_m64<2>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));
             LL_LAUNCH_CHECK();
             return LL_OK;
         }

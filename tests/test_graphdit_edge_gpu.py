@@ -21,6 +21,8 @@ CASES = {
     "no_guidance": (32, 128, 1, 4, 2, 1.0, [20, 32]),
     "tiny_graphs_T1": (32, 128, 1, 4, 1, 2.0, [1, 2, 3]),
     "batch1": (20, 128, 2, 4, 2, 3.0, [13]),
+    # ref-default width at batch 1: the 64-row panel kernels (K chunks 1024 for qkv / fc1 / fc2 slabs, 256 for proj slabs)
+    "h1024_one_molecule": (32, 1024, 2, 16, 2, 2.0, [32]),
 }
 
 

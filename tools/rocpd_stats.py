@@ -21,6 +21,19 @@ def main():
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else "kernel_name"
     rows = cur.execute(f"select {name_col}, (end - start) from kernels").fetchall()
+    if len(sys.argv) > 3:      # third argument: also write the average idle gap AFTER each kernel type (device timeline order)
+        seq = cur.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
+        gaps = {}
+        for (n0, s0, e0), (n1, s1, e1) in zip(seq, seq[1:]):
+            g = s1 - e0
+            if 0 <= g < 50000:     # ignore host-side pauses
+                a = gaps.setdefault(short(n0), [0, 0])
+                a[0] += 1
+                a[1] += g
+        with open(sys.argv[3], "w") as f:
+            f.write("kernel,n,avg_gap_after_us\n")
+            for n, a in sorted(gaps.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"\"{n}\",{a[0]},{a[1]/a[0]/1e3:.2f}\n")
     agg = {}
     for n, d in rows:
         a = agg.setdefault(short(n), [0, 0, 1e30, 0])
