@@ -47,6 +47,7 @@ class GraphedDecoder:
         # "hip": on a HIP device with bf16 logits the sampler (temperature / top-p / multinomial, or argmax) and the loop
         # bookkeeping are ONE launch inside the captured step (ll_sample_token_bf16); "torch": op-by-op PyTorch sampler
         self.sampler = sampler
+        self.len_bucket = 64
         self._sample_key = None
         self._cache_fused = False
         self._key = None
@@ -178,7 +179,9 @@ class GraphedDecoder:
         device = ref.device
         if attention_mask is None:
             attention_mask = torch.ones(B, P, dtype=torch.long, device=device)
-        max_len = P + max_new_tokens
+        # static-cache length rounded up to a bucket: prompts of slightly different lengths (A* expansion prompts, eval
+        # batches) then share one cache allocation and ONE captured graph; unused tail slots stay masked by causality
+        max_len = -(-(P + max_new_tokens) // self.len_bucket) * self.len_bucket
         self._prepare(B, max_len, device, inputs_embeds is not None)
         self._last = None
         eos = torch.tensor(list(eos_token_id) if isinstance(eos_token_id, (list, tuple)) else

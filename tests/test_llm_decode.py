@@ -352,3 +352,30 @@ def test_enable_mi355x_decode_reports_the_whole_stack():
         restore_decoder_layers(llm)
         restore_elementwise(llm)
         restore_linears(llm)
+
+
+@pytest.mark.gpu
+def test_one_captured_graph_serves_prompts_of_different_lengths():
+    """Static-cache length is bucketed (64): prompts of 10 and 17 tokens share the cache allocation and the captured step;
+    each still decodes exactly what a fresh eager decoder produces for it."""
+    from llamole_amd.llm_accel import (accelerate_llm, restore_decoder_layers, restore_elementwise, restore_linears,
+                                       restore_model_decode)
+    llm = e2e.build_llm("tiny", "cuda", torch.bfloat16)
+    kw = dict(max_new_tokens=9, do_sample=False, pad_token_id=0, eos_token_id=[])
+    try:
+        accelerate_llm(llm)
+        g = GraphedDecoder(llm, use_graph=True, fused_cache=True)
+        outs, graphs = [], []
+        for P in (10, 17, 12):
+            prompt = torch.randint(5, 1000, (1, P), generator=torch.Generator().manual_seed(P)).cuda()
+            outs.append((prompt, g.generate(prompt, torch.ones_like(prompt), **kw)))
+            graphs.append(g._graph)
+        assert graphs[0] is graphs[1] is graphs[2] and g.mask.shape[1] == 64
+        for prompt, got in outs:
+            ref = GraphedDecoder(llm, use_graph=False, fused_cache=True).generate(prompt, torch.ones_like(prompt), **kw)
+            assert torch.equal(got, ref)
+    finally:
+        restore_model_decode(llm)
+        restore_decoder_layers(llm)
+        restore_elementwise(llm)
+        restore_linears(llm)
