@@ -717,6 +717,13 @@ static int launch_m64(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *
     return LL_OK;
 }
 
+template <int NS>
+static int launch_m64_cfg(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M, int N,
+                          int K, int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
+    LL_CHECK(M <= 64 && K == NS * 128 * splits, "panel kernel: M <= 64 and K = %d * splits", NS * 128);
+    return launch_m64<NS>(A, lda, W, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s);
+}
+
 static int g_gemm_variant = -1;  // LL_GEMM_VARIANT=0 forces the 2-stage register-staged kernels (A/B testing)
 
 static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
@@ -864,6 +871,9 @@ static const PipeCfg g_pipe_cfgs[] = {
     {1, 1, 208, launch_gemv_cfg<1, 8>},            // 28
     {1, 8, 204, launch_gemv_cfg<8, 4>},            // 29
     {1, 1, 216, launch_gemv_cfg<1, 16>},           // 30
+    {64, 16, 308, launch_m64_cfg<8>},              // 31  all-in-flight panel kernel, K chunk 1024 (M <= 64, K = 1024 * splits)
+    {64, 16, 304, launch_m64_cfg<4>},              // 32  K chunk 512
+    {64, 16, 302, launch_m64_cfg<2>},              // 33  K chunk 256
 };
 }  // namespace ll
 
