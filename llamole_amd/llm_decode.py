@@ -4,8 +4,10 @@ Row f2 of SURVEY.md section 8 ("LLM-side hot loop"): the reference calls ``langu
 (modeling_llamole.py:599, :849), i.e. ~10^3 small launches per token from Python.  On MI355X the decode step
 of a 7-8 B model is launch-bound long before it is HBM-bound, so the step -- the stock HF ``forward`` over a
 ``StaticCache`` -- is captured ONCE as a hipGraph (``torch.cuda.CUDAGraph``; no tracing compiler, no Triton)
-and replayed per token; sampling (temperature, top-p, multinomial) stays on the device and the only host
-sync is an EOS check every ``sync_every`` tokens.  The LLM forward itself is HF code on PyTorch-ROCm.
+and replayed per token; sampling (temperature, top-p, multinomial) stays on the device -- on a HIP device with bf16
+logits it is ONE launch (``ll_sample_token_bf16``) captured in the same graph together with the loop bookkeeping --
+and the only host sync is an EOS check every ``sync_every`` tokens.  The LLM forward itself is HF code on
+PyTorch-ROCm; ``llm_accel`` swaps HIP kernels in underneath its modules.
 
 ``GraphedDecoder.generate(input_ids, attention_mask, ...)`` returns prompt + new tokens like ``generate``
 (rows that stopped are padded with ``pad_token_id``).  Greedy mode is token-identical to HF ``generate``.
@@ -196,9 +198,12 @@ class GraphedDecoder:
         plen = attention_mask.long().sum(dim=1, keepdim=True)            # valid prompt tokens per row (left padding)
         pos_ids = (attention_mask.long().cumsum(dim=1) - 1).clamp_min(0)
         kw = dict(inputs_embeds=inputs_embeds) if inputs_embeds is not None else dict(input_ids=input_ids)
-        out = self.model(attention_mask=self.mask[:, :P], past_key_values=self.cache,
-                         cache_position=torch.arange(P, device=device), position_ids=pos_ids, use_cache=True,
-                         return_dict=True, logits_to_keep=1, **kw)      # only the last position's logits are used
+        pre = dict(attention_mask=self.mask[:, :P], past_key_values=self.cache, cache_position=torch.arange(P, device=device),
+                   position_ids=pos_ids, use_cache=True, return_dict=True, **kw)
+        try:
+            out = self.model(logits_to_keep=1, **pre)       # only the last position's logits are used
+        except TypeError:                                   # a model class without that argument
+            out = self.model(**pre)
         logits = out.logits[:, -1, :]
         for layer in self.cache.layers:          # the next free slot is P whichever update path the prefill took (a short
             if hasattr(layer, "cumulative_length"):   # prompt on a re-used cache goes through the fused append, which
