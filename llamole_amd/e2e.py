@@ -22,6 +22,15 @@ LLM_CONFIGS = {
     "llama-3.1-8b": dict(cls="Llama", hidden_size=4096, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8,
                          intermediate_size=14336, vocab_size=128256, max_position_embeddings=131072, rope_theta=500000.0,
                          rms_norm_eps=1e-5, tie_word_embeddings=False),
+    "mistral-7b": dict(cls="Mistral", hidden_size=4096, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8,
+                       intermediate_size=14336, vocab_size=32768, max_position_embeddings=32768, rope_theta=1000000.0,
+                       rms_norm_eps=1e-5, sliding_window=None, tie_word_embeddings=False),
+    "tiny-llama": dict(cls="Llama", hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                       intermediate_size=512, vocab_size=2048, max_position_embeddings=2048, rope_theta=10000.0,
+                       rms_norm_eps=1e-5, tie_word_embeddings=False),
+    "tiny-mistral": dict(cls="Mistral", hidden_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                         intermediate_size=512, vocab_size=2048, max_position_embeddings=2048, rope_theta=10000.0,
+                         rms_norm_eps=1e-5, sliding_window=None, tie_word_embeddings=False),
     "tiny": dict(cls="Qwen2", hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
                  intermediate_size=512, vocab_size=2048, max_position_embeddings=2048, rope_theta=10000.0,
                  rms_norm_eps=1e-6, tie_word_embeddings=False),

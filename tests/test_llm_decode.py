@@ -379,3 +379,34 @@ def test_one_captured_graph_serves_prompts_of_different_lengths():
         restore_decoder_layers(llm)
         restore_elementwise(llm)
         restore_linears(llm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ["tiny-llama", "tiny-mistral"])
+def test_fused_stack_on_llama_and_mistral_layouts(arch):
+    """BASELINE configs[3]/[4] name Llama-3.1-8B and Mistral-7B: same decoder-layer layout without q/k/v biases (Mistral here
+    with head_dim 128): the whole stack installs and decodes token-identically to the per-op accelerated path."""
+    from llamole_amd.llm_accel import (accelerate_elementwise, accelerate_linears, accelerate_llm, restore_decoder_layers,
+                                       restore_elementwise, restore_linears, restore_model_decode, use_decode_attention)
+    llm = e2e.build_llm(arch, "cuda", torch.bfloat16)
+    prompt = torch.randint(5, 1000, (2, 11), generator=torch.Generator().manual_seed(4)).cuda()
+    mask = torch.ones_like(prompt)
+    mask[0, :3] = 0
+    kw = dict(max_new_tokens=8, do_sample=False, pad_token_id=0, eos_token_id=[])
+    try:
+        accelerate_linears(llm, min_weight_elems=1)
+        accelerate_elementwise(llm)
+        assert use_decode_attention(llm)
+        base = GraphedDecoder(llm, use_graph=False, fused_cache=True)
+        ref = base.generate(prompt, mask, **kw)
+        ref_logits = base.last_logits.clone()
+        info = accelerate_llm(llm, linears=False) or {}
+        from llamole_amd.llm_accel import fuse_decoder_layers, fuse_model_decode
+        assert fuse_decoder_layers(llm) == 2 and fuse_model_decode(llm)
+        g = GraphedDecoder(llm, use_graph=True, fused_cache=True)
+        assert torch.equal(g.generate(prompt, mask, **kw), ref) and torch.equal(g.last_logits, ref_logits)
+    finally:
+        restore_model_decode(llm)
+        restore_decoder_layers(llm)
+        restore_elementwise(llm)
+        restore_linears(llm)
