@@ -97,3 +97,39 @@ def sft_step(model, batch: Dict[str, Any], optimizer=None, bucket_bytes: int = 6
     log = {k: float(v) for k, v in out.additional_log_info.items()}
     log["loss"] = float(loss.detach())
     return log
+
+
+class LoRALinear(torch.nn.Module):
+    """``y = W x + b + (alpha / r) * B(A x)`` around a frozen ``nn.Linear`` (Hu et al. 2021) -- the adapter form Llamole's
+    SFT trains (reference YAMLs: finetuning_type lora, lora_target all); ``peft`` is not in this image, and the decode-time
+    stack never sees these modules (the reference merges the adapter before generation, modeling_llamole.py:139-160)."""
+
+    def __init__(self, base: torch.nn.Linear, r: int = 8, alpha: int = 16):
+        super().__init__()
+        self.base = base
+        for p in self.base.parameters():
+            p.requires_grad = False
+        dev, dt = base.weight.device, base.weight.dtype
+        self.lora_a = torch.nn.Parameter(torch.randn(r, base.in_features, device=dev, dtype=dt) * (1.0 / base.in_features) ** 0.5)
+        self.lora_b = torch.nn.Parameter(torch.zeros(base.out_features, r, device=dev, dtype=dt))
+        self.scale = alpha / r
+
+    def forward(self, x):
+        return self.base(x) + (x @ self.lora_a.t()) @ self.lora_b.t() * self.scale
+
+    def merged_weight(self) -> torch.Tensor:
+        return self.base.weight + (self.lora_b @ self.lora_a) * self.scale
+
+
+def add_lora(model: torch.nn.Module, r: int = 8, alpha: int = 16, targets=("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj",
+                                                                           "up_proj", "down_proj")) -> int:
+    """Freeze ``model`` and wrap its target Linears with LoRA adapters; returns the number of wrapped modules."""
+    for p in model.parameters():
+        p.requires_grad = False
+    n = 0
+    for parent in list(model.modules()):
+        for name, child in list(parent.named_children()):
+            if name in targets and type(child) is torch.nn.Linear:
+                setattr(parent, name, LoRALinear(child, r, alpha))
+                n += 1
+    return n
