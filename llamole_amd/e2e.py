@@ -51,11 +51,25 @@ class SyntheticTokenizer:
         return self.vocab_size
 
     def encode(self, text, add_special_tokens=False, return_tensors=None):
-        if text in self.special:
-            ids = [self.special[text]]
-        else:
-            ids = [5 + (hash(text[i:i + 3]) % 1000) for i in range(0, len(text), 3)]
+        """3 characters per token (stable across processes); special-token strings inside the text become their ids."""
+        import zlib
+        ids, i = [], 0
+        while i < len(text):
+            hit = next((s for s in self.special if text.startswith(s, i)), None)
+            if hit is not None:
+                ids.append(self.special[hit])
+                i += len(hit)
+                continue
+            j = i + 3
+            nxt = min((text.find(s, i) for s in self.special if text.find(s, i) > i), default=len(text))
+            j = min(j, nxt)
+            ids.append(5 + zlib.crc32(text[i:j].encode()) % 1000)
+            i = j
         return torch.tensor([ids]) if return_tensors == "pt" else ids
+
+    def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=False):
+        text = "".join(f"<|{m['role']}|>{m['content']}" for m in messages) + ("<|assistant|>" if add_generation_prompt else "")
+        return self.encode(text) if tokenize else text
 
     def decode(self, ids, skip_special_tokens=False, **k):
         return " ".join(str(int(i)) for i in ids)

@@ -66,6 +66,7 @@ class GraphLLMForCausalMLM(nn.Module):
         self.timings: Dict[str, float] = {}
         self.decoder = None      # optional llm_decode.GraphedDecoder (HIP-graph decode step); None = HF generate
         self.reuse_query_kv = False
+        self.retro_max_new_tokens = 512   # analysis budget of one expansion (the reference hard-codes it, :846-848)
         self.batch_retro = False   # lock-step A* searches of one batch with batched expansions (retrosynthesize_many)
         self.batch_values = True   # A* value estimates of one expansion in one LLM forward (estimate_synthesis_complexity_batch)
 
@@ -387,7 +388,7 @@ class GraphLLMForCausalMLM(nn.Module):
         graphs = GraphBatch.from_data_list((molecule_graphs.to_data_list() if with_context else []) + [product])
         embeds = self._splice_molecules(prompt, graphs)
         if "max_new_tokens" in kwargs:
-            kwargs["max_new_tokens"] = 512
+            kwargs["max_new_tokens"] = self.retro_max_new_tokens
         analysis = self._llm_generate(attention_mask=torch.ones_like(prompt), inputs_embeds=embeds, **kwargs)
         retro_ids = self.add_special_body_tokens(analysis, self.token_id_dict["<retro_body>"], self.num_body_tokens,
                                                  start_token_id=self.token_id_dict["<retro_start>"])
@@ -447,7 +448,7 @@ class GraphLLMForCausalMLM(nn.Module):
             embeds.append(e)
         embeds = torch.cat(embeds, dim=0)
         if "max_new_tokens" in kwargs:
-            kwargs["max_new_tokens"] = 512
+            kwargs["max_new_tokens"] = self.retro_max_new_tokens
         analysis = self._llm_generate(attention_mask=mask, inputs_embeds=embeds, **kwargs)
         retro_ids = self.add_special_body_tokens(analysis, self.token_id_dict["<retro_body>"], self.num_body_tokens,
                                                  start_token_id=self.token_id_dict["<retro_start>"])
