@@ -760,6 +760,14 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
             LL_LAUNCH_CHECK();
             return LL_OK;
         }
+        if (g_gemm_variant != 0 && M <= 32 && cdiv(N, 32) < 4096) {
+            // a few rows (several sequences decoding at once, one small graph): 32x32 tiles, 8-deep ring -- many small
+            // workgroups and a small activation share of each one's ingest (tools/gemm_rows32_sweep.py: 13 vs 17 us on the
+            // Qwen2-7B q|k|v shape, 55 vs 73 us on down_proj at 8-32 rows)
+            LL_TRY((launch_pipe<32, 32, 2, 2, 8>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
+            LL_LAUNCH_CHECK();
+            return LL_OK;
+        }
         if (g_gemm_variant != 0) {
             // pipelined kernels: prefer the largest tile that still gives >= ~1 workgroup per CU
             const long w12864 = (long)cdiv(M, 128) * cdiv(N, 64) * splits;
@@ -874,6 +882,13 @@ static const PipeCfg g_pipe_cfgs[] = {
     {64, 16, 308, launch_m64_cfg<8>},              // 31  all-in-flight panel kernel, K chunk 1024 (M <= 64, K = 1024 * splits)
     {64, 16, 304, launch_m64_cfg<4>},              // 32  K chunk 512
     {64, 16, 302, launch_m64_cfg<2>},              // 33  K chunk 256
+    {32, 96, 4, launch_pipe<32, 96, 2, 2, 4>},     // 34  <= 32 rows (several sequences decoding at once): small A share of the ingest
+    {32, 96, 6, launch_pipe<32, 96, 2, 2, 6>},     // 35
+    {32, 128, 4, launch_pipe<32, 128, 2, 2, 4>},   // 36
+    {32, 64, 4, launch_pipe<32, 64, 2, 2, 4>},     // 37
+    {32, 64, 6, launch_pipe<32, 64, 2, 2, 6>},     // 38
+    {32, 224, 4, launch_pipe<32, 224, 2, 2, 4>},   // 39
+    {32, 32, 8, launch_pipe<32, 32, 2, 2, 8>},     // 40
 };
 }  // namespace ll
 

@@ -66,7 +66,9 @@ def test_linear_matches_torch():
     for (M, N, K) in [(64, 176, 128), (512, 3072, 1024), (450, 266, 256), (3, 128, 768), (1024, 4096, 1024), (64, 1024, 4096),
                       (1, 3584, 3584), (2, 515, 1032), (4, 18944, 3584), (17, 192, 64),
                       # M <= 64 all-in-flight kernel (gemm_m64_kernel): K chunks of 1024 / 512 / 256, ragged M and N
-                      (64, 3072, 1024), (40, 4096, 1024), (64, 1024, 512), (33, 784, 256), (5, 1000, 1024)]:
+                      (64, 3072, 1024), (40, 4096, 1024), (64, 1024, 512), (33, 784, 256), (5, 1000, 1024),
+                      # 5..32 rows over large weight matrices (several sequences decoding at once), ragged N
+                      (8, 18944, 3584), (16, 3584, 18944), (23, 4611, 3584), (32, 2048, 2112)]:
         Mp = (M + 127) // 128 * 128
         A = torch.zeros(Mp, K, device="cuda")
         A[:M] = torch.randn(M, K, device="cuda")
