@@ -47,6 +47,12 @@ const char *ll_last_error(void);
 int ll_linear(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
               int M, int N, int K, int epi, int out_f32, void *stream);
 
+/* bf16 Linear with the K dimension split over `splits` workgroup groups (2..16, K % (64*splits) == 0): for a few rows times a
+ * short, wide weight matrix (batch-8/16 decode through down_proj: 3584 x 18944) an unsplit launch has too few workgroups to
+ * pull HBM bandwidth.  workspace: device f32 [splits * M * N]; partial slabs are summed in order (deterministic). */
+int ll_linear_splitk_bf16(const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, int M, int N,
+                          int K, int epi, int splits, float *workspace, void *stream);
+
 /* Tuning utility: average ms of `iters` launches of pipelined-GEMM configuration `cfg` (-1 = the production
  * dispatch) on an [M,K]x[N,K]^T bf16 problem, cycling over `nweights` weight matrices (HBM-resident stream). */
 int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f32, int iters, int nweights, float *ms);

@@ -37,6 +37,7 @@ SIGNATURES = {
     "ll_version": (_I, []),
     "ll_last_error": (C.c_char_p, []),
     "ll_linear": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ll_linear_splitk_bf16": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ll_gemm_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "ll_launch_bench": (_I, [_I, _I, _I, C.POINTER(_F)]),
     "ll_launch_bench_set_buffers": (_I, [_P, _P]),

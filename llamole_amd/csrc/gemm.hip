@@ -12,6 +12,8 @@
 // f32 path  : exact-f32 VALU tile kernel, used by the parity mode (dtype = LL_F32).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace ll {
@@ -1054,6 +1056,33 @@ extern "C" int ll_launch_bench(int kind, int n, int graph, float *us) {
     if (ext) {}
     else if (big) (void)hipFree(big);
     else { (void)hipFree(a); (void)hipFree(b); }
+    return LL_OK;
+}
+
+namespace ll {
+// out[m][n] = epi(sum_z slabs[z][m][n] + bias[n]) (+ residual) -> bf16; slabs summed in order (deterministic)
+__global__ void slab_reduce_bf16_kernel(const float *__restrict__ slabs, int64_t slab_stride, int splits, const float *__restrict__ bias,
+                                        bf16_t *__restrict__ out, int ldc, int M, int N, int epi) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)M * N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+        float a = 0.f;
+        for (int z = 0; z < splits; ++z) a += slabs[z * slab_stride + i];
+        out[(int64_t)m * ldc + n] = f32_to_bf16(apply_epi(a + (bias ? bias[n] : 0.f), epi));
+    }
+}
+}  // namespace ll
+
+extern "C" int ll_linear_splitk_bf16(const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, int M,
+                                     int N, int K, int epi, int splits, float *workspace, void *stream) {
+    using namespace ll;
+    LL_CHECK(A && W && C && workspace, "ll_linear_splitk_bf16: null argument");
+    LL_CHECK(splits >= 2 && splits <= 16, "ll_linear_splitk_bf16: splits=%d out of range 2..16", splits);
+    hipStream_t st = (hipStream_t)stream;
+    LL_TRY(gemm_dispatch(LL_BF16, A, lda, W, ldw, nullptr, workspace, N, M, N, K, splits, (int64_t)M * N, EPI_NONE, 1, st));
+    const int64_t total = (int64_t)M * N;
+    int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(slab_reduce_bf16_kernel, dim3(blocks), dim3(256), 0, st, workspace, total, splits, bias, (bf16_t *)C, ldc, M, N, epi);
+    LL_LAUNCH_CHECK();
     return LL_OK;
 }
 

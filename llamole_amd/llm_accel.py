@@ -30,6 +30,16 @@ def _hip_linear_forward(self: nn.Linear, x: torch.Tensor) -> torch.Tensor:
             x2 = x2.contiguous()
         M, N = x2.shape[0], self.out_features
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+        if 4 < M <= 32 and K >= 8192 and N <= 8192 and self.bias is None and K % 256 == 0:
+            # a few rows x a short, wide matrix (down_proj at batch 8-16): split K so that >= 256 workgroups stream it
+            splits = 4 if K % 512 == 0 and (N + 31) // 32 * 2 < 256 else 2
+            if K % (64 * splits) == 0:
+                ws = torch.empty(splits * M * N, dtype=torch.float32, device=x.device)
+                rc = self._ll_lib.ll_linear_splitk_bf16(x2.data_ptr(), K, self.weight.data_ptr(), K, None, out.data_ptr(), N, M, N, K, 0,
+                                                        splits, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                if rc != 0:
+                    _lib.check(rc, "ll_linear_splitk_bf16")
+                return out.reshape(*x.shape[:-1], N)
         bias = None
         if self.bias is not None:
             bias = getattr(self, "_ll_bias_f32", None)

@@ -272,3 +272,22 @@ def test_training_forward_matches_oracle_and_reference(name):
     assert torch.isfinite(l2) and int(m._last_train["t_int"].min()) >= 1
     mols, _ = m.generate_graphs(props, text, -200.0, seed=3)
     assert len(mols) == B
+
+
+def test_linear_splitk_matches_torch():
+    """ll_linear_splitk_bf16 (few rows x short, wide weight matrix: batch-8/16 decode through down_proj) vs f64 PyTorch."""
+    from llamole_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(1)
+    for (M, N, K, splits) in [(8, 3584, 18944, 4), (16, 1000, 8192, 2), (5, 96, 1024, 16), (32, 3584, 18944, 4)]:
+        A = torch.randn(M, K, device="cuda").bfloat16()
+        W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
+        bias = torch.randn(N, device="cuda")
+        ws = torch.empty(splits * M * N, device="cuda")
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        _lib.check(lib.ll_linear_splitk_bf16(_lib.dptr(A), K, _lib.dptr(W), K, _lib.dptr(bias), _lib.dptr(out), N, M, N, K, 2, splits,
+                                             _lib.dptr(ws), None))
+        torch.cuda.synchronize()
+        ref = torch.nn.functional.silu(A.double() @ W.double().t() + bias.double()).float()
+        assert torch.allclose(out.float(), ref, rtol=2e-2, atol=2e-2), (M, N, K, (out.float() - ref).abs().max())
+    assert lib.ll_linear_splitk_bf16(_lib.dptr(A), K, _lib.dptr(W), K, None, _lib.dptr(out), N, M, N, K, 0, 1, _lib.dptr(ws), None) == -1
