@@ -238,6 +238,20 @@ int ll_decode_prologue(const int64_t *position_ids, const float *inv_freq, float
                        int64_t mask_stride, const int64_t *pos, void *cos, void *sin, void *mask_out, int B, int D, int maxlen,
                        void *stream);
 int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iters, int nweights, float *ms);
+
+/* ll_linear_rows16_bf16 : out[M,N] = epilogue(x[M,K] . W^T + bias), M in 1..16, K % 32 == 0, bf16 operands, f32 accumulation on MFMA:
+ *     the nn.Linear of a batched decode step (5..16 sequences: lock-step A* searches, several prompts per GPU) as a weight
+ *     stream -- every wave streams its own 16 weight rows in line-contiguous segments through a private LDS image, no barrier in
+ *     the main loop.  Epilogues LL_GEMV_PLAIN / LL_GEMV_RESIDUAL / LL_GEMV_SILU_MUL as ll_gemv_fused_bf16 (W has 2N rows for
+ *     SILU_MUL); replaces nn.Linear.forward (+ the residual add / act_fn(gate)*up of Qwen2DecoderLayer / Qwen2MLP.forward,
+ *     transformers modeling_qwen2.py) under the reference's language_model.generate (modeling_llamole.py:599, :849).
+ * ll_set_rows16_geometry : tuning -- bytes of a row per block (128 | 256 | 512), waves per workgroup (4 | 8 | 16) and how many
+ *     consecutive waves split K of one tile; (0, 0, 0) = chosen by tile count.
+ * ll_rows16_bench : timing utility (HIP events, `nweights` distinct weight matrices). */
+int ll_linear_rows16_bf16(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *residual, int ldr, void *out,
+                          int ldc, int M, int N, int K, int epi, void *stream);
+int ll_set_rows16_geometry(int seg, int waves, int ksplit);
+int ll_rows16_bench(int M, int N, int K, int epi, int iters, int nweights, float *ms);
 int ll_set_gemv_nt(int on);
 
 /* ll_sample_token_bf16 : one decode-loop sampling step per row in ONE launch -- HF TemperatureLogitsWarper + TopPLogitsWarper

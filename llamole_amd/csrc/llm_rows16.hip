@@ -1,0 +1,256 @@
+// Weight-streaming Linear for 5..16 token rows (batched decode of the HF LLM, SURVEY.md section 8 f2: 16 lock-step A* searches,
+// 8 prompts per GPU): out[M,N] = epilogue(x[M,K] . W[N,K]^T + bias), bf16 operands, f32 accumulation on
+// v_mfma_f32_16x16x32_bf16 with the token rows as the 16-wide MFMA column block.
+//
+// What shapes the kernel (tools/ingest_probe.hip, MI355X): a CU pulls 125-150 GB/s when the 16-byte loads of adjacent lanes
+// are contiguous (>= 128 B per row segment) and 38 GB/s in the MFMA operand order (lane & 15 = row, lane >> 4 = 16-B piece:
+// every lane group touches 16 different lines).  So nothing is loaded in operand order: each WAVE streams its own 16 weight
+// rows in 512-byte (256-byte for the gated-MLP pair) row segments, two (four) rows per wave instruction, passes them
+// through a wave-private, padded LDS image (pitch = segment + 16 B: conflict-free ds_read_b128 fragments) and multiplies;
+// the matching x segment goes the same way.  The LDS image is private to the wave, so the main loop has no barrier at all;
+// the next block's loads are in flight (in registers) while the current block is multiplied.
+// A workgroup of `waves` waves (4 or 8) owns waves / ksplit row tiles; `ksplit` consecutive waves split K of one tile and
+// their partial tiles are summed through LDS in wave order (deterministic).  The launcher picks the geometry so that every
+// CU holds two or more workgroups (4-wave workgroups need 52-68 KB of LDS): ksplit 1-2 for gate|up / lm_head (thousands of
+// tiles), 8 waves x ksplit 8 for q|k|v, o_proj, down_proj (a few hundred tiles).
+// Epilogues as ll_gemv_fused_bf16 (same intermediate bf16 roundings as PyTorch's op-by-op evaluation).
+#include "common.h"
+
+namespace ll {
+
+typedef uint32_t r16_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(8))) __bf16 r16_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float r16_f32x4;
+
+enum { R16_PLAIN = 0, R16_RESIDUAL = 1, R16_SILU_MUL = 2 };
+
+__device__ __forceinline__ float r16_bfr(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+template <int EPI, int SEG>
+__global__ __launch_bounds__(1024) void rows16_kernel(const bf16_t *__restrict__ X, int ldx, const bf16_t *__restrict__ W, int ldw,
+                                                     const float *__restrict__ bias, const bf16_t *__restrict__ res, int ldr,
+                                                     bf16_t *__restrict__ C, int ldc, int M, int N, int K, int ksplit) {
+    constexpr int NT = EPI == R16_SILU_MUL ? 2 : 1;     // weight sub-tiles per wave (gate rows + the matching up rows)
+    // SEG = bytes of a row per block (128 | 256 | 512)
+    constexpr int PITCH = SEG + 16;                     // LDS row pitch: (PITCH / 4) % 64 == 4 -> 16 rows cover the 64 banks once
+    constexpr int RPI = 1024 / SEG;                     // rows per wave instruction
+    constexpr int IPT = 16 / RPI;                       // instructions per 16-row tile
+    constexpr int LPR = SEG / 16;                       // lanes per row segment
+    constexpr int KSTEPS = SEG / 64;                    // MFMA k-steps per block
+    constexpr int WAVE_LDS = (NT + 1) * 16 * PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_r16[];
+    const int tid = threadIdx.x, lane = tid & 63, waves = blockDim.x >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char *wl = sm_r16 + wid * WAVE_LDS;        // [NT*16 weight rows | 16 x rows][PITCH]
+    unsigned char *xl = wl + NT * 16 * PITCH;
+    const int tpw = waves / ksplit;                     // tiles per workgroup
+    const int tile = blockIdx.x * tpw + wid / ksplit, slice = wid % ksplit;
+    const int ntiles = (N + 15) / 16;
+    const bool tile_ok = tile < ntiles;
+    // K range of this wave, in bytes of a row (multiples of 64 B = one MFMA k-step)
+    const int steps = K / 32, per = (steps + ksplit - 1) / ksplit;
+    const int kb = min(slice * per, steps) * 64, ke = min((slice + 1) * per, steps) * 64;
+    const int lrow = lane / LPR, lcol = (lane % LPR) * 16;      // this lane's row within an instruction, byte within the segment
+    const int n0 = tile * 16;
+    r16_f32x4 acc[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) acc[s] = (r16_f32x4)(0.f);
+    r16_u32x4 wr[NT][IPT], xr[IPT];
+    auto load_block = [&](int k0) {
+        const bool kin = k0 + lcol < ke;
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) {
+            const int r = q * RPI + lrow;
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                int row = n0 + r;
+                row = row < N ? row : N - 1;
+                const unsigned char *p = reinterpret_cast<const unsigned char *>(W + ((int64_t)row + (int64_t)s * N) * ldw) + k0 + lcol;
+                wr[s][q] = (kin && tile_ok) ? __builtin_nontemporal_load(reinterpret_cast<const r16_u32x4 *>(p)) : (r16_u32x4)(0);
+            }
+            const unsigned char *px = reinterpret_cast<const unsigned char *>(X + (int64_t)r * ldx) + k0 + lcol;
+            xr[q] = (kin && r < M && tile_ok) ? *reinterpret_cast<const r16_u32x4 *>(px) : (r16_u32x4)(0);
+        }
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    if (kb < ke) load_block(kb);
+    for (int k0 = kb; k0 < ke; k0 += SEG) {
+        // registers -> the wave's LDS image (the previous block's fragment reads have retired: same wave, in order)
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) {
+            const int r = q * RPI + lrow;
+#pragma unroll
+            for (int s = 0; s < NT; ++s) *reinterpret_cast<r16_u32x4 *>(wl + (s * 16 + r) * PITCH + lcol) = wr[s][q];
+            *reinterpret_cast<r16_u32x4 *>(xl + r * PITCH + lcol) = xr[q];
+        }
+        if (k0 + SEG < ke) load_block(k0 + SEG);       // next block in flight while this one is multiplied
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const r16_bf16x8 b = *reinterpret_cast<const r16_bf16x8 *>(xl + fr * PITCH + (ks * 4 + fq) * 16);
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                const r16_bf16x8 a = *reinterpret_cast<const r16_bf16x8 *>(wl + (s * 16 + fr) * PITCH + (ks * 4 + fq) * 16);
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[s], 0, 0, 0);
+            }
+        }
+    }
+    // acc[s][j] = C[weight row n0 + (lane>>4)*4 + j][token row lane & 15]
+    if (ksplit > 1) {
+        __syncthreads();                                // every wave is done with its LDS image
+        float *part = reinterpret_cast<float *>(sm_r16);               // [waves][NT][64 lanes][4]
+#pragma unroll
+        for (int s = 0; s < NT; ++s) *reinterpret_cast<r16_f32x4 *>(part + ((wid * NT + s) * 64 + lane) * 4) = acc[s];
+        __syncthreads();
+        if (slice != 0) return;
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            r16_f32x4 t = acc[s];
+            for (int w = 1; w < ksplit; ++w) t += *reinterpret_cast<const r16_f32x4 *>(part + (((wid + w) * NT + s) * 64 + lane) * 4);
+            acc[s] = t;
+        }
+    }
+    if (!tile_ok) return;
+    const int m = lane & 15, nb = n0 + (lane >> 4) * 4;
+    if (m >= M) return;
+    uint16_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = nb + j;
+        const bool ok = n < N;
+        if (EPI == R16_SILU_MUL) {
+            const float g = r16_bfr(acc[0][j] + ((bias && ok) ? bias[n] : 0.f));
+            const float u = r16_bfr(acc[NT - 1][j] + ((bias && ok) ? bias[n + N] : 0.f));
+            o[j] = f32_to_bf16(r16_bfr(silu(g)) * u);
+        } else {
+            float v = acc[0][j] + ((bias && ok) ? bias[n] : 0.f);
+            if (EPI == R16_RESIDUAL) v = (ok ? bf16_to_f32(res[(int64_t)m * ldr + n]) : 0.f) + r16_bfr(v);
+            o[j] = f32_to_bf16(v);
+        }
+    }
+    bf16_t *dst = C + (int64_t)m * ldc + nb;
+    if (nb + 3 < N && ((reinterpret_cast<uintptr_t>(dst) & 7) == 0)) {
+        *reinterpret_cast<uint2 *>(dst) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (nb + j < N) dst[j] = o[j];
+    }
+}
+
+static int g_rows16_geom = 0;     // 0: by tile count; else seg << 16 | waves << 8 | ksplit (tuning)
+
+template <int EPI, int SEG>
+static int launch_rows16_seg(int waves, int ksplit, hipStream_t s, const bf16_t *X, int ldx, const bf16_t *W, int ldw, const float *bias,
+                             const bf16_t *res, int ldr, bf16_t *C, int ldc, int M, int N, int K) {
+    constexpr int NT = EPI == R16_SILU_MUL ? 2 : 1;
+    const int ntiles = (N + 15) / 16;
+    const size_t lds = (size_t)waves * (NT + 1) * 16 * (SEG + 16);
+    LL_CHECK(lds <= 160 * 1024, "ll_linear_rows16_bf16: %d waves x %d-byte segments need %zu bytes of LDS", waves, SEG, lds);
+    static size_t attr_lds = 0;       // > 64 KB of dynamic LDS needs the attribute
+    if (lds > attr_lds) {
+        LL_HIP(hipFuncSetAttribute((const void *)rows16_kernel<EPI, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    const int tpw = waves / ksplit;
+    hipLaunchKernelGGL((rows16_kernel<EPI, SEG>), dim3((ntiles + tpw - 1) / tpw), dim3(waves * 64), lds, s, X, ldx, W, ldw, bias, res, ldr, C,
+                       ldc, M, N, K, ksplit);
+    return LL_OK;
+}
+
+template <int EPI>
+static int launch_rows16(hipStream_t s, const bf16_t *X, int ldx, const bf16_t *W, int ldw, const float *bias, const bf16_t *res, int ldr,
+                         bf16_t *C, int ldc, int M, int N, int K) {
+    const int ntiles = (N + 15) / 16;
+    int seg, waves, ksplit;
+    if (g_rows16_geom) {
+        seg = g_rows16_geom >> 16, waves = (g_rows16_geom >> 8) & 255, ksplit = g_rows16_geom & 255;
+    } else {
+        // enough waves to hide the load -> LDS -> MFMA latency chain of each one: split K until tiles x ksplit >= ~14 per CU
+        // (tools/rows16_sweep.py: gate|up 4 waves x ksplit 4, q|k|v / o_proj / down_proj 8 x 8, lm_head 4 x 1)
+        seg = EPI == R16_SILU_MUL ? 256 : 512;
+        ksplit = 1;
+        while (ksplit < 8 && ntiles * ksplit < 3500) ksplit *= 2;
+        waves = ksplit <= 4 ? 4 : 8;
+    }
+    if (seg == 128) return launch_rows16_seg<EPI, 128>(waves, ksplit, s, X, ldx, W, ldw, bias, res, ldr, C, ldc, M, N, K);
+    if (seg == 256) return launch_rows16_seg<EPI, 256>(waves, ksplit, s, X, ldx, W, ldw, bias, res, ldr, C, ldc, M, N, K);
+    return launch_rows16_seg<EPI, 512>(waves, ksplit, s, X, ldx, W, ldw, bias, res, ldr, C, ldc, M, N, K);
+}
+
+static int linear_rows16(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *residual, int ldr, void *out,
+                         int ldc, int M, int N, int K, int epi, hipStream_t s) {
+    LL_CHECK(x && W && out, "ll_linear_rows16_bf16: null argument");
+    LL_CHECK(M >= 1 && M <= 16, "ll_linear_rows16_bf16: M=%d rows (1..16)", M);
+    LL_CHECK(N >= 1 && K >= 32 && K % 32 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "ll_linear_rows16_bf16: K must be a multiple of 32, ldx / ldw of 8");
+    LL_CHECK(epi >= R16_PLAIN && epi <= R16_SILU_MUL, "ll_linear_rows16_bf16: epilogue %d", epi);
+    LL_CHECK(epi != R16_RESIDUAL || residual, "ll_linear_rows16_bf16: residual epilogue without a residual");
+    LL_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0, "ll_linear_rows16_bf16: operands must be 16-byte aligned");
+    const bf16_t *X = (const bf16_t *)x, *Wt = (const bf16_t *)W, *rs = (const bf16_t *)residual;
+    bf16_t *C = (bf16_t *)out;
+    if (epi == R16_PLAIN) LL_TRY(launch_rows16<R16_PLAIN>(s, X, ldx, Wt, ldw, bias, rs, ldr, C, ldc, M, N, K));
+    else if (epi == R16_RESIDUAL) LL_TRY(launch_rows16<R16_RESIDUAL>(s, X, ldx, Wt, ldw, bias, rs, ldr, C, ldc, M, N, K));
+    else LL_TRY(launch_rows16<R16_SILU_MUL>(s, X, ldx, Wt, ldw, bias, rs, ldr, C, ldc, M, N, K));
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+}  // namespace ll
+
+using namespace ll;
+
+extern "C" {
+
+int ll_linear_rows16_bf16(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *residual, int ldr, void *out,
+                          int ldc, int M, int N, int K, int epi, void *stream) {
+    return linear_rows16(x, ldx, W, ldw, bias, residual, ldr, out, ldc, M, N, K, epi, (hipStream_t)stream);
+}
+
+int ll_set_rows16_geometry(int seg, int waves, int ksplit) {
+    const int old = g_rows16_geom;
+    const bool ok = (seg == 128 || seg == 256 || seg == 512) && (waves == 4 || waves == 8 || waves == 16) && ksplit >= 1 && ksplit <= waves &&
+                    waves % ksplit == 0;
+    g_rows16_geom = ok ? (seg << 16 | waves << 8 | ksplit) : 0;
+    return old;
+}
+
+// Times ll_linear_rows16_bf16 on synthetic operands over `nweights` distinct weight matrices (defeats the Infinity Cache).
+int ll_rows16_bench(int M, int N, int K, int epi, int iters, int nweights, float *ms) {
+    LL_CHECK(ms && iters > 0 && nweights > 0 && M >= 1 && M <= 16, "bad argument");
+    const int rowsW = epi == R16_SILU_MUL ? 2 * N : N;
+    bf16_t *X = nullptr, *W = nullptr, *C = nullptr, *R = nullptr;
+    LL_HIP(hipMalloc(&X, (size_t)16 * K * 2));
+    LL_HIP(hipMalloc(&W, (size_t)nweights * rowsW * K * 2));
+    LL_HIP(hipMalloc(&C, (size_t)16 * N * 2));
+    LL_HIP(hipMalloc(&R, (size_t)16 * N * 2));
+    LL_HIP(hipMemset(X, 0x11, (size_t)16 * K * 2));
+    LL_HIP(hipMemset(R, 0x11, (size_t)16 * N * 2));
+    LL_HIP(hipMemset(W, 0x11, (size_t)nweights * rowsW * K * 2));
+    hipStream_t st;
+    LL_HIP(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    LL_HIP(hipEventCreate(&e0));
+    LL_HIP(hipEventCreate(&e1));
+    int rc = LL_OK;
+    for (int pass = 0; pass < 2 && rc == LL_OK; ++pass) {
+        if (pass == 1) (void)hipEventRecord(e0, st);
+        for (int i = 0; i < (pass ? iters : nweights) && rc == LL_OK; ++i)
+            rc = linear_rows16(X, K, W + (size_t)(i % nweights) * rowsW * K, K, nullptr, R, N, C, N, M, N, K, epi, st);
+    }
+    (void)hipEventRecord(e1, st);
+    hipError_t he = hipEventSynchronize(e1);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    *ms = t / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(st);
+    (void)hipFree(X);
+    (void)hipFree(W);
+    (void)hipFree(C);
+    (void)hipFree(R);
+    if (rc != LL_OK) return rc;
+    LL_HIP(he);
+    return LL_OK;
+}
+
+}  // extern "C"

@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from . import _lib
 
 MAX_ROWS = 128           # GEMV / skinny-GEMM path under nn.Linear (128-token prefill: 8.7 ms vs 10.0 ms on hipBLASLt, tools/prefill_probe.py)
+MAX_STREAM_ROWS = 16    # ll_linear_rows16_bf16: one MFMA column block of token rows (batched decode: 5..16 sequences)
 MAX_APPEND_ROWS = 16     # new positions per call served by the fused KV append / decode attention (decode, query tail)
 MAX_EW_ROWS = 16384      # row-parallel elementwise kernels (RMSNorm, rotary, SiLU*mul) also serve prefill-sized calls
 
@@ -30,6 +31,19 @@ def _hip_linear_forward(self: nn.Linear, x: torch.Tensor) -> torch.Tensor:
             x2 = x2.contiguous()
         M, N = x2.shape[0], self.out_features
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+        if 4 < M <= MAX_STREAM_ROWS and K % 32 == 0:
+            # 5..16 token rows (batched decode): the weight-streaming MFMA Linear, every wave streaming its own 16 weight rows
+            bias = None
+            if self.bias is not None:
+                bias = getattr(self, "_ll_bias_f32", None)
+                if bias is None or bias.device != x.device:
+                    bias = self.bias.detach().float().contiguous()
+                    self._ll_bias_f32 = bias
+            rc = self._ll_lib.ll_linear_rows16_bf16(x2.data_ptr(), K, self.weight.data_ptr(), K, bias.data_ptr() if bias is not None else None,
+                                                    None, 0, out.data_ptr(), N, M, N, K, 0, torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                _lib.check(rc, "ll_linear_rows16_bf16")
+            return out.reshape(*x.shape[:-1], N)
         if 4 < M <= 32 and K >= 8192 and N <= 8192 and self.bias is None and K % 256 == 0:
             # a few rows x a short, wide matrix (down_proj at batch 8-16): split K so that >= 256 workgroups stream it
             splits = 4 if K % 512 == 0 and (N + 31) // 32 * 2 < 256 else 2
@@ -372,9 +386,12 @@ def fuse_cache_update(cache) -> int:
 class _FusedLayer:
     """Decode-step state of one HF decoder layer (Qwen2 / Llama / Mistral layout): concatenated q|k|v and gate|up weights
     (shared with fuse_qkv / the MLP fusion when those ran first), f32 biases, norm weights.  ``run`` is
-    Qwen2DecoderLayer.forward (transformers modeling_qwen2.py) for ONE new token per sequence, batch <= 4:
+    Qwen2DecoderLayer.forward (transformers modeling_qwen2.py) for ONE new token per sequence:
       qkv  = gemv(rmsnorm(h), Wqkv) ; a = rope+append+attention(qkv) ; h = h + gemv(a, Wo)
-      act  = silu(gate)*up of gemv(rmsnorm(h), Wgate|up) ; h = h + gemv(act, Wdown)"""
+      act  = silu(gate)*up of gemv(rmsnorm(h), Wgate|up) ; h = h + gemv(act, Wdown)
+    batch <= 4: five launches (FMA GEMVs with the RMSNorm as their prologue, ll_gemv_fused_bf16); batch 5..16: seven (the two
+    RMSNorms are their own launch, the projections are the weight-streaming MFMA Linear ll_linear_rows16_bf16 with the same
+    residual / SiLU*mul epilogues)."""
 
     def __init__(self, lib, layer):
         att, mlp = layer.self_attn, layer.mlp
@@ -399,9 +416,11 @@ class _FusedLayer:
         self.wdown = mlp.down_proj.weight.detach()
         self.n1, self.n2 = layer.input_layernorm, layer.post_attention_layernorm
         self.eps1, self.eps2 = float(self.n1.variance_epsilon), float(self.n2.variance_epsilon)
+        self.stream_ok = self.H % 32 == 0 and self.nq % 32 == 0 and self.I % 32 == 0 and self.n1.weight.dtype == torch.bfloat16
 
     def eligible(self, h, mask, cache, pe) -> bool:
-        if not (h.is_cuda and h.dtype == torch.bfloat16 and h.dim() == 3 and h.shape[1] == 1 and h.shape[0] <= 4
+        if not (h.is_cuda and h.dtype == torch.bfloat16 and h.dim() == 3 and h.shape[1] == 1
+                and (h.shape[0] <= 4 or (h.shape[0] <= MAX_STREAM_ROWS and self.stream_ok))
                 and not torch.is_grad_enabled() and cache is not None and pe is not None and mask is not None):
             return False
         layers = getattr(cache, "layers", None)
@@ -420,6 +439,20 @@ class _FusedLayer:
     def _gemv(self, x, w, bias, norm_w, eps, res, N, K, epi):
         M = x.shape[0]
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+        if M > 4:
+            st = torch.cuda.current_stream().cuda_stream
+            if norm_w is not None:
+                xn = torch.empty_like(x)
+                rc = self.lib.ll_rmsnorm_bf16(x.data_ptr(), norm_w.data_ptr(), xn.data_ptr(), M, K, eps, st)
+                if rc != 0:
+                    _lib.check(rc, "ll_rmsnorm_bf16")
+                x = xn
+            rc = self.lib.ll_linear_rows16_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
+                                                res.data_ptr() if res is not None else None, res.stride(0) if res is not None else 0,
+                                                out.data_ptr(), N, M, N, K, epi, st)
+            if rc != 0:
+                _lib.check(rc, "ll_linear_rows16_bf16")
+            return out
         rc = self.lib.ll_gemv_fused_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
                                          norm_w.data_ptr() if norm_w is not None else None, eps,
                                          res.data_ptr() if res is not None else None, res.stride(0) if res is not None else 0,
@@ -460,9 +493,9 @@ def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, 
 
 
 def fuse_decoder_layers(model: nn.Module) -> int:
-    """Run every decoder layer of a Qwen2 / Llama / Mistral-layout HF model as five launches at decode (batch <= 4, static
-    cache with the fused append of ``fuse_cache_update``, boolean sdpa-style mask).  Any other call -- prefill, larger
-    batches, a dynamic cache -- takes the layer's previous forward.  Returns the number of patched layers."""
+    """Run every decoder layer of a Qwen2 / Llama / Mistral-layout HF model as five launches at decode (batch <= 4; seven for
+    batch 5..16), static cache with the fused append of ``fuse_cache_update``, boolean sdpa-style mask.  Any other call --
+    prefill, larger batches, a dynamic cache -- takes the layer's previous forward.  Returns the number of patched layers."""
     lib = _lib.load()
     base = getattr(model, "model", model)
     layers = getattr(base, "layers", None)
@@ -509,7 +542,7 @@ def _model_forward(self, input_ids=None, attention_mask=None, position_ids=None,
     st = self._ll_decode
     layers = self.layers[: self.config.num_hidden_layers]
     if (input_ids is not None and inputs_embeds is None and input_ids.dim() == 2 and input_ids.shape[1] == 1
-            and input_ids.shape[0] <= 4 and input_ids.is_cuda and not torch.is_grad_enabled() and past_key_values is not None
+            and input_ids.shape[0] <= MAX_STREAM_ROWS and input_ids.is_cuda and not torch.is_grad_enabled() and past_key_values is not None
             and attention_mask is not None and attention_mask.dim() == 2 and attention_mask.dtype == torch.long
             and attention_mask.stride(1) == 1 and position_ids is not None and position_ids.shape == input_ids.shape
             and position_ids.dtype == torch.long and not kwargs.get("output_hidden_states") and not kwargs.get("output_attentions")

@@ -262,6 +262,95 @@ def test_gemv_fused_epilogues_vs_torch(M):
     assert lib.ll_gemv_fused_bf16(x.data_ptr(), K, w.data_ptr(), K, None, None, eps, None, 0, res.data_ptr(), N, M, N, K, 1, s) == -1   # LL_EINVAL
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [5, 8, 13, 16])
+def test_linear_rows16_epilogues_vs_torch(M):
+    """ll_linear_rows16_bf16 (weight-streaming MFMA Linear for 5..16 token rows) through the C ABI against op-by-op PyTorch with
+    the same bf16 roundings, every workgroup geometry the tuner may pick; N not a multiple of the 16-row tile, K not a multiple
+    of a block; and its error behaviour."""
+    import torch.nn.functional as F
+    from llamole_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M)
+    s = torch.cuda.current_stream().cuda_stream
+    for K, N in ((4640, 1003), (96, 24), (18944, 520)):
+        x = torch.randn(M, K, generator=g).bfloat16().cuda()
+        w = (torch.randn(2 * N, K, generator=g) * 0.02).bfloat16().cuda()
+        bias = torch.randn(2 * N, generator=g).float().cuda()
+        res = torch.randn(M, N, generator=g).bfloat16().cuda()
+        for geom in ((0, 0, 0), (256, 4, 1), (256, 4, 4), (512, 8, 8), (128, 8, 2)):
+            if geom[0] == 512:
+                geoms = [(0, geom), (1, geom)]          # 512-byte segments: single-tile epilogues only (LDS)
+            else:
+                geoms = [(0, geom), (1, geom), (2, geom)]
+            for use_bias in (False, True):
+                b = bias if use_bias else torch.zeros_like(bias)
+                full = (x.float() @ w.float().t() + b).to(torch.bfloat16)
+                want = {0: full[:, :N], 1: res + full[:, :N], 2: F.silu(full[:, :N]) * full[:, N:]}
+                for epi, gm in geoms:
+                    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+                    lib.ll_set_rows16_geometry(*gm)
+                    try:
+                        _lib.check(lib.ll_linear_rows16_bf16(x.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if use_bias else None,
+                                                             res.data_ptr() if epi == 1 else None, N, out.data_ptr(), N, M, N, K, epi, s),
+                                   "ll_linear_rows16_bf16")
+                    finally:
+                        lib.ll_set_rows16_geometry(0, 0, 0)
+                    torch.testing.assert_close(out.float(), want[epi].float(), rtol=3e-2, atol=3e-2)
+    assert lib.ll_linear_rows16_bf16(x.data_ptr(), K, w.data_ptr(), K, None, None, 0, res.data_ptr(), N, 17, N, K, 0, s) == -1     # LL_EINVAL
+    assert lib.ll_linear_rows16_bf16(x.data_ptr(), K, w.data_ptr(), K, None, None, 0, res.data_ptr(), N, M, N, K - 8, 0, s) == -1  # K % 32
+    assert lib.ll_linear_rows16_bf16(x.data_ptr(), K, w.data_ptr(), K, None, None, 0, res.data_ptr(), N, M, N, K, 1, s) == -1      # no residual
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [6, 16])
+def test_fused_decoder_layers_batched_rows(rows):
+    """Batched decode (5..16 sequences): the seven-launch layer on ll_linear_rows16_bf16 against the one-launch-per-op path.
+    MFMA accumulation order differs from the ring GEMM's, so logits agree to bf16 rounding rather than bit for bit; the
+    captured graph replays the eager result exactly."""
+    from llamole_amd.llm_accel import (accelerate_elementwise, accelerate_linears, fuse_decoder_layers, fuse_model_decode,
+                                       restore_decoder_layers, restore_elementwise, restore_linears, restore_model_decode,
+                                       use_decode_attention)
+    llm = e2e.build_llm("tiny", "cuda", torch.bfloat16)
+    g = torch.Generator().manual_seed(rows)
+    prompt = torch.randint(5, 1000, (rows, 12), generator=g).cuda()
+    mask = torch.ones_like(prompt)
+    mask[1, :4] = 0
+    mask[rows - 1, :7] = 0
+    kw = dict(max_new_tokens=2, do_sample=False, pad_token_id=0, eos_token_id=[2047])
+    assert accelerate_linears(llm, min_weight_elems=1) > 0
+    accelerate_elementwise(llm)
+    assert use_decode_attention(llm)
+    try:
+        base = GraphedDecoder(llm, use_graph=False, fused_cache=True)
+        base.generate(prompt, mask, **kw)                       # prefill + ONE decode step: same inputs for both paths
+        ref_logits = base.last_logits.float().clone()
+        ref_kv = [(l.keys.clone(), l.values.clone()) for l in base.cache.layers]
+        assert fuse_decoder_layers(llm) == llm.config.num_hidden_layers and fuse_model_decode(llm)
+        calls = []
+        orig_run = llm.model.layers[0]._ll_fused.run
+        llm.model.layers[0]._ll_fused.run = lambda *a, **k: (calls.append(1), orig_run(*a, **k))[1]
+        dec = GraphedDecoder(llm, use_graph=False, fused_cache=True)
+        dec.generate(prompt, mask, **kw)
+        assert len(calls) == 1                                   # the batched rows went through the fused layer
+        scale = ref_logits.abs().max().item()
+        assert (dec.last_logits.float() - ref_logits).abs().max().item() <= 0.03 * scale
+        P = prompt.shape[1]
+        for (k, v), l in zip(ref_kv, dec.cache.layers):          # the appended position of every layer
+            torch.testing.assert_close(l.keys[:, :, P].float(), k[:, :, P].float(), rtol=5e-2, atol=5e-2)
+            torch.testing.assert_close(l.values[:, :, P].float(), v[:, :, P].float(), rtol=5e-2, atol=5e-2)
+        kw8 = dict(kw, max_new_tokens=8)
+        eager = GraphedDecoder(llm, use_graph=False, fused_cache=True)
+        toks = eager.generate(prompt, mask, **kw8)
+        gr = GraphedDecoder(llm, use_graph=True, fused_cache=True)
+        assert torch.equal(gr.generate(prompt, mask, **kw8), toks) and torch.equal(gr.last_logits, eager.last_logits)
+    finally:
+        restore_model_decode(llm)
+        restore_decoder_layers(llm)
+        restore_elementwise(llm)
+        restore_linears(llm)
+
+
 def _orchestrator(llm, device, dtype):
     import types
     gd = types.SimpleNamespace(text_input_size=768, max_n_nodes=8)
