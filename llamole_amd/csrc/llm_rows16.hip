@@ -29,7 +29,7 @@ __device__ __forceinline__ float r16_bfr(float v) { return bf16_to_f32(f32_to_bf
 template <int EPI, int SEG>
 __global__ __launch_bounds__(1024) void rows16_kernel(const bf16_t *__restrict__ X, int ldx, const bf16_t *__restrict__ W, int ldw,
                                                      const float *__restrict__ bias, const bf16_t *__restrict__ res, int ldr,
-                                                     bf16_t *__restrict__ C, int ldc, int M, int N, int K, int ksplit) {
+                                                     void *__restrict__ Cv, int ldc, int M, int N, int K, int ksplit, int out_f32) {
     constexpr int NT = EPI == R16_SILU_MUL ? 2 : 1;     // weight sub-tiles per wave (gate rows + the matching up rows)
     // SEG = bytes of a row per block (128 | 256 | 512)
     constexpr int PITCH = SEG + 16;                     // LDS row pitch: (PITCH / 4) % 64 == 4 -> 16 rows cover the 64 banks once
@@ -112,6 +112,21 @@ __global__ __launch_bounds__(1024) void rows16_kernel(const bf16_t *__restrict__
     if (!tile_ok) return;
     const int m = lane & 15, nb = n0 + (lane >> 4) * 4;
     if (m >= M) return;
+    if (EPI == R16_PLAIN && out_f32) {      // f32 logits (GIN template head): acc + bias, no rounding
+        float *dst = reinterpret_cast<float *>(Cv) + (int64_t)m * ldc + nb;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[0][j] + ((bias && nb + j < N) ? bias[nb + j] : 0.f);
+        if (nb + 3 < N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (nb + j < N) dst[j] = v[j];
+        }
+        return;
+    }
+    bf16_t *C = reinterpret_cast<bf16_t *>(Cv);
     uint16_t o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -141,7 +156,7 @@ static int g_rows16_geom = 0;     // 0: by tile count; else seg << 16 | waves <<
 
 template <int EPI, int SEG>
 static int launch_rows16_seg(int waves, int ksplit, hipStream_t s, const bf16_t *X, int ldx, const bf16_t *W, int ldw, const float *bias,
-                             const bf16_t *res, int ldr, bf16_t *C, int ldc, int M, int N, int K) {
+                             const bf16_t *res, int ldr, void *C, int ldc, int M, int N, int K, int out_f32) {
     constexpr int NT = EPI == R16_SILU_MUL ? 2 : 1;
     const int ntiles = (N + 15) / 16;
     const size_t lds = (size_t)waves * (NT + 1) * 16 * (SEG + 16);
@@ -153,13 +168,13 @@ static int launch_rows16_seg(int waves, int ksplit, hipStream_t s, const bf16_t 
     }
     const int tpw = waves / ksplit;
     hipLaunchKernelGGL((rows16_kernel<EPI, SEG>), dim3((ntiles + tpw - 1) / tpw), dim3(waves * 64), lds, s, X, ldx, W, ldw, bias, res, ldr, C,
-                       ldc, M, N, K, ksplit);
+                       ldc, M, N, K, ksplit, out_f32);
     return LL_OK;
 }
 
 template <int EPI>
 static int launch_rows16(hipStream_t s, const bf16_t *X, int ldx, const bf16_t *W, int ldw, const float *bias, const bf16_t *res, int ldr,
-                         bf16_t *C, int ldc, int M, int N, int K) {
+                         void *C, int ldc, int M, int N, int K, int out_f32) {
     const int ntiles = (N + 15) / 16;
     int seg, waves, ksplit;
     if (g_rows16_geom) {
@@ -171,14 +186,15 @@ static int launch_rows16(hipStream_t s, const bf16_t *X, int ldx, const bf16_t *
         ksplit = 1;
         while (ksplit < 8 && ntiles * ksplit < 3500) ksplit *= 2;
         waves = ksplit <= 4 ? 4 : 8;
+        if (ksplit == 8 && ntiles * 4 >= 1100) seg = 256, waves = 4, ksplit = 4;      // q|k|v (288 tiles): 11.1 us vs 12.5
     }
-    if (seg == 128) return launch_rows16_seg<EPI, 128>(waves, ksplit, s, X, ldx, W, ldw, bias, res, ldr, C, ldc, M, N, K);
-    if (seg == 256) return launch_rows16_seg<EPI, 256>(waves, ksplit, s, X, ldx, W, ldw, bias, res, ldr, C, ldc, M, N, K);
-    return launch_rows16_seg<EPI, 512>(waves, ksplit, s, X, ldx, W, ldw, bias, res, ldr, C, ldc, M, N, K);
+    if (seg == 128) return launch_rows16_seg<EPI, 128>(waves, ksplit, s, X, ldx, W, ldw, bias, res, ldr, C, ldc, M, N, K, out_f32);
+    if (seg == 256) return launch_rows16_seg<EPI, 256>(waves, ksplit, s, X, ldx, W, ldw, bias, res, ldr, C, ldc, M, N, K, out_f32);
+    return launch_rows16_seg<EPI, 512>(waves, ksplit, s, X, ldx, W, ldw, bias, res, ldr, C, ldc, M, N, K, out_f32);
 }
 
-static int linear_rows16(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *residual, int ldr, void *out,
-                         int ldc, int M, int N, int K, int epi, hipStream_t s) {
+int linear_rows16_launch(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *residual, int ldr, void *out,
+                         int ldc, int M, int N, int K, int epi, int out_f32, hipStream_t s) {
     LL_CHECK(x && W && out, "ll_linear_rows16_bf16: null argument");
     LL_CHECK(M >= 1 && M <= 16, "ll_linear_rows16_bf16: M=%d rows (1..16)", M);
     LL_CHECK(N >= 1 && K >= 32 && K % 32 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "ll_linear_rows16_bf16: K must be a multiple of 32, ldx / ldw of 8");
@@ -186,10 +202,10 @@ static int linear_rows16(const void *x, int ldx, const void *W, int ldw, const f
     LL_CHECK(epi != R16_RESIDUAL || residual, "ll_linear_rows16_bf16: residual epilogue without a residual");
     LL_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0, "ll_linear_rows16_bf16: operands must be 16-byte aligned");
     const bf16_t *X = (const bf16_t *)x, *Wt = (const bf16_t *)W, *rs = (const bf16_t *)residual;
-    bf16_t *C = (bf16_t *)out;
-    if (epi == R16_PLAIN) LL_TRY(launch_rows16<R16_PLAIN>(s, X, ldx, Wt, ldw, bias, rs, ldr, C, ldc, M, N, K));
-    else if (epi == R16_RESIDUAL) LL_TRY(launch_rows16<R16_RESIDUAL>(s, X, ldx, Wt, ldw, bias, rs, ldr, C, ldc, M, N, K));
-    else LL_TRY(launch_rows16<R16_SILU_MUL>(s, X, ldx, Wt, ldw, bias, rs, ldr, C, ldc, M, N, K));
+    LL_CHECK(!out_f32 || epi == R16_PLAIN, "ll_linear_rows16_bf16: f32 output only with the plain epilogue");
+    if (epi == R16_PLAIN) LL_TRY(launch_rows16<R16_PLAIN>(s, X, ldx, Wt, ldw, bias, rs, ldr, out, ldc, M, N, K, out_f32));
+    else if (epi == R16_RESIDUAL) LL_TRY(launch_rows16<R16_RESIDUAL>(s, X, ldx, Wt, ldw, bias, rs, ldr, out, ldc, M, N, K, 0));
+    else LL_TRY(launch_rows16<R16_SILU_MUL>(s, X, ldx, Wt, ldw, bias, rs, ldr, out, ldc, M, N, K, 0));
     LL_LAUNCH_CHECK();
     return LL_OK;
 }
@@ -202,7 +218,7 @@ extern "C" {
 
 int ll_linear_rows16_bf16(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *residual, int ldr, void *out,
                           int ldc, int M, int N, int K, int epi, void *stream) {
-    return linear_rows16(x, ldx, W, ldw, bias, residual, ldr, out, ldc, M, N, K, epi, (hipStream_t)stream);
+    return linear_rows16_launch(x, ldx, W, ldw, bias, residual, ldr, out, ldc, M, N, K, epi, 0, (hipStream_t)stream);
 }
 
 int ll_set_rows16_geometry(int seg, int waves, int ksplit) {
@@ -234,7 +250,7 @@ int ll_rows16_bench(int M, int N, int K, int epi, int iters, int nweights, float
     for (int pass = 0; pass < 2 && rc == LL_OK; ++pass) {
         if (pass == 1) (void)hipEventRecord(e0, st);
         for (int i = 0; i < (pass ? iters : nweights) && rc == LL_OK; ++i)
-            rc = linear_rows16(X, K, W + (size_t)(i % nweights) * rowsW * K, K, nullptr, R, N, C, N, M, N, K, epi, st);
+            rc = linear_rows16_launch(X, K, W + (size_t)(i % nweights) * rowsW * K, K, nullptr, R, N, C, N, M, N, K, epi, 0, st);
     }
     (void)hipEventRecord(e1, st);
     hipError_t he = hipEventSynchronize(e1);

@@ -17,7 +17,9 @@ import torch.nn.functional as F
 from . import _lib
 
 MAX_ROWS = 128           # GEMV / skinny-GEMM path under nn.Linear (128-token prefill: 8.7 ms vs 10.0 ms on hipBLASLt, tools/prefill_probe.py)
-MAX_STREAM_ROWS = 16    # ll_linear_rows16_bf16: one MFMA column block of token rows (batched decode: 5..16 sequences)
+MAX_STREAM_ROWS = 16    # ll_linear_rows16_bf16: one MFMA column block of token rows (batched decode: 3..16 sequences)
+FMA_GEMV_ROWS = 2       # up to here the f32-FMA GEMVs win (RMSNorm prologue fused, 5 launches per layer); from 3 rows on the MFMA
+                        # stream does (tools/batch_sweep.sh: batch 4 = 603 ms per step on the FMA path, 508 ms at batch 8 on MFMA)
 MAX_APPEND_ROWS = 16     # new positions per call served by the fused KV append / decode attention (decode, query tail)
 MAX_EW_ROWS = 16384      # row-parallel elementwise kernels (RMSNorm, rotary, SiLU*mul) also serve prefill-sized calls
 
@@ -31,8 +33,8 @@ def _hip_linear_forward(self: nn.Linear, x: torch.Tensor) -> torch.Tensor:
             x2 = x2.contiguous()
         M, N = x2.shape[0], self.out_features
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
-        if 4 < M <= MAX_STREAM_ROWS and K % 32 == 0:
-            # 5..16 token rows (batched decode): the weight-streaming MFMA Linear, every wave streaming its own 16 weight rows
+        if FMA_GEMV_ROWS < M <= MAX_STREAM_ROWS and K % 32 == 0:
+            # 3..16 token rows (batched decode): the weight-streaming MFMA Linear, every wave streaming its own 16 weight rows
             bias = None
             if self.bias is not None:
                 bias = getattr(self, "_ll_bias_f32", None)
@@ -389,7 +391,8 @@ class _FusedLayer:
     Qwen2DecoderLayer.forward (transformers modeling_qwen2.py) for ONE new token per sequence:
       qkv  = gemv(rmsnorm(h), Wqkv) ; a = rope+append+attention(qkv) ; h = h + gemv(a, Wo)
       act  = silu(gate)*up of gemv(rmsnorm(h), Wgate|up) ; h = h + gemv(act, Wdown)
-    batch <= 4: five launches (FMA GEMVs with the RMSNorm as their prologue, ll_gemv_fused_bf16); batch 5..16: seven (the two
+    batch <= 2 (<= 4 when the sizes are not multiples of 32): five launches (FMA GEMVs with the RMSNorm as their prologue,
+    ll_gemv_fused_bf16); batch 3..16: seven (the two
     RMSNorms are their own launch, the projections are the weight-streaming MFMA Linear ll_linear_rows16_bf16 with the same
     residual / SiLU*mul epilogues)."""
 
@@ -439,7 +442,7 @@ class _FusedLayer:
     def _gemv(self, x, w, bias, norm_w, eps, res, N, K, epi):
         M = x.shape[0]
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
-        if M > 4:
+        if M > FMA_GEMV_ROWS and self.stream_ok:
             st = torch.cuda.current_stream().cuda_stream
             if norm_w is not None:
                 xn = torch.empty_like(x)
