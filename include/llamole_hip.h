@@ -242,16 +242,17 @@ int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iter
 /* ll_linear_rows16_bf16 : out[M,N] = epilogue(x[M,K] . W^T + bias), M in 1..16, K % 32 == 0, bf16 operands, f32 accumulation on MFMA:
  *     the nn.Linear of a batched decode step (5..16 sequences: lock-step A* searches, several prompts per GPU) as a weight
  *     stream -- every wave streams its own 16 weight rows in line-contiguous segments through a private LDS image, no barrier in
- *     the main loop.  Epilogues LL_GEMV_PLAIN / LL_GEMV_RESIDUAL / LL_GEMV_SILU_MUL as ll_gemv_fused_bf16 (W has 2N rows for
- *     SILU_MUL); replaces nn.Linear.forward (+ the residual add / act_fn(gate)*up of Qwen2DecoderLayer / Qwen2MLP.forward,
+ *     the main loop.  Arguments as ll_gemv_fused_bf16: norm_w != NULL = RMSNorm prologue (x is multiplied by the norm weight while it
+ *     is staged and rsqrt(mean(x^2) + eps) of the row scales the accumulator: Qwen2RMSNorm + nn.Linear up to the place of one bf16
+ *     rounding); epilogues LL_GEMV_PLAIN / LL_GEMV_RESIDUAL / LL_GEMV_SILU_MUL (W has 2N rows for SILU_MUL); replaces nn.Linear.forward (+ the residual add / act_fn(gate)*up of Qwen2DecoderLayer / Qwen2MLP.forward,
  *     transformers modeling_qwen2.py) under the reference's language_model.generate (modeling_llamole.py:599, :849).
- * ll_set_rows16_geometry : tuning -- bytes of a row per block (128 | 256 | 512), waves per workgroup (4 | 8 | 16) and how many
+ * ll_set_rows16_geometry : tuning -- bytes of a row per block (128 | 256 | 512), waves per workgroup (4 | 8) and how many
  *     consecutive waves split K of one tile; (0, 0, 0) = chosen by tile count.
  * ll_rows16_bench : timing utility (HIP events, `nweights` distinct weight matrices). */
-int ll_linear_rows16_bf16(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *residual, int ldr, void *out,
-                          int ldc, int M, int N, int K, int epi, void *stream);
+int ll_linear_rows16_bf16(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *norm_w, float eps,
+                          const void *residual, int ldr, void *out, int ldc, int M, int N, int K, int epi, void *stream);
 int ll_set_rows16_geometry(int seg, int waves, int ksplit);
-int ll_rows16_bench(int M, int N, int K, int epi, int iters, int nweights, float *ms);
+int ll_rows16_bench(int M, int N, int K, int epi, int norm, int iters, int nweights, float *ms);
 int ll_set_gemv_nt(int on);
 
 /* ll_sample_token_bf16 : one decode-loop sampling step per row in ONE launch -- HF TemperatureLogitsWarper + TopPLogitsWarper

@@ -645,7 +645,7 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
         // template head [G, 4H] x [out_dim, 4H]^T (740 MB of bf16 weights at out_dim = 180 576): 3..16 graphs stream it through the
         // 16-row MFMA Linear (line-contiguous loads, wave-private LDS transpose), anything else through the GEMM dispatch
         if (dt == LL_BF16 && G >= 3 && G <= 16 && (4 * H) % 32 == 0)
-            LL_TRY(linear_rows16_launch(e->head1a.p, 4 * H, e->pw("decoder.4.weight"), 4 * H, e->pf("decoder.4.bias"), nullptr, 0, out, cf.out_dim, G,
+            LL_TRY(linear_rows16_launch(e->head1a.p, 4 * H, e->pw("decoder.4.weight"), 4 * H, e->pf("decoder.4.bias"), nullptr, 0.f, nullptr, 0, out, cf.out_dim, G,
                                         cf.out_dim, 4 * H, 0, 1, st));
         else
             LL_TRY(linear_launch(dt, e->head1a.p, 4 * H, e->pw("decoder.4.weight"), 4 * H, e->pf("decoder.4.bias"), out, cf.out_dim, G, cf.out_dim, 4 * H, 0, 1, st));

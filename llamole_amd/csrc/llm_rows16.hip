@@ -13,7 +13,10 @@
 // their partial tiles are summed through LDS in wave order (deterministic).  The launcher picks the geometry so that every
 // CU holds two or more workgroups (4-wave workgroups need 52-68 KB of LDS): ksplit 1-2 for gate|up / lm_head (thousands of
 // tiles), 8 waves x ksplit 8 for q|k|v, o_proj, down_proj (a few hundred tiles).
-// Epilogues as ll_gemv_fused_bf16 (same intermediate bf16 roundings as PyTorch's op-by-op evaluation).
+// Epilogues as ll_gemv_fused_bf16 (same intermediate bf16 roundings as PyTorch's op-by-op evaluation).  RMSNorm prologue
+// (norm_w != NULL): x is multiplied by the norm weight while it is staged, x' = bf16(x * w), the waves accumulate sum(x^2)
+// of their K slice on the side, and rsqrt(mean(x^2) + eps) of the token row scales the accumulator in the epilogue -- the
+// same quantity as Qwen2RMSNorm + nn.Linear up to the place of one bf16 rounding (bf16(x * rstd) is not formed).
 #include "common.h"
 
 namespace ll {
@@ -26,10 +29,11 @@ enum { R16_PLAIN = 0, R16_RESIDUAL = 1, R16_SILU_MUL = 2 };
 
 __device__ __forceinline__ float r16_bfr(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 
-template <int EPI, int SEG>
-__global__ __launch_bounds__(1024) void rows16_kernel(const bf16_t *__restrict__ X, int ldx, const bf16_t *__restrict__ W, int ldw,
-                                                     const float *__restrict__ bias, const bf16_t *__restrict__ res, int ldr,
-                                                     void *__restrict__ Cv, int ldc, int M, int N, int K, int ksplit, int out_f32) {
+template <int EPI, int SEG, bool NORM>
+__global__ __launch_bounds__(512) void rows16_kernel(const bf16_t *__restrict__ X, int ldx, const bf16_t *__restrict__ W, int ldw,
+                                                     const float *__restrict__ bias, const bf16_t *__restrict__ normw, float eps,
+                                                     const bf16_t *__restrict__ res, int ldr, void *__restrict__ Cv, int ldc, int M,
+                                                     int N, int K, int ksplit, int out_f32) {
     constexpr int NT = EPI == R16_SILU_MUL ? 2 : 1;     // weight sub-tiles per wave (gate rows + the matching up rows)
     // SEG = bytes of a row per block (128 | 256 | 512)
     constexpr int PITCH = SEG + 16;                     // LDS row pitch: (PITCH / 4) % 64 == 4 -> 16 rows cover the 64 banks once
@@ -55,9 +59,13 @@ __global__ __launch_bounds__(1024) void rows16_kernel(const bf16_t *__restrict__
     r16_f32x4 acc[NT];
 #pragma unroll
     for (int s = 0; s < NT; ++s) acc[s] = (r16_f32x4)(0.f);
-    r16_u32x4 wr[NT][IPT], xr[IPT];
+    r16_u32x4 wr[NT][IPT], xr[IPT], nwr = (r16_u32x4)(0);
+    float ssq[IPT];                                     // NORM: sum of squares of this lane's x elements, per row of its instructions
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) ssq[q] = 0.f;
     auto load_block = [&](int k0) {
         const bool kin = k0 + lcol < ke;
+        if (NORM) nwr = kin ? *reinterpret_cast<const r16_u32x4 *>(reinterpret_cast<const unsigned char *>(normw) + k0 + lcol) : (r16_u32x4)(0);
 #pragma unroll
         for (int q = 0; q < IPT; ++q) {
             const int r = q * RPI + lrow;
@@ -81,7 +89,18 @@ __global__ __launch_bounds__(1024) void rows16_kernel(const bf16_t *__restrict__
             const int r = q * RPI + lrow;
 #pragma unroll
             for (int s = 0; s < NT; ++s) *reinterpret_cast<r16_u32x4 *>(wl + (s * 16 + r) * PITCH + lcol) = wr[s][q];
-            *reinterpret_cast<r16_u32x4 *>(xl + r * PITCH + lcol) = xr[q];
+            r16_u32x4 xv = xr[q];
+            if (NORM) {     // x' = bf16(x * w_norm); the row's rsqrt(mean(x^2) + eps) multiplies the accumulator in the epilogue
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float a = __uint_as_float(xv[t] << 16), b = __uint_as_float(xv[t] & 0xffff0000u);
+                    ssq[q] = fmaf(a, a, ssq[q]);
+                    ssq[q] = fmaf(b, b, ssq[q]);
+                    const float wa = __uint_as_float(nwr[t] << 16), wb = __uint_as_float(nwr[t] & 0xffff0000u);
+                    xv[t] = (uint32_t)f32_to_bf16(a * wa) | ((uint32_t)f32_to_bf16(b * wb) << 16);
+                }
+            }
+            *reinterpret_cast<r16_u32x4 *>(xl + r * PITCH + lcol) = xv;
         }
         if (k0 + SEG < ke) load_block(k0 + SEG);       // next block in flight while this one is multiplied
 #pragma unroll
@@ -95,11 +114,23 @@ __global__ __launch_bounds__(1024) void rows16_kernel(const bf16_t *__restrict__
         }
     }
     // acc[s][j] = C[weight row n0 + (lane>>4)*4 + j][token row lane & 15]
+    if (NORM) {             // lanes of one row segment -> one sum per row of this wave's K slice
+#pragma unroll
+        for (int q = 0; q < IPT; ++q)
+#pragma unroll
+            for (int off = 1; off < LPR; off <<= 1) ssq[q] += __shfl_xor(ssq[q], off, 64);
+    }
+    float rstd = 1.f;
     if (ksplit > 1) {
         __syncthreads();                                // every wave is done with its LDS image
-        float *part = reinterpret_cast<float *>(sm_r16);               // [waves][NT][64 lanes][4]
+        float *part = reinterpret_cast<float *>(sm_r16);               // [waves][NT][64 lanes][4] | [waves][16] sums of squares
+        float *psq = part + waves * NT * 256;
 #pragma unroll
         for (int s = 0; s < NT; ++s) *reinterpret_cast<r16_f32x4 *>(part + ((wid * NT + s) * 64 + lane) * 4) = acc[s];
+        if (NORM && lane % LPR == 0) {
+#pragma unroll
+            for (int q = 0; q < IPT; ++q) psq[wid * 16 + q * RPI + lrow] = ssq[q];
+        }
         __syncthreads();
         if (slice != 0) return;
 #pragma unroll
@@ -108,6 +139,22 @@ __global__ __launch_bounds__(1024) void rows16_kernel(const bf16_t *__restrict__
             for (int w = 1; w < ksplit; ++w) t += *reinterpret_cast<const r16_f32x4 *>(part + (((wid + w) * NT + s) * 64 + lane) * 4);
             acc[s] = t;
         }
+        if (NORM) {
+            float t = psq[wid * 16 + (lane & 15)];
+            for (int w = 1; w < ksplit; ++w) t += psq[(wid + w) * 16 + (lane & 15)];
+            rstd = rsqrtf(t / (float)K + eps);
+        }
+    } else if (NORM) {      // the wave owns the whole K: row sums through its own LDS image (same wave: in order)
+        float *psq = reinterpret_cast<float *>(wl);
+        if (lane % LPR == 0) {
+#pragma unroll
+            for (int q = 0; q < IPT; ++q) psq[q * RPI + lrow] = ssq[q];
+        }
+        rstd = rsqrtf(psq[lane & 15] / (float)K + eps);
+    }
+    if (NORM) {
+#pragma unroll
+        for (int s = 0; s < NT; ++s) acc[s] *= rstd;
     }
     if (!tile_ok) return;
     const int m = lane & 15, nb = n0 + (lane >> 4) * 4;
@@ -154,27 +201,27 @@ __global__ __launch_bounds__(1024) void rows16_kernel(const bf16_t *__restrict__
 
 static int g_rows16_geom = 0;     // 0: by tile count; else seg << 16 | waves << 8 | ksplit (tuning)
 
-template <int EPI, int SEG>
+template <int EPI, int SEG, bool NORM>
 static int launch_rows16_seg(int waves, int ksplit, hipStream_t s, const bf16_t *X, int ldx, const bf16_t *W, int ldw, const float *bias,
-                             const bf16_t *res, int ldr, void *C, int ldc, int M, int N, int K, int out_f32) {
+                             const bf16_t *normw, float eps, const bf16_t *res, int ldr, void *C, int ldc, int M, int N, int K, int out_f32) {
     constexpr int NT = EPI == R16_SILU_MUL ? 2 : 1;
     const int ntiles = (N + 15) / 16;
     const size_t lds = (size_t)waves * (NT + 1) * 16 * (SEG + 16);
     LL_CHECK(lds <= 160 * 1024, "ll_linear_rows16_bf16: %d waves x %d-byte segments need %zu bytes of LDS", waves, SEG, lds);
     static size_t attr_lds = 0;       // > 64 KB of dynamic LDS needs the attribute
     if (lds > attr_lds) {
-        LL_HIP(hipFuncSetAttribute((const void *)rows16_kernel<EPI, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)rows16_kernel<EPI, SEG, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
     const int tpw = waves / ksplit;
-    hipLaunchKernelGGL((rows16_kernel<EPI, SEG>), dim3((ntiles + tpw - 1) / tpw), dim3(waves * 64), lds, s, X, ldx, W, ldw, bias, res, ldr, C,
-                       ldc, M, N, K, ksplit, out_f32);
+    hipLaunchKernelGGL((rows16_kernel<EPI, SEG, NORM>), dim3((ntiles + tpw - 1) / tpw), dim3(waves * 64), lds, s, X, ldx, W, ldw, bias, normw,
+                       eps, res, ldr, C, ldc, M, N, K, ksplit, out_f32);
     return LL_OK;
 }
 
-template <int EPI>
-static int launch_rows16(hipStream_t s, const bf16_t *X, int ldx, const bf16_t *W, int ldw, const float *bias, const bf16_t *res, int ldr,
-                         void *C, int ldc, int M, int N, int K, int out_f32) {
+template <int EPI, bool NORM>
+static int launch_rows16(hipStream_t s, const bf16_t *X, int ldx, const bf16_t *W, int ldw, const float *bias, const bf16_t *normw, float eps,
+                         const bf16_t *res, int ldr, void *C, int ldc, int M, int N, int K, int out_f32) {
     const int ntiles = (N + 15) / 16;
     int seg, waves, ksplit;
     if (g_rows16_geom) {
@@ -188,13 +235,13 @@ static int launch_rows16(hipStream_t s, const bf16_t *X, int ldx, const bf16_t *
         waves = ksplit <= 4 ? 4 : 8;
         if (ksplit == 8 && ntiles * 4 >= 1100) seg = 256, waves = 4, ksplit = 4;      // q|k|v (288 tiles): 11.1 us vs 12.5
     }
-    if (seg == 128) return launch_rows16_seg<EPI, 128>(waves, ksplit, s, X, ldx, W, ldw, bias, res, ldr, C, ldc, M, N, K, out_f32);
-    if (seg == 256) return launch_rows16_seg<EPI, 256>(waves, ksplit, s, X, ldx, W, ldw, bias, res, ldr, C, ldc, M, N, K, out_f32);
-    return launch_rows16_seg<EPI, 512>(waves, ksplit, s, X, ldx, W, ldw, bias, res, ldr, C, ldc, M, N, K, out_f32);
+    if (seg == 128) return launch_rows16_seg<EPI, 128, NORM>(waves, ksplit, s, X, ldx, W, ldw, bias, normw, eps, res, ldr, C, ldc, M, N, K, out_f32);
+    if (seg == 256) return launch_rows16_seg<EPI, 256, NORM>(waves, ksplit, s, X, ldx, W, ldw, bias, normw, eps, res, ldr, C, ldc, M, N, K, out_f32);
+    return launch_rows16_seg<EPI, 512, NORM>(waves, ksplit, s, X, ldx, W, ldw, bias, normw, eps, res, ldr, C, ldc, M, N, K, out_f32);
 }
 
-int linear_rows16_launch(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *residual, int ldr, void *out,
-                         int ldc, int M, int N, int K, int epi, int out_f32, hipStream_t s) {
+int linear_rows16_launch(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *norm_w, float eps,
+                         const void *residual, int ldr, void *out, int ldc, int M, int N, int K, int epi, int out_f32, hipStream_t s) {
     LL_CHECK(x && W && out, "ll_linear_rows16_bf16: null argument");
     LL_CHECK(M >= 1 && M <= 16, "ll_linear_rows16_bf16: M=%d rows (1..16)", M);
     LL_CHECK(N >= 1 && K >= 32 && K % 32 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "ll_linear_rows16_bf16: K must be a multiple of 32, ldx / ldw of 8");
@@ -203,9 +250,17 @@ int linear_rows16_launch(const void *x, int ldx, const void *W, int ldw, const f
     LL_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0, "ll_linear_rows16_bf16: operands must be 16-byte aligned");
     const bf16_t *X = (const bf16_t *)x, *Wt = (const bf16_t *)W, *rs = (const bf16_t *)residual;
     LL_CHECK(!out_f32 || epi == R16_PLAIN, "ll_linear_rows16_bf16: f32 output only with the plain epilogue");
-    if (epi == R16_PLAIN) LL_TRY(launch_rows16<R16_PLAIN>(s, X, ldx, Wt, ldw, bias, rs, ldr, out, ldc, M, N, K, out_f32));
-    else if (epi == R16_RESIDUAL) LL_TRY(launch_rows16<R16_RESIDUAL>(s, X, ldx, Wt, ldw, bias, rs, ldr, out, ldc, M, N, K, 0));
-    else LL_TRY(launch_rows16<R16_SILU_MUL>(s, X, ldx, Wt, ldw, bias, rs, ldr, out, ldc, M, N, K, 0));
+    const bf16_t *nw = (const bf16_t *)norm_w;
+    LL_CHECK(!nw || ((uintptr_t)nw & 15) == 0, "ll_linear_rows16_bf16: norm weight must be 16-byte aligned");
+    if (nw) {
+        if (epi == R16_PLAIN) LL_TRY((launch_rows16<R16_PLAIN, true>(s, X, ldx, Wt, ldw, bias, nw, eps, rs, ldr, out, ldc, M, N, K, out_f32)));
+        else if (epi == R16_RESIDUAL) LL_TRY((launch_rows16<R16_RESIDUAL, true>(s, X, ldx, Wt, ldw, bias, nw, eps, rs, ldr, out, ldc, M, N, K, 0)));
+        else LL_TRY((launch_rows16<R16_SILU_MUL, true>(s, X, ldx, Wt, ldw, bias, nw, eps, rs, ldr, out, ldc, M, N, K, 0)));
+    } else {
+        if (epi == R16_PLAIN) LL_TRY((launch_rows16<R16_PLAIN, false>(s, X, ldx, Wt, ldw, bias, nw, eps, rs, ldr, out, ldc, M, N, K, out_f32)));
+        else if (epi == R16_RESIDUAL) LL_TRY((launch_rows16<R16_RESIDUAL, false>(s, X, ldx, Wt, ldw, bias, nw, eps, rs, ldr, out, ldc, M, N, K, 0)));
+        else LL_TRY((launch_rows16<R16_SILU_MUL, false>(s, X, ldx, Wt, ldw, bias, nw, eps, rs, ldr, out, ldc, M, N, K, 0)));
+    }
     LL_LAUNCH_CHECK();
     return LL_OK;
 }
@@ -216,21 +271,21 @@ using namespace ll;
 
 extern "C" {
 
-int ll_linear_rows16_bf16(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *residual, int ldr, void *out,
-                          int ldc, int M, int N, int K, int epi, void *stream) {
-    return linear_rows16_launch(x, ldx, W, ldw, bias, residual, ldr, out, ldc, M, N, K, epi, 0, (hipStream_t)stream);
+int ll_linear_rows16_bf16(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *norm_w, float eps,
+                          const void *residual, int ldr, void *out, int ldc, int M, int N, int K, int epi, void *stream) {
+    return linear_rows16_launch(x, ldx, W, ldw, bias, norm_w, eps, residual, ldr, out, ldc, M, N, K, epi, 0, (hipStream_t)stream);
 }
 
 int ll_set_rows16_geometry(int seg, int waves, int ksplit) {
     const int old = g_rows16_geom;
-    const bool ok = (seg == 128 || seg == 256 || seg == 512) && (waves == 4 || waves == 8 || waves == 16) && ksplit >= 1 && ksplit <= waves &&
+    const bool ok = (seg == 128 || seg == 256 || seg == 512) && (waves == 4 || waves == 8) && ksplit >= 1 && ksplit <= waves &&
                     waves % ksplit == 0;
     g_rows16_geom = ok ? (seg << 16 | waves << 8 | ksplit) : 0;
     return old;
 }
 
 // Times ll_linear_rows16_bf16 on synthetic operands over `nweights` distinct weight matrices (defeats the Infinity Cache).
-int ll_rows16_bench(int M, int N, int K, int epi, int iters, int nweights, float *ms) {
+int ll_rows16_bench(int M, int N, int K, int epi, int norm, int iters, int nweights, float *ms) {
     LL_CHECK(ms && iters > 0 && nweights > 0 && M >= 1 && M <= 16, "bad argument");
     const int rowsW = epi == R16_SILU_MUL ? 2 * N : N;
     bf16_t *X = nullptr, *W = nullptr, *C = nullptr, *R = nullptr;
@@ -250,7 +305,7 @@ int ll_rows16_bench(int M, int N, int K, int epi, int iters, int nweights, float
     for (int pass = 0; pass < 2 && rc == LL_OK; ++pass) {
         if (pass == 1) (void)hipEventRecord(e0, st);
         for (int i = 0; i < (pass ? iters : nweights) && rc == LL_OK; ++i)
-            rc = linear_rows16_launch(X, K, W + (size_t)(i % nweights) * rowsW * K, K, nullptr, R, N, C, N, M, N, K, epi, 0, st);
+            rc = linear_rows16_launch(X, K, W + (size_t)(i % nweights) * rowsW * K, K, nullptr, norm ? X : nullptr, 1e-6f, R, N, C, N, M, N, K, epi, 0, st);
     }
     (void)hipEventRecord(e1, st);
     hipError_t he = hipEventSynchronize(e1);

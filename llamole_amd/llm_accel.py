@@ -42,7 +42,7 @@ def _hip_linear_forward(self: nn.Linear, x: torch.Tensor) -> torch.Tensor:
                     bias = self.bias.detach().float().contiguous()
                     self._ll_bias_f32 = bias
             rc = self._ll_lib.ll_linear_rows16_bf16(x2.data_ptr(), K, self.weight.data_ptr(), K, bias.data_ptr() if bias is not None else None,
-                                                    None, 0, out.data_ptr(), N, M, N, K, 0, torch.cuda.current_stream().cuda_stream)
+                                                    None, 0.0, None, 0, out.data_ptr(), N, M, N, K, 0, torch.cuda.current_stream().cuda_stream)
             if rc != 0:
                 _lib.check(rc, "ll_linear_rows16_bf16")
             return out.reshape(*x.shape[:-1], N)
@@ -391,10 +391,9 @@ class _FusedLayer:
     Qwen2DecoderLayer.forward (transformers modeling_qwen2.py) for ONE new token per sequence:
       qkv  = gemv(rmsnorm(h), Wqkv) ; a = rope+append+attention(qkv) ; h = h + gemv(a, Wo)
       act  = silu(gate)*up of gemv(rmsnorm(h), Wgate|up) ; h = h + gemv(act, Wdown)
-    batch <= 2 (<= 4 when the sizes are not multiples of 32): five launches (FMA GEMVs with the RMSNorm as their prologue,
-    ll_gemv_fused_bf16); batch 3..16: seven (the two
-    RMSNorms are their own launch, the projections are the weight-streaming MFMA Linear ll_linear_rows16_bf16 with the same
-    residual / SiLU*mul epilogues)."""
+    five launches: batch <= 2 (<= 4 when the sizes are not multiples of 32) on the FMA GEMVs (ll_gemv_fused_bf16), batch 3..16 on
+    the weight-streaming MFMA Linear (ll_linear_rows16_bf16) -- both with the RMSNorm as prologue and the residual / SiLU*mul
+    epilogues."""
 
     def __init__(self, lib, layer):
         att, mlp = layer.self_attn, layer.mlp
@@ -443,16 +442,10 @@ class _FusedLayer:
         M = x.shape[0]
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
         if M > FMA_GEMV_ROWS and self.stream_ok:
-            st = torch.cuda.current_stream().cuda_stream
-            if norm_w is not None:
-                xn = torch.empty_like(x)
-                rc = self.lib.ll_rmsnorm_bf16(x.data_ptr(), norm_w.data_ptr(), xn.data_ptr(), M, K, eps, st)
-                if rc != 0:
-                    _lib.check(rc, "ll_rmsnorm_bf16")
-                x = xn
             rc = self.lib.ll_linear_rows16_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
+                                                norm_w.data_ptr() if norm_w is not None else None, eps,
                                                 res.data_ptr() if res is not None else None, res.stride(0) if res is not None else 0,
-                                                out.data_ptr(), N, M, N, K, epi, st)
+                                                out.data_ptr(), N, M, N, K, epi, torch.cuda.current_stream().cuda_stream)
             if rc != 0:
                 _lib.check(rc, "ll_linear_rows16_bf16")
             return out
@@ -496,8 +489,7 @@ def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, 
 
 
 def fuse_decoder_layers(model: nn.Module) -> int:
-    """Run every decoder layer of a Qwen2 / Llama / Mistral-layout HF model as five launches at decode (batch <= 4; seven for
-    batch 5..16), static cache with the fused append of ``fuse_cache_update``, boolean sdpa-style mask.  Any other call --
+    """Run every decoder layer of a Qwen2 / Llama / Mistral-layout HF model as five launches at decode (batch <= 16), static cache with the fused append of ``fuse_cache_update``, boolean sdpa-style mask.  Any other call --
     prefill, larger batches, a dynamic cache -- takes the layer's previous forward.  Returns the number of patched layers."""
     lib = _lib.load()
     base = getattr(model, "model", model)

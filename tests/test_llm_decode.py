@@ -265,47 +265,57 @@ def test_gemv_fused_epilogues_vs_torch(M):
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [5, 8, 13, 16])
 def test_linear_rows16_epilogues_vs_torch(M):
-    """ll_linear_rows16_bf16 (weight-streaming MFMA Linear for 5..16 token rows) through the C ABI against op-by-op PyTorch with
-    the same bf16 roundings, every workgroup geometry the tuner may pick; N not a multiple of the 16-row tile, K not a multiple
-    of a block; and its error behaviour."""
+    """ll_linear_rows16_bf16 (weight-streaming MFMA Linear for 3..16 token rows) through the C ABI against op-by-op PyTorch with
+    the same bf16 roundings (RMSNorm as HF writes it), every workgroup geometry the tuner may pick; N not a multiple of the
+    16-row tile, K not a multiple of a block; and its error behaviour."""
     import torch.nn.functional as F
     from llamole_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(M)
     s = torch.cuda.current_stream().cuda_stream
+    eps = 1e-6
     for K, N in ((4640, 1003), (96, 24), (18944, 520)):
         x = torch.randn(M, K, generator=g).bfloat16().cuda()
         w = (torch.randn(2 * N, K, generator=g) * 0.02).bfloat16().cuda()
         bias = torch.randn(2 * N, generator=g).float().cuda()
+        nw = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().cuda()
         res = torch.randn(M, N, generator=g).bfloat16().cuda()
+
+        def rms(v):
+            f = v.float()
+            f = f * torch.rsqrt(f.pow(2).mean(-1, keepdim=True) + eps)
+            return nw * f.to(torch.bfloat16)
+
         for geom in ((0, 0, 0), (256, 4, 1), (256, 4, 4), (512, 8, 8), (128, 8, 2)):
-            if geom[0] == 512:
-                geoms = [(0, geom), (1, geom)]          # 512-byte segments: single-tile epilogues only (LDS)
-            else:
-                geoms = [(0, geom), (1, geom), (2, geom)]
-            for use_bias in (False, True):
-                b = bias if use_bias else torch.zeros_like(bias)
-                full = (x.float() @ w.float().t() + b).to(torch.bfloat16)
-                want = {0: full[:, :N], 1: res + full[:, :N], 2: F.silu(full[:, :N]) * full[:, N:]}
-                for epi, gm in geoms:
-                    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-                    lib.ll_set_rows16_geometry(*gm)
-                    try:
-                        _lib.check(lib.ll_linear_rows16_bf16(x.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if use_bias else None,
-                                                             res.data_ptr() if epi == 1 else None, N, out.data_ptr(), N, M, N, K, epi, s),
-                                   "ll_linear_rows16_bf16")
-                    finally:
-                        lib.ll_set_rows16_geometry(0, 0, 0)
-                    torch.testing.assert_close(out.float(), want[epi].float(), rtol=3e-2, atol=3e-2)
-    assert lib.ll_linear_rows16_bf16(x.data_ptr(), K, w.data_ptr(), K, None, None, 0, res.data_ptr(), N, 17, N, K, 0, s) == -1     # LL_EINVAL
-    assert lib.ll_linear_rows16_bf16(x.data_ptr(), K, w.data_ptr(), K, None, None, 0, res.data_ptr(), N, M, N, K - 8, 0, s) == -1  # K % 32
-    assert lib.ll_linear_rows16_bf16(x.data_ptr(), K, w.data_ptr(), K, None, None, 0, res.data_ptr(), N, M, N, K, 1, s) == -1      # no residual
+            epis = (0, 1) if geom[0] == 512 else (0, 1, 2)      # 512-byte segments: single-tile epilogues only (LDS)
+            for norm in (False, True):
+                xin = rms(x) if norm else x
+                for use_bias in ((False, True) if geom == (0, 0, 0) else (False,)):
+                    b = bias if use_bias else torch.zeros_like(bias)
+                    full = (xin.float() @ w.float().t() + b).to(torch.bfloat16)
+                    want = {0: full[:, :N], 1: res + full[:, :N], 2: F.silu(full[:, :N]) * full[:, N:]}
+                    for epi in epis:
+                        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+                        lib.ll_set_rows16_geometry(*geom)
+                        try:
+                            _lib.check(lib.ll_linear_rows16_bf16(x.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if use_bias else None,
+                                                                 nw.data_ptr() if norm else None, eps, res.data_ptr() if epi == 1 else None, N,
+                                                                 out.data_ptr(), N, M, N, K, epi, s), "ll_linear_rows16_bf16")
+                        finally:
+                            lib.ll_set_rows16_geometry(0, 0, 0)
+                        # accumulation order (and, with the RMSNorm prologue, the place of one bf16 rounding) differs from the
+                        # op-by-op evaluation: sums that cancel to ~0 carry an absolute error of ~0.3 % of the typical magnitude
+                        scale = want[epi].float().abs().max().item()
+                        torch.testing.assert_close(out.float(), want[epi].float(), rtol=3e-2, atol=max(3e-2, 0.01 * scale))
+    assert lib.ll_linear_rows16_bf16(x.data_ptr(), K, w.data_ptr(), K, None, None, eps, None, 0, res.data_ptr(), N, 17, N, K, 0, s) == -1     # LL_EINVAL
+    assert lib.ll_linear_rows16_bf16(x.data_ptr(), K, w.data_ptr(), K, None, None, eps, None, 0, res.data_ptr(), N, M, N, K - 8, 0, s) == -1  # K % 32
+    assert lib.ll_linear_rows16_bf16(x.data_ptr(), K, w.data_ptr(), K, None, None, eps, None, 0, res.data_ptr(), N, M, N, K, 1, s) == -1      # no residual
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows", [6, 16])
 def test_fused_decoder_layers_batched_rows(rows):
-    """Batched decode (5..16 sequences): the seven-launch layer on ll_linear_rows16_bf16 against the one-launch-per-op path.
+    """Batched decode (3..16 sequences): the five-launch layer on ll_linear_rows16_bf16 against the one-launch-per-op path.
     MFMA accumulation order differs from the ring GEMM's, so logits agree to bf16 rounding rather than bit for bit; the
     captured graph replays the eager result exactly."""
     from llamole_amd.llm_accel import (accelerate_elementwise, accelerate_linears, fuse_decoder_layers, fuse_model_decode,

@@ -24,7 +24,7 @@ def check(M, N, K, epi, geom):
     r = torch.randn(M, N, device=dev, generator=g).bfloat16()
     out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
     lib.ll_set_rows16_geometry(*geom)
-    _lib.check(lib.ll_linear_rows16_bf16(x.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), r.data_ptr(), N, out.data_ptr(), N, M, N, K, epi, st()),
+    _lib.check(lib.ll_linear_rows16_bf16(x.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), None, 0.0, r.data_ptr(), N, out.data_ptr(), N, M, N, K, epi, st()),
                "ll_linear_rows16_bf16")
     lib.ll_set_rows16_geometry(0, 0, 0)
     y = (x.float() @ w.float().t() + b).bfloat16().float()
@@ -54,8 +54,8 @@ print("correctness:", "FAILED" if bad else "ok")
 H, I, V = 3584, 18944, 152064
 GEOMS = [(0, 0, 0), (256, 4, 4), (128, 8, 8), (256, 8, 8), (256, 8, 4), (512, 8, 8), (512, 4, 4), (256, 4, 1), (256, 4, 2), (128, 8, 2)]
 ms = C.c_float()
-for name, N, K, epi in [("qkv", 4608, H, 0), ("o_proj", H, H, 1), ("gate_up", I, H, 2), ("down", H, I, 1), ("lm_head", V, H, 0),
-                        ("l3_gate_up", 14336, 4096, 2), ("l3_down", 4096, 14336, 1)]:
+for name, N, K, epi, norm in [("qkv", 4608, H, 0, 1), ("o_proj", H, H, 1, 0), ("gate_up", I, H, 2, 1), ("down", H, I, 1, 0), ("lm_head", V, H, 0, 0),
+                              ("l3_gate_up", 14336, 4096, 2, 1), ("l3_down", 4096, 14336, 1, 0)]:
     rows = 2 * N if epi == 2 else N
     mb = rows * K * 2 / 1e6
     nw = max(2, int(600 / mb) + 1)
@@ -67,7 +67,7 @@ for name, N, K, epi in [("qkv", 4608, H, 0), ("o_proj", H, H, 1), ("gate_up", I,
             if ks[0] == 512 and epi == 2 and ks[1] > 4:
                 continue          # 48 rows x 528 B x 8 waves > 160 KB of LDS
             lib.ll_set_rows16_geometry(*ks)
-            rc = lib.ll_rows16_bench(M, N, K, epi, iters, nw, C.byref(ms))
+            rc = lib.ll_rows16_bench(M, N, K, epi, norm, iters, nw, C.byref(ms))
             out.append(f" {ks[0]}/{ks[1]}x{ks[2]}: {ms.value*1e3:5.1f} |" if rc == 0 else f" {ks[0]}/{ks[1]}x{ks[2]}:  n/a |")
         lib.ll_set_rows16_geometry(0, 0, 0)
         print("".join(out), flush=True)
