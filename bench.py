@@ -168,8 +168,8 @@ def cpu_baseline_e2e(args, llm, cfg, meta, sd, props, text, n_nodes):
 def time_dominant_kernel(args, device):
     """The dominant hand-written kernel of the workload, timed by HIP events on the stream it is launched on, back to
     back over enough distinct weight matrices to defeat the 256 MiB Infinity Cache (ll_gemm_bench in the C ABI):
-      e2e      : gemv_bf16_kernel -- the weight-streaming GEMV under the LLM's nn.Linear at decode (15.2 GB of bf16
-                 weights per token for Qwen2-7B); timed on the MLP up/gate projection shape [18944 x 3584], M = batch;
+      e2e      : the weight-streaming kernel under the LLM's gated-MLP gate|up projection at decode (15.2 GB of bf16 weights
+                 per token for Qwen2-7B), shape [2 x 18944 x 3584], M = batch: gemv_fused_kernel (M <= 2) or rows16_kernel (3..16);
       graphdit : gemm_bf16_pipe_kernel at the block-MLP fc1 shape, M = 2*B*N tokens.
     Returns (avg_ms, algorithmic bytes, flops, name, pmc key)."""
     import ctypes as C
@@ -182,7 +182,16 @@ def time_dominant_kernel(args, device):
         spec = LLM_CONFIGS[args.llm]
         M, N, K = args.batch, spec["intermediate_size"], spec["hidden_size"]
         ms = C.c_float()
-        if args.llm_fuse and args.llm_layer_fuse and args.llm_decode != "hf" and M <= 4:
+        if args.llm_fuse and args.llm_layer_fuse and args.llm_decode != "hf" and 3 <= M <= 16 and K % 32 == 0:
+            # batched decode: the same projection on the weight-streaming MFMA Linear (ll_linear_rows16_bf16)
+            rows = 2 * N
+            nw = max(2, int(600e6 // (rows * K * 2)))
+            _lib.check(lib.ll_rows16_bench(M, N, K, 2, 1, 8 * nw, nw, C.byref(ms)), "ll_rows16_bench")
+            name = (f"rows16_kernel<silu_mul,256,norm>, LLM gated-MLP gate|up projection [{M}x{K}]x[{rows}x{K}]^T bf16 + RMSNorm prologue "
+                    f"+ SiLU*mul epilogue (batched decode step)")
+            nbytes = rows * K * 2 + M * K * 2 + K * 2 + M * N * 2
+            return ms.value, nbytes, 2.0 * M * rows * K, name, f"llm_rows16_m{M}_n{rows}_k{K}"
+        if args.llm_fuse and args.llm_layer_fuse and args.llm_decode != "hf" and M <= 2:
             # the fused layer's gated-MLP kernel: RMSNorm prologue, gate|up rows streamed once, SiLU*mul epilogue
             rows = 2 * N
             nw = max(2, int(600e6 // (rows * K * 2)))
