@@ -8,7 +8,7 @@ out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_$tag
-rocprofv3 --pmc $ctr --output-format csv -d /tmp/pmc_$tag -o $tag -- python3 $root/tools/gemm_one.py "$@" > $out/${tag}_pmc.log 2>&1
+timeout 120 rocprofv3 --pmc $ctr --output-format csv -d /tmp/pmc_$tag -o $tag -- python3 $root/tools/gemm_one.py "$@" > $out/${tag}_pmc.log 2>&1
 tail -3 $out/${tag}_pmc.log | cut -c1-200
 find /tmp/pmc_$tag -type f | head
 f=$(find /tmp/pmc_$tag -name '*counter_collection.csv' | head -1)
