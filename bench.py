@@ -218,7 +218,7 @@ def time_dominant_kernel(args, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="e2e", choices=["graphdit", "e2e"])
     ap.add_argument("--batch", type=int, default=None, help="prompts per GPU per step")
