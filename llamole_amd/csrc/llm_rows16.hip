@@ -1,4 +1,4 @@
-// Weight-streaming Linear for 5..16 token rows (batched decode of the HF LLM, SURVEY.md section 8 f2: 16 lock-step A* searches,
+// Weight-streaming Linear for 3..16 token rows (batched decode of the HF LLM, SURVEY.md section 8 f2: 16 lock-step A* searches,
 // 8 prompts per GPU): out[M,N] = epilogue(x[M,K] . W[N,K]^T + bias), bf16 operands, f32 accumulation on
 // v_mfma_f32_16x16x32_bf16 with the token rows as the 16-wide MFMA column block.
 //
@@ -10,9 +10,9 @@
 // the matching x segment goes the same way.  The LDS image is private to the wave, so the main loop has no barrier at all;
 // the next block's loads are in flight (in registers) while the current block is multiplied.
 // A workgroup of `waves` waves (4 or 8) owns waves / ksplit row tiles; `ksplit` consecutive waves split K of one tile and
-// their partial tiles are summed through LDS in wave order (deterministic).  The launcher picks the geometry so that every
-// CU holds two or more workgroups (4-wave workgroups need 52-68 KB of LDS): ksplit 1-2 for gate|up / lm_head (thousands of
-// tiles), 8 waves x ksplit 8 for q|k|v, o_proj, down_proj (a few hundred tiles).
+// their partial tiles are summed through LDS in wave order (deterministic).  What limits a wave is its own latency chain
+// (load -> LDS -> fragment read -> MFMA), so the launcher splits K until there are ~14 waves per CU (tools/rows16_sweep.py):
+// lm_head 4 waves x ksplit 1, gate|up and q|k|v 4 x 4 (52 KB of LDS per workgroup: three per CU), o_proj / down_proj 8 x 8.
 // Epilogues as ll_gemv_fused_bf16 (same intermediate bf16 roundings as PyTorch's op-by-op evaluation).  RMSNorm prologue
 // (norm_w != NULL): x is multiplied by the norm weight while it is staged, x' = bf16(x * w), the waves accumulate sum(x^2)
 // of their K slice on the side, and rsqrt(mean(x^2) + eps) of the token row scales the accumulator in the epilogue -- the
