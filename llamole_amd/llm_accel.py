@@ -8,6 +8,7 @@ hipGraph of ``llm_decode.GraphedDecoder``.
 """
 from __future__ import annotations
 
+import os
 import types
 
 import torch
@@ -18,8 +19,10 @@ from . import _lib
 
 MAX_ROWS = 128           # GEMV / skinny-GEMM path under nn.Linear (128-token prefill: 8.7 ms vs 10.0 ms on hipBLASLt, tools/prefill_probe.py)
 MAX_STREAM_ROWS = 16    # ll_linear_rows16_bf16: one MFMA column block of token rows (batched decode: 3..16 sequences)
-FMA_GEMV_ROWS = 2       # up to here the f32-FMA GEMVs win (RMSNorm prologue fused, 5 launches per layer); from 3 rows on the MFMA
-                        # stream does (tools/batch_sweep.sh: batch 4 = 603 ms per step on the FMA path, 508 ms at batch 8 on MFMA)
+# up to here the f32-FMA GEMVs run (RMSNorm prologue fused, bit-identical to the op-by-op path); from the next row count on the MFMA
+# stream does (tools/batch_sweep.sh: batch 4 = 603 ms per step on the FMA path vs 467 ms, batch 2 = 456 vs 439 ms -- the default
+# stays at 2 so that two-sequence decode keeps the bit-identity with HF's op order; LLAMOLE_FMA_GEMV_ROWS=1 trades it for the 4 %)
+FMA_GEMV_ROWS = int(os.environ.get("LLAMOLE_FMA_GEMV_ROWS", "2"))
 MAX_APPEND_ROWS = 16     # new positions per call served by the fused KV append / decode attention (decode, query tail)
 MAX_EW_ROWS = 16384      # row-parallel elementwise kernels (RMSNorm, rotary, SiLU*mul) also serve prefill-sized calls
 
