@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libllamole_hip.so")
 SOURCES = ["gemm.hip", "graphdit.hip", "gin.hip", "llm_ops.hip", "llm_layer.hip", "llm_rows16.hip", "llm_sample.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def _newer(a, deps):
