@@ -27,19 +27,19 @@ __global__ void k_load_store(const u4 *in, u4 *out, int n) {
 }
 // every workgroup reads `kb` KB (own = its own slice, else one shared panel), 16 B per lane, up to 32 loads in flight per thread;
 // fresh = the panel was written by the previous launch (every launch rewrites what the next one reads), else it is read-only
-template <int KB, bool OWN, bool FRESH>
-__global__ __launch_bounds__(256) void k_wide(const u4 *in, u4 *out, int n) {
-    constexpr int LOADS = KB * 1024 / 16 / 256;
+template <int KB, bool OWN, bool FRESH, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void k_wide(const u4 *in, u4 *out, int n) {
+    constexpr int LOADS = KB * 1024 / 16 / THREADS;
     const u4 *src = (FRESH ? in : in + (size_t)4 * 1024 * 1024) + (OWN ? (size_t)blockIdx.x * (KB * 64) : 0);
     u4 acc = (u4)(0);
 #pragma unroll
-    for (int j = 0; j < LOADS; ++j) acc ^= src[threadIdx.x + j * 256];
+    for (int j = 0; j < LOADS; ++j) acc ^= src[threadIdx.x + j * THREADS];
     acc[0] += 1;
     // rewrite the region the next launch reads (OWN: own slice; shared: the first KB/4 workgroups cover the panel)
     u4 *dst = out + (OWN ? (size_t)blockIdx.x * (KB * 64) : 0);
 #pragma unroll
     for (int j = 0; j < LOADS; ++j)
-        if (OWN || (int)blockIdx.x == j % (int)gridDim.x) dst[threadIdx.x + j * 256] = acc;
+        if (OWN || (int)blockIdx.x == j % (int)gridDim.x) dst[threadIdx.x + j * THREADS] = acc;
 }
 
 template <typename K> static float chain(K kern, dim3 grid, dim3 block, u4 *a, u4 *b, int n) {
@@ -84,5 +84,8 @@ int main() {
     WIDE(128, false, true, 192); WIDE(128, false, true, 32); WIDE(128, false, false, 192); WIDE(128, false, false, 32);
     WIDE(64, false, true, 192); WIDE(32, false, true, 192); WIDE(16, false, true, 192);
     WIDE(128, true, true, 192); WIDE(128, true, false, 192); WIDE(32, true, true, 192);
+    printf("128 KB shared fresh panel, 192 workgroups of 512 threads : %.2f us per launch\n", chain(k_wide<128, false, true, 512>, dim3(192), dim3(512), a, b, n));
+    printf("128 KB shared fresh panel, 192 workgroups of 1024 threads: %.2f us per launch\n", chain(k_wide<128, false, true, 1024>, dim3(192), dim3(1024), a, b, n));
+    printf("128 KB shared fresh panel,  32 workgroups of 1024 threads: %.2f us per launch\n", chain(k_wide<128, false, true, 1024>, dim3(32), dim3(1024), a, b, n));
     return 0;
 }
