@@ -136,6 +136,9 @@ int ll_dit_cvec(void *handle, int s, float *c, void *stream);
 
 /* Timing of the most recent ll_dit_run measured with HIP events on `stream`: total ms and steps. */
 int ll_dit_last_run_ms(void *handle, float *ms, int *steps);
+/* Tuning: ln_mod_res with one wave per 256-column chunk of a row (default) or one wave per row; bit-identical results; returns the
+ * previous setting. */
+int ll_set_lnmod_multiwave(int on);
 
 /* ------------------------------------------------------------------ GIN encoder / predictor
  * Replaces GNNEncoder.forward + ProjectionHead (src/model/graph_encoder/model.py:124-205) and

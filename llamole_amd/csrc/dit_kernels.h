@@ -469,6 +469,68 @@ __global__ __launch_bounds__(64) void ln_mod_res_kernel(const float *__restrict_
     }
 }
 
+// The same row operation with MAXE waves per row: wave e owns the e-th 256-column chunk, so a lane holds NS + 5 loads in flight
+// instead of MAXE * (NS + 5) (tools/phase_floor_probe.hip: beyond ~16 outstanding loads per thread the ingest of a launch gets
+// slower).  The reductions keep the single-wave kernel's order -- per lane the chunk partials are added in chunk order, then the
+// wave reduction -- so the result is bit-identical to ln_mod_res_kernel.
+template <typename T, int NS, int MAXE>
+__global__ __launch_bounds__(64 * MAXE) void ln_mod_res_mw_kernel(const float *__restrict__ y, int64_t slab_stride,
+                                                                   const float *__restrict__ bias, float *__restrict__ x32,
+                                                                   T *__restrict__ xa, const float *__restrict__ modtab,
+                                                                   const int *__restrict__ step_ptr, const int *__restrict__ rowvec,
+                                                                   int layer, int sel, int B, int N, int H, int L, int M2) {
+    __shared__ float part[2][MAXE][64];
+    const int row = blockIdx.x;
+    if (row >= M2) return;
+    const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
+    const int seq = row / N;
+    const int s = rowvec ? rowvec[seq < B ? seq : seq - B] : *step_ptr;
+    const int ci = (seq < B) ? seq : B;
+    const float *mod = modtab + (((int64_t)s * (B + 1) + ci) * L + layer) * (6 * (int64_t)H) + (int64_t)sel * 3 * H;
+    const int h = (lane + e * 64) * 4;
+    const bool ok = h < H;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), xr = v, sh = v, sc = v, ga = v;
+    if (ok) {
+        float4 t[NS];
+#pragma unroll
+        for (int z = 0; z < NS; ++z) t[z] = *reinterpret_cast<const float4 *>(y + z * slab_stride + (int64_t)row * H + h);
+        const float4 bb = *reinterpret_cast<const float4 *>(bias + h);
+        xr = *reinterpret_cast<const float4 *>(x32 + (int64_t)row * H + h);
+        sh = *reinterpret_cast<const float4 *>(mod + h);
+        sc = *reinterpret_cast<const float4 *>(mod + H + h);
+        ga = *reinterpret_cast<const float4 *>(mod + 2 * H + h);
+#pragma unroll
+        for (int z = 0; z < NS; ++z) { v.x += t[z].x; v.y += t[z].y; v.z += t[z].z; v.w += t[z].w; }
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+    }
+    part[0][e][lane] = v.x + v.y + v.z + v.w;
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) sum += part[0][k][lane];
+    const float mean = wave_sum(sum) / (float)H;
+    float d2 = 0.f;
+    if (ok) {
+        const float d0 = v.x - mean, d1 = v.y - mean, d2a = v.z - mean, d3 = v.w - mean;
+        d2 = d0 * d0 + d1 * d1 + d2a * d2a + d3 * d3;
+    }
+    part[1][e][lane] = d2;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) var += part[1][k][lane];
+    const float rstd = rsqrtf(wave_sum(var) / (float)H + 1e-5f);
+    if (ok) {
+        float4 o;
+        o.x = xr.x + ga.x * ((v.x - mean) * rstd * (1.f + sc.x) + sh.x);
+        o.y = xr.y + ga.y * ((v.y - mean) * rstd * (1.f + sc.y) + sh.y);
+        o.z = xr.z + ga.z * ((v.z - mean) * rstd * (1.f + sc.z) + sh.z);
+        o.w = xr.w + ga.w * ((v.w - mean) * rstd * (1.f + sc.w) + sh.w);
+        *reinterpret_cast<float4 *>(x32 + (int64_t)row * H + h) = o;
+        store4<T>(xa + (int64_t)row * H + h, o);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ posterior + CFG + sampling
 // Two launches replace ~40 ATen launches, six dense [B,F,F] builds and six bmm per step of the reference
 // (diffusion_model.py:328-399, diffusion_utils.py:316-349, 376-413, 476-492) with O(N*F) work per graph:

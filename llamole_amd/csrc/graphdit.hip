@@ -221,14 +221,23 @@ template <typename T> static void launch_attn(DitEngine *e, int layer, hipStream
                        e->pfs(p + "k_norm.weight"), e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, N,
                        e->cfg.hidden, hd);
 }
+static int g_lnmod_multiwave = 1;     // one wave per 256-column chunk of a row (ln_mod_res_mw_kernel) instead of one wave per row
+
 template <typename T>
 static void launch_lnmod(DitEngine *e, int layer, int sel, int nslab, const float *bias, hipStream_t st) {
     const dim3 grid(e->M2), blk(64);
     const int64_t ss = (int64_t)e->M2p * e->cfg.hidden;
 #define LL_LNMOD2(NS, ME)                                                                                              \
-    hipLaunchKernelGGL((ln_mod_res_kernel<T, NS, ME>), grid, blk, 0, st, e->ybuf.as<float>(), ss, bias,                 \
-                       e->x32.as<float>(), e->xa.as<T>(), e->modtab.as<float>(), e->step_ptr(), e->rowvec, layer, sel, e->B, \
-                       e->cfg.max_nodes, e->cfg.hidden, e->cfg.depth, e->M2)
+    do {                                                                                                               \
+        if (ME > 1 && g_lnmod_multiwave)                                                                               \
+            hipLaunchKernelGGL((ln_mod_res_mw_kernel<T, NS, ME>), grid, dim3(64 * ME), 0, st, e->ybuf.as<float>(), ss, bias, \
+                               e->x32.as<float>(), e->xa.as<T>(), e->modtab.as<float>(), e->step_ptr(), e->rowvec, layer, sel, \
+                               e->B, e->cfg.max_nodes, e->cfg.hidden, e->cfg.depth, e->M2);                            \
+        else                                                                                                           \
+            hipLaunchKernelGGL((ln_mod_res_kernel<T, NS, ME>), grid, blk, 0, st, e->ybuf.as<float>(), ss, bias,         \
+                               e->x32.as<float>(), e->xa.as<T>(), e->modtab.as<float>(), e->step_ptr(), e->rowvec, layer, sel, \
+                               e->B, e->cfg.max_nodes, e->cfg.hidden, e->cfg.depth, e->M2);                            \
+    } while (0)
 #define LL_LNMOD(NS)                                                                                                   \
     do {                                                                                                               \
         if (e->cfg.hidden <= 256) LL_LNMOD2(NS, 1);                                                                    \
@@ -706,6 +715,12 @@ int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream) {
     LL_HIP(hipEventRecord(e->ev_out, st));
     LL_HIP(hipStreamWaitEvent(caller, e->ev_out, 0));
     return LL_OK;
+}
+
+int ll_set_lnmod_multiwave(int on) {
+    const int old = g_lnmod_multiwave;
+    g_lnmod_multiwave = on ? 1 : 0;
+    return old;
 }
 
 int ll_dit_last_run_ms(void *handle, float *ms, int *steps) {
