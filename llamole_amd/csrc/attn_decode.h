@@ -1,5 +1,5 @@
 // Shared body of the two decode-attention kernels (llm_ops.hip: ll_decode_attn_bf16; llm_layer.hip: the fused
-// rope + append + attention).  One workgroup (256 threads = 4 waves) per (query head, sequence[, query position]).
+// rope + append + attention).  One workgroup (ATTN_WAVES waves) per (query head, sequence[, query position]).
 //
 // Access pattern: a wave-level load instruction covers RPI = 1024/(2 D) whole key (or value) rows -- LPR = D/8 lanes x 16 B
 // per row, fully coalesced -- so a tile of 256 keys is 64/RPI load instructions per wave for K and as many for V.
@@ -17,10 +17,17 @@ namespace ll {
 
 typedef uint32_t au32x4 __attribute__((ext_vector_type(4)));
 
+// Waves per workgroup.  A tile is 256 keys; with 8 waves a lane has 2 x 8 K / V loads of the first tile in flight instead of
+// 2 x 16 -- beyond ~16 outstanding loads per thread the ingest of a launch slows down (tools/phase_floor_probe.hip).
+constexpr int ATTN_WAVES = 8;
+constexpr int ATTN_THREADS = ATTN_WAVES * 64;
+constexpr int ATTN_PART_FLOATS = ATTN_WAVES * 512;      // [waves][rows per load][D]: RPI * D = 512 for either D
+
 template <int D> struct AttnGeom {
-    static constexpr int LPR = D / 8;          // lanes per row (16 B each)
-    static constexpr int RPI = 64 / LPR;       // rows per wave-level load instruction
-    static constexpr int NI = 64 / RPI;        // instructions per wave for its 64 keys of a 256-key tile
+    static constexpr int LPR = D / 8;                      // lanes per row (16 B each)
+    static constexpr int RPI = 64 / LPR;                   // rows per wave-level load instruction
+    static constexpr int KPW = 256 / ATTN_WAVES;           // keys per wave of a 256-key tile
+    static constexpr int NI = KPW / RPI;                   // instructions per wave for its keys of a tile
 };
 
 template <int D> struct AttnTile0 {
@@ -31,7 +38,7 @@ template <int D> struct AttnTile0 {
 
 // key index handled by (wave, instruction i, lane) inside a tile starting at j0
 template <int D> __device__ __forceinline__ int attn_key(int j0, int wave, int i, int lane) {
-    return j0 + wave * 64 + i * AttnGeom<D>::RPI + lane / AttnGeom<D>::LPR;
+    return j0 + wave * AttnGeom<D>::KPW + i * AttnGeom<D>::RPI + lane / AttnGeom<D>::LPR;
 }
 
 template <int D>
@@ -80,7 +87,7 @@ __device__ __forceinline__ void attn_axpy8(float (&acc)[8], float p, au32x4 vv) 
     acc[7] = fmaf(p, __uint_as_float(vv[3] & 0xffff0000u), acc[7]);
 }
 
-// qs [D] f32 query, part [4][RPI][D], sc [maxlen], red [8] in LDS; the caller has synchronised after writing qs (and kn /
+// qs [D] f32 query, part [ATTN_WAVES][RPI][D], sc [maxlen], red [2 * ATTN_WAVES] in LDS; the caller has synchronised after writing qs (and kn /
 // vn).  NEWKV: key / value `p` are taken from kn / vn (LDS, bf16) instead of the cache.  Writes D outputs to outp.
 template <int D, bool NEWKV>
 __device__ __forceinline__ void attn_finish(AttnTile0<D> &t, const float *qs, float *part, float *sc, float *red,
@@ -113,7 +120,7 @@ __device__ __forceinline__ void attn_finish(AttnTile0<D> &t, const float *qs, fl
     __syncthreads();
     // ---- softmax statistics over the unmasked keys
     float mx = -INFINITY;
-    for (int j = tid; j < maxlen; j += 256) {
+    for (int j = tid; j < maxlen; j += ATTN_THREADS) {
         const bool ok = (j == tid ? t.mk : mrow[j]) != 0;
         const float s = ok ? sc[j] : -INFINITY;
         sc[j] = s;
@@ -122,17 +129,21 @@ __device__ __forceinline__ void attn_finish(AttnTile0<D> &t, const float *qs, fl
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < ATTN_WAVES; ++w) mx = fmaxf(mx, red[w]);
     float sum = 0.f;
-    for (int j = tid; j < maxlen; j += 256) {
+    for (int j = tid; j < maxlen; j += ATTN_THREADS) {
         const float e = (sc[j] == -INFINITY) ? 0.f : expf(sc[j] - mx);
         sc[j] = e;
         sum += e;
     }
     sum = wave_sum(sum);
-    if (lane == 0) red[4 + wave] = sum;
+    if (lane == 0) red[ATTN_WAVES + wave] = sum;
     __syncthreads();
-    const float den = red[4] + red[5] + red[6] + red[7];
+    float den = red[ATTN_WAVES];
+#pragma unroll
+    for (int w = 1; w < ATTN_WAVES; ++w) den += red[ATTN_WAVES + w];
     const float inv = den > 0.f ? 1.f / den : 0.f;      // a fully masked query row (left padding) yields zeros, not NaN
     // ---- out = P V: lane (r, c) accumulates columns 8c..8c+7 over the rows it sees
     float acc[8];
@@ -159,7 +170,7 @@ __device__ __forceinline__ void attn_finish(AttnTile0<D> &t, const float *qs, fl
     if (tid < D) {
         float o = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4 * RPI; ++g) o += part[g * D + tid];
+        for (int g = 0; g < ATTN_WAVES * RPI; ++g) o += part[g * D + tid];
         outp[tid] = f32_to_bf16(o * inv);
     }
 }

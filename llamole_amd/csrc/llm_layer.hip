@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const bf16_t *__restric
 // the head's KV group is rotated in LDS and used from there; the first query head of each group also stores it to the
 // cache at *pos.  Nobody reads cache slot *pos in this launch, so there is no cross-workgroup dependency.
 template <int D>
-__global__ __launch_bounds__(256) void decode_attn_rope_kernel(const bf16_t *__restrict__ qkv, int64_t ld_qkv,
+__global__ __launch_bounds__(ATTN_THREADS) void decode_attn_rope_kernel(const bf16_t *__restrict__ qkv, int64_t ld_qkv,
                                                                const bf16_t *__restrict__ cs, const bf16_t *__restrict__ sn,
                                                                int64_t cs0, bf16_t *__restrict__ K, bf16_t *__restrict__ V,
                                                                const long long *__restrict__ pos_ptr,
@@ -220,11 +220,11 @@ __global__ __launch_bounds__(256) void decode_attn_rope_kernel(const bf16_t *__r
                                                                bf16_t *__restrict__ out, int nh, int nkv, int maxlen, float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm_attn2[];
     float *qs = sm_attn2;                 // [D]     rotated query, f32 of its bf16 value
-    float *part = qs + D;                 // [4 waves][rows per load][D] partial outputs = 2048 floats for either D
-    bf16_t *kn = reinterpret_cast<bf16_t *>(part + 2048);    // [D] rotated new key (bf16)
+    float *part = qs + D;                 // [waves][rows per load][D] partial outputs = ATTN_PART_FLOATS for either D
+    bf16_t *kn = reinterpret_cast<bf16_t *>(part + ATTN_PART_FLOATS);    // [D] rotated new key (bf16)
     bf16_t *vn = kn + D;                  // [D] new value
     float *sc = reinterpret_cast<float *>(vn + D);           // [maxlen] scores -> probabilities
-    __shared__ float red[8];
+    __shared__ float red[2 * ATTN_WAVES];
     const int h = blockIdx.x, b = blockIdx.y;
     const int group = nh / nkv, kvh = h / group;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -369,14 +369,14 @@ int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, c
     LL_CHECK(qkv && cos && sin && Kc && Vc && pos && mask && out, "ll_decode_attn_rope_bf16: null argument");
     LL_CHECK((D == 64 || D == 128) && B >= 1 && nkv >= 1 && nh % nkv == 0 && maxlen >= 1 && maxlen <= 16384 && ld_qkv % 8 == 0,
              "ll_decode_attn_rope_bf16: unsupported shape");
-    const size_t lds = (size_t)(D + 2048) * 4 + (size_t)2 * D * 2 + (size_t)maxlen * 4;
+    const size_t lds = (size_t)(D + ATTN_PART_FLOATS) * 4 + (size_t)2 * D * 2 + (size_t)maxlen * 4;
     dim3 grid(nh, B);
     if (D == 128)
-        hipLaunchKernelGGL((decode_attn_rope_kernel<128>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t *)qkv, ld_qkv,
+        hipLaunchKernelGGL((decode_attn_rope_kernel<128>), grid, dim3(ATTN_THREADS), lds, (hipStream_t)stream, (const bf16_t *)qkv, ld_qkv,
                            (const bf16_t *)cos, (const bf16_t *)sin, cs_stride, (bf16_t *)Kc, (bf16_t *)Vc, (const long long *)pos,
                            (const unsigned char *)mask, mask_stride, (bf16_t *)out, nh, nkv, maxlen, scale);
     else
-        hipLaunchKernelGGL((decode_attn_rope_kernel<64>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t *)qkv, ld_qkv,
+        hipLaunchKernelGGL((decode_attn_rope_kernel<64>), grid, dim3(ATTN_THREADS), lds, (hipStream_t)stream, (const bf16_t *)qkv, ld_qkv,
                            (const bf16_t *)cos, (const bf16_t *)sin, cs_stride, (bf16_t *)Kc, (bf16_t *)Vc, (const long long *)pos,
                            (const unsigned char *)mask, mask_stride, (bf16_t *)out, nh, nkv, maxlen, scale);
     LL_LAUNCH_CHECK();

@@ -131,16 +131,16 @@ __global__ __launch_bounds__(64) void kv_append_bf16_kernel(bf16_t *__restrict__
 // Replaces repeat_kv (two full-cache copies) + SDPA + mask fills of the HF sdpa path at decode.  D in {64, 128}.
 // Body in attn_decode.h (shared with the fused rope + append + attention kernel of llm_layer.hip).
 template <int D>
-__global__ __launch_bounds__(256) void decode_attn_bf16_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ K,
+__global__ __launch_bounds__(ATTN_THREADS) void decode_attn_bf16_kernel(const bf16_t *__restrict__ q, const bf16_t *__restrict__ K,
                                                                const bf16_t *__restrict__ V, const unsigned char *__restrict__ mask,
                                                                bf16_t *__restrict__ out, int nh, int nkv, int S, int maxlen,
                                                                float scale, int64_t qs0, int64_t qs1, int64_t qs2,
                                                                int64_t ms0, int64_t ms2) {
     extern __shared__ __attribute__((aligned(16))) float sm_attn[];
     float *qs = sm_attn;                 // [D]     query in f32 (16-B aligned LDS broadcast reads)
-    float *part = qs + D;                // [4 waves][rows per load][D] partial outputs = 2048 floats for either D
-    float *sc = part + 2048;             // [maxlen] scores -> probabilities
-    __shared__ float red[8];
+    float *part = qs + D;                // [waves][rows per load][D] partial outputs = ATTN_PART_FLOATS for either D
+    float *sc = part + ATTN_PART_FLOATS; // [maxlen] scores -> probabilities
+    __shared__ float red[2 * ATTN_WAVES];
     const int h = blockIdx.x, bs = blockIdx.y;
     const int b = bs / S, s = bs - b * S;
     const int kvh = h / (nh / nkv);
@@ -210,14 +210,14 @@ int ll_decode_attn_bf16(const void *q, const void *K, const void *V, const void 
                         int maxlen, int D, float scale, const int64_t *qstr, const int64_t *mstr, void *stream) {
     LL_CHECK(q && K && V && mask && out && qstr && mstr, "null argument");
     LL_CHECK((D == 64 || D == 128) && nh % nkv == 0 && maxlen >= 1 && maxlen <= 16384, "ll_decode_attn_bf16: unsupported shape");
-    const size_t lds = ((size_t)maxlen + D + 2048) * 4;
+    const size_t lds = ((size_t)maxlen + D + ATTN_PART_FLOATS) * 4;
     dim3 grid(nh, B * S);
     if (D == 128)
-        hipLaunchKernelGGL((decode_attn_bf16_kernel<128>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t *)q,
+        hipLaunchKernelGGL((decode_attn_bf16_kernel<128>), grid, dim3(ATTN_THREADS), lds, (hipStream_t)stream, (const bf16_t *)q,
                            (const bf16_t *)K, (const bf16_t *)V, (const unsigned char *)mask, (bf16_t *)out, nh, nkv, S, maxlen,
                            scale, qstr[0], qstr[1], qstr[2], mstr[0], mstr[1]);
     else
-        hipLaunchKernelGGL((decode_attn_bf16_kernel<64>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t *)q,
+        hipLaunchKernelGGL((decode_attn_bf16_kernel<64>), grid, dim3(ATTN_THREADS), lds, (hipStream_t)stream, (const bf16_t *)q,
                            (const bf16_t *)K, (const bf16_t *)V, (const unsigned char *)mask, (bf16_t *)out, nh, nkv, S, maxlen,
                            scale, qstr[0], qstr[1], qstr[2], mstr[0], mstr[1]);
     LL_LAUNCH_CHECK();
