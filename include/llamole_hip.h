@@ -56,6 +56,8 @@ int ll_linear_splitk_bf16(const void *A, int lda, const void *W, int ldw, const 
 /* Tuning utility: average ms of `iters` launches of pipelined-GEMM configuration `cfg` (-1 = the production
  * dispatch) on an [M,K]x[N,K]^T bf16 problem, cycling over `nweights` weight matrices (HBM-resident stream). */
 int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f32, int iters, int nweights, float *ms);
+/* Tuning: waves per workgroup of the <= 64-row panel GEMM (4 | 8; default 8); returns the previous value. */
+int ll_set_m64_waves(int waves);
 
 /* Launch-latency probe (tuning utility): average us per kernel over n launches of a trivial kernel
  * (kind 0 empty, 1 load+store, 2 dependent loads, 3 1-MB copy), eager stream (graph=0) or one hipGraph (graph=1). */

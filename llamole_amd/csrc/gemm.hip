@@ -624,52 +624,62 @@ static int launch_pipe(const bf16_t *A, int lda, const bf16_t *W, int ldw, void 
 //   * each of the 4 waves takes a quarter of the chunk: its weight fragments go straight from global memory into the MFMA
 //     B-operand registers (16 B per lane = 8 consecutive k of one weight row: exactly the operand layout), NS loads;
 //   * 4 NS MFMAs per wave, the four partial 64x16 tiles are summed through LDS in wave order (deterministic).
-template <int NS, typename OutT>
-__global__ __launch_bounds__(256) void gemm_m64_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ W,
-                                                        int ldw, OutT *__restrict__ C, int ldc,
-                                                        const float *__restrict__ bias, int M, int N, int64_t slab_stride,
-                                                        int epi) {
+template <int NS, int WAVES, typename OutT>
+__global__ __launch_bounds__(WAVES * 64) void gemm_m64_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ W,
+                                                              int ldw, OutT *__restrict__ C, int ldc,
+                                                              const float *__restrict__ bias, int M, int N, int64_t slab_stride,
+                                                              int epi) {
+    // WAVES = 8: the activation panel is FRESH (written by the previous launch, so it comes from the Infinity Cache, not this
+    // XCD's L2); pulling 128 KB of it costs 2.2 us with 256 threads holding 32 loads each and 1.4 us with 512 threads holding 16
+    // (tools/phase_floor_probe.hip).  The K chunk is split over the eight waves.  The panel's LDS image has no row padding --
+    // 128 KB of panel + 32 KB of partial tiles is exactly the 160 KB of a CU -- and is made conflict-free by XOR-ing the 16-byte
+    // chunk index with the row's low four bits instead.
+    constexpr int THREADS = WAVES * 64;
     constexpr int KC = NS * 128;
-    constexpr int PITCH = KC * 2 + 16;             // bytes
-    constexpr int CPR = KC / 8;                    // 16-byte chunks per row
-    constexpr int NA = 4 * NS;                     // A chunks per thread: 64 * CPR / 256
+    constexpr int ROWB = KC * 2;                   // bytes per panel row in LDS
+    constexpr int CPR = KC / 8;                    // 16-byte chunks per row (a multiple of 16)
+    constexpr int NA = 64 * CPR / THREADS;         // A chunks per thread
+    constexpr int KS = NS * 4 / WAVES;             // MFMA k-steps (32 k each) per wave
+    static_assert(KS >= 1 && NA >= 1, "K chunk too small for this many waves");
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_m64[];
-    unsigned char *As = sm_m64;                                        // [64][PITCH]
-    float *red = reinterpret_cast<float *>(sm_m64 + 64 * PITCH);       // [4 waves][4 m-tiles][64 lanes][4]
+    unsigned char *As = sm_m64;                                        // [64][ROWB], chunk c of row r at chunk c ^ (r & 15)
+    float *red = reinterpret_cast<float *>(sm_m64 + 64 * ROWB);        // [WAVES][4 m-tiles][64 lanes][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;
     const int kbeg = blockIdx.z * KC;
     u4 areg[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int c = tid + i * 256;
+        const int c = tid + i * THREADS;
         const int row = c / CPR, kc = c - row * CPR;
         areg[i] = row < M ? *reinterpret_cast<const u4 *>(A + (int64_t)row * lda + kbeg + kc * 8) : (u4)(0);
     }
     int wrow = n0 + (lane & 15);
     wrow = wrow < N ? wrow : N - 1;
-    const bf16_t *wp = W + (int64_t)wrow * ldw + kbeg + wave * (NS * 32) + (lane >> 4) * 8;
-    u4 wreg[NS];
+    const bf16_t *wp = W + (int64_t)wrow * ldw + kbeg + wave * (KS * 32) + (lane >> 4) * 8;
+    u4 wreg[KS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) wreg[s] = *reinterpret_cast<const u4 *>(wp + s * 32);
+    for (int s = 0; s < KS; ++s) wreg[s] = *reinterpret_cast<const u4 *>(wp + s * 32);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int c = tid + i * 256;
+        const int c = tid + i * THREADS;
         const int row = c / CPR, kc = c - row * CPR;
-        *reinterpret_cast<u4 *>(As + row * PITCH + kc * 16) = areg[i];
+        *reinterpret_cast<u4 *>(As + row * ROWB + (kc ^ (row & 15)) * 16) = areg[i];
     }
     __syncthreads();
     f32x4 acc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4)(0.f);
-    const unsigned char *ap = As + (lane & 15) * PITCH + (wave * (NS * 32) + (lane >> 4) * 8) * 2;
+    const int fi = lane & 15;                      // row within an m-tile = the swizzle key ((mt * 16 + fi) & 15 = fi)
+    const int c0 = wave * (KS * 4) + (lane >> 4);  // logical 16-byte chunk of this lane's fragment at k-step 0
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    for (int s = 0; s < KS; ++s) {
         const bf16x8 b = __builtin_bit_cast(bf16x8, wreg[s]);
+        const int pc = ((c0 + s * 4) ^ fi) * 16;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(ap + mt * 16 * PITCH + s * 64);
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(As + (mt * 16 + fi) * ROWB + pc);
             acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[mt], 0, 0, 0);
         }
     }
@@ -678,9 +688,10 @@ __global__ __launch_bounds__(256) void gemm_m64_kernel(const bf16_t *__restrict_
     __syncthreads();
     // thread (mt = tid>>6, lane): C rows mt*16 + (lane>>4)*4 + r, column n0 + (lane & 15)
     const int mt = tid >> 6;
+    if (mt >= 4) return;
     f32x4 v = *reinterpret_cast<const f32x4 *>(red + ((0 * 4 + mt) * 64 + lane) * 4);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < WAVES; ++w) {
         const f32x4 t = *reinterpret_cast<const f32x4 *>(red + ((w * 4 + mt) * 64 + lane) * 4);
         v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
     }
@@ -701,22 +712,32 @@ __global__ __launch_bounds__(256) void gemm_m64_kernel(const bf16_t *__restrict_
     }
 }
 
-template <int NS>
-static int launch_m64(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M, int N,
-                      int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
-    constexpr size_t lds = (size_t)64 * (NS * 256 + 16) + 4 * 4 * 64 * 16;
+static int g_m64_waves = 8;     // waves per workgroup of the panel kernel (4 | 8)
+
+template <int NS, int WAVES>
+static int launch_m64_w(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M, int N,
+                        int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
+    constexpr size_t lds = (size_t)64 * (NS * 256) + (size_t)WAVES * 4 * 64 * 16;
+    static_assert(lds <= 160 * 1024, "panel + partial tiles must fit the 160 KB of a CU");
     static bool attr_set = false;
     if (!attr_set) {
-        LL_HIP(hipFuncSetAttribute((const void *)gemm_m64_kernel<NS, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        LL_HIP(hipFuncSetAttribute((const void *)gemm_m64_kernel<NS, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m64_kernel<NS, WAVES, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m64_kernel<NS, WAVES, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid(cdiv(N, 16), 1, splits);
     if (out_f32)
-        hipLaunchKernelGGL((gemm_m64_kernel<NS, float>), grid, dim3(256), lds, s, A, lda, W, ldw, (float *)C, ldc, bias, M, N, slab_stride, epi);
+        hipLaunchKernelGGL((gemm_m64_kernel<NS, WAVES, float>), grid, dim3(WAVES * 64), lds, s, A, lda, W, ldw, (float *)C, ldc, bias, M, N, slab_stride, epi);
     else
-        hipLaunchKernelGGL((gemm_m64_kernel<NS, bf16_t>), grid, dim3(256), lds, s, A, lda, W, ldw, (bf16_t *)C, ldc, bias, M, N, slab_stride, epi);
+        hipLaunchKernelGGL((gemm_m64_kernel<NS, WAVES, bf16_t>), grid, dim3(WAVES * 64), lds, s, A, lda, W, ldw, (bf16_t *)C, ldc, bias, M, N, slab_stride, epi);
     return LL_OK;
+}
+
+template <int NS>
+static int launch_m64(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M, int N,
+                      int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
+    if (g_m64_waves == 8) return launch_m64_w<NS, 8>(A, lda, W, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s);
+    return launch_m64_w<NS, 4>(A, lda, W, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s);
 }
 
 template <int NS>
@@ -1084,6 +1105,12 @@ extern "C" int ll_linear_splitk_bf16(const void *A, int lda, const void *W, int 
     hipLaunchKernelGGL(slab_reduce_bf16_kernel, dim3(blocks), dim3(256), 0, st, workspace, total, splits, bias, (bf16_t *)C, ldc, M, N, epi);
     LL_LAUNCH_CHECK();
     return LL_OK;
+}
+
+extern "C" int ll_set_m64_waves(int waves) {
+    const int old = ll::g_m64_waves;
+    if (waves == 4 || waves == 8) ll::g_m64_waves = waves;
+    return old;
 }
 
 extern "C" int ll_linear(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
