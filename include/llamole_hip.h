@@ -259,6 +259,8 @@ int ll_linear_rows16_bf16(const void *x, int ldx, const void *W, int ldw, const 
 int ll_set_rows16_geometry(int seg, int waves, int ksplit);
 int ll_rows16_bench(int M, int N, int K, int epi, int norm, int iters, int nweights, float *ms);
 int ll_set_gemv_nt(int on);
+/* Tuning: one-row GEMVs without RMSNorm and K >= 8192 (down_proj) stage x in LDS once per workgroup (default on; bit-identical). */
+int ll_set_gemv_stage(int on);
 
 /* ll_sample_token_bf16 : one decode-loop sampling step per row in ONE launch -- HF TemperatureLogitsWarper + TopPLogitsWarper
  *     + softmax + multinomial (transformers generation/logits_process.py, generation/utils.py _sample; the reference reaches

@@ -207,6 +207,61 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const bf16_t *__restric
     }
 }
 
+// gemv_fused_kernel's prologue-free form (down_proj: no RMSNorm, long K) for ONE token row with x staged in LDS: in the
+// generic kernel every wave re-reads its x chunks from L1/L2 next to the weight stream (8 more loads per lane and block,
+// 24 in flight); here the workgroup copies x into LDS once, with its first weight loads already in flight, and the stream
+// keeps 16 loads per lane.  Same FMA order per output row, so the result is bit-identical.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemv_stage_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, int ldw,
+                                                         const float *__restrict__ bias, const bf16_t *__restrict__ res,
+                                                         bf16_t *__restrict__ C, int N, int K) {
+    constexpr int R = 2, UNR = 8, XCS = 10;       // XCS 16-byte chunks of x per thread: K <= 20480
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_gemvs[];
+    bf16_t *xs = reinterpret_cast<bf16_t *>(sm_gemvs);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = blockIdx.x * 4 + (tid >> 6);
+    const int n0 = wave * R;
+    const bool active = n0 < N;
+    const bf16_t *wr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wr[r] = W + (int64_t)(n0 + r < N ? n0 + r : N - 1) * ldw;
+    const int nchunk = K / 8;
+    u32x4 xv0[XCS];
+#pragma unroll
+    for (int c = 0; c < XCS; ++c) {
+        const int ch = tid + c * 256;
+        xv0[c] = ch < nchunk ? *reinterpret_cast<const u32x4 *>(X + ch * 8) : (u32x4)(0);
+    }
+    u32x4 wv[UNR][R];
+    gemv_load_w<UNR, true>(wv, wr, lane, nchunk, active);
+#pragma unroll
+    for (int c = 0; c < XCS; ++c) {
+        const int ch = tid + c * 256;
+        if (ch < nchunk) *reinterpret_cast<u32x4 *>(xs + ch * 8) = xv0[c];
+    }
+    __syncthreads();
+    if (!active) return;
+    float acc[1][R] = {{0.f, 0.f}};
+    gemv_fma<1, UNR, true>(acc, wv, xs, K, lane, nchunk);
+    for (int c0 = lane + 64 * UNR; c0 < nchunk; c0 += 64 * UNR) {
+        gemv_load_w<UNR, true>(wv, wr, c0, nchunk, true);
+        gemv_fma<1, UNR, true>(acc, wv, xs, K, c0, nchunk);
+    }
+    float v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = wave_sum(acc[0][r]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (n0 + r < N) {
+                float o = v[r] + (bias ? bias[n0 + r] : 0.f);
+                if (EPI == GEMV_RESIDUAL) o = bf16_to_f32(res[n0 + r]) + bfr2(o);
+                C[n0 + r] = f32_to_bf16(o);
+            }
+        }
+    }
+}
+
 // Rotary embedding + KV append + GQA decode attention for ONE new position per sequence.
 // grid (nh, B).  qkv row b = [q: nh*D | k: nkv*D | v: nkv*D] (output of the fused q/k/v GEMV).  The new key / value of
 // the head's KV group is rotated in LDS and used from there; the first query head of each group also stores it to the
@@ -297,6 +352,7 @@ __global__ __launch_bounds__(256) void decode_prologue_kernel(const long long *_
 }
 
 static int g_gemv_nt = 1;   // non-temporal weight loads (tools/gemv_fused_sweep.py)
+static int g_gemv_stage = 1;   // one-row GEMVs without RMSNorm stage x in LDS (gemv_stage_kernel)
 
 template <int MROWS, bool NORM, int EPI>
 static void launch_fused(bool nt, dim3 grid, size_t lds, hipStream_t s, const bf16_t *X, int ldx, const bf16_t *W, int ldw,
@@ -344,6 +400,17 @@ static int gemv_fused(bool nt, const void *x, int ldx, const void *W, int ldw, c
     LL_CHECK(!norm_w || (K <= 8192 && (size_t)M * K * 2 <= 65536), "ll_gemv_fused_bf16: RMSNorm prologue needs K <= 8192 and M*K <= 32768");
     const bf16_t *X = (const bf16_t *)x, *Wt = (const bf16_t *)W, *nw = (const bf16_t *)norm_w, *rs = (const bf16_t *)residual;
     bf16_t *C = (bf16_t *)out;
+    if (g_gemv_stage && nt && M == 1 && !nw && epi != GEMV_SILU_MUL && K >= 8192 && K <= 20480) {
+        // one row, no RMSNorm, long K (down_proj): x staged in LDS once per workgroup (down_proj 25.0 -> 23.8 us; for the short K of
+        // o_proj the extra barrier costs more than the eight x loads per block it removes: 6.4 -> 7.0 us)
+        const dim3 grid(cdiv(N, 8));
+        if (epi == GEMV_RESIDUAL)
+            hipLaunchKernelGGL((gemv_stage_kernel<GEMV_RESIDUAL>), grid, dim3(256), (size_t)K * 2, s, X, Wt, ldw, bias, rs, C, N, K);
+        else
+            hipLaunchKernelGGL((gemv_stage_kernel<GEMV_PLAIN>), grid, dim3(256), (size_t)K * 2, s, X, Wt, ldw, bias, rs, C, N, K);
+        LL_LAUNCH_CHECK();
+        return LL_OK;
+    }
     switch (M) {
         case 1: return dispatch_fused<1>(nt, s, X, ldx, Wt, ldw, bias, nw, eps, rs, ldr, C, ldc, N, K, epi);
         case 2: return dispatch_fused<2>(nt, s, X, ldx, Wt, ldw, bias, nw, eps, rs, ldr, C, ldc, N, K, epi);
@@ -438,6 +505,12 @@ int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iter
     if (rc != LL_OK) return rc;
     LL_HIP(he);
     return LL_OK;
+}
+
+int ll_set_gemv_stage(int on) {
+    const int old = g_gemv_stage;
+    g_gemv_stage = on ? 1 : 0;
+    return old;
 }
 
 int ll_set_gemv_nt(int on) {
