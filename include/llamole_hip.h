@@ -141,6 +141,8 @@ int ll_dit_last_run_ms(void *handle, float *ms, int *steps);
 /* Tuning: ln_mod_res with one wave per 256-column chunk of a row (default) or one wave per row; bit-identical results; returns the
  * previous setting. */
 int ll_set_lnmod_multiwave(int on);
+/* Tuning: waves per (sequence, head) of the MFMA graph attention (1 | 2; default 2; bit-identical); returns the previous value. */
+int ll_set_attn_waves(int waves);
 
 /* ------------------------------------------------------------------ GIN encoder / predictor
  * Replaces GNNEncoder.forward + ProjectionHead (src/model/graph_encoder/model.py:124-205) and

@@ -195,15 +195,18 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const T *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------ attention (MFMA, bf16)
-// One 64-lane wave (= one workgroup) per (sequence, head).  The whole graph (N <= 64 nodes) is one tile:
+// One workgroup of one or two 64-lane waves per (sequence, head).  The whole graph (N <= 64 nodes) is one tile:
 //   q,k rows -> f32 LayerNorm(hd) in registers -> bf16 in LDS;  V stored transposed in LDS;
 //   S = Q K^T on v_mfma_f32_16x16x32_bf16, mask + softmax in the MFMA C layout (row reductions are
 //   4-step xor-shuffles inside 16-lane groups), P -> bf16 via LDS, O = P V on MFMA.   (layers.py:56-87)
 typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
 typedef __attribute__((ext_vector_type(4))) float af32x4;
 
-template <int NP, int HD>
-__global__ __launch_bounds__(64) void attn_mfma_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ o,
+// WPB waves per (sequence, head): with two, each wave loads / normalises half the rows (14 instead of 20 loads in flight per
+// lane) and owns half the query rows of S, the softmax and O -- the serial MFMA / softmax chain per wave halves; K and V^T are
+// shared through LDS (two workgroup barriers).  Row-wise arithmetic is unchanged, so the result is bit-identical to WPB = 1.
+template <int NP, int HD, int WPB>
+__global__ __launch_bounds__(64 * WPB) void attn_mfma_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ o,
                                                          const float *__restrict__ qw, const float *__restrict__ qb,
                                                          const float *__restrict__ kw, const float *__restrict__ kb,
                                                          const int *__restrict__ n_nodes, int B, int N, int H,
@@ -215,12 +218,14 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const bf16_t *__restrict_
     constexpr int R0 = QK_ELEMS > P_ELEMS ? QK_ELEMS : P_ELEMS;   // region 0: Q, later P
     constexpr int WAVE_ELEMS = R0 + QK_ELEMS + HD * PLD;          // + K + V^T
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw_attn[];
-    const int wave = 0, lane = threadIdx.x & 63;   // one wave per workgroup (spreads the tiny tiles over more CUs)
+    static_assert(WPB == 1 || WPB == 2, "one or two waves per (sequence, head)");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int head = blockIdx.x;
     if (head >= heads) return;
     const int seq = blockIdx.y;
     const int nv = n_nodes[seq % B];
-    bf16_t *Qs = reinterpret_cast<bf16_t *>(smraw_attn) + (size_t)wave * WAVE_ELEMS;
+    bf16_t *Qs = reinterpret_cast<bf16_t *>(smraw_attn);
+    (void)WAVE_ELEMS;
     bf16_t *Ks = Qs + R0;
     bf16_t *Vt = Ks + QK_ELEMS;
     bf16_t *Ps = Qs;
@@ -231,8 +236,9 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const bf16_t *__restrict_
     {
         constexpr int LPR8 = HD / 8;            // lanes per row
         constexpr int RPP = 64 / LPR8;          // rows per pass
-        constexpr int PASSES = NP / RPP;
-        const int sub = lane % LPR8, rin = lane / LPR8;
+        constexpr int PASSES = NP / RPP / WPB;   // passes of THIS wave: wave w takes rows [w * NP / WPB, (w + 1) * NP / WPB)
+        static_assert(PASSES >= 1, "too few rows for two waves");
+        const int sub = lane % LPR8, rin = lane / LPR8 + wave * (NP / WPB);
         const int d0 = sub * 8;
         uint4 rq[PASSES], rk[PASSES], rv[PASSES];
 #pragma unroll
@@ -299,40 +305,50 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const bf16_t *__restrict_
             }
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (WPB == 1) {
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    } else {
+        __syncthreads();
+    }
 
-    // ---- S = Q K^T
+    // ---- S = Q K^T: this wave's query tiles [wave * MQ, (wave + 1) * MQ) against all key tiles
     constexpr int MT = NP / 16, KS = HD / 32;
-    af32x4 acc[MT][MT];
+    constexpr int MQ = MT / WPB;
+    static_assert(MQ >= 1, "too few query tiles for two waves");
+    const int q0 = wave * MQ;
+    af32x4 acc[MQ][MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MQ; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = af32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fk = lane >> 4;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        abf16x8 fa[MT], fb[MT];
+        abf16x8 fa[MQ], fb[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            fa[i] = *reinterpret_cast<const abf16x8 *>(Qs + (i * 16 + fr) * QLD + ks * 32 + fk * 8);
-            fb[i] = *reinterpret_cast<const abf16x8 *>(Ks + (i * 16 + fr) * QLD + ks * 32 + fk * 8);
-        }
+        for (int i = 0; i < MQ; ++i) fa[i] = *reinterpret_cast<const abf16x8 *>(Qs + ((q0 + i) * 16 + fr) * QLD + ks * 32 + fk * 8);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) fb[i] = *reinterpret_cast<const abf16x8 *>(Ks + (i * 16 + fr) * QLD + ks * 32 + fk * 8);
+#pragma unroll
+        for (int i = 0; i < MQ; ++i)
 #pragma unroll
             for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // all Q reads done before P overwrites region 0
+    if (WPB == 1) {
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // all Q reads done before P overwrites region 0
+    } else {
+        __syncthreads();
+    }
 
     // ---- mask + softmax in the C layout: element r of tile (mt,nt): i = mt*16 + (lane>>4)*4 + r, j = nt*16 + (lane&15)
     const float scale = rsqrtf((float)HD);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MQ; ++mt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int i = mt * 16 + fk * 4 + r;
+            const int i = (q0 + mt) * 16 + fk * 4 + r;
             float mx = -INFINITY;
 #pragma unroll
             for (int nt = 0; nt < MT; ++nt) {
@@ -359,30 +375,30 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const bf16_t *__restrict_
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-    // ---- O = P V
+    // ---- O = P V (this wave's rows of P only: written and read by the same wave)
     constexpr int NT2 = HD / 16, KS2 = NP / 32;
-    af32x4 oc[MT][NT2];
+    af32x4 oc[MQ][NT2];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MQ; ++i)
 #pragma unroll
         for (int j = 0; j < NT2; ++j) oc[i][j] = af32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS2; ++ks) {
-        abf16x8 fa[MT], fb[NT2];
+        abf16x8 fa[MQ], fb[NT2];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const abf16x8 *>(Ps + (i * 16 + fr) * PLD + ks * 32 + fk * 8);
+        for (int i = 0; i < MQ; ++i) fa[i] = *reinterpret_cast<const abf16x8 *>(Ps + ((q0 + i) * 16 + fr) * PLD + ks * 32 + fk * 8);
 #pragma unroll
         for (int j = 0; j < NT2; ++j) fb[j] = *reinterpret_cast<const abf16x8 *>(Vt + (j * 16 + fr) * PLD + ks * 32 + fk * 8);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MQ; ++i)
 #pragma unroll
             for (int j = 0; j < NT2; ++j) oc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], oc[i][j], 0, 0, 0);
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MQ; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int i = mt * 16 + fk * 4 + r;
+            const int i = (q0 + mt) * 16 + fk * 4 + r;
             if (i < N) {
 #pragma unroll
                 for (int nt = 0; nt < NT2; ++nt)

@@ -196,13 +196,19 @@ template <typename T> static void launch_embed(DitEngine *e, hipStream_t st) {
                        e->E.as<int8_t>(), e->wxT.as<float>(), e->pf("x_embedder.1.weight"), e->pf("x_embedder.1.bias"),
                        e->x32.as<float>(), e->xa.as<T>(), e->step_ptr(), e->B, e->cfg.max_nodes, e->cfg.hidden);
 }
+static int g_attn_waves = 2;     // waves per (sequence, head) of attn_mfma_kernel (1 | 2)
+
 template <int NP, int HD>
 static void launch_attn_mfma_t(DitEngine *e, const std::string &p, hipStream_t st) {
     const size_t lds = attn_mfma_lds_bytes<NP, HD>();
-    hipLaunchKernelGGL((attn_mfma_kernel<NP, HD>), dim3(e->cfg.heads, 2 * e->B), dim3(64), lds, st, e->qkv.as<bf16_t>(), e->attn_o.as<bf16_t>(),
-                       e->pfs(p + "q_norm.weight"), e->pfs(p + "q_norm.bias"), e->pfs(p + "k_norm.weight"),
-                       e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, e->cfg.max_nodes, e->cfg.hidden,
-                       e->cfg.heads);
+    if (g_attn_waves == 2)
+        hipLaunchKernelGGL((attn_mfma_kernel<NP, HD, 2>), dim3(e->cfg.heads, 2 * e->B), dim3(128), lds, st, e->qkv.as<bf16_t>(),
+                           e->attn_o.as<bf16_t>(), e->pfs(p + "q_norm.weight"), e->pfs(p + "q_norm.bias"), e->pfs(p + "k_norm.weight"),
+                           e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, e->cfg.max_nodes, e->cfg.hidden, e->cfg.heads);
+    else
+        hipLaunchKernelGGL((attn_mfma_kernel<NP, HD, 1>), dim3(e->cfg.heads, 2 * e->B), dim3(64), lds, st, e->qkv.as<bf16_t>(),
+                           e->attn_o.as<bf16_t>(), e->pfs(p + "q_norm.weight"), e->pfs(p + "q_norm.bias"), e->pfs(p + "k_norm.weight"),
+                           e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, e->cfg.max_nodes, e->cfg.hidden, e->cfg.heads);
 }
 template <typename T> static void launch_attn(DitEngine *e, int layer, hipStream_t st) {
     const int N = e->cfg.max_nodes, hd = e->hd;
@@ -442,10 +448,14 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
     // the generic attention kernel may need > 64 KiB of dynamic LDS (N=64, hd>=64)
     CRH(hipFuncSetAttribute((const void *)attn_generic_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CRH(hipFuncSetAttribute((const void *)attn_generic_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<32, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<32, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<32, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<32, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<32, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     e->force_generic_attn = getenv("LL_GENERIC_ATTN") != nullptr;
     CRH(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
     CRH(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
@@ -715,6 +725,12 @@ int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream) {
     LL_HIP(hipEventRecord(e->ev_out, st));
     LL_HIP(hipStreamWaitEvent(caller, e->ev_out, 0));
     return LL_OK;
+}
+
+int ll_set_attn_waves(int waves) {
+    const int old = g_attn_waves;
+    if (waves == 1 || waves == 2) g_attn_waves = waves;
+    return old;
 }
 
 int ll_set_lnmod_multiwave(int on) {
