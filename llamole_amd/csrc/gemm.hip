@@ -512,8 +512,11 @@ static int launch_gemv_cfg(const bf16_t *A, int lda, const bf16_t *W, int ldw, v
 template <int MROWS>
 static void launch_gemv(const bf16_t *X, int ldx, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int N, int K,
                         int epi, int out_f32, hipStream_t s) {
-    // sweep over the Qwen2-7B / template-head shapes (tools/gemv_sweep.py): 2 rows per wave, 8 x 16 B per row in flight
-    constexpr int R = 2, UNR = MROWS == 1 ? 8 : 4;
+    // sweep over the Qwen2-7B / template-head shapes (tools/gemv_sweep.py): 2 rows per wave, 4 x 16 B per row in flight
+#ifndef LL_GEMV_PLAIN_UNR
+#define LL_GEMV_PLAIN_UNR 4     // see LL_GEMV_UNR in llm_layer.hip
+#endif
+    constexpr int R = 2, UNR = MROWS == 1 ? LL_GEMV_PLAIN_UNR : 4;
     dim3 grid(cdiv(N, 4 * R)), block(256);
     if (out_f32)
         hipLaunchKernelGGL((gemv_bf16_kernel<MROWS, R, UNR, float>), grid, block, 0, s, X, ldx, W, ldw, (float *)C, ldc, bias, N, K, epi);

@@ -17,6 +17,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float bfr2(float v) { return bf16_to_f32(f32_to_bf16(v)); }   // round through bf16
 
 enum { GEMV_PLAIN = 0, GEMV_RESIDUAL = 1, GEMV_SILU_MUL = 2 };
+// 16-byte weight loads per row in flight per lane at one token row (x 2 rows per wave).  Re-swept once the kernels were built with
+// kernel-argument preloading: 4 beats the earlier 8 (q|k|v 9.2 -> 8.2 us, LLM part of a molecule 353.6 -> 347.1 ms with the
+// plain GEMV of lm_head at 4 as well); the FMA order per output row does not depend on it.
+#ifndef LL_GEMV_UNR
+#define LL_GEMV_UNR 4
+#endif
+#ifndef LL_GEMV_STAGE_UNR
+#define LL_GEMV_STAGE_UNR 4
+#endif
 
 template <bool NT> __device__ __forceinline__ u32x4 ldw16(const bf16_t *p) {
     if (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(256) void gemv_fused_kernel(const bf16_t *__restric
                                                          const bf16_t *__restrict__ normw, float eps,
                                                          const bf16_t *__restrict__ res, int ldr, bf16_t *__restrict__ C,
                                                          int ldc, int N, int K) {
-    constexpr int R = 2, UNR = MROWS == 1 ? 8 : 4;
+    constexpr int R = 2, UNR = MROWS == 1 ? LL_GEMV_UNR : 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_gemv[];
     bf16_t *xs = reinterpret_cast<bf16_t *>(sm_gemv);   // NORM: [MROWS][K] normalised x
     __shared__ float red[MROWS][4];
@@ -215,7 +224,7 @@ template <int EPI>
 __global__ __launch_bounds__(256) void gemv_stage_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, int ldw,
                                                          const float *__restrict__ bias, const bf16_t *__restrict__ res,
                                                          bf16_t *__restrict__ C, int N, int K) {
-    constexpr int R = 2, UNR = 8, XCS = 10;       // XCS 16-byte chunks of x per thread: K <= 20480
+    constexpr int R = 2, UNR = LL_GEMV_STAGE_UNR, XCS = 10;       // XCS 16-byte chunks of x per thread: K <= 20480
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_gemvs[];
     bf16_t *xs = reinterpret_cast<bf16_t *>(sm_gemvs);
     const int tid = threadIdx.x, lane = tid & 63;
