@@ -137,6 +137,10 @@ int ll_dit_step_probs(void *handle, int s, float *pX, float *pE, void *stream);
 int ll_dit_cvec(void *handle, int s, float *c, void *stream);
 
 /* Timing of the most recent ll_dit_run measured with HIP events on `stream`: total ms and steps. */
+/* ll_dit_set_overlap : on = the next ll_dit_run trajectories run NEXT TO another stream's kernels (GraphDiT.generate_graphs_async
+ *     under the LLM decode of the next prompt): their <= 64-row panel GEMMs take the 48 KB LDS-DMA ring instead of the panel kernel,
+ *     whose workgroups need a whole CU's LDS (slower alone, faster for the pair); a separate captured step is kept per mode. */
+int ll_dit_set_overlap(void *handle, int on);
 int ll_dit_last_run_ms(void *handle, float *ms, int *steps);
 /* Tuning: ln_mod_res with one wave per 256-column chunk of a row (default) or one wave per row; bit-identical results; returns the
  * previous setting. */

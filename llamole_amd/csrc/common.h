@@ -136,6 +136,10 @@ int linear_splitk_launch(int dtype, const void *A, int lda, const void *W, int l
 
 int convert_f32_to_bf16(const float *src, bf16_t *dst, int64_t n, hipStream_t stream);
 
+// <= 64-row panels: gemm_m64_kernel (a whole CU's LDS per workgroup; fastest alone) or, when off, the LDS-DMA ring (48 KB: leaves room for
+// the workgroups of a concurrent stream).  Consulted at launch / capture time by linear_launch and linear_splitk_launch.
+void set_panel_gemm(bool on);
+
 // weight-streaming MFMA Linear for 1..16 rows of bf16 x (llm_rows16.hip); out bf16, or f32 with the plain epilogue
 int linear_rows16_launch(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *norm_w, float eps,
                          const void *residual, int ldr, void *out, int ldc, int M, int N, int K, int epi, int out_f32, hipStream_t stream);

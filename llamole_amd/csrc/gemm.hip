@@ -751,6 +751,9 @@ static int launch_m64_cfg(const bf16_t *A, int lda, const bf16_t *W, int ldw, vo
 }
 
 static int g_gemm_variant = -1;  // LL_GEMM_VARIANT=0 forces the 2-stage register-staged kernels (A/B testing)
+static int g_no_panel_gemm = 0;  // set_panel_gemm(false): <= 64-row panels take the LDS-DMA ring (48 KB of LDS) instead of gemm_m64_kernel
+
+void set_panel_gemm(bool on) { g_no_panel_gemm = on ? 0 : 1; }
 
 static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
                          int M, int N, int K, int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
@@ -777,7 +780,7 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
             LL_LAUNCH_CHECK();
             return LL_OK;
         }
-        if (g_gemm_variant != 0 && g_gemm_variant != 2 && M <= 64 && (kchunk == 256 || kchunk == 512 || kchunk == 1024) &&
+        if (g_gemm_variant != 0 && g_gemm_variant != 2 && !g_no_panel_gemm && M <= 64 && (kchunk == 256 || kchunk == 512 || kchunk == 1024) &&
             (long)cdiv(N, 16) * splits >= 48) {
             // one molecule's token panel (GraphDiT at batch 1, small GIN batches): everything in flight at once
             if (kchunk == 1024) LL_TRY((launch_m64<8>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));

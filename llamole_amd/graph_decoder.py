@@ -374,8 +374,12 @@ class GraphDiT(nn.Module):
                                            _lib.current_stream_ptr()), "ll_dit_step")
         self._keep_noise = (qx, qe)
 
-    def run(self, seed: int = 0, use_graph: bool = True):
-        _lib.check(_lib.load().ll_dit_run(self._handle, C.c_uint64(seed), int(use_graph), _lib.current_stream_ptr()), "ll_dit_run")
+    def run(self, seed: int = 0, use_graph: bool = True, overlap: bool = False):
+        """``overlap``: the trajectory runs next to another stream's kernels (generate_graphs_async under the LLM decode of the
+        next prompt): the engine then keeps its panel GEMMs on the small-LDS ring so that both streams' workgroups fit a CU."""
+        lib = _lib.load()
+        _lib.check(lib.ll_dit_set_overlap(self._handle, int(overlap)), "ll_dit_set_overlap")
+        _lib.check(lib.ll_dit_run(self._handle, C.c_uint64(seed), int(use_graph), _lib.current_stream_ptr()), "ll_dit_run")
 
     def last_run_ms(self) -> Tuple[float, int]:
         ms, steps = C.c_float(), C.c_int()
@@ -476,7 +480,7 @@ class GraphDiT(nn.Module):
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             self.init_state(qx, qe, seed)
-            self.run(seed, use_graph)
+            self.run(seed, use_graph, overlap=getattr(self, "async_overlap_mode", True))
             X, E = self.get_state()
         for t in (properties, text_embedding):
             if torch.is_tensor(t) and t.is_cuda:

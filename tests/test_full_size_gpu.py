@@ -121,7 +121,18 @@ def test_graphdit_ref_default_trajectory_properties():
     b = run()
     c = run(use_graph=False)
     torch.manual_seed(5)
+    m.async_overlap_mode = False          # same kernels as the synchronous path -> same graphs bit for bit
     d = m.generate_graphs_async(props, text, -200.0, n_nodes=n_nodes, seed=42).result()[0]
+    torch.manual_seed(5)
+    m.async_overlap_mode = True           # default: panel GEMMs on the small-LDS ring (other accumulation order)
+    d_ov = m.generate_graphs_async(props, text, -200.0, n_nodes=n_nodes, seed=42).result()[0]
+    torch.manual_seed(5)
+    d_ov2 = m.generate_graphs_async(props, text, -200.0, n_nodes=n_nodes, seed=42).result()[0]
+    for i, (x, e) in enumerate(d_ov):
+        n = int(n_nodes[i])
+        assert x.shape == (n,) and e.shape == (n, n) and torch.equal(e, e.t()) and int(torch.diagonal(e).abs().sum()) == 0
+        assert int(x.min()) >= 0 and int(x.max()) < 16 and int(e.min()) >= 0 and int(e.max()) < 5
+        assert torch.equal(x, d_ov2[i][0]) and torch.equal(e, d_ov2[i][1])          # deterministic in its own mode
     for i, (x, e) in enumerate(a):
         n = int(n_nodes[i])
         assert x.shape == (n,) and e.shape == (n, n)
