@@ -244,6 +244,8 @@ def main():
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="e2e: run LLM decode and GraphDiT of a batch back to back instead of overlapping the reverse diffusion "
                          "of batch i with the LLM decode of batch i+1")
+    ap.add_argument("--dit-group", type=int, default=1,
+                    help="e2e pipeline: batch the reverse diffusions of this many consecutive prompt batches into one trajectory")
     ap.add_argument("--no-llm-fuse", dest="llm_fuse", action="store_false",
                     help="keep HF's op-by-op RMSNorm / rotary / SiLU*mul at decode instead of the fused HIP kernels")
     ap.add_argument("--llm-decode", default="graph", choices=["graph", "eager", "hf"])
@@ -299,6 +301,8 @@ def main():
     for i in range(args.warmup):
         step_fn(i)
         log("warmup", i)
+    if getattr(step_fn, "pipeline", False):
+        step_fn.finish()                 # no trajectory of a warm-up prompt is left for the timed region
     barrier()
     t0 = time.perf_counter()
     dit_ms = []
@@ -320,7 +324,7 @@ def main():
         dt = float(tmax.item())
         # the path's only exchange: ONE all-gather of the generated integer graphs (fixed-size records)
         from llamole_amd.distributed import all_gather_graphs
-        gathered = all_gather_graphs(mols, N, world * B, device=device if dist.get_backend() == "nccl" else None)
+        gathered = all_gather_graphs((mols or [])[-B:], N, world * B, device=device if dist.get_backend() == "nccl" else None)
         assert len(gathered) == world * B
     if rank != 0:
         if dist is not None:

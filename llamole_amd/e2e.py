@@ -142,7 +142,9 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
     last = {}
 
     pipeline = bool(getattr(args, "pipeline", True))
+    group = max(1, int(getattr(args, "dit_group", 1))) if pipeline else 1
     pending = {"h": None}
+    waiting = []          # (props, cond) of prompts whose trajectory has not been enqueued yet (diffusion batched over `group` prompts)
     dit_ms: list = []
 
     def collect():
@@ -153,10 +155,26 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
         dit_ms.append(h.run_ms)
         return mols
 
+    def launch_group():
+        """Enqueue ONE reverse diffusion for the prompts waiting: their conditions form a batch, so the ~10^4 kernel launches of a
+        trajectory -- each of which also costs the concurrently decoding LLM stream a dispatch slot -- are shared by `group` molecules."""
+        if not waiting:
+            return
+        g_props = torch.cat([w[0] for w in waiting], dim=0)
+        g_cond = torch.cat([w[1] for w in waiting], dim=0)
+        k = len(waiting)
+        del waiting[:]
+        pending["h"] = graph_decoder.generate_graphs_async(g_props, g_cond.float(), -200.0, n_nodes=n_nodes.repeat(k)[: g_props.shape[0]],
+                                                           seed=1000 * rank + launch_group.count, use_graph=not args.no_graph)
+        launch_group.count += 1
+
+    launch_group.count = 0
+
     def step_fn(i):
         """One prompt batch.  Pipelined (default): the reverse diffusion of batch i is enqueued on a side stream and
-        overlaps the LLM decode of batch i+1 (independent prompts); returns the molecules of the PREVIOUS batch, the last
-        batch is collected by ``step_fn.finish()`` inside the timed region."""
+        overlaps the LLM decode of batch i+1 (independent prompts); with ``dit_group`` = k the trajectories of k consecutive
+        prompt batches are ONE batched trajectory enqueued after the k-th decode.  Returns the molecules that completed since
+        the last call (or None), the rest is collected by ``step_fn.finish()`` inside the timed region."""
         torch.manual_seed(1000 * rank + i)
         t0 = time.perf_counter()
         analysis, design_ids, cond = orch.design_hidden(prompt, mask, None, **kw)
@@ -164,9 +182,11 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
             torch.cuda.synchronize()
         t1 = time.perf_counter()
         if pipeline:
-            prev = collect()
-            pending["h"] = graph_decoder.generate_graphs_async(props, cond.float(), -200.0, n_nodes=n_nodes, seed=1000 * rank + i,
-                                                               use_graph=not args.no_graph)
+            waiting.append((props, cond))
+            prev = None
+            if len(waiting) >= group:
+                prev = collect()
+                launch_group()
             last.update(llm_enqueue_s=t1 - t0, new_tokens=int(analysis.shape[1]), **orch.timings)
             return prev
         mols, _ = graph_decoder.generate_graphs(props, cond.float(), -200.0, n_nodes=n_nodes, seed=1000 * rank + i,
@@ -176,9 +196,18 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
         last.update(llm_s=t1 - t0, graphdit_s=t2 - t1, new_tokens=int(analysis.shape[1]), **orch.timings)
         return mols
 
-    step_fn.finish = collect
+    def finish():
+        out = collect()
+        if waiting:               # a last, smaller group
+            launch_group()
+            more = collect()
+            out = (out or []) + (more or [])
+        return out
+
+    step_fn.finish = finish
     step_fn.dit_ms = dit_ms
     step_fn.pipeline = pipeline
+    step_fn.group = group
 
     n_params = sum(p.numel() for p in llm.parameters())
     info = {"llm": args.llm, "llm_params": n_params, "llm_weights": "random-init (no network)", "prompt_len": args.cutoff_len,
@@ -188,7 +217,9 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
             "llm_linear": ("ll_linear (HIP weight-streaming GEMV) under %d nn.Linear modules for decode-shaped calls" % n_accel)
                           if n_accel else "PyTorch-ROCm default (hipBLASLt)",
             "llm_fused_elementwise": fused,
-            "pipeline": ("GraphDiT of prompt batch i runs on a side HIP stream and overlaps the LLM decode of batch i+1"
+            "pipeline": (("GraphDiT of prompt batch i runs on a side HIP stream and overlaps the LLM decode of batch i+1" if group == 1 else
+                          f"the reverse diffusions of {group} consecutive prompt batches run as ONE batched trajectory on a side HIP stream "
+                          f"and overlap the LLM decodes of the next {group}")
                          if pipeline else "none (LLM decode, then GraphDiT, per batch)"),
             "timing_breakdown": last}
     return step_fn, info, orch, llm
