@@ -12,7 +12,8 @@
 // A workgroup of `waves` waves (4 or 8) owns waves / ksplit row tiles; `ksplit` consecutive waves split K of one tile and
 // their partial tiles are summed through LDS in wave order (deterministic).  What limits a wave is its own latency chain
 // (load -> LDS -> fragment read -> MFMA), so the launcher splits K until there are ~14 waves per CU (tools/rows16_sweep.py):
-// lm_head 4 waves x ksplit 1, gate|up and q|k|v 4 x 4 (52 KB of LDS per workgroup: three per CU), o_proj / down_proj 8 x 8.
+// lm_head and the GIN template head 4 waves x ksplit 2, gate|up and q|k|v 4 x 4 (52 KB of LDS per workgroup: three per CU),
+// o_proj / down_proj 8 x 8.
 // Epilogues as ll_gemv_fused_bf16 (same intermediate bf16 roundings as PyTorch's op-by-op evaluation).  RMSNorm prologue
 // (norm_w != NULL): x is multiplied by the norm weight while it is staged, x' = bf16(x * w), the waves accumulate sum(x^2)
 // of their K slice on the side, and rsqrt(mean(x^2) + eps) of the token row scales the accumulator in the epilogue -- the
@@ -234,6 +235,7 @@ static int launch_rows16(hipStream_t s, const bf16_t *X, int ldx, const bf16_t *
         while (ksplit < 8 && ntiles * ksplit < 3500) ksplit *= 2;
         waves = ksplit <= 4 ? 4 : 8;
         if (ksplit == 8 && ntiles * 4 >= 1100) seg = 256, waves = 4, ksplit = 4;      // q|k|v (288 tiles): 11.1 us vs 12.5
+        if (ksplit == 1) seg = 256, ksplit = 2;     // thousands of tiles (lm_head, GIN template head): 4 x 2 beats 4 x 1 (127 vs 141 us on the head)
     }
     if (seg == 128) return launch_rows16_seg<EPI, 128, NORM>(waves, ksplit, s, X, ldx, W, ldw, bias, normw, eps, res, ldr, C, ldc, M, N, K, out_f32);
     if (seg == 256) return launch_rows16_seg<EPI, 256, NORM>(waves, ksplit, s, X, ldx, W, ldw, bias, normw, eps, res, ldr, C, ldc, M, N, K, out_f32);
