@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 from llamole_amd import synth  # noqa: E402
 
+LLM_LABEL = {"qwen2-7b": "Qwen2-7B", "llama-3.1-8b": "Llama-3.1-8B", "mistral-7b": "Mistral-7B"}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0
 
@@ -215,6 +216,45 @@ def time_dominant_kernel(args, device):
     return ms.value, nbytes, flops, name, key
 
 
+def spawn_ranks(n: int) -> int:
+    """Start `n` copies of this command, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, the
+    contract of torch.distributed.run), wait for all of them, return non-zero if any failed.  Rank 0's stdout (the JSON
+    line) is this process's stdout.  No GPU call is made here."""
+    import socket
+    import subprocess
+    shared = os.environ.get("LLAMOLE_BENCH_SHARED_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not shared:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for r, p in enumerate(procs):
+            code = p.wait()
+            if code != 0:
+                print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+                rc = rc or (code if code > 0 else 1)
+                for q in procs:          # a dead rank would leave the others waiting in a collective
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,15 +292,27 @@ def main():
     ap.add_argument("--blas", default="default", choices=["default", "hipblaslt", "hipblas"])
     ap.add_argument("--llm-linear", default="hip", choices=["hip", "torch"],
                     help="kernel under nn.Linear for decode-shaped LLM calls: libllamole_hip GEMV or PyTorch's BLAS")
+    ap.add_argument("--total-prompts", type=int, default=None,
+                    help="strong scaling: one step = this many prompts over ALL ranks (BASELINE configs[3]: 64 prompts, 8 per GPU at "
+                         "8 GPUs); every rank runs its contiguous share in batches of --batch.  Default: weak scaling, --batch per GPU")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this parent starts the N ranks itself, BEFORE it makes any GPU call
+        # (a process that has initialised the GPU must not exec/replace itself on this pool; device_count() does not initialise)
+        raise SystemExit(spawn_ranks(args.gpus))
     if args.batch is None:
-        args.batch = 8 if args.workload == "graphdit" else 1
+        args.batch = 8 if (args.workload == "graphdit" or args.total_prompts) else 1
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" in os.environ and args.gpus != world:
+        log(f"--gpus {args.gpus} overridden by the launcher's WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    shared_gpu = os.environ.get("LLAMOLE_BENCH_SHARED_GPU") == "1"     # single-GPU dry run of the N > 1 path (tests)
+    if world > torch.cuda.device_count() and not shared_gpu:
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, this node shows {torch.cuda.device_count()}")
     dev_index = local_rank % torch.cuda.device_count()    # == local_rank on a real node (one process per GPU)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -276,6 +328,20 @@ def main():
 
     if args.blas != "default":
         torch.backends.cuda.preferred_blas_library(args.blas)
+    n_ranks = 1
+    if dist is not None:
+        # n_gpus of the JSON line is what the collective backend actually connected, not an environment variable
+        ones = torch.ones(1, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        n_ranks = int(ones.item())
+        assert n_ranks == world, (n_ranks, world)
+    from llamole_amd.distributed import shard_range
+    batches_per_step = 1
+    if args.total_prompts:
+        share = len(shard_range(args.total_prompts, rank, world))
+        if args.total_prompts % world or share % args.batch:
+            raise SystemExit(f"--total-prompts {args.total_prompts} must split into whole batches of {args.batch} on {world} rank(s)")
+        batches_per_step = share // args.batch
     m, cfg, meta, sd = build_model(args, device)
     log("model built")
     B, N, T = args.batch, args.nodes, args.T
@@ -298,7 +364,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    nb = batches_per_step          # prompt batches of this rank per step (1 unless --total-prompts)
+    for i in range(args.warmup * nb):
         step_fn(i)
         log("warmup", i)
     if getattr(step_fn, "pipeline", False):
@@ -309,29 +376,34 @@ def main():
     piped = bool(getattr(step_fn, "pipeline", False))
     if piped:
         del step_fn.dit_ms[:]
-    for i in range(args.steps):
-        mols = step_fn(args.warmup + i)
+    done = []                            # molecules this rank produced in the timed region, in prompt order
+    for i in range(args.steps * nb):
+        mols = step_fn(args.warmup * nb + i)
         if not piped:
             dit_ms.append(m.last_run_ms()[0])
+        done.extend(mols or [])
     if piped:
-        mols = step_fn.finish()          # the last batch's trajectory completes inside the timed region
-        dit_ms = list(step_fn.dit_ms)[-args.steps:]
+        done.extend(step_fn.finish() or [])    # the last batch's trajectory completes inside the timed region
+        dit_ms = list(step_fn.dit_ms)[-args.steps * nb:]
     barrier()
     dt = time.perf_counter() - t0
+    assert len(done) == args.steps * nb * B, (len(done), args.steps, nb, B)
+    gathered_n = len(done[-nb * B:])
     if dist is not None:
         tmax = torch.tensor([dt], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        # the path's only exchange: ONE all-gather of the generated integer graphs (fixed-size records)
+        # the path's only exchange: ONE all-gather of the generated integer graphs of a step (fixed-size records)
         from llamole_amd.distributed import all_gather_graphs
-        gathered = all_gather_graphs((mols or [])[-B:], N, world * B, device=device if dist.get_backend() == "nccl" else None)
-        assert len(gathered) == world * B
+        gathered = all_gather_graphs(done[-nb * B:], N, world * nb * B, device=device if dist.get_backend() == "nccl" else None)
+        assert len(gathered) == world * nb * B
+        gathered_n = len(gathered)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    mol_per_s = world * B * args.steps / dt
+    mol_per_s = world * nb * B * args.steps / dt
     step_ms = float(np.mean(dit_ms)) / T
     step_ms_overlapped = None
     if piped:
@@ -372,11 +444,15 @@ def main():
     out = {
         "metric": "generated molecules/sec (end-to-end)" if args.workload == "e2e"
                   else "generated molecules/sec (GraphDiT reverse diffusion, no LLM)",
-        "value": mol_per_s, "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": mol_per_s, "unit": "molecules/s", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "strong" if args.total_prompts else "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": ("Qwen2-7B + GraphDiT material design, batch=%d/GPU" % B) if args.workload == "e2e"
-                   else "GraphDiT %d-step reverse diffusion on %d synthetic %d-node graphs/GPU, no LLM" % (T, B, N),
+        "config": {"workload": (("%s + GraphDiT design, " % LLM_LABEL.get(args.llm, args.llm)) +
+                                (("%d prompts per step sharded over %d GPU(s) in batches of %d" % (args.total_prompts, n_ranks, B))
+                                 if args.total_prompts else "batch=%d/GPU" % B)) if args.workload == "e2e"
+                   else "GraphDiT %d-step reverse diffusion on %d synthetic %d-node graphs/GPU, no LLM" % (T, nb * B, N),
+                   "prompts_per_step": world * nb * B, "gathered_molecules": gathered_n,
                    "denoiser": {"hidden": args.hidden, "depth": args.depth, "heads": args.heads, "max_nodes": N,
                                 "T": T, "guide_scale": args.guide},
                    "hip_graph": not args.no_graph, **e2e_info},

@@ -141,6 +141,11 @@ int ll_dit_cvec(void *handle, int s, float *c, void *stream);
  *     under the LLM decode of the next prompt): their <= 64-row panel GEMMs take the 48 KB LDS-DMA ring instead of the panel kernel,
  *     whose workgroups need a whole CU's LDS (slower alone, faster for the pair); a separate captured step is kept per mode. */
 int ll_dit_set_overlap(void *handle, int on);
+/* ll_dit_set_option : per-engine switches, effective for every later denoiser call of this handle (step / run / denoise /
+ * step_probs).  LL_DIT_OPT_OVERLAP = ll_dit_set_overlap; LL_DIT_OPT_GENERIC_ATTN = run the f32-LDS attention kernel under the
+ * bf16 engine instead of the MFMA one (parity hook: the two are compared on identical q|k|v by the tests). */
+enum { LL_DIT_OPT_OVERLAP = 0, LL_DIT_OPT_GENERIC_ATTN = 1 };
+int ll_dit_set_option(void *handle, int option, int value);
 int ll_dit_last_run_ms(void *handle, float *ms, int *steps);
 /* Tuning: ln_mod_res with one wave per 256-column chunk of a row (default) or one wave per row; bit-identical results; returns the
  * previous setting. */

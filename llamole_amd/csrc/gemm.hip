@@ -751,7 +751,7 @@ static int launch_m64_cfg(const bf16_t *A, int lda, const bf16_t *W, int ldw, vo
 }
 
 static int g_gemm_variant = -1;  // LL_GEMM_VARIANT=0 forces the 2-stage register-staged kernels (A/B testing)
-static int g_no_panel_gemm = 0;  // set_panel_gemm(false): <= 64-row panels take the LDS-DMA ring (48 KB of LDS) instead of gemm_m64_kernel
+static thread_local int g_no_panel_gemm = 0;  // per host thread; set_panel_gemm(false): <= 64-row panels take the LDS-DMA ring (48 KB of LDS) instead of gemm_m64_kernel
 
 void set_panel_gemm(bool on) { g_no_panel_gemm = on ? 0 : 1; }
 

@@ -188,6 +188,13 @@ struct DitEngine {
     float *t_ab() const { return tab(184 + cfg.T + 1); }
 };
 
+// Panel-GEMM choice of this engine for the calls made inside the scope (the flag gemm_dispatch consults is per host thread):
+// overlap mode keeps <= 64-row panels on the 48 KB LDS-DMA ring, everything else on gemm_m64_kernel.
+struct PanelScope {
+    explicit PanelScope(const DitEngine *e) { set_panel_gemm(!e->overlap); }
+    ~PanelScope() { set_panel_gemm(true); }
+};
+
 static void drop_graph(DitEngine *e) {
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
@@ -632,6 +639,7 @@ int ll_dit_step(void *handle, int s, const float *qx, const float *qe, uint64_t 
     LL_CHECK(s >= 0 && s < e->cfg.T, "step %d out of range [0,%d)", s, e->cfg.T);
     LL_CHECK((qx == nullptr) == (qe == nullptr), "qx and qe must both be given or both be null");
     hipStream_t st = (hipStream_t)stream;
+    PanelScope panel(e);
     LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), s, e->seed_ptr(), (unsigned long long)seed);
     LL_LAUNCH_CHECK();
@@ -647,6 +655,7 @@ int ll_dit_denoise(void *handle, int s, float *logX, float *logE, float *hidden,
     LL_TRY(check_ready(e, true));
     LL_CHECK(s >= 0 && s < e->cfg.T, "step %d out of range", s);
     hipStream_t st = (hipStream_t)stream;
+    PanelScope panel(e);
     LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), s, e->seed_ptr(), 0ull);
     LL_TRY(denoise_body(e, st, hidden, tap_layer));
@@ -659,6 +668,7 @@ int ll_dit_denoise_rows(void *handle, const int32_t *t_int, float *logX, float *
     LL_CHECK(t_int && logX && logE, "null argument");
     hipStream_t st = (hipStream_t)stream;
     const int T = e->cfg.T;
+    PanelScope panel(e);
     // the state the denoiser reads is the one a reverse step s = T-1 would read (set by ll_dit_set_state)
     LL_TRY(ensure_state_half(e, T & 1, st));
     LL_TRY(e->rows.ensure((size_t)e->B * 4));
@@ -677,6 +687,7 @@ int ll_dit_step_probs(void *handle, int s, float *pX, float *pE, void *stream) {
     LL_TRY(check_ready(e, true));
     LL_CHECK(s >= 0 && s < e->cfg.T, "step %d out of range", s);
     hipStream_t st = (hipStream_t)stream;
+    PanelScope panel(e);
     LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), s, e->seed_ptr(), 0ull);
     LL_TRY(denoise_body(e, st, nullptr, -1));
@@ -706,10 +717,7 @@ int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream) {
     // overlap mode: the trajectory runs next to another stream's kernels (the LLM decode of the next prompt); gemm_m64_kernel's
     // workgroups need a whole CU's LDS and keep that stream's workgroups off the CU (and wait for a drained CU themselves), so the
     // panel GEMMs take the 48 KB LDS-DMA ring there: 1.36 instead of 1.17 ms per step alone, but +1.2 % molecules/s end to end
-    set_panel_gemm(!e->overlap);
-    struct PanelGuard {
-        ~PanelGuard() { set_panel_gemm(true); }     // every exit path: other engines / the GIN path keep the panel kernel
-    } panel_guard;
+    PanelScope panel(e);      // restored on every exit path: other engines / the GIN path keep the panel kernel
     if (use_graph) {
         hipGraph_t &graph = e->overlap ? e->graph_ov : e->graph;
         hipGraphExec_t &gexec = e->overlap ? e->gexec_ov : e->gexec;
@@ -754,6 +762,20 @@ int ll_dit_set_overlap(void *handle, int on) {
     DitEngine *e = (DitEngine *)handle;
     LL_CHECK(e, "ll_dit_set_overlap: null handle");
     e->overlap = on ? 1 : 0;
+    return LL_OK;
+}
+
+int ll_dit_set_option(void *handle, int option, int value) {
+    DitEngine *e = (DitEngine *)handle;
+    LL_CHECK(e, "ll_dit_set_option: null handle");
+    switch (option) {
+        case LL_DIT_OPT_OVERLAP: e->overlap = value ? 1 : 0; break;
+        case LL_DIT_OPT_GENERIC_ATTN:
+            if (e->force_generic_attn != (value != 0)) drop_graph(e);      // captured steps hold the other kernel
+            e->force_generic_attn = value != 0;
+            break;
+        default: LL_CHECK(false, "ll_dit_set_option: unknown option %d", option);
+    }
     return LL_OK;
 }
 

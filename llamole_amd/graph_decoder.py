@@ -336,6 +336,9 @@ class GraphDiT(nn.Module):
     @torch.no_grad()
     def begin(self, properties: torch.Tensor, text_embedding: torch.Tensor, no_label_index, n_nodes=None):
         """Start a batch on the engine; returns n_nodes (CPU int64)."""
+        if getattr(self, "_pending", None) is not None:
+            # the engine's tables, state and captured step belong to the trajectory still in flight on the side stream
+            raise RuntimeError("a generate_graphs_async trajectory is still pending on this engine: call .result() on it first")
         self._ensure_engine()
         dev = self._device()
         props = properties.detach().to(device=dev, dtype=torch.float32)
@@ -380,6 +383,13 @@ class GraphDiT(nn.Module):
         lib = _lib.load()
         _lib.check(lib.ll_dit_set_overlap(self._handle, int(overlap)), "ll_dit_set_overlap")
         _lib.check(lib.ll_dit_run(self._handle, C.c_uint64(seed), int(use_graph), _lib.current_stream_ptr()), "ll_dit_run")
+
+    ENGINE_OPTIONS = {"overlap": 0, "generic_attn": 1}
+
+    def set_option(self, name: str, value: int):
+        """Per-engine switch (include/llamole_hip.h: ll_dit_set_option), effective for every later denoiser call."""
+        self._ensure_engine()
+        _lib.check(_lib.load().ll_dit_set_option(self._handle, self.ENGINE_OPTIONS[name], int(value)), "ll_dit_set_option")
 
     def last_run_ms(self) -> Tuple[float, int]:
         ms, steps = C.c_float(), C.c_int()

@@ -189,10 +189,11 @@ def test_free_running_trajectory_vs_reference_golden(case):
         assert torch.equal(e, e.t())
         mism += int((a.numpy() != g[f"mol{i}_atoms"]).sum()) + int((e.numpy() != g[f"mol{i}_bonds"]).sum())
         tot += a.numel() + e.numel()
-    # a single near-tie flip early in a trajectory changes everything after it, so this is reported,
-    # and bounded loosely; the teacher-forced test above is the bit-exact statement.
+    # a single near-tie flip early in a trajectory changes everything after it; observed on MI355X (round 2): 0/1874 and
+    # 0/3282 entries differ, i.e. the free-running f32 trajectories are bit-identical to the reference's.  The bound leaves room
+    # for ONE late flip (a few entries); the teacher-forced test above is the per-step bit-exact statement.
     print(f"free-running mismatch {mism}/{tot}")
-    assert mism / tot <= 0.25
+    assert mism / tot <= 0.02, f"free-running mismatch {mism}/{tot}"
 
 
 def test_graph_replay_equals_eager_and_is_deterministic(case):

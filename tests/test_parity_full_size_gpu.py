@@ -1,0 +1,219 @@
+"""Oracle parity of the engines that are actually benchmarked, at the benchmarked sizes.
+
+  * GraphDiT, bf16 engine, ref-default denoiser (H=1024, L=28, 16 heads, N=32; reference transformer.py:27-36), B=1 and
+    B=8 (BASELINE configs[1] / configs[0]), in BOTH engine modes -- the synchronous one (panel GEMMs) and the overlap mode the
+    pipelined e2e bench runs (LDS-DMA ring): z_T bit-exact, per-block hidden-state drift (taps after the embedder and after
+    blocks 7, 14, 28), logit error, total variation of the guided step probabilities, agreement of the exponential-race
+    winners under injected noise -- all against oracle.guided_probs / oracle.denoiser on the same (bf16-rounded) weights.
+  * attn_mfma_kernel against attn_generic_kernel on identical bf16 q|k|v, all four <NP,HD> instances, ragged n_nodes incl. 1.
+  * GIN predictor at BASELINE configs[2] size (H=512, L=5, 180 576 templates, 16 graphs, bf16 engine, f32-output rows16
+    template head) against gin_oracle: logits, top-50 probabilities and index sets.
+
+Tolerances are the measured values of round 2 (profiles/r2_parity_full_size.json) plus margin; they are asserted here and
+quoted in DESIGN.md section 3.  The measured numbers are also written to gpurun_out/r2_parity_full_size.json.
+"""
+import json
+import os
+import tempfile
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from llamole_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = {}
+
+
+def _report(key, val):
+    REPORT[key] = val
+    try:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "r2_parity_full_size.json"), "w") as f:
+            json.dump(REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+# ------------------------------------------------------------------------------------------ GraphDiT at the benchmarked size
+@pytest.fixture(scope="module")
+def full_dit():
+    import bench
+    from oracle import graphdit_oracle as do
+    args = types.SimpleNamespace(hidden=1024, depth=28, heads=16, T=50, guide=2.0, nodes=32, dtype="bf16")
+    m, cfg, meta, sd = bench.build_model(args, torch.device("cuda"))
+    # the engine sees the bf16-cast parameters (reference loader.py:245-247); the oracle gets the same values in f32
+    sd_cpu = {k: v.detach().to(torch.bfloat16).float().cpu() for k, v in sd.items()}
+    spec = do.build_spec(cfg, meta)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    return m, spec, sd_cpu, do
+
+
+def _upper(n_nodes, N):
+    B = len(n_nodes)
+    um = torch.zeros(B, N, N, dtype=torch.bool)
+    for b in range(B):
+        n = int(n_nodes[b])
+        um[b, :n, :n] = torch.triu(torch.ones(n, n, dtype=torch.bool), 1)
+    return um
+
+
+@pytest.mark.parametrize("overlap", [0, 1], ids=["panel", "overlap"])
+@pytest.mark.parametrize("B", [1, 8])
+def test_graphdit_ref_default_bf16_vs_oracle(full_dit, B, overlap):
+    m, spec, sd, do = full_dit
+    N, T, seed = spec.N, spec.T, 11
+    props, text, _ = synth.make_dit_inputs(B, seed=seed, max_node=N)
+    n_nodes = torch.tensor([32] if B == 1 else [32, 32, 17, 5, 32, 1, 29, 32])
+    y = torch.where(props == -200.0, torch.tensor(float("nan")), props)
+    mask = torch.arange(N).unsqueeze(0).expand(B, -1) < n_nodes.unsqueeze(1)
+    s = T - 1
+    qT, qs = synth.exp_noise(seed, T, B, N), synth.exp_noise(seed, s, B, N)
+    with torch.no_grad():
+        X0, E0 = do.initial_state(spec, mask, *qT)
+        t = torch.full((B, 1), float(s + 1) / T)
+        ref = {}
+        for name, unc in (("c", False), ("u", True)):
+            lx, le, _, hs = do.denoiser(sd, spec, X0, E0, mask, y, text, t, uncond=unc, return_hidden=True)
+            ref[name] = (lx, le, hs)
+        pX, pE = do.guided_probs(sd, spec, X0, E0, mask, y, text, s)
+        Xs, Es = do.sample_features(pX, pE, mask, *qs)
+        Xi, Ei = do.collapse(*do.to_onehot_masked(Xs, Es, mask), mask)
+        X0i, E0i = do.collapse(X0, E0, mask)
+
+    m.begin(props, text, -200.0, n_nodes)
+    m.set_option("overlap", overlap)
+    try:
+        m.init_state(*qT)
+        X, E = m.get_state()
+        offd = ~torch.eye(N, dtype=torch.bool).unsqueeze(0).expand(B, -1, -1)   # z_T's diagonal is the all-zero vector (-1 in the engine)
+        assert torch.equal(X.cpu().long(), X0i) and torch.equal(E.cpu().long()[offd], E0i[offd]), "z_T differs from the oracle"
+        rows = mask.unsqueeze(-1)
+        drift = {}
+        for tap in (0, 7, 14, 28):
+            lx, le, hid = m.denoise_logits(s, tap_layer=tap)
+            hid = hid.cpu()
+            worst = 0.0
+            for p, name in enumerate(("c", "u")):
+                h_ref = ref[name][2][tap]
+                scale = float((h_ref * rows).abs().max())
+                worst = max(worst, float(((hid[p] - h_ref) * rows).abs().max()) / scale)
+            drift[tap] = worst
+        lx, le = lx.cpu(), le.cpu()
+        lscale = max(float(ref["c"][1].abs().max()), float(ref["c"][0].abs().max()), 1.0)
+        lerr = max(float((lx[p] - ref[n][0]).abs().max()) for p, n in enumerate(("c", "u")))
+        lerr = max(lerr, max(float((le[p] - ref[n][1]).abs().max()) for p, n in enumerate(("c", "u")))) / lscale
+        px, pe = m.step_probs(s)
+        tvx = float((0.5 * (px.cpu() - pX).abs().sum(-1))[mask].max())
+        um = _upper(n_nodes, N)
+        tve = float((0.5 * (pe.cpu() - pE).abs().sum(-1))[um].max()) if um.any() else 0.0
+        m.step(s, *qs)
+        X, E = m.get_state()
+        X, E = X.cpu().long(), E.cpu().long()
+        n_x, n_e = int(mask.sum()), int(um.sum())
+        agree_x = float((X[mask] == Xi[mask]).float().mean())
+        agree_e = float((E[um] == Ei[um]).float().mean()) if n_e else 1.0
+        assert torch.equal(E, E.transpose(1, 2))
+        assert torch.equal(X[~mask], Xi[~mask])          # padding stays padding
+    finally:
+        m.set_option("overlap", 0)
+    rec = dict(hidden_drift_rel={str(k): v for k, v in drift.items()}, logit_err_rel=lerr, tv_atoms=tvx, tv_bonds=tve,
+               race_agree_atoms=agree_x, race_agree_bonds=agree_e, n_atoms=n_x, n_pairs=n_e)
+    print(f"B={B} overlap={overlap}: {rec}")
+    _report(f"graphdit_B{B}_{'overlap' if overlap else 'panel'}", rec)
+    # bf16 operands / f32 accumulation over 28 post-norm blocks; measured values in profiles/r2_parity_full_size.json
+    assert drift[0] <= 1e-2 and max(drift.values()) <= 5e-2, drift
+    assert lerr <= 5e-2, lerr
+    assert tvx <= 3e-2 and tve <= 3e-2, (tvx, tve)
+    assert agree_x >= 0.95 and agree_e >= 0.98, (agree_x, agree_e)
+
+
+# ------------------------------------------------------------------------------------------ MFMA attention vs f32-LDS attention
+@pytest.mark.parametrize("N,H,heads", [(32, 128, 4), (32, 256, 4), (50, 128, 4), (50, 256, 4)],
+                         ids=["NP32_HD32", "NP32_HD64", "NP64_HD32", "NP64_HD64"])
+def test_attn_mfma_vs_generic_on_identical_qkv(N, H, heads):
+    """One block of the bf16 engine run twice on the same state: attn_mfma_kernel<NP,HD> and attn_generic_kernel<bf16> read the
+    same bf16 q|k|v buffer (same x, same qkv GEMM); the hidden state after block 1 may differ only by the bf16 rounding of the
+    softmax probabilities the MFMA kernel feeds to P.V (the generic kernel keeps P in f32)."""
+    from llamole_amd.graph_decoder import GraphDiT
+    seed, B = 5, 4
+    cfg = synth.make_dit_config(H, 2, heads, 10, 2.0)
+    meta = synth.make_data_meta(N, seed)
+    sd = synth.make_dit_weights(cfg, N, seed)
+    d = tempfile.mkdtemp()
+    synth.write_dit_dir(d, cfg, meta, sd)
+    m = GraphDiT(os.path.join(d, "config.yaml"), os.path.join(d, "data.meta.json"), torch.bfloat16)
+    m.init_model(d)
+    m.to("cuda")
+    for p in m.parameters():
+        p.data = p.data.to(torch.bfloat16)
+    props, text, _ = synth.make_dit_inputs(B, seed, N)
+    n_nodes = torch.tensor([N, 1, max(2, N // 2 + 1), N - 1])
+    m.begin(props, text, -200.0, n_nodes)
+    m.init_state(*synth.exp_noise(seed, m.T, B, N))
+    s = m.T - 1
+    out = {}
+    for generic in (0, 1):
+        m.set_option("generic_attn", generic)
+        lx, le, h1 = m.denoise_logits(s, tap_layer=1)
+        out[generic] = (h1.cpu(), lx.cpu(), le.cpu())
+    m.set_option("generic_attn", 0)
+    valid = (torch.arange(N).unsqueeze(0) < n_nodes.unsqueeze(1)).unsqueeze(0).unsqueeze(-1)      # [1,B,N,1]
+    scale = float((out[1][0] * valid).abs().max())
+    err = float(((out[0][0] - out[1][0]) * valid).abs().max()) / scale
+    lerr = float((out[0][1] - out[1][1]).abs().max()) / max(1.0, float(out[1][1].abs().max()))
+    print(f"attn mfma vs generic N={N} hd={H // heads}: hidden {err:.3e} logits {lerr:.3e}")
+    _report(f"attn_mfma_vs_generic_N{N}_hd{H // heads}", dict(hidden_rel=err, logits_rel=lerr))
+    assert err <= 1e-2 and lerr <= 1e-2, (err, lerr)
+
+
+# ------------------------------------------------------------------------------------------ GIN predictor at configs[2] size
+def test_gin_predictor_full_size_vs_oracle():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gin_bench import fast_weights
+    from llamole_amd.graph_predictor import GraphPredictor
+    from oracle import gin_oracle as go
+    L, H, G, D, k = 5, 512, 16, 180576, 50
+    dev = torch.device("cuda")
+    x, ei, ea, batch = synth.make_mol_graphs(G, 0, min_atoms=32, max_atoms=32)
+    pred = GraphPredictor(L, H, 0.0, D, {}, {})
+    pred.to(dev)
+    sdp = fast_weights(synth.gin_weight_shapes(L, H, "predictor", D), dev, 3)
+    # xavier-initialised heads give near-uniform template distributions (180 k probabilities within 10 % of each other), where
+    # a top-50 SET is decided by rounding noise; a trained head is peaked -- scale the last Linear so the logits span ~ +-10
+    sdp["decoder.4.weight"] = sdp["decoder.4.weight"] * 40.0
+    pred.predictor.load_state_dict(sdp)
+    for p in pred.parameters():
+        p.data = p.data.to(torch.bfloat16)
+    sd_cpu = {k_: v.detach().to(torch.bfloat16).float().cpu() for k_, v in sdp.items()}
+    c = torch.randn(G, 768, generator=torch.Generator().manual_seed(4))
+    xs, eis, eas, bs = x.to(dev), ei.to(dev), ea.to(dev), batch.to(dev)
+    logits = pred(xs, eis, eas, bs, c.to(dev)).float().cpu()
+    p_gpu, i_gpu = pred.topk_templates(xs, eis, eas, bs, c.to(dev), k)
+    p_gpu, i_gpu = p_gpu.cpu(), i_gpu.cpu().long()
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        ref = go.predictor_forward(sd_cpu, L, x, ei, ea, batch, c)
+        rp, ri = go.template_topk(ref, k)
+    scale = float(ref.abs().max())
+    lerr = float((logits - ref).abs().max()) / scale
+    # (forward() hands out bf16 logits like the reference's bf16 module; topk_templates runs the f32-output template head, so the
+    # two are compared with the oracle separately; exactness of the top-k selection itself: test_gin_gpu.py::test_softmax_topk_*)
+    assert (torch.diff(p_gpu, dim=1) <= 0).all() and int(i_gpu.min()) >= 0 and int(i_gpu.max()) < D
+    overlap = float(np.mean([len(set(ri[g].tolist()) & set(i_gpu[g].tolist())) / k for g in range(G)]))
+    top1 = float((ri[:, 0] == i_gpu[:, 0]).float().mean())
+    # probability mass: compare the oracle's probability of the engine's picks with the oracle's own top-k mass
+    ref_p = torch.softmax(ref, dim=1)
+    mass_ratio = float((torch.gather(ref_p, 1, i_gpu).sum(1) / rp.sum(1)).min())
+    perr = float(((p_gpu - rp).abs() / rp)[:, :10].max())       # rank-matched probabilities of the 10 likeliest templates
+    rec = dict(logit_err_rel=lerr, top50_set_overlap=overlap, top1_agree=top1, top50_mass_ratio_min=mass_ratio, top50_prob_rel_err_max=perr)
+    print("GIN predictor full size:", rec)
+    _report("gin_predictor_full", rec)
+    assert lerr <= 3e-2, lerr
+    assert overlap >= 0.9 and mass_ratio >= 0.98 and top1 >= 0.9, (overlap, mass_ratio, top1)
