@@ -199,6 +199,10 @@ int ll_gin_backward_c(void *handle, const int32_t *rowptr_src, const int32_t *ds
 /* softmax over out_dim then top-k (GraphPredictor.sample_templates, graph_predictor/model.py:174-179).
  * probs [rows,k] descending, idx [rows,k]. k <= 64. */
 int ll_softmax_topk(const float *logits, int rows, int out_dim, int k, float *probs, int32_t *idx, void *stream);
+/* ll_set_topk_single : 1 = one workgroup per row for any out_dim (the round-1 form); 0 (default) = rows longer than 4096 templates
+ * are reduced by (out_dim / 4096) x rows workgroups to per-chunk candidates and merged by one workgroup per row -- same result
+ * (set, order, ties to the lowest template index).  Returns the previous setting. */
+int ll_set_topk_single(int on);
 
 /* CostMLP (graph_predictor/model.py:356-391): softplus(W3 relu(W0 fp + b0) + b3); fps [n,2048] f32 0/1.
  * weights: device f32 arena = [layers.0.weight 128x2048 | layers.0.bias 128 | layers.3.weight 1x128 | layers.3.bias 1]. */

@@ -64,6 +64,7 @@ SIGNATURES = {
     "ll_gin_destroy": (_I, [_P]),
     "ll_gin_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "ll_softmax_topk": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "ll_set_topk_single": (_I, [_I]),
     "ll_cost_mlp": (_I, [_P, _P, _I, _P, _P]),
     "ll_rmsnorm_bf16": (_I, [_P, _P, _P, _I, _I, _F, _P]),
     "ll_rope_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), _P]),

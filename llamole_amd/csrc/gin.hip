@@ -10,6 +10,8 @@
 // feature rows read as coalesced 256-B segments.  Virtual-node max-pool / add-pool are segment reductions
 // over the sorted `batch` vector (one workgroup per graph).  All Linears go through the shared MFMA GEMM.
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -321,6 +323,39 @@ __device__ __forceinline__ uint32_t f2key(float f) {
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+// Bin choice of one radix pass by a whole wave (lanes 0..63 of the workgroup): the largest bin b with
+// sum_{j > b} hist[j] < need <= sum_{j >= b} hist[j] and acc = sum_{j > b} hist[j]  (b = 0 when the histogram holds fewer than `need`).
+__device__ __forceinline__ void radix_pick(const unsigned int *hist, unsigned need, int &bsel, unsigned &acc_above) {
+    const int lane = threadIdx.x & 63;
+    const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+    const unsigned tot = h0 + h1 + h2 + h3;
+    unsigned suf = tot;      // inclusive suffix sum over lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_down(suf, o, 64);
+        if (lane + o < 64) suf += t;
+    }
+    const unsigned above = suf - tot;
+    const unsigned long long hit = __ballot(above < need && need <= suf);
+    const int L = hit ? (63 - __clzll((long long)hit)) : 0;
+    unsigned acc = __shfl(above, L, 64);
+    const unsigned b3 = __shfl(h3, L, 64), b2 = __shfl(h2, L, 64), b1 = __shfl(h1, L, 64);
+    int bb = 3;
+    if (acc + b3 < need) {
+        acc += b3;
+        bb = 2;
+        if (acc + b2 < need) {
+            acc += b2;
+            bb = 1;
+            if (acc + b1 < need) {
+                acc += b1;
+                bb = 0;
+            }
+        }
+    }
+    bsel = 4 * L + bb;
+    acc_above = acc;
+}
 // Row scan helper: 4 x float4 per thread in flight (the row is L2-resident after the first pass; a scalar strided
 // loop would serialise ~D/1024 dependent round trips per pass).  f(value, index) is called for every element.
 template <typename F>
@@ -345,8 +380,13 @@ __device__ __forceinline__ void topk_scan_row(const float *__restrict__ x, int D
     for (int i = 4 * D4 + tid; i < D; i += 1024) f(x[i], i);
 }
 
+// MERGE = false: one workgroup scans a whole row of logits (small rows).  MERGE = true: second stage of the chunked form below --
+// the "row" is the list of per-chunk candidates [chunks][k] (values sorted per chunk by value desc / index asc, chunks in index
+// order, so POSITION order among equal values is INDEX order), `ids` their template indices, `stats` the per-chunk (max, sum exp).
+template <bool MERGE>
 __global__ __launch_bounds__(1024) void softmax_topk_kernel(const float *__restrict__ logits, int D, int k,
-                                                             float *__restrict__ probs, int *__restrict__ idx) {
+                                                             float *__restrict__ probs, int *__restrict__ idx,
+                                                             const int *__restrict__ ids, const float *__restrict__ stats, int chunks) {
     __shared__ unsigned int hist[256];
     __shared__ unsigned int whist[16][256];   // one histogram per wave: the top radix byte (sign + exponent) puts most keys
                                               // into a handful of bins, so a single LDS histogram serialises on atomics
@@ -356,32 +396,39 @@ __global__ __launch_bounds__(1024) void softmax_topk_kernel(const float *__restr
     __shared__ float selv[64];
     __shared__ int seli[64];
     const float *x = logits + (int64_t)blockIdx.x * D;
+    if (MERGE) ids += (int64_t)blockIdx.x * D;
     const int tid = threadIdx.x;
-    // pass 0: max and sum(exp)  (online softmax)
-    float m = -INFINITY, s = 0.f;
-    topk_scan_row(x, D, tid, [&](float v, int) {
-        if (v > m) {
-            s = s * expf(m - v) + 1.f;
-            m = v;
-        } else {
-            s += expf(v - m);
+    float gm = -INFINITY, gs = 0.f;
+    if (MERGE) {
+        // softmax statistics of the whole row from the chunk statistics, summed in chunk order by every thread (deterministic)
+        const float *st = stats + (int64_t)blockIdx.x * chunks * 2;
+        for (int c = 0; c < chunks; ++c) gm = fmaxf(gm, st[2 * c]);
+        for (int c = 0; c < chunks; ++c) gs += (st[2 * c] == -INFINITY) ? 0.f : st[2 * c + 1] * expf(st[2 * c] - gm);
+    } else {
+        // pass 0: max and sum(exp)  (online softmax)
+        float m = -INFINITY, s = 0.f;
+        topk_scan_row(x, D, tid, [&](float v, int) {
+            if (v > m) {
+                s = s * expf(m - v) + 1.f;
+                m = v;
+            } else {
+                s += expf(v - m);
+            }
+        });
+        for (int o = 32; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+            const float mn = fmaxf(m, m2);
+            s = ((m == -INFINITY) ? 0.f : s * expf(m - mn)) + ((m2 == -INFINITY) ? 0.f : s2 * expf(m2 - mn));
+            m = mn;
         }
-    });
-    for (int o = 32; o > 0; o >>= 1) {
-        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
-        const float mn = fmaxf(m, m2);
-        s = ((m == -INFINITY) ? 0.f : s * expf(m - mn)) + ((m2 == -INFINITY) ? 0.f : s2 * expf(m2 - mn));
-        m = mn;
+        if ((tid & 63) == 0) {
+            redm[tid >> 6] = m;
+            reds[tid >> 6] = s;
+        }
+        __syncthreads();
+        for (int w = 0; w < 16; ++w) gm = fmaxf(gm, redm[w]);
+        for (int w = 0; w < 16; ++w) gs += (redm[w] == -INFINITY) ? 0.f : reds[w] * expf(redm[w] - gm);
     }
-    if ((tid & 63) == 0) {
-        redm[tid >> 6] = m;
-        reds[tid >> 6] = s;
-    }
-    __syncthreads();
-    float gm = -INFINITY;
-    for (int w = 0; w < 16; ++w) gm = fmaxf(gm, redm[w]);
-    float gs = 0.f;
-    for (int w = 0; w < 16; ++w) gs += (redm[w] == -INFINITY) ? 0.f : reds[w] * expf(redm[w] - gm);
     // radix select, most significant byte first
     if (tid == 0) {
         s_prefix = 0;
@@ -407,15 +454,15 @@ __global__ __launch_bounds__(1024) void softmax_topk_kernel(const float *__restr
             hist[tid] = t;
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned need = s_need, acc = 0;
-            int bsel = 255;
-            for (; bsel > 0; --bsel) {
-                if (acc + hist[bsel] >= need) break;
-                acc += hist[bsel];
+        if (tid < 64) {      // wave 0 picks the bin (a serial scan of 256 LDS bins by one thread cost ~5 us per pass)
+            int bsel;
+            unsigned acc;
+            const unsigned need = s_need;
+            radix_pick(hist, need, bsel, acc);
+            if (tid == 0) {
+                s_need = need - acc;
+                s_prefix = prefix | ((unsigned)bsel << shift);
             }
-            s_need = need - acc;
-            s_prefix = prefix | ((unsigned)bsel << shift);
         }
         __syncthreads();
     }
@@ -432,7 +479,7 @@ __global__ __launch_bounds__(1024) void softmax_topk_kernel(const float *__restr
         if (key > kth) {
             const unsigned p = atomicAdd(&s_cnt, 1u);
             selv[p] = v;
-            seli[p] = i;
+            seli[p] = MERGE ? ids[i] : i;
         } else if (key == kth) {
             const unsigned p = atomicAdd(&s_ties, 1u);
             if (p < 64) tie_idx[p] = i;
@@ -449,7 +496,7 @@ __global__ __launch_bounds__(1024) void softmax_topk_kernel(const float *__restr
                     if (tie_idx[b2] < tie_idx[a2]) { const int t2 = tie_idx[a2]; tie_idx[a2] = tie_idx[b2]; tie_idx[b2] = t2; }
             for (unsigned a2 = 0; a2 < need_eq && a2 < nt; ++a2) {
                 selv[p] = x[tie_idx[a2]];
-                seli[p] = tie_idx[a2];
+                seli[p] = MERGE ? ids[tie_idx[a2]] : tie_idx[a2];
                 ++p;
             }
         } else {
@@ -457,7 +504,7 @@ __global__ __launch_bounds__(1024) void softmax_topk_kernel(const float *__restr
             for (int i = 0; i < D && taken < need_eq; ++i)
                 if (f2key(x[i]) == kth) {
                     selv[p] = x[i];
-                    seli[p] = i;
+                    seli[p] = MERGE ? ids[i] : i;
                     ++p;
                     ++taken;
                 }
@@ -472,6 +519,206 @@ __global__ __launch_bounds__(1024) void softmax_topk_kernel(const float *__restr
         probs[(int64_t)blockIdx.x * k + rank] = expf(v - gm) / gs;
         idx[(int64_t)blockIdx.x * k + rank] = id;
     }
+}
+
+// ---- chunked form.  Stage 1: one 256-thread workgroup per (chunk of <= 4096 templates, row): a row of 180 576 logits is 45
+// chunks, so 16 rows are 720 workgroups over the whole chip instead of 16 (round 1: 330 us = 35 GB/s on 16 CUs).  The chunk is
+// loaded ONCE into registers (16 values per thread); softmax statistics and the selection run on the register copy.  Output per
+// chunk: its top-k as (value, template index) sorted by value desc / index asc, and (max, sum exp(v - max)).  Stage 2: one
+// workgroup per row selects among the chunks x k candidates and emits probabilities.  An element of the row's top-k under the
+// total order (value desc, index asc) is necessarily in its chunk's top-k, so the result -- set, order, ties to the lowest
+// template index -- is exactly that of the one-workgroup form.
+//
+// Selection without a radix pass over everything (LDS atomics on the float exponent byte serialise: 20 us per stage): the k-th
+// largest of the 256 per-thread maxima is a lower bound of the k-th largest value, and only ~k elements lie at or above it, so
+// those few are gathered and rank-sorted.  Too many candidates (thousands of exact ties) -> k rounds of workgroup-wide argmax.
+constexpr int TOPK_VPT = 16, TOPK_CHUNK = 256 * TOPK_VPT, TOPK_CAP = 1024;
+struct __attribute__((aligned(16))) TopkShared {
+    unsigned long long cand[TOPK_CAP];      // (key << 32) | (0x7fffffff - template index): larger = earlier in the total order
+    unsigned tmax[256];
+    unsigned cnt, thr;
+    unsigned long long red[4];
+};
+__device__ __forceinline__ float key2f(unsigned key) {
+    return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+}
+__device__ __forceinline__ unsigned long long topk_pack(unsigned key, int idx) {
+    return ((unsigned long long)key << 32) | (unsigned)(0x7fffffff - idx);
+}
+// key[e] / valid bit e: the VPT values of this thread (order-preserving uint images, all > 0 for non-NaN floats); idx_of(e): template
+// index.  out(rank, key, index) is called exactly once for every rank in [0, k), k <= 64 and <= the number of valid values.
+//   1. threshold: the k-th largest of 64 group maxima (group = the four threads lane, 64 + lane, ...) is a lower bound of the
+//      k-th largest value; one wave ranks the 64 maxima against each other with readlane broadcasts;
+//   2. the ~2k values at or above it are gathered (LDS counter) and rank-sorted as packed 64-bit (key, index) words;
+//   3. more than TOPK_CAP candidates (thousands of exact ties): k rounds of workgroup-wide argmax instead.
+template <int VPT, typename IdxF, typename OutF>
+__device__ __forceinline__ void topk_select_block256(const unsigned (&key)[VPT], unsigned valid, IdxF idx_of, int k, TopkShared &sh, OutF out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned tm = 0;
+#pragma unroll
+    for (int e = 0; e < VPT; ++e) tm = ((valid >> e) & 1u) && key[e] > tm ? key[e] : tm;
+    sh.tmax[tid] = tm;
+    if (tid == 0) sh.cnt = 0;
+    __syncthreads();
+    if (wave == 0) {
+        const unsigned g = max(max(sh.tmax[lane], sh.tmax[64 + lane]), max(sh.tmax[128 + lane], sh.tmax[192 + lane]));
+        int gt = 0, ge = 0;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)g, j);
+            gt += o > g ? 1 : 0;
+            ge += o >= g ? 1 : 0;
+        }
+        // lanes that hold the k-th largest group maximum (they all hold the same value); g == 0: a group without a valid value
+        const unsigned long long hit = __ballot(g != 0 && gt < k && k <= ge);
+        const int src = hit ? (__ffsll((long long)hit) - 1) : 0;
+        const unsigned t = (unsigned)__shfl((int)g, src, 64);
+        if (lane == 0) sh.thr = hit ? t : 0u;      // fewer than k non-empty groups: every valid value is a candidate
+    }
+    __syncthreads();
+    const unsigned thr = sh.thr;
+#pragma unroll
+    for (int e = 0; e < VPT; ++e)
+        if (((valid >> e) & 1u) && key[e] >= thr) {
+            const unsigned p = atomicAdd(&sh.cnt, 1u);
+            if (p < (unsigned)TOPK_CAP) sh.cand[p] = topk_pack(key[e], idx_of(e));
+        }
+    __syncthreads();
+    const unsigned C = sh.cnt;
+    if (C <= (unsigned)TOPK_CAP) {      // workgroup-uniform
+        for (unsigned i = tid; i < C; i += 256) {
+            const unsigned long long mine = sh.cand[i];
+            int r = 0;
+#pragma unroll 8
+            for (unsigned j = 0; j < C; ++j) r += sh.cand[j] > mine ? 1 : 0;
+            if (r < k) out(r, (unsigned)(mine >> 32), 0x7fffffff - (int)(unsigned)(mine & 0xffffffffu));
+        }
+        return;
+    }
+    // k rounds of workgroup-wide argmax of the packed words
+    unsigned taken = ~valid;
+    for (int r = 0; r < k; ++r) {
+        unsigned long long best = 0;
+        int be = -1;
+#pragma unroll
+        for (int e = 0; e < VPT; ++e)
+            if (!((taken >> e) & 1u)) {
+                const unsigned long long pk = topk_pack(key[e], idx_of(e));
+                if (pk > best) { best = pk; be = e; }
+            }
+        unsigned long long wb = best;
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(wb & 0xffffffffu), o, 64);
+            const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(wb >> 32), o, 64);
+            const unsigned long long ob = ((unsigned long long)hi << 32) | lo;
+            wb = ob > wb ? ob : wb;
+        }
+        __syncthreads();
+        if (lane == 0) sh.red[wave] = wb;
+        __syncthreads();
+        unsigned long long g = sh.red[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) g = sh.red[w] > g ? sh.red[w] : g;
+        if (be >= 0 && best == g) taken |= 1u << be;      // template indices are unique: exactly one owner
+        if (tid == 0) out(r, (unsigned)(g >> 32), 0x7fffffff - (int)(unsigned)(g & 0xffffffffu));
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void topk_chunk_kernel(const float *__restrict__ logits, int D, int k, int chunk_len,
+                                                         float *__restrict__ ws_val, int *__restrict__ ws_idx,
+                                                         float *__restrict__ ws_stat) {
+    __shared__ TopkShared sh;
+    __shared__ float redm[4], reds[4];
+    const int c = blockIdx.x, row = blockIdx.y, chunks = gridDim.x, tid = threadIdx.x;
+    const float *x = logits + (int64_t)row * D;
+    const int beg = c * chunk_len;
+    const int n = min(D, beg + chunk_len) - beg;            // >= 1 by construction of the grid
+    auto pos = [&](int e) { return VEC ? (((e >> 2) * 256 + tid) * 4 + (e & 3)) : (e * 256 + tid); };
+    float v[TOPK_VPT];
+    if (VEC) {       // D % 4 == 0, 16-byte aligned rows, chunk_len % 4 == 0: whole float4s are valid or not
+#pragma unroll
+        for (int u = 0; u < TOPK_VPT / 4; ++u) {
+            const int p = (u * 256 + tid) * 4;
+            const float4 t = p < n ? *reinterpret_cast<const float4 *>(x + beg + p) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            v[4 * u] = t.x; v[4 * u + 1] = t.y; v[4 * u + 2] = t.z; v[4 * u + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < TOPK_VPT; ++e) v[e] = pos(e) < n ? x[beg + pos(e)] : -INFINITY;
+    }
+    unsigned valid = 0;
+#pragma unroll
+    for (int e = 0; e < TOPK_VPT; ++e) valid |= (pos(e) < n ? 1u : 0u) << e;
+    // ---- softmax statistics of the chunk
+    float m = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < TOPK_VPT; ++e) m = fmaxf(m, v[e]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((tid & 63) == 0) redm[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    float sm = 0.f;
+#pragma unroll
+    for (int e = 0; e < TOPK_VPT; ++e) sm += (((valid >> e) & 1u) && m != -INFINITY) ? expf(v[e] - m) : 0.f;
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+    if ((tid & 63) == 0) reds[tid >> 6] = sm;
+    __syncthreads();
+    if (tid == 0) {
+        ws_stat[((int64_t)row * chunks + c) * 2] = m;
+        ws_stat[((int64_t)row * chunks + c) * 2 + 1] = (reds[0] + reds[1]) + (reds[2] + reds[3]);
+    }
+    float *ov = ws_val + ((int64_t)row * chunks + c) * k;
+    int *oi = ws_idx + ((int64_t)row * chunks + c) * k;
+    const int kk = min(k, n);        // candidates this chunk hands on (a short last chunk may hold fewer than k templates)
+    if (tid >= kk && tid < k) {
+        ov[tid] = -INFINITY;         // padding that can never be selected (k <= D)
+        oi[tid] = 0x7fffffff;
+    }
+    unsigned key[TOPK_VPT];
+#pragma unroll
+    for (int e = 0; e < TOPK_VPT; ++e) key[e] = f2key(v[e]);
+    topk_select_block256<TOPK_VPT>(key, valid, [&](int e) { return beg + pos(e); }, kk, sh,
+                                   [&](int r, unsigned kq, int id) { ov[r] = key2f(kq); oi[r] = id; });
+}
+
+// Stage 2 for chunks * k <= 4096 candidates (D <= 262 144 at k = 64): the candidates in registers, strided over the threads so
+// that every thread sees a mix of chunks; softmax statistics from the chunk statistics in chunk order (deterministic).
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict__ ws_val, const int *__restrict__ ws_idx,
+                                                         const float *__restrict__ ws_stat, int chunks, int k,
+                                                         float *__restrict__ probs, int *__restrict__ idx) {
+    __shared__ TopkShared sh;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int total = chunks * k;
+    const float *cv = ws_val + (int64_t)row * total;
+    const int *ci = ws_idx + (int64_t)row * total;
+    unsigned key[TOPK_VPT];
+    int id[TOPK_VPT];
+    unsigned valid = 0;
+#pragma unroll
+    for (int e = 0; e < TOPK_VPT; ++e) {
+        const int p = e * 256 + tid;
+        id[e] = p < total ? ci[p] : 0x7fffffff;
+        key[e] = f2key(p < total ? cv[p] : -INFINITY);
+        valid |= (id[e] != 0x7fffffff ? 1u : 0u) << e;
+    }
+    // softmax statistics of the row from the chunk statistics: every wave reduces them redundantly with the same fixed shuffle tree
+    // (deterministic); a serial loop over the chunks was 90 dependent scalar-load round trips (~20 us)
+    const float *st = ws_stat + (int64_t)row * chunks * 2;
+    const int lane = tid & 63;
+    float gm = -INFINITY, gs = 0.f;
+    for (int c0 = 0; c0 < chunks; c0 += 64) gm = fmaxf(gm, c0 + lane < chunks ? st[2 * (c0 + lane)] : -INFINITY);
+    for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
+    for (int c0 = 0; c0 < chunks; c0 += 64) {
+        const int c = c0 + lane;
+        const float mc = c < chunks ? st[2 * c] : -INFINITY;
+        gs += (mc == -INFINITY) ? 0.f : st[2 * c + 1] * expf(mc - gm);
+    }
+    for (int o = 32; o > 0; o >>= 1) gs += __shfl_xor(gs, o, 64);
+    topk_select_block256<TOPK_VPT>(key, valid, [&](int e) { return id[e]; }, k, sh, [&](int r, unsigned kq, int t) {
+        probs[(int64_t)row * k + r] = expf(key2f(kq) - gm) / gs;
+        idx[(int64_t)row * k + r] = t;
+    });
 }
 
 // CostMLP: softplus(w3 . relu(W0 fp + b0) + b3), W0 [128][2048].  One workgroup per fingerprint.
@@ -1032,6 +1279,13 @@ static int gin_backward_c_t(GinEngine *e, const int *rowptr_s, const int *dst_s,
 
 }  // namespace ll
 
+namespace ll {
+struct TopkWs { void *p = nullptr; size_t bytes = 0; };
+static std::mutex g_topk_mu;
+static std::map<hipStream_t, TopkWs> g_topk_ws;
+static int g_topk_single = 0;      // ll_set_topk_single(1): one workgroup per row (round-1 form; A/B and tests)
+}  // namespace ll
+
 using namespace ll;
 
 extern "C" {
@@ -1143,9 +1397,48 @@ int ll_softmax_topk(const float *logits, int rows, int out_dim, int k, float *pr
     LL_CHECK(logits && probs && idx, "null argument");
     LL_CHECK(rows >= 1 && out_dim >= 1, "empty input");
     LL_CHECK(k >= 1 && k <= 64 && k <= out_dim, "k=%d must be in [1, min(64, out_dim)]", k);
-    hipLaunchKernelGGL(softmax_topk_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, out_dim, k, probs, idx);
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = cdiv(out_dim, TOPK_CHUNK);
+    if (chunks == 1 || g_topk_single) {
+        hipLaunchKernelGGL(softmax_topk_kernel<false>, dim3(rows), dim3(1024), 0, st, logits, out_dim, k, probs, idx, nullptr, nullptr, 1);
+        LL_LAUNCH_CHECK();
+        return LL_OK;
+    }
+    // two stages: (chunks x rows) workgroups reduce the row to chunks x k candidates, one workgroup per row merges them.
+    // The candidate workspace belongs to the stream (calls on one stream are ordered; hipFree on growth synchronises).
+    const bool vec = out_dim % 4 == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0;
+    const int chunk_len = round_up(cdiv(out_dim, chunks), 4);
+    const size_t nc = (size_t)rows * chunks * k;
+    float *wv = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_topk_mu);
+        TopkWs &w = g_topk_ws[st];
+        const size_t need = nc * 8 + (size_t)rows * chunks * 8;
+        if (w.bytes < need) {
+            if (w.p) (void)hipFree(w.p);
+            w.p = nullptr;
+            w.bytes = 0;
+            LL_HIP(hipMalloc(&w.p, need));
+            w.bytes = need;
+        }
+        wv = reinterpret_cast<float *>(w.p);
+    }
+    int *wi = reinterpret_cast<int *>(wv + nc);
+    float *wstat = reinterpret_cast<float *>(wi + nc);
+    if (vec) hipLaunchKernelGGL(topk_chunk_kernel<true>, dim3(chunks, rows), dim3(256), 0, st, logits, out_dim, k, chunk_len, wv, wi, wstat);
+    else hipLaunchKernelGGL(topk_chunk_kernel<false>, dim3(chunks, rows), dim3(256), 0, st, logits, out_dim, k, chunk_len, wv, wi, wstat);
+    if (chunks * k <= TOPK_CHUNK)
+        hipLaunchKernelGGL(topk_merge_kernel, dim3(rows), dim3(256), 0, st, wv, wi, wstat, chunks, k, probs, idx);
+    else      // more than 4096 candidates per row (> 262 144 templates at k = 64): the radix merge takes any count
+        hipLaunchKernelGGL(softmax_topk_kernel<true>, dim3(rows), dim3(1024), 0, st, wv, chunks * k, k, probs, idx, wi, wstat, chunks);
     LL_LAUNCH_CHECK();
     return LL_OK;
+}
+
+int ll_set_topk_single(int on) {
+    const int old = g_topk_single;
+    g_topk_single = on ? 1 : 0;
+    return old;
 }
 
 int ll_cost_mlp(const float *weights, const float *fps, int n, float *out, void *stream) {

@@ -114,6 +114,43 @@ def test_softmax_topk_and_cost_mlp():
     np.testing.assert_allclose(out.cpu().numpy().reshape(-1), g["cost_out"].reshape(-1), rtol=1e-4, atol=1e-5)
 
 
+def test_softmax_topk_chunked_equals_single_workgroup():
+    """Rows longer than 4096 templates take the two-stage form (chunk candidates + merge): same indices, same order, ties to the
+    lowest template index, probabilities equal up to the summation order of the softmax denominator -- including rows that are
+    not 16-byte aligned / not a multiple of 4 long, exact ties straddling chunk boundaries, and > 64 exact ties at the threshold."""
+    from llamole_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for rows, D, k, quant in [(16, 180576, 50, 0), (5, 180575, 50, 0), (2, 4097, 64, 0), (3, 9001, 1, 0), (4, 50000, 50, 1), (2, 20000, 37, 2), (2, 10000, 20, 3),
+                                 (2, 300001, 64, 0)]:      # > 4096 candidates per row: radix merge
+        logits = (torch.randn(rows, D, device="cuda", generator=g) * 3).contiguous()
+        if quant == 1:
+            logits = torch.round(logits * 2) / 2          # thousands of exact ties everywhere
+        if quant == 2:
+            logits = torch.round(logits)                  # > 64 ties at the threshold
+        if quant == 3:
+            logits = torch.zeros_like(logits)             # everything ties: the argmax-round path of both stages
+            logits[1, 7000:7005] = 1.0
+        logits[0, 4094:4099] = 11.5                       # ties across the first chunk boundary, above everything else
+        out = {}
+        for single in (1, 0):
+            lib.ll_set_topk_single(single)
+            probs = torch.empty(rows, k, device="cuda")
+            idx = torch.empty(rows, k, device="cuda", dtype=torch.int32)
+            _lib.check(lib.ll_softmax_topk(_lib.dptr(logits), rows, D, k, _lib.dptr(probs), _lib.dptr(idx), None))
+            torch.cuda.synchronize()
+            out[single] = (probs.cpu(), idx.cpu())
+        lib.ll_set_topk_single(0)
+        assert torch.equal(out[0][1], out[1][1]), (rows, D, k, quant)
+        assert torch.allclose(out[0][0], out[1][0], rtol=1e-5, atol=0), (rows, D, k)
+        ref = torch.softmax(logits.double(), dim=1).cpu()
+        rp = torch.topk(ref, k, dim=1).values
+        assert torch.allclose(out[0][0].double(), rp, rtol=1e-4, atol=1e-12)
+        # ties resolved to the lowest index: stable descending sort of the f32 logits
+        order = torch.sort(logits.cpu(), dim=1, descending=True, stable=True).indices[:, :k]
+        assert torch.equal(out[0][1].long(), order)
+
+
 @pytest.mark.parametrize("name", list(GIN_CASES))
 def test_bf16_engine(name):
     L, H, out_dim, G, seed = GIN_CASES[name]
