@@ -56,6 +56,10 @@ int ll_linear_splitk_bf16(const void *A, int lda, const void *W, int ldw, const 
 /* Tuning utility: average ms of `iters` launches of pipelined-GEMM configuration `cfg` (-1 = the production
  * dispatch) on an [M,K]x[N,K]^T bf16 problem, cycling over `nweights` weight matrices (HBM-resident stream). */
 int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f32, int iters, int nweights, float *ms);
+/* ll_linear_cfg : ll_linear (bf16 operands) through ONE kernel configuration of the tuning table (gemm.hip: g_pipe_cfgs), so that
+ * every variant can be checked against a reference.  splits > 1: C receives `splits` raw f32 slabs (stride M * ldc). */
+int ll_linear_cfg(int cfg, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, int M, int N, int K,
+                  int splits, int epi, int out_f32, void *stream);
 /* Tuning: waves per workgroup of the <= 64-row panel GEMM (4 | 8; default 8); returns the previous value. */
 int ll_set_m64_waves(int waves);
 

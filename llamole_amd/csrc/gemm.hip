@@ -750,6 +750,182 @@ static int launch_m64_cfg(const bf16_t *A, int lda, const bf16_t *W, int ldw, vo
     return launch_m64<NS>(A, lda, W, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s);
 }
 
+// ------------------------------------------------------------------------------------------ bf16 MFMA, register-staged deep prefetch
+// For M >= 128 token rows (GraphDiT at batch >= 2..32).  The LDS-DMA ring above tops out at ~40-50 GB/s of ingest per CU whatever
+// its depth (round-2 sweep: every (tile, stages) configuration costs ~0.6-1.3 us per 64-wide k-tile, i.e. time follows the number
+// of k-tiles per workgroup, not bytes or flops), while plain 16-byte loads with contiguous lanes sustain 125-150 GB/s per CU
+// (tools/ingest_probe.hip).  So this kernel stages tiles through VGPRs instead:
+//   * one workgroup per CU-sized output tile (BM x BN = 128 x 64: 256 workgroups for 512 x 4096), 8 waves;
+//   * BK = 128: a tile row is 256 B = 16 lanes x 16 B, a wave instruction reads 4 whole rows;
+//   * TWO k-tiles of loads in flight per thread (12 x 16 B: 96 KB per CU) while a third is being multiplied out of LDS; the
+//     compiler's in-order vmcnt counting keeps the younger tile in flight across the (bare) barrier;
+//   * LDS image [rows][256 B], 16-byte chunk index XOR (row & 15): conflict-free ds_write_b128 and ds_read_b128 fragments;
+//   * wave tile 32 x 32 (WM x WN = 4 x 2), v_mfma_f32_16x16x32_bf16, f32 accumulators; split-K writes f32 slabs.
+template <int BM, int BN, int WM, int WN, typename OutT>
+__global__ __launch_bounds__(WM *WN * 64) void gemm_rs_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ W,
+                                                               int ldw, OutT *__restrict__ C, int ldc,
+                                                               const float *__restrict__ bias, int M, int N, int kchunk,
+                                                               int64_t slab_stride, int epi) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BK = 128, ROWB = BK * 2, CPR = BK / 8;          // 16 chunks of 16 B per tile row
+    constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NTL = TN / 16;
+    constexpr int NA = BM * CPR / NT, NB = BN * CPR / NT;          // 16-byte loads per thread per k-tile
+    static_assert(BM * CPR % NT == 0 && BN * CPR % NT == 0 && NA >= 1 && NB >= 1, "tile rows must divide over the threads");
+    static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be a multiple of 16x16");
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_rs[];   // [2][(BM + BN)][256 B]
+    constexpr int BUF = (BM + BN) * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * kchunk;
+    const int nk = kchunk / BK;
+    // this thread's chunks: chunk id c = tid + i * NT -> row c / 16, 16-byte piece c % 16
+    const bf16_t *pa[NA];
+    const bf16_t *pb[NB];
+    int sa[NA], sb[NB];      // LDS byte offsets (swizzled)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int c = tid + i * NT, row = c / CPR, kc = c % CPR;
+        int ar = m0 + row;
+        ar = ar < M ? ar : M - 1;          // M edge: re-read a valid row, result discarded
+        pa[i] = A + (int64_t)ar * lda + kbeg + kc * 8;
+        sa[i] = row * ROWB + ((kc ^ (row & 15)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int c = tid + i * NT, row = c / CPR, kc = c % CPR;
+        int br = n0 + row;
+        br = br < N ? br : N - 1;
+        pb[i] = W + (int64_t)br * ldw + kbeg + kc * 8;
+        sb[i] = (BM + row) * ROWB + ((kc ^ (row & 15)) << 4);
+    }
+    // The tile loads are hidden from hipcc in asm statements and their completion is counted by hand: with plain loads the
+    // compiler's waitcnt insertion drains vmcnt to 0 at the loop header and again before every ds_write (round-2 ISA audit), which
+    // leaves ONE tile in flight.  landed(): s_waitcnt vmcnt(n), then every destination of the set is "redefined" by an empty asm
+    // so that no consumer (or register copy) of it can be scheduled above the wait (cdna_hip_programming.md 5.7, form ii).
+    u4 ra[2][NA], rb[2][NB];
+    auto gload = [&](int set, int kt) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[set][i]) : "v"(pa[i] + (int64_t)kt * BK) : "memory");
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[set][i]) : "v"(pb[i] + (int64_t)kt * BK) : "memory");
+    };
+    auto landed = [&](int set, bool younger_tile_in_flight) {
+        if (younger_tile_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(ra[set][i]));
+#pragma unroll
+        for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(rb[set][i]));
+    };
+    auto swrite = [&](int set, int buf) {
+        unsigned char *b = sm_rs + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<u4 *>(b + sa[i]) = ra[set][i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<u4 *>(b + sb[i]) = rb[set][i];
+    };
+    f32x4 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fk = lane >> 4;
+    auto compute = [&](int buf) {
+        const unsigned char *Ab = sm_rs + buf * BUF;
+        const unsigned char *Bb = Ab + BM * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 fa[MT], fb[NTL];
+            const int ch = ks * 4 + fk;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = wm * TM + i * 16 + fr;
+                fa[i] = *reinterpret_cast<const bf16x8 *>(Ab + row * ROWB + ((ch ^ (row & 15)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int row = wn * TN + j * 16 + fr;
+                fb[j] = *reinterpret_cast<const bf16x8 *>(Bb + row * ROWB + ((ch ^ (row & 15)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // prologue: tiles 0 and 1 in flight, tile 0 into LDS
+    gload(0, 0);
+    if (nk > 1) gload(1, 1);
+    landed(0, nk > 1);
+    swrite(0, 0);
+    __syncthreads();
+    // main loop, unrolled by two so that the staging registers are statically indexed
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 2 < nk) gload(0, kt + 2);        // set 0 (tile kt) is already in LDS
+        compute(0);
+        if (kt + 1 < nk) {
+            landed(1, kt + 2 < nk);               // tile kt+1 only: tile kt+2 stays in flight across the barrier
+            swrite(1, 1);
+        }
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        if (kt + 3 < nk) gload(1, kt + 3);
+        compute(1);
+        if (kt + 2 < nk) {
+            landed(0, kt + 3 < nk);
+            swrite(0, 0);
+        }
+        __syncthreads();
+    }
+    OutT *Cz = C + (int64_t)blockIdx.z * slab_stride;
+    const bool raw = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const int col = n0 + wn * TN + j * 16 + (lane & 15);
+            if (col >= N) continue;
+            const float bv = (!raw && bias) ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * TM + i * 16 + (lane >> 4) * 4 + r;
+                if (row < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (!raw) v = apply_epi(v, epi);
+                    Cz[(int64_t)row * ldc + col] = from_f32<OutT>(v);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_rs(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M, int N, int K,
+                     int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * (BM + BN) * 256;
+    static_assert(lds <= 160 * 1024, "double-buffered tile must fit the 160 KB of a CU");
+    LL_CHECK(K % (128 * splits) == 0, "gemm_rs: K per split must be a multiple of 128 (K=%d, splits=%d)", K, splits);
+    static bool attr_set = false;
+    if (!attr_set) {
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_rs_kernel<BM, BN, WM, WN, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_rs_kernel<BM, BN, WM, WN, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), splits);
+    const int kchunk = K / splits;
+    if (out_f32)
+        hipLaunchKernelGGL((gemm_rs_kernel<BM, BN, WM, WN, float>), grid, dim3(WM * WN * 64), lds, s, A, lda, W, ldw, (float *)C, ldc, bias, M, N,
+                           kchunk, slab_stride, epi);
+    else
+        hipLaunchKernelGGL((gemm_rs_kernel<BM, BN, WM, WN, bf16_t>), grid, dim3(WM * WN * 64), lds, s, A, lda, W, ldw, (bf16_t *)C, ldc, bias, M, N,
+                           kchunk, slab_stride, epi);
+    return LL_OK;
+}
+
 static int g_gemm_variant = -1;  // LL_GEMM_VARIANT=0 forces the 2-stage register-staged kernels (A/B testing)
 static thread_local int g_no_panel_gemm = 0;  // per host thread; set_panel_gemm(false): <= 64-row panels take the LDS-DMA ring (48 KB of LDS) instead of gemm_m64_kernel
 
@@ -918,6 +1094,13 @@ static const PipeCfg g_pipe_cfgs[] = {
     {32, 64, 6, launch_pipe<32, 64, 2, 2, 6>},     // 38
     {32, 224, 4, launch_pipe<32, 224, 2, 2, 4>},   // 39
     {32, 32, 8, launch_pipe<32, 32, 2, 2, 8>},     // 40
+    {128, 64, 402, launch_rs<128, 64, 4, 2>},      // 41  register-staged deep prefetch, 8 waves, BK = 128
+    {64, 128, 402, launch_rs<64, 128, 2, 4>},      // 42
+    {128, 128, 402, launch_rs<128, 128, 4, 2>},    // 43  wave tile 32 x 64
+    {64, 64, 402, launch_rs<64, 64, 4, 2>},        // 44  wave tile 16 x 32
+    {128, 64, 402, launch_rs<128, 64, 2, 2>},      // 45  4 waves, wave tile 64 x 32
+    {128, 32, 402, launch_rs<128, 32, 4, 2>},      // 46
+    {256, 64, 402, launch_rs<256, 64, 4, 2>},      // 47  wave tile 64 x 32
 };
 }  // namespace ll
 
@@ -965,6 +1148,20 @@ extern "C" int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f
     (void)hipFree(C);
     if (rc != LL_OK) return rc;
     LL_HIP(he);
+    return LL_OK;
+}
+
+// One specific configuration of the table above on caller-provided operands (tests: every kernel variant against PyTorch).
+// splits > 1: C receives `splits` raw f32 slabs of M x ldc (slab stride M * ldc), bias / epilogue skipped.
+extern "C" int ll_linear_cfg(int cfg, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, int M, int N,
+                             int K, int splits, int epi, int out_f32, void *stream) {
+    using namespace ll;
+    const int ncfg = (int)(sizeof(g_pipe_cfgs) / sizeof(g_pipe_cfgs[0]));
+    LL_CHECK(cfg >= 0 && cfg < ncfg, "cfg %d out of range [0,%d)", cfg, ncfg);
+    LL_CHECK(A && W && C && splits >= 1 && K % splits == 0, "bad argument");
+    LL_TRY(g_pipe_cfgs[cfg].fn((const bf16_t *)A, lda, (const bf16_t *)W, ldw, C, ldc, bias, M, N, K, splits, (int64_t)M * ldc, epi,
+                               splits > 1 ? 1 : out_f32, (hipStream_t)stream));
+    LL_LAUNCH_CHECK();
     return LL_OK;
 }
 

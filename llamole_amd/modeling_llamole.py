@@ -484,7 +484,7 @@ class GraphLLMForCausalMLM(nn.Module):
                 Estimate remaining steps for the target {smiles} given the following parameters:
                 Current step {reaction.depth + 1},
                 Current template: {reaction.template},
-                Reactants: {reactants}.
+                Reactants: {reactants}. 
                 Consider the following factors:
                 1. Intermediate complexity
                 2. Reagent availability
@@ -496,11 +496,20 @@ class GraphLLMForCausalMLM(nn.Module):
             [{"role": "user", "content": "Estimate the synthesis complexity:"}, {"role": "assistant", "content": a}],
             tokenize=False, add_generation_prompt=False)) for a in self._ANSWERS]
 
+    # The reference multiplies probs [5, 1] by a cost vector [5] (modeling_llamole.py:984-988): the product broadcasts to the 5 x 5
+    # outer product, so its sum is sum(probs) * sum(costs) = 15 (up to f32 rounding) for EVERY molecule -- the language "cost" is a
+    # constant.  That is what a user of the reference gets (pinned by tests/golden/host_traces.json), so it is the default here;
+    # ``expected_cost_value = True`` switches to the evidently intended expectation sum_k p_k * cost_k.
+    expected_cost_value = False
+
     def _cost_from_logits(self, logits, answer_tokens):
-        """logits [n, vocab] of the last prompt position -> expected remaining-step cost per row (:976-993)."""
+        """logits [n, vocab] of the last prompt position -> remaining-step cost per row (:976-993)."""
         answer_logits = torch.stack([logits[:, toks].mean(dim=1) for toks in answer_tokens])        # [5, n]
         probs = torch.softmax(answer_logits.float(), dim=0)
-        return (probs * torch.tensor(self._ANSWER_COSTS, device=probs.device)[:, None]).sum(dim=0)  # [n]
+        costs = torch.tensor(self._ANSWER_COSTS, device=probs.device)
+        if self.expected_cost_value:
+            return (probs * costs[:, None]).sum(dim=0)                                              # [n]
+        return torch.stack([(probs[:, j:j + 1] * costs).sum() for j in range(probs.shape[1])])      # the reference's outer product
 
     @torch.no_grad()
     def estimate_synthesis_complexity(self, smiles, input_ids=None, reaction=None, molecule_cost_weight=0,

@@ -92,6 +92,35 @@ def test_linear_matches_torch():
         assert torch.allclose(outh.float(), refb, rtol=2e-2, atol=2e-2)
 
 
+def test_register_staged_gemm_configs_match_torch():
+    """gemm_rs_kernel (tuning-table ids 41..47) through ll_linear_cfg: ragged M and N, split-K slabs, bias + GELU epilogue."""
+    from llamole_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(2)
+    for cfg in (41, 42, 43, 44, 45, 46, 47):
+        for (M, N, K, splits) in [(512, 4096, 1024, 1), (512, 1024, 4096, 4), (200, 1000, 256, 1), (130, 72, 128, 1), (2048, 3072, 1024, 1),
+                                  (64, 176, 1024, 2)]:
+            A = torch.randn(M, K, device="cuda").bfloat16()
+            W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
+            bias = torch.randn(N, device="cuda")
+            lin = A.double() @ W.double().t()
+            if splits == 1:
+                out = torch.empty(M, N, device="cuda")
+                _lib.check(lib.ll_linear_cfg(cfg, _lib.dptr(A), K, _lib.dptr(W), K, _lib.dptr(bias), _lib.dptr(out), N, M, N, K, 1, 1, 1, None))
+                torch.cuda.synchronize()
+                ref = torch.nn.functional.gelu(lin + bias.double()).float()
+                assert torch.allclose(out, ref, rtol=2e-3, atol=2e-3), (cfg, M, N, K, (out - ref).abs().max())
+                outh = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+                _lib.check(lib.ll_linear_cfg(cfg, _lib.dptr(A), K, _lib.dptr(W), K, None, _lib.dptr(outh), N, M, N, K, 1, 0, 0, None))
+                torch.cuda.synchronize()
+                assert torch.allclose(outh.float(), lin.float(), rtol=2e-2, atol=2e-2), (cfg, M, N, K)
+            else:
+                slabs = torch.empty(splits, M, N, device="cuda")
+                _lib.check(lib.ll_linear_cfg(cfg, _lib.dptr(A), K, _lib.dptr(W), K, None, _lib.dptr(slabs), N, M, N, K, splits, 0, 1, None))
+                torch.cuda.synchronize()
+                assert torch.allclose(slabs.sum(0), lin.float(), rtol=2e-3, atol=2e-3), (cfg, M, N, K, splits)
+
+
 def test_conditioning_vectors(case):
     g, m, B = case["g"], case["m"], case["B"]
     c = m.cvec(m.T - 1).cpu().numpy()
