@@ -294,6 +294,13 @@ int ll_sample_token_bf16(const void *logits, int64_t ld, int B, int V, float inv
                          const int64_t *seed, const int64_t *eos, int n_eos, int64_t pad, void *done, int64_t *tok,
                          int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid, int64_t *pos,
                          int advance, uint64_t *dbg, void *stream);
+/* ... with HF's TopKLogitsWarper ahead of the nucleus (the reference samples with GeneratingArguments' default top_k = 50,
+ * src/hparams/generating_args.py:39-42): only the top_k highest logits survive (ties with the k-th are kept, as HF's
+ * `logits < kth` test does) and top_p is applied to their renormalised distribution.  top_k <= 0 = off. */
+int ll_sample_token_topk_bf16(const void *logits, int64_t ld, int B, int V, float inv_temp, float top_p, int top_k, int greedy,
+                              const int64_t *seed, const int64_t *eos, int n_eos, int64_t pad, void *done, int64_t *tok,
+                              int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid, int64_t *pos,
+                              int advance, uint64_t *dbg, void *stream);
 
 #ifdef __cplusplus
 }

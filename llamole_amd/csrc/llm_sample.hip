@@ -25,6 +25,7 @@ struct SampleArgs {
     int V;
     float inv_temp;            // 1 / temperature (f32, as PyTorch's tensor / python-scalar computes it)
     float top_p;
+    int top_k;                 // HF TopKLogitsWarper ahead of top-p: keep the k highest logits (0 = off); ties with the k-th are kept
     int greedy;
     const long long *seed;     // device, [1]
     const long long *eos;      // device, [n_eos] (-1 = unused slot)
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
     __shared__ float redf[16];
     __shared__ unsigned int redu[16];
     __shared__ unsigned long long sh_tail, sh_R;
-    __shared__ unsigned int sh_d, sh_key, sh_rank, sh_tok;
+    __shared__ unsigned int sh_d, sh_key, sh_rank, sh_tok, sh_dk;
+    __shared__ unsigned long long sh_Zk;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bf16_t *row = a.logits + (int64_t)b * a.ld;
     const int nchunk = a.V / 8;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
 #pragma unroll
         for (int i = 0; i < SAMPLE_BPT; ++i) cnt[i * 1024 + tid] = 0;
     }
-    if (tid == 0) { sh_tail = 0; sh_d = 0; sh_tok = 0; }
+    if (tid == 0) { sh_tail = 0; sh_d = 0; sh_tok = 0; sh_dk = 0xffffffffu; sh_Zk = 0; }
     reg_fence<CH>(w);
     uint32_t kmaxi = 0;
 #pragma unroll
@@ -171,7 +173,52 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
             Z += wsum[i];
         }
         const unsigned long long excl = base + inc - lsum;
-        const unsigned long long Tq = a.top_p >= 1.f ? ~0ull : (unsigned long long)((double)a.top_p * (double)Z);
+        // top-k ahead of top-p (HF order: temperature, TopKLogitsWarper, TopPLogitsWarper; the reference's GeneratingArguments
+        // default top_k = 50): the cut is the value of the k-th largest token, tokens tied with it stay (HF removes
+        // logits < kth value); the nucleus is then taken over the renormalised survivors, i.e. against their mass Zk
+        uint32_t dk = 0xffffffffu;
+        unsigned long long Zk = Z;
+        if (a.top_k > 0) {
+            uint32_t lc = 0;
+            for (int i = 0; i < SAMPLE_BPT; ++i) {
+                const uint32_t c = cnt[d0 + i];
+                if (c && (uint32_t)(d0 + i) < kmax) lc += c;
+            }
+            uint32_t incc = lc;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const uint32_t o = __shfl_up(incc, dd, 64);
+                if (lane >= dd) incc += o;
+            }
+            if (lane == 63) redu[wave] = incc;
+            __syncthreads();
+            uint32_t basec = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i < wave) basec += redu[i];
+            const uint32_t exclc = basec + incc - lc;
+            const uint32_t kk = (uint32_t)a.top_k;
+            if (exclc < kk && exclc + lc >= kk) {        // exactly one thread: its bins hold the k-th largest token
+                uint32_t run = exclc;
+                unsigned long long A = excl;
+                for (int i = 0; i < SAMPLE_BPT; ++i) {
+                    const uint32_t c = cnt[d0 + i];
+                    if (c && (uint32_t)(d0 + i) < kmax) {
+                        run += c;
+                        A += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
+                        if (run >= kk) {
+                            sh_dk = (unsigned int)(d0 + i);
+                            sh_Zk = A;
+                            break;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            dk = sh_dk;                                  // stays ~0 when fewer than k tokens lie in the window: nothing is cut
+            if (dk != 0xffffffffu) Zk = sh_Zk;
+        }
+        const unsigned long long Tq = a.top_p >= 1.f ? ~0ull : (unsigned long long)((double)a.top_p * (double)Zk);
         // boundary: the lowest value whose mass-above is still < Tq (mass-above is non-decreasing in d)
         {
             unsigned long long A = excl;
@@ -179,7 +226,7 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
             for (int i = 0; i < SAMPLE_BPT; ++i) {
                 const uint32_t c = cnt[d0 + i];
                 if (c && (uint32_t)(d0 + i) < kmax) {
-                    if (A < Tq) last = d0 + i;
+                    if (A < Tq && (uint32_t)(d0 + i) <= dk) last = d0 + i;
                     A += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
                 }
             }
@@ -197,7 +244,7 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
                 }
             }
             unsigned long long M = A;    // kept mass: everything down to and including the boundary value
-            if (a.top_p >= 1.f) M = Z;   // tail included when nothing is filtered
+            if (a.top_p >= 1.f && dk == 0xffffffffu) M = Z;   // tail included when nothing is filtered
             const unsigned long long sd = (unsigned long long)*a.seed;
             const unsigned long long st = (unsigned long long)a.step[b];
             const uint4 rnd = philox4x32(make_uint4((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)b, 0x5A17u),
@@ -307,16 +354,29 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
 
 using namespace ll;
 
+extern "C" int ll_sample_token_topk_bf16(const void *logits, int64_t ld, int B, int V, float inv_temp, float top_p, int top_k, int greedy,
+                                         const int64_t *seed, const int64_t *eos, int n_eos, int64_t pad, void *done, int64_t *tok,
+                                         int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid,
+                                         int64_t *pos, int advance, uint64_t *dbg, void *stream);
+
 extern "C" int ll_sample_token_bf16(const void *logits, int64_t ld, int B, int V, float inv_temp, float top_p, int greedy,
                                     const int64_t *seed, const int64_t *eos, int n_eos, int64_t pad, void *done, int64_t *tok,
                                     int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid,
                                     int64_t *pos, int advance, uint64_t *dbg, void *stream) {
+    return ll_sample_token_topk_bf16(logits, ld, B, V, inv_temp, top_p, 0, greedy, seed, eos, n_eos, pad, done, tok, out_tokens, ld_out,
+                                     max_new, step, posid, pos, advance, dbg, stream);
+}
+
+extern "C" int ll_sample_token_topk_bf16(const void *logits, int64_t ld, int B, int V, float inv_temp, float top_p, int top_k, int greedy,
+                                         const int64_t *seed, const int64_t *eos, int n_eos, int64_t pad, void *done, int64_t *tok,
+                                         int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid,
+                                         int64_t *pos, int advance, uint64_t *dbg, void *stream) {
     LL_CHECK(logits && seed && done && tok && out_tokens && step && (n_eos == 0 || eos), "ll_sample_token_bf16: null argument");
     LL_CHECK(B >= 1 && V >= 8 && V % 8 == 0 && V <= 1024 * 8 * 20 && ld % 8 == 0,
              "ll_sample_token_bf16: vocabulary %d must be a multiple of 8 and <= 163840", V);
     LL_CHECK(greedy || (inv_temp > 0.f && top_p >= 0.f), "ll_sample_token_bf16: temperature and top_p must be positive");
     SampleArgs a;
-    a.logits = (const bf16_t *)logits; a.ld = ld; a.V = V; a.inv_temp = inv_temp; a.top_p = top_p; a.greedy = greedy;
+    a.logits = (const bf16_t *)logits; a.ld = ld; a.V = V; a.inv_temp = inv_temp; a.top_p = top_p; a.top_k = top_k < 0 ? 0 : top_k; a.greedy = greedy;
     a.seed = (const long long *)seed; a.eos = (const long long *)eos; a.n_eos = n_eos; a.pad = pad;
     a.done = (unsigned char *)done; a.tok = (long long *)tok; a.out_tokens = (long long *)out_tokens; a.ld_out = ld_out;
     a.max_new = max_new; a.step = (long long *)step; a.posid = (long long *)posid; a.pos = (long long *)pos;

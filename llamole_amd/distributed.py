@@ -89,10 +89,14 @@ def allreduce_gradients(params, bucket_bytes: int = 64 << 20, group=None) -> int
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 0
     world = dist.get_world_size(group)
+    # The bucket layout must be the SAME on every rank, so it is built from the fixed list of trainable parameters, never from
+    # which of them happen to carry a gradient: a rank whose shard has no <molecule> token produces no connector gradient, a
+    # rank without a retro label none for lm_to_graph_predictor -- those enter as zeros (what DDP's find_unused_parameters
+    # does) and receive the average like everybody else.  Mismatched bucket lengths would hang or corrupt an RCCL all-reduce.
     by_dtype = {}
     for p in params:
-        if p.grad is not None:
-            by_dtype.setdefault((p.grad.dtype, p.grad.device), []).append(p)
+        if p.requires_grad:
+            by_dtype.setdefault((p.dtype, p.device), []).append(p)
     calls = 0
     for (dtype, device), plist in by_dtype.items():
         bucket, size = [], 0
@@ -102,18 +106,21 @@ def allreduce_gradients(params, bucket_bytes: int = 64 << 20, group=None) -> int
             nonlocal calls
             if not bucket:
                 return
-            flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
             flat.div_(world)
             off = 0
             for p in bucket:
-                n = p.grad.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                n = p.numel()
+                if p.grad is None:
+                    p.grad = flat[off:off + n].view_as(p).clone()
+                else:
+                    p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
             calls += 1
             bucket.clear()
         for p in plist:
-            nbytes = p.grad.numel() * itemsize
+            nbytes = p.numel() * itemsize
             if bucket and size + nbytes > bucket_bytes:
                 flush()
                 size = 0

@@ -111,7 +111,7 @@ def build_orchestrator(llm, graph_decoder, device, dtype=torch.bfloat16):
 
 
 def gen_kwargs(tok, new_tokens: int):
-    return dict(do_sample=True, temperature=0.6, top_p=0.9, max_new_tokens=new_tokens,
+    return dict(do_sample=True, temperature=0.6, top_p=0.9, top_k=50, max_new_tokens=new_tokens,      # top_k: GeneratingArguments default
                 eos_token_id=[tok.eos_token_id] + list(tok.special.values()), pad_token_id=tok.pad_token_id)
 
 
@@ -211,7 +211,7 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
 
     n_params = sum(p.numel() for p in llm.parameters())
     info = {"llm": args.llm, "llm_params": n_params, "llm_weights": "random-init (no network)", "prompt_len": args.cutoff_len,
-            "max_new_tokens": args.new_tokens, "sampling": "temperature 0.6, top_p 0.9",
+            "max_new_tokens": args.new_tokens, "sampling": "temperature 0.6, top_k 50, top_p 0.9",
             "llm_decode": {"graph": "stock HF forward over StaticCache, one hipGraph replayed per token",
                            "eager": "stock HF forward over StaticCache, eager", "hf": "HF generate()"}[args.llm_decode],
             "llm_linear": ("ll_linear (HIP weight-streaming GEMV) under %d nn.Linear modules for decode-shaped calls" % n_accel)

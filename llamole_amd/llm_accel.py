@@ -27,10 +27,15 @@ MAX_APPEND_ROWS = 16     # new positions per call served by the fused KV append 
 MAX_EW_ROWS = 16384      # row-parallel elementwise kernels (RMSNorm, rotary, SiLU*mul) also serve prefill-sized calls
 
 
+def _versions(*tensors):
+    return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+
+
 def _hip_linear_forward(self: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     K = self.in_features
     if (x.is_cuda and x.dtype == torch.bfloat16 and self.weight.dtype == torch.bfloat16 and not torch.is_grad_enabled()
-            and x.numel() // K <= MAX_ROWS and x.shape[-1] == K):
+            and x.numel() // K <= MAX_ROWS and x.shape[-1] == K
+            and (K % 64 == 0 or (x.numel() // K <= 4 and K % 8 == 0))):      # gemm_dispatch: K % 64 == 0 beyond the 4-row GEMV
         x2 = x.reshape(-1, K)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
@@ -43,14 +48,15 @@ def _hip_linear_forward(self: nn.Linear, x: torch.Tensor) -> torch.Tensor:
                 bias = getattr(self, "_ll_bias_f32", None)
                 if bias is None or bias.device != x.device:
                     bias = self.bias.detach().float().contiguous()
-                    self._ll_bias_f32 = bias
+                    self._ll_bias_f32, self._ll_bias_key = bias, _versions(self.bias)
             rc = self._ll_lib.ll_linear_rows16_bf16(x2.data_ptr(), K, self.weight.data_ptr(), K, bias.data_ptr() if bias is not None else None,
                                                     None, 0.0, None, 0, out.data_ptr(), N, M, N, K, 0, torch.cuda.current_stream().cuda_stream)
             if rc != 0:
                 _lib.check(rc, "ll_linear_rows16_bf16")
             return out.reshape(*x.shape[:-1], N)
-        if 4 < M <= 32 and K >= 8192 and N <= 8192 and self.bias is None and K % 256 == 0:
-            # a few rows x a short, wide matrix (down_proj at batch 8-16): split K so that >= 256 workgroups stream it
+        if MAX_STREAM_ROWS < M <= 32 and K >= 8192 and N <= 8192 and self.bias is None and K % 256 == 0:
+            # 17..32 rows x a short, wide matrix (down_proj; up to 16 rows the stream above serves it): split K so that >= 256
+            # workgroups stream it
             splits = 4 if K % 512 == 0 and (N + 31) // 32 * 2 < 256 else 2
             if K % (64 * splits) == 0:
                 ws = torch.empty(splits * M * N, dtype=torch.float32, device=x.device)
@@ -64,7 +70,7 @@ def _hip_linear_forward(self: nn.Linear, x: torch.Tensor) -> torch.Tensor:
             bias = getattr(self, "_ll_bias_f32", None)
             if bias is None or bias.device != x.device:
                 bias = self.bias.detach().float().contiguous()
-                self._ll_bias_f32 = bias
+                self._ll_bias_f32, self._ll_bias_key = bias, _versions(self.bias)
         rc = self._ll_lib.ll_linear(_lib.LL_BF16, x2.data_ptr(), K, self.weight.data_ptr(), K,
                                     bias.data_ptr() if bias is not None else None, out.data_ptr(), N, M, N, K, 0, 0,
                                     torch.cuda.current_stream().cuda_stream)
@@ -86,6 +92,58 @@ def accelerate_linears(model: nn.Module, min_weight_elems: int = 1 << 16) -> int
             mod.forward = types.MethodType(_hip_linear_forward, mod)
             n += 1
     return n
+
+
+def refresh_weight_copies(model: nn.Module) -> int:
+    """The fused decode path keeps its own copies of some weights (q|k|v and gate|up concatenated once, biases in f32); a
+    captured decode graph holds their ADDRESSES.  After the source weights changed (an SFT step, a merged LoRA adapter,
+    load_state_dict) the copies are rewritten IN PLACE here -- same storage, so captured graphs stay valid -- keyed on
+    (data_ptr, _version) of the sources, recorded when each copy is made.  GraphedDecoder.generate calls this before every
+    generation (a few hundred tuple compares).  Returns the number of copies rewritten.  The copies cost about one extra set of
+    MLP gate/up + attention q/k/v weights in memory (~8.5 GB for Qwen2-7B in bf16)."""
+    n = 0
+    with torch.no_grad():
+        for mod in model.modules():
+            d = mod.__dict__
+            q = getattr(mod, "q_proj", None)
+            grp = q.__dict__.get("_ll_qkv") if isinstance(q, nn.Module) else None
+            if grp is not None and isinstance(getattr(mod, "k_proj", None), nn.Module):
+                k, v = mod.k_proj, mod.v_proj
+                key = _versions(q.weight, k.weight, v.weight, q.bias, k.bias, v.bias)
+                if grp.key != key:
+                    grp.w.copy_(torch.cat([q.weight.detach(), k.weight.detach(), v.weight.detach()], dim=0))
+                    if grp.bias is not None:
+                        grp.bias.copy_(torch.cat([(m.bias.detach().float() if m.bias is not None else
+                                                   torch.zeros(m.out_features, device=grp.bias.device)) for m in (q, k, v)]))
+                    grp.key = key
+                    n += 1
+            if "_ll_gate_up" in d and isinstance(getattr(mod, "gate_proj", None), nn.Module):
+                key = _versions(mod.gate_proj.weight, mod.up_proj.weight)
+                if d.get("_ll_gate_up_key") != key:
+                    d["_ll_gate_up"].copy_(torch.cat([mod.gate_proj.weight.detach(), mod.up_proj.weight.detach()], dim=0))
+                    d["_ll_gate_up_key"] = key
+                    n += 1
+            if "_ll_bias_f32" in d and getattr(mod, "bias", None) is not None:
+                key = _versions(mod.bias)
+                if d.get("_ll_bias_key") != key:
+                    d["_ll_bias_f32"].copy_(mod.bias.detach().float())
+                    d["_ll_bias_key"] = key
+                    n += 1
+            st = d.get("_ll_fused")
+            if st is not None and st.bo is not None:
+                key = _versions(mod.self_attn.o_proj.bias)
+                if st.bo_key != key:
+                    st.bo.copy_(mod.self_attn.o_proj.bias.detach().float())
+                    st.bo_key = key
+                    n += 1
+    return n
+
+
+def drop_weight_copies(model: nn.Module) -> None:
+    """Forget the concatenated / converted weight copies (restore_* paths): the next install rebuilds them."""
+    for mod in model.modules():
+        for k in ("_ll_gate_up", "_ll_gate_up_key", "_ll_bias_f32", "_ll_bias_key", "_ll_qkv"):
+            mod.__dict__.pop(k, None)
 
 
 def restore_linears(model: nn.Module) -> None:
@@ -132,7 +190,7 @@ def _mlp_forward(self, x: torch.Tensor) -> torch.Tensor:
         w = getattr(self, "_ll_gate_up", None)
         if w is None:   # gate and up share the input: one [2I, K] weight, one weight-streaming launch
             w = torch.cat([self.gate_proj.weight.detach(), self.up_proj.weight.detach()], dim=0).contiguous()
-            self._ll_gate_up = w
+            self._ll_gate_up, self._ll_gate_up_key = w, _versions(self.gate_proj.weight, self.up_proj.weight)
         x2 = x.reshape(-1, K)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
@@ -174,6 +232,7 @@ class _QKVGroup:
                                    for b, m in zip(biases, (q, k, v))]).contiguous()
         self.x = None
         self.buf = None
+        self.key = _versions(q.weight, k.weight, v.weight, q.bias, k.bias, v.bias)
 
     def run(self, x):
         x2 = x.reshape(-1, self.K)
@@ -294,6 +353,7 @@ def restore_elementwise(model: nn.Module) -> None:
         if "_ll_orig_forward" in mod.__dict__ and "forward" in mod.__dict__:
             del mod.__dict__["forward"]
             del mod.__dict__["_ll_orig_forward"]
+    drop_weight_copies(model)            # a later install rebuilds them from the then-current weights
     base = getattr(model, "model", model)
     m = sys.modules.get(type(base).__module__)
     if m is not None and hasattr(getattr(m, "apply_rotary_pos_emb", None), "_ll_orig"):
@@ -412,10 +472,11 @@ class _FusedLayer:
         self.scaling = float(att.scaling)
         self.wo = o.weight.detach()
         self.bo = o.bias.detach().float().contiguous() if o.bias is not None else None
+        self.bo_key = _versions(o.bias)
         wgu = getattr(mlp, "_ll_gate_up", None)
         if wgu is None:
             wgu = torch.cat([mlp.gate_proj.weight.detach(), mlp.up_proj.weight.detach()], dim=0).contiguous()
-            mlp._ll_gate_up = wgu
+            mlp._ll_gate_up, mlp._ll_gate_up_key = wgu, _versions(mlp.gate_proj.weight, mlp.up_proj.weight)
         self.wgu = wgu
         self.I = mlp.gate_proj.out_features
         self.wdown = mlp.down_proj.weight.detach()
@@ -529,6 +590,9 @@ def restore_decoder_layers(model: nn.Module) -> None:
             del layer.__dict__["forward"]
             del layer.__dict__["_ll_fused"]
             del layer.__dict__["_ll_layer_orig"]
+            for sub in layer.modules():       # the layer's concatenated gate|up copy goes with it (rebuilt on the next install)
+                sub.__dict__.pop("_ll_gate_up", None)
+                sub.__dict__.pop("_ll_gate_up_key", None)
 
 
 # ------------------------------------------------------------------------------------------ whole decode step of the base model

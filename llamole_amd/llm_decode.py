@@ -19,12 +19,15 @@ from typing import List, Optional, Sequence
 import torch
 
 
-def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float, generator=None) -> torch.Tensor:
-    """HF TemperatureLogitsWarper + TopPLogitsWarper + multinomial, without host syncs.  logits [B,V] float."""
+def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float, generator=None, top_k: Optional[int] = None) -> torch.Tensor:
+    """HF TemperatureLogitsWarper + TopKLogitsWarper + TopPLogitsWarper + multinomial, without host syncs.  logits [B,V] float."""
     logits = logits.float()
     logits = torch.nan_to_num(logits, nan=0.0, posinf=torch.finfo(torch.float32).max, neginf=torch.finfo(torch.float32).min)
     if temperature is not None and temperature != 1.0:
         logits = logits / temperature
+    if top_k is not None and 0 < top_k < logits.shape[-1]:
+        kth = torch.topk(logits, top_k, dim=-1).values[..., -1:]
+        logits = logits.masked_fill(logits < kth, float("-inf"))      # ties with the k-th value stay, as in HF
     if top_p is not None and top_p < 1.0:
         sorted_logits, sorted_idx = torch.sort(logits, descending=False)
         cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
@@ -34,6 +37,33 @@ def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float, generat
         logits = logits.masked_fill(remove, float("-inf"))
     probs = torch.softmax(logits, dim=-1)
     return torch.multinomial(probs, 1, generator=generator).squeeze(1)
+
+
+def _reject_unsupported_generation_options(other: dict) -> None:
+    """The decoder implements temperature, top_k, top_p, greedy, eos / pad handling.  Anything else HF ``generate`` would honour
+    must be at its neutral value -- a silently dropped option would sample from another distribution than the reference."""
+    bad = []
+    for k, v in other.items():
+        if v is None:
+            continue
+        if k == "repetition_penalty" and float(v) == 1.0:
+            continue
+        if k == "length_penalty" and float(v) == 1.0:
+            continue
+        if k == "num_beams" and int(v) == 1:
+            continue
+        if k == "logits_processor":
+            # the reference passes get_logits_processor() = [InfNanRemoveLogitsProcessor] (extras/misc.py:146-152): the samplers
+            # here sanitise inf / nan themselves; any other processor changes the distribution
+            if all(type(p).__name__ == "InfNanRemoveLogitsProcessor" for p in v):
+                continue
+        if k in ("use_cache", "return_dict_in_generate", "output_scores", "output_hidden_states", "synced_gpus"):
+            if not v or k == "use_cache":
+                continue
+        bad.append(k)
+    if bad:
+        raise NotImplementedError(f"GraphedDecoder.generate does not implement {sorted(bad)}: set them to their neutral values or "
+                                  f"use the HF path (llm_decode='hf')")
 
 
 MAX_HIP_VOCAB = 163840   # ll_sample_token_bf16 keeps a whole row of logits in one workgroup's registers
@@ -118,16 +148,16 @@ class GraphedDecoder:
         """One launch: sample (or argmax) from bf16 logits [B,V], write tok / out_buf[:, step], update done / step and,
         with ``advance``, the position counters the next forward reads."""
         from . import _lib
-        greedy, inv_temp, top_p, pad = sp
+        greedy, inv_temp, top_p, pad, top_k = sp
         B, V = logits.shape
-        rc = _lib.load().ll_sample_token_bf16(logits.data_ptr(), logits.stride(0), B, V, inv_temp, top_p, int(greedy),
-                                              self.seed_buf.data_ptr(), self.eos_buf.data_ptr(), N_EOS_SLOTS, pad,
-                                              self.done.data_ptr(), self.tok.data_ptr(), self.out_buf.data_ptr(),
-                                              self.out_buf.stride(0), self.out_buf.shape[1], self.stepc.data_ptr(),
-                                              self.posid.data_ptr(), self.pos.data_ptr(), advance, None,
-                                              torch.cuda.current_stream().cuda_stream)
+        rc = _lib.load().ll_sample_token_topk_bf16(logits.data_ptr(), logits.stride(0), B, V, inv_temp, top_p, int(top_k), int(greedy),
+                                                   self.seed_buf.data_ptr(), self.eos_buf.data_ptr(), N_EOS_SLOTS, pad,
+                                                   self.done.data_ptr(), self.tok.data_ptr(), self.out_buf.data_ptr(),
+                                                   self.out_buf.stride(0), self.out_buf.shape[1], self.stepc.data_ptr(),
+                                                   self.posid.data_ptr(), self.pos.data_ptr(), advance, None,
+                                                   torch.cuda.current_stream().cuda_stream)
         if rc != 0:
-            _lib.check(rc, "ll_sample_token_bf16")
+            _lib.check(rc, "ll_sample_token_topk_bf16")
 
     def _generate_hip(self, logits, sp, P, plen, eos_list, max_new_tokens, generator, device):
         """Decode loop with the fused sampler: per token the host only replays ONE graph (forward + sampler)."""
@@ -175,7 +205,11 @@ class GraphedDecoder:
     def generate(self, input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
                  inputs_embeds: Optional[torch.Tensor] = None, max_new_tokens: int = 128, do_sample: bool = True,
                  temperature: float = 1.0, top_p: float = 1.0, eos_token_id: Optional[Sequence[int]] = None,
-                 pad_token_id: Optional[int] = None, generator=None, **_ignored) -> torch.Tensor:
+                 pad_token_id: Optional[int] = None, generator=None, top_k: Optional[int] = None, **other) -> torch.Tensor:
+        _reject_unsupported_generation_options(other)
+        top_k = int(top_k) if top_k else 0
+        from .llm_accel import refresh_weight_copies
+        refresh_weight_copies(self.model)       # concatenated / converted weight copies follow their sources (in place)
         ref = input_ids if input_ids is not None else inputs_embeds
         B, P = ref.shape[0], ref.shape[1]
         device = ref.device
@@ -217,7 +251,7 @@ class GraphedDecoder:
                 and (not do_sample or (temperature or 1.0) > 0)):
             import numpy as np
             temp = 1.0 if temperature is None else float(temperature)
-            sp = (not do_sample, float(np.float32(1.0) / np.float32(temp)), 1.0 if top_p is None else float(top_p), int(pad))
+            sp = (not do_sample, float(np.float32(1.0) / np.float32(temp)), 1.0 if top_p is None else float(top_p), int(pad), top_k)
             new_tokens = self._generate_hip(logits, sp, P, plen, eos.tolist(), max_new_tokens, generator, device)
             return torch.cat([input_ids, new_tokens], dim=1) if input_ids is not None else new_tokens
         if self._sample_key is not None:     # a graph captured with the fused sampler does not fit the torch-sampler loop
@@ -228,7 +262,7 @@ class GraphedDecoder:
         self.posid.copy_(plen)                                           # position id of the next token, per row
         n_done_steps = 0
         for t in range(max_new_tokens):
-            nxt = sample_top_p(logits, temperature, top_p, generator) if do_sample else logits.argmax(dim=-1)
+            nxt = sample_top_p(logits, temperature, top_p, generator, top_k) if do_sample else logits.argmax(dim=-1)
             nxt = torch.where(done, torch.full_like(nxt, pad), nxt)
             new_tokens[:, t] = nxt
             if eos.numel():

@@ -90,7 +90,7 @@ def sft_step(model, batch: Dict[str, Any], optimizer=None, bucket_bytes: int = 6
     if optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
     loss.backward()
-    params = [p for p in model.parameters() if p.requires_grad and p.grad is not None]
+    params = [p for p in model.parameters() if p.requires_grad]      # fixed list: identical bucket layout on every rank
     allreduce_gradients(params, bucket_bytes=bucket_bytes)
     if optimizer is not None:
         optimizer.step()

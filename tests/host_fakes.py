@@ -223,7 +223,7 @@ def r4(t):
 
 def cond_digest(c):
     """A condition tensor [B, 768] as a few numbers per row (sum, abs-sum, first 4 entries)."""
-    c = c.double()
+    c = c.detach().double()
     return [[round(float(r.sum()), 3), round(float(r.abs().sum()), 3)] + [round(float(v), 4) for v in r[:4]] for r in c]
 
 

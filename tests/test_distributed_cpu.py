@@ -163,3 +163,41 @@ def test_sft_collator_and_data_parallel_step_world2_gloo():
         a, b2 = torch.from_numpy(res[0][2][k]), torch.from_numpy(res[1][2][k])
         torch.testing.assert_close(a, b2, rtol=0, atol=0)                              # ranks agree bit for bit
         torch.testing.assert_close(a, ref[k], rtol=1e-5, atol=1e-7)
+
+
+def _uneven_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        a = torch.nn.Parameter(torch.ones(5))
+        b = torch.nn.Parameter(torch.ones(3, 2))          # the "connector": only rank 0's shard reaches it
+        c = torch.nn.Parameter(torch.ones(4))
+        frozen = torch.nn.Parameter(torch.ones(2), requires_grad=False)
+        loss = (a * (rank + 1)).sum() + (c * 2).sum() + ((b * 3).sum() if rank == 0 else 0)
+        loss.backward()
+        assert (b.grad is None) == (rank == 1)
+        n = D.allreduce_gradients([a, b, c, frozen], bucket_bytes=16)     # tiny buckets: several collectives, same on both ranks
+        q.put((rank, n, a.grad.tolist(), b.grad.tolist(), c.grad.tolist(), frozen.grad is None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_gradients_with_rank_dependent_grad_sets():
+    """a rank whose shard never touches a trainable parameter (no <molecule> token -> no connector gradient) must
+    still take part in that parameter's bucket, with zeros; the layout comes from requires_grad, not from grad presence."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0][1] == res[1][1] >= 2
+    for r in res:
+        assert r[2] == [1.5] * 5 and r[3] == [[1.5, 1.5]] * 3 and r[4] == [2.0] * 4 and r[5]

@@ -34,13 +34,16 @@ class Sampler:
         self.pos = torch.zeros(1, dtype=torch.long, device=d)
         self.dbg = torch.zeros(B, 4, dtype=torch.int64, device=d)
 
-    def __call__(self, logits, temperature=1.0, top_p=1.0, greedy=False, advance=1):
+    def __call__(self, logits, temperature=1.0, top_p=1.0, greedy=False, advance=1, top_k=None):
         inv = float(np.float32(1.0) / np.float32(temperature))
-        rc = self.lib.ll_sample_token_bf16(logits.data_ptr(), logits.stride(0), self.B, self.V, inv, top_p, int(greedy),
-                                           self.seed.data_ptr(), self.eos.data_ptr(), 8, self.pad, self.done.data_ptr(),
-                                           self.tok.data_ptr(), self.out.data_ptr(), self.out.stride(0), self.out.shape[1],
-                                           self.step.data_ptr(), self.posid.data_ptr(), self.pos.data_ptr(), advance,
-                                           self.dbg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        tail = (self.seed.data_ptr(), self.eos.data_ptr(), 8, self.pad, self.done.data_ptr(),
+                self.tok.data_ptr(), self.out.data_ptr(), self.out.stride(0), self.out.shape[1],
+                self.step.data_ptr(), self.posid.data_ptr(), self.pos.data_ptr(), advance,
+                self.dbg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if top_k is None:
+            rc = self.lib.ll_sample_token_bf16(logits.data_ptr(), logits.stride(0), self.B, self.V, inv, top_p, int(greedy), *tail)
+        else:
+            rc = self.lib.ll_sample_token_topk_bf16(logits.data_ptr(), logits.stride(0), self.B, self.V, inv, top_p, int(top_k), int(greedy), *tail)
         self._lib.check(rc, "ll_sample_token_bf16")
         return self.tok.clone()
 
@@ -103,6 +106,41 @@ def test_nucleus_boundary_matches_reference(V, scale, temperature, top_p):
             assert bool((kept | ~kept_hf).all())                        # HF's nucleus is a subset of ours
             extra = kept & ~kept_hf
             assert bool((sc[extra] <= tau_ref + 1e-9).all())            # extras are ties of the boundary value
+
+
+@pytest.mark.parametrize("V", [2048, 152064])
+@pytest.mark.parametrize("top_k,top_p,temperature", [(50, 0.9, 0.6), (50, 1.0, 1.0), (1, 0.9, 0.6), (7, 0.5, 1.3), (5000, 0.95, 0.8)])
+def test_top_k_then_top_p_matches_hf_warpers(V, top_k, top_p, temperature):
+    """The reference samples with top_k = 50 ahead of top_p (GeneratingArguments default).  Against transformers' own
+    TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper on the same scores: the kernel's kept set contains HF's,
+    extras are ties of HF's lowest kept value; the kept mass over the top-k mass matches; the drawn token is in the set."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    g = torch.Generator().manual_seed(V + top_k)
+    B = 2
+    logits = (torch.randn(B, V, generator=g) * 3.0).bfloat16().cuda()
+    logits[0, 10:14] = logits[0].max()                                  # exact ties at the top
+    s = Sampler(B, V)
+    s.seed.fill_(77)
+    tok = s(logits, temperature=temperature, top_p=top_p, top_k=top_k)
+    dbg = s.dbg.cpu()
+    inv = float(np.float32(1.0) / np.float32(temperature))
+    sc = (logits.float() * inv).cpu()
+    hf = TopKLogitsWarper(top_k)(None, TemperatureLogitsWarper(temperature)(None, logits.float().cpu()))
+    if top_p < 1.0:
+        hf = TopPLogitsWarper(top_p)(None, hf)
+    kept_hf = torch.isfinite(hf)
+    for b in range(B):
+        tau = _key_to_value(int(dbg[b, 2])) * inv
+        kept = sc[b] >= tau - 1e-6 * max(1.0, abs(tau))
+        assert bool((kept | ~kept_hf[b]).all())                         # HF's set is a subset of ours
+        extra = kept & ~kept_hf[b]
+        assert bool((sc[b][extra] <= sc[b][kept_hf[b]].min() + 1e-6).all())      # extras tie with HF's lowest kept value
+        assert int(kept.sum()) >= 1 and bool(kept[tok[b]])
+        # kept mass relative to the top-k mass (f64)
+        p = torch.softmax(sc[b].double(), dim=0)
+        kth = torch.topk(sc[b], min(top_k, V)).values[-1]
+        assert abs(float(dbg[b, 1]) / float(dbg[b, 0]) - (p[kept].sum() / 1.0).item()) < 3e-5
+        assert int((sc[b] >= kth).sum()) >= int(kept.sum()) or top_p >= 1.0
 
 
 def test_sampled_distribution_matches_softmax():
