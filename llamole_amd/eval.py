@@ -52,7 +52,11 @@ def load_yaml_args(path: str, overrides: Optional[Dict[str, Any]] = None):
         flash_attn=cfg.get("flash_attn", "auto"))
     data_args = SimpleNamespace(dataset=cfg.get("dataset"), dataset_dir=cfg.get("dataset_dir", "data"),
                                 template=cfg.get("template"), cutoff_len=int(cfg.get("cutoff_len", 1024)),
-                                learned_query_size=int(cfg.get("learned_query_size", 8)))
+                                learned_query_size=int(cfg.get("learned_query_size", 8)),
+                                # A* budget of phase 2 (constants of the reference driver, eval/workflow.py:171-173); overridable
+                                retro_iterations=int(cfg.get("retro_iterations", 100)),
+                                retro_max_planning_time=float(cfg.get("retro_max_planning_time", 30)),
+                                expansion_topk=int(cfg.get("expansion_topk", 50)))
     training_args = SimpleNamespace(per_device_eval_batch_size=int(cfg.get("per_device_eval_batch_size", 8)),
                                     do_train=bool(cfg.get("do_train", False)), output_dir=cfg.get("output_dir"))
     finetuning_args = SimpleNamespace(finetuning_type=cfg.get("finetuning_type", "lora"))
@@ -142,9 +146,37 @@ def run_molqa(model, tokenizer, records: List[dict], cutoff_len: int, batch_size
     return {"results": results, "stats": stats}
 
 
+def load_tokenizer(model_args):
+    """reference loader.py:88-138 in generate mode: left padding, the new special tokens ADDED to the existing additional
+    special tokens, pad = eos (eval/workflow.py:77)."""
+    from transformers import AutoTokenizer
+    tokenizer = AutoTokenizer.from_pretrained(model_args.model_name_or_path, padding_side="left")
+    new = list(model_args.new_special_tokens or [])
+    if new:
+        try:
+            tokenizer.add_special_tokens({"additional_special_tokens": new}, replace_additional_special_tokens=False)
+        except TypeError:       # transformers >= 5 renamed the keyword
+            tokenizer.add_tokens(new, special_tokens=True)
+    tokenizer.pad_token = tokenizer.eos_token
+    return tokenizer
+
+
+def special_token_ids(tokenizer, new_special_tokens) -> List[int]:
+    """Every added special token stops generation (eval/workflow.py:93-98: eos + tokenizer.additional_special_tokens_ids)."""
+    ids = list(getattr(tokenizer, "additional_special_tokens_ids", None) or [])
+    extra = []
+    for attr in ("additional_special_tokens", "extra_special_tokens"):          # the attribute was renamed in transformers 5
+        v = getattr(tokenizer, attr, None)
+        extra += list(v.values() if isinstance(v, dict) else (v or []))
+    for t in extra + list(new_special_tokens or []):
+        i = tokenizer.convert_tokens_to_ids(t)
+        if isinstance(i, int) and i >= 0 and i not in ids:
+            ids.append(i)
+    return ids
+
+
 def run_eval(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
     """Entry used by ``python main.py eval cfg.yaml``."""
-    from transformers import AutoTokenizer
     from .modeling_llamole import GraphLLMForCausalMLM
     model_args, data_args, training_args, finetuning_args, generating_args = load_yaml_args(config_path, overrides)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,21 +184,23 @@ def run_eval(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> Di
         import torch.distributed as dist
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl")
-    tokenizer = AutoTokenizer.from_pretrained(model_args.model_name_or_path, padding_side="left")   # generate mode: left pad
-    if model_args.new_special_tokens:
-        tokenizer.add_special_tokens({"additional_special_tokens": model_args.new_special_tokens}, replace_additional_special_tokens=False)
-    tokenizer.pad_token = tokenizer.eos_token
+    tokenizer = load_tokenizer(model_args)
     gen_kwargs = generating_args.to_dict()
-    gen_kwargs["eos_token_id"] = [tokenizer.eos_token_id] + list(tokenizer.additional_special_tokens_ids)
+    gen_kwargs["eos_token_id"] = [tokenizer.eos_token_id] + special_token_ids(tokenizer, model_args.new_special_tokens)
     gen_kwargs["pad_token_id"] = tokenizer.pad_token_id
-    model = GraphLLMForCausalMLM.from_pretrained(tokenizer, model_args, data_args, training_args, finetuning_args, load_adapter=True)
+    # the reference always passes load_adapter=True (eval/workflow.py:100-108) and therefore needs an adapter; a YAML without
+    # adapter_name_or_path evaluates the base model with the connectors of graph_lm_connector_path here instead of raising
+    model = GraphLLMForCausalMLM.from_pretrained(tokenizer, model_args, data_args, training_args, finetuning_args,
+                                                 load_adapter=bool(model_args.adapter_name_or_path))
     model.eval()
     accel = model.enable_mi355x_decode()
     model.batch_retro = bool(getattr(generating_args, "batch_retro", False) or (overrides or {}).get("batch_retro", False))
     if rank == 0:
         print(json.dumps({"llm_acceleration": accel}))
     out = run_molqa(model, tokenizer, load_dataset_records(data_args), data_args.cutoff_len,
-                    training_args.per_device_eval_batch_size, gen_kwargs, rank=rank, world=world)
+                    training_args.per_device_eval_batch_size, gen_kwargs, rank=rank, world=world,
+                    expansion_topk=data_args.expansion_topk, iterations=data_args.retro_iterations,
+                    max_planning_time=data_args.retro_max_planning_time)
     if rank == 0:
         print(json.dumps(out["stats"]))
         if training_args.output_dir:

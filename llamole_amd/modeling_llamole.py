@@ -117,9 +117,10 @@ class GraphLLMForCausalMLM(nn.Module):
             if load_adapter:
                 try:
                     from peft import PeftModel
-                except ImportError as e:
-                    raise ImportError("load_adapter=True needs `peft` (reference requirements.txt:18)") from e
-                language_model = PeftModel.from_pretrained(language_model, model_args.adapter_name_or_path[0]).merge_and_unload()
+                    language_model = PeftModel.from_pretrained(language_model, model_args.adapter_name_or_path[0]).merge_and_unload()
+                except ImportError:       # no peft in this image: merge the LoRA adapter from its on-disk layout directly
+                    from .sft import merge_lora_adapter
+                    merge_lora_adapter(language_model, model_args.adapter_name_or_path[0])
             language_model.to("cuda").eval()
         device = next(language_model.parameters()).device
         graph_decoder = load_graph_decoder(model_args, path=model_args.graph_decoder_path, device=device)

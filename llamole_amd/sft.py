@@ -133,3 +133,45 @@ def add_lora(model: torch.nn.Module, r: int = 8, alpha: int = 16, targets=("q_pr
                 setattr(parent, name, LoRALinear(child, r, alpha))
                 n += 1
     return n
+
+
+def merge_lora_adapter(model: torch.nn.Module, adapter_dir: str) -> int:
+    """Merge a LoRA adapter stored in peft's on-disk layout into ``model`` in place: ``W += (alpha / r) * B A`` for every
+    ``<module>.lora_A/lora_B`` pair, ``modules_to_save`` weights (the resized embed_tokens / lm_head the reference trains,
+    adapter.py:224-233) copied over.  What ``PeftModel.from_pretrained(...).merge_and_unload()`` does (reference
+    adapter.py:190-192), for images without ``peft``.  Returns the number of merged Linears."""
+    import json
+    import os
+    with open(os.path.join(adapter_dir, "adapter_config.json")) as f:
+        cfg = json.load(f)
+    if cfg.get("peft_type", "LORA") != "LORA":
+        raise ValueError(f"unsupported adapter type {cfg.get('peft_type')}")
+    r, alpha = int(cfg["r"]), float(cfg["lora_alpha"])
+    scale = alpha / (r ** 0.5) if cfg.get("use_rslora") else alpha / r
+    st_path = os.path.join(adapter_dir, "adapter_model.safetensors")
+    if os.path.exists(st_path):
+        from safetensors.torch import load_file
+        tensors = load_file(st_path)
+    else:
+        tensors = torch.load(os.path.join(adapter_dir, "adapter_model.bin"), map_location="cpu", weights_only=True)
+    mods = dict(model.named_modules())
+    params = dict(model.named_parameters())
+    strip = lambda k: k[len("base_model.model."):] if k.startswith("base_model.model.") else k      # noqa: E731
+    merged = 0
+    with torch.no_grad():
+        for k, a in tensors.items():
+            name = strip(k)
+            if name.endswith(".lora_A.weight"):
+                base = name[:-len(".lora_A.weight")]
+                b = tensors[k.replace("lora_A", "lora_B")]
+                lin = mods[base]
+                delta = (b.float() @ a.float()) * scale
+                if cfg.get("fan_in_fan_out"):
+                    delta = delta.t()
+                lin.weight.add_(delta.to(device=lin.weight.device, dtype=lin.weight.dtype))
+                merged += 1
+            elif ".lora_" not in name:              # modules_to_save: full replacement weights
+                tgt = params.get(name) or params.get(name.replace(".modules_to_save.default", "").replace(".modules_to_save", ""))
+                if tgt is not None and tgt.shape == a.shape:
+                    tgt.copy_(a.to(device=tgt.device, dtype=tgt.dtype))
+    return merged

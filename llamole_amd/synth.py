@@ -362,3 +362,140 @@ def make_dit_train_batch(meta, B, seed, T):
     props[0, 1] = -200.0
     t = [0, T, 3, 3] + [int(rs.randint(1, T + 1)) for _ in range(max(0, B - 4))]
     return x, ei, ea, torch.tensor(bt, dtype=torch.long), props, text, torch.tensor(t[:B], dtype=torch.long).view(B, 1)
+
+
+# --------------------------------------------------------------------------- whole-pipeline fixture (main.py eval on the GPU box)
+EVAL_WORDS = ("design a molecule polymer drug with high low gas permeability co2 n2 o2 synthetic accessibility complexity that can "
+              "you and the of to is has its for this be used analysis follow these procedures synthesize estimate remaining steps "
+              "target consider following factors intermediate reagent availability side reactions stereochemistry challenges all "
+              "readily available some commercial need mix multi step synthesis mostly require complex extensive given parameters "
+              "current template reactants . , : ? 1 2 3 4 5").split()
+
+
+def write_encoder_dir(path: str, num_layer: int = 3, H: int = 64, seed: int = 0) -> str:
+    """GraphCLIP checkpoint directory (reference loader.py:322-363: config.json, model.pt, model_proj.pt)."""
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump({"num_layer": num_layer, "hidden_size": H, "drop_ratio": 0.0}, f)
+    torch.save(make_gin_weights(num_layer, H, "encoder", seed=seed), os.path.join(path, "model.pt"))
+    torch.save(make_proj_weights(H, seed), os.path.join(path, "model_proj.pt"))
+    return path
+
+
+def write_predictor_dir(path: str, num_layer: int = 3, H: int = 64, out_dim: int = 512, seed: int = 0,
+                        available=("R0", "R1", "R2", "R3", "A0", "A1", "A2", "B0", "B1", "B2", "B3", "B4", "B5")) -> str:
+    """GraphPredictor checkpoint directory (reference loader.py:263-320: config.json, model.pt, cost_model.pt,
+    label_to_template.csv.gz {rule_label, retro_templates}, available.csv.gz {smiles}); templates are named T<i>."""
+    import pandas as pd
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump({"num_layer": num_layer, "hidden_size": H, "drop_ratio": 0.0, "num_task": out_dim, "text_input_size": TEXT_DIM}, f)
+    torch.save(make_gin_weights(num_layer, H, "predictor", out_dim, seed), os.path.join(path, "model.pt"))
+    torch.save(make_cost_weights(seed), os.path.join(path, "cost_model.pt"))
+    pd.DataFrame({"rule_label": list(range(out_dim)), "retro_templates": [f"T{i}" for i in range(out_dim)]}).to_csv(
+        os.path.join(path, "label_to_template.csv.gz"), index=False, compression="gzip")
+    pd.DataFrame({"smiles": list(available)}).to_csv(os.path.join(path, "available.csv.gz"), index=False, compression="gzip")
+    return path
+
+
+def write_llm_dir(path: str, special_tokens, name: str = "tiny", seed: int = 0) -> str:
+    """A local `model_name_or_path`: tiny random-init HF causal LM (llamole_amd.e2e.LLM_CONFIGS[name]) saved with
+    save_pretrained, plus a byte-level BPE tokenizer trained on a few sentences (the form AutoTokenizer resolves for a Qwen2 /
+    Llama directory) with a chat template and an eos/pad token; the nine Llamole special tokens are NOT added yet (the driver
+    adds them, like the reference's load_tokenizer, loader.py:88-138)."""
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, trainers
+    from transformers import PreTrainedTokenizerFast
+    from . import e2e
+    os.makedirs(path, exist_ok=True)
+    tok = Tokenizer(models.BPE(unk_token=None))
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tok.decoder = decoders.ByteLevel()
+    trainer = trainers.BpeTrainer(vocab_size=600, special_tokens=["<|endoftext|>", "<|user|>", "<|assistant|>"],
+                                  initial_alphabet=pre_tokenizers.ByteLevel.alphabet(), show_progress=False)
+    corpus = [" ".join(EVAL_WORDS)] * 4 + ["CCO CC(=O)O c1ccccc1 N#C [H] * >> . T0 T1 R0.A1 To synthesize , follow these procedures :"]
+    tok.train_from_iterator(corpus, trainer)
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<|endoftext|>", pad_token="<|endoftext|>",
+                                   additional_special_tokens=["<|user|>", "<|assistant|>"])
+    fast.chat_template = ("{% for m in messages %}<|{{ m['role'] }}|> {{ m['content'] }} {% endfor %}"
+                          "{% if add_generation_prompt %}<|assistant|> {% endif %}")
+    fast.save_pretrained(path)
+    llm = e2e.build_llm(name, "cpu", torch.bfloat16, seed=seed)
+    assert llm.config.vocab_size >= len(fast) + len(list(special_tokens))
+    llm.save_pretrained(path, safe_serialization=True)
+    return path
+
+
+def write_connector_dir(path: str, llm_hidden: int, gin_hidden: int, seed: int = 0) -> str:
+    """connector/{graph_to_lm_connector,lm_to_graph_decoder,lm_to_graph_predictor}.pt (reference modeling_llamole.py:246-275)."""
+    os.makedirs(path, exist_ok=True)
+    g = torch.Generator().manual_seed(8000 + seed)
+    for name, (i, o) in (("graph_to_lm_connector", (gin_hidden, llm_hidden)), ("lm_to_graph_decoder", (llm_hidden, TEXT_DIM)),
+                         ("lm_to_graph_predictor", (llm_hidden, TEXT_DIM))):
+        torch.save({"0.weight": torch.randn(o, i, generator=g) * (1.0 / i) ** 0.5, "0.bias": torch.randn(o, generator=g) * 0.02},
+                   os.path.join(path, name + ".pt"))
+    return path
+
+
+def write_lora_adapter_dir(path: str, llm, r: int = 4, alpha: int = 8, seed: int = 0,
+                           targets=("q_proj", "v_proj", "down_proj")) -> str:
+    """A LoRA adapter in peft's on-disk layout (adapter_config.json + adapter_model.safetensors with
+    ``base_model.model.<module>.lora_A.weight`` / ``lora_B.weight`` keys) for every target Linear of ``llm``."""
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    g = torch.Generator().manual_seed(9000 + seed)
+    tensors = {}
+    for name, mod in llm.named_modules():
+        if name.split(".")[-1] in targets and isinstance(mod, torch.nn.Linear):
+            tensors[f"base_model.model.{name}.lora_A.weight"] = torch.randn(r, mod.in_features, generator=g) * 0.05
+            tensors[f"base_model.model.{name}.lora_B.weight"] = torch.randn(mod.out_features, r, generator=g) * 0.05
+    save_file(tensors, os.path.join(path, "adapter_model.safetensors"))
+    with open(os.path.join(path, "adapter_config.json"), "w") as f:
+        json.dump({"peft_type": "LORA", "r": r, "lora_alpha": alpha, "target_modules": list(targets), "use_rslora": False,
+                   "fan_in_fan_out": False, "bias": "none", "modules_to_save": None}, f)
+    return path
+
+
+def write_molqa_dataset(dataset_dir: str, name: str = "molqa_synth", n: int = 5) -> str:
+    """dataset_info.json + a MolQA-style json (instruction / input / property dict), reference data/*.json layout."""
+    os.makedirs(dataset_dir, exist_ok=True)
+    recs = []
+    for i in range(n):
+        recs.append({"instruction": "design a polymer with high co2 permeability and low synthetic complexity ?",
+                     "input": "", "property": {"CO2": 10.0 + 7 * i, "N2": 1.0 + i, "SA": 3.0, "SC": 2.5}})
+    with open(os.path.join(dataset_dir, "dataset_info.json"), "w") as f:
+        json.dump({name: {"file_name": name + ".json"}}, f)
+    with open(os.path.join(dataset_dir, name + ".json"), "w") as f:
+        json.dump(recs, f)
+    return name
+
+
+def write_eval_fixture(root: str, special_tokens, with_adapter: bool = True) -> str:
+    """Everything `python main.py eval cfg.yaml` reads, synthetic and local: LLM + tokenizer, LoRA adapter + connectors, the
+    three graph checkpoints, a dataset, and the YAML with the reference's keys (config/generate/qwen_material.yaml)."""
+    import yaml
+    from . import e2e
+    llm_dir = write_llm_dir(os.path.join(root, "llm"), special_tokens)
+    cfg = make_dit_config(hidden_size=128, depth=2, num_heads=4, diffusion_steps=10, guide_scale=2.0)
+    meta = make_data_meta(16, 0)
+    write_dit_dir(os.path.join(root, "graph_decoder"), cfg, meta, make_dit_weights(cfg, 16, 0))
+    write_encoder_dir(os.path.join(root, "graph_encoder"))
+    write_predictor_dir(os.path.join(root, "graph_predictor"))
+    hid = e2e.LLM_CONFIGS["tiny"]["hidden_size"]
+    adapter = os.path.join(root, "adapter")
+    if with_adapter:
+        write_lora_adapter_dir(adapter, e2e.build_llm("tiny", "cpu", torch.bfloat16))
+    write_connector_dir(os.path.join(adapter, "connector"), hid, 64)
+    ds = write_molqa_dataset(os.path.join(root, "data"))
+    y = {"model_name_or_path": llm_dir, "new_special_tokens": ",".join(special_tokens),
+         "graph_decoder_path": os.path.join(root, "graph_decoder"), "graph_encoder_path": os.path.join(root, "graph_encoder"),
+         "graph_predictor_path": os.path.join(root, "graph_predictor"), "adapter_name_or_path": adapter,
+         "graph_lm_connector_path": os.path.join(adapter, "connector"), "stage": "mmsft", "do_train": False,
+         "finetuning_type": "lora", "max_new_tokens": 16, "temperature": 0.6, "top_p": 0.9, "learned_query_size": 8,
+         "dataset": ds, "dataset_dir": os.path.join(root, "data"), "template": "qwen", "cutoff_len": 32, "bf16": True,
+         "pure_bf16": True, "per_device_eval_batch_size": 2, "output_dir": os.path.join(root, "out")}
+    if not with_adapter:
+        y.pop("adapter_name_or_path")
+    path = os.path.join(root, "generate.yaml")
+    with open(path, "w") as f:
+        yaml.safe_dump(y, f)
+    return path
