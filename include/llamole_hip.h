@@ -62,6 +62,10 @@ int ll_linear_cfg(int cfg, const void *A, int lda, const void *W, int ldw, const
                   int splits, int epi, int out_f32, void *stream);
 /* Tuning: waves per workgroup of the <= 64-row panel GEMM (4 | 8; default 8); returns the previous value. */
 int ll_set_m64_waves(int waves);
+/* ll_set_gemm_krot : the LDS-DMA GEMM sweeps its k-tiles starting at ((m_tile * (krot & 255) + n_tile * (krot >> 8 or 1)) mod
+ * n_ktiles) instead of 0, so that workgroups sharing an operand tile do not miss L2 on the same lines at the same time.  0 = off.
+ * Changes the f32 summation order per tile (deterministic).  Returns the previous setting. */
+int ll_set_gemm_krot(int krot);
 
 /* Launch-latency probe (tuning utility): average us per kernel over n launches of a trivial kernel
  * (kind 0 empty, 1 load+store, 2 dependent loads, 3 1-MB copy), eager stream (graph=0) or one hipGraph (graph=1). */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "ll_set_gemv_nt": (_I, [_I]),
     "ll_set_gemv_stage": (_I, [_I]),
     "ll_set_m64_waves": (_I, [_I]),
+    "ll_set_gemm_krot": (_I, [_I]),
     "ll_set_lnmod_multiwave": (_I, [_I]),
     "ll_set_attn_waves": (_I, [_I]),
     "ll_dit_set_overlap": (_I, [_P, _I]),

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipe_kernel(const bf16_
                                                                       const bf16_t *__restrict__ W, int ldw,
                                                                       OutT *__restrict__ C, int ldc,
                                                                       const float *__restrict__ bias, int M, int N,
-                                                                      int kchunk, int64_t slab_stride, int epi) {
+                                                                      int kchunk, int64_t slab_stride, int epi, int krot) {
     constexpr int NT = WM * WN * 64, NW = WM * WN;
     constexpr int BK = 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -200,6 +200,11 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipe_kernel(const bf16_
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * kchunk;
     const int nk = kchunk / BK;
+    // k-tile order rotated per workgroup (krot != 0): the workgroups that share an operand tile -- all M-tiles of one N-tile read
+    // the same weight rows, all N-tiles of one M-tile the same activation rows -- otherwise sweep K in lock step, so every one of
+    // them misses L2 on every line together and waits the full HBM / Infinity-Cache latency; staggered, one of them fetches a
+    // line and the others hit it in L2 later
+    const int rot = krot ? (int)((blockIdx.y * krot + blockIdx.x * (krot >> 8 ? krot >> 8 : 1)) % (unsigned)nk) : 0;
 
     // per-lane source pointers (swizzled chunk of the lane's row), advanced by BK elements per tile
     const bf16_t *pa[LA];
@@ -223,13 +228,15 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipe_kernel(const bf16_
     auto issue = [&](int kt) {
         unsigned char *sa = smem_pipe + (kt % STAGES) * STAGE_BYTES;
         unsigned char *sb = sa + BM * 128;
+        int kg = kt + rot;
+        kg = kg >= nk ? kg - nk : kg;
 #pragma unroll
         for (int it = 0; it < LA; ++it)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa[it] + (int64_t)kt * BK),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa[it] + (int64_t)kg * BK),
                                              (__attribute__((address_space(3))) void *)(sa + (it * NW + wave) * 1024), 16, 0, 0);
 #pragma unroll
         for (int it = 0; it < LB; ++it)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb[it] + (int64_t)kt * BK),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb[it] + (int64_t)kg * BK),
                                              (__attribute__((address_space(3))) void *)(sb + (it * NW + wave) * 1024), 16, 0, 0);
     };
 
@@ -592,6 +599,8 @@ static void launch_bf16(const bf16_t *A, int lda, const bf16_t *W, int ldw, void
                            ldc, bias, M, N, kchunk, slab_stride, epi);
 }
 
+static int g_gemm_krot = 0;      // ll_set_gemm_krot: k-tile rotation per workgroup of the LDS-DMA GEMM (0 = off)
+
 template <int BM, int BN, int WM, int WN, int STAGES>
 static int launch_pipe(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M,
                        int N, int K, int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
@@ -609,10 +618,10 @@ static int launch_pipe(const bf16_t *A, int lda, const bf16_t *W, int ldw, void 
     const int kchunk = K / splits;
     if (out_f32)
         hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, WM, WN, STAGES, float>), grid, block, lds, s, A, lda, W, ldw,
-                           (float *)C, ldc, bias, M, N, kchunk, slab_stride, epi);
+                           (float *)C, ldc, bias, M, N, kchunk, slab_stride, epi, g_gemm_krot);
     else
         hipLaunchKernelGGL((gemm_bf16_pipe_kernel<BM, BN, WM, WN, STAGES, bf16_t>), grid, block, lds, s, A, lda, W, ldw,
-                           (bf16_t *)C, ldc, bias, M, N, kchunk, slab_stride, epi);
+                           (bf16_t *)C, ldc, bias, M, N, kchunk, slab_stride, epi, g_gemm_krot);
     return LL_OK;
 }
 
@@ -926,6 +935,178 @@ static int launch_rs(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C
     return LL_OK;
 }
 
+// ------------------------------------------------------------------------------------------ bf16 MFMA, ping-pong wave groups
+// tools/gemm_phase_probe.hip (round 2): in gemm_bf16_pipe_kernel a wave spends, per k-tile, ~80 cycles waiting for data, ~200
+// in the barrier, ~230-390 ISSUING the next tile's DMA pieces (the CU's address path takes ~9-12 cycles per 1-KB piece and every
+// wave of the workgroup issues at the same moment) and ~250 on fragment reads + MFMA (which is the MFMA rate) -- issue and math
+// never overlap because the barrier keeps all waves in the same phase.  Here the eight waves form two groups of four (one wave
+// per SIMD each) that run half a k-tile out of phase: in every slot one group multiplies its half of the output tile while the
+// other issues its half of a future tile's DMA pieces and waits for an older tile of its own to land; one raw s_barrier per slot.
+//   slot 2t   : group 0 = MFMA(tile t)                     | group 1 = DMA(tile t+S-2), wait own pieces of tile t+1
+//   slot 2t+1 : group 0 = DMA(tile t+S-1), wait tile t+1   | group 1 = MFMA(tile t)
+// Hazards: a stage is rewritten two slots after its last reader's slot at the earliest (a barrier in between); a tile is read
+// only after BOTH groups waited for their pieces of it and a barrier has passed (cdna_hip_programming.md: read a staged buffer
+// one phase after the wait that retires it).  Group g owns rows [g*BM/2, (g+1)*BM/2) of the tile; wave tile (BM/4) x (BN/2).
+template <int BM, int BN, int STAGES, typename OutT>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ W, int ldw,
+                                                      OutT *__restrict__ C, int ldc, const float *__restrict__ bias, int M, int N,
+                                                      int kchunk, int64_t slab_stride, int epi) {
+    constexpr int BK = 64;
+    constexpr int TM = BM / 4, TN = BN / 2, MT = TM / 16, NTL = TN / 16;      // 2 groups x (2 x 2) waves
+    constexpr int PIECES = (BM + BN) / 8;            // 1-KB DMA pieces per k-tile (8 rows of 128 B each)
+    constexpr int LPT = PIECES / 8;                  // pieces per wave per tile (each group issues half the tile)
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static_assert(PIECES % 8 == 0 && TM % 16 == 0 && TN % 16 == 0 && STAGES >= 4, "tile / stage geometry");
+    static_assert((STAGES - 2) * LPT <= 63, "vmcnt immediate overflow");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pp[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int wm = grp * 2 + (w4 >> 1), wn = w4 & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * kchunk;
+    const int nk = kchunk / BK;
+    // this wave's pieces: piece p = wave + 8 * i covers rows [8p, 8p + 8) of the stage image (A rows first, then W rows)
+    const bf16_t *src[LPT];
+    int dst[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int p = wave + 8 * i, row = p * 8 + (lane >> 3), slot = lane & 7;
+        const int sw = (slot ^ (row & 7)) << 3;
+        if (row < BM) {
+            int ar = m0 + row;
+            ar = ar < M ? ar : M - 1;
+            src[i] = A + (int64_t)ar * lda + kbeg + sw;
+        } else {
+            int br = n0 + row - BM;
+            br = br < N ? br : N - 1;
+            src[i] = W + (int64_t)br * ldw + kbeg + sw;
+        }
+        dst[i] = p * 1024;
+    }
+    auto issue = [&](int kt) {
+        unsigned char *st = smem_pp + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + (int64_t)kt * BK),
+                                             (__attribute__((address_space(3))) void *)(st + dst[i]), 16, 0, 0);
+    };
+    f32x4 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fk = lane >> 4;
+    auto math = [&](int kt) {
+        const unsigned char *Ab = smem_pp + (kt % STAGES) * STAGE_BYTES;
+        const unsigned char *Bb = Ab + BM * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[MT], fb[NTL];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = wm * TM + i * 16 + frow, ch = kk * 4 + fk;
+                fa[i] = *reinterpret_cast<const bf16x8 *>(Ab + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int row = wn * TN + j * 16 + frow, ch = kk * 4 + fk;
+                fb[j] = *reinterpret_cast<const bf16x8 *>(Bb + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // wait until this wave's pieces of every tile up to `upto` have landed, given that tiles up to `newest` have been issued
+    auto landed = [&](int upto, int newest) {
+        const int younger = newest - upto;           // own tiles still allowed in flight
+        if (younger >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
+        else if (younger == STAGES - 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 3) * LPT) : "memory");
+        else if (STAGES >= 5 && younger == STAGES - 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES >= 5 ? STAGES - 4 : 0) * LPT) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto slot_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // prologue: group 0 has issued tiles 0..S-2, group 1 tiles 0..S-3 (it issues tile S-2 in slot 0); both wait for tile 0
+    {
+        const int pre = grp == 0 ? STAGES - 1 : STAGES - 2;
+        int newest = -1;
+        for (int p = 0; p < pre && p < nk; ++p) { issue(p); newest = p; }
+        landed(0, newest);
+    }
+    slot_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        // ---- slot 2 kt
+        if (grp == 0) {
+            math(kt);
+        } else {
+            const int j = kt + STAGES - 2;
+            const int newest = j < nk ? j : nk - 1;
+            if (j < nk) issue(j);
+            if (kt + 1 < nk) landed(kt + 1, newest);
+        }
+        slot_barrier();
+        // ---- slot 2 kt + 1
+        if (grp == 0) {
+            const int j = kt + STAGES - 1;
+            const int newest = j < nk ? j : nk - 1;
+            if (j < nk) issue(j);
+            if (kt + 1 < nk) landed(kt + 1, newest);    // read in the next slot, after the barrier (S-2 younger tiles stay in flight)
+        } else {
+            math(kt);
+        }
+        slot_barrier();
+    }
+    OutT *Cz = C + (int64_t)blockIdx.z * slab_stride;
+    const bool raw = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const int col = n0 + wn * TN + j * 16 + (lane & 15);
+            if (col >= N) continue;
+            const float bv = (!raw && bias) ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * TM + i * 16 + (lane >> 4) * 4 + r;
+                if (row < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (!raw) v = apply_epi(v, epi);
+                    Cz[(int64_t)row * ldc + col] = from_f32<OutT>(v);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int STAGES>
+static int launch_pp(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M, int N, int K,
+                     int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
+    constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+    static_assert(lds <= 160 * 1024, "ring must fit the 160 KB of a CU");
+    LL_CHECK(K % (64 * splits) == 0, "gemm_pp: K per split must be a multiple of 64");
+    static bool attr_set = false;
+    if (!attr_set) {
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_pp_kernel<BM, BN, STAGES, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_pp_kernel<BM, BN, STAGES, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), splits);
+    const int kchunk = K / splits;
+    if (out_f32)
+        hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, STAGES, float>), grid, dim3(512), lds, s, A, lda, W, ldw, (float *)C, ldc, bias, M, N, kchunk,
+                           slab_stride, epi);
+    else
+        hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, STAGES, bf16_t>), grid, dim3(512), lds, s, A, lda, W, ldw, (bf16_t *)C, ldc, bias, M, N, kchunk,
+                           slab_stride, epi);
+    return LL_OK;
+}
+
 static int g_gemm_variant = -1;  // LL_GEMM_VARIANT=0 forces the 2-stage register-staged kernels (A/B testing)
 static thread_local int g_no_panel_gemm = 0;  // per host thread; set_panel_gemm(false): <= 64-row panels take the LDS-DMA ring (48 KB of LDS) instead of gemm_m64_kernel
 
@@ -1101,6 +1282,14 @@ static const PipeCfg g_pipe_cfgs[] = {
     {128, 64, 402, launch_rs<128, 64, 2, 2>},      // 45  4 waves, wave tile 64 x 32
     {128, 32, 402, launch_rs<128, 32, 4, 2>},      // 46
     {256, 64, 402, launch_rs<256, 64, 4, 2>},      // 47  wave tile 64 x 32
+    {128, 64, 504, launch_pp<128, 64, 4>},         // 48  ping-pong wave groups, LDS-DMA ring
+    {128, 64, 505, launch_pp<128, 64, 5>},         // 49
+    {128, 64, 506, launch_pp<128, 64, 6>},         // 50
+    {64, 64, 504, launch_pp<64, 64, 4>},           // 51
+    {64, 64, 506, launch_pp<64, 64, 6>},           // 52
+    {128, 128, 504, launch_pp<128, 128, 4>},       // 53
+    {128, 128, 505, launch_pp<128, 128, 5>},       // 54
+    {64, 128, 505, launch_pp<64, 128, 5>},         // 55
 };
 }  // namespace ll
 
@@ -1308,6 +1497,12 @@ extern "C" int ll_linear_splitk_bf16(const void *A, int lda, const void *W, int 
     hipLaunchKernelGGL(slab_reduce_bf16_kernel, dim3(blocks), dim3(256), 0, st, workspace, total, splits, bias, (bf16_t *)C, ldc, M, N, epi);
     LL_LAUNCH_CHECK();
     return LL_OK;
+}
+
+extern "C" int ll_set_gemm_krot(int krot) {
+    const int old = ll::g_gemm_krot;
+    ll::g_gemm_krot = krot < 0 ? 0 : krot;
+    return old;
 }
 
 extern "C" int ll_set_m64_waves(int waves) {

@@ -93,11 +93,12 @@ def test_linear_matches_torch():
 
 
 def test_register_staged_gemm_configs_match_torch():
-    """gemm_rs_kernel (tuning-table ids 41..47) through ll_linear_cfg: ragged M and N, split-K slabs, bias + GELU epilogue."""
+    """gemm_rs_kernel (tuning-table ids 41..47) and gemm_pp_kernel (48..55) through ll_linear_cfg: ragged M and N, split-K slabs,
+    bias + GELU epilogue, K chunks down to 2 k-tiles (shorter than the ring)."""
     from llamole_amd import _lib
     lib = _lib.load()
     torch.manual_seed(2)
-    for cfg in (41, 42, 43, 44, 45, 46, 47):
+    for cfg in (41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55):
         for (M, N, K, splits) in [(512, 4096, 1024, 1), (512, 1024, 4096, 4), (200, 1000, 256, 1), (130, 72, 128, 1), (2048, 3072, 1024, 1),
                                   (64, 176, 1024, 2)]:
             A = torch.randn(M, K, device="cuda").bfloat16()

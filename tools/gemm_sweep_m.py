@@ -10,6 +10,8 @@ from llamole_amd import _lib  # noqa: E402
 
 lib = _lib.load()
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+if len(sys.argv) > 3:
+    lib.ll_set_gemm_krot(int(sys.argv[3]))
 cfgs = [int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else [-1, 0, 1, 5, 6, 7, 8, 9, 11, 17, 18, 19, 20, 21, 22]
 H = 1024
 shapes = [("qkv", 3 * H, H, 1), ("proj", H, H, 1), ("proj", H, H, 2), ("proj", H, H, 4), ("fc1", 4 * H, H, 1), ("fc2", H, 4 * H, 1),
