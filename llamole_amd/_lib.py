@@ -105,6 +105,16 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m llamole_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the graph hot path.")
+    # PyTorch-ROCm ships its own HIP runtime; the one that is loaded FIRST in a process is the one that can open the device
+    # (build() followed by smoke() in one process loaded this library before torch had touched HIP, and every hipMalloc of the
+    # library then failed with "no ROCm-capable device is detected").  Torch provides the device memory and streams this library
+    # is handed, so its runtime goes first; libamdhip64 of this library then resolves to the copy already in the process.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
