@@ -326,6 +326,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if world > 1:
+        # N ranks share this node's host cores: keep every rank's intra-op thread pool to its share (an oversubscribed OpenMP pool
+        # stalls the Python thread that replays the decode graphs)
+        torch.set_num_threads(max(1, usable_cores() // world))
     if args.blas != "default":
         torch.backends.cuda.preferred_blas_library(args.blas)
     n_ranks = 1

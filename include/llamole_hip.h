@@ -158,6 +158,10 @@ int ll_dit_last_run_ms(void *handle, float *ms, int *steps);
 /* Tuning: ln_mod_res with one wave per 256-column chunk of a row (default) or one wave per row; bit-identical results; returns the
  * previous setting. */
 int ll_set_lnmod_multiwave(int on);
+/* ll_set_stage_mod : 1 (default) = every step first copies its (B+1) x L x 6H modulation rows to a fixed buffer, so that the 2L
+ * AdaLN epilogue launches of the step address them without waiting for the step index in device memory (one memory round trip per
+ * launch instead of two); 0 = every launch walks the hoisted table.  Bit-identical.  Takes effect at the next graph capture. */
+int ll_set_stage_mod(int on);
 /* Tuning: waves per (sequence, head) of the MFMA graph attention (1 | 2; default 2; bit-identical); returns the previous value. */
 int ll_set_attn_waves(int waves);
 

@@ -81,6 +81,7 @@ SIGNATURES = {
     "ll_set_m64_waves": (_I, [_I]),
     "ll_set_gemm_krot": (_I, [_I]),
     "ll_set_lnmod_multiwave": (_I, [_I]),
+    "ll_set_stage_mod": (_I, [_I]),
     "ll_set_attn_waves": (_I, [_I]),
     "ll_dit_set_overlap": (_I, [_P, _I]),
     "ll_dit_set_option": (_I, [_P, _I, _I]),

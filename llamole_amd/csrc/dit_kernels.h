@@ -424,6 +424,7 @@ __global__ __launch_bounds__(64) void ln_mod_res_kernel(const float *__restrict_
                                                           T *__restrict__ xa, const float *__restrict__ modtab,
                                                           const int *__restrict__ step_ptr,
                                                           const int *__restrict__ rowvec /*[B] table rows or null*/,
+                                                          const float *__restrict__ modcur /*[B+1][L][6H] rows of the current step or null*/,
                                                           int layer, int sel, int B, int N, int H, int L, int M2) {
     // one 64-lane wave = one token row = one workgroup: rows spread over as many CUs as possible, because the
     // per-CU load path (~25-40 GB/s), not HBM, bounds these small row kernels
@@ -432,9 +433,16 @@ __global__ __launch_bounds__(64) void ln_mod_res_kernel(const float *__restrict_
     const int lane = threadIdx.x & 63;
     const int seq = row / N;
     // table row: the shared reverse step, or (training forward) a per-graph row -- t differs from graph to graph there
-    const int s = rowvec ? rowvec[seq < B ? seq : seq - B] : *step_ptr;
     const int ci = (seq < B) ? seq : B;  // unconditional pass shares one row
-    const float *mod = modtab + (((int64_t)s * (B + 1) + ci) * L + layer) * (6 * (int64_t)H) + (int64_t)sel * 3 * H;
+    // modcur: this step's rows staged at a fixed address by stage_mod_kernel -- the modulation loads then do not wait for the
+    // step index (one memory round trip per launch instead of two); the table walk stays for per-graph rows (training forward)
+    const float *mod;
+    if (modcur) {
+        mod = modcur + ((int64_t)ci * L + layer) * (6 * (int64_t)H) + (int64_t)sel * 3 * H;
+    } else {
+        const int s = rowvec ? rowvec[seq < B ? seq : seq - B] : *step_ptr;
+        mod = modtab + (((int64_t)s * (B + 1) + ci) * L + layer) * (6 * (int64_t)H) + (int64_t)sel * 3 * H;
+    }
     // MAXE float4 chunks per lane (H <= 256*MAXE).  Every load of the row -- split-K slabs, bias, residual
     // and the three modulation vectors -- is issued up front: one memory round trip after the step index.
     float4 v[MAXE], xr[MAXE], sh[MAXE], sc[MAXE], ga[MAXE];
@@ -494,15 +502,21 @@ __global__ __launch_bounds__(64 * MAXE) void ln_mod_res_mw_kernel(const float *_
                                                                    const float *__restrict__ bias, float *__restrict__ x32,
                                                                    T *__restrict__ xa, const float *__restrict__ modtab,
                                                                    const int *__restrict__ step_ptr, const int *__restrict__ rowvec,
+                                                                   const float *__restrict__ modcur,
                                                                    int layer, int sel, int B, int N, int H, int L, int M2) {
     __shared__ float part[2][MAXE][64];
     const int row = blockIdx.x;
     if (row >= M2) return;
     const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
     const int seq = row / N;
-    const int s = rowvec ? rowvec[seq < B ? seq : seq - B] : *step_ptr;
     const int ci = (seq < B) ? seq : B;
-    const float *mod = modtab + (((int64_t)s * (B + 1) + ci) * L + layer) * (6 * (int64_t)H) + (int64_t)sel * 3 * H;
+    const float *mod;
+    if (modcur) {
+        mod = modcur + ((int64_t)ci * L + layer) * (6 * (int64_t)H) + (int64_t)sel * 3 * H;
+    } else {
+        const int s = rowvec ? rowvec[seq < B ? seq : seq - B] : *step_ptr;
+        mod = modtab + (((int64_t)s * (B + 1) + ci) * L + layer) * (6 * (int64_t)H) + (int64_t)sel * 3 * H;
+    }
     const int h = (lane + e * 64) * 4;
     const bool ok = h < H;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f), xr = v, sh = v, sc = v, ga = v;
@@ -1008,6 +1022,16 @@ __global__ void set_scalars_kernel(int *step_ptr, int s, unsigned long long *see
     *seed_ptr = seed;
 }
 __global__ void advance_step_kernel(int *step_ptr) { *step_ptr = *step_ptr - 1; }
+
+// modcur[ci][l][6H] = modtab[s][ci][l][6H] for the step s in device memory: the first node of every step
+__global__ __launch_bounds__(256) void stage_mod_kernel(const float *__restrict__ modtab, float *__restrict__ modcur,
+                                                         const int *__restrict__ step_ptr, int64_t row_floats) {
+    const int s = *step_ptr;
+    const float4 *src = reinterpret_cast<const float4 *>(modtab + (int64_t)s * row_floats);
+    float4 *dst = reinterpret_cast<float4 *>(modcur);
+    const int64_t n4 = row_floats / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
 
 // out[c][r] = in[r][c]  (weight re-layout at create time)
 __global__ void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int R, int C) {

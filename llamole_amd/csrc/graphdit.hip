@@ -145,7 +145,7 @@ struct DitEngine {
     int B = 0, M2 = 0, M2p = 0, splits_h = 1, splits_m = 1;
     bool begun = false, state_set = false;
     DevBuf n_nodes, X, E, x32, xa, qkv, attn_o, ybuf, h1, ho, outF;
-    DevBuf ct_in, ct_h, ct, zy, cy, txt_op, ctxt, ynan, tnan, c32, ca, m1, modtab, modo, rows;
+    DevBuf ct_in, ct_h, ct, zy, cy, txt_op, ctxt, ynan, tnan, c32, ca, m1, modtab, modo, rows, modcur;
     DevBuf scal;  // [0] int step, [8] u64 seed
     DevBuf predX, pxe;
     int state_half = 0;      // which half of X/E holds the current state
@@ -244,21 +244,23 @@ template <typename T> static void launch_attn(DitEngine *e, int layer, hipStream
                        e->pfs(p + "k_norm.weight"), e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, N,
                        e->cfg.hidden, hd);
 }
+static int g_stage_mod = 1;           // stage the step's modulation rows at a fixed address (ll_set_stage_mod)
 static int g_lnmod_multiwave = 1;     // one wave per 256-column chunk of a row (ln_mod_res_mw_kernel) instead of one wave per row
 
 template <typename T>
 static void launch_lnmod(DitEngine *e, int layer, int sel, int nslab, const float *bias, hipStream_t st) {
     const dim3 grid(e->M2), blk(64);
     const int64_t ss = (int64_t)e->M2p * e->cfg.hidden;
+    const float *mc = (e->rowvec == nullptr && g_stage_mod) ? e->modcur.as<float>() : nullptr;   // staged rows of this step (denoise_body)
 #define LL_LNMOD2(NS, ME)                                                                                              \
     do {                                                                                                               \
         if (ME > 1 && g_lnmod_multiwave)                                                                               \
             hipLaunchKernelGGL((ln_mod_res_mw_kernel<T, NS, ME>), grid, dim3(64 * ME), 0, st, e->ybuf.as<float>(), ss, bias, \
-                               e->x32.as<float>(), e->xa.as<T>(), e->modtab.as<float>(), e->step_ptr(), e->rowvec, layer, sel, \
+                               e->x32.as<float>(), e->xa.as<T>(), e->modtab.as<float>(), e->step_ptr(), e->rowvec, mc, layer, sel, \
                                e->B, e->cfg.max_nodes, e->cfg.hidden, e->cfg.depth, e->M2);                            \
         else                                                                                                           \
             hipLaunchKernelGGL((ln_mod_res_kernel<T, NS, ME>), grid, blk, 0, st, e->ybuf.as<float>(), ss, bias,         \
-                               e->x32.as<float>(), e->xa.as<T>(), e->modtab.as<float>(), e->step_ptr(), e->rowvec, layer, sel, \
+                               e->x32.as<float>(), e->xa.as<T>(), e->modtab.as<float>(), e->step_ptr(), e->rowvec, mc, layer, sel, \
                                e->B, e->cfg.max_nodes, e->cfg.hidden, e->cfg.depth, e->M2);                            \
     } while (0)
 #define LL_LNMOD(NS)                                                                                                   \
@@ -291,6 +293,10 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
     const LLDitConfig &c = e->cfg;
     const int H = c.hidden, Hm = c.mlp_hidden, M2 = e->M2, dt = c.dtype;
     const bool bf = dt == LL_BF16;
+    if (e->rowvec == nullptr && g_stage_mod) {
+        const int64_t row_floats = (int64_t)(e->B + 1) * c.depth * 6 * H;
+        hipLaunchKernelGGL(stage_mod_kernel, dim3(256), dim3(256), 0, st, e->modtab.as<float>(), e->modcur.as<float>(), e->step_ptr(), row_floats);
+    }
     if (bf) launch_embed<bf16_t>(e, st); else launch_embed<float>(e, st);
     LL_LAUNCH_CHECK();
     if (hidden_tap && tap_layer == 0)
@@ -474,6 +480,7 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
     CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     e->force_generic_attn = getenv("LL_GENERIC_ATTN") != nullptr;
+    if (const char *ev = getenv("LL_STAGE_MOD")) g_stage_mod = atoi(ev) ? 1 : 0;      // A/B switch for bench runs
     CRH(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
     CRH(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
     CRH(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
@@ -494,7 +501,7 @@ int ll_dit_destroy(void *handle) {
     DevBuf *bufs[] = {&e->wop, &e->wxT, &e->wycat, &e->yw0, &e->yb0, &e->tables, &e->n_nodes, &e->X, &e->E, &e->x32,
                       &e->xa, &e->qkv, &e->attn_o, &e->ybuf, &e->h1, &e->ho, &e->outF, &e->ct_in, &e->ct_h, &e->ct,
                       &e->zy, &e->cy, &e->txt_op, &e->ctxt, &e->ynan, &e->tnan, &e->c32, &e->ca, &e->m1, &e->modtab,
-                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows};
+                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur};
     for (DevBuf *b : bufs) b->release();
     if (e->own) (void)hipStreamDestroy(e->own);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -523,7 +530,7 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
     const int Mc = (T + 1) * (B + 1), Mcp = round_up(Mc, 128);   // rows 0..T-1: reverse steps (t = s+1); row T: t = 0 (training)
     const int Tp = round_up(T + 1, 128), Bp = round_up(B, 128);
     const size_t M2p = e->M2p;
-    void *oldp[] = {e->x32.p, e->xa.p, e->qkv.p, e->attn_o.p, e->ybuf.p, e->h1.p, e->ho.p, e->outF.p, e->modtab.p, e->modo.p, e->X.p, e->E.p, e->n_nodes.p};
+    void *oldp[] = {e->x32.p, e->xa.p, e->qkv.p, e->attn_o.p, e->ybuf.p, e->h1.p, e->ho.p, e->outF.p, e->modtab.p, e->modo.p, e->X.p, e->E.p, e->n_nodes.p, e->modcur.p};
     LL_TRY(e->n_nodes.ensure((size_t)B * 4));
     LL_TRY(e->X.ensure((size_t)2 * B * N));
     LL_TRY(e->E.ensure((size_t)2 * B * N * N));
@@ -551,7 +558,8 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
     LL_TRY(e->m1.ensure((size_t)Mcp * H * es));
     LL_TRY(e->modtab.ensure((size_t)Mc * L * 6 * H * 4));
     LL_TRY(e->modo.ensure((size_t)Mc * 2 * F * 4));
-    void *newp[] = {e->x32.p, e->xa.p, e->qkv.p, e->attn_o.p, e->ybuf.p, e->h1.p, e->ho.p, e->outF.p, e->modtab.p, e->modo.p, e->X.p, e->E.p, e->n_nodes.p};
+    LL_TRY(e->modcur.ensure((size_t)(B + 1) * L * 6 * H * 4));
+    void *newp[] = {e->x32.p, e->xa.p, e->qkv.p, e->attn_o.p, e->ybuf.p, e->h1.p, e->ho.p, e->outF.p, e->modtab.p, e->modo.p, e->X.p, e->E.p, e->n_nodes.p, e->modcur.p};
     for (size_t i = 0; i < sizeof(oldp) / sizeof(oldp[0]); ++i)
         if (oldp[i] != newp[i]) { drop_graph(e); break; }
 
@@ -782,6 +790,12 @@ int ll_dit_set_option(void *handle, int option, int value) {
 int ll_set_attn_waves(int waves) {
     const int old = g_attn_waves;
     if (waves == 1 || waves == 2) g_attn_waves = waves;
+    return old;
+}
+
+int ll_set_stage_mod(int on) {
+    const int old = g_stage_mod;
+    g_stage_mod = on ? 1 : 0;
     return old;
 }
 
