@@ -63,6 +63,7 @@ SIGNATURES = {
     "ll_gin_arena_elems": (_I64, [C.POINTER(LLGinConfig)]),
     "ll_gin_create": (_I, [C.POINTER(LLGinConfig), _P, C.POINTER(_P)]),
     "ll_gin_destroy": (_I, [_P]),
+    "ll_graph_csr": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ll_gin_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "ll_softmax_topk": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "ll_set_topk_single": (_I, [_I]),

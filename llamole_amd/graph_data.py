@@ -26,6 +26,7 @@ class GraphBatch:
         self.x, self.edge_index, self.edge_attr, self.batch = x, edge_index, edge_attr, batch
         self._sizes = list(sizes)
         self.num_graphs = len(self._sizes)
+        self.batch._ll_num_graphs = self.num_graphs      # lets the GIN wrappers skip reading batch[-1] back from the device
 
     @classmethod
     def from_data_list(cls, data_list):
@@ -51,4 +52,5 @@ class GraphBatch:
     def to(self, device):
         self.x, self.edge_index = self.x.to(device), self.edge_index.to(device)
         self.edge_attr, self.batch = self.edge_attr.to(device), self.batch.to(device)
+        self.batch._ll_num_graphs = self.num_graphs
         return self

@@ -42,6 +42,44 @@ def graph_csr(x, edge_index, edge_attr, batch):
             gptr.contiguous(), n, int(src.numel()), G)
 
 
+CSR_KERNEL_MAX_NODES, CSR_KERNEL_MAX_EDGES = 32768, 262144     # one workgroup builds the CSR; beyond this the ATen route
+
+
+def graph_csr_device(x, edge_index, edge_attr, batch, num_graphs=None):
+    """``graph_csr`` in ONE launch on the HIP device (``ll_graph_csr``).  With ``num_graphs`` given (``GraphBatch`` tags its
+    ``batch`` tensor with it, single-graph callers pass 1) nothing synchronises with the host; otherwise the graph count is read
+    back from ``batch[-1]`` like the ATen route does, and the kernel's error flag (unsorted ``batch``, edge out of range) is checked."""
+    dev = x.device
+    n, ne = int(x.shape[0]), int(edge_index.shape[1])
+    known = num_graphs is not None
+    G = int(num_graphs) if known else int(batch[-1].item()) + 1
+    i32 = dict(dtype=torch.int32, device=dev)
+    xs, rowptr, b32, gptr = torch.empty(n, **i32), torch.empty(n + 1, **i32), torch.empty(n, **i32), torch.empty(G + 1, **i32)
+    src, attr = torch.empty(ne, **i32), torch.empty(ne, **i32)
+    scratch, err = torch.empty(n, **i32), torch.empty(1, **i32)
+    x64, ei64, ea64, b64 = (t.long().contiguous() for t in (x, edge_index, edge_attr, batch))
+    _lib.check(_lib.load().ll_graph_csr(_lib.dptr(x64), _lib.dptr(ei64) if ne else None, _lib.dptr(ea64) if ne else None, _lib.dptr(b64),
+                                        n, ne, G, _lib.dptr(xs), _lib.dptr(rowptr), _lib.dptr(src) if ne else None,
+                                        _lib.dptr(attr) if ne else None, _lib.dptr(b32), _lib.dptr(gptr), _lib.dptr(scratch),
+                                        _lib.dptr(err), _lib.current_stream_ptr()), "ll_graph_csr")
+    if not known:
+        code = int(err.item())
+        if code == 1:
+            raise ValueError("`batch` must be sorted (PyG Batch convention)")
+        if code == 2:
+            raise ValueError("edge_index refers to a node outside the batch")
+    return xs, rowptr, src, attr, b32, gptr, n, ne, G
+
+
+def csr_for_engine(x, edge_index, edge_attr, batch, num_graphs=None):
+    """CSR arrays for ll_gin_forward: the one-launch kernel on the device, the ATen route for very large batches / CPU tensors."""
+    if num_graphs is None:
+        num_graphs = getattr(batch, "_ll_num_graphs", None)
+    if x.is_cuda and x.shape[0] <= CSR_KERNEL_MAX_NODES and edge_index.shape[1] <= CSR_KERNEL_MAX_EDGES:
+        return graph_csr_device(x, edge_index, edge_attr, batch, num_graphs)
+    return graph_csr(x, edge_index, edge_attr, batch)
+
+
 class _GinModule(nn.Module):
     """Shared engine plumbing of the encoder and the predictor."""
 
@@ -91,10 +129,12 @@ class _GinModule(nn.Module):
         except Exception:
             pass
 
-    def _run(self, x, edge_index, edge_attr, batch, c, out_cols, want_pooled=False):
+    def _run(self, x, edge_index, edge_attr, batch, c, out_cols, want_pooled=False, num_graphs=None):
         self._ensure_engine()
         dev = self._device()
-        xs, rowptr, src, attr, b, gptr, n, ne, G = graph_csr(x.to(dev), edge_index.to(dev), edge_attr.to(dev), batch.to(dev))
+        if num_graphs is None:
+            num_graphs = getattr(batch, "_ll_num_graphs", None)      # GraphBatch tags its batch vector: no read-back of batch[-1]
+        xs, rowptr, src, attr, b, gptr, n, ne, G = csr_for_engine(x.to(dev), edge_index.to(dev), edge_attr.to(dev), batch.to(dev), num_graphs)
         out = torch.empty(G, out_cols, device=dev, dtype=torch.float32)
         pooled = torch.empty(G, self.hidden_size, device=dev, dtype=torch.float32) if want_pooled else None
         if c is not None:
@@ -104,7 +144,8 @@ class _GinModule(nn.Module):
         _lib.check(_lib.load().ll_gin_forward(self._handle, _lib.dptr(xs), _lib.dptr(rowptr), _lib.dptr(src), _lib.dptr(attr),
                                               _lib.dptr(b), _lib.dptr(gptr), n, ne, G, _lib.dptr(c), _lib.dptr(out),
                                               _lib.dptr(pooled), _lib.current_stream_ptr()), "ll_gin_forward")
-        torch.cuda.current_stream().synchronize()   # temporaries above must outlive the async launch
+        # no host synchronisation: the temporaries above come from torch's stream-ordered caching allocator and every launch of
+        # the engine went to torch's current stream, so their memory cannot be handed out again before those launches have run
         return (out, pooled) if want_pooled else out
 
     def disable_grads(self):

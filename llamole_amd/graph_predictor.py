@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .graph_encoder import graph_csr, _GinModule
+from .graph_encoder import csr_for_engine, graph_csr, _GinModule
 from .synth import gin_weight_shapes
 from .weights import WeightBag
 
@@ -129,17 +129,17 @@ class GraphPredictor(_GinModule):
         self._ensure_engine()
         dev = self._device()
         x, edge_index, edge_attr, batch = x.to(dev), edge_index.to(dev), edge_attr.to(dev), batch.to(dev)
-        xs, rowptr, src, attr, b, gptr, n, ne, G = graph_csr(x, edge_index, edge_attr, batch)
+        ng = getattr(batch, "_ll_num_graphs", None) or int(c32.shape[0])     # one condition row per graph
+        xs, rowptr, src, attr, b, gptr, n, ne, G = csr_for_engine(x, edge_index, edge_attr, batch, ng)
         if c32.shape[0] != G:
             raise ValueError(f"condition rows {c32.shape[0]} != number of graphs {G}")
-        # the reverse sweep walks OUT-edges: CSR keyed by source = graph_csr of the flipped edge list
-        _, rowptr_s, dst_s, attr_s, _, _, _, _, _ = graph_csr(x, edge_index.flip(0), edge_attr, batch)
+        # the reverse sweep walks OUT-edges: CSR keyed by source = the CSR of the flipped edge list
+        _, rowptr_s, dst_s, attr_s, _, _, _, _, _ = csr_for_engine(x, edge_index.flip(0), edge_attr, batch, ng)
         out = torch.empty(G, self.out_dim, device=dev, dtype=torch.float32)
         _lib.check(_lib.load().ll_gin_forward_train(self._handle, _lib.dptr(xs), _lib.dptr(rowptr), _lib.dptr(src), _lib.dptr(attr),
                                                     _lib.dptr(b), _lib.dptr(gptr), n, ne, G, _lib.dptr(c32), _lib.dptr(out),
                                                     _lib.current_stream_ptr()), "ll_gin_forward_train")
-        torch.cuda.current_stream().synchronize()
-        return out, (rowptr_s, dst_s, attr_s, b, gptr, n, ne, G)
+        return out, (rowptr_s, dst_s, attr_s, b, gptr, n, ne, G)       # stream-ordered: no host synchronisation needed
 
     def _backward_c(self, saved, c32, dlogits):
         rowptr_s, dst_s, attr_s, b, gptr, n, ne, G = saved
@@ -148,15 +148,14 @@ class GraphPredictor(_GinModule):
         _lib.check(_lib.load().ll_gin_backward_c(self._handle, _lib.dptr(rowptr_s), _lib.dptr(dst_s), _lib.dptr(attr_s), _lib.dptr(b),
                                                  _lib.dptr(gptr), n, ne, G, _lib.dptr(c32), _lib.dptr(dlogits), _lib.dptr(dc),
                                                  _lib.current_stream_ptr()), "ll_gin_backward_c")
-        torch.cuda.current_stream().synchronize()
         return dc
 
     @torch.no_grad()
-    def topk_templates(self, x, edge_index, edge_attr, batch, c, topk: int):
+    def topk_templates(self, x, edge_index, edge_attr, batch, c, topk: int, num_graphs=None):
         """Device part of sample_templates: logits -> softmax -> top-k (model.py:174-179).
         The reference also evaluates the text-dropped predictor and discards it (:175-177); that dead
         pass is not reproduced."""
-        logits = self._run(x, edge_index, edge_attr, batch, c, self.out_dim)
+        logits = self._run(x, edge_index, edge_attr, batch, c, self.out_dim, num_graphs=num_graphs)
         G = logits.shape[0]
         k = min(int(topk), self.out_dim)
         if k > 64:
@@ -165,14 +164,13 @@ class GraphPredictor(_GinModule):
         idx = torch.empty(G, k, device=logits.device, dtype=torch.int32)
         _lib.check(_lib.load().ll_softmax_topk(_lib.dptr(logits), G, self.out_dim, k, _lib.dptr(probs), _lib.dptr(idx),
                                                _lib.current_stream_ptr()), "ll_softmax_topk")
-        torch.cuda.current_stream().synchronize()
-        return probs, idx
+        return probs, idx        # on the current stream; the caller's .cpu() is the only synchronisation
 
     @torch.no_grad()
     def sample_templates(self, product_graph, c, product_smiles, topk=10):
         x, edge_index, edge_attr = product_graph.x, product_graph.edge_index, product_graph.edge_attr
         batch = torch.zeros(x.size(0), dtype=torch.long, device=x.device)
-        probs, idx = self.topk_templates(x, edge_index, edge_attr, batch, c, topk)
+        probs, idx = self.topk_templates(x, edge_index, edge_attr, batch, c, topk, num_graphs=1)
         topk_probs = probs.float().cpu().numpy()[0]
         topk_indices = idx.cpu().numpy()[0]
         templates = [self.label_to_template[int(i)] for i in topk_indices]

@@ -339,3 +339,32 @@ def test_sft_forward_with_hip_engines_matches_oracle():
     ga = llm.model.layers[1].mlp.down_proj.weight.grad.cpu()
     gr = ref_llm.model.layers[1].mlp.down_proj.weight.grad
     assert F.cosine_similarity(ga.flatten(), gr.flatten(), dim=0) > 0.999
+
+
+def test_graph_csr_kernel_equals_aten_route():
+    """ll_graph_csr (one launch) == graph_csr (stable argsort / bincount / cumsum) on molecule batches, a shuffled edge list, a
+    bond-free batch and a hub of degree 300; the error flag reports an unsorted batch vector."""
+    from llamole_amd.graph_encoder import csr_for_engine, graph_csr, graph_csr_device
+    g = torch.Generator().manual_seed(0)
+    cases = []
+    x, ei, ea, batch = synth.make_mol_graphs(16, 3)
+    cases.append((x, ei, ea, batch))
+    perm = torch.randperm(ei.shape[1], generator=g)
+    cases.append((x, ei[:, perm], ea[perm], batch))
+    cases.append((x[:7], torch.empty((2, 0), dtype=torch.long), torch.empty((0,), dtype=torch.long), torch.zeros(7, dtype=torch.long)))
+    hub_src = torch.arange(1, 301)
+    hub = torch.stack([torch.cat([hub_src, torch.zeros(300, dtype=torch.long)]), torch.cat([torch.zeros(300, dtype=torch.long), hub_src])])
+    cases.append((torch.randint(0, 118, (301,), generator=g), hub, torch.randint(1, 5, (600,), generator=g), torch.zeros(301, dtype=torch.long)))
+    for x, ei, ea, batch in cases:
+        xd, eid, ead, bd = x.cuda(), ei.cuda(), ea.cuda(), batch.cuda()
+        ref = graph_csr(xd, eid, ead, bd)
+        for ng in (None, int(batch[-1]) + 1):
+            got = graph_csr_device(xd, eid, ead, bd, ng)
+            torch.cuda.synchronize()
+            assert got[6:] == ref[6:]
+            for a, b in zip(got[:6], ref[:6]):
+                assert a.dtype == torch.int32 and torch.equal(a, b)
+    x, ei, ea, batch = cases[0]
+    with pytest.raises(ValueError):
+        graph_csr_device(x.cuda(), ei.cuda(), ea.cuda(), torch.flip(batch, [0]).cuda(), None)
+    assert csr_for_engine(x, ei, ea, batch)[8] == 16          # CPU tensors: the ATen route
