@@ -1146,6 +1146,14 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
             LL_LAUNCH_CHECK();
             return LL_OK;
         }
+        if (g_gemm_variant != 0 && g_gemm_variant != 2 && M > 4 && M <= 16 && splits == 1 && epi == EPI_NONE && K % 32 == 0 && N >= 256 &&
+            ((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0) {
+            // 5..16 rows (per-graph vectors of a GIN batch: virtual-node MLPs, projection head, decoder input; GraphDiT's hoisted
+            // per-graph conditions): the weight-streaming MFMA Linear of the batched LLM decode (llm_rows16.hip) instead of 32x32 ring
+            // tiles -- 13 -> ~5 us per launch on [16 x 2048 x 512] (profiles/r2_gin_kernel_stats.csv)
+            LL_TRY(linear_rows16_launch(a, lda, w, ldw, bias, nullptr, 0.f, nullptr, 0, C, ldc, M, N, K, 0, out_f32, s));
+            return LL_OK;
+        }
         if (g_gemm_variant != 0 && M <= 32 && cdiv(N, 32) < 4096) {
             // a few rows (several sequences decoding at once, one small graph): 32x32 tiles, 8-deep ring -- many small
             // workgroups and a small activation share of each one's ingest (tools/gemm_rows32_sweep.py: 13 vs 17 us on the

@@ -208,6 +208,79 @@ __global__ __launch_bounds__(64) void rows_ln_act_kernel(const float *__restrict
     }
 }
 
+// The same row operation with WAVES waves per row and every load -- the row, the LayerNorm weight and bias -- issued up front
+// (one memory round trip; a lane holds 3 * CH float4 loads in flight instead of up to 32 + a second round trip for w / b).  The
+// one-wave kernel above ran the [512 x 2048] rows of the GIN MLPs at 11.7 us per launch (profiles/r2_gin_kernel_stats.csv).
+template <typename T, int WAVES, int CH>
+__global__ __launch_bounds__(64 * WAVES) void rows_ln_act_mw_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                                    const float *__restrict__ b, T *__restrict__ out, int R, int C,
+                                                                    int gelu) {
+    __shared__ float part[2][WAVES];
+    const int r = blockIdx.x;
+    if (r >= R) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *x = in + (int64_t)r * C;
+    float4 v[CH], ww[CH], bb[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+        const int k = (tid + e * 64 * WAVES) * 4;      // C == WAVES * 64 * 4 * CH
+        v[e] = *reinterpret_cast<const float4 *>(x + k);
+        ww[e] = *reinterpret_cast<const float4 *>(w + k);
+        bb[e] = *reinterpret_cast<const float4 *>(b + k);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) s += v[e].x + v[e].y + v[e].z + v[e].w;
+    s = wave_sum(s);
+    if (lane == 0) part[0][wave] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) tot += part[0][i];
+    const float mean = tot / (float)C;
+    float vr = 0.f;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+        const float d0 = v[e].x - mean, d1 = v[e].y - mean, d2 = v[e].z - mean, d3 = v[e].w - mean;
+        vr += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    vr = wave_sum(vr);
+    if (lane == 0) part[1][wave] = vr;
+    __syncthreads();
+    float tv = 0.f;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) tv += part[1][i];
+    const float rstd = rsqrtf(tv / (float)C + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+        const int k = (tid + e * 64 * WAVES) * 4;
+        float4 y = make_float4((v[e].x - mean) * rstd * ww[e].x + bb[e].x, (v[e].y - mean) * rstd * ww[e].y + bb[e].y,
+                               (v[e].z - mean) * rstd * ww[e].z + bb[e].z, (v[e].w - mean) * rstd * ww[e].w + bb[e].w);
+        if (gelu) y = gelu4(y);
+        gin_store4<T>(out + (int64_t)r * C + k, y);
+    }
+}
+
+template <typename T>
+static void launch_rows_ln_act(const float *in, const float *w, const float *b, T *out, int R, int C, int gelu, hipStream_t st) {
+    if (C % 1024 == 0 && C / 1024 <= 4) {            // 4 waves per row, 1..4 float4 per lane
+        switch (C / 1024) {
+            case 1: hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, 4, 1>), dim3(R), dim3(256), 0, st, in, w, b, out, R, C, gelu); return;
+            case 2: hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, 4, 2>), dim3(R), dim3(256), 0, st, in, w, b, out, R, C, gelu); return;
+            case 3: hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, 4, 3>), dim3(R), dim3(256), 0, st, in, w, b, out, R, C, gelu); return;
+            default: hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, 4, 4>), dim3(R), dim3(256), 0, st, in, w, b, out, R, C, gelu); return;
+        }
+    }
+    if (C % 256 == 0 && C / 256 <= 3) {              // narrow rows (H = 64 .. 192 -> 4H = 256 .. 768): one wave, loads up front
+        switch (C / 256) {
+            case 1: hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, 1, 1>), dim3(R), dim3(64), 0, st, in, w, b, out, R, C, gelu); return;
+            case 2: hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, 1, 2>), dim3(R), dim3(64), 0, st, in, w, b, out, R, C, gelu); return;
+            default: hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, 1, 3>), dim3(R), dim3(64), 0, st, in, w, b, out, R, C, gelu); return;
+        }
+    }
+    hipLaunchKernelGGL((rows_ln_act_kernel<T>), dim3(R), dim3(64), 0, st, in, w, b, out, R, C, gelu);
+}
+
 // Layer tail.  Encoder: z = LN_affine(z); predictor: z = LN0(z) * (1 + scale) + shift, residual gated.
 //   if not last: z = GELU(z);  h = (gate *) z + h_in         (model.py:137-145 / predictor :331-340)
 __global__ __launch_bounds__(64) void gin_post_kernel(const float *__restrict__ z, const float *__restrict__ h_in,
@@ -915,7 +988,7 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
                            e->pf(p + "bond_encoder.weight"), e->pf(p + "eps"), e->h_in.as<float>(), e->z0.as<T>(), n, H);
         LL_LAUNCH_CHECK();
         LL_TRY(linear_launch(dt, e->z0.p, H, e->pw(p + "mlp.0.weight"), H, e->pf(p + "mlp.0.bias"), e->t1.p, 4 * H, n, 4 * H, H, 0, 1, st));
-        hipLaunchKernelGGL((rows_ln_act_kernel<T>), w_n, wblk, 0, st, e->t1.as<float>(), e->pf(p + "mlp.1.weight"), e->pf(p + "mlp.1.bias"), e->t1a.as<T>(), n, 4 * H, 1);
+        launch_rows_ln_act<T>(e->t1.as<float>(), e->pf(p + "mlp.1.weight"), e->pf(p + "mlp.1.bias"), e->t1a.as<T>(), n, 4 * H, 1, st);
         LL_LAUNCH_CHECK();
         LL_TRY(linear_launch(dt, e->t1a.p, 4 * H, e->pw(p + "mlp.4.weight"), 4 * H, e->pf(p + "mlp.4.bias"), e->z.p, H, n, H, 4 * H, 0, 1, st));
         const float *lnw = cf.kind == 0 ? e->pf("norms." + std::to_string(l) + ".weight") : nullptr;
@@ -936,7 +1009,7 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
             hipLaunchKernelGGL((segment_pool_kernel<T, true>), dim3(G, cdiv(H, 1024)), blk, 0, st, e->h_in.as<float>(), gptr, (float *)nullptr, e->poola.as<T>(), H);
             LL_LAUNCH_CHECK();
             LL_TRY(linear_launch(dt, e->poola.p, H, e->pw(q + "0.weight"), H, e->pf(q + "0.bias"), e->vt1.p, 4 * H, G, 4 * H, H, 0, 1, st));
-            hipLaunchKernelGGL((rows_ln_act_kernel<T>), w_g, wblk, 0, st, e->vt1.as<float>(), e->pf(q + "1.weight"), e->pf(q + "1.bias"), e->vt1a.as<T>(), G, 4 * H, 1);
+            launch_rows_ln_act<T>(e->vt1.as<float>(), e->pf(q + "1.weight"), e->pf(q + "1.bias"), e->vt1a.as<T>(), G, 4 * H, 1, st);
             LL_LAUNCH_CHECK();
             if (e->keep) {
                 LL_TRY(e->sv_vt1[l].ensure((size_t)Gp * 4 * H * 4));
@@ -955,7 +1028,7 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
         LL_TRY(e->head1a.ensure((size_t)Gp * H * es));
         LL_TRY(e->head2.ensure((size_t)Gp * H * 4));
         LL_TRY(linear_launch(dt, e->poola.p, H, e->pw("proj.fc1.weight"), H, e->pf("proj.fc1.bias"), e->head1.p, H, G, H, H, 0, 1, st));
-        hipLaunchKernelGGL((rows_ln_act_kernel<T>), w_g, wblk, 0, st, e->head1.as<float>(), e->pf("proj.norm1.weight"), e->pf("proj.norm1.bias"), e->head1a.as<T>(), G, H, 1);
+        launch_rows_ln_act<T>(e->head1.as<float>(), e->pf("proj.norm1.weight"), e->pf("proj.norm1.bias"), e->head1a.as<T>(), G, H, 1, st);
         LL_LAUNCH_CHECK();
         LL_TRY(linear_launch(dt, e->head1a.p, H, e->pw("proj.fc2.weight"), H, e->pf("proj.fc2.bias"), e->head2.p, H, G, H, H, 0, 1, st));
         hipLaunchKernelGGL(l2norm_rows_kernel, rows_g, blk, 0, st, e->head2.as<float>(), out, G, H);
@@ -964,7 +1037,7 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
         LL_TRY(e->head1.ensure((size_t)Gp * 4 * H * 4));
         LL_TRY(e->head1a.ensure((size_t)Gp * 4 * H * es));
         LL_TRY(linear_launch(dt, e->poola.p, H, e->pw("decoder.0.weight"), H, e->pf("decoder.0.bias"), e->head1.p, 4 * H, G, 4 * H, H, 0, 1, st));
-        hipLaunchKernelGGL((rows_ln_act_kernel<T>), w_g, wblk, 0, st, e->head1.as<float>(), e->pf("decoder.1.weight"), e->pf("decoder.1.bias"), e->head1a.as<T>(), G, 4 * H, 1);
+        launch_rows_ln_act<T>(e->head1.as<float>(), e->pf("decoder.1.weight"), e->pf("decoder.1.bias"), e->head1a.as<T>(), G, 4 * H, 1, st);
         LL_LAUNCH_CHECK();
         if (e->keep) {
             LL_TRY(e->sv_head1.ensure((size_t)Gp * 4 * H * 4));
