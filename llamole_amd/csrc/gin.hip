@@ -799,21 +799,27 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
 // syncs per GIN forward, in a path whose figure of merit is microseconds per graph-layer).  One 1024-thread workgroup: degree
 // counts by atomics, workgroup scans, an unordered scatter of edge ids and a per-node insertion sort of each (short) segment by
 // edge id, which restores the reference's per-destination summation order (= a stable sort by destination).
-__device__ __forceinline__ void wg_exclusive_scan_inplace(int *a, int n, int *part /*[1024]*/) {
-    // a[0..n) counts -> a[i] = sum of counts before i; returns nothing (total = part[1023] after the call)
-    const int tid = threadIdx.x, per = (n + 1023) / 1024;
+__device__ __forceinline__ void wg_exclusive_scan_inplace(int *a, int n, int *part /*[16]*/) {
+    // a[0..n) counts -> a[i] = sum of the counts before i.  Thread t owns a contiguous chunk; chunk sums are scanned inside each
+    // wave with shuffles and across the 16 waves through LDS (two workgroup barriers in all).
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, per = (n + 1023) / 1024;
     const int lo = min(tid * per, n), hi = min(lo + per, n);
     int sum = 0;
     for (int i = lo; i < hi; ++i) sum += a[i];
-    part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
     }
-    int run = part[tid] - sum;
+    __syncthreads();                    // part[] of a previous scan has been consumed
+    if (lane == 63) part[wave] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w)
+        if (w < wave) base += part[w];
+    int run = base + inc - sum;
     for (int i = lo; i < hi; ++i) {
         const int c = a[i];
         a[i] = run;
@@ -827,7 +833,7 @@ __global__ __launch_bounds__(1024) void graph_csr_kernel(const int64_t *__restri
                                                           int E, int G, int *__restrict__ x32, int *__restrict__ rowptr, int *__restrict__ src,
                                                           int *__restrict__ attr, int *__restrict__ b32, int *__restrict__ gptr,
                                                           int *__restrict__ cursor, int *__restrict__ err) {
-    __shared__ int part[1024];
+    __shared__ int part[16];
     const int tid = threadIdx.x;
     const int64_t *esrc = edge_index, *edst = edge_index + E;
     if (tid == 0) *err = 0;
