@@ -308,6 +308,127 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipe_kernel(const bf16_
     }
 }
 
+// The same kernel with the tile's DMA pieces dealt to the waves from ONE list over both operands (round 2: lets sixteen-wave
+// workgroups run tiles whose operands have fewer than 16 pieces, e.g. 64 x 64).
+template <int BM, int BN, int WM, int WN, int STAGES, typename OutT>
+__global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipeu_kernel(const bf16_t *__restrict__ A, int lda,
+                                                                      const bf16_t *__restrict__ W, int ldw,
+                                                                      OutT *__restrict__ C, int ldc,
+                                                                      const float *__restrict__ bias, int M, int N,
+                                                                      int kchunk, int64_t slab_stride, int epi, int krot) {
+    constexpr int NW = WM * WN;
+    constexpr int BK = 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MT = TM / 16, NTL = TN / 16;
+    constexpr int PIECES = (BM + BN) / 8;     // 1-KB DMA pieces per k-tile: 8 rows of 128 B each, A rows first, then W rows
+    constexpr int LPT = PIECES / NW;          // pieces per wave per tile (one list over both operands, so that workgroups of more
+    constexpr int STAGE_BYTES = (BM + BN) * 128;   // waves than an operand has pieces -- 16 waves on a 64-row operand -- still balance)
+    static_assert(PIECES % NW == 0 && LPT >= 1, "the tile's DMA pieces must divide over the waves");
+    static_assert((STAGES - 2) * LPT <= 63, "vmcnt immediate overflow");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pipeu[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * kchunk;
+    const int nk = kchunk / BK;
+    (void)krot;
+
+    const bf16_t *src[LPT];
+    int dst[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int p = wave + NW * i, row = p * 8 + (lane >> 3), slot = lane & 7;
+        const int sw = (slot ^ (row & 7)) << 3;
+        if (row < BM) {
+            int ar = m0 + row;
+            ar = ar < M ? ar : M - 1;
+            src[i] = A + (int64_t)ar * lda + kbeg + sw;
+        } else {
+            int br = n0 + row - BM;
+            br = br < N ? br : N - 1;
+            src[i] = W + (int64_t)br * ldw + kbeg + sw;
+        }
+        dst[i] = p * 1024;
+    }
+    auto issue = [&](int kt) {
+        unsigned char *st = smem_pipeu + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + (int64_t)kt * BK),
+                                             (__attribute__((address_space(3))) void *)(st + dst[i]), 16, 0, 0);
+    };
+
+    f32x4 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p)
+        if (p < nk) issue(p);
+
+    const int frow = lane & 15, fk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed once at most (STAGES-2) younger tiles of this wave are still in flight
+        if (kt + STAGES - 2 < nk) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);  // overwrites the buffer read in iteration kt-1
+        const unsigned char *Ab = smem_pipeu + (kt % STAGES) * STAGE_BYTES;
+        const unsigned char *Bb = Ab + BM * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[MT], fb[NTL];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = wm * TM + i * 16 + frow;
+                const int ch = kk * 4 + fk;
+                fa[i] = *reinterpret_cast<const bf16x8 *>(Ab + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int row = wn * TN + j * 16 + frow;
+                const int ch = kk * 4 + fk;
+                fb[j] = *reinterpret_cast<const bf16x8 *>(Bb + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    OutT *Cz = C + (int64_t)blockIdx.z * slab_stride;
+    const bool raw = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const int col = n0 + wn * TN + j * 16 + (lane & 15);
+            if (col >= N) continue;
+            const float bv = (!raw && bias) ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * TM + i * 16 + (lane >> 4) * 4 + r;
+                if (row < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (!raw) v = apply_epi(v, epi);
+                    Cz[(int64_t)row * ldc + col] = from_f32<OutT>(v);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ bf16 MFMA, skinny M
 // M <= 64 rows per workgroup (the sampler at B = 1: M2 = 2*N tokens).  A k-loop of 16-64 tiles serialised behind
 // barriers is latency-bound here, so the K dimension is split across the NW waves of the workgroup instead:
@@ -624,6 +745,31 @@ static int launch_pipe(const bf16_t *A, int lda, const bf16_t *W, int ldw, void 
                            (bf16_t *)C, ldc, bias, M, N, kchunk, slab_stride, epi, g_gemm_krot);
     return LL_OK;
 }
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+static int launch_pipeu(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M,
+                        int N, int K, int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
+    constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_bf16_pipeu_kernel<BM, BN, WM, WN, STAGES, float>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_bf16_pipeu_kernel<BM, BN, WM, WN, STAGES, bf16_t>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), splits);
+    dim3 block(WM * WN * 64);
+    const int kchunk = K / splits;
+    if (out_f32)
+        hipLaunchKernelGGL((gemm_bf16_pipeu_kernel<BM, BN, WM, WN, STAGES, float>), grid, block, lds, s, A, lda, W, ldw,
+                           (float *)C, ldc, bias, M, N, kchunk, slab_stride, epi, 0);
+    else
+        hipLaunchKernelGGL((gemm_bf16_pipeu_kernel<BM, BN, WM, WN, STAGES, bf16_t>), grid, block, lds, s, A, lda, W, ldw,
+                           (bf16_t *)C, ldc, bias, M, N, kchunk, slab_stride, epi, 0);
+    return LL_OK;
+}
+
 
 // ------------------------------------------------------------------------------------------ bf16 MFMA, M <= 64 rows
 // The GraphDiT sampler at batch 1 multiplies a 64-row activation panel (cond + uncond tokens of one molecule) by every
@@ -1162,6 +1308,22 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
             LL_LAUNCH_CHECK();
             return LL_OK;
         }
+        if (g_gemm_variant != 0 && M >= 1024 && kchunk >= 256) {
+            // batch >= 16 (M = 2 B N >= 1024): sixteen-wave workgroups on 128 x 128 / 256 x 128 tiles -- twice the waves issuing DMA
+            // pieces per CU and half the L2 -> LDS traffic per flop of the 64 x 64 tiles (profiles/r2_gemm_16w_sweep_m{1024,2048}.txt:
+            // fc1 at M = 2048 32.5 -> 22.6 us = 760 TF, hipBLASLt's MT256x128x64 kernel: 21.3 us; at M = 1024 17.8 -> 14.5 us)
+            const long t256 = (long)cdiv(M, 256) * cdiv(N, 128) * splits, t128 = (long)cdiv(M, 128) * cdiv(N, 128) * splits;
+            if (M >= 2048 && t256 >= 192) {
+                LL_TRY((launch_pipe<256, 128, 4, 4, 3>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
+                LL_LAUNCH_CHECK();
+                return LL_OK;
+            }
+            if (t128 >= 192) {
+                LL_TRY((launch_pipe<128, 128, 4, 4, 3>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
+                LL_LAUNCH_CHECK();
+                return LL_OK;
+            }
+        }
         if (g_gemm_variant != 0) {
             // pipelined kernels: prefer the largest tile that still gives >= ~1 workgroup per CU
             const long w12864 = (long)cdiv(M, 128) * cdiv(N, 64) * splits;
@@ -1173,6 +1335,10 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
                 LL_TRY((launch_pipe<64, 64, 2, 2, 4>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
             else if (w12864 >= 1024)
                 LL_TRY((launch_pipe<128, 64, 4, 2, 4>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
+            else if (w6464 >= 200 && M > 64)
+                // sixteen waves per 64 x 64 tile, one DMA piece per wave (round 2: 5-8 % faster than eight waves with two pieces each
+                // on the GraphDiT block shapes at M = 128..512, profiles/r2_gemm_16w64_sweep_m512.txt)
+                LL_TRY((launch_pipeu<64, 64, 4, 4, 4>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
             else if (w6464 >= 200 || (N % 32 != 0 && N < 64))
                 LL_TRY((launch_pipe<64, 64, 4, 2, 4>(a, lda, w, ldw, C, ldc, bias, M, N, K, splits, slab_stride, epi, out_f32, s)));
             else
@@ -1298,6 +1464,18 @@ static const PipeCfg g_pipe_cfgs[] = {
     {128, 128, 504, launch_pp<128, 128, 4>},       // 53
     {128, 128, 505, launch_pp<128, 128, 5>},       // 54
     {64, 128, 505, launch_pp<64, 128, 5>},         // 55
+    {256, 128, 3, launch_pipe<256, 128, 4, 2, 3>}, // 56  one tile per CU at M = 2048, N = 4096 (wave tile 64 x 64)
+    {256, 128, 3, launch_pipe<256, 128, 4, 4, 3>}, // 57  16 waves (wave tile 64 x 32)
+    {128, 256, 3, launch_pipe<128, 256, 2, 4, 3>}, // 58
+    {256, 256, 2, launch_pipe<256, 256, 4, 4, 2>}, // 59  (no tile in flight across the barrier: reference point only)
+    {128, 128, 4, launch_pipe<128, 128, 4, 4, 4>}, // 60  16-wave workgroups (both operand tiles need >= 128 rows: one DMA piece per wave)
+    {128, 128, 3, launch_pipe<128, 128, 4, 4, 3>}, // 61
+    {256, 128, 3, launch_pipe<256, 128, 8, 2, 3>}, // 62  16 waves, wave tile 32 x 64
+    {128, 128, 5, launch_pipe<128, 128, 4, 4, 5>}, // 63
+    {64, 64, 4, launch_pipeu<64, 64, 4, 4, 4>},    // 64  sixteen waves on 64 x 64 (one piece per wave, wave tile 16 x 16)
+    {64, 64, 6, launch_pipeu<64, 64, 4, 4, 6>},    // 65
+    {64, 128, 4, launch_pipeu<64, 128, 2, 4, 4>},  // 66  eight waves, unified pieces
+    {128, 64, 4, launch_pipeu<128, 64, 4, 2, 4>},  // 67  eight waves, unified pieces (A/B of the piece list)
 };
 }  // namespace ll
 

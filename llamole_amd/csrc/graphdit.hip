@@ -281,6 +281,13 @@ static void launch_lnmod(DitEngine *e, int layer, int sel, int nslab, const floa
 }
 
 static int pick_splits(int M2, int H, int K) {
+    if (M2 >= 2048 || (M2 >= 1024 && K >= 2048)) {
+        // 128 x 128 tiles on sixteen-wave workgroups (gemm_dispatch): split K until the launch has ~256 of them
+        const long t = (long)cdiv(M2, 128) * cdiv(H, 128);
+        int s = 1;
+        while (s < 4 && t * s < 256 && K / (s * 2) >= 512 && (K / (s * 2)) % 64 == 0) s *= 2;
+        return s;
+    }
     const long tiles = (long)cdiv(M2, 64) * cdiv(H, 64);
     int s = 1;
     // each split costs the consumer one more f32 slab to read back: cap at 4

@@ -65,6 +65,8 @@ def test_linear_matches_torch():
     torch.manual_seed(0)
     for (M, N, K) in [(64, 176, 128), (512, 3072, 1024), (450, 266, 256), (3, 128, 768), (1024, 4096, 1024), (64, 1024, 4096),
                       (1, 3584, 3584), (2, 515, 1032), (4, 18944, 3584), (17, 192, 64),
+                      # batch >= 16: sixteen-wave 128x128 / 256x128 tiles, ragged edges
+                      (2048, 3072, 1024), (2100, 3000, 256), (1024, 1024, 4096), (1500, 2050, 512),
                       # M <= 64 all-in-flight kernel (gemm_m64_kernel): K chunks of 1024 / 512 / 256, ragged M and N
                       (64, 3072, 1024), (40, 4096, 1024), (64, 1024, 512), (33, 784, 256), (5, 1000, 1024),
                       # 5..32 rows over large weight matrices (several sequences decoding at once), ragged N
@@ -98,7 +100,7 @@ def test_register_staged_gemm_configs_match_torch():
     from llamole_amd import _lib
     lib = _lib.load()
     torch.manual_seed(2)
-    for cfg in (41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55):
+    for cfg in (41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 60, 61, 62, 63, 64, 65, 66, 67):
         for (M, N, K, splits) in [(512, 4096, 1024, 1), (512, 1024, 4096, 4), (200, 1000, 256, 1), (130, 72, 128, 1), (2048, 3072, 1024, 1),
                                   (64, 176, 1024, 2)]:
             A = torch.randn(M, K, device="cuda").bfloat16()
