@@ -128,3 +128,49 @@ def allreduce_gradients(params, bucket_bytes: int = 64 << 20, group=None) -> int
             size += nbytes
         flush()
     return calls
+
+
+class WorkQueue:
+    """Dynamic distribution of work items over the ranks (decode lengths and A* iteration counts vary from prompt
+    to prompt, so a static contiguous shard can leave ranks idle): every rank claims the next unclaimed item -- a batch of
+    prompts -- from ONE shared counter until the items are exhausted.  The counter lives in a ``torch.distributed.TCPStore`` on
+    rank 0 (``store.add`` is atomic); no GPU collective is involved and the ranks never wait for each other.  With one rank (or
+    no process group) it degenerates to ``range(n_items)``."""
+
+    def __init__(self, n_items: int, rank: int = 0, world: int = 1, key: str = "llamole_work", port_offset: int = 17,
+                 store=None):
+        self.n, self.rank, self.world, self.key = int(n_items), rank, world, key
+        self._local = 0
+        self.store = store
+        if world > 1 and store is None:
+            import datetime
+            import os
+            host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+            port = int(os.environ.get("MASTER_PORT", "29500")) + port_offset
+            self.store = dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=600),
+                                       wait_for_workers=True)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> int:
+        if self.store is None:
+            i = self._local
+            self._local += 1
+        else:
+            i = int(self.store.add(self.key, 1)) - 1
+        if i >= self.n:
+            self._finish()
+            raise StopIteration
+        return i
+
+    def _finish(self):
+        """The store lives in rank 0's process: rank 0 leaves only after every rank has seen the end of the queue."""
+        if self.store is None or getattr(self, "_finished", False):
+            return
+        self._finished = True
+        import time
+        self.store.add(self.key + "_done", 1)
+        if self.rank == 0:
+            while int(self.store.add(self.key + "_done", 0)) < self.world:
+                time.sleep(0.01)

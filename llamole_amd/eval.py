@@ -56,7 +56,8 @@ def load_yaml_args(path: str, overrides: Optional[Dict[str, Any]] = None):
                                 # A* budget of phase 2 (constants of the reference driver, eval/workflow.py:171-173); overridable
                                 retro_iterations=int(cfg.get("retro_iterations", 100)),
                                 retro_max_planning_time=float(cfg.get("retro_max_planning_time", 30)),
-                                expansion_topk=int(cfg.get("expansion_topk", 50)))
+                                expansion_topk=int(cfg.get("expansion_topk", 50)),
+                                dynamic_sharding=bool(cfg.get("dynamic_sharding", True)))
     training_args = SimpleNamespace(per_device_eval_batch_size=int(cfg.get("per_device_eval_batch_size", 8)),
                                     do_train=bool(cfg.get("do_train", False)), output_dir=cfg.get("output_dir"))
     finetuning_args = SimpleNamespace(finetuning_type=cfg.get("finetuning_type", "lora"))
@@ -93,16 +94,27 @@ def encode_batch(tokenizer, records: List[dict], max_len: int):
 
 def run_molqa(model, tokenizer, records: List[dict], cutoff_len: int, batch_size: int, gen_kwargs: Dict[str, Any],
               do_retrosynthesis: bool = True, rank: int = 0, world: int = 1, expansion_topk: int = 50, iterations: int = 100,
-              max_planning_time: int = 30) -> Dict[str, Any]:
-    """Phase 1 (design) for this rank's shard, then phase 2 (retrosynthesis); returns {"results": [...], "stats": {...}}."""
+              max_planning_time: int = 30, work_queue=None) -> Dict[str, Any]:
+    """Phase 1 (design) for this rank's prompts, then phase 2 (retrosynthesis) for the same prompts; returns {"results": [...],
+    "stats": {...}}.  Prompts are a static contiguous shard per rank, or -- with ``work_queue`` (distributed.WorkQueue over the
+    batches) -- claimed batch by batch from a shared counter, which evens out prompts whose decodes / searches run long."""
     from .distributed import shard_range
-    mine = list(shard_range(len(records), rank, world))
+    def claim():
+        """This rank's prompt batches, one at a time (a batch is claimed only when the previous one is done)."""
+        if work_queue is not None:
+            for b in work_queue:
+                yield list(range(b * batch_size, min((b + 1) * batch_size, len(records))))
+        else:
+            shard = list(shard_range(len(records), rank, world))
+            for lo in range(0, len(shard), batch_size):
+                yield shard[lo:lo + batch_size]
     results: List[dict] = []
+    taken: List[List[int]] = []          # the batches this rank processed, in order (phase 2 revisits them)
     dev = model.device
     t0 = time.perf_counter()
     dit_ms, dit_steps = 0.0, 0
-    for lo in range(0, len(mine), batch_size):
-        idxs = mine[lo:lo + batch_size]
+    for idxs in claim():
+        taken.append(idxs)
         ids, mask, props = encode_batch(tokenizer, [records[i] for i in idxs], cutoff_len)
         info = model.generate(input_ids=ids.to(dev), attention_mask=mask.to(dev), molecule_properties=props.to(dev),
                               do_molecular_design=True, do_retrosynthesis=False, rollback=True, **gen_kwargs)
@@ -119,8 +131,8 @@ def run_molqa(model, tokenizer, records: List[dict], cutoff_len: int, batch_size
             results.append(rec)
     t1 = time.perf_counter()
     if do_retrosynthesis:
-        for lo in range(0, len(mine), batch_size):
-            idxs = mine[lo:lo + batch_size]
+        lo = 0
+        for idxs in taken:
             ids, mask, _ = encode_batch(tokenizer, [records[i] for i in idxs], cutoff_len)
             smiles = [results[lo + j]["llm_smiles"] for j in range(len(idxs))]
             info = model.generate(input_ids=ids.to(dev), attention_mask=mask.to(dev), do_molecular_design=False,
@@ -134,9 +146,11 @@ def run_molqa(model, tokenizer, records: List[dict], cutoff_len: int, batch_size
                 new_text = "".join(x for x in info["text_lists"][j] if x is not None)
                 rec["llm_response"] = remove_extra_spaces(rec["llm_response"] + new_text)
                 rec["response_retro"] = remove_extra_spaces(new_text)
+            lo += len(idxs)
     t2 = time.perf_counter()
-    stats = {"n_prompts": len(mine), "design_s": t1 - t0, "retro_s": t2 - t1,
-             "molecules_per_s": len(mine) / max(t1 - t0, 1e-9),
+    n_mine = sum(len(b) for b in taken)
+    stats = {"n_prompts": n_mine, "design_s": t1 - t0, "retro_s": t2 - t1,
+             "molecules_per_s": n_mine / max(t1 - t0, 1e-9),
              "denoise_steps_per_s": (1e3 * dit_steps / dit_ms) if dit_ms > 0 else None}
     if world > 1:
         import torch.distributed as dist
@@ -197,8 +211,14 @@ def run_eval(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> Di
     model.batch_retro = bool(getattr(generating_args, "batch_retro", False) or (overrides or {}).get("batch_retro", False))
     if rank == 0:
         print(json.dumps({"llm_acceleration": accel}))
-    out = run_molqa(model, tokenizer, load_dataset_records(data_args), data_args.cutoff_len,
-                    training_args.per_device_eval_batch_size, gen_kwargs, rank=rank, world=world,
+    records = load_dataset_records(data_args)
+    queue = None
+    if world > 1 and bool((overrides or {}).get("dynamic_sharding", getattr(data_args, "dynamic_sharding", True))):
+        from .distributed import WorkQueue      # prompts are claimed batch by batch: long decodes / searches do not idle other ranks
+        bs = training_args.per_device_eval_batch_size
+        queue = WorkQueue((len(records) + bs - 1) // bs, rank, world)
+    out = run_molqa(model, tokenizer, records, data_args.cutoff_len,
+                    training_args.per_device_eval_batch_size, gen_kwargs, rank=rank, world=world, work_queue=queue,
                     expansion_topk=data_args.expansion_topk, iterations=data_args.retro_iterations,
                     max_planning_time=data_args.retro_max_planning_time)
     if rank == 0:

@@ -201,3 +201,33 @@ def test_allreduce_gradients_with_rank_dependent_grad_sets():
     assert res[0][1] == res[1][1] >= 2
     for r in res:
         assert r[2] == [1.5] * 5 and r[3] == [[1.5, 1.5]] * 3 and r[4] == [2.0] * 4 and r[5]
+
+
+def _queue_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import time
+    wq = D.WorkQueue(11, rank, world)
+    got = []
+    for i in wq:
+        got.append(i)
+        time.sleep(0.02 if rank == 0 else 0.005)        # rank 1 is "faster": it must end up with more items
+    q.put((rank, got))
+
+
+def test_work_queue_hands_out_every_item_once():
+    """dynamic distribution of prompt batches -- every item is claimed exactly once, the faster rank takes more."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_queue_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res[0] + res[1]) == list(range(11)) and set(res[0]).isdisjoint(res[1])
+    assert len(res[1]) > len(res[0])
+    assert list(D.WorkQueue(4)) == [0, 1, 2, 3]            # one rank: plain range
