@@ -437,11 +437,12 @@ def main():
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["traffic"] = None
     try:   # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same shape)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        pmc_file = "r2_pmc_traffic.json"       # r1 entries (LLM kernels, frozen since) + the GraphDiT fc1 GEMM re-measured at HEAD
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
         key = kkey
         if key in pmc and args.dtype == "bf16" and (not key.startswith("fc1") or args.hidden == 1024):
             roof["traffic"] = pmc[key]["hbm_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
+            roof["traffic_source"] = f"profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
     except Exception:
         pass
     roof["algorithmic_bytes"] = kbytes
