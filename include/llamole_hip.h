@@ -151,8 +151,11 @@ int ll_dit_cvec(void *handle, int s, float *c, void *stream);
 int ll_dit_set_overlap(void *handle, int on);
 /* ll_dit_set_option : per-engine switches, effective for every later denoiser call of this handle (step / run / denoise /
  * step_probs).  LL_DIT_OPT_OVERLAP = ll_dit_set_overlap; LL_DIT_OPT_GENERIC_ATTN = run the f32-LDS attention kernel under the
- * bf16 engine instead of the MFMA one (parity hook: the two are compared on identical q|k|v by the tests). */
-enum { LL_DIT_OPT_OVERLAP = 0, LL_DIT_OPT_GENERIC_ATTN = 1 };
+ * bf16 engine instead of the MFMA one (parity hook: the two are compared on identical q|k|v by the tests);
+ * LL_DIT_OPT_FUSED_QKV_ATTN = the block's q|k|v projection and attention as ONE launch per (sequence, head) (bf16, head
+ * dimension 64, hidden 256 | 512 | a multiple of 1024): -1 = when the launch has 64..512 such workgroups, i.e. batch 2..16 at 16 heads
+ * (default), 0 = never, 1 = whenever eligible. */
+enum { LL_DIT_OPT_OVERLAP = 0, LL_DIT_OPT_GENERIC_ATTN = 1, LL_DIT_OPT_FUSED_QKV_ATTN = 2 };
 int ll_dit_set_option(void *handle, int option, int value);
 int ll_dit_last_run_ms(void *handle, float *ms, int *steps);
 /* Tuning: ln_mod_res with one wave per 256-column chunk of a row (default) or one wave per row; bit-identical results; returns the

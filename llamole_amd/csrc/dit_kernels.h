@@ -194,6 +194,15 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const T *__restrict__
     }
 }
 
+#ifdef LL_QA_PROBE      // tools/qkv_attn_probe.hip: cycle stamps of wave 0 of every workgroup
+__device__ unsigned long long g_qa_stamps[4096 * 8];
+__device__ unsigned long long g_qa_wstamps[1024 * 12 * 4];     // per wave: stamps 0..3
+#define LL_QA_STAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter();                                   \
+        if (threadIdx.x == 0) g_qa_stamps[(blockIdx.x & 4095) * 8 + (i)] = t_;                                          \
+        if ((i) < 4 && (threadIdx.x & 63) == 0) g_qa_wstamps[((blockIdx.x & 1023) * 12 + (threadIdx.x >> 6)) * 4 + (i)] = t_; } while (0)
+#else
+#define LL_QA_STAMP(i) do { } while (0)
+#endif
 // ------------------------------------------------------------------------------------------ attention (MFMA, bf16)
 // One workgroup of one or two 64-lane waves per (sequence, head).  The whole graph (N <= 64 nodes) is one tile:
 //   q,k rows -> f32 LayerNorm(hd) in registers -> bf16 in LDS;  V stored transposed in LDS;
@@ -202,30 +211,133 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const T *__restrict__
 typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
 typedef __attribute__((ext_vector_type(4))) float af32x4;
 
+// S = Q K^T, mask + softmax, O = P V for the query tiles of wave `wave` (of WPB), operands in LDS: Qs / Ks [NP][HD + 8] bf16
+// (LayerNorm applied), Vt [HD][NP + 8] (V transposed, zero columns for padded keys), Ps [NP][NP + 8] scratch for P.  PSEP =
+// Ps is its own region; otherwise it aliases Qs and the WPB waves synchronise before P is written.  exp and the reciprocal of
+// the row sum are the hardware v_exp_f32 / v_rcp_f32 (1 ulp; P is rounded to bf16 right after).  PV is evaluated as
+// O^T = V^T P^T, so a lane ends up with four consecutive head columns of one query row: 8-byte stores.
+template <int NP, int HD, int WPB, bool PSEP>
+__device__ __forceinline__ void attn_core(const bf16_t *Qs, const bf16_t *Ks, const bf16_t *Vt, bf16_t *Ps,
+                                          bf16_t *__restrict__ ohead, int N, int nv, int H, int wave, int lane) {
+    constexpr int QLD = HD + 8, PLD = NP + 8;
+    constexpr int MT = NP / 16, KS = HD / 32;
+    constexpr int MQ = MT / WPB;
+    static_assert(MQ >= 1 && MQ * WPB == MT, "query tiles must divide among the waves");
+    LL_QA_STAMP(5);
+    const int q0 = wave * MQ;
+    af32x4 acc[MQ][MT];
+#pragma unroll
+    for (int i = 0; i < MQ; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = af32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        abf16x8 fa[MQ], fb[MT];
+#pragma unroll
+        for (int i = 0; i < MQ; ++i) fa[i] = *reinterpret_cast<const abf16x8 *>(Qs + ((q0 + i) * 16 + fr) * QLD + ks * 32 + fk * 8);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fb[i] = *reinterpret_cast<const abf16x8 *>(Ks + (i * 16 + fr) * QLD + ks * 32 + fk * 8);
+#pragma unroll
+        for (int i = 0; i < MQ; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (!PSEP) {
+        if (WPB == 1) {
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // all Q reads done before P overwrites region 0
+        } else {
+            __syncthreads();
+        }
+    }
+
+    // ---- mask + softmax in the C layout: element r of tile (mt,nt): i = mt*16 + (lane>>4)*4 + r, j = nt*16 + (lane&15)
+    const float scale2 = rsqrtf((float)HD) * 1.44269504088896340736f;       // softmax(s / sqrt(hd)) through exp2
+#pragma unroll
+    for (int mt = 0; mt < MQ; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = (q0 + mt) * 16 + fk * 4 + r;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nt = 0; nt < MT; ++nt) {
+                const int j = nt * 16 + fr;
+                const bool allow = (j < N) && ((i >= nv) || (j < nv));
+                const float sv = allow ? acc[mt][nt][r] * scale2 : -INFINITY;
+                acc[mt][nt][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+            mx = row16_max(mx);
+            float sm = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < MT; ++nt) {
+                const float ev = __builtin_amdgcn_exp2f(acc[mt][nt][r] - mx);
+                acc[mt][nt][r] = ev;
+                sm += ev;
+            }
+            sm = row16_sum(sm);
+            const float inv = __builtin_amdgcn_rcpf(sm);
+#pragma unroll
+            for (int nt = 0; nt < MT; ++nt) Ps[i * PLD + nt * 16 + fr] = f32_to_bf16(acc[mt][nt][r] * inv);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    LL_QA_STAMP(6);
+
+    // ---- O^T = V^T P^T (this wave's rows of P only: written and read by the same wave)
+    constexpr int NT2 = HD / 16, KS2 = NP / 32;
+    af32x4 oc[MQ][NT2];
+#pragma unroll
+    for (int i = 0; i < MQ; ++i)
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) oc[i][j] = af32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) {
+        abf16x8 fp[MQ], fv[NT2];
+#pragma unroll
+        for (int i = 0; i < MQ; ++i) fp[i] = *reinterpret_cast<const abf16x8 *>(Ps + ((q0 + i) * 16 + fr) * PLD + ks * 32 + fk * 8);
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) fv[j] = *reinterpret_cast<const abf16x8 *>(Vt + (j * 16 + fr) * PLD + ks * 32 + fk * 8);
+#pragma unroll
+        for (int i = 0; i < MQ; ++i)
+#pragma unroll
+            for (int j = 0; j < NT2; ++j) oc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[j], fp[i], oc[i][j], 0, 0, 0);
+    }
+    // oc[mt][nt][r] = O[query (q0 + mt) * 16 + fr][head column nt * 16 + fk * 4 + r]
+#pragma unroll
+    for (int mt = 0; mt < MQ; ++mt) {
+        const int i = (q0 + mt) * 16 + fr;
+        if (i < N) {
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) {
+                const uint32_t lo = (uint32_t)f32_to_bf16(oc[mt][nt][0]) | ((uint32_t)f32_to_bf16(oc[mt][nt][1]) << 16);
+                const uint32_t hi = (uint32_t)f32_to_bf16(oc[mt][nt][2]) | ((uint32_t)f32_to_bf16(oc[mt][nt][3]) << 16);
+                *reinterpret_cast<uint2 *>(ohead + (int64_t)i * H + nt * 16 + fk * 4) = make_uint2(lo, hi);
+            }
+        }
+    }
+}
+
 // WPB waves per (sequence, head): with two, each wave loads / normalises half the rows (14 instead of 20 loads in flight per
 // lane) and owns half the query rows of S, the softmax and O -- the serial MFMA / softmax chain per wave halves; K and V^T are
 // shared through LDS (two workgroup barriers).  Row-wise arithmetic is unchanged, so the result is bit-identical to WPB = 1.
-template <int NP, int HD, int WPB>
-__global__ __launch_bounds__(64 * WPB) void attn_mfma_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ o,
-                                                         const float *__restrict__ qw, const float *__restrict__ qb,
-                                                         const float *__restrict__ kw, const float *__restrict__ kb,
-                                                         const int *__restrict__ n_nodes, int B, int N, int H,
-                                                         int heads) {
+// `ld(row, which, d0)` returns the 8 bf16 at columns [d0, d0 + 8) of this head's q (which = 0), k (1) or v (2) row: from
+// the qkv activation in global memory (attn_mfma_kernel) or from the LDS image the fused q|k|v GEMM left (qkv_attn_kernel);
+// `ohead` = o + first row of the sequence * H + head * HD.  Waves >= WPB of a larger workgroup must not enter.
+template <int NP, int HD, int WPB, typename LD>
+__device__ __forceinline__ void attn_mfma_body(LD ld, bf16_t *__restrict__ ohead, const float *__restrict__ qw,
+                                               const float *__restrict__ qb, const float *__restrict__ kw,
+                                               const float *__restrict__ kb, int N, int nv, int H, unsigned char *smraw_attn,
+                                               int wave, int lane) {
     constexpr int QLD = HD + 8;           // padded row strides (elements)
     constexpr int PLD = NP + 8;
     constexpr int QK_ELEMS = NP * QLD;
     constexpr int P_ELEMS = NP * PLD;
     constexpr int R0 = QK_ELEMS > P_ELEMS ? QK_ELEMS : P_ELEMS;   // region 0: Q, later P
-    constexpr int WAVE_ELEMS = R0 + QK_ELEMS + HD * PLD;          // + K + V^T
-    extern __shared__ __attribute__((aligned(16))) unsigned char smraw_attn[];
     static_assert(WPB == 1 || WPB == 2, "one or two waves per (sequence, head)");
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int head = blockIdx.x;
-    if (head >= heads) return;
-    const int seq = blockIdx.y;
-    const int nv = n_nodes[seq % B];
     bf16_t *Qs = reinterpret_cast<bf16_t *>(smraw_attn);
-    (void)WAVE_ELEMS;
     bf16_t *Ks = Qs + R0;
     bf16_t *Vt = Ks + QK_ELEMS;
     bf16_t *Ps = Qs;
@@ -243,11 +355,10 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_kernel(const bf16_t *__res
         uint4 rq[PASSES], rk[PASSES], rv[PASSES];
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int row = p * RPP + rin;
-            const bf16_t *src = qkv + ((int64_t)seq * N + (row < N ? row : 0)) * (3 * (int64_t)H) + head * HD + d0;
-            rq[p] = *reinterpret_cast<const uint4 *>(src);
-            rk[p] = *reinterpret_cast<const uint4 *>(src + H);
-            rv[p] = *reinterpret_cast<const uint4 *>(src + 2 * H);
+            const int row = p * RPP + rin, srow = row < N ? row : 0;
+            rq[p] = ld(srow, 0, d0);
+            rk[p] = ld(srow, 1, d0);
+            rv[p] = ld(srow, 2, d0);
         }
         float wq[8], bq[8], wk[8], bk[8];
         {
@@ -311,100 +422,27 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_kernel(const bf16_t *__res
     } else {
         __syncthreads();
     }
+    attn_core<NP, HD, WPB, false>(Qs, Ks, Vt, Ps, ohead, N, nv, H, wave, lane);
+}
 
-    // ---- S = Q K^T: this wave's query tiles [wave * MQ, (wave + 1) * MQ) against all key tiles
-    constexpr int MT = NP / 16, KS = HD / 32;
-    constexpr int MQ = MT / WPB;
-    static_assert(MQ >= 1, "too few query tiles for two waves");
-    const int q0 = wave * MQ;
-    af32x4 acc[MQ][MT];
-#pragma unroll
-    for (int i = 0; i < MQ; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = af32x4{0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, fk = lane >> 4;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        abf16x8 fa[MQ], fb[MT];
-#pragma unroll
-        for (int i = 0; i < MQ; ++i) fa[i] = *reinterpret_cast<const abf16x8 *>(Qs + ((q0 + i) * 16 + fr) * QLD + ks * 32 + fk * 8);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) fb[i] = *reinterpret_cast<const abf16x8 *>(Ks + (i * 16 + fr) * QLD + ks * 32 + fk * 8);
-#pragma unroll
-        for (int i = 0; i < MQ; ++i)
-#pragma unroll
-            for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    if (WPB == 1) {
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // all Q reads done before P overwrites region 0
-    } else {
-        __syncthreads();
-    }
-
-    // ---- mask + softmax in the C layout: element r of tile (mt,nt): i = mt*16 + (lane>>4)*4 + r, j = nt*16 + (lane&15)
-    const float scale = rsqrtf((float)HD);
-#pragma unroll
-    for (int mt = 0; mt < MQ; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = (q0 + mt) * 16 + fk * 4 + r;
-            float mx = -INFINITY;
-#pragma unroll
-            for (int nt = 0; nt < MT; ++nt) {
-                const int j = nt * 16 + fr;
-                const bool allow = (j < N) && ((i >= nv) || (j < nv));
-                const float sv = allow ? acc[mt][nt][r] * scale : -INFINITY;
-                acc[mt][nt][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
-            mx = row16_max(mx);
-            float sm = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < MT; ++nt) {
-                const float ev = expf(acc[mt][nt][r] - mx);
-                acc[mt][nt][r] = ev;
-                sm += ev;
-            }
-            sm = row16_sum(sm);
-            const float inv = 1.f / sm;
-#pragma unroll
-            for (int nt = 0; nt < MT; ++nt) Ps[i * PLD + nt * 16 + fr] = f32_to_bf16(acc[mt][nt][r] * inv);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-
-    // ---- O = P V (this wave's rows of P only: written and read by the same wave)
-    constexpr int NT2 = HD / 16, KS2 = NP / 32;
-    af32x4 oc[MQ][NT2];
-#pragma unroll
-    for (int i = 0; i < MQ; ++i)
-#pragma unroll
-        for (int j = 0; j < NT2; ++j) oc[i][j] = af32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS2; ++ks) {
-        abf16x8 fa[MQ], fb[NT2];
-#pragma unroll
-        for (int i = 0; i < MQ; ++i) fa[i] = *reinterpret_cast<const abf16x8 *>(Ps + ((q0 + i) * 16 + fr) * PLD + ks * 32 + fk * 8);
-#pragma unroll
-        for (int j = 0; j < NT2; ++j) fb[j] = *reinterpret_cast<const abf16x8 *>(Vt + (j * 16 + fr) * PLD + ks * 32 + fk * 8);
-#pragma unroll
-        for (int i = 0; i < MQ; ++i)
-#pragma unroll
-            for (int j = 0; j < NT2; ++j) oc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], oc[i][j], 0, 0, 0);
-    }
-#pragma unroll
-    for (int mt = 0; mt < MQ; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = (q0 + mt) * 16 + fk * 4 + r;
-            if (i < N) {
-#pragma unroll
-                for (int nt = 0; nt < NT2; ++nt)
-                    o[((int64_t)seq * N + i) * H + head * HD + nt * 16 + fr] = f32_to_bf16(oc[mt][nt][r]);
-            }
-        }
+template <int NP, int HD, int WPB>
+__global__ __launch_bounds__(64 * WPB) void attn_mfma_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ o,
+                                                         const float *__restrict__ qw, const float *__restrict__ qb,
+                                                         const float *__restrict__ kw, const float *__restrict__ kb,
+                                                         const int *__restrict__ n_nodes, int B, int N, int H,
+                                                         int heads) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw_attn[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int head = blockIdx.x;
+    if (head >= heads) return;
+    const int seq = blockIdx.y;
+    const int nv = n_nodes[seq % B];
+    const bf16_t *base = qkv + (int64_t)seq * N * (3 * (int64_t)H) + head * HD;
+    attn_mfma_body<NP, HD, WPB>(
+        [&](int row, int which, int d0) {
+            return *reinterpret_cast<const uint4 *>(base + (int64_t)row * (3 * (int64_t)H) + (int64_t)which * H + d0);
+        },
+        o + (int64_t)seq * N * H + head * HD, qw, qb, kw, kb, N, nv, H, smraw_attn, wave, lane);
 }
 
 template <int NP, int HD> static constexpr size_t attn_mfma_lds_bytes() {
@@ -412,6 +450,226 @@ template <int NP, int HD> static constexpr size_t attn_mfma_lds_bytes() {
     constexpr int QK = NP * QLD, P = NP * PLD;
     constexpr int R0 = QK > P ? QK : P;
     return (size_t)(R0 + QK + HD * PLD) * 2;
+}
+
+// ------------------------------------------------------------------------------------------ q|k|v GEMM + attention, one launch
+// One workgroup per (sequence, head): the head's 3 * HD rows of the q|k|v weight (3 * HD * H bf16 = 384 KB at H = 1024) times
+// the sequence's token panel, then the attention above on the result -- the q|k|v activation never leaves the CU and the block
+// loses one dependent launch (layers.py:56-87; there is no full-row LayerNorm between the projection and the attention, q/k
+// LayerNorm is per head).  Twelve waves; wave w owns output columns [16 w, 16 w + 16) of the head's q|k|v for all token rows.
+// The weight comes from a copy the engine packs once at creation in MFMA A-operand order (pack_mfma16_kernel: the 16 rows x
+// 32 k block of a fragment is 1 KB contiguous, lane l's 16 bytes at offset 16 l), so a wave's stream is one contiguous 32 KB
+// run read with full-line wave instructions STRAIGHT INTO the operand registers -- no LDS round trip, and not the 16-lines-per-
+// instruction pattern fragment loads from the row-major weight have (38 GB/s per CU, tools/ingest_probe.hip); two blocks of
+// four k-steps stay in flight per lane.  The token panel is staged in LDS once per K chunk for all waves (XOR-swizzled 16-byte
+// pieces: conflict-free fragment reads).  bf16(acc) goes to an LDS image of the qkv rows -- the same rounding the separate GEMM
+// applies when it stores its output -- and two waves run attn_mfma_body on it.  Pays when the launch has >= ~128 workgroups
+// (batch >= 4): a workgroup pulls its 384 KB at the per-CU rate, which 32 workgroups cannot hide.
+// Workgroup barrier that makes LDS writes visible but leaves global loads in flight (__syncthreads() drains vmcnt, which
+// would stall every wave on the weight blocks it has prefetched).
+__device__ __forceinline__ void qa_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__global__ __launch_bounds__(256) void pack_mfma16_kernel(const bf16_t *__restrict__ W, bf16_t *__restrict__ out, int Nout, int K) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;        // one 16-byte piece per thread
+    const int kts = K / 32;
+    if (g >= (int64_t)(Nout / 16) * kts * 64) return;
+    const int l = (int)(g & 63);
+    const int64_t blk = g >> 6;
+    const int kt = (int)(blk % kts);
+    const int64_t nt = blk / kts;
+    *reinterpret_cast<uint4 *>(out + g * 8) =
+        *reinterpret_cast<const uint4 *>(W + (nt * 16 + (l & 15)) * (int64_t)K + kt * 32 + (l >> 4) * 8);
+}
+
+template <int NP, int KC> struct QkvAttnGeom {                     // KC = K chunk of the token panel staged in LDS (elements; 256 | 512 | 1024)
+    static constexpr int HD = 64, WAVES = 12;
+    static constexpr int KPB = KC >= 512 ? 8 : 4;                     // k-steps (of 32) per prefetch block; two blocks in flight per lane
+    static constexpr int XBYTES = NP * 2 * KC;
+    // after the K loop the panel's LDS holds the Q | K | V^T | P images (< 37 KB) and the LayerNorm partials at 40 KB (<= 16 KB)
+    static constexpr size_t lds_bytes() { return XBYTES > 57344 ? XBYTES : 57344; }
+};
+
+template <int NP, int KC>
+__global__ __launch_bounds__(768) void qkv_attn_kernel(const bf16_t *__restrict__ xa, const bf16_t *__restrict__ Wp,
+                                                       bf16_t *__restrict__ o, const float *__restrict__ qw,
+                                                       const float *__restrict__ qb, const float *__restrict__ kw,
+                                                       const float *__restrict__ kb, const int *__restrict__ n_nodes, int B,
+                                                       int N, int H, int heads) {
+    using G = QkvAttnGeom<NP, KC>;
+    constexpr int HD = G::HD, MT = NP / 16, KPB = G::KPB, XPITCH = 2 * KC;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_qa[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = blockIdx.x % heads, seq = blockIdx.x / heads;    // consecutive workgroups = the heads of one sequence:
+    const int nv = n_nodes[seq % B];                                  // head h of every sequence lands on XCD h % 8 (one L2 copy of its weights)
+    unsigned char *xs = sm_qa;                                        // [NP][XPITCH] token panel chunk, 16-byte piece p of row r at p ^ (r & 15)
+    LL_QA_STAMP(0);
+    const int part = wid >> 2, sub = wid & 3;                         // q | k | v, 16-column group inside the head
+    const int fr = lane & 15, fq = lane >> 4;
+    const int kts = H / 32;
+    // LayerNorm weight / bias of this lane's four output columns (q and k waves); requested first, used after the K loop
+    const float4 lnw = *reinterpret_cast<const float4 *>((part == 1 ? kw : qw) + sub * 16 + fq * 4);
+    const float4 lnb = *reinterpret_cast<const float4 *>((part == 1 ? kb : qb) + sub * 16 + fq * 4);
+    const unsigned char *wtile = reinterpret_cast<const unsigned char *>(Wp) + (int64_t)((part * H + head * HD) / 16 + sub) * kts * 1024;   // uniform
+    af32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = af32x4{0.f, 0.f, 0.f, 0.f};
+    abf16x8 wa[KPB], wb[KPB];
+    const int nblk = kts / KPB;
+    auto loadw = [&](abf16x8 (&r)[KPB], int blk) {
+        const unsigned char *pb = wtile + (int64_t)blk * (KPB * 1024);
+#pragma unroll
+        for (int q = 0; q < KPB; ++q) r[q] = *reinterpret_cast<const abf16x8 *>(pb + lane * 16 + q * 1024);
+    };
+    // fragment (token row mt * 16 + fr, 16-byte piece A + fq) with A a multiple of 4 sits at piece (A ^ (fr & 12)) + (fq ^ (fr & 3))
+    const int flo = fr * XPITCH + ((fq ^ (fr & 3)) << 4), fhi = fr & 12;
+    auto mulblk = [&](const abf16x8 (&r)[KPB], int pin) {             // pin = first 16-byte piece of the block inside the staged chunk
+        const unsigned char *xb = xs + flo + (pin << 4);
+#if defined(LL_QA_MODE) && LL_QA_MODE == 5      // probe: pure ingest, the blocks are only folded into the accumulator
+#pragma unroll
+        for (int ks = 0; ks < KPB; ++ks) acc[0][0] += __builtin_bit_cast(af32x4, r[ks])[ks & 3];
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+#endif
+#pragma unroll
+        for (int ks = 0; ks < KPB; ++ks) {
+            const unsigned char *xk = xb + (((ks * 4) ^ fhi) << 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r[ks], *reinterpret_cast<const abf16x8 *>(xk + mt * 16 * XPITCH), acc[mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);                            // the loads that follow stay behind these MFMAs, and ahead of the next block's
+    };
+    // Block order: the workgroups of the 2B sequences that share this head's weights (same XCD) start at different places of the
+    // K loop, so between them the whole weight slice is requested within the first memory round trip and everything after it is
+    // an L2 hit -- in lock step they would all wait for the same HBM line four times over.
+    constexpr int BPC = KC / (32 * KPB);                              // blocks per staged chunk
+    const int nch = H / KC;                                           // chunks
+#if defined(LL_QA_MODE) && LL_QA_MODE == 4      // probe: the waves of a workgroup start at different blocks too
+    const int rot = (seq + (wid >> 1)) % BPC, cs = (seq / BPC) % nch;
+#else
+    const int rot = seq % BPC, cs = (seq / BPC) % nch;
+#endif
+    auto chunk_of = [&](int i) { return nch == 1 ? 0 : (cs + i / BPC) % nch; };
+    auto blk_in = [&](int i) { return (rot + i) % BPC; };
+    auto wblock = [&](int i) { return chunk_of(i) * BPC + blk_in(i); };
+    constexpr int PPR = KC / 8, PIECES = NP * PPR;                    // 16-byte pieces per panel row / per chunk (powers of two)
+    constexpr int XPT = (PIECES + 767) / 768;
+    const bf16_t *xseq = xa + (int64_t)seq * N * H;
+    auto stage = [&](int c0, bool first) {
+        u32x4 xr[XPT];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int pc = (tid + i * 768) & (PIECES - 1);            // wraps onto pieces another thread stages too (same bytes)
+            const int row = pc / PPR, col = pc % PPR;
+#if defined(LL_QA_MODE) && LL_QA_MODE == 2      // probe: no panel loads
+            xr[i] = (u32x4)(0x3c003c00u);
+#else
+            xr[i] = *reinterpret_cast<const u32x4 *>(xseq + (row < N ? row : 0) * H + c0 + col * 8);
+#endif
+        }
+#if !defined(LL_QA_MODE) || LL_QA_MODE != 1
+        if (first) {
+#if defined(LL_QA_MODE) && LL_QA_MODE == 3      // probe: every wave's panel pieces are requested before anybody's weight blocks
+            asm volatile("s_barrier" ::: "memory");
+#endif
+            loadw(wa, wblock(0));
+            loadw(wb, wblock(1));
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);                            // every load above is issued before the first one is waited for
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int pc = (tid + i * 768) & (PIECES - 1);
+            const int row = pc / PPR, col = pc % PPR;
+            *reinterpret_cast<u32x4 *>(xs + row * XPITCH + ((col ^ (row & 15)) << 4)) = row < N ? xr[i] : (u32x4)(0);
+        }
+    };
+    stage(cs * KC, true);
+    LL_QA_STAMP(1);
+    qa_barrier();
+    LL_QA_STAMP(2);
+#if defined(LL_QA_MODE) && LL_QA_MODE == 1      // probe: weight blocks requested only after the panel is staged
+    loadw(wa, wblock(0));
+    loadw(wb, wblock(1));
+#endif
+    auto pair = [&](int i, bool more) {
+        if (i && i % BPC == 0) {                                      // next K chunk of the token panel (H > KC only)
+            qa_barrier();
+            stage(chunk_of(i) * KC, false);
+            qa_barrier();
+        }
+        mulblk(wa, blk_in(i) * 4 * KPB);
+        if (more) loadw(wa, wblock(i + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        mulblk(wb, blk_in(i + 1) * 4 * KPB);
+        if (more) loadw(wb, wblock(i + 3));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int i = 0; i < nblk - 2; i += 2) pair(i, true);
+    pair(nblk - 2, false);
+    LL_QA_STAMP(3);
+    // ---- per-head LayerNorm of q and k, V^T, all in place: wave `wid` holds output columns [16 wid, 16 wid + 16) of q|k|v for
+    //      every token, acc[mt][j] = C[column wid * 16 + fq * 4 + j][token mt * 16 + fr].  The row statistics over the head's
+    //      64 columns (four waves x four lane groups) go through LDS as (sum, sum of squares) partials of the bf16-rounded
+    //      projection -- the value the separate GEMM would have stored; var = E[x^2] - mean^2 in f32 (64 terms).
+    constexpr int QLD = HD + 8, PLD = NP + 8;
+    bf16_t *Qs = reinterpret_cast<bf16_t *>(sm_qa);
+    bf16_t *Ks = Qs + NP * QLD;
+    bf16_t *Vt = Ks + NP * QLD;
+    bf16_t *Ps = Vt + HD * PLD;
+    float2 *st = reinterpret_cast<float2 *>(sm_qa + 40960);           // [2][4][NP] (sum, sum of squares) per 16-column group; images above: < 37 KB
+    float v[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[mt][j] = bf16_to_f32(f32_to_bf16(acc[mt][j]));
+    qa_barrier();                                                     // panel reads done: its LDS is reused from here on
+    if (part < 2) {
+        const int x16 = (lane ^ 16) << 2, x32 = (lane ^ 32) << 2;     // the four lane groups of a token: lanes fr, fr + 16, fr + 32, fr + 48
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float s1 = (v[mt][0] + v[mt][1]) + (v[mt][2] + v[mt][3]);
+            float s2 = (v[mt][0] * v[mt][0] + v[mt][1] * v[mt][1]) + (v[mt][2] * v[mt][2] + v[mt][3] * v[mt][3]);
+            s1 += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(x16, __builtin_bit_cast(int, s1)));
+            s2 += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(x16, __builtin_bit_cast(int, s2)));
+            s1 += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(x32, __builtin_bit_cast(int, s1)));
+            s2 += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(x32, __builtin_bit_cast(int, s2)));
+            if (fq == 0) st[(part * 4 + sub) * NP + mt * 16 + fr] = make_float2(s1, s2);
+        }
+    }
+    qa_barrier();
+    if (part < 2) {
+        bf16_t *dst = part == 0 ? Qs : Ks;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int tok = mt * 16 + fr;
+            const float2 t0 = st[(part * 4 + 0) * NP + tok], t1 = st[(part * 4 + 1) * NP + tok];
+            const float2 t2 = st[(part * 4 + 2) * NP + tok], t3 = st[(part * 4 + 3) * NP + tok];
+            const float s1 = (t0.x + t1.x) + (t2.x + t3.x), s2 = (t0.y + t1.y) + (t2.y + t3.y);
+            const float mean = s1 * (1.f / HD);
+            const float rstd = rsqrtf(fmaxf(s2 * (1.f / HD) - mean * mean, 0.f) + 1e-5f);
+            const bool live = tok < N;
+            const float o0 = live ? (v[mt][0] - mean) * rstd * lnw.x + lnb.x : 0.f, o1 = live ? (v[mt][1] - mean) * rstd * lnw.y + lnb.y : 0.f;
+            const float o2 = live ? (v[mt][2] - mean) * rstd * lnw.z + lnb.z : 0.f, o3 = live ? (v[mt][3] - mean) * rstd * lnw.w + lnb.w : 0.f;
+            *reinterpret_cast<uint2 *>(dst + tok * QLD + sub * 16 + fq * 4) =
+                make_uint2((uint32_t)f32_to_bf16(o0) | ((uint32_t)f32_to_bf16(o1) << 16), (uint32_t)f32_to_bf16(o2) | ((uint32_t)f32_to_bf16(o3) << 16));
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int tok = mt * 16 + fr;
+            const bool live = tok < N;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Vt[(sub * 16 + fq * 4 + j) * PLD + tok] = live ? f32_to_bf16(acc[mt][j]) : (bf16_t)0;
+        }
+    }
+    qa_barrier();
+    LL_QA_STAMP(4);
+    if (wid < MT) attn_core<NP, HD, MT, true>(Qs, Ks, Vt, Ps, o + (int64_t)seq * N * H + head * HD, N, nv, H, wid, lane);
+    LL_QA_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------ AdaLN epilogue

@@ -139,6 +139,7 @@ struct DitEngine {
     DevBuf wop;                  // operand-dtype copy of the arena (bf16 mode)
     DevBuf wxT;                  // x_embedder weight transposed [F][H] f32
     DevBuf wycat;                // [H][10H] operand dtype
+    DevBuf wqkvp;                // [depth][3H x H] q|k|v weights in MFMA A-operand order (pack_mfma16_kernel), bf16 mode
     DevBuf yw0, yb0;             // packed [10][H] f32
     DevBuf tables;               // x_marg16 e_marg8 u_xe80 u_ex80 betas[T+1] alphas_bar[T+1]
     // per-batch
@@ -164,6 +165,7 @@ struct DitEngine {
     int last_steps = 0;
     bool timed = false;
     bool force_generic_attn = false;
+    int fuse_qkv_attn = -1;          // q|k|v GEMM + attention in one launch: -1 = by workgroup count, 0 = never, 1 = whenever eligible
 
     const float *pf(const char *name) const {
         for (auto &p : layout)
@@ -214,6 +216,7 @@ template <typename T> static void launch_embed(DitEngine *e, hipStream_t st) {
                        e->x32.as<float>(), e->xa.as<T>(), e->step_ptr(), e->B, e->cfg.max_nodes, e->cfg.hidden);
 }
 static int g_attn_waves = 2;     // waves per (sequence, head) of attn_mfma_kernel (1 | 2)
+static int g_fuse_qkv_min_wgs = 64, g_fuse_qkv_max_wgs = 512;   // fuse_qkv_attn = -1: fuse when the launch has this many (sequence, head) workgroups
 
 template <int NP, int HD>
 static void launch_attn_mfma_t(DitEngine *e, const std::string &p, hipStream_t st) {
@@ -243,6 +246,34 @@ template <typename T> static void launch_attn(DitEngine *e, int layer, hipStream
                        e->attn_o.as<T>(), e->pfs(p + "q_norm.weight"), e->pfs(p + "q_norm.bias"),
                        e->pfs(p + "k_norm.weight"), e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, N,
                        e->cfg.hidden, hd);
+}
+// q|k|v projection + attention of block `layer` as ONE launch (qkv_attn_kernel); false = not eligible, run the two launches
+static bool qkv_attn_eligible(const DitEngine *e) {
+    const int H = e->cfg.hidden, N = e->cfg.max_nodes;
+    if (e->cfg.dtype != LL_BF16 || e->cfg.heads * 64 != H || N > 64) return false;
+    const int kc = std::min(H, N <= 32 ? 1024 : 512);                 // staged K chunk: 256 | 512 | 1024, dividing H
+    return (kc == 256 || kc == 512 || kc == 1024) && H % kc == 0;
+}
+static bool qkv_attn_wanted(const DitEngine *e) {
+    if (e->wqkvp.p == nullptr || e->force_generic_attn || e->fuse_qkv_attn == 0) return false;
+    // measured: a workgroup takes its 448 KB in at the per-CU rate whatever the batch, so below ~64 workgroups the
+    // two launches with 192+ workgroups each are faster, and beyond two rounds of workgroups per CU the 128-row tiles of the GEMM are
+    const int wgs = 2 * e->B * e->cfg.heads;
+    return e->fuse_qkv_attn == 1 || (wgs >= g_fuse_qkv_min_wgs && wgs <= g_fuse_qkv_max_wgs);
+}
+static void launch_qkv_attn(DitEngine *e, int layer, hipStream_t st) {
+    const std::string p = "blocks." + std::to_string(layer) + ".attn.";
+    const int N = e->cfg.max_nodes;
+    const dim3 grid(2 * e->B * e->cfg.heads), blk(768);
+    const int kc = std::min(e->cfg.hidden, N <= 32 ? 1024 : 512);     // K chunk of the token panel staged in LDS
+#define LL_QA(NP, KC)                                                                                                  \
+    hipLaunchKernelGGL((qkv_attn_kernel<NP, KC>), grid, blk, (QkvAttnGeom<NP, KC>::lds_bytes()), st, e->xa.as<bf16_t>(),   \
+                       e->wqkvp.as<bf16_t>() + (size_t)layer * 3 * e->cfg.hidden * e->cfg.hidden, e->attn_o.as<bf16_t>(), e->pfs(p + "q_norm.weight"), \
+                       e->pfs(p + "q_norm.bias"), e->pfs(p + "k_norm.weight"), e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, N, \
+                       e->cfg.hidden, e->cfg.heads)
+    if (N <= 32) { if (kc == 1024) LL_QA(32, 1024); else if (kc == 512) LL_QA(32, 512); else LL_QA(32, 256); }
+    else { if (kc == 512) LL_QA(64, 512); else LL_QA(64, 256); }
+#undef LL_QA
 }
 static int g_stage_mod = 1;           // stage the step's modulation rows at a fixed address (ll_set_stage_mod)
 static int g_lnmod_multiwave = 1;     // one wave per 256-column chunk of a row (ln_mod_res_mw_kernel) instead of one wave per row
@@ -309,10 +340,15 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
     if (hidden_tap && tap_layer == 0)
         LL_HIP(hipMemcpyAsync(hidden_tap, e->x32.p, (size_t)M2 * H * 4, hipMemcpyDeviceToDevice, st));
     const int64_t slab = (int64_t)e->M2p * H;
+    const bool fused_qkv = qkv_attn_wanted(e);
     for (int l = 0; l < c.depth; ++l) {
         const std::string p = "blocks." + std::to_string(l) + ".";
-        LL_TRY(linear_launch(dt, e->xa.p, H, e->pw(p + "attn.qkv.weight"), H, nullptr, e->qkv.p, 3 * H, M2, 3 * H, H, 0, 0, st));
-        if (bf) launch_attn<bf16_t>(e, l, st); else launch_attn<float>(e, l, st);
+        if (fused_qkv) {
+            launch_qkv_attn(e, l, st);
+        } else {
+            LL_TRY(linear_launch(dt, e->xa.p, H, e->pw(p + "attn.qkv.weight"), H, nullptr, e->qkv.p, 3 * H, M2, 3 * H, H, 0, 0, st));
+            if (bf) launch_attn<bf16_t>(e, l, st); else launch_attn<float>(e, l, st);
+        }
         LL_LAUNCH_CHECK();
         if (e->splits_h > 1)
             LL_TRY(linear_splitk_launch(dt, e->attn_o.p, H, e->pw(p + "attn.proj.weight"), H, e->ybuf.as<float>(), H, slab, M2, H, H, e->splits_h, st));
@@ -478,6 +514,9 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
     // the generic attention kernel may need > 64 KiB of dynamic LDS (N=64, hd>=64)
     CRH(hipFuncSetAttribute((const void *)attn_generic_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CRH(hipFuncSetAttribute((const void *)attn_generic_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+#define LL_QA_ATTR(NP, KC) CRH(hipFuncSetAttribute((const void *)(qkv_attn_kernel<NP, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(QkvAttnGeom<NP, KC>::lds_bytes())))
+    LL_QA_ATTR(32, 1024); LL_QA_ATTR(32, 512); LL_QA_ATTR(32, 256); LL_QA_ATTR(64, 512); LL_QA_ATTR(64, 256);
+#undef LL_QA_ATTR
     CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<32, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<32, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<32, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -486,7 +525,16 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
     CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    if (qkv_attn_eligible(e)) {
+        const size_t per = (size_t)3 * H * H;
+        CR(e->wqkvp.ensure(per * cfg->depth * 2));
+        for (int l = 0; l < cfg->depth; ++l)
+            hipLaunchKernelGGL(pack_mfma16_kernel, dim3((unsigned)((per / 8 + 255) / 256)), dim3(256), 0, 0,
+                               reinterpret_cast<const bf16_t *>(e->pw("blocks." + std::to_string(l) + ".attn.qkv.weight")),
+                               e->wqkvp.as<bf16_t>() + per * l, 3 * H, H);
+    }
     e->force_generic_attn = getenv("LL_GENERIC_ATTN") != nullptr;
+    if (const char *v = getenv("LL_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v);
     if (const char *ev = getenv("LL_STAGE_MOD")) g_stage_mod = atoi(ev) ? 1 : 0;      // A/B switch for bench runs
     CRH(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
     CRH(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
@@ -508,7 +556,7 @@ int ll_dit_destroy(void *handle) {
     DevBuf *bufs[] = {&e->wop, &e->wxT, &e->wycat, &e->yw0, &e->yb0, &e->tables, &e->n_nodes, &e->X, &e->E, &e->x32,
                       &e->xa, &e->qkv, &e->attn_o, &e->ybuf, &e->h1, &e->ho, &e->outF, &e->ct_in, &e->ct_h, &e->ct,
                       &e->zy, &e->cy, &e->txt_op, &e->ctxt, &e->ynan, &e->tnan, &e->c32, &e->ca, &e->m1, &e->modtab,
-                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur};
+                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wqkvp};
     for (DevBuf *b : bufs) b->release();
     if (e->own) (void)hipStreamDestroy(e->own);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -788,6 +836,10 @@ int ll_dit_set_option(void *handle, int option, int value) {
         case LL_DIT_OPT_GENERIC_ATTN:
             if (e->force_generic_attn != (value != 0)) drop_graph(e);      // captured steps hold the other kernel
             e->force_generic_attn = value != 0;
+            break;
+        case LL_DIT_OPT_FUSED_QKV_ATTN:
+            if (e->fuse_qkv_attn != value) drop_graph(e);
+            e->fuse_qkv_attn = value < 0 ? -1 : (value ? 1 : 0);
             break;
         default: LL_CHECK(false, "ll_dit_set_option: unknown option %d", option);
     }

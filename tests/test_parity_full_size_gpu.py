@@ -63,10 +63,13 @@ def _upper(n_nodes, N):
     return um
 
 
-@pytest.mark.parametrize("overlap", [0, 1], ids=["panel", "overlap"])
+@pytest.mark.parametrize("mode", ["panel", "overlap", "fused"])
 @pytest.mark.parametrize("B", [1, 8])
-def test_graphdit_ref_default_bf16_vs_oracle(full_dit, B, overlap):
+def test_graphdit_ref_default_bf16_vs_oracle(full_dit, B, mode):
+    """panel / overlap: seven launches per block with the synchronous or the overlap-mode GEMMs; fused: q|k|v projection +
+    attention as one launch per (sequence, head) (qkv_attn_kernel; the engine's default from batch 4 up)."""
     m, spec, sd, do = full_dit
+    overlap = int(mode == "overlap")
     N, T, seed = spec.N, spec.T, 11
     props, text, _ = synth.make_dit_inputs(B, seed=seed, max_node=N)
     n_nodes = torch.tensor([32] if B == 1 else [32, 32, 17, 5, 32, 1, 29, 32])
@@ -88,6 +91,7 @@ def test_graphdit_ref_default_bf16_vs_oracle(full_dit, B, overlap):
 
     m.begin(props, text, -200.0, n_nodes)
     m.set_option("overlap", overlap)
+    m.set_option("fused_qkv_attn", int(mode == "fused"))
     try:
         m.init_state(*qT)
         X, E = m.get_state()
@@ -122,10 +126,11 @@ def test_graphdit_ref_default_bf16_vs_oracle(full_dit, B, overlap):
         assert torch.equal(X[~mask], Xi[~mask])          # padding stays padding
     finally:
         m.set_option("overlap", 0)
+        m.set_option("fused_qkv_attn", -1)
     rec = dict(hidden_drift_rel={str(k): v for k, v in drift.items()}, logit_err_rel=lerr, tv_atoms=tvx, tv_bonds=tve,
                race_agree_atoms=agree_x, race_agree_bonds=agree_e, n_atoms=n_x, n_pairs=n_e)
-    print(f"B={B} overlap={overlap}: {rec}")
-    _report(f"graphdit_B{B}_{'overlap' if overlap else 'panel'}", rec)
+    print(f"B={B} {mode}: {rec}")
+    _report(f"graphdit_B{B}_{mode}", rec)
     # bf16 operands / f32 accumulation over 28 post-norm blocks; measured values in profiles/r2_parity_full_size.json
     assert drift[0] <= 1e-2 and max(drift.values()) <= 5e-2, drift
     assert lerr <= 5e-2, lerr
@@ -169,6 +174,47 @@ def test_attn_mfma_vs_generic_on_identical_qkv(N, H, heads):
     lerr = float((out[0][1] - out[1][1]).abs().max()) / max(1.0, float(out[1][1].abs().max()))
     print(f"attn mfma vs generic N={N} hd={H // heads}: hidden {err:.3e} logits {lerr:.3e}")
     _report(f"attn_mfma_vs_generic_N{N}_hd{H // heads}", dict(hidden_rel=err, logits_rel=lerr))
+    assert err <= 1e-2 and lerr <= 1e-2, (err, lerr)
+
+
+# ------------------------------------------------------------------------------------------ fused q|k|v + attention launch
+@pytest.mark.parametrize("N,H,heads,B", [(32, 256, 4, 3), (50, 256, 4, 4), (50, 1024, 16, 2), (20, 512, 8, 5)],
+                         ids=["NP32_H256", "NP64_H256", "NP64_H1024_two_chunks", "N20_H512"])
+def test_fused_qkv_attention_vs_separate_launches(N, H, heads, B):
+    """qkv_attn_kernel (packed q|k|v weight straight into MFMA operands, token panel in LDS, attention on the LDS image of
+    q|k|v) against the q|k|v GEMM + attn_mfma_kernel pair on the same state: both round q|k|v to bf16 before the per-head
+    LayerNorm, so they differ only by the accumulation order of the projection."""
+    from llamole_amd.graph_decoder import GraphDiT
+    seed = 7
+    cfg = synth.make_dit_config(H, 2, heads, 10, 2.0)
+    meta = synth.make_data_meta(N, seed)
+    sd = synth.make_dit_weights(cfg, N, seed)
+    d = tempfile.mkdtemp()
+    synth.write_dit_dir(d, cfg, meta, sd)
+    m = GraphDiT(os.path.join(d, "config.yaml"), os.path.join(d, "data.meta.json"), torch.bfloat16)
+    m.init_model(d)
+    m.to("cuda")
+    for p in m.parameters():
+        p.data = p.data.to(torch.bfloat16)
+    props, text, _ = synth.make_dit_inputs(B, seed, N)
+    n_nodes = torch.tensor(([N, 1, max(2, N // 2 + 1), N - 1, N])[:B])
+    m.begin(props, text, -200.0, n_nodes)
+    m.init_state(*synth.exp_noise(seed, m.T, B, N))
+    s = m.T - 1
+    out = {}
+    for fused in (0, 1):
+        m.set_option("fused_qkv_attn", fused)
+        lx, le, h = m.denoise_logits(s, tap_layer=2)
+        out[fused] = (h.cpu(), lx.cpu(), le.cpu())
+    m.set_option("fused_qkv_attn", -1)
+    valid = (torch.arange(N).unsqueeze(0) < n_nodes.unsqueeze(1)).unsqueeze(0).unsqueeze(-1)      # [1,B,N,1]
+    assert torch.isfinite(out[1][0]).all() and torch.isfinite(out[1][1]).all() and torch.isfinite(out[1][2]).all()
+    scale = float((out[0][0] * valid).abs().max())
+    err = float(((out[0][0] - out[1][0]) * valid).abs().max()) / scale
+    lerr = max(float((out[0][1] - out[1][1]).abs().max()), float((out[0][2] - out[1][2]).abs().max()))
+    lerr /= max(1.0, float(out[0][1].abs().max()), float(out[0][2].abs().max()))
+    print(f"fused qkv+attn vs separate N={N} H={H}: hidden {err:.3e} logits {lerr:.3e}")
+    _report(f"fused_qkv_attn_N{N}_H{H}", dict(hidden_rel=err, logits_rel=lerr))
     assert err <= 1e-2 and lerr <= 1e-2, (err, lerr)
 
 
