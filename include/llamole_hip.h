@@ -56,6 +56,11 @@ int ll_linear_splitk_bf16(const void *A, int lda, const void *W, int ldw, const 
 /* Tuning utility: average ms of `iters` launches of pipelined-GEMM configuration `cfg` (-1 = the production
  * dispatch) on an [M,K]x[N,K]^T bf16 problem, cycling over `nweights` weight matrices (HBM-resident stream). */
 int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f32, int iters, int nweights, float *ms);
+/* ll_linear_xw : test hook of the packed-weight panel GEMM (gemm_xw_kernel: 64 token rows in LDS, the weight streamed from a copy in
+ * MFMA operand order; K / splits = 512 | 1024, N % 128 == 0): packs the row-major W [N, K] into a temporary and runs it; splits > 1
+ * writes raw f32 slabs of M x ldc.  ll_gemm_bench(cfg = -2) times the same kernel. */
+int ll_linear_xw(const void *A, int lda, const void *W, const float *bias, void *C, int ldc, int M, int N, int K, int splits,
+                 int epi, int out_f32, void *stream);
 /* ll_linear_cfg : ll_linear (bf16 operands) through ONE kernel configuration of the tuning table (gemm.hip: g_pipe_cfgs), so that
  * every variant can be checked against a reference.  splits > 1: C receives `splits` raw f32 slabs (stride M * ldc). */
 int ll_linear_cfg(int cfg, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, int M, int N, int K,
@@ -154,8 +159,10 @@ int ll_dit_set_overlap(void *handle, int on);
  * bf16 engine instead of the MFMA one (parity hook: the two are compared on identical q|k|v by the tests);
  * LL_DIT_OPT_FUSED_QKV_ATTN = the block's q|k|v projection and attention as ONE launch per (sequence, head) (bf16, head
  * dimension 64, hidden 256 | 512 | a multiple of 1024): -1 = when the launch has 64..512 such workgroups, i.e. batch 2..16 at 16 heads
- * (default), 0 = never, 1 = whenever eligible. */
-enum { LL_DIT_OPT_OVERLAP = 0, LL_DIT_OPT_GENERIC_ATTN = 1, LL_DIT_OPT_FUSED_QKV_ATTN = 2 };
+ * (default), 0 = never, 1 = whenever eligible;
+ * LL_DIT_OPT_XW_GEMM = the block's fc1 GEMM on the packed-weight panel kernel (gemm_xw_kernel; bf16, hidden 512 | 1024): 1 = whenever
+ * eligible, 0 / -1 (default) = never -- a measured variant that did not beat the LDS-DMA ring inside the step; kept for the tests. */
+enum { LL_DIT_OPT_OVERLAP = 0, LL_DIT_OPT_GENERIC_ATTN = 1, LL_DIT_OPT_FUSED_QKV_ATTN = 2, LL_DIT_OPT_XW_GEMM = 3 };
 int ll_dit_set_option(void *handle, int option, int value);
 int ll_dit_last_run_ms(void *handle, float *ms, int *steps);
 /* Tuning: ln_mod_res with one wave per 256-column chunk of a row (default) or one wave per row; bit-identical results; returns the

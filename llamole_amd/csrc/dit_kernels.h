@@ -457,7 +457,7 @@ template <int NP, int HD> static constexpr size_t attn_mfma_lds_bytes() {
 // the sequence's token panel, then the attention above on the result -- the q|k|v activation never leaves the CU and the block
 // loses one dependent launch (layers.py:56-87; there is no full-row LayerNorm between the projection and the attention, q/k
 // LayerNorm is per head).  Twelve waves; wave w owns output columns [16 w, 16 w + 16) of the head's q|k|v for all token rows.
-// The weight comes from a copy the engine packs once at creation in MFMA A-operand order (pack_mfma16_kernel: the 16 rows x
+// The weight comes from a copy the engine packs once at creation in MFMA A-operand order (gemm.hip pack_mfma16: the 16 rows x
 // 32 k block of a fragment is 1 KB contiguous, lane l's 16 bytes at offset 16 l), so a wave's stream is one contiguous 32 KB
 // run read with full-line wave instructions STRAIGHT INTO the operand registers -- no LDS round trip, and not the 16-lines-per-
 // instruction pattern fragment loads from the row-major weight have (38 GB/s per CU, tools/ingest_probe.hip); two blocks of
@@ -470,18 +470,6 @@ template <int NP, int HD> static constexpr size_t attn_mfma_lds_bytes() {
 __device__ __forceinline__ void qa_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-__global__ __launch_bounds__(256) void pack_mfma16_kernel(const bf16_t *__restrict__ W, bf16_t *__restrict__ out, int Nout, int K) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;        // one 16-byte piece per thread
-    const int kts = K / 32;
-    if (g >= (int64_t)(Nout / 16) * kts * 64) return;
-    const int l = (int)(g & 63);
-    const int64_t blk = g >> 6;
-    const int kt = (int)(blk % kts);
-    const int64_t nt = blk / kts;
-    *reinterpret_cast<uint4 *>(out + g * 8) =
-        *reinterpret_cast<const uint4 *>(W + (nt * 16 + (l & 15)) * (int64_t)K + kt * 32 + (l >> 4) * 8);
-}
-
 template <int NP, int KC> struct QkvAttnGeom {                     // KC = K chunk of the token panel staged in LDS (elements; 256 | 512 | 1024)
     static constexpr int HD = 64, WAVES = 12;
     static constexpr int KPB = KC >= 512 ? 8 : 4;                     // k-steps (of 32) per prefetch block; two blocks in flight per lane

@@ -139,7 +139,11 @@ struct DitEngine {
     DevBuf wop;                  // operand-dtype copy of the arena (bf16 mode)
     DevBuf wxT;                  // x_embedder weight transposed [F][H] f32
     DevBuf wycat;                // [H][10H] operand dtype
-    DevBuf wqkvp;                // [depth][3H x H] q|k|v weights in MFMA A-operand order (pack_mfma16_kernel), bf16 mode
+    DevBuf wqkvp;                // [depth][3H x H] q|k|v weights in MFMA A-operand order (pack_mfma16), bf16 mode
+    DevBuf wfc1p, wfc2p;         // [depth][Hm x H], [depth][H x Hm]: the MLP weights packed the same way (gemm_xw_kernel)
+    int xw_gemm = -1;            // fc1 (and with xw_fc2, fc2) on gemm_xw_kernel: 1 = whenever eligible; -1 / 0 = never (it lost)
+    int splits_x = 1;            // split-K of fc2 on gemm_xw_kernel (K slices of 512 | 1024)
+    int xw_fc2 = 0;              // fc2 too (env LL_XW_FC2; measured slower than the ring with two slabs)
     DevBuf yw0, yb0;             // packed [10][H] f32
     DevBuf tables;               // x_marg16 e_marg8 u_xe80 u_ex80 betas[T+1] alphas_bar[T+1]
     // per-batch
@@ -261,6 +265,18 @@ static bool qkv_attn_wanted(const DitEngine *e) {
     const int wgs = 2 * e->B * e->cfg.heads;
     return e->fuse_qkv_attn == 1 || (wgs >= g_fuse_qkv_min_wgs && wgs <= g_fuse_qkv_max_wgs);
 }
+// MLP of the block on the packed-weight panel GEMM (gemm.hip gemm_xw_kernel): fc1 with K = H in one slice, fc2 split over K
+static int xw_slice(int K) { return K % 1024 == 0 ? 1024 : 512; }
+static bool xw_eligible(const DitEngine *e) {
+    const int H = e->cfg.hidden, Hm = e->cfg.mlp_hidden;
+    if (e->cfg.dtype != LL_BF16 || (H != 512 && H != 1024) || Hm % 512 != 0) return false;
+    const int sp = Hm / xw_slice(Hm);
+    return (sp == 1 || sp == 2 || sp == 4 || sp == 8) && Hm % 128 == 0 && H % 128 == 0;
+}
+static bool xw_wanted(const DitEngine *e) {
+    if (e->wfc1p.p == nullptr || e->xw_gemm == 0) return false;
+    return e->xw_gemm == 1;      // never by default: measured equal or slower than the LDS-DMA ring inside the step
+}
 static void launch_qkv_attn(DitEngine *e, int layer, hipStream_t st) {
     const std::string p = "blocks." + std::to_string(layer) + ".attn.";
     const int N = e->cfg.max_nodes;
@@ -340,7 +356,7 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
     if (hidden_tap && tap_layer == 0)
         LL_HIP(hipMemcpyAsync(hidden_tap, e->x32.p, (size_t)M2 * H * 4, hipMemcpyDeviceToDevice, st));
     const int64_t slab = (int64_t)e->M2p * H;
-    const bool fused_qkv = qkv_attn_wanted(e);
+    const bool fused_qkv = qkv_attn_wanted(e), xw = xw_wanted(e);
     for (int l = 0; l < c.depth; ++l) {
         const std::string p = "blocks." + std::to_string(l) + ".";
         if (fused_qkv) {
@@ -357,13 +373,23 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
         if (bf) launch_lnmod<bf16_t>(e, l, 0, e->splits_h, e->pfs(p + "attn.proj.bias"), st);
         else launch_lnmod<float>(e, l, 0, e->splits_h, e->pfs(p + "attn.proj.bias"), st);
         LL_LAUNCH_CHECK();
-        LL_TRY(linear_launch(dt, e->xa.p, H, e->pw(p + "mlp.fc1.weight"), H, e->pfs(p + "mlp.fc1.bias"), e->h1.p, Hm, M2, Hm, H, 1, 0, st));
-        if (e->splits_m > 1)
-            LL_TRY(linear_splitk_launch(dt, e->h1.p, Hm, e->pw(p + "mlp.fc2.weight"), Hm, e->ybuf.as<float>(), H, slab, M2, H, Hm, e->splits_m, st));
-        else
-            LL_TRY(linear_launch(dt, e->h1.p, Hm, e->pw(p + "mlp.fc2.weight"), Hm, nullptr, e->ybuf.p, H, M2, H, Hm, 0, 1, st));
-        if (bf) launch_lnmod<bf16_t>(e, l, 1, e->splits_m, e->pfs(p + "mlp.fc2.bias"), st);
-        else launch_lnmod<float>(e, l, 1, e->splits_m, e->pfs(p + "mlp.fc2.bias"), st);
+        int nslab_m = e->splits_m;
+        if (xw) {
+            LL_TRY(linear_xw_launch(e->xa.p, H, e->wfc1p.as<bf16_t>() + (size_t)l * Hm * H, e->pfs(p + "mlp.fc1.bias"), e->h1.p, Hm, M2, Hm, H, 1, 0, 1, 0, st));
+        } else {
+            LL_TRY(linear_launch(dt, e->xa.p, H, e->pw(p + "mlp.fc1.weight"), H, e->pfs(p + "mlp.fc1.bias"), e->h1.p, Hm, M2, Hm, H, 1, 0, st));
+        }
+        if (xw && e->xw_fc2) {
+            LL_TRY(linear_xw_launch(e->h1.p, Hm, e->wfc2p.as<bf16_t>() + (size_t)l * Hm * H, nullptr, e->ybuf.p, H, M2, H, Hm, e->splits_x, slab, 0, 1, st));
+            nslab_m = e->splits_x;
+        } else {
+            if (e->splits_m > 1)
+                LL_TRY(linear_splitk_launch(dt, e->h1.p, Hm, e->pw(p + "mlp.fc2.weight"), Hm, e->ybuf.as<float>(), H, slab, M2, H, Hm, e->splits_m, st));
+            else
+                LL_TRY(linear_launch(dt, e->h1.p, Hm, e->pw(p + "mlp.fc2.weight"), Hm, nullptr, e->ybuf.p, H, M2, H, Hm, 0, 1, st));
+        }
+        if (bf) launch_lnmod<bf16_t>(e, l, 1, nslab_m, e->pfs(p + "mlp.fc2.bias"), st);
+        else launch_lnmod<float>(e, l, 1, nslab_m, e->pfs(p + "mlp.fc2.bias"), st);
         LL_LAUNCH_CHECK();
         if (hidden_tap && tap_layer == l + 1)
             LL_HIP(hipMemcpyAsync(hidden_tap, e->x32.p, (size_t)M2 * H * 4, hipMemcpyDeviceToDevice, st));
@@ -529,10 +555,23 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
         const size_t per = (size_t)3 * H * H;
         CR(e->wqkvp.ensure(per * cfg->depth * 2));
         for (int l = 0; l < cfg->depth; ++l)
-            hipLaunchKernelGGL(pack_mfma16_kernel, dim3((unsigned)((per / 8 + 255) / 256)), dim3(256), 0, 0,
-                               reinterpret_cast<const bf16_t *>(e->pw("blocks." + std::to_string(l) + ".attn.qkv.weight")),
-                               e->wqkvp.as<bf16_t>() + per * l, 3 * H, H);
+            CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw("blocks." + std::to_string(l) + ".attn.qkv.weight")),
+                           e->wqkvp.as<bf16_t>() + per * l, 3 * H, H, 0));
     }
+    if (xw_eligible(e)) {
+        const int Hm = cfg->mlp_hidden;
+        const size_t per = (size_t)Hm * H;
+        CR(e->wfc1p.ensure(per * cfg->depth * 2));
+        CR(e->wfc2p.ensure(per * cfg->depth * 2));
+        for (int l = 0; l < cfg->depth; ++l) {
+            const std::string p = "blocks." + std::to_string(l) + ".mlp.";
+            CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw(p + "fc1.weight")), e->wfc1p.as<bf16_t>() + per * l, Hm, H, 0));
+            CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw(p + "fc2.weight")), e->wfc2p.as<bf16_t>() + per * l, H, Hm, 0));
+        }
+        e->splits_x = Hm / xw_slice(Hm);
+    }
+    if (const char *v = getenv("LL_XW_GEMM")) e->xw_gemm = atoi(v);
+    if (const char *v = getenv("LL_XW_FC2")) e->xw_fc2 = atoi(v) ? 1 : 0;
     e->force_generic_attn = getenv("LL_GENERIC_ATTN") != nullptr;
     if (const char *v = getenv("LL_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v);
     if (const char *ev = getenv("LL_STAGE_MOD")) g_stage_mod = atoi(ev) ? 1 : 0;      // A/B switch for bench runs
@@ -556,7 +595,7 @@ int ll_dit_destroy(void *handle) {
     DevBuf *bufs[] = {&e->wop, &e->wxT, &e->wycat, &e->yw0, &e->yb0, &e->tables, &e->n_nodes, &e->X, &e->E, &e->x32,
                       &e->xa, &e->qkv, &e->attn_o, &e->ybuf, &e->h1, &e->ho, &e->outF, &e->ct_in, &e->ct_h, &e->ct,
                       &e->zy, &e->cy, &e->txt_op, &e->ctxt, &e->ynan, &e->tnan, &e->c32, &e->ca, &e->m1, &e->modtab,
-                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wqkvp};
+                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wqkvp, &e->wfc1p, &e->wfc2p};
     for (DevBuf *b : bufs) b->release();
     if (e->own) (void)hipStreamDestroy(e->own);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -581,7 +620,7 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
     e->M2p = round_up(e->M2, 128);
     e->splits_h = pick_splits(e->M2, H, H);
     e->splits_m = pick_splits(e->M2, H, Hm);
-    const int smax = e->splits_h > e->splits_m ? e->splits_h : e->splits_m;
+    const int smax = std::max(std::max(e->splits_h, e->splits_m), e->wfc1p.p ? e->splits_x : 1);
     const int Mc = (T + 1) * (B + 1), Mcp = round_up(Mc, 128);   // rows 0..T-1: reverse steps (t = s+1); row T: t = 0 (training)
     const int Tp = round_up(T + 1, 128), Bp = round_up(B, 128);
     const size_t M2p = e->M2p;
@@ -840,6 +879,10 @@ int ll_dit_set_option(void *handle, int option, int value) {
         case LL_DIT_OPT_FUSED_QKV_ATTN:
             if (e->fuse_qkv_attn != value) drop_graph(e);
             e->fuse_qkv_attn = value < 0 ? -1 : (value ? 1 : 0);
+            break;
+        case LL_DIT_OPT_XW_GEMM:
+            if (e->xw_gemm != value) drop_graph(e);
+            e->xw_gemm = value < 0 ? -1 : (value ? 1 : 0);
             break;
         default: LL_CHECK(false, "ll_dit_set_option: unknown option %d", option);
     }

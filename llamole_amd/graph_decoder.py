@@ -384,7 +384,7 @@ class GraphDiT(nn.Module):
         _lib.check(lib.ll_dit_set_overlap(self._handle, int(overlap)), "ll_dit_set_overlap")
         _lib.check(lib.ll_dit_run(self._handle, C.c_uint64(seed), int(use_graph), _lib.current_stream_ptr()), "ll_dit_run")
 
-    ENGINE_OPTIONS = {"overlap": 0, "generic_attn": 1, "fused_qkv_attn": 2}
+    ENGINE_OPTIONS = {"overlap": 0, "generic_attn": 1, "fused_qkv_attn": 2, "xw_gemm": 3}
 
     def set_option(self, name: str, value: int):
         """Per-engine switch (include/llamole_hip.h: ll_dit_set_option), effective for every later denoiser call."""
