@@ -261,9 +261,11 @@ static bool qkv_attn_eligible(const DitEngine *e) {
 static bool qkv_attn_wanted(const DitEngine *e) {
     if (e->wqkvp.p == nullptr || e->force_generic_attn || e->fuse_qkv_attn == 0) return false;
     // measured: a workgroup takes its 448 KB in at the per-CU rate whatever the batch, so below ~64 workgroups the
-    // two launches with 192+ workgroups each are faster, and beyond two rounds of workgroups per CU the 128-row tiles of the GEMM are
+    // two launches with 192+ workgroups each are faster, and beyond two rounds of workgroups per CU what the 128-row tiles of the GEMM save
+    // exceeds what they save.  Next to another stream's kernels (overlap mode: the trajectory under the LLM decode) every launch costs
+    // the other stream a dispatch slot as well: fused from batch 1 (e2e 369.4 -> 366.9 ms per molecule).
     const int wgs = 2 * e->B * e->cfg.heads;
-    return e->fuse_qkv_attn == 1 || (wgs >= g_fuse_qkv_min_wgs && wgs <= g_fuse_qkv_max_wgs);
+    return e->fuse_qkv_attn == 1 || e->overlap || (wgs >= g_fuse_qkv_min_wgs && wgs <= g_fuse_qkv_max_wgs);
 }
 // MLP of the block on the packed-weight panel GEMM (gemm.hip gemm_xw_kernel): fc1 with K = H in one slice, fc2 split over K
 static int xw_slice(int K) { return K % 1024 == 0 ? 1024 : 512; }

@@ -63,14 +63,15 @@ def _upper(n_nodes, N):
     return um
 
 
-@pytest.mark.parametrize("mode", ["panel", "overlap", "fused", "fused_xw"])
+@pytest.mark.parametrize("mode", ["panel", "overlap", "fused", "overlap_default", "fused_xw"])
 @pytest.mark.parametrize("B", [1, 8])
 def test_graphdit_ref_default_bf16_vs_oracle(full_dit, B, mode):
     """panel / overlap: seven launches per block with the synchronous or the overlap-mode GEMMs; fused: q|k|v projection +
-    attention as one launch per (sequence, head) (qkv_attn_kernel; the engine's default for batch 2..16); fused_xw: that plus the MLP
+    attention as one launch per (sequence, head) (qkv_attn_kernel; the engine's default for batch 2..16); overlap_default: the
+    overlap mode as the pipelined bench runs it (ring GEMMs + the fused launch at any batch); fused_xw: fused plus the MLP
     fc1 GEMM on the packed-weight panel kernel (gemm_xw_kernel; opt-in, it did not beat the ring)."""
     m, spec, sd, do = full_dit
-    overlap = int(mode == "overlap")
+    overlap = int(mode.startswith("overlap"))
     N, T, seed = spec.N, spec.T, 11
     props, text, _ = synth.make_dit_inputs(B, seed=seed, max_node=N)
     n_nodes = torch.tensor([32] if B == 1 else [32, 32, 17, 5, 32, 1, 29, 32])
@@ -92,7 +93,7 @@ def test_graphdit_ref_default_bf16_vs_oracle(full_dit, B, mode):
 
     m.begin(props, text, -200.0, n_nodes)
     m.set_option("overlap", overlap)
-    m.set_option("fused_qkv_attn", int(mode.startswith("fused")))
+    m.set_option("fused_qkv_attn", -1 if mode == "overlap_default" else int(mode.startswith("fused")))
     m.set_option("xw_gemm", int(mode == "fused_xw"))
     try:
         m.init_state(*qT)
