@@ -172,7 +172,8 @@ int ll_set_lnmod_multiwave(int on);
  * AdaLN epilogue launches of the step address them without waiting for the step index in device memory (one memory round trip per
  * launch instead of two); 0 = every launch walks the hoisted table.  Bit-identical.  Takes effect at the next graph capture. */
 int ll_set_stage_mod(int on);
-/* Tuning: waves per (sequence, head) of the MFMA graph attention (1 | 2; default 2; bit-identical); returns the previous value. */
+/* Tuning: waves per (sequence, head) of the MFMA graph attention (1 | 2 | 4; default 4 = LayerNorm / transpose rows on four waves at
+ * head dimension 64, two elsewhere; bit-identical); returns the previous value. */
 int ll_set_attn_waves(int waves);
 
 /* ------------------------------------------------------------------ GIN encoder / predictor

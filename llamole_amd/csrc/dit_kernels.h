@@ -336,11 +336,13 @@ __device__ __forceinline__ void attn_mfma_body(LD ld, bf16_t *__restrict__ ohead
     constexpr int QK_ELEMS = NP * QLD;
     constexpr int P_ELEMS = NP * PLD;
     constexpr int R0 = QK_ELEMS > P_ELEMS ? QK_ELEMS : P_ELEMS;   // region 0: Q, later P
-    static_assert(WPB == 1 || WPB == 2, "one or two waves per (sequence, head)");
+    static_assert(WPB == 1 || WPB == 2 || WPB == 4, "one, two or four waves per (sequence, head)");
+    constexpr int CW = WPB > NP / 16 ? NP / 16 : WPB;             // waves of the QK^T / softmax / PV part: at most one per query tile
+    constexpr bool PSEP = CW != WPB;                              // then P gets its own region (no barrier inside the core)
     bf16_t *Qs = reinterpret_cast<bf16_t *>(smraw_attn);
     bf16_t *Ks = Qs + R0;
     bf16_t *Vt = Ks + QK_ELEMS;
-    bf16_t *Ps = Qs;
+    bf16_t *Ps = PSEP ? Vt + HD * PLD : Qs;
 
     // ---- load + LayerNorm (q, k), transpose (v).  HD/8 lanes cover one row with 16-B loads (full 128-B
     //      lines for hd = 64); every global load of the wave (3 tensors x PASSES + LN parameters) is issued
@@ -349,7 +351,7 @@ __device__ __forceinline__ void attn_mfma_body(LD ld, bf16_t *__restrict__ ohead
         constexpr int LPR8 = HD / 8;            // lanes per row
         constexpr int RPP = 64 / LPR8;          // rows per pass
         constexpr int PASSES = NP / RPP / WPB;   // passes of THIS wave: wave w takes rows [w * NP / WPB, (w + 1) * NP / WPB)
-        static_assert(PASSES >= 1, "too few rows for two waves");
+        static_assert(PASSES >= 1, "too few rows for this many waves");
         const int sub = lane % LPR8, rin = lane / LPR8 + wave * (NP / WPB);
         const int d0 = sub * 8;
         uint4 rq[PASSES], rk[PASSES], rv[PASSES];
@@ -422,7 +424,8 @@ __device__ __forceinline__ void attn_mfma_body(LD ld, bf16_t *__restrict__ ohead
     } else {
         __syncthreads();
     }
-    attn_core<NP, HD, WPB, false>(Qs, Ks, Vt, Ps, ohead, N, nv, H, wave, lane);
+    if (PSEP && wave >= CW) return;
+    attn_core<NP, HD, CW, PSEP>(Qs, Ks, Vt, Ps, ohead, N, nv, H, wave, lane);
 }
 
 template <int NP, int HD, int WPB>
@@ -445,9 +448,10 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_kernel(const bf16_t *__res
         o + (int64_t)seq * N * H + head * HD, qw, qb, kw, kb, N, nv, H, smraw_attn, wave, lane);
 }
 
-template <int NP, int HD> static constexpr size_t attn_mfma_lds_bytes() {
+template <int NP, int HD, int WPB = 2> static constexpr size_t attn_mfma_lds_bytes() {
     constexpr int QLD = HD + 8, PLD = NP + 8;
     constexpr int QK = NP * QLD, P = NP * PLD;
+    if (WPB > NP / 16) return (size_t)((QK > P ? QK : P) + QK + HD * PLD + P) * 2;
     constexpr int R0 = QK > P ? QK : P;
     return (size_t)(R0 + QK + HD * PLD) * 2;
 }

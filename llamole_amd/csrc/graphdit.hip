@@ -219,20 +219,20 @@ template <typename T> static void launch_embed(DitEngine *e, hipStream_t st) {
                        e->E.as<int8_t>(), e->wxT.as<float>(), e->pf("x_embedder.1.weight"), e->pf("x_embedder.1.bias"),
                        e->x32.as<float>(), e->xa.as<T>(), e->step_ptr(), e->B, e->cfg.max_nodes, e->cfg.hidden);
 }
-static int g_attn_waves = 2;     // waves per (sequence, head) of attn_mfma_kernel (1 | 2)
+static int g_attn_waves = 4;     // waves per (sequence, head) of attn_mfma_kernel (1 | 2 | 4; four only at head dimension 64)
 static int g_fuse_qkv_min_wgs = 64, g_fuse_qkv_max_wgs = 512;   // fuse_qkv_attn = -1: fuse when the launch has this many (sequence, head) workgroups
 
 template <int NP, int HD>
 static void launch_attn_mfma_t(DitEngine *e, const std::string &p, hipStream_t st) {
-    const size_t lds = attn_mfma_lds_bytes<NP, HD>();
-    if (g_attn_waves == 2)
-        hipLaunchKernelGGL((attn_mfma_kernel<NP, HD, 2>), dim3(e->cfg.heads, 2 * e->B), dim3(128), lds, st, e->qkv.as<bf16_t>(),
-                           e->attn_o.as<bf16_t>(), e->pfs(p + "q_norm.weight"), e->pfs(p + "q_norm.bias"), e->pfs(p + "k_norm.weight"),
-                           e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, e->cfg.max_nodes, e->cfg.hidden, e->cfg.heads);
-    else
-        hipLaunchKernelGGL((attn_mfma_kernel<NP, HD, 1>), dim3(e->cfg.heads, 2 * e->B), dim3(64), lds, st, e->qkv.as<bf16_t>(),
-                           e->attn_o.as<bf16_t>(), e->pfs(p + "q_norm.weight"), e->pfs(p + "q_norm.bias"), e->pfs(p + "k_norm.weight"),
-                           e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, e->cfg.max_nodes, e->cfg.hidden, e->cfg.heads);
+#define LL_ATTN(W)                                                                                                     \
+    hipLaunchKernelGGL((attn_mfma_kernel<NP, HD, W>), dim3(e->cfg.heads, 2 * e->B), dim3(64 * W), (attn_mfma_lds_bytes<NP, HD, W>()), st, \
+                       e->qkv.as<bf16_t>(), e->attn_o.as<bf16_t>(), e->pfs(p + "q_norm.weight"), e->pfs(p + "q_norm.bias"),   \
+                       e->pfs(p + "k_norm.weight"), e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, e->cfg.max_nodes,  \
+                       e->cfg.hidden, e->cfg.heads)
+    if (g_attn_waves == 4 && HD == 64) LL_ATTN((HD == 64 ? 4 : 2));      // LayerNorm / transpose rows on four waves (eight rows each per pass)
+    else if (g_attn_waves >= 2) LL_ATTN(2);
+    else LL_ATTN(1);
+#undef LL_ATTN
 }
 template <typename T> static void launch_attn(DitEngine *e, int layer, hipStream_t st) {
     const int N = e->cfg.max_nodes, hd = e->hd;
@@ -553,6 +553,8 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
     CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<32, 64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<64, 64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     if (qkv_attn_eligible(e)) {
         const size_t per = (size_t)3 * H * H;
         CR(e->wqkvp.ensure(per * cfg->depth * 2));
@@ -893,7 +895,7 @@ int ll_dit_set_option(void *handle, int option, int value) {
 
 int ll_set_attn_waves(int waves) {
     const int old = g_attn_waves;
-    if (waves == 1 || waves == 2) g_attn_waves = waves;
+    if (waves == 1 || waves == 2 || waves == 4) g_attn_waves = waves;
     return old;
 }
 
