@@ -67,6 +67,10 @@ int ll_linear_cfg(int cfg, const void *A, int lda, const void *W, int ldw, const
                   int splits, int epi, int out_f32, void *stream);
 /* Tuning: waves per workgroup of the <= 64-row panel GEMM (4 | 8; default 8); returns the previous value. */
 int ll_set_m64_waves(int waves);
+/* Tuning: 1 (default) = the <= 64-row panel GEMM reads the GraphDiT engine's MFMA-operand-order weight copies where they exist (one
+ * full-line wave instruction per fragment), 0 = the row-major weights; same products and order, bit-identical; returns the previous value.
+ * Takes effect at the next graph capture. */
+int ll_set_m64_packed(int on);
 /* ll_set_gemm_krot : the LDS-DMA GEMM sweeps its k-tiles starting at ((m_tile * (krot & 255) + n_tile * (krot >> 8 or 1)) mod
  * n_ktiles) instead of 0, so that workgroups sharing an operand tile do not miss L2 on the same lines at the same time.  0 = off.
  * Changes the f32 summation order per tile (deterministic).  Returns the previous setting. */

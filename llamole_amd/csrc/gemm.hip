@@ -13,6 +13,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 
 #include "common.h"
 
@@ -782,7 +784,7 @@ static int launch_pipeu(const bf16_t *A, int lda, const bf16_t *W, int ldw, void
 //   * each of the 4 waves takes a quarter of the chunk: its weight fragments go straight from global memory into the MFMA
 //     B-operand registers (16 B per lane = 8 consecutive k of one weight row: exactly the operand layout), NS loads;
 //   * 4 NS MFMAs per wave, the four partial 64x16 tiles are summed through LDS in wave order (deterministic).
-template <int NS, int WAVES, typename OutT>
+template <int NS, int WAVES, typename OutT, bool PACKED>
 __global__ __launch_bounds__(WAVES * 64) void gemm_m64_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ W,
                                                               int ldw, OutT *__restrict__ C, int ldc,
                                                               const float *__restrict__ bias, int M, int N, int64_t slab_stride,
@@ -815,10 +817,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_m64_kernel(const bf16_t *__re
     }
     int wrow = n0 + (lane & 15);
     wrow = wrow < N ? wrow : N - 1;
-    const bf16_t *wp = W + (int64_t)wrow * ldw + kbeg + wave * (KS * 32) + (lane >> 4) * 8;
+    // PACKED: W is the pack_mfma16 copy (ldw = K): the fragment block (row tile, k-step) is 1 KB contiguous, lane l at 16 l -- one
+    // full-line wave instruction per k-step instead of sixteen 64-byte row pieces
+    const bf16_t *wp = PACKED ? W + (((int64_t)blockIdx.x * (ldw / 32) + kbeg / 32 + wave * KS) * 64 + lane) * 8
+                              : W + (int64_t)wrow * ldw + kbeg + wave * (KS * 32) + (lane >> 4) * 8;
     u4 wreg[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) wreg[s] = *reinterpret_cast<const u4 *>(wp + s * 32);
+    for (int s = 0; s < KS; ++s) wreg[s] = *reinterpret_cast<const u4 *>(wp + s * (PACKED ? 512 : 32));
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int c = tid + i * THREADS;
@@ -872,6 +877,21 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_m64_kernel(const bf16_t *__re
 
 static int g_m64_waves = 8;     // waves per workgroup of the panel kernel (4 | 8)
 
+// packed (pack_mfma16) copies of row-major weights, registered by their owner (the GraphDiT engine): the panel kernel reads those
+static std::mutex g_packed_mu;
+static std::unordered_map<const void *, const void *> g_packed;
+static int g_use_packed = 1;
+void register_packed_weight(const void *w, const void *packed) {
+    std::lock_guard<std::mutex> lk(g_packed_mu);
+    if (packed) g_packed[w] = packed; else g_packed.erase(w);
+}
+static const bf16_t *packed_copy_of(const bf16_t *w) {
+    if (!g_use_packed) return nullptr;
+    std::lock_guard<std::mutex> lk(g_packed_mu);
+    auto it = g_packed.find(w);
+    return it == g_packed.end() ? nullptr : (const bf16_t *)it->second;
+}
+
 template <int NS, int WAVES>
 static int launch_m64_w(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M, int N,
                         int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
@@ -879,15 +899,25 @@ static int launch_m64_w(const bf16_t *A, int lda, const bf16_t *W, int ldw, void
     static_assert(lds <= 160 * 1024, "panel + partial tiles must fit the 160 KB of a CU");
     static bool attr_set = false;
     if (!attr_set) {
-        LL_HIP(hipFuncSetAttribute((const void *)gemm_m64_kernel<NS, WAVES, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        LL_HIP(hipFuncSetAttribute((const void *)gemm_m64_kernel<NS, WAVES, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m64_kernel<NS, WAVES, float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m64_kernel<NS, WAVES, bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m64_kernel<NS, WAVES, float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m64_kernel<NS, WAVES, bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid(cdiv(N, 16), 1, splits);
+    const bf16_t *Wp = (N % 16 == 0 && ldw % 32 == 0) ? packed_copy_of(W) : nullptr;
+    if (Wp) {
+        if (out_f32)
+            hipLaunchKernelGGL((gemm_m64_kernel<NS, WAVES, float, true>), grid, dim3(WAVES * 64), lds, s, A, lda, Wp, ldw, (float *)C, ldc, bias, M, N, slab_stride, epi);
+        else
+            hipLaunchKernelGGL((gemm_m64_kernel<NS, WAVES, bf16_t, true>), grid, dim3(WAVES * 64), lds, s, A, lda, Wp, ldw, (bf16_t *)C, ldc, bias, M, N, slab_stride, epi);
+        return LL_OK;
+    }
     if (out_f32)
-        hipLaunchKernelGGL((gemm_m64_kernel<NS, WAVES, float>), grid, dim3(WAVES * 64), lds, s, A, lda, W, ldw, (float *)C, ldc, bias, M, N, slab_stride, epi);
+        hipLaunchKernelGGL((gemm_m64_kernel<NS, WAVES, float, false>), grid, dim3(WAVES * 64), lds, s, A, lda, W, ldw, (float *)C, ldc, bias, M, N, slab_stride, epi);
     else
-        hipLaunchKernelGGL((gemm_m64_kernel<NS, WAVES, bf16_t>), grid, dim3(WAVES * 64), lds, s, A, lda, W, ldw, (bf16_t *)C, ldc, bias, M, N, slab_stride, epi);
+        hipLaunchKernelGGL((gemm_m64_kernel<NS, WAVES, bf16_t, false>), grid, dim3(WAVES * 64), lds, s, A, lda, W, ldw, (bf16_t *)C, ldc, bias, M, N, slab_stride, epi);
     return LL_OK;
 }
 
@@ -1870,6 +1900,12 @@ extern "C" int ll_linear_splitk_bf16(const void *A, int lda, const void *W, int 
 extern "C" int ll_set_gemm_krot(int krot) {
     const int old = ll::g_gemm_krot;
     ll::g_gemm_krot = krot < 0 ? 0 : krot;
+    return old;
+}
+
+extern "C" int ll_set_m64_packed(int on) {
+    const int old = ll::g_use_packed;
+    ll::g_use_packed = on ? 1 : 0;
     return old;
 }
 

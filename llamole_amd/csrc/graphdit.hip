@@ -140,7 +140,9 @@ struct DitEngine {
     DevBuf wxT;                  // x_embedder weight transposed [F][H] f32
     DevBuf wycat;                // [H][10H] operand dtype
     DevBuf wqkvp;                // [depth][3H x H] q|k|v weights in MFMA A-operand order (pack_mfma16), bf16 mode
-    DevBuf wfc1p, wfc2p;         // [depth][Hm x H], [depth][H x Hm]: the MLP weights packed the same way (gemm_xw_kernel)
+    DevBuf wfc1p, wfc2p;         // [depth][Hm x H], [depth][H x Hm]: the MLP weights packed the same way (gemm_m64_kernel, gemm_xw_kernel)
+    DevBuf wprojp;               // [depth][H x H]
+    std::vector<const void *> packed_keys;   // row-major weights registered with register_packed_weight
     int xw_gemm = -1;            // fc1 (and with xw_fc2, fc2) on gemm_xw_kernel: 1 = whenever eligible; -1 / 0 = never (it lost)
     int splits_x = 1;            // split-K of fc2 on gemm_xw_kernel (K slices of 512 | 1024)
     int xw_fc2 = 0;              // fc2 too (env LL_XW_FC2; measured slower than the ring with two slabs)
@@ -276,7 +278,7 @@ static bool xw_eligible(const DitEngine *e) {
     return (sp == 1 || sp == 2 || sp == 4 || sp == 8) && Hm % 128 == 0 && H % 128 == 0;
 }
 static bool xw_wanted(const DitEngine *e) {
-    if (e->wfc1p.p == nullptr || e->xw_gemm == 0) return false;
+    if (e->wfc1p.p == nullptr || !xw_eligible(e) || e->xw_gemm == 0) return false;
     return e->xw_gemm == 1;      // never by default: measured equal or slower than the LDS-DMA ring inside the step
 }
 static void launch_qkv_attn(DitEngine *e, int layer, hipStream_t st) {
@@ -562,17 +564,28 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
             CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw("blocks." + std::to_string(l) + ".attn.qkv.weight")),
                            e->wqkvp.as<bf16_t>() + per * l, 3 * H, H, 0));
     }
-    if (xw_eligible(e)) {
+    if (cfg->dtype == LL_BF16 && H % 32 == 0 && cfg->mlp_hidden % 32 == 0) {
+        // MFMA-operand-order copies of the MLP and proj weights: the batch-1 panel GEMM (gemm_m64_kernel) reads fragments from them
         const int Hm = cfg->mlp_hidden;
-        const size_t per = (size_t)Hm * H;
+        const size_t per = (size_t)Hm * H, perh = (size_t)H * H;
         CR(e->wfc1p.ensure(per * cfg->depth * 2));
         CR(e->wfc2p.ensure(per * cfg->depth * 2));
+        CR(e->wprojp.ensure(perh * cfg->depth * 2));
+        auto reg = [&](const std::string &name, const bf16_t *packed) {
+            register_packed_weight(e->pw(name), packed);
+            e->packed_keys.push_back(e->pw(name));
+        };
         for (int l = 0; l < cfg->depth; ++l) {
-            const std::string p = "blocks." + std::to_string(l) + ".mlp.";
-            CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw(p + "fc1.weight")), e->wfc1p.as<bf16_t>() + per * l, Hm, H, 0));
-            CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw(p + "fc2.weight")), e->wfc2p.as<bf16_t>() + per * l, H, Hm, 0));
+            const std::string p = "blocks." + std::to_string(l) + ".";
+            CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw(p + "mlp.fc1.weight")), e->wfc1p.as<bf16_t>() + per * l, Hm, H, 0));
+            CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw(p + "mlp.fc2.weight")), e->wfc2p.as<bf16_t>() + per * l, H, Hm, 0));
+            CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw(p + "attn.proj.weight")), e->wprojp.as<bf16_t>() + perh * l, H, H, 0));
+            reg(p + "mlp.fc1.weight", e->wfc1p.as<bf16_t>() + per * l);
+            reg(p + "mlp.fc2.weight", e->wfc2p.as<bf16_t>() + per * l);
+            reg(p + "attn.proj.weight", e->wprojp.as<bf16_t>() + perh * l);
+            if (e->wqkvp.p) reg(p + "attn.qkv.weight", e->wqkvp.as<bf16_t>() + (size_t)3 * H * H * l);
         }
-        e->splits_x = Hm / xw_slice(Hm);
+        if (xw_eligible(e)) e->splits_x = Hm / xw_slice(Hm);
     }
     if (const char *v = getenv("LL_XW_GEMM")) e->xw_gemm = atoi(v);
     if (const char *v = getenv("LL_XW_FC2")) e->xw_fc2 = atoi(v) ? 1 : 0;
@@ -599,7 +612,8 @@ int ll_dit_destroy(void *handle) {
     DevBuf *bufs[] = {&e->wop, &e->wxT, &e->wycat, &e->yw0, &e->yb0, &e->tables, &e->n_nodes, &e->X, &e->E, &e->x32,
                       &e->xa, &e->qkv, &e->attn_o, &e->ybuf, &e->h1, &e->ho, &e->outF, &e->ct_in, &e->ct_h, &e->ct,
                       &e->zy, &e->cy, &e->txt_op, &e->ctxt, &e->ynan, &e->tnan, &e->c32, &e->ca, &e->m1, &e->modtab,
-                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wqkvp, &e->wfc1p, &e->wfc2p};
+                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wqkvp, &e->wfc1p, &e->wfc2p, &e->wprojp};
+    for (const void *k : e->packed_keys) register_packed_weight(k, nullptr);
     for (DevBuf *b : bufs) b->release();
     if (e->own) (void)hipStreamDestroy(e->own);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -624,7 +638,7 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
     e->M2p = round_up(e->M2, 128);
     e->splits_h = pick_splits(e->M2, H, H);
     e->splits_m = pick_splits(e->M2, H, Hm);
-    const int smax = std::max(std::max(e->splits_h, e->splits_m), e->wfc1p.p ? e->splits_x : 1);
+    const int smax = std::max(std::max(e->splits_h, e->splits_m), e->splits_x);
     const int Mc = (T + 1) * (B + 1), Mcp = round_up(Mc, 128);   // rows 0..T-1: reverse steps (t = s+1); row T: t = 0 (training)
     const int Tp = round_up(T + 1, 128), Bp = round_up(B, 128);
     const size_t M2p = e->M2p;

@@ -263,6 +263,29 @@ def test_packed_weight_mlp_vs_ring_gemms(N, H, heads, B):
     assert err <= 1e-2 and lerr <= 1e-2, (err, lerr)
 
 
+def test_panel_gemm_on_packed_weights_is_bit_identical(full_dit):
+    """Batch 1 at the benchmarked size: gemm_m64_kernel reading its weight fragments from the engine's MFMA-operand-order copies
+    (default) against the same kernel on the row-major weights -- same products in the same order."""
+    from llamole_amd import _lib
+    m, spec, _, _ = full_dit
+    lib = _lib.load()
+    B, N, seed = 1, spec.N, 3
+    props, text, _ = synth.make_dit_inputs(B, seed=seed, max_node=N)
+    m.begin(props, text, -200.0, torch.tensor([N - 3]))
+    m.init_state(*synth.exp_noise(seed, spec.T, B, N))
+    out = {}
+    old = lib.ll_set_m64_packed(1)
+    try:
+        for packed in (1, 0):
+            lib.ll_set_m64_packed(packed)
+            lx, le, h = m.denoise_logits(spec.T - 1, tap_layer=28)
+            out[packed] = (lx.clone(), le.clone(), h.clone())
+    finally:
+        lib.ll_set_m64_packed(old)
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------ GIN predictor at configs[2] size
 def test_gin_predictor_full_size_vs_oracle():
     import sys
