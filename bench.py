@@ -206,7 +206,7 @@ def time_dominant_kernel(args, device):
     else:
         H, Hm = args.hidden, int(args.hidden * 4)
         M, N, K = 2 * args.batch * args.nodes, Hm, H
-        kern = ("gemm_m64_kernel<8,8>" if M <= 64 else "gemm_bf16_pipeu_kernel<64,64,4,4,4>" if M < 1024 else
+        kern = ("gemm_m64_kernel<8,8,bf16,packed>" if M <= 64 else "gemm_bf16_pipeu_kernel<64,64,4,4,4>" if M < 1024 else
                 "gemm_bf16_pipe_kernel<128,128,4,4,3>" if M < 2048 else "gemm_bf16_pipe_kernel<256,128,4,4,3>")
         name = f"{kern}, GraphDiT block-MLP fc1 [{M}x{K}]x[{N}x{K}]^T bf16"
         key = f"fc1_m{M}"
