@@ -295,6 +295,7 @@ static void launch_qkv_attn(DitEngine *e, int layer, hipStream_t st) {
     else { if (kc == 512) LL_QA(64, 512); else LL_QA(64, 256); }
 #undef LL_QA
 }
+static int g_steps_per_graph = 5;      // reverse steps captured per hipGraph of ll_dit_run (when it divides T; env LL_STEPS_PER_GRAPH)
 static int g_stage_mod = 1;           // stage the step's modulation rows at a fixed address (ll_set_stage_mod)
 static int g_lnmod_multiwave = 1;     // one wave per 256-column chunk of a row (ln_mod_res_mw_kernel) instead of one wave per row
 
@@ -591,6 +592,7 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
     if (const char *v = getenv("LL_XW_FC2")) e->xw_fc2 = atoi(v) ? 1 : 0;
     e->force_generic_attn = getenv("LL_GENERIC_ATTN") != nullptr;
     if (const char *v = getenv("LL_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v);
+    if (const char *v = getenv("LL_STEPS_PER_GRAPH")) g_steps_per_graph = std::max(1, atoi(v));
     if (const char *ev = getenv("LL_STAGE_MOD")) g_stage_mod = atoi(ev) ? 1 : 0;      // A/B switch for bench runs
     CRH(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
     CRH(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
@@ -842,15 +844,20 @@ int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream) {
         hipGraph_t &graph = e->overlap ? e->graph_ov : e->graph;
         hipGraphExec_t &gexec = e->overlap ? e->gexec_ov : e->gexec;
         int &graph_B = e->overlap ? e->graph_ov_B : e->graph_B;
+        // consecutive graph launches leave ~9 us between them on the device; five steps per graph share one such gap
+        const int spg = g_steps_per_graph > 1 && T % g_steps_per_graph == 0 ? g_steps_per_graph : 1;
         if (!gexec || graph_B != e->B) {
             if (gexec) (void)hipGraphExecDestroy(gexec);
             if (graph) (void)hipGraphDestroy(graph);
             gexec = nullptr;
             graph = nullptr;
             LL_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            int rc = denoise_body(e, st, nullptr, -1);
-            if (rc == LL_OK) rc = posterior_launch(e, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, st);
-            if (rc == LL_OK) hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, st, e->step_ptr());
+            int rc = LL_OK;
+            for (int g = 0; g < spg && rc == LL_OK; ++g) {        // `spg` reverse steps per captured graph: the step index lives in device memory
+                rc = denoise_body(e, st, nullptr, -1);
+                if (rc == LL_OK) rc = posterior_launch(e, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, st);
+                if (rc == LL_OK) hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, st, e->step_ptr());
+            }
             hipError_t ce = hipStreamEndCapture(st, &graph);
             if (rc != LL_OK) return rc;
             LL_HIP(ce);
@@ -858,7 +865,7 @@ int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream) {
             graph_B = e->B;
         }
         LL_HIP(hipEventRecord(e->ev_t0, st));
-        for (int i = 0; i < T; ++i) LL_HIP(hipGraphLaunch(gexec, st));
+        for (int i = 0; i < T / spg; ++i) LL_HIP(hipGraphLaunch(gexec, st));
         LL_HIP(hipEventRecord(e->ev_t1, st));
     } else {
         LL_HIP(hipEventRecord(e->ev_t0, st));
