@@ -182,8 +182,9 @@ def test_attn_mfma_vs_generic_on_identical_qkv(N, H, heads):
 
 
 # ------------------------------------------------------------------------------------------ fused q|k|v + attention launch
-@pytest.mark.parametrize("N,H,heads,B", [(32, 256, 4, 3), (50, 256, 4, 4), (50, 1024, 16, 2), (20, 512, 8, 5)],
-                         ids=["NP32_H256", "NP64_H256", "NP64_H1024_two_chunks", "N20_H512"])
+@pytest.mark.parametrize("N,H,heads,B", [(32, 256, 4, 3), (50, 256, 4, 4), (50, 1024, 16, 2), (20, 512, 8, 5), (32, 1024, 16, 3),
+                                         (24, 2048, 32, 1)],
+                         ids=["NP32_H256", "NP64_H256", "NP64_H1024_two_chunks", "N20_H512", "NP32_H1024", "H2048_two_chunks"])
 def test_fused_qkv_attention_vs_separate_launches(N, H, heads, B):
     """qkv_attn_kernel (packed q|k|v weight straight into MFMA operands, token panel in LDS, attention on the LDS image of
     q|k|v) against the q|k|v GEMM + attn_mfma_kernel pair on the same state: both round q|k|v to bf16 before the per-head
