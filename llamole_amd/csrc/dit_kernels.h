@@ -216,9 +216,12 @@ typedef __attribute__((ext_vector_type(4))) float af32x4;
 // Ps is its own region; otherwise it aliases Qs and the WPB waves synchronise before P is written.  exp and the reciprocal of
 // the row sum are the hardware v_exp_f32 / v_rcp_f32 (1 ulp; P is rounded to bf16 right after).  PV is evaluated as
 // O^T = V^T P^T, so a lane ends up with four consecutive head columns of one query row: 8-byte stores.
-template <int NP, int HD, int WPB, bool PSEP>
+struct AttnNoWait { __device__ __forceinline__ void operator()() const {} };
+// `before_pv()` runs between the softmax and the first read of Vt (qkv_attn_kernel waits there for the waves that write V^T).
+template <int NP, int HD, int WPB, bool PSEP, typename BeforePV = AttnNoWait>
 __device__ __forceinline__ void attn_core(const bf16_t *Qs, const bf16_t *Ks, const bf16_t *Vt, bf16_t *Ps,
-                                          bf16_t *__restrict__ ohead, int N, int nv, int H, int wave, int lane) {
+                                          bf16_t *__restrict__ ohead, int N, int nv, int H, int wave, int lane,
+                                          BeforePV before_pv = BeforePV()) {
     constexpr int QLD = HD + 8, PLD = NP + 8;
     constexpr int MT = NP / 16, KS = HD / 32;
     constexpr int MQ = MT / WPB;
@@ -285,6 +288,7 @@ __device__ __forceinline__ void attn_core(const bf16_t *Qs, const bf16_t *Ks, co
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     LL_QA_STAMP(6);
+    before_pv();
 
     // ---- O^T = V^T P^T (this wave's rows of P only: written and read by the same wave)
     constexpr int NT2 = HD / 16, KS2 = NP / 32;
@@ -474,12 +478,38 @@ template <int NP, int HD, int WPB = 2> static constexpr size_t attn_mfma_lds_byt
 __device__ __forceinline__ void qa_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// Hand-off between the waves of a workgroup without a workgroup barrier: a wave publishes its LDS writes and bumps a counter;
+// a consumer spins (s_sleep) until the counter reaches the number of producers.  All waves of the workgroup are resident.
+__device__ __forceinline__ void qa_signal(int *ctr, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // this wave's LDS writes have landed
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void qa_wait(int *ctr, int target) {
+    while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(ctr)) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+// x[l] + x[l ^ 16] + x[l ^ 32] + x[l ^ 48] in every lane: v_permlane16_swap exchanges the odd 16-lane rows of its first operand
+// with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the second; with both
+// operands holding x the two results add up to the pairwise sums.  (Inline asm: with identical inputs the builtin's second result
+// came back as the first on ROCm 7.2.)
+__device__ __forceinline__ float qa_sum_lane_groups(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a += b;
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 template <int NP, int KC> struct QkvAttnGeom {                     // KC = K chunk of the token panel staged in LDS (elements; 256 | 512 | 1024)
     static constexpr int HD = 64, WAVES = 12;
     static constexpr int KPB = KC >= 512 ? 8 : 4;                     // k-steps (of 32) per prefetch block; two blocks in flight per lane
     static constexpr int XBYTES = NP * 2 * KC;
-    // after the K loop the panel's LDS holds the Q | K | V^T | P images (< 37 KB) and the LayerNorm partials at 40 KB (<= 16 KB)
-    static constexpr size_t lds_bytes() { return XBYTES > 57344 ? XBYTES : 57344; }
+    // behind the panel: the Q | K | V^T | P images (< 37 KB), the LayerNorm partials at + 37 KB (<= 4 KB) and the hand-off counters
+    // at + 41 KB -- their own region, because the waves that finish their K loop first write them while the others still read the panel
+    static constexpr int TAIL_BYTES = 42 * 1024;
+    static constexpr size_t lds_bytes() { return (size_t)XBYTES + TAIL_BYTES; }
 };
 
 template <int NP, int KC>
@@ -497,6 +527,8 @@ __global__ __launch_bounds__(768) void qkv_attn_kernel(const bf16_t *__restrict_
     const int head = blockIdx.x % heads, seq = blockIdx.x / heads;    // consecutive workgroups = the heads of one sequence:
     const int nv = n_nodes[seq % B];                                  // head h of every sequence lands on XCD h % 8 (one L2 copy of its weights)
     unsigned char *xs = sm_qa;                                        // [NP][XPITCH] token panel chunk, 16-byte piece p of row r at p ^ (r & 15)
+    int *ctr = reinterpret_cast<int *>(sm_qa + G::XBYTES + 41 * 1024);    // hand-off counters of the tail (zeroed before the first barrier)
+    if (tid < 8) ctr[tid] = 0;
     LL_QA_STAMP(0);
     const int part = wid >> 2, sub = wid & 3;                         // q | k | v, 16-column group inside the head
     const int fr = lane & 15, fq = lane >> 4;
@@ -607,33 +639,33 @@ __global__ __launch_bounds__(768) void qkv_attn_kernel(const bf16_t *__restrict_
     //      every token, acc[mt][j] = C[column wid * 16 + fq * 4 + j][token mt * 16 + fr].  The row statistics over the head's
     //      64 columns (four waves x four lane groups) go through LDS as (sum, sum of squares) partials of the bf16-rounded
     //      projection -- the value the separate GEMM would have stored; var = E[x^2] - mean^2 in f32 (64 terms).
+    //      No workgroup barrier from here on: data arrives in issue order, so the q waves (0-3) leave the K loop ~700 cycles before
+    //      the k waves and ~1 400 before the v waves; each group hands its part over through an LDS counter as soon as it has it.
     constexpr int QLD = HD + 8, PLD = NP + 8;
-    bf16_t *Qs = reinterpret_cast<bf16_t *>(sm_qa);
+    unsigned char *tail = sm_qa + G::XBYTES;
+    bf16_t *Qs = reinterpret_cast<bf16_t *>(tail);
     bf16_t *Ks = Qs + NP * QLD;
     bf16_t *Vt = Ks + NP * QLD;
     bf16_t *Ps = Vt + HD * PLD;
-    float2 *st = reinterpret_cast<float2 *>(sm_qa + 40960);           // [2][4][NP] (sum, sum of squares) per 16-column group; images above: < 37 KB
-    float v[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[mt][j] = bf16_to_f32(f32_to_bf16(acc[mt][j]));
-    qa_barrier();                                                     // panel reads done: its LDS is reused from here on
+    float2 *st = reinterpret_cast<float2 *>(tail + 37 * 1024);        // [2][4][NP] (sum, sum of squares) per 16-column group
     if (part < 2) {
-        const int x16 = (lane ^ 16) << 2, x32 = (lane ^ 32) << 2;     // the four lane groups of a token: lanes fr, fr + 16, fr + 32, fr + 48
+        float v[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[mt][j] = bf16_to_f32(f32_to_bf16(acc[mt][j]));
+        // the four lane groups of a token are lanes fr, fr + 16, fr + 32, fr + 48: summed with the gfx950 row / half swaps on the
+        // VALU (the LDS crossbar is busy with the fragment reads of the waves that are still in their K loop)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             float s1 = (v[mt][0] + v[mt][1]) + (v[mt][2] + v[mt][3]);
             float s2 = (v[mt][0] * v[mt][0] + v[mt][1] * v[mt][1]) + (v[mt][2] * v[mt][2] + v[mt][3] * v[mt][3]);
-            s1 += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(x16, __builtin_bit_cast(int, s1)));
-            s2 += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(x16, __builtin_bit_cast(int, s2)));
-            s1 += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(x32, __builtin_bit_cast(int, s1)));
-            s2 += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(x32, __builtin_bit_cast(int, s2)));
+            s1 = qa_sum_lane_groups(s1);
+            s2 = qa_sum_lane_groups(s2);
             if (fq == 0) st[(part * 4 + sub) * NP + mt * 16 + fr] = make_float2(s1, s2);
         }
-    }
-    qa_barrier();
-    if (part < 2) {
+        qa_signal(ctr + part, lane);                                  // ctr[0] / ctr[1]: statistics of the q / k column groups
+        qa_wait(ctr + part, 4);
         bf16_t *dst = part == 0 ? Qs : Ks;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -649,6 +681,7 @@ __global__ __launch_bounds__(768) void qkv_attn_kernel(const bf16_t *__restrict_
             *reinterpret_cast<uint2 *>(dst + tok * QLD + sub * 16 + fq * 4) =
                 make_uint2((uint32_t)f32_to_bf16(o0) | ((uint32_t)f32_to_bf16(o1) << 16), (uint32_t)f32_to_bf16(o2) | ((uint32_t)f32_to_bf16(o3) << 16));
         }
+        qa_signal(ctr + 2 + part, lane);                              // ctr[2] / ctr[3]: Q / K image column groups written
     } else {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -657,10 +690,13 @@ __global__ __launch_bounds__(768) void qkv_attn_kernel(const bf16_t *__restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) Vt[(sub * 16 + fq * 4 + j) * PLD + tok] = live ? f32_to_bf16(acc[mt][j]) : (bf16_t)0;
         }
+        qa_signal(ctr + 4, lane);                                     // ctr[4]: V^T column groups written
     }
-    qa_barrier();
     LL_QA_STAMP(4);
-    if (wid < MT) attn_core<NP, HD, MT, true>(Qs, Ks, Vt, Ps, o + (int64_t)seq * N * H + head * HD, N, nv, H, wid, lane);
+    if (wid >= MT) return;                                            // one wave per query tile (they are q waves) runs the attention
+    qa_wait(ctr + 2, 4);
+    qa_wait(ctr + 3, 4);
+    attn_core<NP, HD, MT, true>(Qs, Ks, Vt, Ps, o + (int64_t)seq * N * H + head * HD, N, nv, H, wid, lane, [&]() { qa_wait(ctr + 4, 4); });
     LL_QA_STAMP(7);
 }
 

@@ -3,8 +3,8 @@
 //         tools/qkv_attn_probe.hip -o /tmp/qkv_attn_probe && /tmp/qkv_attn_probe [B=8]
 // Launches the production kernel (llamole_amd/csrc/dit_kernels.h, compiled with cycle stamps of wave 0) over `copies` distinct
 // weight sets back to back (more than the 256 MiB Infinity Cache holds), prints the event-timed average launch and the stamp
-// deltas: 0 start | 1 panel + first weight blocks requested, panel in LDS | 2 barrier | 3 K loop done | 4 qkv image written +
-// barriers | 5 LayerNorm(q, k), V^T in LDS | 6 QK^T + softmax | 7 PV + store.
+// deltas: 0 start | 1 panel + first weight blocks requested, panel in LDS | 2 barrier | 3 K loop done | 4 LayerNorm statistics exchanged,
+// this wave's Q column group written | 5 all of Q and K written | 6 QK^T + softmax | 7 V^T written by its waves, PV + store.
 #include "../llamole_amd/csrc/dit_kernels.h"
 #include <vector>
 namespace ll { void set_error(const char *, ...) {} }
@@ -57,7 +57,7 @@ int main(int argc, char **argv) {
     double d[8] = {0};
     for (int w = 0; w < nw; ++w)
         for (int i = 1; i < 8; ++i) d[i] += (double)(st[w * 8 + i] - st[w * 8 + i - 1]);
-    printf("cycles (wave 0, mean over %d workgroups): stage %.0f | barrier %.0f | k loop %.0f | ln + images %.0f | (core entry) %.0f | qk+softmax %.0f | pv+store %.0f | total %.0f\n",
+    printf("cycles (wave 0, mean over %d workgroups): stage %.0f | barrier %.0f | k loop %.0f | ln + own image %.0f | wait for Q, K images %.0f | qk+softmax %.0f | wait for V^T + pv + store %.0f | total %.0f\n",
            nw, d[1] / nw, d[2] / nw, d[3] / nw, d[4] / nw, d[5] / nw, d[6] / nw, d[7] / nw,
            (d[1] + d[2] + d[3] + d[4] + d[5] + d[6] + d[7]) / nw);
     std::vector<unsigned long long> ws(1024 * 12 * 4);
