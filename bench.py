@@ -257,6 +257,9 @@ def spawn_ranks(n: int) -> int:
     return rc
 
 
+GRAPH_MODE = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,7 +274,8 @@ def main():
     ap.add_argument("--T", type=int, default=50)
     ap.add_argument("--guide", type=float, default=2.0)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="GraphDiT trajectory: launch every kernel (no hipGraph replay)")
+    ap.add_argument("--graph", action="store_true", help="GraphDiT trajectory: force the hipGraph replay (default: the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--llm", default="qwen2-7b")
     ap.add_argument("--new-tokens", type=int, default=128)
@@ -298,6 +302,8 @@ def main():
                     help="strong scaling: one step = this many prompts over ALL ranks (BASELINE configs[3]: 64 prompts, 8 per GPU at "
                          "8 GPUs); every rank runs its contiguous share in batches of --batch.  Default: weak scaling, --batch per GPU")
     args = ap.parse_args()
+    global GRAPH_MODE
+    GRAPH_MODE = False if args.no_graph else (True if args.graph else None)      # None: the library's choice
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` without a launcher: this parent starts the N ranks itself, BEFORE it makes any GPU call
         # (a process that has initialised the GPU must not exec/replace itself on this pool; device_count() does not initialise)
@@ -362,7 +368,7 @@ def main():
 
         def step_fn(i):
             mols, _ = m.generate_graphs(props, text, -200.0, n_nodes=n_nodes, seed=1000 * rank + i,
-                                        use_graph=not args.no_graph)
+                                        use_graph=GRAPH_MODE)
             return mols
 
     def barrier():
@@ -417,7 +423,7 @@ def main():
         # figure (denoise_step_ms, step_roofline) is one trajectory on an otherwise idle GPU, measured after the timed region
         step_ms_overlapped = step_ms
         m.generate_graphs(props, text if args.workload != "e2e" else torch.zeros(B, 768), -200.0, n_nodes=n_nodes,
-                          seed=12345, use_graph=not args.no_graph)
+                          seed=12345, use_graph=GRAPH_MODE)
         step_ms = m.last_run_ms()[0] / T
     esz = 2 if args.dtype == "bf16" else 4
     Hm = int(args.hidden * 4)
@@ -462,7 +468,7 @@ def main():
                    "prompts_per_step": world * nb * B, "gathered_molecules": gathered_n,
                    "denoiser": {"hidden": args.hidden, "depth": args.depth, "heads": args.heads, "max_nodes": N,
                                 "T": T, "guide_scale": args.guide},
-                   "hip_graph": not args.no_graph, **e2e_info},
+                   "dit_launch": ("launches" if args.no_graph else "graph" if args.graph else "auto (launches alone, graph replay when overlapped with the LLM)"), **e2e_info},
         "denoise_steps_per_s": world * 1e3 / step_ms,
         "denoise_step_ms": step_ms,
         "denoise_step_ms_overlapped_with_llm": step_ms_overlapped,

@@ -17,6 +17,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <unordered_map>
 #include <vector>
 
 #include "dit_kernels.h"
@@ -173,17 +174,45 @@ struct DitEngine {
     bool force_generic_attn = false;
     int fuse_qkv_attn = -1;          // q|k|v GEMM + attention in one launch: -1 = by workgroup count, 0 = never, 1 = whenever eligible
 
-    const float *pf(const char *name) const {
-        for (auto &p : layout)
-            if (p.name == name) return w32 + p.offset;
-        return nullptr;
+    std::unordered_map<std::string, size_t> index;      // parameter name -> layout entry (filled by index_params)
+    void index_params() {
+        index.clear();
+        for (size_t i = 0; i < layout.size(); ++i) index.emplace(layout[i].name, i);
     }
+    const float *pfs(const std::string &name) const {
+        auto it = index.find(name);
+        return it == index.end() ? nullptr : w32 + layout[it->second].offset;
+    }
+    const float *pf(const char *name) const { return pfs(std::string(name)); }
     const void *pw(const std::string &name) const {  // operand-dtype weight
-        for (auto &p : layout)
-            if (p.name == name) return cfg.dtype == LL_BF16 ? (const void *)(wop.as<bf16_t>() + p.offset) : (const void *)(w32 + p.offset);
-        return nullptr;
+        auto it = index.find(name);
+        if (it == index.end()) return nullptr;
+        const auto &p = layout[it->second];
+        return cfg.dtype == LL_BF16 ? (const void *)(wop.as<bf16_t>() + p.offset) : (const void *)(w32 + p.offset);
     }
-    const float *pfs(const std::string &name) const { return pf(name.c_str()); }
+    // the block's parameters the per-step loop needs, resolved once (the loop launches ~200 kernels per millisecond: no string work there)
+    struct BlockW {
+        const void *qkv, *proj, *fc1, *fc2;
+        const float *proj_b, *fc1_b, *fc2_b, *qn_w, *qn_b, *kn_w, *kn_b;
+    };
+    std::vector<BlockW> bw;
+    const void *w_out1 = nullptr, *w_out2 = nullptr;
+    const float *b_out1 = nullptr, *b_out2 = nullptr, *xe_w = nullptr, *xe_b = nullptr;
+    void cache_block_params() {
+        bw.resize(cfg.depth);
+        for (int l = 0; l < cfg.depth; ++l) {
+            const std::string p = "blocks." + std::to_string(l) + ".";
+            BlockW &b = bw[l];
+            b.qkv = pw(p + "attn.qkv.weight"); b.proj = pw(p + "attn.proj.weight");
+            b.fc1 = pw(p + "mlp.fc1.weight"); b.fc2 = pw(p + "mlp.fc2.weight");
+            b.proj_b = pfs(p + "attn.proj.bias"); b.fc1_b = pfs(p + "mlp.fc1.bias"); b.fc2_b = pfs(p + "mlp.fc2.bias");
+            b.qn_w = pfs(p + "attn.q_norm.weight"); b.qn_b = pfs(p + "attn.q_norm.bias");
+            b.kn_w = pfs(p + "attn.k_norm.weight"); b.kn_b = pfs(p + "attn.k_norm.bias");
+        }
+        w_out1 = pw("output_layer.xedecoder.fc1.weight"); w_out2 = pw("output_layer.xedecoder.fc2.weight");
+        b_out1 = pf("output_layer.xedecoder.fc1.bias"); b_out2 = pf("output_layer.xedecoder.fc2.bias");
+        xe_w = pf("x_embedder.1.weight"); xe_b = pf("x_embedder.1.bias");
+    }
     int *step_ptr() const { return scal.as<int>(); }
     const int *rowvec = nullptr;   // per-graph table rows while ll_dit_denoise_rows runs, else null
     unsigned long long *seed_ptr() const { return reinterpret_cast<unsigned long long *>(scal.as<char>() + 8); }
@@ -218,18 +247,18 @@ static void drop_graph(DitEngine *e) {
 
 template <typename T> static void launch_embed(DitEngine *e, hipStream_t st) {
     hipLaunchKernelGGL((embed_kernel<T>), dim3(e->B * e->cfg.max_nodes), dim3(256), 0, st, e->X.as<int8_t>(),
-                       e->E.as<int8_t>(), e->wxT.as<float>(), e->pf("x_embedder.1.weight"), e->pf("x_embedder.1.bias"),
+                       e->E.as<int8_t>(), e->wxT.as<float>(), e->xe_w, e->xe_b,
                        e->x32.as<float>(), e->xa.as<T>(), e->step_ptr(), e->B, e->cfg.max_nodes, e->cfg.hidden);
 }
 static int g_attn_waves = 4;     // waves per (sequence, head) of attn_mfma_kernel (1 | 2 | 4; four only at head dimension 64)
 static int g_fuse_qkv_min_wgs = 64, g_fuse_qkv_max_wgs = 512;   // fuse_qkv_attn = -1: fuse when the launch has this many (sequence, head) workgroups
 
 template <int NP, int HD>
-static void launch_attn_mfma_t(DitEngine *e, const std::string &p, hipStream_t st) {
+static void launch_attn_mfma_t(DitEngine *e, const DitEngine::BlockW &w, hipStream_t st) {
 #define LL_ATTN(W)                                                                                                     \
     hipLaunchKernelGGL((attn_mfma_kernel<NP, HD, W>), dim3(e->cfg.heads, 2 * e->B), dim3(64 * W), (attn_mfma_lds_bytes<NP, HD, W>()), st, \
-                       e->qkv.as<bf16_t>(), e->attn_o.as<bf16_t>(), e->pfs(p + "q_norm.weight"), e->pfs(p + "q_norm.bias"),   \
-                       e->pfs(p + "k_norm.weight"), e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, e->cfg.max_nodes,  \
+                       e->qkv.as<bf16_t>(), e->attn_o.as<bf16_t>(), w.qn_w, w.qn_b,                                            \
+                       w.kn_w, w.kn_b, e->n_nodes.as<int>(), e->B, e->cfg.max_nodes,                                           \
                        e->cfg.hidden, e->cfg.heads)
     if (g_attn_waves == 4 && HD == 64) LL_ATTN((HD == 64 ? 4 : 2));      // LayerNorm / transpose rows on four waves (eight rows each per pass)
     else if (g_attn_waves >= 2) LL_ATTN(2);
@@ -238,19 +267,18 @@ static void launch_attn_mfma_t(DitEngine *e, const std::string &p, hipStream_t s
 }
 template <typename T> static void launch_attn(DitEngine *e, int layer, hipStream_t st) {
     const int N = e->cfg.max_nodes, hd = e->hd;
-    const std::string p = "blocks." + std::to_string(layer) + ".attn.";
+    const DitEngine::BlockW &w = e->bw[layer];
     if (sizeof(T) == 2 && (hd == 32 || hd == 64) && !e->force_generic_attn) {
         const int NP = N <= 32 ? 32 : 64;
-        if (NP == 32 && hd == 32) launch_attn_mfma_t<32, 32>(e, p, st);
-        else if (NP == 32 && hd == 64) launch_attn_mfma_t<32, 64>(e, p, st);
-        else if (NP == 64 && hd == 32) launch_attn_mfma_t<64, 32>(e, p, st);
-        else launch_attn_mfma_t<64, 64>(e, p, st);
+        if (NP == 32 && hd == 32) launch_attn_mfma_t<32, 32>(e, w, st);
+        else if (NP == 32 && hd == 64) launch_attn_mfma_t<32, 64>(e, w, st);
+        else if (NP == 64 && hd == 32) launch_attn_mfma_t<64, 32>(e, w, st);
+        else launch_attn_mfma_t<64, 64>(e, w, st);
         return;
     }
     const size_t lds = (size_t)(3 * N * (hd + 1) + N * (N + 1)) * 4;
     hipLaunchKernelGGL((attn_generic_kernel<T>), dim3(e->cfg.heads, 2 * e->B), dim3(256), lds, st, e->qkv.as<T>(),
-                       e->attn_o.as<T>(), e->pfs(p + "q_norm.weight"), e->pfs(p + "q_norm.bias"),
-                       e->pfs(p + "k_norm.weight"), e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, N,
+                       e->attn_o.as<T>(), w.qn_w, w.qn_b, w.kn_w, w.kn_b, e->n_nodes.as<int>(), e->B, N,
                        e->cfg.hidden, hd);
 }
 // q|k|v projection + attention of block `layer` as ONE launch (qkv_attn_kernel); false = not eligible, run the two launches
@@ -282,14 +310,14 @@ static bool xw_wanted(const DitEngine *e) {
     return e->xw_gemm == 1;      // never by default: measured equal or slower than the LDS-DMA ring inside the step
 }
 static void launch_qkv_attn(DitEngine *e, int layer, hipStream_t st) {
-    const std::string p = "blocks." + std::to_string(layer) + ".attn.";
+    const DitEngine::BlockW &w = e->bw[layer];
     const int N = e->cfg.max_nodes;
     const dim3 grid(2 * e->B * e->cfg.heads), blk(768);
     const int kc = std::min(e->cfg.hidden, N <= 32 ? 1024 : 512);     // K chunk of the token panel staged in LDS
 #define LL_QA(NP, KC)                                                                                                  \
     hipLaunchKernelGGL((qkv_attn_kernel<NP, KC>), grid, blk, (QkvAttnGeom<NP, KC>::lds_bytes()), st, e->xa.as<bf16_t>(),   \
-                       e->wqkvp.as<bf16_t>() + (size_t)layer * 3 * e->cfg.hidden * e->cfg.hidden, e->attn_o.as<bf16_t>(), e->pfs(p + "q_norm.weight"), \
-                       e->pfs(p + "q_norm.bias"), e->pfs(p + "k_norm.weight"), e->pfs(p + "k_norm.bias"), e->n_nodes.as<int>(), e->B, N, \
+                       e->wqkvp.as<bf16_t>() + (size_t)layer * 3 * e->cfg.hidden * e->cfg.hidden, e->attn_o.as<bf16_t>(), w.qn_w, \
+                       w.qn_b, w.kn_w, w.kn_b, e->n_nodes.as<int>(), e->B, N, \
                        e->cfg.hidden, e->cfg.heads)
     if (N <= 32) { if (kc == 1024) LL_QA(32, 1024); else if (kc == 512) LL_QA(32, 512); else LL_QA(32, 256); }
     else { if (kc == 512) LL_QA(64, 512); else LL_QA(64, 256); }
@@ -363,44 +391,44 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
     const int64_t slab = (int64_t)e->M2p * H;
     const bool fused_qkv = qkv_attn_wanted(e), xw = xw_wanted(e);
     for (int l = 0; l < c.depth; ++l) {
-        const std::string p = "blocks." + std::to_string(l) + ".";
+        const DitEngine::BlockW &w = e->bw[l];
         if (fused_qkv) {
             launch_qkv_attn(e, l, st);
         } else {
-            LL_TRY(linear_launch(dt, e->xa.p, H, e->pw(p + "attn.qkv.weight"), H, nullptr, e->qkv.p, 3 * H, M2, 3 * H, H, 0, 0, st));
+            LL_TRY(linear_launch(dt, e->xa.p, H, w.qkv, H, nullptr, e->qkv.p, 3 * H, M2, 3 * H, H, 0, 0, st));
             if (bf) launch_attn<bf16_t>(e, l, st); else launch_attn<float>(e, l, st);
         }
         LL_LAUNCH_CHECK();
         if (e->splits_h > 1)
-            LL_TRY(linear_splitk_launch(dt, e->attn_o.p, H, e->pw(p + "attn.proj.weight"), H, e->ybuf.as<float>(), H, slab, M2, H, H, e->splits_h, st));
+            LL_TRY(linear_splitk_launch(dt, e->attn_o.p, H, w.proj, H, e->ybuf.as<float>(), H, slab, M2, H, H, e->splits_h, st));
         else
-            LL_TRY(linear_launch(dt, e->attn_o.p, H, e->pw(p + "attn.proj.weight"), H, nullptr, e->ybuf.p, H, M2, H, H, 0, 1, st));
-        if (bf) launch_lnmod<bf16_t>(e, l, 0, e->splits_h, e->pfs(p + "attn.proj.bias"), st);
-        else launch_lnmod<float>(e, l, 0, e->splits_h, e->pfs(p + "attn.proj.bias"), st);
+            LL_TRY(linear_launch(dt, e->attn_o.p, H, w.proj, H, nullptr, e->ybuf.p, H, M2, H, H, 0, 1, st));
+        if (bf) launch_lnmod<bf16_t>(e, l, 0, e->splits_h, w.proj_b, st);
+        else launch_lnmod<float>(e, l, 0, e->splits_h, w.proj_b, st);
         LL_LAUNCH_CHECK();
         int nslab_m = e->splits_m;
         if (xw) {
-            LL_TRY(linear_xw_launch(e->xa.p, H, e->wfc1p.as<bf16_t>() + (size_t)l * Hm * H, e->pfs(p + "mlp.fc1.bias"), e->h1.p, Hm, M2, Hm, H, 1, 0, 1, 0, st));
+            LL_TRY(linear_xw_launch(e->xa.p, H, e->wfc1p.as<bf16_t>() + (size_t)l * Hm * H, w.fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, 1, 0, st));
         } else {
-            LL_TRY(linear_launch(dt, e->xa.p, H, e->pw(p + "mlp.fc1.weight"), H, e->pfs(p + "mlp.fc1.bias"), e->h1.p, Hm, M2, Hm, H, 1, 0, st));
+            LL_TRY(linear_launch(dt, e->xa.p, H, w.fc1, H, w.fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, st));
         }
         if (xw && e->xw_fc2) {
             LL_TRY(linear_xw_launch(e->h1.p, Hm, e->wfc2p.as<bf16_t>() + (size_t)l * Hm * H, nullptr, e->ybuf.p, H, M2, H, Hm, e->splits_x, slab, 0, 1, st));
             nslab_m = e->splits_x;
         } else {
             if (e->splits_m > 1)
-                LL_TRY(linear_splitk_launch(dt, e->h1.p, Hm, e->pw(p + "mlp.fc2.weight"), Hm, e->ybuf.as<float>(), H, slab, M2, H, Hm, e->splits_m, st));
+                LL_TRY(linear_splitk_launch(dt, e->h1.p, Hm, w.fc2, Hm, e->ybuf.as<float>(), H, slab, M2, H, Hm, e->splits_m, st));
             else
-                LL_TRY(linear_launch(dt, e->h1.p, Hm, e->pw(p + "mlp.fc2.weight"), Hm, nullptr, e->ybuf.p, H, M2, H, Hm, 0, 1, st));
+                LL_TRY(linear_launch(dt, e->h1.p, Hm, w.fc2, Hm, nullptr, e->ybuf.p, H, M2, H, Hm, 0, 1, st));
         }
-        if (bf) launch_lnmod<bf16_t>(e, l, 1, nslab_m, e->pfs(p + "mlp.fc2.bias"), st);
-        else launch_lnmod<float>(e, l, 1, nslab_m, e->pfs(p + "mlp.fc2.bias"), st);
+        if (bf) launch_lnmod<bf16_t>(e, l, 1, nslab_m, w.fc2_b, st);
+        else launch_lnmod<float>(e, l, 1, nslab_m, w.fc2_b, st);
         LL_LAUNCH_CHECK();
         if (hidden_tap && tap_layer == l + 1)
             LL_HIP(hipMemcpyAsync(hidden_tap, e->x32.p, (size_t)M2 * H * 4, hipMemcpyDeviceToDevice, st));
     }
-    LL_TRY(linear_launch(dt, e->xa.p, H, e->pw("output_layer.xedecoder.fc1.weight"), H, e->pf("output_layer.xedecoder.fc1.bias"), e->ho.p, H, M2, H, H, 1, 0, st));
-    LL_TRY(linear_launch(dt, e->ho.p, H, e->pw("output_layer.xedecoder.fc2.weight"), H, e->pf("output_layer.xedecoder.fc2.bias"), e->outF.p, e->F, M2, e->F, H, 0, 1, st));
+    LL_TRY(linear_launch(dt, e->xa.p, H, e->w_out1, H, e->b_out1, e->ho.p, H, M2, H, H, 1, 0, st));
+    LL_TRY(linear_launch(dt, e->ho.p, H, e->w_out2, H, e->b_out2, e->outF.p, e->F, M2, e->F, H, 0, 1, st));
     return LL_OK;
 }
 
@@ -484,6 +512,7 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
     DitEngine *e = new DitEngine();
     e->cfg = *cfg;
     e->layout = dit_layout(*cfg);
+    e->index_params();
     e->F = LL_XDIM + LL_EDIM * cfg->max_nodes;
     e->hd = cfg->hidden / cfg->heads;
     e->esz = cfg->dtype == LL_BF16 ? 2 : 4;
@@ -497,6 +526,7 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
         CR(e->wop.ensure((size_t)elems * 2));
         CR(convert_f32_to_bf16(d_weights_f32, e->wop.as<bf16_t>(), elems, 0));
     }
+    e->cache_block_params();          // after wop exists: pw() resolves into it
     // x_embedder weight transposed to [F][H] (gather-sum form)
     CR(e->wxT.ensure((size_t)e->F * H * 4));
     hipLaunchKernelGGL(transpose_kernel, dim3(256), dim3(256), 0, 0, e->pf("x_embedder.0.weight"), e->wxT.as<float>(), H, e->F);
@@ -840,7 +870,7 @@ int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream) {
     // workgroups need a whole CU's LDS and keep that stream's workgroups off the CU (and wait for a drained CU themselves), so the
     // panel GEMMs take the 48 KB LDS-DMA ring there: 1.36 instead of 1.17 ms per step alone, but +1.2 % molecules/s end to end
     PanelScope panel(e);      // restored on every exit path: other engines / the GIN path keep the panel kernel
-    if (use_graph) {
+    if (use_graph == LL_DIT_RUN_GRAPH || (use_graph == LL_DIT_RUN_AUTO && e->overlap)) {
         hipGraph_t &graph = e->overlap ? e->graph_ov : e->graph;
         hipGraphExec_t &gexec = e->overlap ? e->gexec_ov : e->gexec;
         int &graph_B = e->overlap ? e->graph_ov_B : e->graph_B;

@@ -75,6 +75,12 @@ class SyntheticTokenizer:
         return " ".join(str(int(i)) for i in ids)
 
 
+
+def dit_graph_mode(args):
+    """GraphDiT trajectory launch mode from the bench switches: --no-graph -> launches, --graph -> hipGraph replay, else the
+    library's choice (launches when the trajectory runs alone, the replay when it overlaps the LLM decode)."""
+    return False if getattr(args, "no_graph", False) else (True if getattr(args, "graph", False) else None)
+
 def build_llm(name: str, device, dtype=torch.bfloat16, seed: int = 0):
     import transformers
     spec = dict(LLM_CONFIGS[name])
@@ -165,7 +171,7 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
         k = len(waiting)
         del waiting[:]
         pending["h"] = graph_decoder.generate_graphs_async(g_props, g_cond.float(), -200.0, n_nodes=n_nodes.repeat(k)[: g_props.shape[0]],
-                                                           seed=1000 * rank + launch_group.count, use_graph=not args.no_graph)
+                                                           seed=1000 * rank + launch_group.count, use_graph=dit_graph_mode(args))
         launch_group.count += 1
 
     launch_group.count = 0
@@ -190,7 +196,7 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
             last.update(llm_enqueue_s=t1 - t0, new_tokens=int(analysis.shape[1]), **orch.timings)
             return prev
         mols, _ = graph_decoder.generate_graphs(props, cond.float(), -200.0, n_nodes=n_nodes, seed=1000 * rank + i,
-                                                use_graph=not args.no_graph)
+                                                use_graph=dit_graph_mode(args))
         t2 = time.perf_counter()
         dit_ms.append(graph_decoder.last_run_ms()[0])
         last.update(llm_s=t1 - t0, graphdit_s=t2 - t1, new_tokens=int(analysis.shape[1]), **orch.timings)

@@ -1,6 +1,6 @@
 // GPU box: where does qkv_attn_kernel (q|k|v projection + attention, one workgroup per (sequence, head)) spend its time?
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -mllvm -amdgpu-kernarg-preload-count=16 -DLL_QA_PROBE \
-//         tools/qkv_attn_probe.hip -o /tmp/qkv_attn_probe && /tmp/qkv_attn_probe [B=8]
+//         tools/qkv_attn_probe.hip -o /tmp/qkv_attn_probe && /tmp/qkv_attn_probe [B=8] [weight sets=64]
 // Launches the production kernel (llamole_amd/csrc/dit_kernels.h, compiled with cycle stamps of wave 0) over `copies` distinct
 // weight sets back to back (more than the 256 MiB Infinity Cache holds), prints the event-timed average launch and the stamp
 // deltas: 0 start | 1 panel + first weight blocks requested, panel in LDS | 2 barrier | 3 K loop done | 4 LayerNorm statistics exchanged,
@@ -13,7 +13,7 @@ using namespace ll;
 
 int main(int argc, char **argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 8, kpb = QkvAttnGeom<32, 1024>::KPB;
-    const int N = 32, H = 1024, heads = 16, S = 2 * B, copies = 64;
+    const int N = 32, H = 1024, heads = 16, S = 2 * B, copies = argc > 2 ? atoi(argv[2]) : 64;      // copies = 1: L2 / Infinity-Cache-hot weights
     bf16_t *xa, *W, *o;
     float *ln;
     int *nn;
@@ -50,7 +50,7 @@ int main(int argc, char **argv) {
     CK(hipDeviceSynchronize());
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("B=%d kpb=%d: %d workgroups, %.2f us per launch (cold weights, back to back)\n", B, kpb, S * heads, ms * 1000.f / (4 * copies));
+    printf("B=%d kpb=%d: %d workgroups, %.2f us per launch (%d weight sets, back to back)\n", B, kpb, S * heads, ms * 1000.f / (4 * copies), copies);
     std::vector<unsigned long long> st(4096 * 8);
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_qa_stamps), st.size() * 8));
     const int nw = std::min(S * heads, 4096);
