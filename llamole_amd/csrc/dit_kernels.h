@@ -819,23 +819,40 @@ __global__ __launch_bounds__(64 * MAXE) void ln_mod_res_mw_kernel(const float *_
         for (int z = 0; z < NS; ++z) { v.x += t[z].x; v.y += t[z].y; v.z += t[z].z; v.w += t[z].w; }
         v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
     }
-    part[0][e][lane] = v.x + v.y + v.z + v.w;
-    __syncthreads();
-    float sum = 0.f;
+    float mean, rstd;
+    if (sizeof(T) == 2) {
+        // bf16 engine: sum and sum of squares in ONE exchange (one barrier and one LDS round trip less per launch; the f32 engine keeps
+        // the two-pass form the golden-vector tests pin): var = E[y^2] - mean^2 in f32 over H terms, clamped at 0
+        part[0][e][lane] = v.x + v.y + v.z + v.w;
+        part[1][e][lane] = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        __syncthreads();
+        float sum = 0.f, sq = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXE; ++k) sum += part[0][k][lane];
-    const float mean = wave_sum(sum) / (float)H;
-    float d2 = 0.f;
-    if (ok) {
-        const float d0 = v.x - mean, d1 = v.y - mean, d2a = v.z - mean, d3 = v.w - mean;
-        d2 = d0 * d0 + d1 * d1 + d2a * d2a + d3 * d3;
+        for (int k = 0; k < MAXE; ++k) {
+            sum += part[0][k][lane];
+            sq += part[1][k][lane];
+        }
+        mean = wave_sum(sum) / (float)H;
+        rstd = rsqrtf(fmaxf(wave_sum(sq) / (float)H - mean * mean, 0.f) + 1e-5f);
+    } else {
+        part[0][e][lane] = v.x + v.y + v.z + v.w;
+        __syncthreads();
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) sum += part[0][k][lane];
+        mean = wave_sum(sum) / (float)H;
+        float d2 = 0.f;
+        if (ok) {
+            const float d0 = v.x - mean, d1 = v.y - mean, d2a = v.z - mean, d3 = v.w - mean;
+            d2 = d0 * d0 + d1 * d1 + d2a * d2a + d3 * d3;
+        }
+        part[1][e][lane] = d2;
+        __syncthreads();
+        float var = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) var += part[1][k][lane];
+        rstd = rsqrtf(wave_sum(var) / (float)H + 1e-5f);
     }
-    part[1][e][lane] = d2;
-    __syncthreads();
-    float var = 0.f;
-#pragma unroll
-    for (int k = 0; k < MAXE; ++k) var += part[1][k][lane];
-    const float rstd = rsqrtf(wave_sum(var) / (float)H + 1e-5f);
     if (ok) {
         float4 o;
         o.x = xr.x + ga.x * ((v.x - mean) * rstd * (1.f + sc.x) + sh.x);

@@ -843,13 +843,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_m64_kernel(const bf16_t *__re
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(As + (mt * 16 + fi) * ROWB + pc);
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[mt], 0, 0, 0);
+            // weights as the MFMA "row" operand: the accumulator holds C^T, i.e. a lane ends up with FOUR CONSECUTIVE OUTPUT COLUMNS of
+            // one token row (one 8- / 16-byte store instead of four 2- / 4-byte ones); same products, same order
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc[mt], 0, 0, 0);
         }
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4 *>(red + ((wave * 4 + mt) * 64 + lane) * 4) = acc[mt];
     __syncthreads();
-    // thread (mt = tid>>6, lane): C rows mt*16 + (lane>>4)*4 + r, column n0 + (lane & 15)
+    // thread (mt = tid>>6, lane): C row mt*16 + (lane & 15), columns n0 + (lane>>4)*4 + 0..3
     const int mt = tid >> 6;
     if (mt >= 4) return;
     f32x4 v = *reinterpret_cast<const f32x4 *>(red + ((0 * 4 + mt) * 64 + lane) * 4);
@@ -858,19 +860,34 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_m64_kernel(const bf16_t *__re
         const f32x4 t = *reinterpret_cast<const f32x4 *>(red + ((w * 4 + mt) * 64 + lane) * 4);
         v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
     }
-    const int col = n0 + (lane & 15);
-    if (col < N) {
-        const bool raw = gridDim.z > 1;
-        const float bv = (bias && !raw) ? bias[col] : 0.f;
-        OutT *Cz = C + (int64_t)blockIdx.z * slab_stride;
+    const int row = mt * 16 + (lane & 15), col = n0 + (lane >> 4) * 4;
+    if (row < M && col < N) {
+        const bool raw = gridDim.z > 1, full = col + 3 < N;
+        float o[4] = {v[0], v[1], v[2], v[3]};
+        if (bias && !raw) {
+            if (full) {
+                const float4 bv = *reinterpret_cast<const float4 *>(bias + col);
+                o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+            } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = mt * 16 + (lane >> 4) * 4 + r;
-            if (row < M) {
-                float o = v[r] + bv;
-                if (!raw) o = apply_epi(o, epi);
-                Cz[(int64_t)row * ldc + col] = from_f32<OutT>(o);
+                for (int j = 0; j < 4; ++j) o[j] += col + j < N ? bias[col + j] : 0.f;
             }
+        }
+        if (!raw) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = apply_epi(o[j], epi);
+        }
+        OutT *dst = C + (int64_t)blockIdx.z * slab_stride + (int64_t)row * ldc + col;
+        if (full && (ldc & 3) == 0) {
+            if (sizeof(OutT) == 4)
+                *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            else
+                *reinterpret_cast<uint2 *>(dst) = make_uint2((uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16),
+                                                            (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (col + j < N) dst[j] = from_f32<OutT>(o[j]);
         }
     }
 }
