@@ -135,7 +135,7 @@ int ll_dit_step(void *handle, int s, const float *qx, const float *qe, uint64_t 
  * measured 4-14 % faster per step than the replay when the trajectory has the GPU to itself (consecutive kernel nodes of a replayed
  * graph start ~1.8 us apart at best, consecutive queued launches ~1.3 us), but the host is busy for most of the trajectory's duration
  * (~4 us per launch); 2 = the library's choice: launches when the engine is not in overlap mode, the replay when it is (the host then
- * has the next prompt's LLM decode to feed). */
+ * has the next prompt's LLM decode to feed); the environment variable LL_DIT_RUN_MODE = graph | launches overrides that choice. */
 enum { LL_DIT_RUN_LAUNCHES = 0, LL_DIT_RUN_GRAPH = 1, LL_DIT_RUN_AUTO = 2 };
 int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream);
 

@@ -870,7 +870,14 @@ int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream) {
     // workgroups need a whole CU's LDS and keep that stream's workgroups off the CU (and wait for a drained CU themselves), so the
     // panel GEMMs take the 48 KB LDS-DMA ring there: 1.36 instead of 1.17 ms per step alone, but +1.2 % molecules/s end to end
     PanelScope panel(e);      // restored on every exit path: other engines / the GIN path keep the panel kernel
-    if (use_graph == LL_DIT_RUN_GRAPH || (use_graph == LL_DIT_RUN_AUTO && e->overlap)) {
+    if (use_graph == LL_DIT_RUN_AUTO) {      // env LL_DIT_RUN_MODE = graph | launches overrides the library's choice (e.g. a host too busy to feed launches)
+        static const int forced = [] {
+            const char *v = getenv("LL_DIT_RUN_MODE");
+            return !v ? -1 : (strcmp(v, "graph") == 0 ? LL_DIT_RUN_GRAPH : strcmp(v, "launches") == 0 ? LL_DIT_RUN_LAUNCHES : -1);
+        }();
+        use_graph = forced >= 0 ? forced : (e->overlap ? LL_DIT_RUN_GRAPH : LL_DIT_RUN_LAUNCHES);
+    }
+    if (use_graph == LL_DIT_RUN_GRAPH) {
         hipGraph_t &graph = e->overlap ? e->graph_ov : e->graph;
         hipGraphExec_t &gexec = e->overlap ? e->gexec_ov : e->gexec;
         int &graph_B = e->overlap ? e->graph_ov_B : e->graph_B;
