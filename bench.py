@@ -468,6 +468,7 @@ def main():
                    "prompts_per_step": world * nb * B, "gathered_molecules": gathered_n,
                    "denoiser": {"hidden": args.hidden, "depth": args.depth, "heads": args.heads, "max_nodes": N,
                                 "T": T, "guide_scale": args.guide},
+                   "dit_mlp_kernels": (m.mlp_choice() if hasattr(m, "mlp_choice") and args.dtype == "bf16" else None),
                    "dit_launch": ("launches" if args.no_graph else "graph" if args.graph else "auto (launches alone, graph replay when overlapped with the LLM)"), **e2e_info},
         "denoise_steps_per_s": world * 1e3 / step_ms,
         "denoise_step_ms": step_ms,

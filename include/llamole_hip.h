@@ -170,11 +170,15 @@ int ll_dit_set_overlap(void *handle, int on);
  * LL_DIT_OPT_FUSED_QKV_ATTN = the block's q|k|v projection and attention as ONE launch per (sequence, head) (bf16, head
  * dimension 64, hidden 256 | 512 | a multiple of 1024): -1 = when the launch has 64..512 such workgroups, i.e. batch 2..16 at 16 heads
  * (default), 0 = never, 1 = whenever eligible;
- * LL_DIT_OPT_XW_GEMM = the block's fc1 GEMM on the packed-weight panel kernel (gemm_xw_kernel; bf16, hidden 512 | 1024): 1 = whenever
- * eligible, 0 / -1 (default) = never -- a measured variant that did not beat the LDS-DMA ring inside the step; kept for the tests. */
+ * LL_DIT_OPT_XW_GEMM = the block's MLP GEMMs on the packed-weight panel kernel (gemm_xw_kernel; bf16, hidden 512 | 1024): 1 = fc1
+ * whenever eligible, 0 = never, -1 (default) = per device: ll_dit_begin times fc1 and fc2 (+ its AdaLN epilogue) on both kernels once per
+ * batch size (>= 128 token rows) and keeps the faster -- the LDS-DMA ring and the panel kernel trade places between MI355X boxes. */
 enum { LL_DIT_OPT_OVERLAP = 0, LL_DIT_OPT_GENERIC_ATTN = 1, LL_DIT_OPT_FUSED_QKV_ATTN = 2, LL_DIT_OPT_XW_GEMM = 3 };
 int ll_dit_set_option(void *handle, int option, int value);
 int ll_dit_last_run_ms(void *handle, float *ms, int *steps);
+/* What ll_dit_begin's calibration measured for the current batch (us per launch: fc1 ring, fc1 panel, fc2 + AdaLN ring, fc2 + AdaLN panel;
+ * zeros when it did not run) and which kernels the step uses. */
+int ll_dit_mlp_choice(void *handle, float *us4, int *xw_fc1, int *xw_fc2);
 /* Tuning: ln_mod_res with one wave per 256-column chunk of a row (default) or one wave per row; bit-identical results; returns the
  * previous setting. */
 int ll_set_lnmod_multiwave(int on);

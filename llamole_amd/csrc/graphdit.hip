@@ -144,9 +144,12 @@ struct DitEngine {
     DevBuf wfc1p, wfc2p;         // [depth][Hm x H], [depth][H x Hm]: the MLP weights packed the same way (gemm_m64_kernel, gemm_xw_kernel)
     DevBuf wprojp;               // [depth][H x H]
     std::vector<const void *> packed_keys;   // row-major weights registered with register_packed_weight
-    int xw_gemm = -1;            // fc1 (and with xw_fc2, fc2) on gemm_xw_kernel: 1 = whenever eligible; -1 / 0 = never (it lost)
+    int xw_gemm = -1;            // fc1 / fc2 on gemm_xw_kernel: 1 = whenever eligible, 0 = never, -1 = whichever ll_dit_begin measured faster
     int splits_x = 1;            // split-K of fc2 on gemm_xw_kernel (K slices of 512 | 1024)
-    int xw_fc2 = 0;              // fc2 too (env LL_XW_FC2; measured slower than the ring with two slabs)
+    int xw_fc2 = 0;              // with xw_gemm = 1: fc2 too (env LL_XW_FC2)
+    int xw_cal_B = -1;           // batch the choice below was measured for (ll_dit_begin re-measures when the batch changes)
+    float cal_us[4] = {0, 0, 0, 0};  // fc1 ring | fc1 xw | fc2 + AdaLN ring | fc2 + AdaLN xw, us per launch at the last calibration
+    bool xw_fc1_auto = false, xw_fc2_auto = false;   // xw_gemm = -1: gemm_xw_kernel beat the LDS-DMA ring on THIS device at this batch
     DevBuf yw0, yb0;             // packed [10][H] f32
     DevBuf tables;               // x_marg16 e_marg8 u_xe80 u_ex80 betas[T+1] alphas_bar[T+1]
     // per-batch
@@ -305,9 +308,13 @@ static bool xw_eligible(const DitEngine *e) {
     const int sp = Hm / xw_slice(Hm);
     return (sp == 1 || sp == 2 || sp == 4 || sp == 8) && Hm % 128 == 0 && H % 128 == 0;
 }
-static bool xw_wanted(const DitEngine *e) {
+static bool xw_fc1_wanted(const DitEngine *e) {
     if (e->wfc1p.p == nullptr || !xw_eligible(e) || e->xw_gemm == 0) return false;
-    return e->xw_gemm == 1;      // never by default: measured equal or slower than the LDS-DMA ring inside the step
+    return e->xw_gemm == 1 || (e->xw_cal_B == e->B && e->xw_fc1_auto);
+}
+static bool xw_fc2_wanted(const DitEngine *e) {
+    if (e->wfc1p.p == nullptr || !xw_eligible(e) || e->xw_gemm == 0) return false;
+    return e->xw_gemm == 1 ? e->xw_fc2 != 0 : (e->xw_cal_B == e->B && e->xw_fc2_auto);
 }
 static void launch_qkv_attn(DitEngine *e, int layer, hipStream_t st) {
     const DitEngine::BlockW &w = e->bw[layer];
@@ -389,7 +396,7 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
     if (hidden_tap && tap_layer == 0)
         LL_HIP(hipMemcpyAsync(hidden_tap, e->x32.p, (size_t)M2 * H * 4, hipMemcpyDeviceToDevice, st));
     const int64_t slab = (int64_t)e->M2p * H;
-    const bool fused_qkv = qkv_attn_wanted(e), xw = xw_wanted(e);
+    const bool fused_qkv = qkv_attn_wanted(e), xw = xw_fc1_wanted(e), xw2 = xw_fc2_wanted(e);
     for (int l = 0; l < c.depth; ++l) {
         const DitEngine::BlockW &w = e->bw[l];
         if (fused_qkv) {
@@ -412,7 +419,7 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
         } else {
             LL_TRY(linear_launch(dt, e->xa.p, H, w.fc1, H, w.fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, st));
         }
-        if (xw && e->xw_fc2) {
+        if (xw2) {
             LL_TRY(linear_xw_launch(e->h1.p, Hm, e->wfc2p.as<bf16_t>() + (size_t)l * Hm * H, nullptr, e->ybuf.p, H, M2, H, Hm, e->splits_x, slab, 0, 1, st));
             nslab_m = e->splits_x;
         } else {
@@ -656,6 +663,52 @@ int ll_dit_destroy(void *handle) {
     return LL_OK;
 }
 
+// Which MLP GEMM kernels for this batch on THIS device?  The LDS-DMA ring and the packed-weight panel kernel trade places from one MI355X
+// box to the next (same image, same clocks reported): fc1 at 512 rows 11.4 vs 10.4 us on most, 16.7-19 vs 10.5 on some -- so the
+// engine times both once per batch size (2 + 8 launches each over different layers' weights, ~0.5 ms) and keeps the faster pair.
+// The activation buffers hold no state yet at this point (ll_dit_begin precedes ll_dit_init_state).
+static int calibrate_mlp(DitEngine *e, hipStream_t st) {
+    const LLDitConfig &c = e->cfg;
+    const int H = c.hidden, Hm = c.mlp_hidden, M2 = e->M2, dt = c.dtype;
+    e->xw_cal_B = e->B;
+    e->xw_fc1_auto = e->xw_fc2_auto = false;
+    if (e->xw_gemm != -1 || dt != LL_BF16 || e->wfc1p.p == nullptr || !xw_eligible(e) || M2 < 128) return LL_OK;
+    const int64_t slab = (int64_t)e->M2p * H;
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), 0, e->seed_ptr(), 0ull);
+    auto timeit = [&](auto &&fn, float &us) -> int {
+        for (int i = 0; i < 2; ++i) LL_TRY(fn(i % c.depth));
+        LL_HIP(hipEventRecord(e->ev_t0, st));
+        const int reps = 8;
+        for (int i = 0; i < reps; ++i) LL_TRY(fn((i + 2) % c.depth));
+        LL_HIP(hipEventRecord(e->ev_t1, st));
+        LL_HIP(hipEventSynchronize(e->ev_t1));
+        float ms = 0.f;
+        LL_HIP(hipEventElapsedTime(&ms, e->ev_t0, e->ev_t1));
+        us = ms * 1000.f / reps;
+        return LL_OK;
+    };
+    float ring1 = 0, xw1 = 0, ring2 = 0, xw2 = 0;
+    LL_TRY(timeit([&](int l) { return linear_launch(dt, e->xa.p, H, e->bw[l].fc1, H, e->bw[l].fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, st); }, ring1));
+    LL_TRY(timeit([&](int l) { return linear_xw_launch(e->xa.p, H, e->wfc1p.as<bf16_t>() + (size_t)l * Hm * H, e->bw[l].fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, 1, 0, st); }, xw1));
+    LL_TRY(timeit([&](int l) {
+        if (e->splits_m > 1) LL_TRY(linear_splitk_launch(dt, e->h1.p, Hm, e->bw[l].fc2, Hm, e->ybuf.as<float>(), H, slab, M2, H, Hm, e->splits_m, st));
+        else LL_TRY(linear_launch(dt, e->h1.p, Hm, e->bw[l].fc2, Hm, nullptr, e->ybuf.p, H, M2, H, Hm, 0, 1, st));
+        launch_lnmod<bf16_t>(e, l, 1, e->splits_m, e->bw[l].fc2_b, st);
+        return (int)LL_OK;
+    }, ring2));
+    LL_TRY(timeit([&](int l) {
+        LL_TRY(linear_xw_launch(e->h1.p, Hm, e->wfc2p.as<bf16_t>() + (size_t)l * Hm * H, nullptr, e->ybuf.p, H, M2, H, Hm, e->splits_x, slab, 0, 1, st));
+        launch_lnmod<bf16_t>(e, l, 1, e->splits_x, e->bw[l].fc2_b, st);
+        return (int)LL_OK;
+    }, xw2));
+    // 10 % in favour of the ring: where the two are within a few per cent in isolation the ring is the better neighbour inside the step
+    // (same-box step times 1.510 vs 1.529 ms at batch 8); on the boxes where the ring is slow the margin is 40 % and more
+    e->xw_fc1_auto = xw1 < 0.90f * ring1;
+    e->xw_fc2_auto = xw2 < 0.90f * ring2;
+    e->cal_us[0] = ring1; e->cal_us[1] = xw1; e->cal_us[2] = ring2; e->cal_us[3] = xw2;
+    return LL_OK;
+}
+
 int ll_dit_begin(void *handle, int B, const float *props, const float *text, const int32_t *n_nodes, void *stream) {
     DitEngine *e = (DitEngine *)handle;
     LL_CHECK(e && props && text && n_nodes, "null argument");
@@ -707,6 +760,11 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
     for (size_t i = 0; i < sizeof(oldp) / sizeof(oldp[0]); ++i)
         if (oldp[i] != newp[i]) { drop_graph(e); break; }
 
+    if (e->xw_cal_B != B) {
+        const bool f1 = e->xw_fc1_auto, f2 = e->xw_fc2_auto;
+        LL_TRY(calibrate_mlp(e, st));
+        if (f1 != e->xw_fc1_auto || f2 != e->xw_fc2_auto) drop_graph(e);
+    }
     LL_HIP(hipMemcpyAsync(e->n_nodes.p, n_nodes, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     // ---- c_t for every step: sinusoid -> Linear(256,H)+SiLU -> Linear(H,H)          (conditions.py:53-58)
     if (bf) hipLaunchKernelGGL((tfreq_kernel<bf16_t>), dim3(T + 1), dim3(128), 0, st, e->ct_in.as<bf16_t>(), T);
@@ -948,6 +1006,15 @@ int ll_dit_set_option(void *handle, int option, int value) {
             break;
         default: LL_CHECK(false, "ll_dit_set_option: unknown option %d", option);
     }
+    return LL_OK;
+}
+
+int ll_dit_mlp_choice(void *handle, float *us4, int *xw_fc1, int *xw_fc2) {
+    DitEngine *e = (DitEngine *)handle;
+    LL_CHECK(e, "ll_dit_mlp_choice: null handle");
+    if (us4) memcpy(us4, e->cal_us, sizeof(e->cal_us));
+    if (xw_fc1) *xw_fc1 = xw_fc1_wanted(e) ? 1 : 0;
+    if (xw_fc2) *xw_fc2 = xw_fc2_wanted(e) ? 1 : 0;
     return LL_OK;
 }
 
