@@ -171,13 +171,13 @@ int ll_dit_set_overlap(void *handle, int on);
  * dimension 64, hidden 256 | 512 | a multiple of 1024): -1 = when the launch has 64..512 such workgroups, i.e. batch 2..16 at 16 heads
  * (default), 0 = never, 1 = whenever eligible;
  * LL_DIT_OPT_XW_GEMM = the block's MLP GEMMs on the packed-weight panel kernel (gemm_xw_kernel; bf16, hidden 512 | 1024): 1 = fc1
- * whenever eligible, 0 = never, -1 (default) = per device: ll_dit_begin times fc1 and fc2 (+ its AdaLN epilogue) on both kernels once per
- * batch size (>= 128 token rows) and keeps the faster -- the LDS-DMA ring and the panel kernel trade places between MI355X boxes. */
+ * whenever eligible, 0 = never, -1 (default) = per device: ll_dit_begin times the MLP chain fc1 -> fc2 -> AdaLN epilogue with either kernel under
+ * each GEMM once per batch size (>= 128 token rows) and keeps the fastest pair -- the LDS-DMA ring and the panel kernel trade places between MI355X boxes. */
 enum { LL_DIT_OPT_OVERLAP = 0, LL_DIT_OPT_GENERIC_ATTN = 1, LL_DIT_OPT_FUSED_QKV_ATTN = 2, LL_DIT_OPT_XW_GEMM = 3 };
 int ll_dit_set_option(void *handle, int option, int value);
 int ll_dit_last_run_ms(void *handle, float *ms, int *steps);
-/* What ll_dit_begin's calibration measured for the current batch (us per launch: fc1 ring, fc1 panel, fc2 + AdaLN ring, fc2 + AdaLN panel;
- * zeros when it did not run) and which kernels the step uses. */
+/* What ll_dit_begin's calibration measured for the current batch (us per fc1 -> fc2 -> AdaLN chain with fc1 / fc2 on ring/ring,
+ * panel/ring, ring/panel, panel/panel; zeros when it did not run) and which kernels the step uses. */
 int ll_dit_mlp_choice(void *handle, float *us4, int *xw_fc1, int *xw_fc2);
 /* Tuning: ln_mod_res with one wave per 256-column chunk of a row (default) or one wave per row; bit-identical results; returns the
  * previous setting. */

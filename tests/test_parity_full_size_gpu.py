@@ -246,7 +246,7 @@ def test_packed_weight_mlp_vs_ring_gemms(N, H, heads, B):
     m.begin(props, text, -200.0, n_nodes)
     choice = m.mlp_choice()            # ll_dit_begin timed both kernels on this device for this batch
     assert choice["fc1"] in ("ring", "panel") and choice["fc2"] in ("ring", "panel")
-    assert min(choice["us_fc1_ring"], choice["us_fc1_panel"], choice["us_fc2_ln_ring"], choice["us_fc2_ln_panel"]) > 0, choice
+    assert min(choice["chain_us"].values()) > 0, choice
     m.init_state(*synth.exp_noise(seed, m.T, B, N))
     s = m.T - 1
     out = {}
