@@ -216,7 +216,13 @@ struct DitEngine {
         b_out1 = pf("output_layer.xedecoder.fc1.bias"); b_out2 = pf("output_layer.xedecoder.fc2.bias");
         xe_w = pf("x_embedder.1.weight"); xe_b = pf("x_embedder.1.bias");
     }
-    int *step_ptr() const { return scal.as<int>(); }
+    // The step index the kernels read: the device scalar (captured graphs: advance_step_kernel counts it down), or -- when ll_dit_run
+    // launches the kernels itself and knows the step -- entry `step_host` of a constant table, so that no launch waits for a value an
+    // earlier launch wrote and the count-down launch disappears.
+    DevBuf steps_tab;            // int [T + 1]: steps_tab[i] == i
+    int step_host = -1;
+    int *step_ptr() const { return step_host >= 0 ? steps_tab.as<int>() + step_host : scal.as<int>(); }
+    int *step_scalar() const { return scal.as<int>(); }
     const int *rowvec = nullptr;   // per-graph table rows while ll_dit_denoise_rows runs, else null
     unsigned long long *seed_ptr() const { return reinterpret_cast<unsigned long long *>(scal.as<char>() + 8); }
     float *tab(int off) const { return tables.as<float>() + off; }
@@ -338,7 +344,12 @@ template <typename T>
 static void launch_lnmod(DitEngine *e, int layer, int sel, int nslab, const float *bias, hipStream_t st) {
     const dim3 grid(e->M2), blk(64);
     const int64_t ss = (int64_t)e->M2p * e->cfg.hidden;
-    const float *mc = (e->rowvec == nullptr && g_stage_mod) ? e->modcur.as<float>() : nullptr;   // staged rows of this step (denoise_body)
+    // the step's modulation rows at an address known at launch time: the slice of the hoisted table itself when the host knows the step
+    // (ll_dit_run launching), else the copy stage_mod_kernel made (denoise_body)
+    const float *mc = e->rowvec != nullptr ? nullptr
+                      : e->step_host >= 0  ? e->modtab.as<float>() + (int64_t)e->step_host * (e->B + 1) * e->cfg.depth * 6 * e->cfg.hidden
+                      : g_stage_mod        ? e->modcur.as<float>()
+                                           : nullptr;
 #define LL_LNMOD2(NS, ME)                                                                                              \
     do {                                                                                                               \
         if (ME > 1 && g_lnmod_multiwave)                                                                               \
@@ -387,7 +398,7 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
     const LLDitConfig &c = e->cfg;
     const int H = c.hidden, Hm = c.mlp_hidden, M2 = e->M2, dt = c.dtype;
     const bool bf = dt == LL_BF16;
-    if (e->rowvec == nullptr && g_stage_mod) {
+    if (e->rowvec == nullptr && g_stage_mod && e->step_host < 0) {
         const int64_t row_floats = (int64_t)(e->B + 1) * c.depth * 6 * H;
         hipLaunchKernelGGL(stage_mod_kernel, dim3(256), dim3(256), 0, st, e->modtab.as<float>(), e->modcur.as<float>(), e->step_ptr(), row_floats);
     }
@@ -579,6 +590,12 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
         CRH(hipMemcpy(e->tables.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     }
     CR(e->scal.ensure(64));
+    {
+        std::vector<int> ids(T + 1);
+        for (int i = 0; i <= T; ++i) ids[i] = i;
+        CR(e->steps_tab.ensure(ids.size() * 4));
+        CRH(hipMemcpy(e->steps_tab.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+    }
     // the generic attention kernel may need > 64 KiB of dynamic LDS (N=64, hd>=64)
     CRH(hipFuncSetAttribute((const void *)attn_generic_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CRH(hipFuncSetAttribute((const void *)attn_generic_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -651,7 +668,7 @@ int ll_dit_destroy(void *handle) {
     DevBuf *bufs[] = {&e->wop, &e->wxT, &e->wycat, &e->yw0, &e->yb0, &e->tables, &e->n_nodes, &e->X, &e->E, &e->x32,
                       &e->xa, &e->qkv, &e->attn_o, &e->ybuf, &e->h1, &e->ho, &e->outF, &e->ct_in, &e->ct_h, &e->ct,
                       &e->zy, &e->cy, &e->txt_op, &e->ctxt, &e->ynan, &e->tnan, &e->c32, &e->ca, &e->m1, &e->modtab,
-                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wqkvp, &e->wfc1p, &e->wfc2p, &e->wprojp};
+                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wqkvp, &e->wfc1p, &e->wfc2p, &e->wprojp, &e->steps_tab};
     for (const void *k : e->packed_keys) register_packed_weight(k, nullptr);
     for (DevBuf *b : bufs) b->release();
     if (e->own) (void)hipStreamDestroy(e->own);
@@ -674,7 +691,7 @@ static int calibrate_mlp(DitEngine *e, hipStream_t st) {
     e->xw_fc1_auto = e->xw_fc2_auto = false;
     if (e->xw_gemm != -1 || dt != LL_BF16 || e->wfc1p.p == nullptr || !xw_eligible(e) || M2 < 128) return LL_OK;
     const int64_t slab = (int64_t)e->M2p * H;
-    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), 0, e->seed_ptr(), 0ull);
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), 0, e->seed_ptr(), 0ull);
     auto timeit = [&](auto &&fn, float &us) -> int {
         for (int i = 0; i < 2; ++i) LL_TRY(fn(i % c.depth));
         LL_HIP(hipEventRecord(e->ev_t0, st));
@@ -817,7 +834,7 @@ int ll_dit_init_state(void *handle, const float *qx, const float *qe, uint64_t s
     LL_TRY(check_ready(e, false));
     LL_CHECK((qx == nullptr) == (qe == nullptr), "qx and qe must both be given or both be null");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), e->cfg.T - 1, e->seed_ptr(), (unsigned long long)seed);
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), e->cfg.T - 1, e->seed_ptr(), (unsigned long long)seed);
     {
         const int half = e->cfg.T & 1;
         const size_t nx = (size_t)e->B * e->cfg.max_nodes, ne = nx * e->cfg.max_nodes;
@@ -864,7 +881,7 @@ int ll_dit_step(void *handle, int s, const float *qx, const float *qe, uint64_t 
     hipStream_t st = (hipStream_t)stream;
     PanelScope panel(e);
     LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
-    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), s, e->seed_ptr(), (unsigned long long)seed);
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), s, e->seed_ptr(), (unsigned long long)seed);
     LL_LAUNCH_CHECK();
     LL_TRY(denoise_body(e, st, nullptr, -1));
     LL_TRY(posterior_launch(e, qx, qe, 1, nullptr, nullptr, nullptr, nullptr, st));
@@ -880,7 +897,7 @@ int ll_dit_denoise(void *handle, int s, float *logX, float *logE, float *hidden,
     hipStream_t st = (hipStream_t)stream;
     PanelScope panel(e);
     LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
-    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), s, e->seed_ptr(), 0ull);
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), s, e->seed_ptr(), 0ull);
     LL_TRY(denoise_body(e, st, hidden, tap_layer));
     return posterior_launch(e, nullptr, nullptr, 0, nullptr, nullptr, logX, logE, st);
 }
@@ -896,7 +913,7 @@ int ll_dit_denoise_rows(void *handle, const int32_t *t_int, float *logX, float *
     LL_TRY(ensure_state_half(e, T & 1, st));
     LL_TRY(e->rows.ensure((size_t)e->B * 4));
     hipLaunchKernelGGL(t_to_row_kernel, dim3(1), dim3(256), 0, st, t_int, e->rows.as<int>(), e->B, T);
-    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), T - 1, e->seed_ptr(), 0ull);
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), T - 1, e->seed_ptr(), 0ull);
     LL_LAUNCH_CHECK();
     e->rowvec = e->rows.as<int>();
     int rc = denoise_body(e, st, nullptr, -1);
@@ -912,7 +929,7 @@ int ll_dit_step_probs(void *handle, int s, float *pX, float *pE, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     PanelScope panel(e);
     LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
-    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), s, e->seed_ptr(), 0ull);
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), s, e->seed_ptr(), 0ull);
     LL_TRY(denoise_body(e, st, nullptr, -1));
     return posterior_launch(e, nullptr, nullptr, 0, pX, pE, nullptr, nullptr, st);
 }
@@ -935,7 +952,7 @@ int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream) {
     LL_HIP(hipEventRecord(e->ev_in, caller));
     LL_HIP(hipStreamWaitEvent(st, e->ev_in, 0));
     LL_TRY(ensure_state_half(e, T & 1, st));
-    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_ptr(), T - 1, e->seed_ptr(), (unsigned long long)seed);
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), T - 1, e->seed_ptr(), (unsigned long long)seed);
     LL_LAUNCH_CHECK();
     // overlap mode: the trajectory runs next to another stream's kernels (the LLM decode of the next prompt); gemm_m64_kernel's
     // workgroups need a whole CU's LDS and keep that stream's workgroups off the CU (and wait for a drained CU themselves), so the
@@ -977,11 +994,15 @@ int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream) {
         LL_HIP(hipEventRecord(e->ev_t1, st));
     } else {
         LL_HIP(hipEventRecord(e->ev_t0, st));
-        for (int i = 0; i < T; ++i) {
-            LL_TRY(denoise_body(e, st, nullptr, -1));
-            LL_TRY(posterior_launch(e, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, st));
-            hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, st, e->step_ptr());
+        int rc = LL_OK;
+        for (int i = 0; i < T && rc == LL_OK; ++i) {
+            e->step_host = T - 1 - i;        // the kernels read this step from the constant table: no count-down launch, no staged rows
+            rc = denoise_body(e, st, nullptr, -1);
+            if (rc == LL_OK) rc = posterior_launch(e, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, st);
         }
+        e->step_host = -1;
+        LL_TRY(rc);
+        hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), -1, e->seed_ptr(), (unsigned long long)seed);   // as the count-down leaves it
         LL_HIP(hipEventRecord(e->ev_t1, st));
     }
     e->last_steps = T;
