@@ -147,7 +147,8 @@ struct DitEngine {
     int xw_gemm = -1;            // fc1 / fc2 on gemm_xw_kernel: 1 = whenever eligible, 0 = never, -1 = whichever ll_dit_begin measured faster
     int splits_x = 1;            // split-K of fc2 on gemm_xw_kernel (K slices of 512 | 1024)
     int xw_fc2 = 0;              // with xw_gemm = 1: fc2 too (env LL_XW_FC2)
-    int xw_cal_B = -1;           // batch the choice below was measured for (ll_dit_begin re-measures when the batch changes)
+    int xw_cal_B = -1;           // batch the choice below was measured for (ll_dit_begin measures once per batch size)
+    std::unordered_map<int, std::pair<bool, bool>> xw_cal_cache;   // batch -> (fc1 on the panel kernel, fc2 on the panel kernel)
     float cal_us[4] = {0, 0, 0, 0};  // us per fc1 -> fc2 -> AdaLN chain at the last calibration: ring/ring | panel/ring | ring/panel | panel/panel
     bool xw_fc1_auto = false, xw_fc2_auto = false;   // xw_gemm = -1: gemm_xw_kernel beat the LDS-DMA ring on THIS device at this batch
     DevBuf yw0, yb0;             // packed [10][H] f32
@@ -690,6 +691,12 @@ static int calibrate_mlp(DitEngine *e, hipStream_t st) {
     e->xw_cal_B = e->B;
     e->xw_fc1_auto = e->xw_fc2_auto = false;
     if (e->xw_gemm != -1 || dt != LL_BF16 || e->wfc1p.p == nullptr || !xw_eligible(e) || M2 < 128) return LL_OK;
+    auto hit = e->xw_cal_cache.find(e->B);
+    if (hit != e->xw_cal_cache.end()) {
+        e->xw_fc1_auto = hit->second.first;
+        e->xw_fc2_auto = hit->second.second;
+        return LL_OK;
+    }
     const int64_t slab = (int64_t)e->M2p * H;
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), 0, e->seed_ptr(), 0ull);
     auto timeit = [&](auto &&fn, float &us) -> int {
@@ -734,6 +741,7 @@ static int calibrate_mlp(DitEngine *e, hipStream_t st) {
     if (xr < best) { best = xr; e->xw_fc1_auto = true; e->xw_fc2_auto = false; }
     if (rx < best) { best = rx; e->xw_fc1_auto = false; e->xw_fc2_auto = true; }
     if (xx < best) { best = xx; e->xw_fc1_auto = true; e->xw_fc2_auto = true; }
+    e->xw_cal_cache[e->B] = std::make_pair(e->xw_fc1_auto, e->xw_fc2_auto);
     const float ring1 = rr, xw1 = xr, ring2 = rx, xw2 = xx;
     e->cal_us[0] = ring1; e->cal_us[1] = xw1; e->cal_us[2] = ring2; e->cal_us[3] = xw2;
     return LL_OK;
@@ -1035,7 +1043,10 @@ int ll_dit_set_option(void *handle, int option, int value) {
             e->fuse_qkv_attn = value < 0 ? -1 : (value ? 1 : 0);
             break;
         case LL_DIT_OPT_XW_GEMM:
-            if (e->xw_gemm != value) drop_graph(e);
+            if (e->xw_gemm != value) {
+                drop_graph(e);
+                e->xw_cal_B = -1;        // the next ll_dit_begin looks the per-device choice up (or measures it) again
+            }
             e->xw_gemm = value < 0 ? -1 : (value ? 1 : 0);
             break;
         default: LL_CHECK(false, "ll_dit_set_option: unknown option %d", option);
