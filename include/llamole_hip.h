@@ -71,6 +71,9 @@ int ll_set_m64_waves(int waves);
  * full-line wave instruction per fragment), 0 = the row-major weights; same products and order, bit-identical; returns the previous value.
  * Takes effect at the next graph capture. */
 int ll_set_m64_packed(int on);
+/* Tuning: 1 (default) = Linears with 65..128 rows take the two-panel form of the panel GEMM (gemm_m128_kernel), 0 = the LDS-DMA ring;
+ * returns the previous value.  Takes effect at the next launch / graph capture. */
+int ll_set_m128_panel(int on);
 /* ll_set_gemm_krot : the LDS-DMA GEMM sweeps its k-tiles starting at ((m_tile * (krot & 255) + n_tile * (krot >> 8 or 1)) mod
  * n_ktiles) instead of 0, so that workgroups sharing an operand tile do not miss L2 on the same lines at the same time.  0 = off.
  * Changes the f32 summation order per tile (deterministic).  Returns the previous setting. */
@@ -168,8 +171,8 @@ int ll_dit_set_overlap(void *handle, int on);
  * step_probs).  LL_DIT_OPT_OVERLAP = ll_dit_set_overlap; LL_DIT_OPT_GENERIC_ATTN = run the f32-LDS attention kernel under the
  * bf16 engine instead of the MFMA one (parity hook: the two are compared on identical q|k|v by the tests);
  * LL_DIT_OPT_FUSED_QKV_ATTN = the block's q|k|v projection and attention as ONE launch per (sequence, head) (bf16, head
- * dimension 64, hidden 256 | 512 | a multiple of 1024): -1 = when the launch has 64..512 such workgroups, i.e. batch 2..16 at 16 heads
- * (default), 0 = never, 1 = whenever eligible;
+ * dimension 64, hidden 256 | 512 | a multiple of 1024): -1 = above 128 token rows when the launch has 64..512 such workgroups, i.e. batch 3..16
+ * at 16 heads and 32 nodes, and always in overlap mode (default), 0 = never, 1 = whenever eligible;
  * LL_DIT_OPT_XW_GEMM = the block's MLP GEMMs on the packed-weight panel kernel (gemm_xw_kernel; bf16, hidden 512 | 1024): 1 = fc1
  * whenever eligible, 0 = never, -1 (default) = per device: ll_dit_begin times the MLP chain fc1 -> fc2 -> AdaLN epilogue with either kernel under
  * each GEMM once per batch size (>= 128 token rows) and keeps the fastest pair -- the LDS-DMA ring and the panel kernel trade places between MI355X boxes. */

@@ -81,6 +81,7 @@ SIGNATURES = {
     "ll_set_gemv_nt": (_I, [_I]),
     "ll_set_gemv_stage": (_I, [_I]),
     "ll_set_m64_waves": (_I, [_I]),
+    "ll_set_m128_panel": (_I, [_I]),
     "ll_set_m64_packed": (_I, [_I]),
     "ll_set_gemm_krot": (_I, [_I]),
     "ll_set_lnmod_multiwave": (_I, [_I]),

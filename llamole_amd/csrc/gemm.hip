@@ -892,7 +892,111 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_m64_kernel(const bf16_t *__re
     }
 }
 
+// The same all-in-flight panel kernel for 65..128 token rows (GraphDiT at batch 2 with 32 nodes, or at batch 1 with up to 64 nodes): two
+// workgroups along M (blockIdx.y), each with its own 64-row panel, and TWO 16-column tiles per workgroup so that the launch still has
+// ~200-256 workgroups and every weight fragment feeds eight MFMAs instead of four.  The partial-tile exchange (64 KB) reuses the
+// panel's LDS after a barrier.  Eight waves, K chunk split over them as above.
+template <int NS, typename OutT, bool PACKED>
+__global__ __launch_bounds__(512) void gemm_m128_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ W, int ldw,
+                                                        OutT *__restrict__ C, int ldc, const float *__restrict__ bias, int M, int N,
+                                                        int64_t slab_stride, int epi) {
+    constexpr int WAVES = 8, NT = 2, THREADS = 512;
+    constexpr int KC = NS * 128, ROWB = KC * 2, CPR = KC / 8, NA = 64 * CPR / THREADS, KS = NS * 4 / WAVES;
+    static_assert(KS >= 1 && NA >= 1, "K chunk too small for eight waves");
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_m128[];
+    unsigned char *As = sm_m128;                                       // [64][ROWB], chunk c of row r at chunk c ^ (r & 15)
+    float *red = reinterpret_cast<float *>(sm_m128);                   // after the MFMA loop: [WAVES][NT][4 m-tiles][64 lanes][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * (16 * NT), kbeg = blockIdx.z * KC;
+    const int rows = M - m0;                                           // live rows of this panel (>= 1)
+    u4 areg[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int c = tid + i * THREADS;
+        const int row = c / CPR, kc = c - row * CPR;
+        areg[i] = row < rows ? *reinterpret_cast<const u4 *>(A + (int64_t)(m0 + row) * lda + kbeg + kc * 8) : (u4)(0);
+    }
+    u4 wreg[NT][KS];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int nt0 = n0 + t * 16;
+        int wrow = nt0 + (lane & 15);
+        wrow = wrow < N ? wrow : N - 1;
+        const bool tile_ok = nt0 < N;
+        const bf16_t *wp = PACKED ? W + (((int64_t)(tile_ok ? nt0 / 16 : 0) * (ldw / 32) + kbeg / 32 + wave * KS) * 64 + lane) * 8
+                                  : W + (int64_t)wrow * ldw + kbeg + wave * (KS * 32) + (lane >> 4) * 8;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) wreg[t][s] = *reinterpret_cast<const u4 *>(wp + s * (PACKED ? 512 : 32));
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int c = tid + i * THREADS;
+        const int row = c / CPR, kc = c - row * CPR;
+        *reinterpret_cast<u4 *>(As + row * ROWB + (kc ^ (row & 15)) * 16) = areg[i];
+    }
+    __syncthreads();
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[t][mt] = (f32x4)(0.f);
+    const int fi = lane & 15;
+    const int c0 = wave * (KS * 4) + (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int pc = ((c0 + s * 4) ^ fi) * 16;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(As + (mt * 16 + fi) * ROWB + pc);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[t][s]), a, acc[t][mt], 0, 0, 0);
+        }
+    }
+    __syncthreads();                               // every wave is done with the panel: its LDS takes the partial tiles
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4 *>(red + (((wave * NT + t) * 4 + mt) * 64 + lane) * 4) = acc[t][mt];
+    __syncthreads();
+    // wave w sums tile (t = w >> 2, mt = w & 3): C row m0 + mt*16 + (lane & 15), columns n0 + t*16 + (lane>>4)*4 + 0..3
+    const int t = wave >> 2, mt = wave & 3;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(red + (((0 * NT + t) * 4 + mt) * 64 + lane) * 4);
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) {
+        const f32x4 u = *reinterpret_cast<const f32x4 *>(red + (((w * NT + t) * 4 + mt) * 64 + lane) * 4);
+        v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+    }
+    const int row = mt * 16 + (lane & 15), col = n0 + t * 16 + (lane >> 4) * 4;
+    if (row < rows && col < N) {
+        const bool raw = gridDim.z > 1, full = col + 3 < N;
+        float o[4] = {v[0], v[1], v[2], v[3]};
+        if (bias && !raw) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += col + j < N ? bias[col + j] : 0.f;
+        }
+        if (!raw) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = apply_epi(o[j], epi);
+        }
+        OutT *dst = C + (int64_t)blockIdx.z * slab_stride + (int64_t)(m0 + row) * ldc + col;
+        if (full && (ldc & 3) == 0) {
+            if (sizeof(OutT) == 4)
+                *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            else
+                *reinterpret_cast<uint2 *>(dst) = make_uint2((uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16),
+                                                            (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (col + j < N) dst[j] = from_f32<OutT>(o[j]);
+        }
+    }
+}
+
 static int g_m64_waves = 8;     // waves per workgroup of the panel kernel (4 | 8)
+static int g_m128_panel = 1;    // 65..128 rows on gemm_m128_kernel (ll_set_m128_panel)
 
 // packed (pack_mfma16) copies of row-major weights, registered by their owner (the GraphDiT engine): the panel kernel reads those
 static std::mutex g_packed_mu;
@@ -943,6 +1047,27 @@ static int launch_m64(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *
                       int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
     if (g_m64_waves == 8) return launch_m64_w<NS, 8>(A, lda, W, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s);
     return launch_m64_w<NS, 4>(A, lda, W, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s);
+}
+
+template <int NS>
+static int launch_m128(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M, int N,
+                       int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
+    constexpr int lds = 64 * (NS * 256) > 8 * 2 * 4 * 64 * 16 ? 64 * (NS * 256) : 8 * 2 * 4 * 64 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m128_kernel<NS, float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m128_kernel<NS, bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m128_kernel<NS, float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m128_kernel<NS, bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const dim3 grid(cdiv(N, 32), cdiv(M, 64), splits);
+    const bf16_t *Wp = (N % 16 == 0 && ldw % 32 == 0) ? packed_copy_of(W) : nullptr;
+#define LL_M128(T, P, WPTR) hipLaunchKernelGGL((gemm_m128_kernel<NS, T, P>), grid, dim3(512), lds, s, A, lda, WPTR, ldw, (T *)C, ldc, bias, M, N, slab_stride, epi)
+    if (Wp) { if (out_f32) LL_M128(float, true, Wp); else LL_M128(bf16_t, true, Wp); }
+    else { if (out_f32) LL_M128(float, false, W); else LL_M128(bf16_t, false, W); }
+#undef LL_M128
+    return LL_OK;
 }
 
 template <int NS>
@@ -1501,6 +1626,15 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
             LL_LAUNCH_CHECK();
             return LL_OK;
         }
+        if (g_gemm_variant != 0 && g_gemm_variant != 2 && g_m128_panel && !g_no_panel_gemm && M > 64 && M <= 128 &&
+            (kchunk == 256 || kchunk == 512 || kchunk == 1024) && (long)cdiv(N, 32) * splits >= 24) {
+            // two 64-row panels (GraphDiT at batch 2, or at batch 1 with 33..64 nodes): the all-in-flight panel kernel with 32 columns per workgroup
+            if (kchunk == 1024) LL_TRY((launch_m128<8>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));
+            else if (kchunk == 512) LL_TRY((launch_m128<4>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));
+            else LL_TRY((launch_m128<2>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));
+            LL_LAUNCH_CHECK();
+            return LL_OK;
+        }
         if (g_gemm_variant != 0 && g_gemm_variant != 2 && M > 4 && M <= 16 && splits == 1 && epi == EPI_NONE && K % 32 == 0 && N >= 256 &&
             ((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0) {
             // 5..16 rows (per-graph vectors of a GIN batch: virtual-node MLPs, projection head, decoder input; GraphDiT's hoisted
@@ -1924,6 +2058,12 @@ extern "C" int ll_linear_splitk_bf16(const void *A, int lda, const void *W, int 
 extern "C" int ll_set_gemm_krot(int krot) {
     const int old = ll::g_gemm_krot;
     ll::g_gemm_krot = krot < 0 ? 0 : krot;
+    return old;
+}
+
+extern "C" int ll_set_m128_panel(int on) {
+    const int old = ll::g_m128_panel;
+    ll::g_m128_panel = on ? 1 : 0;
     return old;
 }
 

@@ -305,7 +305,8 @@ static bool qkv_attn_wanted(const DitEngine *e) {
     // exceeds what they save.  Next to another stream's kernels (overlap mode: the trajectory under the LLM decode) every launch costs
     // the other stream a dispatch slot as well: fused from batch 1 (e2e 369.4 -> 366.9 ms per molecule).
     const int wgs = 2 * e->B * e->cfg.heads;
-    return e->fuse_qkv_attn == 1 || e->overlap || (wgs >= g_fuse_qkv_min_wgs && wgs <= g_fuse_qkv_max_wgs);
+    // up to 128 token rows the q|k|v projection runs on the all-in-flight panel kernels (gemm_m64 / gemm_m128), which beat the fused launch
+    return e->fuse_qkv_attn == 1 || e->overlap || (e->M2 > 128 && wgs >= g_fuse_qkv_min_wgs && wgs <= g_fuse_qkv_max_wgs);
 }
 // MLP of the block on the packed-weight panel GEMM (gemm.hip gemm_xw_kernel): fc1 with K = H in one slice, fc2 split over K
 static int xw_slice(int K) { return K % 1024 == 0 ? 1024 : 512; }

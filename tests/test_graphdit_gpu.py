@@ -69,6 +69,8 @@ def test_linear_matches_torch():
                       (2048, 3072, 1024), (2100, 3000, 256), (1024, 1024, 4096), (1500, 2050, 512),
                       # M <= 64 all-in-flight kernel (gemm_m64_kernel): K chunks of 1024 / 512 / 256, ragged M and N
                       (64, 3072, 1024), (40, 4096, 1024), (64, 1024, 512), (33, 784, 256), (5, 1000, 1024),
+                      # 65..128 rows: two 64-row panels (gemm_m128_kernel), K chunks 1024 / 512 / 256, ragged M and N (odd tile counts)
+                      (128, 3072, 1024), (100, 4096, 1024), (65, 1024, 512), (127, 784, 256), (100, 176, 1024), (128, 1040, 512),
                       # 5..32 rows over large weight matrices (several sequences decoding at once), ragged N
                       (8, 18944, 3584), (16, 3584, 18944), (23, 4611, 3584), (32, 2048, 2112)]:
         Mp = (M + 127) // 128 * 128
@@ -342,7 +344,8 @@ def test_linear_splitk_matches_torch():
     from llamole_amd import _lib
     lib = _lib.load()
     torch.manual_seed(1)
-    for (M, N, K, splits) in [(8, 3584, 18944, 4), (16, 1000, 8192, 2), (5, 96, 1024, 16), (32, 3584, 18944, 4)]:
+    for (M, N, K, splits) in [(8, 3584, 18944, 4), (16, 1000, 8192, 2), (5, 96, 1024, 16), (32, 3584, 18944, 4),
+                              (100, 1024, 4096, 4), (128, 1024, 1024, 4), (64, 1024, 4096, 4)]:       # panel kernels with K slabs
         A = torch.randn(M, K, device="cuda").bfloat16()
         W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
         bias = torch.randn(N, device="cuda")
