@@ -64,7 +64,7 @@ def _upper(n_nodes, N):
 
 
 @pytest.mark.parametrize("mode", ["panel", "overlap", "fused", "overlap_default", "fused_xw"])
-@pytest.mark.parametrize("B", [1, 8])
+@pytest.mark.parametrize("B", [1, 2, 8])
 def test_graphdit_ref_default_bf16_vs_oracle(full_dit, B, mode):
     """panel / overlap: seven launches per block with the synchronous or the overlap-mode GEMMs; fused: q|k|v projection +
     attention as one launch per (sequence, head) (qkv_attn_kernel; the engine's default for batch 2..16); overlap_default: the
@@ -74,7 +74,7 @@ def test_graphdit_ref_default_bf16_vs_oracle(full_dit, B, mode):
     overlap = int(mode.startswith("overlap"))
     N, T, seed = spec.N, spec.T, 11
     props, text, _ = synth.make_dit_inputs(B, seed=seed, max_node=N)
-    n_nodes = torch.tensor([32] if B == 1 else [32, 32, 17, 5, 32, 1, 29, 32])
+    n_nodes = torch.tensor([32] if B == 1 else [32, 11] if B == 2 else [32, 32, 17, 5, 32, 1, 29, 32])     # B = 2: the two-panel GEMM (128 rows)
     y = torch.where(props == -200.0, torch.tensor(float("nan")), props)
     mask = torch.arange(N).unsqueeze(0).expand(B, -1) < n_nodes.unsqueeze(1)
     s = T - 1
