@@ -71,8 +71,9 @@ int ll_set_m64_waves(int waves);
  * full-line wave instruction per fragment), 0 = the row-major weights; same products and order, bit-identical; returns the previous value.
  * Takes effect at the next graph capture. */
 int ll_set_m64_packed(int on);
-/* Tuning: 1 (default) = Linears with 65..128 rows take the two-panel form of the panel GEMM (gemm_m128_kernel), 0 = the LDS-DMA ring;
- * returns the previous value.  Takes effect at the next launch / graph capture. */
+/* Tuning: 1 (default) = Linears with 65..224 rows take the multi-panel form of the panel GEMM (gemm_m128_kernel: 32 columns per workgroup
+ * up to 128 rows, 64 beyond), 2 = up to 256 rows, 0 = the LDS-DMA ring; returns the previous value.  Takes effect at the next launch /
+ * graph capture. */
 int ll_set_m128_panel(int on);
 /* ll_set_gemm_krot : the LDS-DMA GEMM sweeps its k-tiles starting at ((m_tile * (krot & 255) + n_tile * (krot >> 8 or 1)) mod
  * n_ktiles) instead of 0, so that workgroups sharing an operand tile do not miss L2 on the same lines at the same time.  0 = off.

@@ -896,11 +896,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_m64_kernel(const bf16_t *__re
 // workgroups along M (blockIdx.y), each with its own 64-row panel, and TWO 16-column tiles per workgroup so that the launch still has
 // ~200-256 workgroups and every weight fragment feeds eight MFMAs instead of four.  The partial-tile exchange (64 KB) reuses the
 // panel's LDS after a barrier.  Eight waves, K chunk split over them as above.
-template <int NS, typename OutT, bool PACKED>
+template <int NS, int NT, typename OutT, bool PACKED>
 __global__ __launch_bounds__(512) void gemm_m128_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ W, int ldw,
                                                         OutT *__restrict__ C, int ldc, const float *__restrict__ bias, int M, int N,
                                                         int64_t slab_stride, int epi) {
-    constexpr int WAVES = 8, NT = 2, THREADS = 512;
+    constexpr int WAVES = 8, THREADS = 512;       // NT = 16-column tiles per workgroup: 2 (65..128 rows) | 4 (129..256 rows)
     constexpr int KC = NS * 128, ROWB = KC * 2, CPR = KC / 8, NA = 64 * CPR / THREADS, KS = NS * 4 / WAVES;
     static_assert(KS >= 1 && NA >= 1, "K chunk too small for eight waves");
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -960,8 +960,10 @@ __global__ __launch_bounds__(512) void gemm_m128_kernel(const bf16_t *__restrict
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4 *>(red + (((wave * NT + t) * 4 + mt) * 64 + lane) * 4) = acc[t][mt];
     __syncthreads();
-    // wave w sums tile (t = w >> 2, mt = w & 3): C row m0 + mt*16 + (lane & 15), columns n0 + t*16 + (lane>>4)*4 + 0..3
-    const int t = wave >> 2, mt = wave & 3;
+    // wave w sums tiles (t, mt = w & 3) for t = w >> 2, w >> 2 + 2, ...: C row m0 + mt*16 + (lane & 15), columns n0 + t*16 + (lane>>4)*4 + 0..3
+    const int mt = wave & 3;
+#pragma unroll
+    for (int t = wave >> 2; t < NT; t += 2) {
     f32x4 v = *reinterpret_cast<const f32x4 *>(red + (((0 * NT + t) * 4 + mt) * 64 + lane) * 4);
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) {
@@ -993,10 +995,12 @@ __global__ __launch_bounds__(512) void gemm_m128_kernel(const bf16_t *__restrict
                 if (col + j < N) dst[j] = from_f32<OutT>(o[j]);
         }
     }
+    }
 }
 
 static int g_m64_waves = 8;     // waves per workgroup of the panel kernel (4 | 8)
-static int g_m128_panel = 1;    // 65..128 rows on gemm_m128_kernel (ll_set_m128_panel)
+static int g_m128_panel = 1;    // 65..g_panel_max_rows rows on gemm_m128_kernel (ll_set_m128_panel)
+static int g_panel_max_rows = 224;   // measured: 3 panels (192 rows) 1.305 -> 1.22 ms per GraphDiT step, 4 panels (256 rows) level with the ring
 
 // packed (pack_mfma16) copies of row-major weights, registered by their owner (the GraphDiT engine): the panel kernel reads those
 static std::mutex g_packed_mu;
@@ -1049,21 +1053,22 @@ static int launch_m64(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *
     return launch_m64_w<NS, 4>(A, lda, W, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s);
 }
 
-template <int NS>
+template <int NS, int NT>
 static int launch_m128(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M, int N,
                        int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
-    constexpr int lds = 64 * (NS * 256) > 8 * 2 * 4 * 64 * 16 ? 64 * (NS * 256) : 8 * 2 * 4 * 64 * 16;
+    constexpr int red_bytes = 8 * NT * 4 * 64 * 16;
+    constexpr int lds = 64 * (NS * 256) > red_bytes ? 64 * (NS * 256) : red_bytes;
     static bool attr_set = false;
     if (!attr_set) {
-        LL_HIP(hipFuncSetAttribute((const void *)gemm_m128_kernel<NS, float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        LL_HIP(hipFuncSetAttribute((const void *)gemm_m128_kernel<NS, bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        LL_HIP(hipFuncSetAttribute((const void *)gemm_m128_kernel<NS, float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        LL_HIP(hipFuncSetAttribute((const void *)gemm_m128_kernel<NS, bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m128_kernel<NS, NT, float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m128_kernel<NS, NT, bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m128_kernel<NS, NT, float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_m128_kernel<NS, NT, bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    const dim3 grid(cdiv(N, 32), cdiv(M, 64), splits);
+    const dim3 grid(cdiv(N, 16 * NT), cdiv(M, 64), splits);
     const bf16_t *Wp = (N % 16 == 0 && ldw % 32 == 0) ? packed_copy_of(W) : nullptr;
-#define LL_M128(T, P, WPTR) hipLaunchKernelGGL((gemm_m128_kernel<NS, T, P>), grid, dim3(512), lds, s, A, lda, WPTR, ldw, (T *)C, ldc, bias, M, N, slab_stride, epi)
+#define LL_M128(T, P, WPTR) hipLaunchKernelGGL((gemm_m128_kernel<NS, NT, T, P>), grid, dim3(512), lds, s, A, lda, WPTR, ldw, (T *)C, ldc, bias, M, N, slab_stride, epi)
     if (Wp) { if (out_f32) LL_M128(float, true, Wp); else LL_M128(bf16_t, true, Wp); }
     else { if (out_f32) LL_M128(float, false, W); else LL_M128(bf16_t, false, W); }
 #undef LL_M128
@@ -1626,12 +1631,18 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
             LL_LAUNCH_CHECK();
             return LL_OK;
         }
-        if (g_gemm_variant != 0 && g_gemm_variant != 2 && g_m128_panel && !g_no_panel_gemm && M > 64 && M <= 128 &&
+        if (g_gemm_variant != 0 && g_gemm_variant != 2 && g_m128_panel && !g_no_panel_gemm && M > 64 && M <= g_panel_max_rows &&
             (kchunk == 256 || kchunk == 512 || kchunk == 1024) && (long)cdiv(N, 32) * splits >= 24) {
-            // two 64-row panels (GraphDiT at batch 2, or at batch 1 with 33..64 nodes): the all-in-flight panel kernel with 32 columns per workgroup
-            if (kchunk == 1024) LL_TRY((launch_m128<8>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));
-            else if (kchunk == 512) LL_TRY((launch_m128<4>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));
-            else LL_TRY((launch_m128<2>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));
+            // 64-row panels along M (GraphDiT at batch 2..4, or at batch 1 with 33..64 nodes): the all-in-flight panel kernel with 32 (up to 128
+            // rows) or 64 (up to 256 rows) columns per workgroup
+#define LL_PANELS(NT)                                                                                                              \
+    do {                                                                                                                           \
+        if (kchunk == 1024) LL_TRY((launch_m128<8, NT>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s))); \
+        else if (kchunk == 512) LL_TRY((launch_m128<4, NT>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s))); \
+        else LL_TRY((launch_m128<2, NT>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));              \
+    } while (0)
+            if (M <= 128) LL_PANELS(2); else LL_PANELS(4);
+#undef LL_PANELS
             LL_LAUNCH_CHECK();
             return LL_OK;
         }
@@ -2061,9 +2072,10 @@ extern "C" int ll_set_gemm_krot(int krot) {
     return old;
 }
 
-extern "C" int ll_set_m128_panel(int on) {
-    const int old = ll::g_m128_panel;
+extern "C" int ll_set_m128_panel(int on) {      // 0 = off, 1 = up to 224 rows (default), 2 = up to 256 rows
+    const int old = ll::g_m128_panel ? (ll::g_panel_max_rows > 224 ? 2 : 1) : 0;
     ll::g_m128_panel = on ? 1 : 0;
+    if (on) ll::g_panel_max_rows = on >= 2 ? 256 : 224;
     return old;
 }
 

@@ -306,7 +306,9 @@ static bool qkv_attn_wanted(const DitEngine *e) {
     // the other stream a dispatch slot as well: fused from batch 1 (e2e 369.4 -> 366.9 ms per molecule).
     const int wgs = 2 * e->B * e->cfg.heads;
     // up to 128 token rows the q|k|v projection runs on the all-in-flight panel kernels (gemm_m64 / gemm_m128), which beat the fused launch
-    return e->fuse_qkv_attn == 1 || e->overlap || (e->M2 > 128 && wgs >= g_fuse_qkv_min_wgs && wgs <= g_fuse_qkv_max_wgs);
+    // (graphs of more than 32 nodes stage their 64-row panel in two K chunks: there the fused launch needs twice the workgroups to pay)
+    const int min_wgs = e->cfg.max_nodes <= 32 ? g_fuse_qkv_min_wgs : 2 * g_fuse_qkv_min_wgs;
+    return e->fuse_qkv_attn == 1 || e->overlap || (e->M2 > 128 && wgs >= min_wgs && wgs <= g_fuse_qkv_max_wgs);
 }
 // MLP of the block on the packed-weight panel GEMM (gemm.hip gemm_xw_kernel): fc1 with K = H in one slice, fc2 split over K
 static int xw_slice(int K) { return K % 1024 == 0 ? 1024 : 512; }

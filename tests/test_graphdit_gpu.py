@@ -71,8 +71,10 @@ def test_linear_matches_torch():
                       (64, 3072, 1024), (40, 4096, 1024), (64, 1024, 512), (33, 784, 256), (5, 1000, 1024),
                       # 65..128 rows: two 64-row panels (gemm_m128_kernel), K chunks 1024 / 512 / 256, ragged M and N (odd tile counts)
                       (128, 3072, 1024), (100, 4096, 1024), (65, 1024, 512), (127, 784, 256), (100, 176, 1024), (128, 1040, 512),
+                      (256, 3072, 1024), (192, 4096, 1024), (130, 1000, 512), (256, 176, 256),
                       # 5..32 rows over large weight matrices (several sequences decoding at once), ragged N
                       (8, 18944, 3584), (16, 3584, 18944), (23, 4611, 3584), (32, 2048, 2112)]:
+        lib.ll_set_m128_panel(2 if M == 256 else 1)      # 225..256 rows on the 64-column form of the panel kernel: opt-in
         Mp = (M + 127) // 128 * 128
         A = torch.zeros(Mp, K, device="cuda")
         A[:M] = torch.randn(M, K, device="cuda")
@@ -94,6 +96,7 @@ def test_linear_matches_torch():
         _lib.check(lib.ll_linear(1, _lib.dptr(Ab), K, _lib.dptr(Wb), K, _lib.dptr(bias), _lib.dptr(outh), N, M, N, K, 1, 0, None))
         torch.cuda.synchronize()
         assert torch.allclose(outh.float(), refb, rtol=2e-2, atol=2e-2)
+    lib.ll_set_m128_panel(1)
 
 
 def test_register_staged_gemm_configs_match_torch():
