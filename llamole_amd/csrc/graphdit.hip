@@ -238,7 +238,10 @@ struct DitEngine {
 // Panel-GEMM choice of this engine for the calls made inside the scope (the flag gemm_dispatch consults is per host thread):
 // overlap mode keeps <= 64-row panels on the 48 KB LDS-DMA ring, everything else on gemm_m64_kernel.
 struct PanelScope {
-    explicit PanelScope(const DitEngine *e) { set_panel_gemm(!e->overlap); }
+    explicit PanelScope(const DitEngine *e) {
+        static const bool keep = getenv("LL_OVERLAP_PANEL") && atoi(getenv("LL_OVERLAP_PANEL")) != 0;     // A/B switch: panel GEMMs in overlap mode too
+        set_panel_gemm(!e->overlap || keep);
+    }
     ~PanelScope() { set_panel_gemm(true); }
 };
 
