@@ -56,6 +56,9 @@ int ll_linear_splitk_bf16(const void *A, int lda, const void *W, int ldw, const 
 /* Tuning utility: average ms of `iters` launches of pipelined-GEMM configuration `cfg` (-1 = the production
  * dispatch) on an [M,K]x[N,K]^T bf16 problem, cycling over `nweights` weight matrices (HBM-resident stream). */
 int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f32, int iters, int nweights, float *ms);
+/* ll_host_launch_probe : HOST time per enqueued launch (wall time of the issuing loop): kind 0 = empty kernel, 1 = two-argument kernel,
+ * 2 = linear_launch onto the <= 64-row panel GEMM, 3 = linear_launch onto the LDS-DMA ring. */
+int ll_host_launch_probe(int kind, int n, float *us_per_launch);
 /* ll_linear_xw : test hook of the packed-weight panel GEMM (gemm_xw_kernel: 64 token rows in LDS, the weight streamed from a copy in
  * MFMA operand order; K / splits = 512 | 1024, N % 128 == 0): packs the row-major W [N, K] into a temporary and runs it; splits > 1
  * writes raw f32 slabs of M x ldc.  ll_gemm_bench(cfg = -2) times the same kernel. */

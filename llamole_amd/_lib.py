@@ -38,6 +38,7 @@ SIGNATURES = {
     "ll_last_error": (C.c_char_p, []),
     "ll_linear": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ll_linear_splitk_bf16": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "ll_host_launch_probe": (_I, [_I, _I, C.POINTER(_F)]),
     "ll_gemm_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "ll_linear_xw": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ll_linear_cfg": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <unordered_map>
 
@@ -1955,6 +1956,39 @@ __global__ __launch_bounds__(1024) void lb_write_kernel(lbf4 *q, int n) {
 // either eagerly on a stream (graph=0) or as one captured hipGraph of n nodes (graph=1).
 // kind: 0 empty, 1 one load+store (64 threads), 2 dependent load chain, 3 1 MB streaming copy (256 blocks).
 static void *g_probe_a = nullptr, *g_probe_b = nullptr;
+// Host cost of enqueueing launches (wall time of the issuing loop, no synchronisation inside): kind 0 = empty kernel, 1 = two-argument
+// kernel, 2 = the whole linear_launch path onto gemm_m64_kernel ([64 x 256] x [16 x 256]^T bf16, one workgroup), 3 = the same onto the ring
+// ([200 x 256] x [64 x 256]^T).  n <= 8000 launches (below the queue depth).
+extern "C" int ll_host_launch_probe(int kind, int n, float *us_per_launch) {
+    using namespace ll;
+    LL_CHECK(us_per_launch && n > 0 && n <= 8000 && kind >= 0 && kind <= 3, "bad argument");
+    int *a = nullptr, *b = nullptr;
+    LL_HIP(hipMalloc(&a, 1 << 20));
+    LL_HIP(hipMalloc(&b, 1 << 20));
+    LL_HIP(hipMemset(a, 0, 1 << 20));
+    hipStream_t st;
+    LL_HIP(hipStreamCreate(&st));
+    auto launch = [&]() -> int {
+        switch (kind) {
+            case 0: hipLaunchKernelGGL(lb_empty_kernel, dim3(1), dim3(64), 0, st); return LL_OK;
+            case 1: hipLaunchKernelGGL(lb_load_kernel, dim3(1), dim3(64), 0, st, a, b); return LL_OK;
+            case 2: return linear_launch(LL_BF16, a, 256, (char *)a + (256 << 10), 256, nullptr, b, 16, 64, 16, 256, 0, 0, st);
+            default: return linear_launch(LL_BF16, a, 256, (char *)a + (256 << 10), 256, nullptr, b, 64, 200, 64, 256, 0, 0, st);
+        }
+    };
+    for (int i = 0; i < 32; ++i) LL_TRY(launch());
+    LL_HIP(hipStreamSynchronize(st));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) LL_TRY(launch());
+    const auto t1 = std::chrono::steady_clock::now();
+    LL_HIP(hipStreamSynchronize(st));
+    *us_per_launch = (float)(std::chrono::duration<double, std::micro>(t1 - t0).count() / n);
+    (void)hipStreamDestroy(st);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return LL_OK;
+}
+
 extern "C" int ll_launch_bench_set_buffers(void *a, void *b) {
     g_probe_a = a;
     g_probe_b = b;
