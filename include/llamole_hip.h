@@ -176,7 +176,8 @@ int ll_dit_set_overlap(void *handle, int on);
  * bf16 engine instead of the MFMA one (parity hook: the two are compared on identical q|k|v by the tests);
  * LL_DIT_OPT_FUSED_QKV_ATTN = the block's q|k|v projection and attention as ONE launch per (sequence, head) (bf16, head
  * dimension 64, hidden 256 | 512 | a multiple of 1024): -1 = above 128 token rows when the launch has 64..512 such workgroups, i.e. batch 3..16
- * at 16 heads and 32 nodes, and always in overlap mode (default), 0 = never, 1 = whenever eligible;
+ * at 16 heads and 32 nodes -- two sequences per workgroup from batch 11 to 24 -- and always in overlap mode (default), 0 = never,
+ * 1 = whenever eligible, 2 = two sequences per workgroup whenever eligible (graphs of <= 32 nodes);
  * LL_DIT_OPT_XW_GEMM = the block's MLP GEMMs on the packed-weight panel kernel (gemm_xw_kernel; bf16, hidden 512 | 1024): 1 = fc1
  * whenever eligible, 0 = never, -1 (default) = per device: ll_dit_begin times the MLP chain fc1 -> fc2 -> AdaLN epilogue with either kernel under
  * each GEMM once per batch size (>= 128 token rows) and keeps the fastest pair -- the LDS-DMA ring and the panel kernel trade places between MI355X boxes. */

@@ -218,10 +218,13 @@ typedef __attribute__((ext_vector_type(4))) float af32x4;
 // O^T = V^T P^T, so a lane ends up with four consecutive head columns of one query row: 8-byte stores.
 struct AttnNoWait { __device__ __forceinline__ void operator()() const {} };
 // `before_pv()` runs between the softmax and the first read of Vt (qkv_attn_kernel waits there for the waves that write V^T).
-template <int NP, int HD, int WPB, bool PSEP, typename BeforePV = AttnNoWait>
+// PAIR (NP = 64): rows 0..31 and 32..63 of the images are the tokens of TWO sequences (nv / nv1 valid nodes; `ohead` = first row of the
+// first one, the second follows N rows later): a query attends only to the keys of its own half.
+template <int NP, int HD, int WPB, bool PSEP, typename BeforePV = AttnNoWait, bool PAIR = false>
 __device__ __forceinline__ void attn_core(const bf16_t *Qs, const bf16_t *Ks, const bf16_t *Vt, bf16_t *Ps,
                                           bf16_t *__restrict__ ohead, int N, int nv, int H, int wave, int lane,
-                                          BeforePV before_pv = BeforePV()) {
+                                          BeforePV before_pv = BeforePV(), int nv1 = 0) {
+    static_assert(!PAIR || NP == 64, "two sequences per workgroup: 2 x 32 token rows");
     constexpr int QLD = HD + 8, PLD = NP + 8;
     constexpr int MT = NP / 16, KS = HD / 32;
     constexpr int MQ = MT / WPB;
@@ -266,7 +269,13 @@ __device__ __forceinline__ void attn_core(const bf16_t *Qs, const bf16_t *Ks, co
 #pragma unroll
             for (int nt = 0; nt < MT; ++nt) {
                 const int j = nt * 16 + fr;
-                const bool allow = (j < N) && ((i >= nv) || (j < nv));
+                bool allow;
+                if (PAIR) {
+                    const int il = i & 31, jl = j & 31, nvh = (i >> 5) ? nv1 : nv;
+                    allow = ((i >> 5) == (j >> 5)) && (jl < N) && ((il >= nvh) || (jl < nvh));
+                } else {
+                    allow = (j < N) && ((i >= nv) || (j < nv));
+                }
                 const float sv = allow ? acc[mt][nt][r] * scale2 : -INFINITY;
                 acc[mt][nt][r] = sv;
                 mx = fmaxf(mx, sv);
@@ -313,12 +322,13 @@ __device__ __forceinline__ void attn_core(const bf16_t *Qs, const bf16_t *Ks, co
 #pragma unroll
     for (int mt = 0; mt < MQ; ++mt) {
         const int i = (q0 + mt) * 16 + fr;
-        if (i < N) {
+        const int orow = PAIR ? (i >> 5) * N + (i & 31) : i;          // output row relative to `ohead`
+        if (PAIR ? (i & 31) < N : i < N) {
 #pragma unroll
             for (int nt = 0; nt < NT2; ++nt) {
                 const uint32_t lo = (uint32_t)f32_to_bf16(oc[mt][nt][0]) | ((uint32_t)f32_to_bf16(oc[mt][nt][1]) << 16);
                 const uint32_t hi = (uint32_t)f32_to_bf16(oc[mt][nt][2]) | ((uint32_t)f32_to_bf16(oc[mt][nt][3]) << 16);
-                *reinterpret_cast<uint2 *>(ohead + (int64_t)i * H + nt * 16 + fk * 4) = make_uint2(lo, hi);
+                *reinterpret_cast<uint2 *>(ohead + (int64_t)orow * H + nt * 16 + fk * 4) = make_uint2(lo, hi);
             }
         }
     }
@@ -512,7 +522,7 @@ template <int NP, int KC> struct QkvAttnGeom {                     // KC = K chu
     static constexpr size_t lds_bytes() { return (size_t)XBYTES + TAIL_BYTES; }
 };
 
-template <int NP, int KC>
+template <int NP, int KC, bool PAIR = false>
 __global__ __launch_bounds__(768) void qkv_attn_kernel(const bf16_t *__restrict__ xa, const bf16_t *__restrict__ Wp,
                                                        bf16_t *__restrict__ o, const float *__restrict__ qw,
                                                        const float *__restrict__ qb, const float *__restrict__ kw,
@@ -524,8 +534,14 @@ __global__ __launch_bounds__(768) void qkv_attn_kernel(const bf16_t *__restrict_
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_qa[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int head = blockIdx.x % heads, seq = blockIdx.x / heads;    // consecutive workgroups = the heads of one sequence:
+    // PAIR (NP = 64, N <= 32): the workgroup takes TWO sequences (rows 0..31 / 32..63 of its panel) through the head's weights -- half the
+    // weight intake per sequence; the engine's choice when one sequence per workgroup would need more than two rounds of workgroups
+    static_assert(!PAIR || NP == 64, "two sequences per workgroup: 2 x 32 token rows");
+    const int head = blockIdx.x % heads, seq = (blockIdx.x / heads) * (PAIR ? 2 : 1);    // consecutive workgroups = the heads of one sequence (pair):
     const int nv = n_nodes[seq % B];                                  // head h of every sequence lands on XCD h % 8 (one L2 copy of its weights)
+    const int nv1 = PAIR ? n_nodes[(seq + 1) % B] : 0;
+    auto tok_of = [&](int row) { return PAIR ? (row & 31) : row; };              // token index of a panel row inside its sequence
+    auto grow_of = [&](int row) { return PAIR ? (row >> 5) * N + (row & 31) : row; };   // its row relative to the first sequence's first row
     unsigned char *xs = sm_qa;                                        // [NP][XPITCH] token panel chunk, 16-byte piece p of row r at p ^ (r & 15)
     int *ctr = reinterpret_cast<int *>(sm_qa + G::XBYTES + 41 * 1024);    // hand-off counters of the tail (zeroed before the first barrier)
     if (tid < 8) ctr[tid] = 0;
@@ -591,7 +607,7 @@ __global__ __launch_bounds__(768) void qkv_attn_kernel(const bf16_t *__restrict_
 #if defined(LL_QA_MODE) && LL_QA_MODE == 2      // probe: no panel loads
             xr[i] = (u32x4)(0x3c003c00u);
 #else
-            xr[i] = *reinterpret_cast<const u32x4 *>(xseq + (row < N ? row : 0) * H + c0 + col * 8);
+            xr[i] = *reinterpret_cast<const u32x4 *>(xseq + (tok_of(row) < N ? grow_of(row) : 0) * H + c0 + col * 8);
 #endif
         }
 #if !defined(LL_QA_MODE) || LL_QA_MODE != 1
@@ -608,7 +624,7 @@ __global__ __launch_bounds__(768) void qkv_attn_kernel(const bf16_t *__restrict_
         for (int i = 0; i < XPT; ++i) {
             const int pc = (tid + i * 768) & (PIECES - 1);
             const int row = pc / PPR, col = pc % PPR;
-            *reinterpret_cast<u32x4 *>(xs + row * XPITCH + ((col ^ (row & 15)) << 4)) = row < N ? xr[i] : (u32x4)(0);
+            *reinterpret_cast<u32x4 *>(xs + row * XPITCH + ((col ^ (row & 15)) << 4)) = tok_of(row) < N ? xr[i] : (u32x4)(0);
         }
     };
     stage(cs * KC, true);
@@ -675,7 +691,7 @@ __global__ __launch_bounds__(768) void qkv_attn_kernel(const bf16_t *__restrict_
             const float s1 = (t0.x + t1.x) + (t2.x + t3.x), s2 = (t0.y + t1.y) + (t2.y + t3.y);
             const float mean = s1 * (1.f / HD);
             const float rstd = rsqrtf(fmaxf(s2 * (1.f / HD) - mean * mean, 0.f) + 1e-5f);
-            const bool live = tok < N;
+            const bool live = tok_of(tok) < N;
             const float o0 = live ? (v[mt][0] - mean) * rstd * lnw.x + lnb.x : 0.f, o1 = live ? (v[mt][1] - mean) * rstd * lnw.y + lnb.y : 0.f;
             const float o2 = live ? (v[mt][2] - mean) * rstd * lnw.z + lnb.z : 0.f, o3 = live ? (v[mt][3] - mean) * rstd * lnw.w + lnb.w : 0.f;
             *reinterpret_cast<uint2 *>(dst + tok * QLD + sub * 16 + fq * 4) =
@@ -686,7 +702,7 @@ __global__ __launch_bounds__(768) void qkv_attn_kernel(const bf16_t *__restrict_
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int tok = mt * 16 + fr;
-            const bool live = tok < N;
+            const bool live = tok_of(tok) < N;
 #pragma unroll
             for (int j = 0; j < 4; ++j) Vt[(sub * 16 + fq * 4 + j) * PLD + tok] = live ? f32_to_bf16(acc[mt][j]) : (bf16_t)0;
         }
@@ -696,7 +712,8 @@ __global__ __launch_bounds__(768) void qkv_attn_kernel(const bf16_t *__restrict_
     if (wid >= MT) return;                                            // one wave per query tile (they are q waves) runs the attention
     qa_wait(ctr + 2, 4);
     qa_wait(ctr + 3, 4);
-    attn_core<NP, HD, MT, true>(Qs, Ks, Vt, Ps, o + (int64_t)seq * N * H + head * HD, N, nv, H, wid, lane, [&]() { qa_wait(ctr + 4, 4); });
+    auto wait_v = [&]() { qa_wait(ctr + 4, 4); };
+    attn_core<NP, HD, MT, true, decltype(wait_v), PAIR>(Qs, Ks, Vt, Ps, o + (int64_t)seq * N * H + head * HD, N, nv, H, wid, lane, wait_v, nv1);
     LL_QA_STAMP(7);
 }
 

@@ -264,6 +264,7 @@ template <typename T> static void launch_embed(DitEngine *e, hipStream_t st) {
                        e->x32.as<float>(), e->xa.as<T>(), e->step_ptr(), e->B, e->cfg.max_nodes, e->cfg.hidden);
 }
 static int g_attn_waves = 4;     // waves per (sequence, head) of attn_mfma_kernel (1 | 2 | 4; four only at head dimension 64)
+static int g_fuse_qkv_pair_wgs = 320, g_fuse_qkv_pair_max_wgs = 768;   // between these many (sequence, head) pairs two sequences share a workgroup (batch 11..24 at 16 heads)
 static int g_fuse_qkv_min_wgs = 64, g_fuse_qkv_max_wgs = 512;   // fuse_qkv_attn = -1: fuse when the launch has this many (sequence, head) workgroups
 
 template <int NP, int HD>
@@ -301,18 +302,31 @@ static bool qkv_attn_eligible(const DitEngine *e) {
     const int kc = std::min(H, N <= 32 ? 1024 : 512);                 // staged K chunk: 256 | 512 | 1024, dividing H
     return (kc == 256 || kc == 512 || kc == 1024) && H % kc == 0;
 }
-static bool qkv_attn_wanted(const DitEngine *e) {
-    if (e->wqkvp.p == nullptr || e->force_generic_attn || e->fuse_qkv_attn == 0) return false;
+// two sequences per workgroup (qkv_attn_kernel<64, 512, true>): graphs of <= 32 nodes, hidden a multiple of 512
+static bool qkv_attn_pair_eligible(const DitEngine *e) { return e->wqkvp.p != nullptr && e->cfg.max_nodes <= 32 && e->cfg.hidden % 512 == 0; }
+// 0 = the two launches, 1 = one (sequence, head) per workgroup, 2 = two sequences per workgroup
+static int qkv_attn_mode(const DitEngine *e) {
+    if (e->wqkvp.p == nullptr || e->force_generic_attn || e->fuse_qkv_attn == 0) return 0;
+    if (e->fuse_qkv_attn == 2) return qkv_attn_pair_eligible(e) ? 2 : 1;
+    if (e->fuse_qkv_attn == 1) return 1;
     // measured: a workgroup takes its 448 KB in at the per-CU rate whatever the batch, so below ~64 workgroups the
     // two launches with 192+ workgroups each are faster, and beyond two rounds of workgroups per CU what the 128-row tiles of the GEMM save
-    // exceeds what they save.  Next to another stream's kernels (overlap mode: the trajectory under the LLM decode) every launch costs
+    // exceeds what they save -- unless two sequences share a workgroup's weight stream (half the intake per sequence).
+    // Next to another stream's kernels (overlap mode: the trajectory under the LLM decode) every launch costs
     // the other stream a dispatch slot as well: fused from batch 1 (e2e 369.4 -> 366.9 ms per molecule).
     const int wgs = 2 * e->B * e->cfg.heads;
+    if (e->overlap) return 1;
     // up to 128 token rows the q|k|v projection runs on the all-in-flight panel kernels (gemm_m64 / gemm_m128), which beat the fused launch
     // (graphs of more than 32 nodes stage their 64-row panel in two K chunks: there the fused launch needs twice the workgroups to pay)
     const int min_wgs = e->cfg.max_nodes <= 32 ? g_fuse_qkv_min_wgs : 2 * g_fuse_qkv_min_wgs;
-    return e->fuse_qkv_attn == 1 || e->overlap || (e->M2 > 128 && wgs >= min_wgs && wgs <= g_fuse_qkv_max_wgs);
+    if (e->M2 <= 128 || wgs < min_wgs) return 0;
+    // measured, ms per step unfused / one / two sequences per workgroup: B=8 1.61 / 1.50 / 1.65, B=12 2.12 / 2.07 / 2.01, B=16 2.22 / 2.22 / 2.15,
+    // B=32 3.34 / 3.48 / 3.37
+    if (wgs <= g_fuse_qkv_pair_wgs) return 1;
+    if (qkv_attn_pair_eligible(e) && wgs <= g_fuse_qkv_pair_max_wgs) return 2;
+    return wgs <= g_fuse_qkv_max_wgs ? 1 : 0;
 }
+static bool qkv_attn_wanted(const DitEngine *e) { return qkv_attn_mode(e) != 0; }
 // MLP of the block on the packed-weight panel GEMM (gemm.hip gemm_xw_kernel): fc1 with K = H in one slice, fc2 split over K
 static int xw_slice(int K) { return K % 1024 == 0 ? 1024 : 512; }
 static bool xw_eligible(const DitEngine *e) {
@@ -332,7 +346,16 @@ static bool xw_fc2_wanted(const DitEngine *e) {
 static void launch_qkv_attn(DitEngine *e, int layer, hipStream_t st) {
     const DitEngine::BlockW &w = e->bw[layer];
     const int N = e->cfg.max_nodes;
-    const dim3 grid(2 * e->B * e->cfg.heads), blk(768);
+    const dim3 blk(768);
+    if (qkv_attn_mode(e) == 2) {
+        const dim3 grid(e->B * e->cfg.heads);
+        if (e->cfg.hidden % 512 == 0)
+            hipLaunchKernelGGL((qkv_attn_kernel<64, 512, true>), grid, blk, (QkvAttnGeom<64, 512>::lds_bytes()), st, e->xa.as<bf16_t>(),
+                               e->wqkvp.as<bf16_t>() + (size_t)layer * 3 * e->cfg.hidden * e->cfg.hidden, e->attn_o.as<bf16_t>(), w.qn_w, w.qn_b,
+                               w.kn_w, w.kn_b, e->n_nodes.as<int>(), e->B, N, e->cfg.hidden, e->cfg.heads);
+        return;
+    }
+    const dim3 grid(2 * e->B * e->cfg.heads);
     const int kc = std::min(e->cfg.hidden, N <= 32 ? 1024 : 512);     // K chunk of the token panel staged in LDS
 #define LL_QA(NP, KC)                                                                                                  \
     hipLaunchKernelGGL((qkv_attn_kernel<NP, KC>), grid, blk, (QkvAttnGeom<NP, KC>::lds_bytes()), st, e->xa.as<bf16_t>(),   \
@@ -608,6 +631,7 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
     CRH(hipFuncSetAttribute((const void *)attn_generic_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 #define LL_QA_ATTR(NP, KC) CRH(hipFuncSetAttribute((const void *)(qkv_attn_kernel<NP, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(QkvAttnGeom<NP, KC>::lds_bytes())))
     LL_QA_ATTR(32, 1024); LL_QA_ATTR(32, 512); LL_QA_ATTR(32, 256); LL_QA_ATTR(64, 512); LL_QA_ATTR(64, 256);
+    CRH(hipFuncSetAttribute((const void *)(qkv_attn_kernel<64, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(QkvAttnGeom<64, 512>::lds_bytes())));
 #undef LL_QA_ATTR
     CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<32, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<32, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -653,6 +677,7 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
     if (const char *v = getenv("LL_XW_FC2")) e->xw_fc2 = atoi(v) ? 1 : 0;
     e->force_generic_attn = getenv("LL_GENERIC_ATTN") != nullptr;
     if (const char *v = getenv("LL_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v);
+    if (const char *v = getenv("LL_FUSE_PAIR_WGS")) g_fuse_qkv_pair_wgs = atoi(v);
     if (const char *v = getenv("LL_STEPS_PER_GRAPH")) g_steps_per_graph = std::max(1, atoi(v));
     if (const char *ev = getenv("LL_STAGE_MOD")) g_stage_mod = atoi(ev) ? 1 : 0;      // A/B switch for bench runs
     CRH(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
@@ -1046,7 +1071,7 @@ int ll_dit_set_option(void *handle, int option, int value) {
             break;
         case LL_DIT_OPT_FUSED_QKV_ATTN:
             if (e->fuse_qkv_attn != value) drop_graph(e);
-            e->fuse_qkv_attn = value < 0 ? -1 : (value ? 1 : 0);
+            e->fuse_qkv_attn = value < 0 ? -1 : (value >= 2 ? 2 : value ? 1 : 0);
             break;
         case LL_DIT_OPT_XW_GEMM:
             if (e->xw_gemm != value) {

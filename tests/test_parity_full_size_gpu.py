@@ -208,7 +208,8 @@ def test_fused_qkv_attention_vs_separate_launches(N, H, heads, B):
     s = m.T - 1
     out = {}
     m.set_option("xw_gemm", 0)
-    for fused in (0, 1):
+    modes = (0, 1, 2) if N <= 32 and H % 512 == 0 else (0, 1)      # 2: two sequences per workgroup (graphs of <= 32 nodes)
+    for fused in modes:
         m.set_option("fused_qkv_attn", fused)
         lx, le, h = m.denoise_logits(s, tap_layer=2)
         out[fused] = (h.cpu(), lx.cpu(), le.cpu())
@@ -220,6 +221,14 @@ def test_fused_qkv_attention_vs_separate_launches(N, H, heads, B):
     err = float(((out[0][0] - out[1][0]) * valid).abs().max()) / scale
     lerr = max(float((out[0][1] - out[1][1]).abs().max()), float((out[0][2] - out[1][2]).abs().max()))
     lerr /= max(1.0, float(out[0][1].abs().max()), float(out[0][2].abs().max()))
+    if 2 in out:
+        assert torch.isfinite(out[2][0]).all() and torch.isfinite(out[2][1]).all() and torch.isfinite(out[2][2]).all()
+        err2 = float(((out[0][0] - out[2][0]) * valid).abs().max()) / scale
+        lerr2 = max(float((out[0][1] - out[2][1]).abs().max()), float((out[0][2] - out[2][2]).abs().max()))
+        lerr2 /= max(1.0, float(out[0][1].abs().max()), float(out[0][2].abs().max()))
+        print(f"fused qkv+attn (two sequences per workgroup) vs separate N={N} H={H}: hidden {err2:.3e} logits {lerr2:.3e}")
+        _report(f"fused_pair_qkv_attn_N{N}_H{H}", dict(hidden_rel=err2, logits_rel=lerr2))
+        assert err2 <= 1e-2 and lerr2 <= 1e-2, (err2, lerr2)
     print(f"fused qkv+attn vs separate N={N} H={H}: hidden {err:.3e} logits {lerr:.3e}")
     _report(f"fused_qkv_attn_N{N}_H{H}", dict(hidden_rel=err, logits_rel=lerr))
     assert err <= 1e-2 and lerr <= 1e-2, (err, lerr)
