@@ -1624,7 +1624,7 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
             return LL_OK;
         }
         if (g_gemm_variant != 0 && g_gemm_variant != 2 && !g_no_panel_gemm && M <= 64 && (kchunk == 256 || kchunk == 512 || kchunk == 1024) &&
-            (long)cdiv(N, 16) * splits >= 48) {
+            (long)cdiv(N, 16) * splits >= 8) {      // even 11 workgroups (the GraphDiT output layer, N = 176): 4.1 us against 6.5 us on the ring -- the phase is one round trip either way
             // one molecule's token panel (GraphDiT at batch 1, small GIN batches): everything in flight at once
             if (kchunk == 1024) LL_TRY((launch_m64<8>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));
             else if (kchunk == 512) LL_TRY((launch_m64<4>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));
