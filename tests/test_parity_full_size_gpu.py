@@ -213,6 +213,10 @@ def test_fused_qkv_attention_vs_separate_launches(N, H, heads, B):
         m.set_option("fused_qkv_attn", fused)
         lx, le, h = m.denoise_logits(s, tap_layer=2)
         out[fused] = (h.cpu(), lx.cpu(), le.cpu())
+    for fused in modes[1:]:          # run-to-run determinism of the fused launch (its waves hand over through LDS counters, not barriers)
+        m.set_option("fused_qkv_attn", fused)
+        lx, le, h = m.denoise_logits(s, tap_layer=2)
+        assert torch.equal(h.cpu(), out[fused][0]) and torch.equal(lx.cpu(), out[fused][1]) and torch.equal(le.cpu(), out[fused][2])
     m.set_option("fused_qkv_attn", -1)
     m.set_option("xw_gemm", -1)
     valid = (torch.arange(N).unsqueeze(0) < n_nodes.unsqueeze(1)).unsqueeze(0).unsqueeze(-1)      # [1,B,N,1]
