@@ -179,8 +179,12 @@ int ll_dit_set_overlap(void *handle, int on);
  * at 16 heads and 32 nodes -- two sequences per workgroup from batch 11 to 24 -- and always in overlap mode (default), 0 = never,
  * 1 = whenever eligible, 2 = two sequences per workgroup whenever eligible (graphs of <= 32 nodes);
  * LL_DIT_OPT_XW_GEMM = the block's MLP GEMMs on the packed-weight panel kernel (gemm_xw_kernel; bf16, hidden 512 | 1024): 1 = fc1
- * whenever eligible, 0 = never, -1 (default) = per device: ll_dit_begin times the MLP chain fc1 -> fc2 -> AdaLN epilogue with either kernel under
- * each GEMM once per batch size (>= 128 token rows) and keeps the fastest pair -- the LDS-DMA ring and the panel kernel trade places between MI355X boxes. */
+ * whenever eligible, 0 (default) = never: the kernels of a step are a pure function of (config, batch, options), so a seed fixes the
+ * molecules across processes and boxes; -1 = opt-in per-device calibration (also env LL_DIT_CALIBRATE=1): ll_dit_begin times the MLP
+ * chain fc1 -> fc2 -> AdaLN epilogue with either kernel under each GEMM once per batch size (>= 128 token rows) and keeps the fastest
+ * pair -- the LDS-DMA ring and the panel kernel trade places between MI355X boxes; the alternatives sum K in different orders, so
+ * with -1 low-order bits (and through a near-tie of the sampling race, molecules) may differ from run to run, and that ll_dit_begin
+ * blocks the host once per batch size. */
 enum { LL_DIT_OPT_OVERLAP = 0, LL_DIT_OPT_GENERIC_ATTN = 1, LL_DIT_OPT_FUSED_QKV_ATTN = 2, LL_DIT_OPT_XW_GEMM = 3 };
 int ll_dit_set_option(void *handle, int option, int value);
 int ll_dit_last_run_ms(void *handle, float *ms, int *steps);

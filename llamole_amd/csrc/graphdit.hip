@@ -144,7 +144,9 @@ struct DitEngine {
     DevBuf wfc1p, wfc2p;         // [depth][Hm x H], [depth][H x Hm]: the MLP weights packed the same way (gemm_m64_kernel, gemm_xw_kernel)
     DevBuf wprojp;               // [depth][H x H]
     std::vector<const void *> packed_keys;   // row-major weights registered with register_packed_weight
-    int xw_gemm = -1;            // fc1 / fc2 on gemm_xw_kernel: 1 = whenever eligible, 0 = never, -1 = whichever ll_dit_begin measured faster
+    int xw_gemm = 0;             // fc1 / fc2 on gemm_xw_kernel: 0 = never (the fixed default: a seed fixes the molecules on every box), 1 = whenever
+                                 // eligible, -1 = whichever ll_dit_begin measures faster on this device (opt-in: env LL_DIT_CALIBRATE=1 or
+                                 // ll_dit_set_option(LL_DIT_OPT_XW_GEMM, -1); the alternatives sum K in different orders, so the choice changes low-order bits)
     int splits_x = 1;            // split-K of fc2 on gemm_xw_kernel (K slices of 512 | 1024)
     int xw_fc2 = 0;              // with xw_gemm = 1: fc2 too (env LL_XW_FC2)
     int xw_cal_B = -1;           // batch the choice below was measured for (ll_dit_begin measures once per batch size)
@@ -673,6 +675,7 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
         }
         if (xw_eligible(e)) e->splits_x = Hm / xw_slice(Hm);
     }
+    if (const char *v = getenv("LL_DIT_CALIBRATE")) e->xw_gemm = atoi(v) ? -1 : 0;
     if (const char *v = getenv("LL_XW_GEMM")) e->xw_gemm = atoi(v);
     if (const char *v = getenv("LL_XW_FC2")) e->xw_fc2 = atoi(v) ? 1 : 0;
     e->force_generic_attn = getenv("LL_GENERIC_ATTN") != nullptr;
@@ -712,6 +715,9 @@ int ll_dit_destroy(void *handle) {
     return LL_OK;
 }
 
+// OPT-IN (xw_gemm == -1: env LL_DIT_CALIBRATE=1 or ll_dit_set_option(LL_DIT_OPT_XW_GEMM, -1)); by default the MLP GEMMs run the LDS-DMA ring
+// on every device, no stopwatch is consulted and ll_dit_begin never blocks the host -- a kernel choice made by timing would let the same seed
+// give different molecules in two processes (the alternatives accumulate K in different orders).
 // Which MLP GEMM kernels for this batch on THIS device?  The LDS-DMA ring and the packed-weight panel kernel trade places from one MI355X
 // box to the next (same image, same clocks reported): fc1 at 512 rows 11.4 vs 10.4 us on most, 16.7-19 vs 10.5 on some -- so the
 // engine times both once per batch size (one pass over every layer's weights per variant, ~4 ms in all) and keeps the fastest pair.
@@ -721,7 +727,10 @@ static int calibrate_mlp(DitEngine *e, hipStream_t st) {
     const int H = c.hidden, Hm = c.mlp_hidden, M2 = e->M2, dt = c.dtype;
     e->xw_cal_B = e->B;
     e->xw_fc1_auto = e->xw_fc2_auto = false;
-    if (e->xw_gemm != -1 || dt != LL_BF16 || e->wfc1p.p == nullptr || !xw_eligible(e) || M2 < 128) return LL_OK;
+    if (e->xw_gemm != -1 || dt != LL_BF16 || e->wfc1p.p == nullptr || !xw_eligible(e) || M2 < 128) {
+        for (float &u : e->cal_us) u = 0.f;      // nothing was timed for this batch
+        return LL_OK;
+    }
     auto hit = e->xw_cal_cache.find(e->B);
     if (hit != e->xw_cal_cache.end()) {
         e->xw_fc1_auto = hit->second.first;
@@ -729,6 +738,7 @@ static int calibrate_mlp(DitEngine *e, hipStream_t st) {
         return LL_OK;
     }
     const int64_t slab = (int64_t)e->M2p * H;
+    PanelScope panel(e);      // time the kernels the run will use (overlap mode keeps <= 64-row panels off gemm_m64_kernel)
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), 0, e->seed_ptr(), 0ull);
     auto timeit = [&](auto &&fn, float &us) -> int {
         for (int i = 0; i < 2; ++i) LL_TRY(fn(i % c.depth));

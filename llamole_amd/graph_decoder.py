@@ -388,13 +388,15 @@ class GraphDiT(nn.Module):
         _lib.check(lib.ll_dit_run(self._handle, C.c_uint64(seed), mode, _lib.current_stream_ptr()), "ll_dit_run")
 
     def mlp_choice(self) -> dict:
-        """Which kernels the block MLP runs on this device at the current batch, and the calibration timings behind it (us per
-        fc1 -> fc2 -> AdaLN chain by fc1 / fc2 kernel)
+        """Which kernels the block MLP runs at the current batch.  Default: the LDS-DMA ring under both GEMMs on every device
+        (``calibrated`` False, no timings) -- the kernels of a step are a pure function of (config, batch, options), so a seed
+        fixes the molecules.  With the opt-in per-device calibration (``set_option("xw_gemm", -1)`` / env LL_DIT_CALIBRATE=1):
+        the timings behind the choice, us per fc1 -> fc2 -> AdaLN chain by fc1 / fc2 kernel
         (include/llamole_hip.h: ll_dit_mlp_choice)."""
         us = (C.c_float * 4)()
         a, b = C.c_int(), C.c_int()
         _lib.check(_lib.load().ll_dit_mlp_choice(self._handle, us, C.byref(a), C.byref(b)), "ll_dit_mlp_choice")
-        return {"fc1": "panel" if a.value else "ring", "fc2": "panel" if b.value else "ring",
+        return {"fc1": "panel" if a.value else "ring", "fc2": "panel" if b.value else "ring", "calibrated": max(us) > 0,
                 "chain_us": {"ring/ring": round(us[0], 2), "panel/ring": round(us[1], 2), "ring/panel": round(us[2], 2),
                              "panel/panel": round(us[3], 2)}}
 

@@ -251,13 +251,16 @@ def posterior(spec: DitSpec, logX, logE, X_t, E_t, s_int: int):
     return prX, prE
 
 
-def guided_probs(sd, spec: DitSpec, X_t, E_t, mask, y, txt, s_int: int):
-    """reference diffusion_model.py:309-382: cond + uncond passes, CFG combine, renormalise."""
+def guided_probs(sd, spec: DitSpec, X_t, E_t, mask, y, txt, s_int: int, return_logits: bool = False):
+    """reference diffusion_model.py:309-382: cond + uncond passes, CFG combine, renormalise.
+    ``return_logits``: also return the denoiser outputs ``(lx, le, ux, ue)`` behind the probabilities (ux / ue are None
+    without guidance) -- same arithmetic, for tests that compare logits and probabilities of one step."""
     B = X_t.shape[0]
     t = torch.full((B, 1), float(s_int), dtype=torch.float32)
     t = (t + 1) / spec.T
     lx, le = denoiser(sd, spec, X_t, E_t, mask, y, txt, t, uncond=False)
     pX, pE = posterior(spec, lx, le, X_t, E_t, s_int)
+    ux = ue = None
     if spec.guide_scale is not None and spec.guide_scale != 1:
         ux, ue = denoiser(sd, spec, X_t, E_t, mask, y, txt, t, uncond=True)
         uX, uE = posterior(spec, ux, ue, X_t, E_t, s_int)
@@ -265,6 +268,8 @@ def guided_probs(sd, spec: DitSpec, X_t, E_t, mask, y, txt, s_int: int):
         pE = uE * (pE / uE.clamp_min(1e-5)) ** spec.guide_scale
         pX = pX / pX.sum(dim=-1, keepdim=True).clamp_min(1e-5)
         pE = pE / pE.sum(dim=-1, keepdim=True).clamp_min(1e-5)
+    if return_logits:
+        return pX, pE, (lx, le, ux, ue)
     return pX, pE
 
 
@@ -337,17 +342,23 @@ def sample_n_nodes(spec: DitSpec, batch: int, generator=None) -> torch.Tensor:
 
 
 def generate(sd, spec: DitSpec, y, txt, n_nodes, noise_fn: Callable[[int], Tuple[torch.Tensor, torch.Tensor]],
-             no_label_index: float = -200.0, trace_every: int = 0):
+             no_label_index: float = -200.0, trace_every: int = 0, step_hook=None):
     """reference diffusion_model.py:252-304 up to the integer graphs (the rdkit tail,
     molecule_utils.py:49-111, is host chemistry and not part of the oracle).
-    ``noise_fn(step)`` returns (qx, qe); step == T is the initial z_T draw, then T-1 .. 0."""
+    ``noise_fn(step)`` returns (qx, qe); step == T is the initial z_T draw, then T-1 .. 0.
+    ``step_hook(s_int, X_t, E_t, pX, pE, logits)`` (tests): sees every step's input state, guided probabilities and the
+    denoiser outputs behind them."""
     y = torch.where(y == no_label_index, torch.tensor(float("nan")), y)
     B = y.shape[0]
     mask = torch.arange(spec.N).unsqueeze(0).expand(B, -1) < n_nodes.unsqueeze(1)
     X, E = initial_state(spec, mask, *noise_fn(spec.T))
     trace = {}
     for s_int in reversed(range(spec.T)):
-        pX, pE = guided_probs(sd, spec, X, E, mask, y, txt, s_int)
+        if step_hook is not None:
+            pX, pE, logits = guided_probs(sd, spec, X, E, mask, y, txt, s_int, return_logits=True)
+            step_hook(s_int, X, E, pX, pE, logits)
+        else:
+            pX, pE = guided_probs(sd, spec, X, E, mask, y, txt, s_int)
         Xs, Es = sample_features(pX, pE, mask, *noise_fn(s_int))
         X, E = to_onehot_masked(Xs, Es, mask)
         if trace_every and s_int % trace_every == 0:

@@ -1,0 +1,74 @@
+"""A seed fixes the molecules -- across PROCESSES, not only inside one.
+
+Round 2 picked the block-MLP GEMM kernels by a stopwatch inside ll_dit_begin (won by 0.07 us in one recorded run); the
+alternatives sum K in different orders, so two processes with the same seed could sample different graphs.  The engine's
+kernels are now a pure function of (config, batch, options); the calibration is opt-in.  Here two FRESH processes build the
+benchmarked bf16 engine (ref-default denoiser, B = 8), run the same seeded trajectory -- queued launches, the hipGraph replay
+and the overlap-mode replay -- and must print identical digests of every sampled graph.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import hashlib, json, sys, types
+import torch
+sys.path.insert(0, %(root)r)
+import bench
+from llamole_amd import synth
+torch.cuda.set_device(0)
+args = types.SimpleNamespace(hidden=1024, depth=28, heads=16, T=50, guide=2.0, nodes=32, dtype="bf16")
+m, cfg, meta, sd = bench.build_model(args, torch.device("cuda", 0))
+out = {}
+for B in (8, 16):
+    props, text, _ = synth.make_dit_inputs(B, seed=3, max_node=32)
+    n_nodes = torch.tensor(([32, 32, 17, 5, 32, 2, 29, 32] * 2)[:B])
+    for mode, kw in (("launches", dict(use_graph=False)), ("graph", dict(use_graph=True)), ("overlap", None)):
+        torch.manual_seed(5)            # z_T is drawn from torch's CPU generator (the reference's draw order)
+        if kw is None:
+            pend = m.generate_graphs_async(props, text, -200.0, n_nodes=n_nodes, seed=77)
+            mols, _ = pend.result()
+        else:
+            mols, _ = m.generate_graphs(props, text, -200.0, n_nodes=n_nodes, seed=77, **kw)
+        h = hashlib.sha256()
+        for a, e in mols:
+            h.update(a.cpu().numpy().tobytes()); h.update(e.cpu().numpy().tobytes())
+        out[f"B{B}_{mode}"] = h.hexdigest()
+    out[f"B{B}_mlp"] = m.mlp_choice()
+print("DIGEST " + json.dumps(out, sort_keys=True))
+"""
+
+
+def _run_worker():
+    env = dict(os.environ)
+    for k in ("LL_DIT_CALIBRATE", "LL_XW_GEMM"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("DIGEST ")][-1]
+    return json.loads(line[len("DIGEST "):])
+
+
+def test_same_seed_same_molecules_in_two_fresh_processes():
+    a = _run_worker()
+    b = _run_worker()
+    assert a == b, (a, b)
+    for B in (8, 16):
+        ch = a[f"B{B}_mlp"]
+        assert ch["fc1"] == "ring" and ch["fc2"] == "ring" and ch["calibrated"] is False, ch
+        # queued launches and the hipGraph replay run the same kernels on the same data: same graphs
+        assert a[f"B{B}_launches"] == a[f"B{B}_graph"]
+    try:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "r3_determinism.json"), "w") as f:
+            json.dump({"process_1": a, "process_2": b, "identical": a == b}, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
