@@ -134,6 +134,11 @@ int linear_launch(int dtype, const void *A, int lda, const void *W, int ldw, con
 int linear_splitk_launch(int dtype, const void *A, int lda, const void *W, int ldw, float *Cslabs, int ldc,
                          int64_t slab_stride, int M, int N, int K, int splits, hipStream_t stream);
 
+// two row groups in one launch: rows [0, m_split) x W1 (+ bias1), rows [m_split, M) x W2 (+ bias2); m_split % 64 == 0 (gemm.hip)
+int linear_grouped2_launch(int dtype, const void *A, int lda, const void *W1, const void *W2, int ldw, const float *bias1,
+                           const float *bias2, void *C, int ldc, int M, int m_split, int N, int K, int splits, int64_t slab_stride,
+                           int epi, int out_f32, hipStream_t stream);
+
 int convert_f32_to_bf16(const float *src, bf16_t *dst, int64_t n, hipStream_t stream);
 
 // [Nout, K] bf16 weight -> MFMA A-operand order (fragment blocks of 16 rows x 32 k, 1 KB contiguous each, row-tile major); and the

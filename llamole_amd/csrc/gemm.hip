@@ -314,11 +314,9 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipe_kernel(const bf16_
 // The same kernel with the tile's DMA pieces dealt to the waves from ONE list over both operands (round 2: lets sixteen-wave
 // workgroups run tiles whose operands have fewer than 16 pieces, e.g. 64 x 64).
 template <int BM, int BN, int WM, int WN, int STAGES, typename OutT>
-__global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipeu_kernel(const bf16_t *__restrict__ A, int lda,
-                                                                      const bf16_t *__restrict__ W, int ldw,
-                                                                      OutT *__restrict__ C, int ldc,
-                                                                      const float *__restrict__ bias, int M, int N,
-                                                                      int kchunk, int64_t slab_stride, int epi, int krot) {
+__device__ __forceinline__ void pipeu_tile(unsigned char *smem_pipeu, const bf16_t *__restrict__ A, int lda,
+                                           const bf16_t *__restrict__ W, int ldw, OutT *__restrict__ C, int ldc,
+                                           const float *__restrict__ bias, int M, int N, int kchunk, int64_t slab_stride, int epi) {
     constexpr int NW = WM * WN;
     constexpr int BK = 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -328,7 +326,6 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipeu_kernel(const bf16
     constexpr int STAGE_BYTES = (BM + BN) * 128;   // waves than an operand has pieces -- 16 waves on a 64-row operand -- still balance)
     static_assert(PIECES % NW == 0 && LPT >= 1, "the tile's DMA pieces must divide over the waves");
     static_assert((STAGES - 2) * LPT <= 63, "vmcnt immediate overflow");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pipeu[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -337,7 +334,6 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipeu_kernel(const bf16
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * kchunk;
     const int nk = kchunk / BK;
-    (void)krot;
 
     const bf16_t *src[LPT];
     int dst[LPT];
@@ -430,6 +426,31 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipeu_kernel(const bf16
             }
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, typename OutT>
+__global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipeu_kernel(const bf16_t *__restrict__ A, int lda,
+                                                                      const bf16_t *__restrict__ W, int ldw,
+                                                                      OutT *__restrict__ C, int ldc,
+                                                                      const float *__restrict__ bias, int M, int N,
+                                                                      int kchunk, int64_t slab_stride, int epi, int krot) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pipeu[];
+    (void)krot;
+    pipeu_tile<BM, BN, WM, WN, STAGES, OutT>(smem_pipeu, A, lda, W, ldw, C, ldc, bias, M, N, kchunk, slab_stride, epi);
+}
+
+// Two row groups in ONE launch (round 3, the GIN layer: the node rows and the per-graph virtual-node rows go through MLPs of the same
+// shape with different weights): M-tiles starting at row >= m_split multiply by (W2, bias2), the others by (W, bias); same N, K, epilogue.
+template <int BM, int BN, int WM, int WN, int STAGES, typename OutT>
+__global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_pipeu2_kernel(const bf16_t *__restrict__ A, int lda,
+                                                                       const bf16_t *__restrict__ W, const bf16_t *__restrict__ W2, int ldw,
+                                                                       OutT *__restrict__ C, int ldc,
+                                                                       const float *__restrict__ bias, const float *__restrict__ bias2,
+                                                                       int M, int m_split, int N, int kchunk, int64_t slab_stride, int epi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pipeu2[];
+    const bool second = (int)blockIdx.y * BM >= m_split;      // uniform per workgroup
+    pipeu_tile<BM, BN, WM, WN, STAGES, OutT>(smem_pipeu2, A, lda, second ? W2 : W, ldw, C, ldc, second ? bias2 : bias, M, N, kchunk,
+                                             slab_stride, epi);
 }
 
 // ------------------------------------------------------------------------------------------ bf16 MFMA, skinny M
@@ -770,6 +791,31 @@ static int launch_pipeu(const bf16_t *A, int lda, const bf16_t *W, int ldw, void
     else
         hipLaunchKernelGGL((gemm_bf16_pipeu_kernel<BM, BN, WM, WN, STAGES, bf16_t>), grid, block, lds, s, A, lda, W, ldw,
                            (bf16_t *)C, ldc, bias, M, N, kchunk, slab_stride, epi, 0);
+    return LL_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+static int launch_pipeu2(const bf16_t *A, int lda, const bf16_t *W, const bf16_t *W2, int ldw, void *C, int ldc, const float *bias,
+                         const float *bias2, int M, int m_split, int N, int K, int splits, int64_t slab_stride, int epi, int out_f32,
+                         hipStream_t s) {
+    constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_bf16_pipeu2_kernel<BM, BN, WM, WN, STAGES, float>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)gemm_bf16_pipeu2_kernel<BM, BN, WM, WN, STAGES, bf16_t>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), splits);
+    dim3 block(WM * WN * 64);
+    const int kchunk = K / splits;
+    if (out_f32)
+        hipLaunchKernelGGL((gemm_bf16_pipeu2_kernel<BM, BN, WM, WN, STAGES, float>), grid, block, lds, s, A, lda, W, W2, ldw,
+                           (float *)C, ldc, bias, bias2, M, m_split, N, kchunk, slab_stride, epi);
+    else
+        hipLaunchKernelGGL((gemm_bf16_pipeu2_kernel<BM, BN, WM, WN, STAGES, bf16_t>), grid, block, lds, s, A, lda, W, W2, ldw,
+                           (bf16_t *)C, ldc, bias, bias2, M, m_split, N, kchunk, slab_stride, epi);
     return LL_OK;
 }
 
@@ -1735,6 +1781,33 @@ int linear_launch(int dtype, const void *A, int lda, const void *W, int ldw, con
 int linear_splitk_launch(int dtype, const void *A, int lda, const void *W, int ldw, float *Cslabs, int ldc,
                          int64_t slab_stride, int M, int N, int K, int splits, hipStream_t stream) {
     return gemm_dispatch(dtype, A, lda, W, ldw, nullptr, Cslabs, ldc, M, N, K, splits, slab_stride, EPI_NONE, 1, stream);
+}
+
+// Two row groups, one launch: rows [0, m_split) x W1 (+ bias1), rows [m_split, M) x W2 (+ bias2); m_split a multiple of 64; same N, K for
+// both.  splits > 1: f32 slabs C[z][M][ldc], no bias / epilogue (the consumer sums the slabs in order).  bf16: 64 x 64 tiles on sixteen
+// waves (gemm_bf16_pipeu2_kernel); f32: the two groups as two launches of the generic kernel.
+int linear_grouped2_launch(int dtype, const void *A, int lda, const void *W1, const void *W2, int ldw, const float *bias1,
+                           const float *bias2, void *C, int ldc, int M, int m_split, int N, int K, int splits, int64_t slab_stride,
+                           int epi, int out_f32, hipStream_t stream) {
+    LL_CHECK(M > 0 && N > 0 && K > 0 && splits >= 1 && K % splits == 0, "linear_grouped2: bad problem M=%d N=%d K=%d splits=%d", M, N, K, splits);
+    LL_CHECK(m_split % 64 == 0 && m_split > 0, "linear_grouped2: m_split=%d must be a positive multiple of 64", m_split);
+    if (M <= m_split || W2 == nullptr) return gemm_dispatch(dtype, A, lda, W1, ldw, splits > 1 ? nullptr : bias1, C, ldc, std::min(M, m_split), N, K,
+                                                           splits, slab_stride, splits > 1 ? (int)EPI_NONE : epi, splits > 1 ? 1 : out_f32, stream);
+    if (dtype == LL_BF16) {
+        const int kchunk = K / splits;
+        LL_CHECK(kchunk % 64 == 0 && lda % 8 == 0 && ldw % 8 == 0, "linear_grouped2(bf16): K per split (%d) must be a multiple of 64, lda/ldw of 8", kchunk);
+        LL_TRY((launch_pipeu2<64, 64, 4, 4, 4>((const bf16_t *)A, lda, (const bf16_t *)W1, (const bf16_t *)W2, ldw, C, ldc,
+                                              splits > 1 ? nullptr : bias1, splits > 1 ? nullptr : bias2, M, m_split, N, K, splits, slab_stride,
+                                              splits > 1 ? (int)EPI_NONE : epi, splits > 1 ? 1 : out_f32, stream)));
+        LL_LAUNCH_CHECK();
+        return LL_OK;
+    }
+    const size_t esz = 4, osz = 4;      // f32 operands, f32 output
+    LL_TRY(gemm_dispatch(dtype, A, lda, W1, ldw, splits > 1 ? nullptr : bias1, C, ldc, m_split, N, K, splits, slab_stride,
+                         splits > 1 ? (int)EPI_NONE : epi, 1, stream));
+    return gemm_dispatch(dtype, (const char *)A + (size_t)m_split * lda * esz, lda, W2, ldw, splits > 1 ? nullptr : bias2,
+                         (char *)C + (size_t)m_split * ldc * osz, ldc, M - m_split, N, K, splits, slab_stride,
+                         splits > 1 ? (int)EPI_NONE : epi, 1, stream);
 }
 
 __global__ void cvt_f32_bf16_kernel(const float *__restrict__ src, bf16_t *__restrict__ dst, int64_t n) {

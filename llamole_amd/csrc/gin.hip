@@ -93,16 +93,6 @@ static int gin_check(const LLGinConfig *c) {
 }
 
 // ------------------------------------------------------------------------------------------ kernels
-// h0 = atom_encoder[x]
-__global__ __launch_bounds__(256) void gin_embed_kernel(const int *__restrict__ x, const float *__restrict__ emb,
-                                                         float *__restrict__ h, int n, int H) {
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (v >= n) return;
-    const int lane = threadIdx.x & 63;
-    const float *r = emb + (int64_t)x[v] * H;
-    for (int k = lane; k < H; k += 64) h[(int64_t)v * H + k] = r[k];
-}
-
 // One wave per destination node:
 //   h_in[v] = h[v] + vn[batch[v]]
 //   z0[v]   = (1+eps) h_in[v] + sum_{e: dst(e)=v} GELU(h_in[src(e)] + bond_emb[attr(e)])
@@ -117,62 +107,17 @@ template <> __device__ __forceinline__ void gin_store4<bf16_t>(bf16_t *p, float4
 }
 __device__ __forceinline__ float4 gelu4(float4 v) { return make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)); }
 
-template <typename T>
-__global__ __launch_bounds__(64) void gin_aggregate_kernel(const float *__restrict__ h, const float *__restrict__ vn,
-                                                            const int *__restrict__ batch,
-                                                            const int *__restrict__ rowptr, const int *__restrict__ src,
-                                                            const int *__restrict__ attr, const float *__restrict__ bond,
-                                                            const float *__restrict__ eps, float *__restrict__ h_in,
-                                                            T *__restrict__ z0, int n, int H) {
-    const int v = blockIdx.x;   // one wave = one destination node = one workgroup
-    if (v >= n) return;
-    const int lane = threadIdx.x;
-    const float *vr = vn + (int64_t)batch[v] * H;
-    const float e1 = 1.f + eps[0];
-    const int e0 = rowptr[v], e_end = rowptr[v + 1];
-    // the wave's edge list (molecular graphs: degree <= ~6) is read once by the first lanes and broadcast
-    const int my_e = e0 + lane;
-    const int my_src = my_e < e_end ? src[my_e] : 0;
-    const int my_att = my_e < e_end ? attr[my_e] : 0;
-    for (int k = lane * 4; k < H; k += 256) {
-        const float4 vk = *reinterpret_cast<const float4 *>(vr + k);
-        float4 hv = *reinterpret_cast<const float4 *>(h + (int64_t)v * H + k);
-        hv.x += vk.x; hv.y += vk.y; hv.z += vk.z; hv.w += vk.w;
-        float4 agg = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int eb = e0; eb < e_end; eb += 4) {       // 4 neighbour rows in flight
-            float4 hn[4], bn[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = eb + u;
-                const bool ok = e < e_end;
-                const int sidx = __builtin_amdgcn_readlane(my_src, ok ? (e - e0) & 63 : 0);   // uniform index
-                const int aidx = __builtin_amdgcn_readlane(my_att, ok ? (e - e0) & 63 : 0);
-                const int sv = (e - e0) < 64 ? sidx : src[ok ? e : e0];
-                const int av = (e - e0) < 64 ? aidx : attr[ok ? e : e0];
-                hn[u] = ok ? *reinterpret_cast<const float4 *>(h + (int64_t)sv * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-                bn[u] = ok ? *reinterpret_cast<const float4 *>(bond + (int64_t)av * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (eb + u < e_end) {
-                    const float4 m = gelu4(make_float4(hn[u].x + vk.x + bn[u].x, hn[u].y + vk.y + bn[u].y,
-                                                       hn[u].z + vk.z + bn[u].z, hn[u].w + vk.w + bn[u].w));
-                    agg.x += m.x; agg.y += m.y; agg.z += m.z; agg.w += m.w;
-                }
-            }
-        }
-        *reinterpret_cast<float4 *>(h_in + (int64_t)v * H + k) = hv;
-        gin_store4<T>(z0 + (int64_t)v * H + k, make_float4(e1 * hv.x + agg.x, e1 * hv.y + agg.y, e1 * hv.z + agg.z, e1 * hv.w + agg.w));
-    }
-}
-
 // out[r] = act(LayerNorm_affine(in[r]))  -> operand dtype.  One wave per row, any C.
+// Second row group (round 3: node rows and virtual-node rows of a GIN layer in one launch): rows [0, n1) take (w, b), rows [n1, r2) are
+// padding and skipped, rows [r2, R) take (w2, b2); n1 = r2 = R for a plain call.
 template <typename T>
 __global__ __launch_bounds__(64) void rows_ln_act_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                           const float *__restrict__ b, T *__restrict__ out, int R,
-                                                          int C, int gelu) {
+                                                          int C, int gelu, int n1, int r2, const float *__restrict__ w2,
+                                                          const float *__restrict__ b2) {
     const int r = blockIdx.x;   // one wave = one row = one workgroup
-    if (r >= R) return;
+    if (r >= R || (r >= n1 && r < r2)) return;
+    if (r >= r2) { w = w2; b = b2; }
     const int lane = threadIdx.x;
     const float *x = in + (int64_t)r * C;
     constexpr int MAXE = 32;   // float4 chunks per lane: C <= 8192
@@ -214,10 +159,12 @@ __global__ __launch_bounds__(64) void rows_ln_act_kernel(const float *__restrict
 template <typename T, int WAVES, int CH>
 __global__ __launch_bounds__(64 * WAVES) void rows_ln_act_mw_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                                     const float *__restrict__ b, T *__restrict__ out, int R, int C,
-                                                                    int gelu) {
+                                                                    int gelu, int n1, int r2, const float *__restrict__ w2,
+                                                                    const float *__restrict__ b2) {
     __shared__ float part[2][WAVES];
     const int r = blockIdx.x;
-    if (r >= R) return;
+    if (r >= R || (r >= n1 && r < r2)) return;
+    if (r >= r2) { w = w2; b = b2; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *x = in + (int64_t)r * C;
     float4 v[CH], ww[CH], bb[CH];
@@ -262,44 +209,197 @@ __global__ __launch_bounds__(64 * WAVES) void rows_ln_act_mw_kernel(const float 
 }
 
 template <typename T>
-static void launch_rows_ln_act(const float *in, const float *w, const float *b, T *out, int R, int C, int gelu, hipStream_t st) {
+static void launch_rows_ln_act2(const float *in, const float *w, const float *b, T *out, int R, int C, int gelu, int n1, int r2,
+                                const float *w2, const float *b2, hipStream_t st) {
+#define LL_RLA(W, CH, BLK) hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, W, CH>), dim3(R), dim3(BLK), 0, st, in, w, b, out, R, C, gelu, n1, r2, w2, b2)
     if (C % 1024 == 0 && C / 1024 <= 4) {            // 4 waves per row, 1..4 float4 per lane
         switch (C / 1024) {
-            case 1: hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, 4, 1>), dim3(R), dim3(256), 0, st, in, w, b, out, R, C, gelu); return;
-            case 2: hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, 4, 2>), dim3(R), dim3(256), 0, st, in, w, b, out, R, C, gelu); return;
-            case 3: hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, 4, 3>), dim3(R), dim3(256), 0, st, in, w, b, out, R, C, gelu); return;
-            default: hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, 4, 4>), dim3(R), dim3(256), 0, st, in, w, b, out, R, C, gelu); return;
+            case 1: LL_RLA(4, 1, 256); return;
+            case 2: LL_RLA(4, 2, 256); return;
+            case 3: LL_RLA(4, 3, 256); return;
+            default: LL_RLA(4, 4, 256); return;
         }
     }
     if (C % 256 == 0 && C / 256 <= 3) {              // narrow rows (H = 64 .. 192 -> 4H = 256 .. 768): one wave, loads up front
         switch (C / 256) {
-            case 1: hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, 1, 1>), dim3(R), dim3(64), 0, st, in, w, b, out, R, C, gelu); return;
-            case 2: hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, 1, 2>), dim3(R), dim3(64), 0, st, in, w, b, out, R, C, gelu); return;
-            default: hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, 1, 3>), dim3(R), dim3(64), 0, st, in, w, b, out, R, C, gelu); return;
+            case 1: LL_RLA(1, 1, 64); return;
+            case 2: LL_RLA(1, 2, 64); return;
+            default: LL_RLA(1, 3, 64); return;
         }
     }
-    hipLaunchKernelGGL((rows_ln_act_kernel<T>), dim3(R), dim3(64), 0, st, in, w, b, out, R, C, gelu);
+#undef LL_RLA
+    hipLaunchKernelGGL((rows_ln_act_kernel<T>), dim3(R), dim3(64), 0, st, in, w, b, out, R, C, gelu, n1, r2, w2, b2);
+}
+template <typename T>
+static void launch_rows_ln_act(const float *in, const float *w, const float *b, T *out, int R, int C, int gelu, hipStream_t st) {
+    launch_rows_ln_act2<T>(in, w, b, out, R, C, gelu, R, R, nullptr, nullptr, st);
 }
 
-// Layer tail.  Encoder: z = LN_affine(z); predictor: z = LN0(z) * (1 + scale) + shift, residual gated.
+// Layer tail (gin_post2_kernel below).  Encoder: z = LN_affine(z); predictor: z = LN0(z) * (1 + scale) + shift, residual gated.
 //   if not last: z = GELU(z);  h = (gate *) z + h_in         (model.py:137-145 / predictor :331-340)
-__global__ __launch_bounds__(64) void gin_post_kernel(const float *__restrict__ z, const float *__restrict__ h_in,
-                                                       const float *__restrict__ lnw, const float *__restrict__ lnb,
-                                                       const float *__restrict__ mod /*[G][3H] or null*/,
-                                                       const int *__restrict__ batch, float *__restrict__ h, int n,
-                                                       int H, int gelu) {
-    const int v = blockIdx.x;
+// ---- round 3: the layer as FIVE launches (aggregate | Linear | LayerNorm+GELU | Linear | tail), the virtual-node MLP riding in the same
+// launches as a second row group.  What made that possible: max_v (h[v] + vn[g]) == max_v h[v] + vn[g] exactly (rounding is monotone),
+// so the pooled input of the virtual-node MLP depends only on the INPUTS of the aggregation launch and extra workgroups of that launch
+// can produce it; everything downstream (Linear -> LN+GELU -> Linear -> += ) has the node MLP's shape with other weights.
+
+// h0 = atom_encoder[x], vn0 = virtual-node embedding row, csilu = SiLU(c or text_dropping row): one launch instead of three
+template <typename T>
+__global__ __launch_bounds__(256) void gin_prologue_kernel(const int *__restrict__ x, const float *__restrict__ emb,
+                                                            const float *__restrict__ vemb, const float *__restrict__ c,
+                                                            const float *__restrict__ drop, float *__restrict__ h, float *__restrict__ vn,
+                                                            T *__restrict__ csilu, int n, int G, int H, int D) {
+    const int H4 = H / 4, D4 = D / 4;
+    const int64_t n4 = (int64_t)n * H4, g4 = (int64_t)G * H4, c4 = csilu ? (int64_t)G * D4 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4 + g4 + c4; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n4) {
+            const int v = (int)(i / H4), k = (int)(i % H4) * 4;
+            *reinterpret_cast<float4 *>(h + (int64_t)v * H + k) = *reinterpret_cast<const float4 *>(emb + (int64_t)x[v] * H + k);
+        } else if (i < n4 + g4) {
+            const int64_t j = i - n4;
+            *reinterpret_cast<float4 *>(vn + j * 4) = *reinterpret_cast<const float4 *>(vemb + (j % H4) * 4);
+        } else {
+            const int64_t j = i - n4 - g4;
+            const float4 v = c ? *reinterpret_cast<const float4 *>(c + j * 4) : *reinterpret_cast<const float4 *>(drop + (j % D4) * 4);
+            gin_store4<T>(csilu + j * 4, make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w)));
+        }
+    }
+}
+
+// Workgroups [0, nbn): four waves = four destination nodes, each as in gin_aggregate_kernel.  Workgroups [nbn, ...): (graph g, 256-feature
+// chunk): pool[g] = max over the graph's nodes of h[v], + vn[g]  (== segment max of h_in, model.py:147-148) in operand dtype -- the A rows
+// of the virtual-node MLP; the four waves take every fourth node with eight rows in flight, partial maxima meet in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void gin_aggregate2_kernel(const float *__restrict__ h, const float *__restrict__ vn,
+                                                             const int *__restrict__ batch, const int *__restrict__ rowptr,
+                                                             const int *__restrict__ src, const int *__restrict__ attr,
+                                                             const float *__restrict__ bond, const float *__restrict__ eps,
+                                                             float *__restrict__ h_in, T *__restrict__ z0, const int *__restrict__ gptr,
+                                                             T *__restrict__ pool, int n, int H, int nbn) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)blockIdx.x >= nbn) {
+        __shared__ float4 red[4][64];
+        const int pb = blockIdx.x - nbn, chunks = (H + 255) / 256;
+        const int g = pb / chunks, k = (pb % chunks) * 256 + lane * 4;
+        const int v0 = gptr[g], v1 = gptr[g + 1];
+        float4 acc = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (k < H) {
+            for (int vb = v0 + wave; vb < v1; vb += 32) {
+                float4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    t[u] = (vb + 4 * u < v1) ? *reinterpret_cast<const float4 *>(h + (int64_t)(vb + 4 * u) * H + k)
+                                             : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc.x = fmaxf(acc.x, t[u].x); acc.y = fmaxf(acc.y, t[u].y); acc.z = fmaxf(acc.z, t[u].z); acc.w = fmaxf(acc.w, t[u].w);
+                }
+            }
+        }
+        red[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && k < H) {
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 o = red[w][lane];
+                acc.x = fmaxf(acc.x, o.x); acc.y = fmaxf(acc.y, o.y); acc.z = fmaxf(acc.z, o.z); acc.w = fmaxf(acc.w, o.w);
+            }
+            const float4 vk = *reinterpret_cast<const float4 *>(vn + (int64_t)g * H + k);
+            gin_store4<T>(pool + (int64_t)g * H + k, make_float4(acc.x + vk.x, acc.y + vk.y, acc.z + vk.z, acc.w + vk.w));
+        }
+        return;
+    }
+    const int v = blockIdx.x * 4 + wave;   // one wave = one destination node
     if (v >= n) return;
+    const float *vr = vn + (int64_t)batch[v] * H;
+    const float e1 = 1.f + eps[0];
+    const int e0 = rowptr[v], e_end = rowptr[v + 1];
+    // the wave's edge list (molecular graphs: degree <= ~6) is read once by the first lanes and broadcast
+    const int my_e = e0 + lane;
+    const int my_src = my_e < e_end ? src[my_e] : 0;
+    const int my_att = my_e < e_end ? attr[my_e] : 0;
+    for (int k = lane * 4; k < H; k += 256) {
+        const float4 vk = *reinterpret_cast<const float4 *>(vr + k);
+        float4 hv = *reinterpret_cast<const float4 *>(h + (int64_t)v * H + k);
+        hv.x += vk.x; hv.y += vk.y; hv.z += vk.z; hv.w += vk.w;
+        float4 agg = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int eb = e0; eb < e_end; eb += 4) {       // 4 neighbour rows in flight
+            float4 hn[4], bn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = eb + u;
+                const bool ok = e < e_end;
+                const int sidx = __builtin_amdgcn_readlane(my_src, ok ? (e - e0) & 63 : 0);   // uniform index
+                const int aidx = __builtin_amdgcn_readlane(my_att, ok ? (e - e0) & 63 : 0);
+                const int sv = (e - e0) < 64 ? sidx : src[ok ? e : e0];
+                const int av = (e - e0) < 64 ? aidx : attr[ok ? e : e0];
+                hn[u] = ok ? *reinterpret_cast<const float4 *>(h + (int64_t)sv * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bn[u] = ok ? *reinterpret_cast<const float4 *>(bond + (int64_t)av * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (eb + u < e_end) {
+                    const float4 m = gelu4(make_float4(hn[u].x + vk.x + bn[u].x, hn[u].y + vk.y + bn[u].y,
+                                                       hn[u].z + vk.z + bn[u].z, hn[u].w + vk.w + bn[u].w));
+                    agg.x += m.x; agg.y += m.y; agg.z += m.z; agg.w += m.w;
+                }
+            }
+        }
+        *reinterpret_cast<float4 *>(h_in + (int64_t)v * H + k) = hv;
+        gin_store4<T>(z0 + (int64_t)v * H + k, make_float4(e1 * hv.x + agg.x, e1 * hv.y + agg.y, e1 * hv.z + agg.z, e1 * hv.w + agg.w));
+    }
+}
+
+// Layer tail over the split-K slabs of the second Linear.  Workgroups [0, n): node v, z = sum of `ns` slabs (in order) + bias, then as
+// gin_post_kernel (z is also stored to z_keep for the reverse sweep when given).  Workgroups [n, n + G): vn[g] += sum of the slabs of row
+// vrow0 + g + vbias  (model.py:149-150).  `mod` rows have pitch modld (all layers' adapters come from one GEMM: [G][L * 3H]).
+__global__ __launch_bounds__(64) void gin_post2_kernel(const float *__restrict__ slabs, int64_t slab_stride, int ns,
+                                                        const float *__restrict__ bias, const float *__restrict__ h_in,
+                                                        const float *__restrict__ lnw, const float *__restrict__ lnb,
+                                                        const float *__restrict__ mod, int modld, const int *__restrict__ batch,
+                                                        float *__restrict__ h, float *__restrict__ z_keep, int n, int H, int gelu,
+                                                        float *__restrict__ vn, const float *__restrict__ vbias, int vrow0) {
     const int lane = threadIdx.x;
-    const float *x = z + (int64_t)v * H;
     constexpr int MAXE = 8;   // H <= 2048
+    if ((int)blockIdx.x >= n) {
+        const int g = blockIdx.x - n;
+        const float *x = slabs + (int64_t)(vrow0 + g) * H;
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) {
+            const int k = (lane + e * 64) * 4;
+            if (k < H) {
+                float4 a = *reinterpret_cast<const float4 *>(x + k);
+                for (int q = 1; q < ns; ++q) {
+                    const float4 o = *reinterpret_cast<const float4 *>(x + q * slab_stride + k);
+                    a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+                }
+                const float4 bb = *reinterpret_cast<const float4 *>(vbias + k);
+                float4 *dst = reinterpret_cast<float4 *>(vn + (int64_t)g * H + k);
+                const float4 old = *dst;
+                *dst = make_float4(old.x + (a.x + bb.x), old.y + (a.y + bb.y), old.z + (a.z + bb.z), old.w + (a.w + bb.w));
+            }
+        }
+        return;
+    }
+    const int v = blockIdx.x;
+    const float *x = slabs + (int64_t)v * H;
     float4 t[MAXE], hi[MAXE];
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
         const int k = (lane + e * 64) * 4;
-        t[e] = k < H ? *reinterpret_cast<const float4 *>(x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        hi[e] = k < H ? *reinterpret_cast<const float4 *>(h_in + (int64_t)v * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        t[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        hi[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < H) {
+            float4 a = *reinterpret_cast<const float4 *>(x + k);
+            for (int q = 1; q < ns; ++q) {
+                const float4 o = *reinterpret_cast<const float4 *>(x + q * slab_stride + k);
+                a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+            }
+            const float4 bb = *reinterpret_cast<const float4 *>(bias + k);
+            t[e] = make_float4(a.x + bb.x, a.y + bb.y, a.z + bb.z, a.w + bb.w);
+            hi[e] = *reinterpret_cast<const float4 *>(h_in + (int64_t)v * H + k);
+            if (z_keep) *reinterpret_cast<float4 *>(z_keep + (int64_t)v * H + k) = t[e];
+        }
         s += t[e].x + t[e].y + t[e].z + t[e].w;
     }
     const float mean = wave_sum(s) / (float)H;
@@ -312,7 +412,7 @@ __global__ __launch_bounds__(64) void gin_post_kernel(const float *__restrict__ 
         }
     }
     const float rstd = rsqrtf(wave_sum(vr) / (float)H + 1e-5f);
-    const float *m = mod ? mod + (int64_t)batch[v] * 3 * H : nullptr;
+    const float *m = mod ? mod + (int64_t)batch[v] * modld : nullptr;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
         const int k = (lane + e * 64) * 4;
@@ -363,17 +463,6 @@ __global__ __launch_bounds__(256) void segment_pool_kernel(const float *__restri
 
 __global__ void add_rows_kernel(float *__restrict__ dst, const float *__restrict__ src, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] += src[i];
-}
-__global__ void bcast_rows_kernel(float *__restrict__ dst, const float *__restrict__ row, int G, int H) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)G * H; i += (int64_t)gridDim.x * blockDim.x) dst[i] = row[i % H];
-}
-// SiLU(c) -> operand dtype; c == null -> broadcast the text_dropping row (predictor model.py:315-316,322)
-template <typename T>
-__global__ void silu_rows_kernel(const float *__restrict__ c, const float *__restrict__ drop, T *__restrict__ out, int G, int D) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)G * D; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = c ? c[i] : drop[i % D];
-        out[i] = from_f32<T>(silu(v));
-    }
 }
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float *__restrict__ in, float *__restrict__ out, int R, int C) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -836,20 +925,26 @@ __global__ __launch_bounds__(1024) void graph_csr_kernel(const int64_t *__restri
     __shared__ int part[16];
     const int tid = threadIdx.x;
     const int64_t *esrc = edge_index, *edst = edge_index + E;
+    // error flag: 0 ok | 1 unsorted or out-of-range `batch` | 2 edge endpoint outside the batch | 3 atom / bond type outside the embedding
+    // tables.  Zeroed before anyone can raise it, raised with atomicMax.  Whatever the flag says, the arrays written below are SAFE to run
+    // the GIN kernels on (ids clamped into range, bad edges dropped): the host may look at the flag later than it launches them.
     if (tid == 0) *err = 0;
+    __syncthreads();
     for (int i = tid; i <= n; i += 1024) rowptr[i] = 0;
     for (int i = tid; i <= G; i += 1024) gptr[i] = 0;
     for (int i = tid; i < n; i += 1024) {
-        x32[i] = (int)x[i];
+        const long long xv = x[i];
+        if (xv < 0 || xv >= 118) atomicMax(err, 3);
+        x32[i] = (int)(xv < 0 ? 0 : xv >= 118 ? 117 : xv);
         const long long b = batch[i];
-        b32[i] = (int)b;
+        b32[i] = (int)(b < 0 ? 0 : b >= G ? G - 1 : b);
         cursor[i] = 0;
-        if (b < 0 || b >= G || (i > 0 && batch[i - 1] > b)) *err = 1;      // unsorted / out-of-range `batch`
+        if (b < 0 || b >= G || (i > 0 && batch[i - 1] > b)) atomicMax(err, 1);      // unsorted / out-of-range `batch`
     }
     __syncthreads();
     for (int e = tid; e < E; e += 1024) {
         const long long d = edst[e], sidx = esrc[e];
-        if (d < 0 || d >= n || sidx < 0 || sidx >= n) *err = 2;
+        if (d < 0 || d >= n || sidx < 0 || sidx >= n) atomicMax(err, 2);
         else atomicAdd(&rowptr[d], 1);
     }
     for (int i = tid; i < n; i += 1024) {
@@ -878,7 +973,9 @@ __global__ __launch_bounds__(1024) void graph_csr_kernel(const int64_t *__restri
         for (int i = lo; i < hi; ++i) {
             const int e = src[i];
             src[i] = (int)esrc[e];
-            attr[i] = (int)edge_attr[e];
+            const long long av = edge_attr[e];
+            if (av < 0 || av >= 5) atomicMax(err, 3);
+            attr[i] = (int)(av < 0 ? 0 : av >= 5 ? 4 : av);
         }
     }
 }
@@ -932,11 +1029,12 @@ struct GinEngine {
     std::vector<GinParam> layout;
     const float *w32 = nullptr;
     GBuf wop;
-    GBuf h, h_in, z0, t1, t1a, z, vn, pool32, poola, vt1, vt1a, vt2, mod, csilu, head1, head1a, head2;
+    GBuf adcat, adbcat;          // predictor: the L adapter Linears concatenated along N ([L * 3H, text_dim] operand dtype, [L * 3H] f32 bias): one GEMM
+    GBuf h, h_in, a0, t1, t1a, zs, vn, pool32, poola, mod, csilu, head1, head1a, head2;
     // ---- training (ll_gin_forward keep=1 + ll_gin_backward_c): per-layer activations, transposed weights, gradients
     bool keep = false;
     int kept_n = -1, kept_G = -1;
-    std::vector<GBuf> sv_hin, sv_t1, sv_z, sv_vt1;
+    std::vector<GBuf> sv_hin, sv_t1, sv_z;      // sv_t1[l]: rows [0, n) node MLP, rows [round_up(n, 64), +G) virtual-node MLP (pre-LayerNorm)
     GBuf sv_head1, wT, adT;
     GBuf g_dh, g_dz, g_dt1a, g_dt1, g_dz0, g_c3, g_dmod, g_dmoda, g_dvn, g_dvna, g_dvt1a, g_dvt1, g_dpool, g_tmpG, g_dhead1a,
         g_dhead1, g_dlog, g_slabs, g_dcs;
@@ -950,81 +1048,113 @@ struct GinEngine {
             if (p.name == n) return cfg.dtype == LL_BF16 ? (const void *)(wop.as<bf16_t>() + p.offset) : (const void *)(w32 + p.offset);
         return nullptr;
     }
+    // the layer's parameters, resolved once (pf / pw compare strings; the forward makes ~15 lookups per layer)
+    struct LayerW {
+        const float *bond, *eps, *b0, *ln_w, *ln_b, *b4, *norm_w, *norm_b, *vb0, *vln_w, *vln_b, *vb4;
+        const void *w0, *w4, *vw0, *vw4;
+    };
+    std::vector<LayerW> lw;
+    const float *atom_emb = nullptr, *vn_emb = nullptr, *text_drop = nullptr;
+    const void *w_h0 = nullptr, *w_h2 = nullptr;            // head: proj.fc1 / fc2 or decoder.0 / decoder.4
+    const float *b_h0 = nullptr, *b_h2 = nullptr, *hln_w = nullptr, *hln_b = nullptr;
+    void cache_params() {
+        const int L = cfg.num_layer;
+        lw.assign(L, LayerW{});
+        for (int l = 0; l < L; ++l) {
+            const std::string p = "convs." + std::to_string(l) + ".", q = "mlp_virtualnode_list." + std::to_string(l) + ".";
+            LayerW &w = lw[l];
+            w.bond = pf(p + "bond_encoder.weight"); w.eps = pf(p + "eps");
+            w.w0 = pw(p + "mlp.0.weight"); w.b0 = pf(p + "mlp.0.bias"); w.ln_w = pf(p + "mlp.1.weight"); w.ln_b = pf(p + "mlp.1.bias");
+            w.w4 = pw(p + "mlp.4.weight"); w.b4 = pf(p + "mlp.4.bias");
+            w.norm_w = cfg.kind == 0 ? pf("norms." + std::to_string(l) + ".weight") : nullptr;
+            w.norm_b = cfg.kind == 0 ? pf("norms." + std::to_string(l) + ".bias") : nullptr;
+            if (l < L - 1) {
+                w.vw0 = pw(q + "0.weight"); w.vb0 = pf(q + "0.bias"); w.vln_w = pf(q + "1.weight"); w.vln_b = pf(q + "1.bias");
+                w.vw4 = pw(q + "4.weight"); w.vb4 = pf(q + "4.bias");
+            }
+        }
+        atom_emb = pf("atom_encoder.weight"); vn_emb = pf("virtualnode_embedding.weight");
+        text_drop = cfg.kind == 1 ? pf("text_dropping.weight") : nullptr;
+        if (cfg.kind == 0) {
+            w_h0 = pw("proj.fc1.weight"); b_h0 = pf("proj.fc1.bias"); hln_w = pf("proj.norm1.weight"); hln_b = pf("proj.norm1.bias");
+            w_h2 = pw("proj.fc2.weight"); b_h2 = pf("proj.fc2.bias");
+        } else {
+            w_h0 = pw("decoder.0.weight"); b_h0 = pf("decoder.0.bias"); hln_w = pf("decoder.1.weight"); hln_b = pf("decoder.1.bias");
+            w_h2 = pw("decoder.4.weight"); b_h2 = pf("decoder.4.bias");
+        }
+    }
 };
 
+// split-K of the layer's second Linear ([M, 4H] x [H, 4H]^T, 64 x 64 tiles): until the launch has ~256 workgroups, at most 4 slabs
+static int gin_k_splits(int M, int H) {
+    const long tiles = (long)cdiv(M, 64) * cdiv(H, 64);
+    int s = 1;
+    while (s < 4 && tiles * s < 256 && (4 * H / (2 * s)) % 64 == 0 && 4 * H / (2 * s) >= 256) s *= 2;
+    return s;
+}
+
+// One layer = five launches (round 3; was ten):  aggregate (+ the graph max-pool workgroups) | Linear(H, 4H) | LayerNorm + GELU |
+// Linear(4H, H) as split-K slabs | tail; rows [0, n) are the nodes, rows [n64, n64 + G) the graphs' virtual-node MLP (other weights, same
+// shapes) -- one grouped GEMM instead of two launches, no separate pool / add launches.  Whole predictor forward at L = 5: 2 + 25 + 4
+// launches (was ~60) + the CSR conversion and the two top-k launches.
 template <typename T>
 static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const int *src, const int *attr,
                          const int *batch, const int *gptr, int n, int ne, int G, const float *c, float *out,
                          float *pooled, hipStream_t st) {
     const LLGinConfig &cf = e->cfg;
     const int H = cf.hidden, L = cf.num_layer, dt = cf.dtype, es = sizeof(T);
-    const int np = round_up(n, 128), Gp = round_up(G, 128);
-    LL_TRY(e->h.ensure((size_t)np * H * 4));
-    LL_TRY(e->h_in.ensure((size_t)np * H * 4));
-    LL_TRY(e->z0.ensure((size_t)np * H * es));
-    LL_TRY(e->t1.ensure((size_t)np * 4 * H * 4));
-    LL_TRY(e->t1a.ensure((size_t)np * 4 * H * es));
-    LL_TRY(e->z.ensure((size_t)np * H * 4));
+    const int n64 = round_up(n, 64), MR = n64 + round_up(G, 64), Gp = round_up(G, 128);
+    const int ks = gin_k_splits(n64 + G, H);
+    const int64_t zstride = (int64_t)MR * H;
+    LL_TRY(e->h.ensure((size_t)n64 * H * 4));
+    LL_TRY(e->h_in.ensure((size_t)n64 * H * 4));
+    LL_TRY(e->a0.ensure((size_t)MR * H * es));
+    LL_TRY(e->t1.ensure((size_t)MR * 4 * H * 4));
+    LL_TRY(e->t1a.ensure((size_t)MR * 4 * H * es));
+    LL_TRY(e->zs.ensure((size_t)4 * MR * H * 4));
     LL_TRY(e->vn.ensure((size_t)Gp * H * 4));
     LL_TRY(e->pool32.ensure((size_t)Gp * H * 4));
     LL_TRY(e->poola.ensure((size_t)Gp * H * es));
-    LL_TRY(e->vt1.ensure((size_t)Gp * 4 * H * 4));
-    LL_TRY(e->vt1a.ensure((size_t)Gp * 4 * H * es));
-    LL_TRY(e->vt2.ensure((size_t)Gp * H * 4));
-    const dim3 rows_n(cdiv(n, 4)), rows_g(cdiv(G, 4)), blk(256), w_n(n), w_g(G), wblk(64);
-
-    hipLaunchKernelGGL(gin_embed_kernel, rows_n, blk, 0, st, x, e->pf("atom_encoder.weight"), e->h.as<float>(), n, H);
-    hipLaunchKernelGGL(bcast_rows_kernel, dim3(cdiv(G * H, 256)), blk, 0, st, e->vn.as<float>(), e->pf("virtualnode_embedding.weight"), G, H);
-    LL_LAUNCH_CHECK();
+    const dim3 blk(256), wblk(64);
+    const int modld = L * 3 * H;
+    T *csilu = nullptr;
     if (cf.kind == 1) {
         LL_TRY(e->csilu.ensure((size_t)Gp * cf.text_dim * es));
-        LL_TRY(e->mod.ensure((size_t)L * Gp * 3 * H * 4));
-        hipLaunchKernelGGL((silu_rows_kernel<T>), dim3(cdiv(G * cf.text_dim, 256)), blk, 0, st, c, e->pf("text_dropping.weight"), e->csilu.as<T>(), G, cf.text_dim);
-        LL_LAUNCH_CHECK();
-        for (int l = 0; l < L; ++l) {
-            const std::string p = "adapters." + std::to_string(l) + ".1.";
-            LL_TRY(linear_launch(dt, e->csilu.p, cf.text_dim, e->pw(p + "weight"), cf.text_dim, e->pf(p + "bias"),
-                                 e->mod.as<float>() + (size_t)l * Gp * 3 * H, 3 * H, G, 3 * H, cf.text_dim, 0, 1, st));
-        }
+        LL_TRY(e->mod.ensure((size_t)Gp * modld * 4));
+        csilu = e->csilu.as<T>();
     }
+    {
+        const int64_t items = ((int64_t)n * H + (int64_t)G * H + (csilu ? (int64_t)G * cf.text_dim : 0)) / 4;
+        hipLaunchKernelGGL((gin_prologue_kernel<T>), dim3((unsigned)std::min<int64_t>((items + 255) / 256, 2048)), blk, 0, st,
+                           x, e->atom_emb, e->vn_emb, c, e->text_drop, e->h.as<float>(), e->vn.as<float>(), csilu, n, G, H, cf.text_dim);
+        LL_LAUNCH_CHECK();
+    }
+    if (cf.kind == 1)   // (shift, scale, gate) of every layer: ONE GEMM over the N-concatenated adapters -> mod [G][L * 3H]
+        LL_TRY(linear_launch(dt, e->csilu.p, cf.text_dim, e->adcat.p, cf.text_dim, e->adbcat.as<float>(), e->mod.p, modld, G, modld, cf.text_dim, 0, 1, st));
+    const int nbn = cdiv(n, 4), chunks = cdiv(H, 256);
     for (int l = 0; l < L; ++l) {
-        const std::string p = "convs." + std::to_string(l) + ".";
+        const GinEngine::LayerW &w = e->lw[l];
         const bool last = (l == L - 1);
-        hipLaunchKernelGGL((gin_aggregate_kernel<T>), w_n, wblk, 0, st, e->h.as<float>(), e->vn.as<float>(), batch, rowptr, src, attr,
-                           e->pf(p + "bond_encoder.weight"), e->pf(p + "eps"), e->h_in.as<float>(), e->z0.as<T>(), n, H);
-        LL_LAUNCH_CHECK();
-        LL_TRY(linear_launch(dt, e->z0.p, H, e->pw(p + "mlp.0.weight"), H, e->pf(p + "mlp.0.bias"), e->t1.p, 4 * H, n, 4 * H, H, 0, 1, st));
-        launch_rows_ln_act<T>(e->t1.as<float>(), e->pf(p + "mlp.1.weight"), e->pf(p + "mlp.1.bias"), e->t1a.as<T>(), n, 4 * H, 1, st);
-        LL_LAUNCH_CHECK();
-        LL_TRY(linear_launch(dt, e->t1a.p, 4 * H, e->pw(p + "mlp.4.weight"), 4 * H, e->pf(p + "mlp.4.bias"), e->z.p, H, n, H, 4 * H, 0, 1, st));
-        const float *lnw = cf.kind == 0 ? e->pf("norms." + std::to_string(l) + ".weight") : nullptr;
-        const float *lnb = cf.kind == 0 ? e->pf("norms." + std::to_string(l) + ".bias") : nullptr;
-        const float *mod = cf.kind == 1 ? e->mod.as<float>() + (size_t)l * Gp * 3 * H : nullptr;
-        hipLaunchKernelGGL(gin_post_kernel, w_n, wblk, 0, st, e->z.as<float>(), e->h_in.as<float>(), lnw, lnb, mod, batch, e->h.as<float>(), n, H, last ? 0 : 1);
-        LL_LAUNCH_CHECK();
-        if (e->keep) {
-            LL_TRY(e->sv_hin[l].ensure((size_t)np * H * 4));
-            LL_TRY(e->sv_t1[l].ensure((size_t)np * 4 * H * 4));
-            LL_TRY(e->sv_z[l].ensure((size_t)np * H * 4));
-            LL_HIP(hipMemcpyAsync(e->sv_hin[l].p, e->h_in.p, (size_t)n * H * 4, hipMemcpyDeviceToDevice, st));
-            LL_HIP(hipMemcpyAsync(e->sv_t1[l].p, e->t1.p, (size_t)n * 4 * H * 4, hipMemcpyDeviceToDevice, st));
-            LL_HIP(hipMemcpyAsync(e->sv_z[l].p, e->z.p, (size_t)n * H * 4, hipMemcpyDeviceToDevice, st));
+        float *h_in = e->h_in.as<float>(), *t1 = e->t1.as<float>(), *z_keep = nullptr;
+        if (e->keep) {      // the reverse sweep reads these: write them in place instead of copying them out afterwards
+            LL_TRY(e->sv_hin[l].ensure((size_t)n64 * H * 4));
+            LL_TRY(e->sv_t1[l].ensure((size_t)MR * 4 * H * 4));
+            LL_TRY(e->sv_z[l].ensure((size_t)n64 * H * 4));
+            h_in = e->sv_hin[l].as<float>(); t1 = e->sv_t1[l].as<float>(); z_keep = e->sv_z[l].as<float>();
         }
-        if (!last) {  // virtual node update from max-pooled h_in (model.py:147-150)
-            const std::string q = "mlp_virtualnode_list." + std::to_string(l) + ".";
-            hipLaunchKernelGGL((segment_pool_kernel<T, true>), dim3(G, cdiv(H, 1024)), blk, 0, st, e->h_in.as<float>(), gptr, (float *)nullptr, e->poola.as<T>(), H);
-            LL_LAUNCH_CHECK();
-            LL_TRY(linear_launch(dt, e->poola.p, H, e->pw(q + "0.weight"), H, e->pf(q + "0.bias"), e->vt1.p, 4 * H, G, 4 * H, H, 0, 1, st));
-            launch_rows_ln_act<T>(e->vt1.as<float>(), e->pf(q + "1.weight"), e->pf(q + "1.bias"), e->vt1a.as<T>(), G, 4 * H, 1, st);
-            LL_LAUNCH_CHECK();
-            if (e->keep) {
-                LL_TRY(e->sv_vt1[l].ensure((size_t)Gp * 4 * H * 4));
-                LL_HIP(hipMemcpyAsync(e->sv_vt1[l].p, e->vt1.p, (size_t)G * 4 * H * 4, hipMemcpyDeviceToDevice, st));
-            }
-            LL_TRY(linear_launch(dt, e->vt1a.p, 4 * H, e->pw(q + "4.weight"), 4 * H, e->pf(q + "4.bias"), e->vt2.p, H, G, H, 4 * H, 0, 1, st));
-            hipLaunchKernelGGL(add_rows_kernel, dim3(cdiv(G * H, 256)), blk, 0, st, e->vn.as<float>(), e->vt2.as<float>(), (int64_t)G * H);
-            LL_LAUNCH_CHECK();
-        }
+        const int M = last ? n : n64 + G;      // rows of the layer's GEMMs
+        hipLaunchKernelGGL((gin_aggregate2_kernel<T>), dim3(nbn + (last ? 0 : G * chunks)), blk, 0, st, e->h.as<float>(), e->vn.as<float>(), batch,
+                           rowptr, src, attr, w.bond, w.eps, h_in, e->a0.as<T>(), gptr, e->a0.as<T>() + (size_t)n64 * H, n, H, nbn);
+        LL_LAUNCH_CHECK();
+        LL_TRY(linear_grouped2_launch(dt, e->a0.p, H, w.w0, last ? nullptr : w.vw0, H, w.b0, w.vb0, t1, 4 * H, M, n64, 4 * H, H, 1, 0, 0, 1, st));
+        launch_rows_ln_act2<T>(t1, w.ln_w, w.ln_b, e->t1a.as<T>(), M, 4 * H, 1, n, last ? M : n64, w.vln_w, w.vln_b, st);
+        LL_LAUNCH_CHECK();
+        LL_TRY(linear_grouped2_launch(dt, e->t1a.p, 4 * H, w.w4, last ? nullptr : w.vw4, 4 * H, nullptr, nullptr, e->zs.p, H, M, n64, H, 4 * H, ks,
+                                      zstride, 0, 1, st));
+        const float *mod = cf.kind == 1 ? e->mod.as<float>() + (size_t)l * 3 * H : nullptr;
+        hipLaunchKernelGGL(gin_post2_kernel, dim3(n + (last ? 0 : G)), wblk, 0, st, e->zs.as<float>(), zstride, ks, w.b4, h_in, w.norm_w, w.norm_b,
+                           mod, modld, batch, e->h.as<float>(), z_keep, n, H, last ? 0 : 1, e->vn.as<float>(), w.vb4, n64);
+        LL_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL((segment_pool_kernel<T, false>), dim3(G, cdiv(H, 1024)), blk, 0, st, e->h.as<float>(), gptr, e->pool32.as<float>(), e->poola.as<T>(), H);
     LL_LAUNCH_CHECK();
@@ -1033,31 +1163,34 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
         LL_TRY(e->head1.ensure((size_t)Gp * H * 4));
         LL_TRY(e->head1a.ensure((size_t)Gp * H * es));
         LL_TRY(e->head2.ensure((size_t)Gp * H * 4));
-        LL_TRY(linear_launch(dt, e->poola.p, H, e->pw("proj.fc1.weight"), H, e->pf("proj.fc1.bias"), e->head1.p, H, G, H, H, 0, 1, st));
-        launch_rows_ln_act<T>(e->head1.as<float>(), e->pf("proj.norm1.weight"), e->pf("proj.norm1.bias"), e->head1a.as<T>(), G, H, 1, st);
+        LL_TRY(linear_launch(dt, e->poola.p, H, e->w_h0, H, e->b_h0, e->head1.p, H, G, H, H, 0, 1, st));
+        launch_rows_ln_act<T>(e->head1.as<float>(), e->hln_w, e->hln_b, e->head1a.as<T>(), G, H, 1, st);
         LL_LAUNCH_CHECK();
-        LL_TRY(linear_launch(dt, e->head1a.p, H, e->pw("proj.fc2.weight"), H, e->pf("proj.fc2.bias"), e->head2.p, H, G, H, H, 0, 1, st));
-        hipLaunchKernelGGL(l2norm_rows_kernel, rows_g, blk, 0, st, e->head2.as<float>(), out, G, H);
+        LL_TRY(linear_launch(dt, e->head1a.p, H, e->w_h2, H, e->b_h2, e->head2.p, H, G, H, H, 0, 1, st));
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cdiv(G, 4)), blk, 0, st, e->head2.as<float>(), out, G, H);
         LL_LAUNCH_CHECK();
     } else {  // decoder: Linear(H,4H) -> LN -> GELU -> Linear(4H,out_dim)  (model.py:272-278)
-        LL_TRY(e->head1.ensure((size_t)Gp * 4 * H * 4));
         LL_TRY(e->head1a.ensure((size_t)Gp * 4 * H * es));
-        LL_TRY(linear_launch(dt, e->poola.p, H, e->pw("decoder.0.weight"), H, e->pf("decoder.0.bias"), e->head1.p, 4 * H, G, 4 * H, H, 0, 1, st));
-        launch_rows_ln_act<T>(e->head1.as<float>(), e->pf("decoder.1.weight"), e->pf("decoder.1.bias"), e->head1a.as<T>(), G, 4 * H, 1, st);
-        LL_LAUNCH_CHECK();
+        float *head1 = nullptr;
         if (e->keep) {
             LL_TRY(e->sv_head1.ensure((size_t)Gp * 4 * H * 4));
-            LL_HIP(hipMemcpyAsync(e->sv_head1.p, e->head1.p, (size_t)G * 4 * H * 4, hipMemcpyDeviceToDevice, st));
+            head1 = e->sv_head1.as<float>();
             e->kept_n = n;
             e->kept_G = G;
+        } else {
+            LL_TRY(e->head1.ensure((size_t)Gp * 4 * H * 4));
+            head1 = e->head1.as<float>();
         }
+        LL_TRY(linear_launch(dt, e->poola.p, H, e->w_h0, H, e->b_h0, head1, 4 * H, G, 4 * H, H, 0, 1, st));
+        launch_rows_ln_act<T>(head1, e->hln_w, e->hln_b, e->head1a.as<T>(), G, 4 * H, 1, st);
+        LL_LAUNCH_CHECK();
         // template head [G, 4H] x [out_dim, 4H]^T (740 MB of bf16 weights at out_dim = 180 576): 3..16 graphs stream it through the
         // 16-row MFMA Linear (line-contiguous loads, wave-private LDS transpose), anything else through the GEMM dispatch
         if (dt == LL_BF16 && G >= 3 && G <= 16 && (4 * H) % 32 == 0)
-            LL_TRY(linear_rows16_launch(e->head1a.p, 4 * H, e->pw("decoder.4.weight"), 4 * H, e->pf("decoder.4.bias"), nullptr, 0.f, nullptr, 0, out, cf.out_dim, G,
+            LL_TRY(linear_rows16_launch(e->head1a.p, 4 * H, e->w_h2, 4 * H, e->b_h2, nullptr, 0.f, nullptr, 0, out, cf.out_dim, G,
                                         cf.out_dim, 4 * H, 0, 1, st));
         else
-            LL_TRY(linear_launch(dt, e->head1a.p, 4 * H, e->pw("decoder.4.weight"), 4 * H, e->pf("decoder.4.bias"), out, cf.out_dim, G, cf.out_dim, 4 * H, 0, 1, st));
+            LL_TRY(linear_launch(dt, e->head1a.p, 4 * H, e->w_h2, 4 * H, e->b_h2, out, cf.out_dim, G, cf.out_dim, 4 * H, 0, 1, st));
     }
     return LL_OK;
 }
@@ -1143,7 +1276,7 @@ __global__ __launch_bounds__(64) void ln_gelu_bwd_kernel(const float *__restrict
 //   dz (operand dtype), per-node contributions to d shift / d scale / d gate (summed per graph afterwards); dh is left in
 //   place as the running d h_in (the residual path is the identity).
 template <typename T>
-__global__ __launch_bounds__(64) void gin_post_bwd_kernel(const float *__restrict__ z, const float *__restrict__ mod,
+__global__ __launch_bounds__(64) void gin_post_bwd_kernel(const float *__restrict__ z, const float *__restrict__ mod, int modld,
                                                            const int *__restrict__ batch, const float *__restrict__ dh,
                                                            T *__restrict__ dz, float *__restrict__ c3 /*[3][n][H]*/, int n,
                                                            int H, int gelu) {
@@ -1170,7 +1303,7 @@ __global__ __launch_bounds__(64) void gin_post_bwd_kernel(const float *__restric
         }
     }
     const float rstd = rsqrtf(wave_sum(vr) / (float)H + 1e-5f);
-    const float *m = mod + (int64_t)batch[v] * 3 * H;
+    const float *m = mod + (int64_t)batch[v] * modld;
     float4 dxh[MAXE];
     float m1 = 0.f, m2 = 0.f;
     const int64_t plane = (int64_t)n * H;
@@ -1391,9 +1524,9 @@ static int gin_backward_c_t(GinEngine *e, const int *rowptr_s, const int *dst_s,
     for (int l = L - 1; l >= 0; --l) {
         const std::string p = "convs." + std::to_string(l) + ".";
         const bool last = (l == L - 1);
-        const float *mod = e->mod.as<float>() + (size_t)l * Gp * 3 * H;
+        const float *mod = e->mod.as<float>() + (size_t)l * 3 * H;      // rows of pitch L * 3H (one GEMM over all layers' adapters)
         // tail: h = gate * act(LN0(z)(1+scale)+shift) + h_in
-        hipLaunchKernelGGL((gin_post_bwd_kernel<T>), w_n, wblk, 0, st, e->sv_z[l].as<float>(), mod, batch, e->g_dh.as<float>(), e->g_dz.as<T>(),
+        hipLaunchKernelGGL((gin_post_bwd_kernel<T>), w_n, wblk, 0, st, e->sv_z[l].as<float>(), mod, L * 3 * H, batch, e->g_dh.as<float>(), e->g_dz.as<T>(),
                            e->g_c3.as<float>(), n, H, last ? 0 : 1);
         LL_LAUNCH_CHECK();
         for (int q = 0; q < 3; ++q) {   // d(shift | scale | gate)[g] = sum over the graph's nodes
@@ -1418,7 +1551,7 @@ static int gin_backward_c_t(GinEngine *e, const int *rowptr_s, const int *dst_s,
             hipLaunchKernelGGL((cvt_rows_kernel<T>), ew((int64_t)G * H), blk, 0, st, e->g_dvn.as<float>(), (int64_t)H, e->g_dvna.as<T>(), (int64_t)H, G, H);
             LL_LAUNCH_CHECK();
             LL_TRY(linear_launch(dt, e->g_dvna.p, H, wt(q + "4.weight"), H, nullptr, e->g_dvt1a.p, 4 * H, G, 4 * H, H, 0, 1, st));
-            hipLaunchKernelGGL((ln_gelu_bwd_kernel<T>), w_g, wblk, 0, st, e->sv_vt1[l].as<float>(), e->pf(q + "1.weight"), e->pf(q + "1.bias"),
+            hipLaunchKernelGGL((ln_gelu_bwd_kernel<T>), w_g, wblk, 0, st, e->sv_t1[l].as<float>() + (size_t)round_up(n, 64) * 4 * H, e->pf(q + "1.weight"), e->pf(q + "1.bias"),
                                e->g_dvt1a.as<float>(), e->g_dvt1.as<T>(), G, 4 * H);
             LL_LAUNCH_CHECK();
             LL_TRY(linear_launch(dt, e->g_dvt1.p, 4 * H, wt(q + "0.weight"), 4 * H, nullptr, e->g_dpool.p, H, G, H, 4 * H, 0, 1, st));
@@ -1480,7 +1613,6 @@ int ll_gin_create(const LLGinConfig *cfg, const float *d_weights_f32, void **han
     e->sv_hin.resize(cfg->num_layer);
     e->sv_t1.resize(cfg->num_layer);
     e->sv_z.resize(cfg->num_layer);
-    e->sv_vt1.resize(cfg->num_layer);
     if (cfg->dtype == LL_BF16) {
         const int64_t elems = ll_gin_arena_elems(cfg);
         int rc = e->wop.ensure((size_t)elems * 2);
@@ -1490,9 +1622,29 @@ int ll_gin_create(const LLGinConfig *cfg, const float *d_weights_f32, void **han
             return rc;
         }
     }
+    e->cache_params();
+    if (cfg->kind == 1) {      // the L adapter Linears as one [L * 3H, text_dim] weight (+ bias): their slots are not adjacent in the arena
+        const int L = cfg->num_layer, es = cfg->dtype == LL_BF16 ? 2 : 4;
+        const size_t per = (size_t)3 * cfg->hidden * cfg->text_dim;
+        int rc = e->adcat.ensure(per * L * es);
+        if (rc == LL_OK) rc = e->adbcat.ensure((size_t)L * 3 * cfg->hidden * 4);
+        for (int l = 0; l < L && rc == LL_OK; ++l) {
+            const std::string p = "adapters." + std::to_string(l) + ".1.";
+            if (hipMemcpy((char *)e->adcat.p + per * l * es, e->pw(p + "weight"), per * es, hipMemcpyDeviceToDevice) != hipSuccess ||
+                hipMemcpy(e->adbcat.as<float>() + (size_t)l * 3 * cfg->hidden, e->pf(p + "bias"), (size_t)3 * cfg->hidden * 4,
+                          hipMemcpyDeviceToDevice) != hipSuccess) {
+                set_error("ll_gin_create: copying the adapter weights failed");
+                rc = LL_EHIP;
+            }
+        }
+        if (rc != LL_OK) {
+            ll_gin_destroy(e);
+            return rc;
+        }
+    }
     if (hipDeviceSynchronize() != hipSuccess) {
         set_error("hipDeviceSynchronize failed in ll_gin_create");
-        delete e;
+        ll_gin_destroy(e);
         return LL_EHIP;
     }
     *handle = e;
@@ -1502,14 +1654,14 @@ int ll_gin_destroy(void *handle) {
     GinEngine *e = (GinEngine *)handle;
     if (!e) return LL_OK;
     (void)hipDeviceSynchronize();
-    GBuf *bufs[] = {&e->wop, &e->h, &e->h_in, &e->z0, &e->t1, &e->t1a, &e->z, &e->vn, &e->pool32, &e->poola, &e->vt1,
-                    &e->vt1a, &e->vt2, &e->mod, &e->csilu, &e->head1, &e->head1a, &e->head2};
+    GBuf *bufs[] = {&e->wop, &e->adcat, &e->adbcat, &e->h, &e->h_in, &e->a0, &e->t1, &e->t1a, &e->zs, &e->vn, &e->pool32, &e->poola,
+                    &e->mod, &e->csilu, &e->head1, &e->head1a, &e->head2};
     for (GBuf *b : bufs) b->release();
     GBuf *tb[] = {&e->sv_head1, &e->wT, &e->adT, &e->g_dh, &e->g_dz, &e->g_dt1a, &e->g_dt1, &e->g_dz0, &e->g_c3, &e->g_dmod, &e->g_dmoda,
                   &e->g_dvn, &e->g_dvna, &e->g_dvt1a, &e->g_dvt1, &e->g_dpool, &e->g_tmpG, &e->g_dhead1a, &e->g_dhead1, &e->g_dlog,
                   &e->g_slabs, &e->g_dcs};
     for (GBuf *b : tb) b->release();
-    for (auto *v : {&e->sv_hin, &e->sv_t1, &e->sv_z, &e->sv_vt1})
+    for (auto *v : {&e->sv_hin, &e->sv_t1, &e->sv_z})
         for (GBuf &b : *v) b.release();
     delete e;
     return LL_OK;

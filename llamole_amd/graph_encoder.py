@@ -45,10 +45,36 @@ def graph_csr(x, edge_index, edge_attr, batch):
 CSR_KERNEL_MAX_NODES, CSR_KERNEL_MAX_EDGES = 32768, 262144     # one workgroup builds the CSR; beyond this the ATen route
 
 
+_CSR_ERRORS = {1: "`batch` must be sorted (PyG Batch convention) with ids in [0, num_graphs)",
+               2: "edge_index refers to a node outside the batch",
+               3: "atom type outside [0, 118) or bond type outside [0, 5)"}
+_pending_csr_flags = []       # (pinned int32[1], event): error flags of conversions whose launch the host has not waited for
+
+
+def check_graph_errors(wait: bool = False):
+    """Raise ValueError if an earlier ``graph_csr_device`` call saw a malformed batch.  The conversion kernel clamps every id it
+    writes (so the GIN kernels never index out of bounds) and raises a flag, which travels to pinned host memory on the stream;
+    this looks at the flags that have ARRIVED (``wait=True``: at all of them) -- no device synchronisation on the hot path."""
+    keep, code = [], 0
+    for flag, ev in _pending_csr_flags:
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            code = max(code, int(flag[0]))
+        else:
+            keep.append((flag, ev))
+    _pending_csr_flags[:] = keep
+    if code:
+        raise ValueError(_CSR_ERRORS.get(code, f"malformed graph batch (code {code})"))
+
+
 def graph_csr_device(x, edge_index, edge_attr, batch, num_graphs=None):
     """``graph_csr`` in ONE launch on the HIP device (``ll_graph_csr``).  With ``num_graphs`` given (``GraphBatch`` tags its
-    ``batch`` tensor with it, single-graph callers pass 1) nothing synchronises with the host; otherwise the graph count is read
-    back from ``batch[-1]`` like the ATen route does, and the kernel's error flag (unsorted ``batch``, edge out of range) is checked."""
+    ``batch`` tensor with it, single-graph callers pass 1) nothing synchronises with the host: the kernel's error flag (unsorted
+    ``batch``, edge / atom / bond id out of range -- all clamped, so whatever runs on the arrays stays in bounds) is copied to pinned
+    memory behind the launch and raised by the next call that finds it (``check_graph_errors``).  Otherwise the graph count is
+    read back from ``batch[-1]`` like the ATen route does and the flag is checked right away."""
+    check_graph_errors()
     dev = x.device
     n, ne = int(x.shape[0]), int(edge_index.shape[1])
     known = num_graphs is not None
@@ -64,10 +90,16 @@ def graph_csr_device(x, edge_index, edge_attr, batch, num_graphs=None):
                                         _lib.dptr(err), _lib.current_stream_ptr()), "ll_graph_csr")
     if not known:
         code = int(err.item())
-        if code == 1:
-            raise ValueError("`batch` must be sorted (PyG Batch convention)")
-        if code == 2:
-            raise ValueError("edge_index refers to a node outside the batch")
+        if code:
+            raise ValueError(_CSR_ERRORS.get(code, f"malformed graph batch (code {code})"))
+    else:
+        flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        flag.copy_(err, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        _pending_csr_flags.append((flag, ev))
+        if len(_pending_csr_flags) > 64:
+            check_graph_errors(wait=True)
     return xs, rowptr, src, attr, b32, gptr, n, ne, G
 
 

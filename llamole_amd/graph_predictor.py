@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .graph_encoder import csr_for_engine, graph_csr, _GinModule
+from .graph_encoder import check_graph_errors, csr_for_engine, graph_csr, _GinModule
 from .synth import gin_weight_shapes
 from .weights import WeightBag
 
@@ -143,6 +143,7 @@ class GraphPredictor(_GinModule):
 
     def _backward_c(self, saved, c32, dlogits):
         rowptr_s, dst_s, attr_s, b, gptr, n, ne, G = saved
+        check_graph_errors(wait=True)      # the forward's batch conversion is long done: an unsorted batch / bad edge raises here
         dlogits = dlogits.to(torch.float32).contiguous()
         dc = torch.empty_like(c32)
         _lib.check(_lib.load().ll_gin_backward_c(self._handle, _lib.dptr(rowptr_s), _lib.dptr(dst_s), _lib.dptr(attr_s), _lib.dptr(b),
