@@ -230,7 +230,9 @@ int ll_gin_destroy(void *handle);
 /* ll_graph_csr : the reference's graph batch (int64 x [n], edge_index [2,E], edge_attr [E], sorted batch [n]; modeling_llamole.py:
  * 328-333, 611-616, 829-834) -> the int32 arrays of ll_gin_forward in one launch: x32 [n], rowptr [n+1] / src [E] / attr [E] =
  * CSR by destination with every node's in-edges in edge-list order (the reference's summation order), batch32 [n], gptr [G+1].
- * scratch: n int32.  *err (device) = 0, 1 (batch unsorted / out of range) or 2 (edge endpoint out of range). */
+ * scratch: n int32.  *err (device memory, or pinned host memory so that the caller's stream never carries a read-back) = 0, 1 (batch
+ * unsorted / graph id out of range), 2 (edge endpoint out of range) or 3 (atom type outside [0,118) / bond type outside [0,5)).  Whatever
+ * the flag says the output arrays are in bounds for ll_gin_forward (ids clamped, bad edges dropped), so the caller may check it late. */
 int ll_graph_csr(const int64_t *x, const int64_t *edge_index, const int64_t *edge_attr, const int64_t *batch, int n_nodes, int n_edges,
                  int n_graphs, int32_t *x32, int32_t *rowptr, int32_t *src, int32_t *attr, int32_t *batch32, int32_t *gptr,
                  int32_t *scratch, int32_t *err, void *stream);

@@ -1796,9 +1796,19 @@ int linear_grouped2_launch(int dtype, const void *A, int lda, const void *W1, co
     if (dtype == LL_BF16) {
         const int kchunk = K / splits;
         LL_CHECK(kchunk % 64 == 0 && lda % 8 == 0 && ldw % 8 == 0, "linear_grouped2(bf16): K per split (%d) must be a multiple of 64, lda/ldw of 8", kchunk);
-        LL_TRY((launch_pipeu2<64, 64, 4, 4, 4>((const bf16_t *)A, lda, (const bf16_t *)W1, (const bf16_t *)W2, ldw, C, ldc,
-                                              splits > 1 ? nullptr : bias1, splits > 1 ? nullptr : bias2, M, m_split, N, K, splits, slab_stride,
-                                              splits > 1 ? (int)EPI_NONE : epi, splits > 1 ? 1 : out_f32, stream)));
+        // sixteen waves per 64 x 64 tile while the launch fits one round of workgroups (one such workgroup per CU); beyond 256 tiles the
+        // second round would double the launch's time (the extra M-tile of the second group makes 288 of 256), so eight-wave workgroups,
+        // two per CU, take over there
+        const long wgs = (long)cdiv(M, 64) * cdiv(N, 64) * splits;
+        static const int force = getenv("LL_GROUPED_WAVES") ? atoi(getenv("LL_GROUPED_WAVES")) : 0;
+        if ((wgs <= 256 && force != 8) || force == 16)
+            LL_TRY((launch_pipeu2<64, 64, 4, 4, 4>((const bf16_t *)A, lda, (const bf16_t *)W1, (const bf16_t *)W2, ldw, C, ldc,
+                                                  splits > 1 ? nullptr : bias1, splits > 1 ? nullptr : bias2, M, m_split, N, K, splits, slab_stride,
+                                                  splits > 1 ? (int)EPI_NONE : epi, splits > 1 ? 1 : out_f32, stream)));
+        else
+            LL_TRY((launch_pipeu2<64, 64, 4, 2, 4>((const bf16_t *)A, lda, (const bf16_t *)W1, (const bf16_t *)W2, ldw, C, ldc,
+                                                  splits > 1 ? nullptr : bias1, splits > 1 ? nullptr : bias2, M, m_split, N, K, splits, slab_stride,
+                                                  splits > 1 ? (int)EPI_NONE : epi, splits > 1 ? 1 : out_f32, stream)));
         LL_LAUNCH_CHECK();
         return LL_OK;
     }

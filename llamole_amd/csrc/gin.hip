@@ -242,35 +242,55 @@ static void launch_rows_ln_act(const float *in, const float *w, const float *b, 
 // so the pooled input of the virtual-node MLP depends only on the INPUTS of the aggregation launch and extra workgroups of that launch
 // can produce it; everything downstream (Linear -> LN+GELU -> Linear -> += ) has the node MLP's shape with other weights.
 
-// h0 = atom_encoder[x], vn0 = virtual-node embedding row, csilu = SiLU(c or text_dropping row): one launch instead of three
+// h0 = atom_encoder[x], vn0 = virtual-node embedding row, csilu = SiLU(c or text_dropping row), and the per-node neighbour records
+// the L aggregation launches read: one launch instead of three.  Record of node v = 8 ints: up to 6 in-edges as (src << 3 | bond type),
+// the in-degree, the graph id -- ONE 32-byte load gives an aggregation wave what took the chain rowptr -> src / attr -> rows before
+// (molecular graphs: degree <= 4 almost always; edges beyond the sixth are read from the CSR arrays).
+constexpr int ELL_SLOTS = 6;
 template <typename T>
 __global__ __launch_bounds__(256) void gin_prologue_kernel(const int *__restrict__ x, const float *__restrict__ emb,
                                                             const float *__restrict__ vemb, const float *__restrict__ c,
                                                             const float *__restrict__ drop, float *__restrict__ h, float *__restrict__ vn,
-                                                            T *__restrict__ csilu, int n, int G, int H, int D) {
+                                                            T *__restrict__ csilu, const int *__restrict__ rowptr, const int *__restrict__ src,
+                                                            const int *__restrict__ attr, const int *__restrict__ batch, int *__restrict__ ell,
+                                                            int n, int G, int H, int D) {
     const int H4 = H / 4, D4 = D / 4;
     const int64_t n4 = (int64_t)n * H4, g4 = (int64_t)G * H4, c4 = csilu ? (int64_t)G * D4 : 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4 + g4 + c4; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4 + g4 + c4 + n; i += (int64_t)gridDim.x * blockDim.x) {
         if (i < n4) {
             const int v = (int)(i / H4), k = (int)(i % H4) * 4;
             *reinterpret_cast<float4 *>(h + (int64_t)v * H + k) = *reinterpret_cast<const float4 *>(emb + (int64_t)x[v] * H + k);
         } else if (i < n4 + g4) {
             const int64_t j = i - n4;
             *reinterpret_cast<float4 *>(vn + j * 4) = *reinterpret_cast<const float4 *>(vemb + (j % H4) * 4);
-        } else {
+        } else if (i < n4 + g4 + c4) {
             const int64_t j = i - n4 - g4;
             const float4 v = c ? *reinterpret_cast<const float4 *>(c + j * 4) : *reinterpret_cast<const float4 *>(drop + (j % D4) * 4);
             gin_store4<T>(csilu + j * 4, make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w)));
+        } else {
+            const int v = (int)(i - n4 - g4 - c4);
+            const int e0 = rowptr[v], deg = rowptr[v + 1] - e0;
+            int r[8];
+#pragma unroll
+            for (int j = 0; j < ELL_SLOTS; ++j) r[j] = j < deg ? ((src[e0 + j] << 3) | (attr[e0 + j] & 7)) : 0;
+            r[6] = deg;
+            r[7] = batch[v];
+            *reinterpret_cast<int4 *>(ell + (int64_t)v * 8) = make_int4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<int4 *>(ell + (int64_t)v * 8 + 4) = make_int4(r[4], r[5], r[6], r[7]);
         }
     }
 }
 
-// Workgroups [0, nbn): four waves = four destination nodes, each as in gin_aggregate_kernel.  Workgroups [nbn, ...): (graph g, 256-feature
-// chunk): pool[g] = max over the graph's nodes of h[v], + vn[g]  (== segment max of h_in, model.py:147-148) in operand dtype -- the A rows
-// of the virtual-node MLP; the four waves take every fourth node with eight rows in flight, partial maxima meet in LDS.
-template <typename T>
+// Workgroups [0, nbn): 4 / NPW destination nodes, NPW waves (NPW * 256 features per pass) each: the node's neighbour record arrives with
+// one load, then its own row, the virtual-node row and up to six neighbour + bond-embedding rows are all in flight together.
+//   h_in[v] = h[v] + vn[batch[v]];   z0[v] = (1+eps) h_in[v] + sum_{e: dst(e)=v} GELU(h_in[src(e)] + bond_emb[attr(e)])
+// (graph_encoder/model.py:133-134,167-173; edges never cross graphs, so vn[batch[src]] == vn[batch[v]]; edges in CSR order = the
+// reference's summation order).  Workgroups [nbn, ...): (graph g, 256-feature chunk): pool[g] = max over the graph's nodes of h[v],
+// + vn[g]  (== segment max of h_in, model.py:147-148) in operand dtype -- the A rows of the virtual-node MLP; the four waves take every
+// fourth node with eight rows in flight, partial maxima meet in LDS.
+template <typename T, int NPW>
 __global__ __launch_bounds__(256) void gin_aggregate2_kernel(const float *__restrict__ h, const float *__restrict__ vn,
-                                                             const int *__restrict__ batch, const int *__restrict__ rowptr,
+                                                             const int *__restrict__ ell, const int *__restrict__ rowptr,
                                                              const int *__restrict__ src, const int *__restrict__ attr,
                                                              const float *__restrict__ bond, const float *__restrict__ eps,
                                                              float *__restrict__ h_in, T *__restrict__ z0, const int *__restrict__ gptr,
@@ -308,40 +328,41 @@ __global__ __launch_bounds__(256) void gin_aggregate2_kernel(const float *__rest
         }
         return;
     }
-    const int v = blockIdx.x * 4 + wave;   // one wave = one destination node
+    const int v = blockIdx.x * (4 / NPW) + wave / NPW, sub = wave % NPW;
     if (v >= n) return;
-    const float *vr = vn + (int64_t)batch[v] * H;
+    const int rec = ell[(int64_t)v * 8 + (lane & 7)];
+    const int deg = __builtin_amdgcn_readlane(rec, 6);
+    const float *vr = vn + (int64_t)__builtin_amdgcn_readlane(rec, 7) * H;
     const float e1 = 1.f + eps[0];
-    const int e0 = rowptr[v], e_end = rowptr[v + 1];
-    // the wave's edge list (molecular graphs: degree <= ~6) is read once by the first lanes and broadcast
-    const int my_e = e0 + lane;
-    const int my_src = my_e < e_end ? src[my_e] : 0;
-    const int my_att = my_e < e_end ? attr[my_e] : 0;
-    for (int k = lane * 4; k < H; k += 256) {
+    const int nd = deg < ELL_SLOTS ? deg : ELL_SLOTS;
+    for (int k = (sub * 64 + lane) * 4; k < H; k += NPW * 256) {
+        float4 hn[ELL_SLOTS], bn[ELL_SLOTS];
+#pragma unroll
+        for (int u = 0; u < ELL_SLOTS; ++u) {
+            const int pk = __builtin_amdgcn_readlane(rec, u);      // uniform
+            const bool ok = u < nd;
+            hn[u] = ok ? *reinterpret_cast<const float4 *>(h + (int64_t)(pk >> 3) * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bn[u] = ok ? *reinterpret_cast<const float4 *>(bond + (int64_t)(pk & 7) * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         const float4 vk = *reinterpret_cast<const float4 *>(vr + k);
         float4 hv = *reinterpret_cast<const float4 *>(h + (int64_t)v * H + k);
         hv.x += vk.x; hv.y += vk.y; hv.z += vk.z; hv.w += vk.w;
         float4 agg = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int eb = e0; eb < e_end; eb += 4) {       // 4 neighbour rows in flight
-            float4 hn[4], bn[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = eb + u;
-                const bool ok = e < e_end;
-                const int sidx = __builtin_amdgcn_readlane(my_src, ok ? (e - e0) & 63 : 0);   // uniform index
-                const int aidx = __builtin_amdgcn_readlane(my_att, ok ? (e - e0) & 63 : 0);
-                const int sv = (e - e0) < 64 ? sidx : src[ok ? e : e0];
-                const int av = (e - e0) < 64 ? aidx : attr[ok ? e : e0];
-                hn[u] = ok ? *reinterpret_cast<const float4 *>(h + (int64_t)sv * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-                bn[u] = ok ? *reinterpret_cast<const float4 *>(bond + (int64_t)av * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < ELL_SLOTS; ++u) {
+            if (u < nd) {
+                const float4 m = gelu4(make_float4(hn[u].x + vk.x + bn[u].x, hn[u].y + vk.y + bn[u].y,
+                                                   hn[u].z + vk.z + bn[u].z, hn[u].w + vk.w + bn[u].w));
+                agg.x += m.x; agg.y += m.y; agg.z += m.z; agg.w += m.w;
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (eb + u < e_end) {
-                    const float4 m = gelu4(make_float4(hn[u].x + vk.x + bn[u].x, hn[u].y + vk.y + bn[u].y,
-                                                       hn[u].z + vk.z + bn[u].z, hn[u].w + vk.w + bn[u].w));
-                    agg.x += m.x; agg.y += m.y; agg.z += m.z; agg.w += m.w;
-                }
+        }
+        if (deg > ELL_SLOTS) {      // rare: the remaining in-edges from the CSR arrays, in order
+            const int e0 = rowptr[v];
+            for (int e = e0 + ELL_SLOTS; e < e0 + deg; ++e) {
+                const float4 hs = *reinterpret_cast<const float4 *>(h + (int64_t)src[e] * H + k);
+                const float4 bs = *reinterpret_cast<const float4 *>(bond + (int64_t)attr[e] * H + k);
+                const float4 m = gelu4(make_float4(hs.x + vk.x + bs.x, hs.y + vk.y + bs.y, hs.z + vk.z + bs.z, hs.w + vk.w + bs.w));
+                agg.x += m.x; agg.y += m.y; agg.z += m.z; agg.w += m.w;
             }
         }
         *reinterpret_cast<float4 *>(h_in + (int64_t)v * H + k) = hv;
@@ -433,6 +454,111 @@ __global__ __launch_bounds__(64) void gin_post2_kernel(const float *__restrict__
             *reinterpret_cast<float4 *>(h + (int64_t)v * H + k) =
                 make_float4(gate.x * y.x + hi[e].x, gate.y * y.y + hi[e].y, gate.z * y.z + hi[e].z, gate.w * y.w + hi[e].w);
         }
+    }
+}
+
+// The same tail with one wave per 256-column chunk of the row (H == WAVES * 256): a lane holds ns + 5 loads in flight instead of
+// (ns + 5) * H / 256, the two row reductions go through LDS (wave order: deterministic).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gin_post2_mw_kernel(const float *__restrict__ slabs, int64_t slab_stride, int ns,
+                                                                  const float *__restrict__ bias, const float *__restrict__ h_in,
+                                                                  const float *__restrict__ lnw, const float *__restrict__ lnb,
+                                                                  const float *__restrict__ mod, int modld, const int *__restrict__ batch,
+                                                                  float *__restrict__ h, float *__restrict__ z_keep, int n, int H, int gelu,
+                                                                  float *__restrict__ vn, const float *__restrict__ vbias, int vrow0) {
+    __shared__ float part[2][WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = tid * 4;
+    if ((int)blockIdx.x >= n) {
+        const int g = blockIdx.x - n;
+        const float *x = slabs + (int64_t)(vrow0 + g) * H;
+        float4 a = *reinterpret_cast<const float4 *>(x + k);
+        for (int q = 1; q < ns; ++q) {
+            const float4 o = *reinterpret_cast<const float4 *>(x + q * slab_stride + k);
+            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        }
+        const float4 bb = *reinterpret_cast<const float4 *>(vbias + k);
+        float4 *dst = reinterpret_cast<float4 *>(vn + (int64_t)g * H + k);
+        const float4 old = *dst;
+        *dst = make_float4(old.x + (a.x + bb.x), old.y + (a.y + bb.y), old.z + (a.z + bb.z), old.w + (a.w + bb.w));
+        return;
+    }
+    const int v = blockIdx.x;
+    const float *x = slabs + (int64_t)v * H;
+    const float *m = mod ? mod + (int64_t)batch[v] * modld : nullptr;
+    float4 a = *reinterpret_cast<const float4 *>(x + k);
+    const float4 hi = *reinterpret_cast<const float4 *>(h_in + (int64_t)v * H + k);
+    const float4 bb = *reinterpret_cast<const float4 *>(bias + k);
+    float4 p0, p1, p2 = make_float4(1.f, 1.f, 1.f, 1.f);      // shift | scale | gate, or LayerNorm weight | bias
+    if (m) {
+        p0 = *reinterpret_cast<const float4 *>(m + k);
+        p1 = *reinterpret_cast<const float4 *>(m + H + k);
+        p2 = *reinterpret_cast<const float4 *>(m + 2 * H + k);
+    } else {
+        p0 = *reinterpret_cast<const float4 *>(lnw + k);
+        p1 = *reinterpret_cast<const float4 *>(lnb + k);
+    }
+    for (int q = 1; q < ns; ++q) {
+        const float4 o = *reinterpret_cast<const float4 *>(x + q * slab_stride + k);
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+    }
+    const float4 t = make_float4(a.x + bb.x, a.y + bb.y, a.z + bb.z, a.w + bb.w);
+    if (z_keep) *reinterpret_cast<float4 *>(z_keep + (int64_t)v * H + k) = t;
+    float s = wave_sum(t.x + t.y + t.z + t.w);
+    if (lane == 0) part[0][wave] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) tot += part[0][i];
+    const float mean = tot / (float)H;
+    const float d0 = t.x - mean, d1 = t.y - mean, d2 = t.z - mean, d3 = t.w - mean;
+    float vr = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+    if (lane == 0) part[1][wave] = vr;
+    __syncthreads();
+    float tv = 0.f;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) tv += part[1][i];
+    const float rstd = rsqrtf(tv / (float)H + 1e-5f);
+    float4 y = make_float4(d0 * rstd, d1 * rstd, d2 * rstd, d3 * rstd);
+    if (m) y = make_float4(y.x * (1.f + p1.x) + p0.x, y.y * (1.f + p1.y) + p0.y, y.z * (1.f + p1.z) + p0.z, y.w * (1.f + p1.w) + p0.w);
+    else y = make_float4(y.x * p0.x + p1.x, y.y * p0.y + p1.y, y.z * p0.z + p1.z, y.w * p0.w + p1.w);
+    if (gelu) y = gelu4(y);
+    *reinterpret_cast<float4 *>(h + (int64_t)v * H + k) = make_float4(p2.x * y.x + hi.x, p2.y * y.y + hi.y, p2.z * y.z + hi.z, p2.w * y.w + hi.w);
+}
+
+// Readout: pool[g] = sum over the graph's nodes of h[v] (global_add_pool, model.py:152), f32 and operand dtype.  Workgroup = (graph,
+// 256-feature chunk); wave w sums nodes v0 + w, v0 + w + 4, ... with eight rows in flight, the four partial sums are added in wave
+// order (deterministic).  The one-workgroup-per-graph form walked the 32 nodes of a molecule in four dependent rounds on half-idle
+// waves (9.5 us at 16 graphs x 512 features).
+template <typename T>
+__global__ __launch_bounds__(256) void gin_pool_add_kernel(const float *__restrict__ h, const int *__restrict__ gptr,
+                                                            float *__restrict__ out32, T *__restrict__ outa, int H) {
+    __shared__ float4 red[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunks = (H + 255) / 256;
+    const int g = blockIdx.x / chunks, k = (blockIdx.x % chunks) * 256 + lane * 4;
+    const int v0 = gptr[g], v1 = gptr[g + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < H) {
+        for (int vb = v0 + wave; vb < v1; vb += 32) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                t[u] = (vb + 4 * u < v1) ? *reinterpret_cast<const float4 *>(h + (int64_t)(vb + 4 * u) * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
+        }
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && k < H) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 o = red[w][lane];
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        if (out32) *reinterpret_cast<float4 *>(out32 + (int64_t)g * H + k) = acc;
+        if (outa) gin_store4<T>(outa + (int64_t)g * H + k, acc);
     }
 }
 
@@ -926,25 +1052,25 @@ __global__ __launch_bounds__(1024) void graph_csr_kernel(const int64_t *__restri
     const int tid = threadIdx.x;
     const int64_t *esrc = edge_index, *edst = edge_index + E;
     // error flag: 0 ok | 1 unsorted or out-of-range `batch` | 2 edge endpoint outside the batch | 3 atom / bond type outside the embedding
-    // tables.  Zeroed before anyone can raise it, raised with atomicMax.  Whatever the flag says, the arrays written below are SAFE to run
+    // tables.  Zeroed before anyone can raise it.  Whatever the flag says, the arrays written below are SAFE to run
     // the GIN kernels on (ids clamped into range, bad edges dropped): the host may look at the flag later than it launches them.
-    if (tid == 0) *err = 0;
-    __syncthreads();
+    if (tid == 0) *err = 0;      // `err` may be pinned HOST memory (no device read-back on the caller's stream): plain stores only --
+    __syncthreads();             // concurrent writers store different non-zero codes, any of which reports the batch as malformed
     for (int i = tid; i <= n; i += 1024) rowptr[i] = 0;
     for (int i = tid; i <= G; i += 1024) gptr[i] = 0;
     for (int i = tid; i < n; i += 1024) {
         const long long xv = x[i];
-        if (xv < 0 || xv >= 118) atomicMax(err, 3);
+        if (xv < 0 || xv >= 118) *err = 3;
         x32[i] = (int)(xv < 0 ? 0 : xv >= 118 ? 117 : xv);
         const long long b = batch[i];
         b32[i] = (int)(b < 0 ? 0 : b >= G ? G - 1 : b);
         cursor[i] = 0;
-        if (b < 0 || b >= G || (i > 0 && batch[i - 1] > b)) atomicMax(err, 1);      // unsorted / out-of-range `batch`
+        if (b < 0 || b >= G || (i > 0 && batch[i - 1] > b)) *err = 1;      // unsorted / out-of-range `batch`
     }
     __syncthreads();
     for (int e = tid; e < E; e += 1024) {
         const long long d = edst[e], sidx = esrc[e];
-        if (d < 0 || d >= n || sidx < 0 || sidx >= n) atomicMax(err, 2);
+        if (d < 0 || d >= n || sidx < 0 || sidx >= n) *err = 2;
         else atomicAdd(&rowptr[d], 1);
     }
     for (int i = tid; i < n; i += 1024) {
@@ -974,7 +1100,7 @@ __global__ __launch_bounds__(1024) void graph_csr_kernel(const int64_t *__restri
             const int e = src[i];
             src[i] = (int)esrc[e];
             const long long av = edge_attr[e];
-            if (av < 0 || av >= 5) atomicMax(err, 3);
+            if (av < 0 || av >= 5) *err = 3;
             attr[i] = (int)(av < 0 ? 0 : av >= 5 ? 4 : av);
         }
     }
@@ -1030,7 +1156,7 @@ struct GinEngine {
     const float *w32 = nullptr;
     GBuf wop;
     GBuf adcat, adbcat;          // predictor: the L adapter Linears concatenated along N ([L * 3H, text_dim] operand dtype, [L * 3H] f32 bias): one GEMM
-    GBuf h, h_in, a0, t1, t1a, zs, vn, pool32, poola, mod, csilu, head1, head1a, head2;
+    GBuf h, h_in, a0, t1, t1a, zs, vn, pool32, poola, mod, csilu, head1, head1a, head2, ell;
     // ---- training (ll_gin_forward keep=1 + ll_gin_backward_c): per-layer activations, transposed weights, gradients
     bool keep = false;
     int kept_n = -1, kept_G = -1;
@@ -1115,7 +1241,8 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
     LL_TRY(e->vn.ensure((size_t)Gp * H * 4));
     LL_TRY(e->pool32.ensure((size_t)Gp * H * 4));
     LL_TRY(e->poola.ensure((size_t)Gp * H * es));
-    const dim3 blk(256), wblk(64);
+    LL_TRY(e->ell.ensure((size_t)n64 * 8 * 4));
+    const dim3 blk(256);
     const int modld = L * 3 * H;
     T *csilu = nullptr;
     if (cf.kind == 1) {
@@ -1124,14 +1251,17 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
         csilu = e->csilu.as<T>();
     }
     {
-        const int64_t items = ((int64_t)n * H + (int64_t)G * H + (csilu ? (int64_t)G * cf.text_dim : 0)) / 4;
+        const int64_t items = ((int64_t)n * H + (int64_t)G * H + (csilu ? (int64_t)G * cf.text_dim : 0)) / 4 + n;
         hipLaunchKernelGGL((gin_prologue_kernel<T>), dim3((unsigned)std::min<int64_t>((items + 255) / 256, 2048)), blk, 0, st,
-                           x, e->atom_emb, e->vn_emb, c, e->text_drop, e->h.as<float>(), e->vn.as<float>(), csilu, n, G, H, cf.text_dim);
+                           x, e->atom_emb, e->vn_emb, c, e->text_drop, e->h.as<float>(), e->vn.as<float>(), csilu, rowptr, src, attr, batch,
+                           e->ell.as<int>(), n, G, H, cf.text_dim);
         LL_LAUNCH_CHECK();
     }
     if (cf.kind == 1)   // (shift, scale, gate) of every layer: ONE GEMM over the N-concatenated adapters -> mod [G][L * 3H]
         LL_TRY(linear_launch(dt, e->csilu.p, cf.text_dim, e->adcat.p, cf.text_dim, e->adbcat.as<float>(), e->mod.p, modld, G, modld, cf.text_dim, 0, 1, st));
-    const int nbn = cdiv(n, 4), chunks = cdiv(H, 256);
+    const int npw = H >= 1024 ? 4 : H >= 512 ? 2 : 1;      // waves per node of the aggregation launch: one pass over the row
+    const int nbn = cdiv(n, 4 / npw), chunks = cdiv(H, 256);
+    const int post_waves = (H % 256 == 0 && H / 256 <= 8 && ((H / 256) & (H / 256 - 1)) == 0) ? H / 256 : 0;
     for (int l = 0; l < L; ++l) {
         const GinEngine::LayerW &w = e->lw[l];
         const bool last = (l == L - 1);
@@ -1143,8 +1273,11 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
             h_in = e->sv_hin[l].as<float>(); t1 = e->sv_t1[l].as<float>(); z_keep = e->sv_z[l].as<float>();
         }
         const int M = last ? n : n64 + G;      // rows of the layer's GEMMs
-        hipLaunchKernelGGL((gin_aggregate2_kernel<T>), dim3(nbn + (last ? 0 : G * chunks)), blk, 0, st, e->h.as<float>(), e->vn.as<float>(), batch,
-                           rowptr, src, attr, w.bond, w.eps, h_in, e->a0.as<T>(), gptr, e->a0.as<T>() + (size_t)n64 * H, n, H, nbn);
+#define LL_AGG(NPW)                                                                                                                \
+    hipLaunchKernelGGL((gin_aggregate2_kernel<T, NPW>), dim3(nbn + (last ? 0 : G * chunks)), blk, 0, st, e->h.as<float>(), e->vn.as<float>(), \
+                       e->ell.as<int>(), rowptr, src, attr, w.bond, w.eps, h_in, e->a0.as<T>(), gptr, e->a0.as<T>() + (size_t)n64 * H, n, H, nbn)
+        if (npw == 4) LL_AGG(4); else if (npw == 2) LL_AGG(2); else LL_AGG(1);
+#undef LL_AGG
         LL_LAUNCH_CHECK();
         LL_TRY(linear_grouped2_launch(dt, e->a0.p, H, w.w0, last ? nullptr : w.vw0, H, w.b0, w.vb0, t1, 4 * H, M, n64, 4 * H, H, 1, 0, 0, 1, st));
         launch_rows_ln_act2<T>(t1, w.ln_w, w.ln_b, e->t1a.as<T>(), M, 4 * H, 1, n, last ? M : n64, w.vln_w, w.vln_b, st);
@@ -1152,11 +1285,20 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
         LL_TRY(linear_grouped2_launch(dt, e->t1a.p, 4 * H, w.w4, last ? nullptr : w.vw4, 4 * H, nullptr, nullptr, e->zs.p, H, M, n64, H, 4 * H, ks,
                                       zstride, 0, 1, st));
         const float *mod = cf.kind == 1 ? e->mod.as<float>() + (size_t)l * 3 * H : nullptr;
-        hipLaunchKernelGGL(gin_post2_kernel, dim3(n + (last ? 0 : G)), wblk, 0, st, e->zs.as<float>(), zstride, ks, w.b4, h_in, w.norm_w, w.norm_b,
-                           mod, modld, batch, e->h.as<float>(), z_keep, n, H, last ? 0 : 1, e->vn.as<float>(), w.vb4, n64);
+#define LL_POST(KERNEL, BLK)                                                                                                       \
+    hipLaunchKernelGGL(KERNEL, dim3(n + (last ? 0 : G)), dim3(BLK), 0, st, e->zs.as<float>(), zstride, ks, w.b4, h_in, w.norm_w, w.norm_b, \
+                       mod, modld, batch, e->h.as<float>(), z_keep, n, H, last ? 0 : 1, e->vn.as<float>(), w.vb4, n64)
+        switch (post_waves) {
+            case 1: LL_POST(gin_post2_mw_kernel<1>, 64); break;
+            case 2: LL_POST(gin_post2_mw_kernel<2>, 128); break;
+            case 4: LL_POST(gin_post2_mw_kernel<4>, 256); break;
+            case 8: LL_POST(gin_post2_mw_kernel<8>, 512); break;
+            default: LL_POST(gin_post2_kernel, 64); break;
+        }
+#undef LL_POST
         LL_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL((segment_pool_kernel<T, false>), dim3(G, cdiv(H, 1024)), blk, 0, st, e->h.as<float>(), gptr, e->pool32.as<float>(), e->poola.as<T>(), H);
+    hipLaunchKernelGGL((gin_pool_add_kernel<T>), dim3(G * chunks), blk, 0, st, e->h.as<float>(), gptr, e->pool32.as<float>(), e->poola.as<T>(), H);
     LL_LAUNCH_CHECK();
     if (pooled) LL_HIP(hipMemcpyAsync(pooled, e->pool32.p, (size_t)G * H * 4, hipMemcpyDeviceToDevice, st));
     if (cf.kind == 0) {  // ProjectionHead + L2 normalise (model.py:37-41,198-205)
@@ -1654,7 +1796,7 @@ int ll_gin_destroy(void *handle) {
     GinEngine *e = (GinEngine *)handle;
     if (!e) return LL_OK;
     (void)hipDeviceSynchronize();
-    GBuf *bufs[] = {&e->wop, &e->adcat, &e->adbcat, &e->h, &e->h_in, &e->a0, &e->t1, &e->t1a, &e->zs, &e->vn, &e->pool32, &e->poola,
+    GBuf *bufs[] = {&e->ell, &e->wop, &e->adcat, &e->adbcat, &e->h, &e->h_in, &e->a0, &e->t1, &e->t1a, &e->zs, &e->vn, &e->pool32, &e->poola,
                     &e->mod, &e->csilu, &e->head1, &e->head1a, &e->head2};
     for (GBuf *b : bufs) b->release();
     GBuf *tb[] = {&e->sv_head1, &e->wT, &e->adT, &e->g_dh, &e->g_dz, &e->g_dt1a, &e->g_dt1, &e->g_dz0, &e->g_c3, &e->g_dmod, &e->g_dmoda,

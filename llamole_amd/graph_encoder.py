@@ -48,21 +48,34 @@ CSR_KERNEL_MAX_NODES, CSR_KERNEL_MAX_EDGES = 32768, 262144     # one workgroup b
 _CSR_ERRORS = {1: "`batch` must be sorted (PyG Batch convention) with ids in [0, num_graphs)",
                2: "edge_index refers to a node outside the batch",
                3: "atom type outside [0, 118) or bond type outside [0, 5)"}
-_pending_csr_flags = []       # (pinned int32[1], event): error flags of conversions whose launch the host has not waited for
+_pending_csr_flags = []       # (slot of the pinned flag ring, event): conversions whose launch the host has not waited for
+_flag_ring = None             # pinned int32[256]: the conversion kernel writes its error flag straight into host memory
+_flag_next = 0
+
+
+def _flag_slot():
+    global _flag_ring, _flag_next
+    if _flag_ring is None:
+        _flag_ring = torch.zeros(256, dtype=torch.int32).pin_memory()
+    if len(_pending_csr_flags) >= 128:
+        check_graph_errors(wait=True)
+    slot = _flag_next
+    _flag_next = (_flag_next + 1) % 256
+    return slot
 
 
 def check_graph_errors(wait: bool = False):
     """Raise ValueError if an earlier ``graph_csr_device`` call saw a malformed batch.  The conversion kernel clamps every id it
-    writes (so the GIN kernels never index out of bounds) and raises a flag, which travels to pinned host memory on the stream;
-    this looks at the flags that have ARRIVED (``wait=True``: at all of them) -- no device synchronisation on the hot path."""
+    writes (so the GIN kernels never index out of bounds) and stores a flag in pinned host memory; this looks at the flags of
+    the launches that have COMPLETED (``wait=True``: waits for all of them) -- no copy and no synchronisation on the hot path."""
     keep, code = [], 0
-    for flag, ev in _pending_csr_flags:
+    for slot, ev in _pending_csr_flags:
         if wait:
             ev.synchronize()
         if ev.query():
-            code = max(code, int(flag[0]))
+            code = max(code, int(_flag_ring[slot]))
         else:
-            keep.append((flag, ev))
+            keep.append((slot, ev))
     _pending_csr_flags[:] = keep
     if code:
         raise ValueError(_CSR_ERRORS.get(code, f"malformed graph batch (code {code})"))
@@ -71,8 +84,8 @@ def check_graph_errors(wait: bool = False):
 def graph_csr_device(x, edge_index, edge_attr, batch, num_graphs=None):
     """``graph_csr`` in ONE launch on the HIP device (``ll_graph_csr``).  With ``num_graphs`` given (``GraphBatch`` tags its
     ``batch`` tensor with it, single-graph callers pass 1) nothing synchronises with the host: the kernel's error flag (unsorted
-    ``batch``, edge / atom / bond id out of range -- all clamped, so whatever runs on the arrays stays in bounds) is copied to pinned
-    memory behind the launch and raised by the next call that finds it (``check_graph_errors``).  Otherwise the graph count is
+    ``batch``, edge / atom / bond id out of range -- all clamped, so whatever runs on the arrays stays in bounds) is written by the
+    kernel into pinned host memory and raised by the next call that finds it (``check_graph_errors``).  Otherwise the graph count is
     read back from ``batch[-1]`` like the ATen route does and the flag is checked right away."""
     check_graph_errors()
     dev = x.device
@@ -82,24 +95,26 @@ def graph_csr_device(x, edge_index, edge_attr, batch, num_graphs=None):
     i32 = dict(dtype=torch.int32, device=dev)
     xs, rowptr, b32, gptr = torch.empty(n, **i32), torch.empty(n + 1, **i32), torch.empty(n, **i32), torch.empty(G + 1, **i32)
     src, attr = torch.empty(ne, **i32), torch.empty(ne, **i32)
-    scratch, err = torch.empty(n, **i32), torch.empty(1, **i32)
+    scratch = torch.empty(n, **i32)
     x64, ei64, ea64, b64 = (t.long().contiguous() for t in (x, edge_index, edge_attr, batch))
+    if known:
+        slot = _flag_slot()
+        err_ptr = C.c_void_p(_flag_ring.data_ptr() + 4 * slot)      # pinned host memory is device-accessible at the same address
+    else:
+        err = torch.empty(1, **i32)
+        err_ptr = _lib.dptr(err)
     _lib.check(_lib.load().ll_graph_csr(_lib.dptr(x64), _lib.dptr(ei64) if ne else None, _lib.dptr(ea64) if ne else None, _lib.dptr(b64),
                                         n, ne, G, _lib.dptr(xs), _lib.dptr(rowptr), _lib.dptr(src) if ne else None,
                                         _lib.dptr(attr) if ne else None, _lib.dptr(b32), _lib.dptr(gptr), _lib.dptr(scratch),
-                                        _lib.dptr(err), _lib.current_stream_ptr()), "ll_graph_csr")
+                                        err_ptr, _lib.current_stream_ptr()), "ll_graph_csr")
     if not known:
         code = int(err.item())
         if code:
             raise ValueError(_CSR_ERRORS.get(code, f"malformed graph batch (code {code})"))
     else:
-        flag = torch.zeros(1, dtype=torch.int32).pin_memory()
-        flag.copy_(err, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        _pending_csr_flags.append((flag, ev))
-        if len(_pending_csr_flags) > 64:
-            check_graph_errors(wait=True)
+        _pending_csr_flags.append((slot, ev))
     return xs, rowptr, src, attr, b32, gptr, n, ne, G
 
 

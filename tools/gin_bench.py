@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--out-dim", type=int, default=180576)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--only", default="all", choices=["all", "encoder", "predictor", "train"], help="time one leg only (profiling)")
     a = ap.parse_args()
     from llamole_amd.graph_encoder import GraphCLIP
     from llamole_amd.graph_predictor import GraphPredictor
@@ -68,8 +69,9 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / a.iters
 
-    t_enc = timeit(lambda: enc(xs, eis, eas, bs))
-    t_pred = timeit(lambda: pred.topk_templates(xs, eis, eas, bs, c, 50))
+    nan = float("nan")
+    t_enc = timeit(lambda: enc(xs, eis, eas, bs)) if a.only in ("all", "encoder") else nan
+    t_pred = timeit(lambda: pred.topk_templates(xs, eis, eas, bs, c, 50)) if a.only in ("all", "predictor") else nan
     # SFT: retro cross-entropy forward + reverse sweep w.r.t. the condition (weights frozen)
     labels = torch.randint(0, a.out_dim, (G,), device=dev)
 
@@ -78,7 +80,7 @@ def main():
         loss = torch.nn.functional.cross_entropy(pred(xs, eis, eas, bs, cg).float(), labels)
         loss.backward()
         return cg.grad
-    t_train = timeit(train_step)
+    t_train = timeit(train_step) if a.only in ("all", "train") else nan
     dec_bytes = a.out_dim * 4 * H * 2
     out = {"workload": f"GIN encoder + predictor(top-50 of {a.out_dim}) on {G} graphs x 32 atoms, H={H}, L={L}, bf16",
            "encoder_ms": 1e3 * t_enc, "predictor_topk_ms": 1e3 * t_pred,
@@ -86,7 +88,7 @@ def main():
            "sft_retro_fwd_bwd_ms": 1e3 * t_train, "sft_retro_graphs_per_s": G / t_train,
            "sft_head_hbm_frac_if_all_time": 2 * dec_bytes / t_train / 8e12,
            "decoder_hbm_frac_if_all_time": dec_bytes / t_pred / 8e12}
-    if not a.no_cpu:
+    if not a.no_cpu and a.only == "all":
         from bench import usable_cores
         from oracle import gin_oracle as go
         cores = usable_cores()
