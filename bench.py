@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """Benchmark of the Llamole interleaved-generation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload graphdit|e2e]
+    python bench.py --gpus N --steps K --warmup W [--workload graphdit|e2e|retro|sft]
 
 One "step" = one pass of the hot path over one batch of synthetic prompts+conditions:
   * graphdit : B property/text conditions -> full T-step GraphDiT reverse diffusion -> B integer
                molecule graphs (BASELINE.json configs[0] shape at the reference-default denoiser size);
-  * e2e      : BASELINE.json configs[1]: Qwen2-7B (random-init, HF on PyTorch-ROCm) decodes to the
-               design trigger, query-token re-forward, connector, then the GraphDiT trajectory.
-Prints ONE JSON line (rank 0).  `value` = molecules/s over all ranks (weak scaling: every rank runs
-its own batch of independent prompts; no data-path collective, one small all-gather of the graphs).
+  * e2e      : BASELINE.json configs[1] (the default): Qwen2-7B (random-init, HF on PyTorch-ROCm) decodes to the
+               design trigger, query-token re-forward, connector, then the GraphDiT trajectory;
+  * retro    : BASELINE.json configs[2]: Qwen2-7B + GraphDiT + GIN predictor, 16 prompts per GPU: design phase as one
+               batch, then 16 A* retrosynthesis searches in lock step, <= 5 expansions each (scripted chemistry);
+  * sft      : BASELINE.json configs[4]: Mistral-7B architecture + LoRA, LM loss + retro cross-entropy through the
+               frozen HIP GIN encoder / predictor (forward + reverse sweep), AdamW, gradient all-reduce over the ranks.
+Prints ONE JSON line (rank 0).  `value` = molecules/s (samples/s for sft) over all ranks (weak scaling: every rank runs
+its own batch of independent prompts; no data-path collective, one small all-gather of the results; sft: one bucketed
+gradient all-reduce per step).
 """
 import argparse
 import json
 import os
 import sys
 import time
+import types
 
 import numpy as np
 import torch
@@ -166,6 +172,103 @@ def cpu_baseline_e2e(args, llm, cfg, meta, sd, props, text, n_nodes):
             "denoise_steps_per_s": dit["denoise_steps_per_s"]}
 
 
+def cpu_baseline_retro(args, llm, sd_pred, cores: int, n_new_nodes: float):
+    """The reference's CPU path of one expansion on this box's host cores, bounded sample, extrapolated: the same HF LLM on the CPU
+    (prompt pass + 2 decode tokens) and the GIN oracle (predictor forward + top-k of one product).  One expansion of the reference =
+    analysis decode (`retro_tokens`) + query re-forward + predictor + one LLM forward per new tree node (value estimates)."""
+    from oracle import gin_oracle as go      # test infrastructure: the CPU restatement is only ever the thing TIMED here, never shipped
+    torch.set_num_threads(cores)
+    llm_cpu = llm.to("cpu")
+    prompt = torch.randint(5, 1000, (1, args.cutoff_len))
+    kw = dict(do_sample=False, pad_token_id=0)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        llm_cpu.generate(inputs=prompt, attention_mask=torch.ones_like(prompt), max_new_tokens=1, **kw)
+        t1 = time.perf_counter()
+        llm_cpu.generate(inputs=prompt, attention_mask=torch.ones_like(prompt), max_new_tokens=3, **kw)
+        t2 = time.perf_counter()
+    prefill = t1 - t0
+    per_tok = max(1e-6, ((t2 - t1) - prefill) / 2)
+    x, ei, ea, batch = synth.make_mol_graphs(1, 0, min_atoms=32, max_atoms=32)
+    sd_cpu = {k: v.float().cpu() for k, v in sd_pred.items()}
+    c = torch.randn(1, 768)
+    with torch.no_grad():
+        go.predictor_forward(sd_cpu, 5, x, ei, ea, batch, c)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 4.0 and n < 10:
+            go.template_topk(go.predictor_forward(sd_cpu, 5, x, ei, ea, batch, c), args.topk)
+            n += 1
+        gin_s = (time.perf_counter() - t0) / n
+    requery = prefill * (args.cutoff_len + args.retro_tokens + 9) / args.cutoff_len
+    per_exp = prefill + args.retro_tokens * per_tok + requery + gin_s + n_new_nodes * prefill
+    per_search = args.iterations * per_exp
+    return {"value": 1.0 / per_search, "unit": "molecules/s", "cores": cores, "kind": "port",
+            "sample": f"HF {args.llm} (random-init, bf16) on {cores} CPU threads: prompt pass {prefill:.2f} s, {per_tok:.3f} s/token over 2 decode "
+                      f"tokens; fp32 GIN oracle predictor + top-{args.topk} of one product {gin_s * 1e3:.0f} ms ({n} calls); one expansion = "
+                      f"{args.retro_tokens}-token analysis + query re-forward + predictor + {n_new_nodes:.0f} value forwards (one per new tree "
+                      f"node, the reference's structure) = {per_exp:.1f} s; a search = {args.iterations} expansions; design phase not included",
+            "expansions_per_s": 1.0 / per_exp}
+
+
+
+def cpu_baseline_sft(args, cores: int, sd_pred, n_retro: int):
+    """The reference's CPU path of one SFT step on this box's host cores, bounded sample, extrapolated: forward + backward of a
+    TWO-layer slice of the same LLM architecture with LoRA on `sft_batch` x `sft_seq` tokens (times layers / 2, plus the measured
+    lm_head + loss), and the fp32 GIN oracle's predictor forward + autograd for the step's retro queries."""
+    import transformers
+    from oracle import gin_oracle as go
+    from llamole_amd import e2e
+    from llamole_amd.sft import add_lora
+    torch.set_num_threads(cores)
+    spec = dict(e2e.LLM_CONFIGS[args.llm])
+    kind = spec.pop("cls")
+    L = spec["num_hidden_layers"]
+    spec["num_hidden_layers"] = 2
+    cfg = getattr(transformers, kind + "Config")(**spec)
+    torch.manual_seed(0)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        m = getattr(transformers, kind + "ForCausalLM")(cfg)
+    finally:
+        torch.set_default_dtype(prev)
+    add_lora(m)
+    ids = torch.randint(5, 1000, (args.sft_batch, args.sft_seq))
+
+    def run(model):
+        out = model(input_ids=ids, labels=ids)
+        out.loss.backward()
+    run(m)
+    t0 = time.perf_counter()
+    run(m)
+    t2 = time.perf_counter() - t0
+    # the same with the decoder layers skipped: embedding + lm_head + loss only
+    m.model.layers = m.model.layers[:0]
+    run(m)
+    t0 = time.perf_counter()
+    run(m)
+    t_head = time.perf_counter() - t0
+    per_layer = max(0.0, (t2 - t_head) / 2)
+    x, ei, ea, batch = synth.make_mol_graphs(n_retro, 0, min_atoms=32, max_atoms=32)
+    sd_cpu = {k: v.float().cpu() for k, v in sd_pred.items()}
+    c = torch.randn(n_retro, 768, requires_grad=True)
+    lab = torch.randint(0, args.out_dim, (n_retro,))
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 6.0 and n < 5:
+        loss = torch.nn.functional.cross_entropy(go.predictor_forward(sd_cpu, 5, x, ei, ea, batch, c), lab)
+        torch.autograd.grad(loss, c)
+        n += 1
+    gin_s = (time.perf_counter() - t0) / n
+    step_s = per_layer * L + t_head + gin_s
+    return {"value": args.sft_batch / step_s, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"HF {args.llm} architecture (random-init, bf16) + LoRA on {cores} CPU threads: forward + backward of a 2-layer slice on "
+                      f"{args.sft_batch} x {args.sft_seq} tokens = {per_layer:.2f} s per layer (x {L} layers), embedding + lm_head + loss "
+                      f"{t_head:.2f} s; fp32 GIN oracle predictor forward + autograd for {n_retro} retro queries {gin_s * 1e3:.0f} ms ({n} calls); "
+                      f"extrapolated step {step_s:.1f} s (optimizer step not included)"}
+
+
 def time_dominant_kernel(args, device):
     """The dominant hand-written kernel of the workload, timed by HIP events on the stream it is launched on, back to
     back over enough distinct weight matrices to defeat the 256 MiB Infinity Cache (ll_gemm_bench in the C ABI):
@@ -204,18 +307,62 @@ def time_dominant_kernel(args, device):
         name = f"gemv_bf16_kernel, LLM MLP up-projection [{M}x{K}]x[{N}x{K}]^T bf16 (decode step)"
         key = f"llm_gemv_m{M}_n{N}_k{K}"
     else:
-        H, Hm = args.hidden, int(args.hidden * 4)
-        M, N, K = 2 * args.batch * args.nodes, Hm, H
-        kern = ("gemm_m64_kernel<8,8,bf16,packed>" if M <= 64 else "gemm_bf16_pipeu_kernel<64,64,4,4,4>" if M < 1024 else
-                "gemm_bf16_pipe_kernel<128,128,4,4,3>" if M < 2048 else "gemm_bf16_pipe_kernel<256,128,4,4,3>")
-        name = f"{kern}, GraphDiT block-MLP fc1 [{M}x{K}]x[{N}x{K}]^T bf16"
-        key = f"fc1_m{M}"
+        return time_graphdit_kernel(args, args.batch)
     nw = max(2, int(600e6 // (N * K * 2)))
     ms = C.c_float()
     _lib.check(lib.ll_gemm_bench(M, N, K, -1, 1, 0, 4 * nw, nw, C.byref(ms)), "ll_gemm_bench")
     nbytes = N * K * 2 + M * K * 2 + M * N * 2
     flops = 2.0 * M * N * K
     return ms.value, nbytes, flops, name, key
+
+
+def time_graphdit_kernel(args, batch: int):
+    """The dominant kernel of the GraphDiT step at `batch` graphs: the block-MLP fc1 GEMM at M = 2 * batch * N token rows, on whatever
+    kernel the production dispatch picks for that M (32-33 % of the step's GPU time in profiles/r*_graphdit_b{1,8}_kernel_stats.csv),
+    timed by HIP events over distinct weight matrices (ll_gemm_bench).  Returns (avg_ms, algorithmic bytes, flops, name, pmc key)."""
+    import ctypes as C
+    from llamole_amd import _lib
+    lib = _lib.load()
+    H, Hm = args.hidden, int(args.hidden * 4)
+    M, N, K = 2 * batch * args.nodes, Hm, H
+    kern = ("gemm_m64_kernel<8,8,bf16,packed>" if M <= 64 else "gemm_m128_kernel" if M <= 224 else
+            "gemm_bf16_pipeu_kernel<64,64,4,4,4>" if M < 1024 else
+            "gemm_bf16_pipe_kernel<128,128,4,4,3>" if M < 2048 else "gemm_bf16_pipe_kernel<256,128,4,4,3>")
+    name = f"{kern}, GraphDiT block-MLP fc1 [{M}x{K}]x[{N}x{K}]^T bf16"
+    key = f"fc1_m{M}"
+    nw = max(2, int(600e6 // (N * K * 2)))
+    ms = C.c_float()
+    _lib.check(lib.ll_gemm_bench(M, N, K, -1, 1, 0, 4 * nw, nw, C.byref(ms)), "ll_gemm_bench")
+    nbytes = N * K * 2 + M * K * 2 + M * N * 2
+    flops = 2.0 * M * N * K
+    return ms.value, nbytes, flops, name, key
+
+
+def roofline_object(args, dom):
+    """`roofline` of the JSON line from (avg_ms, algorithmic bytes, flops, kernel name, pmc key): HBM- or MFMA-bound by which peak the
+    kernel's algorithmic work would take longer on; `traffic` from the PMC passes committed under profiles/ (same kernel, same shape)."""
+    kms, kbytes, kflops, kname, kkey = dom
+    hbm_t, mfma_t = kbytes / (HBM_PEAK_GBS * 1e9), kflops / (MFMA_BF16_PEAK_TF * 1e12)
+    if hbm_t >= mfma_t or args.dtype != "bf16":
+        roof = {"bound": "hbm", "achieved": kbytes / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    else:
+        roof = {"bound": "mfma", "achieved": kflops / (kms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["traffic"] = None
+    for pmc_file in ("r3_pmc_traffic.json", "r2_pmc_traffic.json"):     # r1/r2 entries: LLM kernels (frozen since) and the GraphDiT fc1 GEMMs
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+        except Exception:
+            continue
+        if kkey in pmc and args.dtype == "bf16" and (not kkey.startswith("fc1") or args.hidden == 1024):
+            roof["traffic"] = pmc[kkey]["hbm_bytes_per_launch"]
+            roof["traffic_source"] = f"profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
+            break
+    roof["algorithmic_bytes"] = kbytes
+    roof["algorithmic_flops"] = kflops
+    roof["kernel"] = kname
+    roof["kernel_ms"] = kms
+    return roof
 
 
 def spawn_ranks(n: int) -> int:
@@ -257,6 +404,155 @@ def spawn_ranks(n: int) -> int:
     return rc
 
 
+
+def _barrier(ctx):
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _max_over_ranks(ctx, dt: float) -> float:
+    if ctx.dist is None:
+        return dt
+    t = torch.tensor([dt], device=ctx.device if ctx.dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+    ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def time_template_head(args, graphs: int):
+    """The weight stream of the GIN predictor's template head ([graphs, 4H] x [out_dim, 4H]^T, 740 MB of bf16 at 180 576 templates:
+    rows16_kernel<plain, f32 out>), timed by HIP events on its own stream over two distinct weight copies (ll_rows16_bench)."""
+    import ctypes as C
+    from llamole_amd import _lib
+    lib = _lib.load()
+    K, N, M = 4 * 512, args.out_dim, max(3, min(16, graphs))
+    ms = C.c_float()
+    _lib.check(lib.ll_rows16_bench(M, N, K, 0x100, 0, 16, 2, C.byref(ms)), "ll_rows16_bench")
+    nbytes = N * K * 2 + M * K * 2 + M * N * 4 + N * 4
+    roof = {"bound": "hbm", "achieved": nbytes / (ms.value * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["traffic"] = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))
+        key = f"gin_head_rows16_m{M}_n{N}_k{K}"
+        if key in pmc:
+            roof["traffic"] = pmc[key]["hbm_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/r3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
+    except Exception:
+        pass
+    roof["algorithmic_bytes"] = nbytes
+    roof["kernel"] = (f"rows16_kernel<plain, f32 out>, GIN predictor template head [{M}x{K}]x[{N}x{K}]^T bf16 (decoder.4 of "
+                      f"graph_predictor/model.py:272-278)")
+    roof["kernel_ms"] = ms.value
+    return roof
+
+
+def run_retro(args, ctx):
+    """BASELINE.json configs[2]: design + lock-step A* retrosynthesis for `targets` prompts per GPU (llamole_amd/workloads.py)."""
+    from llamole_amd.workloads import build_retro_step
+    m, cfg, meta, sd = build_model(args, ctx.device)
+    step_fn, info, orch, llm, sd_pred = build_retro_step(args, m, ctx.device, ctx.rank)
+    log("retro workload built")
+    for i in range(args.warmup):
+        step_fn(i)
+    _barrier(ctx)
+    step_fn.count.update(expansions=0, value_estimates=0)
+    t0 = time.perf_counter()
+    recs, design_s, retro_s, value_s = [], 0.0, 0.0, 0.0
+    for i in range(args.steps):
+        _maybe_fail(ctx.rank, i)
+        mols, rec = step_fn(args.warmup + i)
+        recs.append(rec)
+        design_s += info["timing_breakdown"]["design_s"]
+        retro_s += info["timing_breakdown"]["retro_s"]
+        value_s += info["timing_breakdown"]["value_forward_s"]
+    _barrier(ctx)
+    dt = _max_over_ranks(ctx, time.perf_counter() - t0)
+    n_exp, n_val = step_fn.count["expansions"], step_fn.count["value_estimates"]
+    gathered = recs[-1]
+    if ctx.dist is not None:
+        # the path's only exchange: one all-gather of fixed-size per-target route records (and of the expansion counts)
+        dev = ctx.device if ctx.dist.get_backend() == "nccl" else "cpu"
+        bufs = [torch.empty_like(recs[-1], device=dev) for _ in range(ctx.world)]
+        ctx.dist.all_gather(bufs, recs[-1].to(dev))
+        gathered = torch.cat([b.cpu() for b in bufs])
+        cnt = torch.tensor([n_exp, n_val], device=dev, dtype=torch.float64)
+        ctx.dist.all_reduce(cnt)
+        n_exp, n_val = int(cnt[0].item()), int(cnt[1].item())
+    if ctx.rank != 0:
+        return None
+    T = args.targets
+    roof = time_template_head(args, T)
+    out = {"metric": "retrosynthesis-planned molecules/sec (design + A* search, depth <= %d)" % args.iterations,
+           "value": ctx.world * T * args.steps / dt, "unit": "molecules/s", "n_gpus": ctx.n_ranks, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+           "data": "synthetic",
+           "config": {"workload": "%s + GraphDiT + GIN predictor A* retrosynthesis, depth<=%d, batch=%d/GPU" % (LLM_LABEL.get(args.llm, args.llm), args.iterations, T),
+                      "prompts_per_step": ctx.world * T, "gathered_routes": int(gathered.shape[0]),
+                      "denoiser": {"hidden": args.hidden, "depth": args.depth, "heads": args.heads, "max_nodes": args.nodes, "T": args.T,
+                                   "guide_scale": args.guide}, **{k: v for k, v in info.items() if k != "timing_breakdown"}},
+           "expansions_per_s": n_exp / dt, "expansions": n_exp, "value_estimates_per_expansion": n_val / max(1, n_exp),
+           "design_share_of_step": design_s / max(1e-9, design_s + retro_s),
+           "value_forward_share_of_step": value_s / max(1e-9, design_s + retro_s),
+           "value_forward_note": "A* value estimates: one left-padded LLM prefill per 64 new tree nodes (~100 nodes per expansion, ~130 tokens each) -- "
+                                 "stock HF forward on PyTorch-ROCm / hipBLASLt at M ~ 8 k rows, compute-bound; the reference runs one forward per node",
+           "routes_found": int(gathered[:, 0].sum().item()),
+           "roofline": roof}
+    if not args.no_cpu_baseline and ctx.world == 1:
+        log("cpu baseline ...")
+        out["cpu_baseline"] = cpu_baseline_retro(args, llm, sd_pred, usable_cores(), n_val / max(1, n_exp))
+    return out
+
+
+def run_sft(args, ctx):
+    """BASELINE.json configs[4]: one SFT optimizer step per bench step, data-parallel over the ranks (llamole_amd/workloads.py)."""
+    from llamole_amd.workloads import build_sft_step
+    step_fn, info, model, sd_pred, batch = build_sft_step(args, ctx.device, ctx.rank)
+    log("sft workload built")
+    for i in range(args.warmup):
+        step_fn(i)
+    _barrier(ctx)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        _maybe_fail(ctx.rank, i)
+        logd = step_fn(args.warmup + i)
+    _barrier(ctx)
+    dt = _max_over_ranks(ctx, time.perf_counter() - t0)
+    if ctx.rank != 0:
+        return None
+    B, S = args.sft_batch, args.sft_seq
+    n_retro = int(batch["retro_product_graphs"].num_graphs)
+    graph_ms = step_fn.graph_side_ms()
+    roof = time_template_head(args, n_retro)
+    roof["kernel"] += "; the reverse sweep streams the same 740 MB once more (dlogits x W, 16-way split-K)"
+    out = {"metric": "SFT samples/sec (LM loss + retro cross-entropy, LoRA)", "value": ctx.world * B * args.steps / dt, "unit": "samples/s",
+           "n_gpus": ctx.n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "%s LoRA SFT (LLM fwd/bwd + GIN encoder + GIN predictor fwd/bwd), %d x %d tokens/GPU, data-parallel"
+                                  % (LLM_LABEL.get(args.llm, args.llm), B, S),
+                      "global_batch": ctx.world * B, "seq_len": S, "parallelism": "dp%d" % ctx.world,
+                      "gradient_exchange": "one direct all-reduce per 64 MB bucket of the trainable set (llamole_amd.distributed.allreduce_gradients)",
+                      **{k: v for k, v in info.items() if k != "last_log"}},
+           "tokens_per_s": ctx.world * B * S * args.steps / dt, "graph_side_ms": graph_ms, "graph_side_share": graph_ms / (1e3 * dt / args.steps),
+           "loss": logd["loss"], "lm_loss": logd.get("lm_loss"), "retro_loss": logd.get("retro_loss"),
+           "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+           "roofline": roof}
+    if not args.no_cpu_baseline and ctx.world == 1:
+        log("cpu baseline ...")
+        del model
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline_sft(args, usable_cores(), sd_pred, n_retro)
+    return out
+
+
+def _maybe_fail(rank: int, step: int):
+    """Test hook (tests/test_bench_gpu.py): LLAMOLE_BENCH_FAIL_RANK=r makes rank r raise inside its first timed step, to check that the
+    launcher ends the job with a non-zero exit instead of leaving the peers waiting in a collective."""
+    r = os.environ.get("LLAMOLE_BENCH_FAIL_RANK")
+    if r is not None and int(r) == rank and step == 0:
+        raise RuntimeError(f"bench.py: injected failure on rank {rank} (LLAMOLE_BENCH_FAIL_RANK)")
+
+
 GRAPH_MODE = None
 
 
@@ -265,7 +561,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="e2e", choices=["graphdit", "e2e"])
+    ap.add_argument("--workload", default="e2e", choices=["graphdit", "e2e", "retro", "sft"])
     ap.add_argument("--batch", type=int, default=None, help="prompts per GPU per step")
     ap.add_argument("--nodes", type=int, default=32)
     ap.add_argument("--hidden", type=int, default=1024)
@@ -277,7 +573,14 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="GraphDiT trajectory: launch every kernel (no hipGraph replay)")
     ap.add_argument("--graph", action="store_true", help="GraphDiT trajectory: force the hipGraph replay (default: the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--llm", default="qwen2-7b")
+    ap.add_argument("--llm", default=None, help="LLM architecture (default: qwen2-7b; mistral-7b for --workload sft)")
+    ap.add_argument("--targets", type=int, default=16, help="retro: target molecules (prompts) per GPU per step")
+    ap.add_argument("--iterations", type=int, default=5, help="retro: expansions per A* search (search depth <= this)")
+    ap.add_argument("--retro-tokens", type=int, default=64, help="retro: analysis tokens decoded per expansion (the reference allows 512)")
+    ap.add_argument("--topk", type=int, default=50, help="retro: templates kept per expansion")
+    ap.add_argument("--out-dim", type=int, default=180576, help="retro / sft: reaction templates of the GIN predictor head")
+    ap.add_argument("--sft-batch", type=int, default=2, help="sft: rows per GPU per step")
+    ap.add_argument("--sft-seq", type=int, default=512, help="sft: tokens per row")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--cutoff-len", type=int, default=128)
     ap.add_argument("--no-llm-layer-fuse", dest="llm_layer_fuse", action="store_false",
@@ -302,6 +605,8 @@ def main():
                     help="strong scaling: one step = this many prompts over ALL ranks (BASELINE configs[3]: 64 prompts, 8 per GPU at "
                          "8 GPUs); every rank runs its contiguous share in batches of --batch.  Default: weak scaling, --batch per GPU")
     args = ap.parse_args()
+    if args.llm is None:
+        args.llm = "mistral-7b" if args.workload == "sft" else "qwen2-7b"
     global GRAPH_MODE
     GRAPH_MODE = False if args.no_graph else (True if args.graph else None)      # None: the library's choice
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -309,7 +614,9 @@ def main():
         # (a process that has initialised the GPU must not exec/replace itself on this pool; device_count() does not initialise)
         raise SystemExit(spawn_ranks(args.gpus))
     if args.batch is None:
-        args.batch = 8 if (args.workload == "graphdit" or args.total_prompts) else 1
+        args.batch = 8 if (args.workload == "graphdit" or args.total_prompts) else args.targets if args.workload == "retro" else 1
+    if args.workload == "retro":
+        args.batch = args.targets
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -347,6 +654,14 @@ def main():
         dist.all_reduce(ones)
         n_ranks = int(ones.item())
         assert n_ranks == world, (n_ranks, world)
+    if args.workload in ("retro", "sft"):
+        ctx = types.SimpleNamespace(rank=rank, world=world, device=device, dist=dist, n_ranks=n_ranks)
+        out = run_retro(args, ctx) if args.workload == "retro" else run_sft(args, ctx)
+        if out is not None:
+            print(json.dumps(out))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     from llamole_amd.distributed import shard_range
     batches_per_step = 1
     if args.total_prompts:
@@ -390,6 +705,7 @@ def main():
         del step_fn.dit_ms[:]
     done = []                            # molecules this rank produced in the timed region, in prompt order
     for i in range(args.steps * nb):
+        _maybe_fail(rank, i)
         mols = step_fn(args.warmup * nb + i)
         if not piped:
             dit_ms.append(m.last_run_ms()[0])
@@ -433,27 +749,14 @@ def main():
     dom = time_dominant_kernel(args, device)
     if dom is None:      # f32 parity mode has no tuned kernel to report
         dom = (float("nan"), 0, 0.0, "n/a (f32 parity mode)", "")
-    kms, kbytes, kflops, kname, kkey = dom
-    log("dominant kernel timed", kms)
-    hbm_t, mfma_t = kbytes / (HBM_PEAK_GBS * 1e9), kflops / (MFMA_BF16_PEAK_TF * 1e12)
-    if hbm_t >= mfma_t or args.dtype != "bf16":
-        roof = {"bound": "hbm", "achieved": kbytes / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-    else:
-        roof = {"bound": "mfma", "achieved": kflops / (kms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s"}
-    roof["frac"] = roof["achieved"] / roof["peak"]
-    roof["traffic"] = None
-    try:   # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same shape)
-        pmc_file = "r2_pmc_traffic.json"       # r1 entries (LLM kernels, frozen since) + the GraphDiT fc1 GEMM re-measured at HEAD
-        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-        key = kkey
-        if key in pmc and args.dtype == "bf16" and (not key.startswith("fc1") or args.hidden == 1024):
-            roof["traffic"] = pmc[key]["hbm_bytes_per_launch"]
-            roof["traffic_source"] = f"profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
-    except Exception:
-        pass
-    roof["algorithmic_bytes"] = kbytes
-    roof["kernel"] = kname
-    roof["kernel_ms"] = kms
+    log("dominant kernel timed", dom[0])
+    roof = roofline_object(args, dom)
+    # north_star's own kernel target is the GraphDiT step: its dominant kernel at the batch the trajectories of this run had
+    dit_batch = B * int(getattr(step_fn, "group", 1) or 1)
+    roof_dit = roofline_object(args, time_graphdit_kernel(args, dit_batch)) if args.dtype == "bf16" else None
+    if roof_dit is not None:
+        roof_dit["graphs_per_trajectory"] = dit_batch
+        roof_dit["share_of_step"] = "32-33 % of the GraphDiT step's GPU time (profiles/r3_graphdit_b1|b8_kernel_stats.csv)"
     out = {
         "metric": "generated molecules/sec (end-to-end)" if args.workload == "e2e"
                   else "generated molecules/sec (GraphDiT reverse diffusion, no LLM)",
@@ -477,6 +780,7 @@ def main():
                           "hbm_frac": sbytes / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
                           "mfma_frac": sflops / (step_ms * 1e-3) / (MFMA_BF16_PEAK_TF * 1e12)},
         "roofline": roof,
+        "roofline_graphdit": roof_dit,
     }
     if not args.no_cpu_baseline and world == 1:
         log("cpu baseline ...")

@@ -326,7 +326,7 @@ int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iter
  *     transformers modeling_qwen2.py) under the reference's language_model.generate (modeling_llamole.py:599, :849).
  * ll_set_rows16_geometry : tuning -- bytes of a row per block (128 | 256 | 512), waves per workgroup (4 | 8) and how many
  *     consecutive waves split K of one tile; (0, 0, 0) = chosen by tile count.
- * ll_rows16_bench : timing utility (HIP events, `nweights` distinct weight matrices). */
+ * ll_rows16_bench : timing utility (HIP events, `nweights` distinct weight matrices); epi | 0x100 = f32 output (the GIN template head). */
 int ll_linear_rows16_bf16(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *norm_w, float eps,
                           const void *residual, int ldr, void *out, int ldc, int M, int N, int K, int epi, void *stream);
 int ll_set_rows16_geometry(int seg, int waves, int ksplit);

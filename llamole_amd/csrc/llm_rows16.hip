@@ -289,11 +289,13 @@ int ll_set_rows16_geometry(int seg, int waves, int ksplit) {
 // Times ll_linear_rows16_bf16 on synthetic operands over `nweights` distinct weight matrices (defeats the Infinity Cache).
 int ll_rows16_bench(int M, int N, int K, int epi, int norm, int iters, int nweights, float *ms) {
     LL_CHECK(ms && iters > 0 && nweights > 0 && M >= 1 && M <= 16, "bad argument");
+    const int out_f32 = (epi & 0x100) ? 1 : 0;      // epi | 0x100: f32 output (the GIN template head), plain epilogue only
+    epi &= 0xff;
     const int rowsW = epi == R16_SILU_MUL ? 2 * N : N;
     bf16_t *X = nullptr, *W = nullptr, *C = nullptr, *R = nullptr;
     LL_HIP(hipMalloc(&X, (size_t)16 * K * 2));
     LL_HIP(hipMalloc(&W, (size_t)nweights * rowsW * K * 2));
-    LL_HIP(hipMalloc(&C, (size_t)16 * N * 2));
+    LL_HIP(hipMalloc(&C, (size_t)16 * N * 4));
     LL_HIP(hipMalloc(&R, (size_t)16 * N * 2));
     LL_HIP(hipMemset(X, 0x11, (size_t)16 * K * 2));
     LL_HIP(hipMemset(R, 0x11, (size_t)16 * N * 2));
@@ -307,7 +309,7 @@ int ll_rows16_bench(int M, int N, int K, int epi, int norm, int iters, int nweig
     for (int pass = 0; pass < 2 && rc == LL_OK; ++pass) {
         if (pass == 1) (void)hipEventRecord(e0, st);
         for (int i = 0; i < (pass ? iters : nweights) && rc == LL_OK; ++i)
-            rc = linear_rows16_launch(X, K, W + (size_t)(i % nweights) * rowsW * K, K, nullptr, norm ? X : nullptr, 1e-6f, R, N, C, N, M, N, K, epi, 0, st);
+            rc = linear_rows16_launch(X, K, W + (size_t)(i % nweights) * rowsW * K, K, nullptr, norm ? X : nullptr, 1e-6f, R, N, C, N, M, N, K, epi, out_f32, st);
     }
     (void)hipEventRecord(e1, st);
     hipError_t he = hipEventSynchronize(e1);

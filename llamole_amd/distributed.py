@@ -91,8 +91,11 @@ def allreduce_gradients(params, bucket_bytes: int = 64 << 20, group=None) -> int
     world = dist.get_world_size(group)
     # The bucket layout must be the SAME on every rank, so it is built from the fixed list of trainable parameters, never from
     # which of them happen to carry a gradient: a rank whose shard has no <molecule> token produces no connector gradient, a
-    # rank without a retro label none for lm_to_graph_predictor -- those enter as zeros (what DDP's find_unused_parameters
-    # does) and receive the average like everybody else.  Mismatched bucket lengths would hang or corrupt an RCCL all-reduce.
+    # rank without a retro label none for lm_to_graph_predictor -- those enter the sum as zeros.  A parameter that has a gradient
+    # on NO rank must stay without one, exactly as on a single GPU (AdamW would otherwise apply weight decay and moment decay to
+    # it under N GPUs and skip it under one): each bucket carries one extra element per parameter, 1 where the rank has a
+    # gradient, and parameters whose count comes back 0 get ``grad = None`` again.  Mismatched bucket lengths would hang or
+    # corrupt an RCCL all-reduce; this layout depends on the parameter list alone.
     by_dtype = {}
     for p in params:
         if p.requires_grad:
@@ -106,13 +109,29 @@ def allreduce_gradients(params, bucket_bytes: int = 64 << 20, group=None) -> int
             nonlocal calls
             if not bucket:
                 return
-            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-            flat.div_(world)
+            total = sum(p.numel() for p in bucket)
+            flat = torch.zeros(total + len(bucket), dtype=dtype, device=device)
             off = 0
-            for p in bucket:
+            for i, p in enumerate(bucket):
                 n = p.numel()
-                if p.grad is None:
+                if p.grad is not None:
+                    flat[off:off + n].copy_(p.grad.reshape(-1))
+                    flat[total + i] = 1
+                off += n
+            if flat.is_cuda and dist.get_backend(group) == "gloo":      # single-GPU dry runs of the N > 1 path: gloo reduces host tensors
+                host = flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                flat.copy_(host)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            have = flat[total:].float().cpu()          # ranks holding a gradient, per parameter (<= world: exact in bf16 up to 256)
+            flat[:total].div_(world)
+            off = 0
+            for i, p in enumerate(bucket):
+                n = p.numel()
+                if have[i] == 0:
+                    p.grad = None
+                elif p.grad is None:
                     p.grad = flat[off:off + n].view_as(p).clone()
                 else:
                     p.grad.copy_(flat[off:off + n].view_as(p.grad))
@@ -138,16 +157,20 @@ class WorkQueue:
     no process group) it degenerates to ``range(n_items)``."""
 
     def __init__(self, n_items: int, rank: int = 0, world: int = 1, key: str = "llamole_work", port_offset: int = 17,
-                 store=None):
+                 store=None, port: Optional[int] = None, timeout_s: float = 600.0):
+        """``port``: TCP port of the counter's store (default: env LLAMOLE_QUEUE_PORT, else MASTER_PORT + ``port_offset``);
+        ``store``: an existing ``torch.distributed`` store to use instead (e.g. a ``PrefixStore`` over the process group's)."""
         self.n, self.rank, self.world, self.key = int(n_items), rank, world, key
         self._local = 0
         self.store = store
+        self.timeout_s = float(timeout_s)
         if world > 1 and store is None:
             import datetime
             import os
             host = os.environ.get("MASTER_ADDR", "127.0.0.1")
-            port = int(os.environ.get("MASTER_PORT", "29500")) + port_offset
-            self.store = dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=600),
+            if port is None:
+                port = int(os.environ.get("LLAMOLE_QUEUE_PORT", int(os.environ.get("MASTER_PORT", "29500")) + port_offset))
+            self.store = dist.TCPStore(host, int(port), world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=self.timeout_s),
                                        wait_for_workers=True)
 
     def __iter__(self):
@@ -165,12 +188,18 @@ class WorkQueue:
         return i
 
     def _finish(self):
-        """The store lives in rank 0's process: rank 0 leaves only after every rank has seen the end of the queue."""
+        """The store lives in rank 0's process: rank 0 leaves only after every rank has seen the end of the queue -- or raises
+        after ``timeout_s`` (a peer that died mid-evaluation never reports; waiting for it forever would hang the job)."""
         if self.store is None or getattr(self, "_finished", False):
             return
         self._finished = True
         import time
         self.store.add(self.key + "_done", 1)
         if self.rank == 0:
+            deadline = time.monotonic() + self.timeout_s
             while int(self.store.add(self.key + "_done", 0)) < self.world:
+                if time.monotonic() > deadline:
+                    done = int(self.store.add(self.key + "_done", 0))
+                    raise RuntimeError(f"WorkQueue: only {done} of {self.world} ranks reached the end of the queue within "
+                                       f"{self.timeout_s:.0f} s -- a peer has died or hangs")
                 time.sleep(0.01)

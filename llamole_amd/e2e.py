@@ -121,6 +121,17 @@ def gen_kwargs(tok, new_tokens: int):
                 eos_token_id=[tok.eos_token_id] + list(tok.special.values()), pad_token_id=tok.pad_token_id)
 
 
+def _decode_label(mode: str, fused: dict) -> str:
+    """What actually runs per decoded token (the label used to say "stock HF forward" while the layers ran fused HIP launches)."""
+    if mode == "hf":
+        return "HF generate() (stock modules)"
+    layers = fused.get("decoder_layers_5_launches")
+    body = (f"{layers} decoder layers as five fused HIP launches each (RMSNorm-prologue q|k|v GEMV, rope + KV append + attention, o_proj + "
+            "residual, RMSNorm-prologue gate|up GEMV + SiLU*mul, down_proj + residual), one-launch rotary / mask prologue, lm_head GEMV and the "
+            "fused sampler, over a static KV cache") if layers else "HF decoder modules over a StaticCache (per-op HIP kernels under nn.Linear where enabled)"
+    return body + ("; one hipGraph replayed per token" if mode == "graph" else "; launched eagerly")
+
+
 def build_e2e_step(args, graph_decoder, device, props, rank: int):
     """Returns (step_fn, info).  step_fn(i) -> list of integer molecule graphs for the rank's batch."""
     llm = build_llm(args.llm, device)
@@ -218,8 +229,7 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
     n_params = sum(p.numel() for p in llm.parameters())
     info = {"llm": args.llm, "llm_params": n_params, "llm_weights": "random-init (no network)", "prompt_len": args.cutoff_len,
             "max_new_tokens": args.new_tokens, "sampling": "temperature 0.6, top_k 50, top_p 0.9",
-            "llm_decode": {"graph": "stock HF forward over StaticCache, one hipGraph replayed per token",
-                           "eager": "stock HF forward over StaticCache, eager", "hf": "HF generate()"}[args.llm_decode],
+            "llm_decode": _decode_label(args.llm_decode, fused),
             "llm_linear": ("ll_linear (HIP weight-streaming GEMV) under %d nn.Linear modules for decode-shaped calls" % n_accel)
                           if n_accel else "PyTorch-ROCm default (hipBLASLt)",
             "llm_fused_elementwise": fused,

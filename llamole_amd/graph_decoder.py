@@ -396,7 +396,15 @@ class GraphDiT(nn.Module):
         us = (C.c_float * 4)()
         a, b = C.c_int(), C.c_int()
         _lib.check(_lib.load().ll_dit_mlp_choice(self._handle, us, C.byref(a), C.byref(b)), "ll_dit_mlp_choice")
+        # which GEMM family the dispatch runs under the block Linears at this batch (gemm.hip: gemm_dispatch): up to 64 token rows the
+        # all-in-flight panel kernel, up to 224 its two-/four-panel form, beyond that the LDS-DMA ring (or, opt-in, the packed-weight
+        # panel kernel); a trajectory overlapped with the LLM decode keeps <= 64-row panels on the ring (ll_dit_set_overlap)
+        rows = 2 * int(getattr(self, "_B", 0) or 0) * self.max_n_nodes
+        family = ("gemm_m64_kernel (64-row panel, all loads in flight)" if rows <= 64 else
+                  "gemm_m128_kernel (64-row panels)" if rows <= 224 else
+                  "gemm_bf16_pipeu_kernel<64,64> (LDS-DMA ring, 16 waves)" if rows < 1024 else "gemm_bf16_pipe_kernel (LDS-DMA ring, 128/256-row tiles)")
         return {"fc1": "panel" if a.value else "ring", "fc2": "panel" if b.value else "ring", "calibrated": max(us) > 0,
+                "token_rows": rows, "kernel": family if not (a.value or b.value) else "gemm_xw_kernel (packed-weight panel)",
                 "chain_us": {"ring/ring": round(us[0], 2), "panel/ring": round(us[1], 2), "ring/panel": round(us[2], 2),
                              "panel/panel": round(us[3], 2)}}
 

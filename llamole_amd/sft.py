@@ -171,7 +171,15 @@ def merge_lora_adapter(model: torch.nn.Module, adapter_dir: str) -> int:
                 lin.weight.add_(delta.to(device=lin.weight.device, dtype=lin.weight.dtype))
                 merged += 1
             elif ".lora_" not in name:              # modules_to_save: full replacement weights
-                tgt = params.get(name) or params.get(name.replace(".modules_to_save.default", "").replace(".modules_to_save", ""))
-                if tgt is not None and tgt.shape == a.shape:
-                    tgt.copy_(a.to(device=tgt.device, dtype=tgt.dtype))
+                # peft strips the adapter name from saved keys, so a modules_to_save tensor arrives as `<module>.weight` or as
+                # `<module>.modules_to_save[.<adapter>].weight`; try the name as it is, then without the wrapper segment
+                tgt = params.get(name)
+                if tgt is None:
+                    tgt = params.get(name.replace(".modules_to_save.default", "").replace(".modules_to_save", ""))
+                if tgt is None:
+                    raise KeyError(f"adapter tensor {k!r} has no parameter in the base model (modules_to_save target missing)")
+                if tuple(tgt.shape) != tuple(a.shape):
+                    raise ValueError(f"adapter tensor {k!r} has shape {tuple(a.shape)} but the model's {name!r} is {tuple(tgt.shape)}: "
+                                     "resize the embeddings (resize_vocab) before merging the adapter")
+                tgt.copy_(a.to(device=tgt.device, dtype=tgt.dtype))
     return merged

@@ -437,9 +437,11 @@ def write_connector_dir(path: str, llm_hidden: int, gin_hidden: int, seed: int =
 
 
 def write_lora_adapter_dir(path: str, llm, r: int = 4, alpha: int = 8, seed: int = 0,
-                           targets=("q_proj", "v_proj", "down_proj")) -> str:
+                           targets=("q_proj", "v_proj", "down_proj"), modules_to_save=("embed_tokens", "lm_head")) -> str:
     """A LoRA adapter in peft's on-disk layout (adapter_config.json + adapter_model.safetensors with
-    ``base_model.model.<module>.lora_A.weight`` / ``lora_B.weight`` keys) for every target Linear of ``llm``."""
+    ``base_model.model.<module>.lora_A.weight`` / ``lora_B.weight`` keys) for every target Linear of ``llm``, plus full
+    replacement weights for ``modules_to_save`` -- the resized embed_tokens / lm_head a reference adapter trained with
+    resize_vocab carries (adapter.py:224-233); peft strips the adapter name, so they are stored as ``<module>.weight``."""
     from safetensors.torch import save_file
     os.makedirs(path, exist_ok=True)
     g = torch.Generator().manual_seed(9000 + seed)
@@ -448,10 +450,14 @@ def write_lora_adapter_dir(path: str, llm, r: int = 4, alpha: int = 8, seed: int
         if name.split(".")[-1] in targets and isinstance(mod, torch.nn.Linear):
             tensors[f"base_model.model.{name}.lora_A.weight"] = torch.randn(r, mod.in_features, generator=g) * 0.05
             tensors[f"base_model.model.{name}.lora_B.weight"] = torch.randn(mod.out_features, r, generator=g) * 0.05
+    for name, mod in llm.named_modules():
+        if modules_to_save and name.split(".")[-1] in modules_to_save and hasattr(mod, "weight"):
+            tensors[f"base_model.model.{name}.weight"] = (mod.weight.detach().float().cpu()
+                                                           + 0.01 * torch.randn(mod.weight.shape, generator=g)).to(mod.weight.dtype)
     save_file(tensors, os.path.join(path, "adapter_model.safetensors"))
     with open(os.path.join(path, "adapter_config.json"), "w") as f:
         json.dump({"peft_type": "LORA", "r": r, "lora_alpha": alpha, "target_modules": list(targets), "use_rslora": False,
-                   "fan_in_fan_out": False, "bias": "none", "modules_to_save": None}, f)
+                   "fan_in_fan_out": False, "bias": "none", "modules_to_save": list(modules_to_save) if modules_to_save else None}, f)
     return path
 
 

@@ -174,11 +174,12 @@ def _uneven_worker(rank, world, port, q):
         b = torch.nn.Parameter(torch.ones(3, 2))          # the "connector": only rank 0's shard reaches it
         c = torch.nn.Parameter(torch.ones(4))
         frozen = torch.nn.Parameter(torch.ones(2), requires_grad=False)
+        unused = torch.nn.Parameter(torch.ones(3))        # trainable, but no rank's loss reaches it (a step without a <molecule> token)
         loss = (a * (rank + 1)).sum() + (c * 2).sum() + ((b * 3).sum() if rank == 0 else 0)
         loss.backward()
         assert (b.grad is None) == (rank == 1)
-        n = D.allreduce_gradients([a, b, c, frozen], bucket_bytes=16)     # tiny buckets: several collectives, same on both ranks
-        q.put((rank, n, a.grad.tolist(), b.grad.tolist(), c.grad.tolist(), frozen.grad is None))
+        n = D.allreduce_gradients([a, b, unused, c, frozen], bucket_bytes=16)     # tiny buckets: several collectives, same on both ranks
+        q.put((rank, n, a.grad.tolist(), b.grad.tolist(), c.grad.tolist(), frozen.grad is None, unused.grad is None))
     finally:
         dist.destroy_process_group()
 
@@ -201,6 +202,7 @@ def test_allreduce_gradients_with_rank_dependent_grad_sets():
     assert res[0][1] == res[1][1] >= 2
     for r in res:
         assert r[2] == [1.5] * 5 and r[3] == [[1.5, 1.5]] * 3 and r[4] == [2.0] * 4 and r[5]
+        assert r[6], "a parameter without a gradient on ANY rank must keep grad = None (as on one GPU), not get zeros"
 
 
 def _queue_worker(rank, world, port, q):
@@ -231,3 +233,36 @@ def test_work_queue_hands_out_every_item_once():
     assert sorted(res[0] + res[1]) == list(range(11)) and set(res[0]).isdisjoint(res[1])
     assert len(res[1]) > len(res[0])
     assert list(D.WorkQueue(4)) == [0, 1, 2, 3]            # one rank: plain range
+
+
+def _dying_peer_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    wq = D.WorkQueue(4, rank, world, timeout_s=3.0)
+    if rank == 1:
+        next(wq)            # claims one item, then "dies" without ever reaching the end of the queue
+        q.put((rank, "left"))
+        import time
+        time.sleep(8)       # keeps the process (not the queue) alive so that rank 0's store connection stays valid
+        return
+    try:
+        list(wq)
+        q.put((rank, "finished"))
+    except RuntimeError as e:
+        q.put((rank, "raised: " + str(e)))
+
+
+def test_work_queue_rank0_raises_instead_of_hanging_when_a_peer_dies():
+    """rank 0 used to spin forever in _finish when a peer died mid-evaluation."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dying_peer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    assert res[1] == "left" and res[0].startswith("raised") and "1 of 2 ranks" in res[0], res

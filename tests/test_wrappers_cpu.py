@@ -139,3 +139,28 @@ def test_graph_batch_roundtrip():
     assert torch.equal(gb.x, x) and torch.equal(gb.batch, batch) and torch.equal(gb.edge_index, ei) and torch.equal(gb.edge_attr, ea)
     back = gb.to_data_list()
     assert [d.num_nodes for d in back] == sizes and torch.equal(back[1].edge_index, parts[1].edge_index)
+
+
+def test_merge_lora_adapter_with_modules_to_save(tmp_path):
+    """reference adapters trained with resize_vocab carry embed_tokens / lm_head as modules_to_save (reference
+    adapter.py:224-233); peft stores them as plain `<module>.weight`.  They must be copied (not crash on `tensor or tensor`),
+    and a shape mismatch (embeddings not resized) must raise instead of being skipped."""
+    import pytest
+    from safetensors.torch import load_file
+    from llamole_amd import e2e, synth
+    from llamole_amd.sft import merge_lora_adapter
+    llm = e2e.build_llm("tiny", "cpu", torch.float32)
+    synth.write_lora_adapter_dir(str(tmp_path / "ad"), llm)
+    t = load_file(str(tmp_path / "ad" / "adapter_model.safetensors"))
+    assert "base_model.model.lm_head.weight" in t and "base_model.model.model.embed_tokens.weight" in t
+    w0 = llm.model.layers[0].self_attn.q_proj.weight.detach().clone()
+    assert merge_lora_adapter(llm, str(tmp_path / "ad")) == 6
+    torch.testing.assert_close(llm.lm_head.weight.detach(), t["base_model.model.lm_head.weight"])
+    torch.testing.assert_close(llm.model.embed_tokens.weight.detach(), t["base_model.model.model.embed_tokens.weight"])
+    a = t["base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight"]
+    b = t["base_model.model.model.layers.0.self_attn.q_proj.lora_B.weight"]
+    torch.testing.assert_close(llm.model.layers[0].self_attn.q_proj.weight.detach(), w0 + 2.0 * (b @ a), rtol=1e-5, atol=1e-6)
+    small = e2e.build_llm("tiny", "cpu", torch.float32)
+    small.resize_token_embeddings(small.config.vocab_size - 64)          # the base model was NOT resized to the adapter's vocabulary
+    with pytest.raises(ValueError, match="resize"):
+        merge_lora_adapter(small, str(tmp_path / "ad"))

@@ -13,20 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llamole_amd import synth  # noqa: E402
 
 
-def fast_weights(shapes, device, seed):
-    g = torch.Generator(device=device).manual_seed(seed)
-    sd = {}
-    for k, shp in shapes.items():
-        if k.endswith("eps"):
-            sd[k] = torch.zeros(1, device=device)
-        elif len(shp) == 1:
-            gain = k.endswith((".1.weight", "norm1.weight")) or ".norms." in "." + k and k.endswith("weight")
-            sd[k] = (1.0 if gain else 0.0) + 0.05 * torch.randn(shp, generator=g, device=device)
-        elif "encoder.weight" in k or "embedding" in k or "text_dropping" in k:
-            sd[k] = 0.5 * torch.randn(shp, generator=g, device=device)
-        else:
-            sd[k] = (2.0 / (shp[0] + shp[1])) ** 0.5 * torch.randn(shp, generator=g, device=device)
-    return sd
+from llamole_amd.workloads import device_gin_weights as fast_weights  # noqa: E402,F401  (tools/retro_bench.py, sft_bench.py import it from here)
 
 
 def main():
