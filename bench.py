@@ -245,6 +245,7 @@ def cpu_baseline_sft(args, cores: int, sd_pred, n_retro: int):
     t2 = time.perf_counter() - t0
     # the same with the decoder layers skipped: embedding + lm_head + loss only
     m.model.layers = m.model.layers[:0]
+    m.get_input_embeddings().weight.requires_grad_(True)      # with no LoRA layer left something must carry the backward through lm_head
     run(m)
     t0 = time.perf_counter()
     run(m)
