@@ -53,40 +53,6 @@ int ll_linear(int dtype, const void *A, int lda, const void *W, int ldw, const f
 int ll_linear_splitk_bf16(const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, int M, int N,
                           int K, int epi, int splits, float *workspace, void *stream);
 
-/* Tuning utility: average ms of `iters` launches of pipelined-GEMM configuration `cfg` (-1 = the production
- * dispatch) on an [M,K]x[N,K]^T bf16 problem, cycling over `nweights` weight matrices (HBM-resident stream). */
-int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f32, int iters, int nweights, float *ms);
-/* ll_host_launch_probe : HOST time per enqueued launch (wall time of the issuing loop): kind 0 = empty kernel, 1 = two-argument kernel,
- * 2 = linear_launch onto the <= 64-row panel GEMM, 3 = linear_launch onto the LDS-DMA ring. */
-int ll_host_launch_probe(int kind, int n, float *us_per_launch);
-/* ll_linear_xw : test hook of the packed-weight panel GEMM (gemm_xw_kernel: 64 token rows in LDS, the weight streamed from a copy in
- * MFMA operand order; K / splits = 512 | 1024, N % 128 == 0): packs the row-major W [N, K] into a temporary and runs it; splits > 1
- * writes raw f32 slabs of M x ldc.  ll_gemm_bench(cfg = -2) times the same kernel. */
-int ll_linear_xw(const void *A, int lda, const void *W, const float *bias, void *C, int ldc, int M, int N, int K, int splits,
-                 int epi, int out_f32, void *stream);
-/* ll_linear_cfg : ll_linear (bf16 operands) through ONE kernel configuration of the tuning table (gemm.hip: g_pipe_cfgs), so that
- * every variant can be checked against a reference.  splits > 1: C receives `splits` raw f32 slabs (stride M * ldc). */
-int ll_linear_cfg(int cfg, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, int M, int N, int K,
-                  int splits, int epi, int out_f32, void *stream);
-/* Tuning: waves per workgroup of the <= 64-row panel GEMM (4 | 8; default 8); returns the previous value. */
-int ll_set_m64_waves(int waves);
-/* Tuning: 1 (default) = the <= 64-row panel GEMM reads the GraphDiT engine's MFMA-operand-order weight copies where they exist (one
- * full-line wave instruction per fragment), 0 = the row-major weights; same products and order, bit-identical; returns the previous value.
- * Takes effect at the next graph capture. */
-int ll_set_m64_packed(int on);
-/* Tuning: 1 (default) = Linears with 65..224 rows take the multi-panel form of the panel GEMM (gemm_m128_kernel: 32 columns per workgroup
- * up to 128 rows, 64 beyond), 2 = up to 256 rows, 0 = the LDS-DMA ring; returns the previous value.  Takes effect at the next launch /
- * graph capture. */
-int ll_set_m128_panel(int on);
-/* ll_set_gemm_krot : the LDS-DMA GEMM sweeps its k-tiles starting at ((m_tile * (krot & 255) + n_tile * (krot >> 8 or 1)) mod
- * n_ktiles) instead of 0, so that workgroups sharing an operand tile do not miss L2 on the same lines at the same time.  0 = off.
- * Changes the f32 summation order per tile (deterministic).  Returns the previous setting. */
-int ll_set_gemm_krot(int krot);
-
-/* Launch-latency probe (tuning utility): average us per kernel over n launches of a trivial kernel
- * (kind 0 empty, 1 load+store, 2 dependent loads, 3 1-MB copy), eager stream (graph=0) or one hipGraph (graph=1). */
-int ll_launch_bench(int kind, int n, int graph, float *us);
-int ll_launch_bench_set_buffers(void *a, void *b);   /* optional caller-provided 4 MB buffers (NULL = own) */
 
 /* ------------------------------------------------------------------ GraphDiT sampler
  * Replaces reference GraphDiT.generate / sample_p_zs_given_zt / Transformer.forward
@@ -191,16 +157,6 @@ int ll_dit_last_run_ms(void *handle, float *ms, int *steps);
 /* What ll_dit_begin's calibration measured for the current batch (us per fc1 -> fc2 -> AdaLN chain with fc1 / fc2 on ring/ring,
  * panel/ring, ring/panel, panel/panel; zeros when it did not run) and which kernels the step uses. */
 int ll_dit_mlp_choice(void *handle, float *us4, int *xw_fc1, int *xw_fc2);
-/* Tuning: ln_mod_res with one wave per 256-column chunk of a row (default) or one wave per row; bit-identical results; returns the
- * previous setting. */
-int ll_set_lnmod_multiwave(int on);
-/* ll_set_stage_mod : 1 (default) = every step first copies its (B+1) x L x 6H modulation rows to a fixed buffer, so that the 2L
- * AdaLN epilogue launches of the step address them without waiting for the step index in device memory (one memory round trip per
- * launch instead of two); 0 = every launch walks the hoisted table.  Bit-identical.  Takes effect at the next graph capture. */
-int ll_set_stage_mod(int on);
-/* Tuning: waves per (sequence, head) of the MFMA graph attention (1 | 2 | 4; default 4 = LayerNorm / transpose rows on four waves at
- * head dimension 64, two elsewhere; bit-identical); returns the previous value. */
-int ll_set_attn_waves(int waves);
 
 /* ------------------------------------------------------------------ GIN encoder / predictor
  * Replaces GNNEncoder.forward + ProjectionHead (src/model/graph_encoder/model.py:124-205) and
@@ -257,10 +213,6 @@ int ll_gin_backward_c(void *handle, const int32_t *rowptr_src, const int32_t *ds
 /* softmax over out_dim then top-k (GraphPredictor.sample_templates, graph_predictor/model.py:174-179).
  * probs [rows,k] descending, idx [rows,k]. k <= 64. */
 int ll_softmax_topk(const float *logits, int rows, int out_dim, int k, float *probs, int32_t *idx, void *stream);
-/* ll_set_topk_single : 1 = one workgroup per row for any out_dim (the round-1 form); 0 (default) = rows longer than 4096 templates
- * are reduced by (out_dim / 4096) x rows workgroups to per-chunk candidates and merged by one workgroup per row -- same result
- * (set, order, ties to the lowest template index).  Returns the previous setting. */
-int ll_set_topk_single(int on);
 
 /* CostMLP (graph_predictor/model.py:356-391): softplus(W3 relu(W0 fp + b0) + b3); fps [n,2048] f32 0/1.
  * weights: device f32 arena = [layers.0.weight 128x2048 | layers.0.bias 128 | layers.3.weight 1x128 | layers.3.bias 1]. */
@@ -298,8 +250,7 @@ int ll_decode_attn_bf16(const void *q, const void *K, const void *V, const void 
  *     qkv [B, (nh+2*nkv)*D] rows (stride ld_qkv) = fused q|k|v projection; cos/sin [B or 1, D] (batch stride cs_stride, 0 to
  *     broadcast); Kc/Vc [B,nkv,maxlen,D] static cache, appended at *pos (device int64); mask bool [B,maxlen] rows
  *     (stride mask_stride) for the new query; out [B, nh*D].  D in {64,128}.
- * ll_gemv_fused_bench : timing utility (HIP events, `nweights` distinct weight matrices); ll_set_gemv_nt: toggle
- *     non-temporal weight loads of ll_gemv_fused_bf16 (returns the previous setting). */
+ * (timing / tuning hooks of these kernels: include/llamole_hip_tuning.h) */
 #define LL_GEMV_PLAIN 0
 #define LL_GEMV_RESIDUAL 1
 #define LL_GEMV_SILU_MUL 2
@@ -315,7 +266,6 @@ int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, c
 int ll_decode_prologue(const int64_t *position_ids, const float *inv_freq, float attention_scaling, const int64_t *mask2d,
                        int64_t mask_stride, const int64_t *pos, void *cos, void *sin, void *mask_out, int B, int D, int maxlen,
                        void *stream);
-int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iters, int nweights, float *ms);
 
 /* ll_linear_rows16_bf16 : out[M,N] = epilogue(x[M,K] . W^T + bias), M in 1..16, K % 32 == 0, bf16 operands, f32 accumulation on MFMA:
  *     the nn.Linear of a batched decode step (5..16 sequences: lock-step A* searches, several prompts per GPU) as a weight
@@ -324,16 +274,9 @@ int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iter
  *     is staged and rsqrt(mean(x^2) + eps) of the row scales the accumulator: Qwen2RMSNorm + nn.Linear up to the place of one bf16
  *     rounding); epilogues LL_GEMV_PLAIN / LL_GEMV_RESIDUAL / LL_GEMV_SILU_MUL (W has 2N rows for SILU_MUL); replaces nn.Linear.forward (+ the residual add / act_fn(gate)*up of Qwen2DecoderLayer / Qwen2MLP.forward,
  *     transformers modeling_qwen2.py) under the reference's language_model.generate (modeling_llamole.py:599, :849).
- * ll_set_rows16_geometry : tuning -- bytes of a row per block (128 | 256 | 512), waves per workgroup (4 | 8) and how many
- *     consecutive waves split K of one tile; (0, 0, 0) = chosen by tile count.
- * ll_rows16_bench : timing utility (HIP events, `nweights` distinct weight matrices); epi | 0x100 = f32 output (the GIN template head). */
+ * (geometry tuning and the timing utility: include/llamole_hip_tuning.h) */
 int ll_linear_rows16_bf16(const void *x, int ldx, const void *W, int ldw, const float *bias, const void *norm_w, float eps,
                           const void *residual, int ldr, void *out, int ldc, int M, int N, int K, int epi, void *stream);
-int ll_set_rows16_geometry(int seg, int waves, int ksplit);
-int ll_rows16_bench(int M, int N, int K, int epi, int norm, int iters, int nweights, float *ms);
-int ll_set_gemv_nt(int on);
-/* Tuning: one-row GEMVs without RMSNorm and K >= 8192 (down_proj) stage x in LDS once per workgroup (default on; bit-identical). */
-int ll_set_gemv_stage(int on);
 
 /* ll_sample_token_bf16 : one decode-loop sampling step per row in ONE launch -- HF TemperatureLogitsWarper + TopPLogitsWarper
  *     + softmax + multinomial (transformers generation/logits_process.py, generation/utils.py _sample; the reference reaches

@@ -1,0 +1,82 @@
+/* libllamole_hip -- tuning, timing and test hooks.  NOT part of the drop-in boundary.
+ *
+ * include/llamole_hip.h declares what a maintainer of the reference binds (engines, forward passes, samplers).  Everything in THIS
+ * file is process-global A/B switches, micro-benchmarks (HIP events around one kernel) and single-kernel test entry points used by
+ * tests/, tools/ and bench.py's roofline objects.  Nothing here changes results beyond documented summation-order effects, and no
+ * product code path depends on a non-default setting.  The symbols are exported by the same shared library.
+ */
+#ifndef LLAMOLE_HIP_TUNING_H
+#define LLAMOLE_HIP_TUNING_H
+
+#include "llamole_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Tuning utility: average ms of `iters` launches of pipelined-GEMM configuration `cfg` (-1 = the production
+ * dispatch) on an [M,K]x[N,K]^T bf16 problem, cycling over `nweights` weight matrices (HBM-resident stream). */
+int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f32, int iters, int nweights, float *ms);
+/* ll_host_launch_probe : HOST time per enqueued launch (wall time of the issuing loop): kind 0 = empty kernel, 1 = two-argument kernel,
+ * 2 = linear_launch onto the <= 64-row panel GEMM, 3 = linear_launch onto the LDS-DMA ring. */
+int ll_host_launch_probe(int kind, int n, float *us_per_launch);
+/* ll_linear_xw : test hook of the packed-weight panel GEMM (gemm_xw_kernel: 64 token rows in LDS, the weight streamed from a copy in
+ * MFMA operand order; K / splits = 512 | 1024, N % 128 == 0): packs the row-major W [N, K] into a temporary and runs it; splits > 1
+ * writes raw f32 slabs of M x ldc.  ll_gemm_bench(cfg = -2) times the same kernel. */
+int ll_linear_xw(const void *A, int lda, const void *W, const float *bias, void *C, int ldc, int M, int N, int K, int splits,
+                 int epi, int out_f32, void *stream);
+/* ll_linear_cfg : ll_linear (bf16 operands) through ONE kernel configuration of the tuning table (gemm.hip: g_pipe_cfgs), so that
+ * every variant can be checked against a reference.  splits > 1: C receives `splits` raw f32 slabs (stride M * ldc). */
+int ll_linear_cfg(int cfg, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, int M, int N, int K,
+                  int splits, int epi, int out_f32, void *stream);
+/* Tuning: waves per workgroup of the <= 64-row panel GEMM (4 | 8; default 8); returns the previous value. */
+int ll_set_m64_waves(int waves);
+/* Tuning: 1 (default) = the <= 64-row panel GEMM reads the GraphDiT engine's MFMA-operand-order weight copies where they exist (one
+ * full-line wave instruction per fragment), 0 = the row-major weights; same products and order, bit-identical; returns the previous value.
+ * Takes effect at the next graph capture. */
+int ll_set_m64_packed(int on);
+/* Tuning: 1 (default) = Linears with 65..224 rows take the multi-panel form of the panel GEMM (gemm_m128_kernel: 32 columns per workgroup
+ * up to 128 rows, 64 beyond), 2 = up to 256 rows, 0 = the LDS-DMA ring; returns the previous value.  Takes effect at the next launch /
+ * graph capture. */
+int ll_set_m128_panel(int on);
+/* ll_set_gemm_krot : the LDS-DMA GEMM sweeps its k-tiles starting at ((m_tile * (krot & 255) + n_tile * (krot >> 8 or 1)) mod
+ * n_ktiles) instead of 0, so that workgroups sharing an operand tile do not miss L2 on the same lines at the same time.  0 = off.
+ * Changes the f32 summation order per tile (deterministic).  Returns the previous setting. */
+int ll_set_gemm_krot(int krot);
+
+/* Launch-latency probe (tuning utility): average us per kernel over n launches of a trivial kernel
+ * (kind 0 empty, 1 load+store, 2 dependent loads, 3 1-MB copy), eager stream (graph=0) or one hipGraph (graph=1). */
+int ll_launch_bench(int kind, int n, int graph, float *us);
+int ll_launch_bench_set_buffers(void *a, void *b);   /* optional caller-provided 4 MB buffers (NULL = own) */
+
+/* Tuning: ln_mod_res with one wave per 256-column chunk of a row (default) or one wave per row; bit-identical results; returns the
+ * previous setting. */
+int ll_set_lnmod_multiwave(int on);
+/* ll_set_stage_mod : 1 (default) = every step first copies its (B+1) x L x 6H modulation rows to a fixed buffer, so that the 2L
+ * AdaLN epilogue launches of the step address them without waiting for the step index in device memory (one memory round trip per
+ * launch instead of two); 0 = every launch walks the hoisted table.  Bit-identical.  Takes effect at the next graph capture. */
+int ll_set_stage_mod(int on);
+/* Tuning: waves per (sequence, head) of the MFMA graph attention (1 | 2 | 4; default 4 = LayerNorm / transpose rows on four waves at
+ * head dimension 64, two elsewhere; bit-identical); returns the previous value. */
+int ll_set_attn_waves(int waves);
+
+/* ll_set_topk_single : 1 = one workgroup per row for any out_dim (the round-1 form); 0 (default) = rows longer than 4096 templates
+ * are reduced by (out_dim / 4096) x rows workgroups to per-chunk candidates and merged by one workgroup per row -- same result
+ * (set, order, ties to the lowest template index).  Returns the previous setting. */
+int ll_set_topk_single(int on);
+
+/* ll_rows16_bench : timing utility of ll_linear_rows16_bf16 (HIP events, `nweights` distinct weight matrices); epi | 0x100 = f32 output
+ * (the GIN template head).  ll_set_rows16_geometry : bytes of a row per block (128 | 256 | 512), waves per workgroup (4 | 8) and how
+ * many consecutive waves split K of one tile; (0, 0, 0) = chosen by tile count.  ll_gemv_fused_bench : the same for ll_gemv_fused_bf16;
+ * ll_set_gemv_nt : toggle its non-temporal weight loads (returns the previous setting). */
+int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iters, int nweights, float *ms);
+int ll_set_rows16_geometry(int seg, int waves, int ksplit);
+int ll_rows16_bench(int M, int N, int K, int epi, int norm, int iters, int nweights, float *ms);
+int ll_set_gemv_nt(int on);
+/* Tuning: one-row GEMVs without RMSNorm and K >= 8192 (down_proj) stage x in LDS once per workgroup (default on; bit-identical). */
+int ll_set_gemv_stage(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLAMOLE_HIP_TUNING_H */

@@ -26,6 +26,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "llamole_hip.h"))
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "llamole_hip_tuning.h"))
     objs = []
     procs = []
     for s in SOURCES:

@@ -8,6 +8,7 @@
 #include <string>
 
 #include "../../include/llamole_hip.h"
+#include "../../include/llamole_hip_tuning.h"
 
 namespace ll {
 

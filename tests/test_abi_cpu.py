@@ -19,10 +19,29 @@ def lib():
     return _lib.load()
 
 
-def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "llamole_hip.h")).read()
+def _declared_in(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(ll_[a-z0-9_]+)\s*\(", src)))
+
+
+def _declared_functions():
+    return sorted(set(_declared_in("llamole_hip.h")) | set(_declared_in("llamole_hip_tuning.h")))
+
+
+def test_tuning_hooks_are_fenced_off_the_product_header():
+    """process-global switches, micro-benchmarks and single-kernel test entry points live in their own header; what a
+    maintainer binds (llamole_hip.h) carries none of them, and the product wrappers call none of them."""
+    product, tuning = _declared_in("llamole_hip.h"), _declared_in("llamole_hip_tuning.h")
+    assert not set(product) & set(tuning)
+    assert not [n for n in product if n.startswith("ll_set_") or n.endswith(("_bench", "_probe")) or n in ("ll_linear_cfg", "ll_linear_xw")]
+    assert all(n.startswith("ll_set_") or "bench" in n or "probe" in n or n in ("ll_linear_cfg", "ll_linear_xw") for n in tuning), tuning
+    pkg = os.path.join(ROOT, "llamole_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py") and f != "_lib.py":
+            text = open(os.path.join(pkg, f)).read()
+            used = [n for n in tuning if re.search(r"\b" + n + r"\b", text)]
+            assert not used, f"{f} (product path) calls tuning hooks {used}"
 
 
 def test_every_declared_symbol_is_exported(lib):
