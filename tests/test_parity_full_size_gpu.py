@@ -474,3 +474,49 @@ def test_gin_predictor_full_size_vs_oracle():
     _report("gin_predictor_full", rec)
     assert lerr <= 3e-2, lerr
     assert overlap >= 0.9 and mass_ratio >= 0.98 and top1 >= 0.9, (overlap, mass_ratio, top1)
+
+
+def test_gin_backward_full_size_vs_oracle_autograd():
+    """VERDICT r2 missing #6: the reverse sweep ll_gin_backward_c at BASELINE configs[4] size -- 16 product graphs of 32 atoms, H = 512,
+    L = 5, 180 576 templates (the 740 MB template head read once more as dlogits x W with its 16-way split-K), bf16 engine -- against
+    torch.autograd through the f32 CPU oracle on the same bf16-rounded weights: loss and d(retro cross-entropy)/d c."""
+    import sys
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gin_bench import fast_weights
+    from llamole_amd.graph_predictor import GraphPredictor
+    from oracle import gin_oracle as go
+    L, H, G, D = 5, 512, 16, 180576
+    dev = torch.device("cuda")
+    x, ei, ea, batch = synth.make_mol_graphs(G, 1, min_atoms=32, max_atoms=32)
+    pred = GraphPredictor(L, H, 0.0, D, {}, {})
+    pred.to(dev)
+    sdp = fast_weights(synth.gin_weight_shapes(L, H, "predictor", D), dev, 5)
+    sdp["decoder.4.weight"] = sdp["decoder.4.weight"] * 40.0          # a peaked head, as a trained one (see the forward test above)
+    pred.predictor.load_state_dict(sdp)
+    for p in pred.parameters():
+        p.data = p.data.to(torch.bfloat16)
+    sd_cpu = {k_: v.detach().to(torch.bfloat16).float().cpu() for k_, v in sdp.items()}
+    g = torch.Generator().manual_seed(6)
+    c0 = torch.randn(G, 768, generator=g)
+    labels = torch.randint(0, D, (G,), generator=g)
+    c = c0.clone().to(dev).requires_grad_(True)
+    logits = pred(x.to(dev), ei.to(dev), ea.to(dev), batch.to(dev), c)
+    loss = F.cross_entropy(logits.float(), labels.to(dev))
+    loss.backward()
+    dc = c.grad.float().cpu()
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    c_ref = c0.clone().requires_grad_(True)
+    loss_ref = F.cross_entropy(go.predictor_forward(sd_cpu, L, x, ei, ea, batch, c_ref), labels)
+    (dc_ref,) = torch.autograd.grad(loss_ref, c_ref)
+    scale = float(dc_ref.abs().max())
+    err = float((dc - dc_ref).abs().max()) / scale
+    cos = float(F.cosine_similarity(dc.flatten(), dc_ref.flatten(), dim=0))
+    row_cos = float(F.cosine_similarity(dc, dc_ref, dim=1).min())
+    lerr = abs(float(loss.detach()) - float(loss_ref.detach())) / max(1.0, abs(float(loss_ref.detach())))
+    rec = dict(loss=float(loss.detach()), loss_ref=float(loss_ref.detach()), loss_rel=lerr, dc_err_rel_to_max=err, dc_cosine=cos, dc_cosine_min_row=row_cos)
+    print(f"GIN reverse sweep full size: {rec}")
+    _report("gin_backward_full_size", rec)
+    assert scale > 0 and torch.isfinite(dc).all()
+    assert lerr <= 2e-2, rec
+    assert cos >= 0.995 and row_cos >= 0.98 and err <= 0.1, rec
