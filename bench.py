@@ -560,8 +560,8 @@ GRAPH_MODE = None
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 20; retro: 2 -- a step is 16 searches x 5 expansions, ~20 s; sft: 10)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 2; retro: 1)")
     ap.add_argument("--workload", default="e2e", choices=["graphdit", "e2e", "retro", "sft"])
     ap.add_argument("--batch", type=int, default=None, help="prompts per GPU per step")
     ap.add_argument("--nodes", type=int, default=32)
@@ -608,6 +608,10 @@ def main():
     args = ap.parse_args()
     if args.llm is None:
         args.llm = "mistral-7b" if args.workload == "sft" else "qwen2-7b"
+    if args.steps is None:
+        args.steps = {"retro": 2, "sft": 10}.get(args.workload, 20)
+    if args.warmup is None:
+        args.warmup = {"retro": 1}.get(args.workload, 2)
     global GRAPH_MODE
     GRAPH_MODE = False if args.no_graph else (True if args.graph else None)      # None: the library's choice
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

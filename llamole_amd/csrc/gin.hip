@@ -1043,67 +1043,79 @@ __device__ __forceinline__ void wg_exclusive_scan_inplace(int *a, int n, int *pa
     __syncthreads();
 }
 
+// Error flag of both kernels (device memory, or pinned HOST memory so that the caller's stream never carries a read-back): gathered in
+// LDS and stored ONCE, by the last instruction of the kernel -- a host that pre-set the word to -1 reads -1 until the conversion has
+// run, then 0 (ok) | 1 unsorted or out-of-range `batch` | 2 edge endpoint outside the batch | 3 atom / bond type outside the embedding
+// tables.  Whatever the flag says, the arrays written are SAFE to run the GIN kernels on (ids clamped into range, bad edges dropped).
+template <bool IN_LDS>
 __global__ __launch_bounds__(1024) void graph_csr_kernel(const int64_t *__restrict__ x, const int64_t *__restrict__ edge_index,
                                                           const int64_t *__restrict__ edge_attr, const int64_t *__restrict__ batch, int n,
                                                           int E, int G, int *__restrict__ x32, int *__restrict__ rowptr, int *__restrict__ src,
                                                           int *__restrict__ attr, int *__restrict__ b32, int *__restrict__ gptr,
                                                           int *__restrict__ cursor, int *__restrict__ err) {
+    extern __shared__ int sm_csr[];
     __shared__ int part[16];
+    __shared__ int s_err;
     const int tid = threadIdx.x;
     const int64_t *esrc = edge_index, *edst = edge_index + E;
-    // error flag: 0 ok | 1 unsorted or out-of-range `batch` | 2 edge endpoint outside the batch | 3 atom / bond type outside the embedding
-    // tables.  Zeroed before anyone can raise it.  Whatever the flag says, the arrays written below are SAFE to run
-    // the GIN kernels on (ids clamped into range, bad edges dropped): the host may look at the flag later than it launches them.
-    if (tid == 0) *err = 0;      // `err` may be pinned HOST memory (no device read-back on the caller's stream): plain stores only --
-    __syncthreads();             // concurrent writers store different non-zero codes, any of which reports the batch as malformed
-    for (int i = tid; i <= n; i += 1024) rowptr[i] = 0;
-    for (int i = tid; i <= G; i += 1024) gptr[i] = 0;
+    // IN_LDS (molecule batches: 2n + G + E + 2 ints fit the dynamic LDS): degree counts, cursors, graph counts and the scattered edge ids
+    // all live in LDS -- LDS atomics and no global round trip between the phases; otherwise the caller's global arrays are the workspace
+    int *rp = IN_LDS ? sm_csr : rowptr;
+    int *cur = IN_LDS ? rp + n + 1 : cursor;
+    int *gp = IN_LDS ? cur + n : gptr;
+    int *eid = IN_LDS ? gp + G + 1 : src;
+    if (tid == 0) s_err = 0;
+    for (int i = tid; i <= n; i += 1024) rp[i] = 0;
+    for (int i = tid; i <= G; i += 1024) gp[i] = 0;
+    __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         const long long xv = x[i];
-        if (xv < 0 || xv >= 118) *err = 3;
+        if (xv < 0 || xv >= 118) s_err = 3;
         x32[i] = (int)(xv < 0 ? 0 : xv >= 118 ? 117 : xv);
         const long long b = batch[i];
         b32[i] = (int)(b < 0 ? 0 : b >= G ? G - 1 : b);
-        cursor[i] = 0;
-        if (b < 0 || b >= G || (i > 0 && batch[i - 1] > b)) *err = 1;      // unsorted / out-of-range `batch`
+        cur[i] = 0;
+        if (b < 0 || b >= G || (i > 0 && batch[i - 1] > b)) s_err = 1;      // unsorted / out-of-range `batch`
+        if (b >= 0 && b < G) atomicAdd(&gp[b], 1);
     }
-    __syncthreads();
     for (int e = tid; e < E; e += 1024) {
         const long long d = edst[e], sidx = esrc[e];
-        if (d < 0 || d >= n || sidx < 0 || sidx >= n) *err = 2;
-        else atomicAdd(&rowptr[d], 1);
-    }
-    for (int i = tid; i < n; i += 1024) {
-        const long long b = batch[i];
-        if (b >= 0 && b < G) atomicAdd(&gptr[b], 1);
+        if (d < 0 || d >= n || sidx < 0 || sidx >= n) s_err = 2;
+        else atomicAdd(&rp[d], 1);
     }
     __syncthreads();
-    wg_exclusive_scan_inplace(rowptr, n + 1, part);       // rowptr[n] (count 0) becomes the total
-    wg_exclusive_scan_inplace(gptr, G + 1, part);
+    wg_exclusive_scan_inplace(rp, n + 1, part);       // rp[n] (count 0) becomes the total
+    wg_exclusive_scan_inplace(gp, G + 1, part);
     for (int e = tid; e < E; e += 1024) {
         const long long d = edst[e];
-        if (d >= 0 && d < n && esrc[e] >= 0 && esrc[e] < n) src[rowptr[d] + atomicAdd(&cursor[d], 1)] = e;
+        if (d >= 0 && d < n && esrc[e] >= 0 && esrc[e] < n) eid[rp[d] + atomicAdd(&cur[d], 1)] = e;
     }
     __syncthreads();
     for (int v = tid; v < n; v += 1024) {
-        const int lo = rowptr[v], hi = rowptr[v + 1];
+        const int lo = rp[v], hi = rp[v + 1];
         for (int i = lo + 1; i < hi; ++i) {               // insertion sort by edge id: molecular degrees are <= ~6
-            const int key = src[i];
+            const int key = eid[i];
             int j = i - 1;
-            while (j >= lo && src[j] > key) {
-                src[j + 1] = src[j];
+            while (j >= lo && eid[j] > key) {
+                eid[j + 1] = eid[j];
                 --j;
             }
-            src[j + 1] = key;
+            eid[j + 1] = key;
         }
         for (int i = lo; i < hi; ++i) {
-            const int e = src[i];
+            const int e = eid[i];
             src[i] = (int)esrc[e];
             const long long av = edge_attr[e];
-            if (av < 0 || av >= 5) *err = 3;
+            if (av < 0 || av >= 5) s_err = 3;
             attr[i] = (int)(av < 0 ? 0 : av >= 5 ? 4 : av);
         }
     }
+    if (IN_LDS) {
+        for (int i = tid; i <= n; i += 1024) rowptr[i] = rp[i];
+        for (int i = tid; i <= G; i += 1024) gptr[i] = gp[i];
+    }
+    __syncthreads();
+    if (tid == 0) *err = s_err;
 }
 
 // CostMLP: softplus(w3 . relu(W0 fp + b0) + b3), W0 [128][2048].  One workgroup per fingerprint.
@@ -1815,8 +1827,13 @@ int ll_graph_csr(const int64_t *x, const int64_t *edge_index, const int64_t *edg
     LL_CHECK(x && batch && x32 && rowptr && batch32 && gptr && scratch && err, "ll_graph_csr: null argument");
     LL_CHECK(n_nodes >= 1 && n_graphs >= 1 && n_edges >= 0, "ll_graph_csr: empty graph batch");
     LL_CHECK(n_edges == 0 || (edge_index && edge_attr && src && attr), "ll_graph_csr: edges given without edge_index / edge_attr / outputs");
-    hipLaunchKernelGGL(graph_csr_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, edge_index, edge_attr, batch, n_nodes, n_edges, n_graphs,
-                       x32, rowptr, src, attr, batch32, gptr, scratch, err);
+    const size_t lds = (size_t)(2 * (size_t)n_nodes + n_graphs + n_edges + 2) * sizeof(int);
+    if (lds <= 60 * 1024)
+        hipLaunchKernelGGL(graph_csr_kernel<true>, dim3(1), dim3(1024), lds, (hipStream_t)stream, x, edge_index, edge_attr, batch, n_nodes, n_edges,
+                           n_graphs, x32, rowptr, src, attr, batch32, gptr, scratch, err);
+    else
+        hipLaunchKernelGGL(graph_csr_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, edge_index, edge_attr, batch, n_nodes, n_edges,
+                           n_graphs, x32, rowptr, src, attr, batch32, gptr, scratch, err);
     LL_LAUNCH_CHECK();
     return LL_OK;
 }

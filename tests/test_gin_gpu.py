@@ -355,6 +355,9 @@ def test_graph_csr_kernel_equals_aten_route():
     hub_src = torch.arange(1, 301)
     hub = torch.stack([torch.cat([hub_src, torch.zeros(300, dtype=torch.long)]), torch.cat([torch.zeros(300, dtype=torch.long), hub_src])])
     cases.append((torch.randint(0, 118, (301,), generator=g), hub, torch.randint(1, 5, (600,), generator=g), torch.zeros(301, dtype=torch.long)))
+    xb, eib, eab, bb = synth.make_mol_graphs(700, 5, min_atoms=24, max_atoms=32)      # ~20 k nodes / ~45 k edges: beyond the kernel's LDS workspace
+    assert 2 * xb.numel() + 700 + eib.shape[1] + 2 > 15360
+    cases.append((xb, eib, eab, bb))
     for x, ei, ea, batch in cases:
         xd, eid, ead, bd = x.cuda(), ei.cuda(), ea.cuda(), batch.cuda()
         ref = graph_csr(xd, eid, ead, bd)
@@ -367,4 +370,20 @@ def test_graph_csr_kernel_equals_aten_route():
     x, ei, ea, batch = cases[0]
     with pytest.raises(ValueError):
         graph_csr_device(x.cuda(), ei.cuda(), ea.cuda(), torch.flip(batch, [0]).cuda(), None)
+    # with the graph count known nothing synchronises: the flag arrives in pinned host memory and the NEXT look at it raises; whatever it
+    # says, the arrays handed to the GIN kernels are in bounds (ids clamped, bad edges dropped)
+    from llamole_amd.graph_encoder import check_graph_errors
+    check_graph_errors(wait=True)
+    got = graph_csr_device(x.cuda(), ei.cuda(), ea.cuda(), torch.flip(batch, [0]).cuda(), 16)       # unsorted batch: no exception here
+    with pytest.raises(ValueError, match="sorted"):
+        check_graph_errors(wait=True)
+    assert int(got[4].min()) >= 0 and int(got[4].max()) < 16
+    bad_x, bad_ei, bad_ea = x.clone(), ei.clone(), ea.clone()
+    bad_x[3], bad_ei[0, 5], bad_ea[7] = 400, 10 ** 6, 9
+    got = graph_csr_device(bad_x.cuda(), bad_ei.cuda(), bad_ea.cuda(), batch.cuda(), 16)
+    with pytest.raises(ValueError):
+        check_graph_errors(wait=True)
+    assert int(got[0].max()) <= 117 and int(got[3].max()) <= 4 and int(got[2].max()) < x.numel()
+    assert int(got[1][-1]) == ei.shape[1] - 1                                                        # the bad edge was dropped, the rest kept
+    check_graph_errors(wait=True)                                                                    # reported once, then clean
     assert csr_for_engine(x, ei, ea, batch)[8] == 16          # CPU tensors: the ATen route
