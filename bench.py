@@ -579,6 +579,9 @@ def main():
     ap.add_argument("--iterations", type=int, default=5, help="retro: expansions per A* search (search depth <= this)")
     ap.add_argument("--retro-tokens", type=int, default=64, help="retro: analysis tokens decoded per expansion (the reference allows 512)")
     ap.add_argument("--topk", type=int, default=50, help="retro: templates kept per expansion")
+    ap.add_argument("--retro-constant-value", action="store_true",
+                    help="retro: opt-in shortcut -- the reference-compatible A* language cost is the constant 15 for every molecule (its [5,1] x [5] "
+                         "broadcast), so return it without the LLM forward (default: every value forward runs, as in the reference)")
     ap.add_argument("--out-dim", type=int, default=180576, help="retro / sft: reaction templates of the GIN predictor head")
     ap.add_argument("--sft-batch", type=int, default=2, help="sft: rows per GPU per step")
     ap.add_argument("--sft-seq", type=int, default=512, help="sft: tokens per row")

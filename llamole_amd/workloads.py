@@ -80,6 +80,7 @@ def build_retro_step(args, graph_decoder, device, rank: int):
     pool = GraphBatch(x, ei, ea, batch, [32] * 64).to_data_list()
     orch.smiles_to_graph = lambda s: type(pool[0])(*(t.clone() for t in (lambda g: (g.x, g.edge_index, g.edge_attr))(pool[zlib.crc32(s.encode()) % 64])))
     accel = orch.enable_mi355x_decode()
+    orch.constant_language_cost_shortcut = bool(getattr(args, "retro_constant_value", False))      # opt-in; default: every value forward runs
     T = args.targets
     kw = dict(expansion_topk=args.topk, iterations=args.iterations, starting_mols={"<none>"}, max_planning_time=1e9, rollback=False,
               design_text="Design", do_sample=True, temperature=0.6, top_p=0.9, max_new_tokens=args.retro_tokens,
@@ -137,6 +138,9 @@ def build_retro_step(args, graph_decoder, device, rank: int):
                          "(template, product) -> a two-reactant string",
             "search": "lock-step A* over the batch: batched GIN encode / LLM decode / predictor + top-k / value forward per expansion round "
                       "(reference: searches one after the other, one LLM forward per new tree node)",
+            "value_estimates": ("constant-cost shortcut (opt-in): the reference-compatible language cost is 15 for every molecule, returned without the "
+                                "LLM forward" if orch.constant_language_cost_shortcut else
+                                "one left-padded LLM prefill per 64 new tree nodes, every forward executed (the reference: one forward per node)"),
             "llm_acceleration": accel, "timing_breakdown": last}
     return step_fn, info, orch, llm, sd_pred
 

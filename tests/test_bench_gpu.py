@@ -103,6 +103,11 @@ def test_bench_retro_workload(gpus):
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and "A* retrosynthesis" in d["config"]["workload"]
 
 
+def test_bench_retro_constant_value_shortcut():
+    d = _line(_run(["--retro-constant-value"] + RETRO_TINY, {}, workload="retro"))
+    assert d["expansions"] == 3 * 2 and "shortcut" in d["config"]["value_estimates"] and d["value_forward_share_of_step"] < 0.2
+
+
 @pytest.mark.parametrize("gpus", [1, 2])
 def test_bench_sft_workload(gpus):
     d = _line(_run(["--gpus", str(gpus)] + SFT_TINY, SHARED if gpus > 1 else {}, workload="sft"))
