@@ -495,8 +495,8 @@ def run_retro(args, ctx):
            "expansions_per_s": n_exp / dt, "expansions": n_exp, "value_estimates_per_expansion": n_val / max(1, n_exp),
            "design_share_of_step": design_s / max(1e-9, design_s + retro_s),
            "value_forward_share_of_step": value_s / max(1e-9, design_s + retro_s),
-           "value_forward_note": "A* value estimates: one left-padded LLM prefill per 64 new tree nodes (~100 nodes per expansion, ~130 tokens each) -- "
-                                 "stock HF forward on PyTorch-ROCm / hipBLASLt at M ~ 8 k rows, compute-bound; the reference runs one forward per node",
+           "value_forward_note": "A* value estimates: one left-padded LLM prefill per 256 new tree nodes (~100 nodes per expansion, ~130 tokens each) -- "
+                                 "stock HF forward on PyTorch-ROCm / hipBLASLt at M ~ 33 k rows, compute-bound; the reference runs one forward per node",
            "routes_found": int(gathered[:, 0].sum().item()),
            "roofline": roof}
     if not args.no_cpu_baseline and ctx.world == 1:

@@ -537,9 +537,14 @@ class GraphLLMForCausalMLM(nn.Module):
             cost += self._cost_from_logits(logits, self._answer_tokens()).sum().item() * language_cost_weight
         return cost
 
+    # prompts per LLM forward of estimate_synthesis_complexity_batch (env LLAMOLE_VALUE_BATCH overrides).  Measured on the retro workload
+    # (Qwen2-7B, ~130-token prompts, ~1 600 prompts per expansion round): 64 -> 21.4 s per step, 256 -> 18.6 s, 512 -> 18.6 s -- the prefill
+    # GEMMs of stock HF / hipBLASLt want M >= ~32 k rows; 256 prompts x 130 tokens x 18 944 x 2 B = 1.3 GB of MLP activations
+    value_batch = 256
+
     @torch.no_grad()
     def estimate_synthesis_complexity_batch(self, items, input_ids=None, molecule_cost_weight=0, language_cost_weight=1,
-                                            max_batch: int = 64) -> List[float]:
+                                            max_batch: Optional[int] = None) -> List[float]:
         """``estimate_synthesis_complexity`` for many ``(smiles, reaction)`` pairs with ONE LLM forward per ``max_batch``
         prompts instead of one per new tree node: prompts are left-padded, padding is masked and position
         ids count real tokens only, so every row computes exactly what its own unpadded forward computes."""
@@ -547,6 +552,8 @@ class GraphLLMForCausalMLM(nn.Module):
         costs = [0.0] * n
         if n == 0:
             return costs
+        if max_batch is None:
+            max_batch = int(os.environ.get("LLAMOLE_VALUE_BATCH", self.value_batch))
         if molecule_cost_weight is not None and molecule_cost_weight > 0:
             for i, (smiles, _) in enumerate(items):
                 costs[i] += self.graph_predictor.estimate_cost(smiles) * molecule_cost_weight

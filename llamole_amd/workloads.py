@@ -140,7 +140,7 @@ def build_retro_step(args, graph_decoder, device, rank: int):
                       "(reference: searches one after the other, one LLM forward per new tree node)",
             "value_estimates": ("constant-cost shortcut (opt-in): the reference-compatible language cost is 15 for every molecule, returned without the "
                                 "LLM forward" if orch.constant_language_cost_shortcut else
-                                "one left-padded LLM prefill per 64 new tree nodes, every forward executed (the reference: one forward per node)"),
+                                f"one left-padded LLM prefill per {orch.value_batch} new tree nodes, every forward executed (the reference: one forward per node)"),
             "llm_acceleration": accel, "timing_breakdown": last}
     return step_fn, info, orch, llm, sd_pred
 
