@@ -52,19 +52,22 @@ class SyntheticTokenizer:
 
     def encode(self, text, add_special_tokens=False, return_tensors=None):
         """3 characters per token (stable across processes); special-token strings inside the text become their ids."""
+        import re
         import zlib
-        ids, i = [], 0
-        while i < len(text):
-            hit = next((s for s in self.special if text.startswith(s, i)), None)
-            if hit is not None:
-                ids.append(self.special[hit])
-                i += len(hit)
+        if getattr(self, "_split", None) is None:
+            self._split = re.compile("(" + "|".join(re.escape(t) for t in sorted(self.special, key=len, reverse=True)) + ")")
+        ids = []
+        for piece in self._split.split(text):
+            if not piece:
                 continue
-            j = i + 3
-            nxt = min((text.find(s, i) for s in self.special if text.find(s, i) > i), default=len(text))
-            j = min(j, nxt)
-            ids.append(5 + zlib.crc32(text[i:j].encode()) % 1000)
-            i = j
+            if piece in self.special:
+                ids.append(self.special[piece])
+                continue
+            data = piece.encode()
+            if len(data) == len(piece):       # ASCII: chunk the bytes directly
+                ids.extend(5 + zlib.crc32(data[i:i + 3]) % 1000 for i in range(0, len(data), 3))
+            else:
+                ids.extend(5 + zlib.crc32(piece[i:i + 3].encode()) % 1000 for i in range(0, len(piece), 3))
         return torch.tensor([ids]) if return_tensors == "pt" else ids
 
     def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=False):

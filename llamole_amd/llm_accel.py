@@ -24,7 +24,13 @@ MAX_STREAM_ROWS = 16    # ll_linear_rows16_bf16: one MFMA column block of token 
 # stays at 2 so that two-sequence decode keeps the bit-identity with HF's op order; LLAMOLE_FMA_GEMV_ROWS=1 trades it for the 4 %)
 FMA_GEMV_ROWS = int(os.environ.get("LLAMOLE_FMA_GEMV_ROWS", "2"))
 MAX_APPEND_ROWS = 16     # new positions per call served by the fused KV append / decode attention (decode, query tail)
-MAX_EW_ROWS = 16384      # row-parallel elementwise kernels (RMSNorm, rotary, SiLU*mul) also serve prefill-sized calls
+# row-parallel elementwise kernels (RMSNorm, rotary, SiLU*mul) also serve prefill-sized calls.  Round 3: the A* value estimates push
+# 256 prompts x ~144 tokens = 37 k rows through the model per forward; above the old 16 k-row limit HF's op-by-op RMSNorm (pow, mean, rsqrt,
+# two casts, two multiplies: ~0.7 ms per norm at 37 k x 3584) and act_fn(gate) * up (1.3 ms per layer) were 17 % of that forward
+MAX_EW_ROWS = 1 << 20
+# vocabulary-sized outputs for a few hundred rows (the lm_head of a batched `logits_to_keep = 1` forward: 256 x 152 064 x 3584): hipBLASLt
+# picks a 256 x 16 tile there and takes 32 ms (8.6 TFLOP/s); the LDS-DMA ring GEMM streams the 1.09 GB of weights once
+MAX_WIDE_ROWS, WIDE_N = 1024, 65536
 
 
 def _versions(*tensors):
@@ -34,7 +40,7 @@ def _versions(*tensors):
 def _hip_linear_forward(self: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     K = self.in_features
     if (x.is_cuda and x.dtype == torch.bfloat16 and self.weight.dtype == torch.bfloat16 and not torch.is_grad_enabled()
-            and x.numel() // K <= MAX_ROWS and x.shape[-1] == K
+            and (x.numel() // K <= MAX_ROWS or (x.numel() // K <= MAX_WIDE_ROWS and self.out_features >= WIDE_N)) and x.shape[-1] == K
             and (K % 64 == 0 or (x.numel() // K <= 4 and K % 8 == 0))):      # gemm_dispatch: K % 64 == 0 beyond the 4-row GEMV
         x2 = x.reshape(-1, K)
         if not x2.is_contiguous():

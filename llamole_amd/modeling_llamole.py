@@ -578,8 +578,8 @@ class GraphLLMForCausalMLM(nn.Module):
                 ids, mask = ids.to(self.device), mask.to(self.device)
                 posid = (mask.cumsum(dim=1) - 1).clamp_min(0)
                 kw = dict(input_ids=ids, attention_mask=mask, position_ids=posid)
-                try:
-                    logits = self.language_model(logits_to_keep=1, **kw).logits[:, -1, :]
+                try:      # only the last position's logits are read: no [B, L, vocab] product, no KV cache
+                    logits = self.language_model(logits_to_keep=1, use_cache=False, **kw).logits[:, -1, :]
                 except TypeError:
                     logits = self.language_model(**kw).logits[:, -1, :]
                 c = self._cost_from_logits(logits, answer_tokens) * language_cost_weight
