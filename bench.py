@@ -10,8 +10,9 @@ One "step" = one pass of the hot path over one batch of synthetic prompts+condit
                design trigger, query-token re-forward, connector, then the GraphDiT trajectory;
   * retro    : BASELINE.json configs[2]: Qwen2-7B + GraphDiT + GIN predictor, 16 prompts per GPU: design phase as one
                batch, then 16 A* retrosynthesis searches in lock step, <= 5 expansions each (scripted chemistry);
-  * sft      : BASELINE.json configs[4]: Mistral-7B architecture + LoRA, LM loss + retro cross-entropy through the
-               frozen HIP GIN encoder / predictor (forward + reverse sweep), AdamW, gradient all-reduce over the ranks.
+  * sft      : BASELINE.json configs[4]: Mistral-7B architecture + LoRA, 6 rows x 2048 tokens per GPU (the reference's
+               config/train/mistral_lora.yaml), LM loss + retro cross-entropy through the frozen HIP GIN encoder / predictor
+               (forward + reverse sweep), AdamW, gradient all-reduce over the ranks.
 Prints ONE JSON line (rank 0).  `value` = molecules/s (samples/s for sft) over all ranks (weak scaling: every rank runs
 its own batch of independent prompts; no data-path collective, one small all-gather of the results; sft: one bucketed
 gradient all-reduce per step).
@@ -583,8 +584,8 @@ def main():
                     help="retro: opt-in shortcut -- the reference-compatible A* language cost is the constant 15 for every molecule (its [5,1] x [5] "
                          "broadcast), so return it without the LLM forward (default: every value forward runs, as in the reference)")
     ap.add_argument("--out-dim", type=int, default=180576, help="retro / sft: reaction templates of the GIN predictor head")
-    ap.add_argument("--sft-batch", type=int, default=2, help="sft: rows per GPU per step")
-    ap.add_argument("--sft-seq", type=int, default=512, help="sft: tokens per row")
+    ap.add_argument("--sft-batch", type=int, default=6, help="sft: rows per GPU per step (reference config/train/mistral_lora.yaml:30 per_device_train_batch_size)")
+    ap.add_argument("--sft-seq", type=int, default=2048, help="sft: tokens per row (reference config/train/mistral_lora.yaml:18 cutoff_len; every row is full length)")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--cutoff-len", type=int, default=128)
     ap.add_argument("--no-llm-layer-fuse", dest="llm_layer_fuse", action="store_false",
