@@ -132,6 +132,49 @@ def test_fused_elementwise_matches_hf_modules():
 
 
 @pytest.mark.gpu
+def test_prefill_sized_rows_and_vocabulary_wide_linear():
+    """Round 3 (the A* value estimates: 256 prompts x ~144 tokens per forward): the row-parallel RMSNorm / SiLU*mul / rotary kernels at
+    37 k rows -- above the old 16 k-row limit HF's op-by-op code ran -- and a vocabulary-wide Linear at a few hundred rows on the ring GEMM
+    (hipBLASLt picks a 256 x 16 tile there), each against the stock modules."""
+    import torch.nn as nn
+    from llamole_amd import llm_accel
+    from llamole_amd.llm_accel import accelerate_elementwise, accelerate_linears, restore_elementwise, restore_linears
+    from transformers.models.qwen2 import modeling_qwen2 as mq
+    llm, prompt, mask = _case("cuda", torch.bfloat16)
+    torch.manual_seed(1)
+    rows = 36864
+    assert rows > 16384 and llm_accel.MAX_EW_ROWS >= rows
+    norm, mlp = llm.model.layers[0].input_layernorm, llm.model.layers[0].mlp
+    x = torch.randn(256, rows // 256, llm.config.hidden_size, device="cuda", dtype=torch.bfloat16) * 2
+    q = torch.randn(64, rows // 64, 4, 64, device="cuda", dtype=torch.bfloat16).transpose(1, 2)
+    k = torch.randn(64, rows // 64, 2, 64, device="cuda", dtype=torch.bfloat16).transpose(1, 2)
+    cos = torch.randn(64, rows // 64, 64, device="cuda", dtype=torch.bfloat16)
+    sin = torch.randn(64, rows // 64, 64, device="cuda", dtype=torch.bfloat16)
+    wide = nn.Linear(256, 70000, bias=False, device="cuda", dtype=torch.bfloat16)       # "lm_head": N >= WIDE_N
+    xs = torch.randn(300, 256, device="cuda", dtype=torch.bfloat16)                      # 128 < rows <= MAX_WIDE_ROWS
+    holder = nn.ModuleDict({"wide": wide})
+    with torch.no_grad():
+        ref_n, ref_m = norm(x), mlp(x)
+        ref_q, ref_k = mq.apply_rotary_pos_emb(q, k, cos, sin)
+        ref_w = wide(xs).float()
+        accelerate_elementwise(llm)
+        assert accelerate_linears(holder, min_weight_elems=1) == 1
+        got_n, got_m = norm(x), mlp(x)
+        got_q, got_k = mq.apply_rotary_pos_emb(q, k, cos, sin)
+        got_w = wide(xs).float()
+        narrow = nn.ModuleDict({"n": nn.Linear(256, 512, bias=False, device="cuda", dtype=torch.bfloat16)})
+        accelerate_linears(narrow, min_weight_elems=1)
+        assert torch.equal(narrow["n"](xs), torch.nn.functional.linear(xs, narrow["n"].weight))      # 300 rows x a narrow output: still F.linear
+    restore_elementwise(llm)
+    restore_linears(holder)
+    assert torch.equal(got_q, ref_q) and torch.equal(got_k, ref_k)
+    for got, ref in ((got_n, ref_n), (got_m, ref_m)):
+        diff = (got.float() - ref.float()).abs()
+        assert (diff > 0).float().mean() < 0.02 and (diff <= 2 ** -7 * ref.float().abs() + 1e-6).all()
+    assert (got_w - ref_w).abs().max() <= 2e-2 * ref_w.abs().max()
+
+
+@pytest.mark.gpu
 def test_decode_attention_and_fused_cache():
     """Fused GQA decode attention + KV append vs HF sdpa + StaticLayer.update: logits within bf16 tolerance, identical
     token stream eager vs hipGraph, and cache contents identical to the unfused run."""
