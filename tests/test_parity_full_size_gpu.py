@@ -265,6 +265,53 @@ def test_graphdit_bf16_vs_oracle_at_informative_steps(full_dit, oracle_traj, B, 
     assert free[T - 1] == 1.0 and free[30] >= 0.995 and free[20] >= 0.98 and free[10] >= 0.95 and free[0] >= 0.6, free
 
 
+def test_graphdit_f32_engine_vs_oracle_at_informative_steps(full_dit, oracle_traj):
+    """The f32 engine (exact f32 FMA chains; the parity engine behind the bit-exact fixture tests) at the BENCHMARKED size, on the same
+    bf16-rounded weights as the oracle, teacher-forced from the oracle's states at PROBE_STEPS: integer work must agree bit for bit --
+    every sampled atom and bond under the oracle's noise -- and the probabilities to f32 rounding."""
+    import bench
+    m_bf16, spec, sd, do = full_dit
+    tr = oracle_traj
+    args = types.SimpleNamespace(hidden=1024, depth=28, heads=16, T=50, guide=2.0, nodes=32, dtype="f32")
+    m, _, _, _ = bench.build_model(args, torch.device("cuda"))
+    m.denoiser.load_state_dict({k: v.cuda() for k, v in sd.items()})          # the oracle's (bf16-rounded) values as f32 masters
+    N, T, B0 = spec.N, spec.T, tr["B0"]
+    rows = BATCH_ROWS[8]
+    props, text, n_nodes = tr["props"][rows], tr["text"][rows], tr["n_nodes"][rows]
+    mask = torch.arange(N).unsqueeze(0).expand(8, -1) < n_nodes.unsqueeze(1)
+    um = _upper(n_nodes, N)
+    m.begin(props, text, -200.0, n_nodes)
+    bad = total = 0
+    worst_tv = worst_l = 0.0
+    for s in PROBE_STEPS:
+        pr = tr["probes"][s]
+        if s == T - 1:
+            m.init_state(*_rows_noise(T, rows, B0, N))
+        else:
+            oX, oE = tr["trace"][s + 1]
+            m.set_state(oX[rows].to(torch.int8), oE[rows].to(torch.int8))
+        lx, le = m.denoise_logits(s)
+        ref_l = pr["logits"]
+        lscale = max(float(ref_l[0].abs().max()), float(ref_l[1].abs().max()), 1.0)
+        worst_l = max(worst_l, float(((lx[0].cpu() - ref_l[0]) * mask.unsqueeze(-1)).abs().max()) / lscale,
+                      float(((le[1].cpu() - ref_l[3]) * um.unsqueeze(-1)).abs().max()) / lscale)
+        px, pe = m.step_probs(s)
+        worst_tv = max(worst_tv, float((0.5 * (px.cpu() - pr["pX"]).abs().sum(-1))[mask].max()),
+                       float((0.5 * (pe.cpu() - pr["pE"]).abs().sum(-1))[um].max()))
+        m.step(s, *_rows_noise(s, rows, B0, N))
+        X, E = m.get_state()
+        oX, oE = tr["trace"][s]
+        bad += int((X.cpu().long()[mask] != oX[mask]).sum()) + int((E.cpu().long()[um] != oE[um]).sum())
+        total += int(mask.sum()) + int(um.sum())
+    rec = dict(mismatched_samples=bad, samples=total, tv_max=worst_tv, logit_err_rel=worst_l)
+    print(f"f32 engine at the benchmarked size: {rec}")
+    _report("graphdit_steps_B8_f32_engine", rec)
+    assert bad == 0, rec                       # bit-exact integer work
+    assert worst_tv <= 1e-4 and worst_l <= 1e-4, rec
+    del m
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------ MFMA attention vs f32-LDS attention
 @pytest.mark.parametrize("N,H,heads", [(32, 128, 4), (32, 256, 4), (50, 128, 4), (50, 256, 4)],
                          ids=["NP32_HD32", "NP32_HD64", "NP64_HD32", "NP64_HD64"])
