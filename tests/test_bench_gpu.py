@@ -114,3 +114,25 @@ def test_bench_sft_workload(gpus):
     assert d["n_gpus"] == gpus and d["unit"] == "samples/s" and d["value"] > 0
     assert d["config"]["global_batch"] == 2 * gpus and d["config"]["parallelism"] == f"dp{gpus}"
     assert d["loss"] == d["loss"] and d["retro_loss"] > 0 and d["graph_side_ms"] > 0 and d["roofline"]["frac"] > 0
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's own launch line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N --steps K --warmup W` -- ranks from the launcher's environment, ONE JSON line from rank 0."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, **SHARED)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LLAMOLE_BENCH_FAIL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--batch", "2"] + TINY_DIT + E2E_TINY
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["config"]["gathered_molecules"] == 4
