@@ -567,24 +567,30 @@ class GraphLLMForCausalMLM(nn.Module):
                 add_generation_prompt=True)) for smiles, reaction in items]
             pad = getattr(self.tokenizer, "pad_token_id", None)
             pad = self.tokenizer.eos_token_id if pad is None else pad
+            # prompts of similar length share a forward (less padding; every row still computes exactly its own unpadded forward), and
+            # the host never waits between forwards: the per-chunk costs stay on the device until all chunks are enqueued
+            order = sorted(range(n), key=lambda i: len(rows[i]))
+            pending = []
             for lo in range(0, n, max_batch):
-                chunk = rows[lo:lo + max_batch]
+                sel = order[lo:lo + max_batch]
+                chunk = [rows[i] for i in sel]
                 L = max(len(r) for r in chunk)
                 ids = torch.full((len(chunk), L), pad, dtype=torch.long)
                 mask = torch.zeros((len(chunk), L), dtype=torch.long)
                 for j, r in enumerate(chunk):
                     ids[j, L - len(r):] = torch.tensor(r, dtype=torch.long)
                     mask[j, L - len(r):] = 1
-                ids, mask = ids.to(self.device), mask.to(self.device)
+                ids, mask = ids.to(self.device, non_blocking=True), mask.to(self.device, non_blocking=True)
                 posid = (mask.cumsum(dim=1) - 1).clamp_min(0)
                 kw = dict(input_ids=ids, attention_mask=mask, position_ids=posid)
                 try:      # only the last position's logits are read: no [B, L, vocab] product, no KV cache
                     logits = self.language_model(logits_to_keep=1, use_cache=False, **kw).logits[:, -1, :]
                 except TypeError:
                     logits = self.language_model(**kw).logits[:, -1, :]
-                c = self._cost_from_logits(logits, answer_tokens) * language_cost_weight
-                for j, v in enumerate(c.tolist()):
-                    costs[lo + j] += v
+                pending.append((sel, self._cost_from_logits(logits, answer_tokens) * language_cost_weight))
+            for sel, c in pending:
+                for i, v in zip(sel, c.tolist()):
+                    costs[i] += v
         return costs
 
     def _create_failure_result(self, target_smiles, generated_tokens=None) -> Dict[str, Any]:
