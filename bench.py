@@ -485,6 +485,8 @@ def run_retro(args, ctx):
         return None
     T = args.targets
     roof = time_template_head(args, T)
+    roof["note"] = ("dominant HAND-WRITTEN kernel of the workload; the step's dominant kernel overall is hipBLASLt's MT256x256x64 GEMM under the stock "
+                    "HF forward of the A* value estimates (78 % of that forward, profiles/r3_value_forward_kernel_stats.csv; see value_forward_share_of_step)")
     out = {"metric": "retrosynthesis-planned molecules/sec (design + A* search, depth <= %d)" % args.iterations,
            "value": ctx.world * T * args.steps / dt, "unit": "molecules/s", "n_gpus": ctx.n_ranks, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
@@ -527,6 +529,8 @@ def run_sft(args, ctx):
     graph_ms = step_fn.graph_side_ms()
     roof = time_template_head(args, n_retro)
     roof["kernel"] += "; the reverse sweep streams the same 740 MB once more (dlogits x W, 16-way split-K)"
+    roof["note"] = ("dominant HAND-WRITTEN kernel of the workload (graph side of the loss, graph_side_share of the step); the step itself is the stock HF "
+                    "forward / backward of the LLM under PyTorch autograd (hipBLASLt GEMMs)")
     out = {"metric": "SFT samples/sec (LM loss + retro cross-entropy, LoRA)", "value": ctx.world * B * args.steps / dt, "unit": "samples/s",
            "n_gpus": ctx.n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
