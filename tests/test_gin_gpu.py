@@ -167,6 +167,46 @@ def test_bf16_engine(name):
     assert hits >= 0.8, hits
 
 
+@pytest.mark.parametrize("H,dtype,tol", [(256, torch.float32, 3e-3), (768, torch.float32, 3e-3), (1024, torch.float32, 3e-3),
+                                         (1024, torch.bfloat16, 6e-2), (2048, torch.bfloat16, 6e-2)])
+def test_gin_wide_hidden_sizes_vs_oracle(H, dtype, tol):
+    """Every instance of the round-3 layer kernels: one / two / four waves per node in the aggregation launch (H < 512, < 1024, >= 1024),
+    the multi-wave tail for H = 256 x 2^k and the one-wave tail otherwise (H = 768), split-K counts 2 and 4 -- encoder and predictor against
+    the CPU oracle on ragged molecule graphs incl. a hub of degree 9 (more in-edges than a neighbour record holds)."""
+    from llamole_amd.graph_encoder import GraphCLIP
+    from llamole_amd.graph_predictor import GraphPredictor
+    from oracle import gin_oracle as go
+    L, out_dim, G, seed = 2, 640, 5, 7
+    x, ei, ea, batch = synth.make_mol_graphs(G, seed)
+    n0 = x.numel()                                          # one more graph: a hub with 9 neighbours
+    x = torch.cat([x, torch.tensor([6] + [1] * 9)])
+    hub_e = torch.tensor([[n0] * 9 + list(range(n0 + 1, n0 + 10)), list(range(n0 + 1, n0 + 10)) + [n0] * 9])
+    ei = torch.cat([ei, hub_e], dim=1)
+    ea = torch.cat([ea, torch.tensor([1 + (i % 4) for i in range(9)] * 2)])
+    batch = torch.cat([batch, torch.full((10,), G, dtype=torch.long)])
+    G += 1
+    sd_e, sd_j = synth.make_gin_weights(L, H, "encoder", seed=seed), synth.make_proj_weights(H, seed)
+    sd_p = synth.make_gin_weights(L, H, "predictor", out_dim, seed)
+    if dtype != torch.float32:
+        sd_e, sd_j, sd_p = ({k: v.to(dtype).float() for k, v in d.items()} for d in (sd_e, sd_j, sd_p))
+    enc = GraphCLIP(L, H, 0.0, {})
+    enc.molecule_encoder.load_state_dict(sd_e)
+    enc.molecule_projection.load_state_dict(sd_j)
+    pred = GraphPredictor(L, H, 0.0, out_dim, {}, {})
+    pred.predictor.load_state_dict(sd_p)
+    for m in (enc, pred):
+        m.to("cuda")
+        for p in m.parameters():
+            p.data = p.data.to(dtype)
+    c = torch.randn(G, 768, generator=torch.Generator().manual_seed(seed))
+    ref_e = go.graphclip_forward(sd_e, sd_j, L, x, ei, ea, batch)
+    ref_p = go.predictor_forward(sd_p, L, x, ei, ea, batch, c)
+    got_e = enc(x.cuda(), ei.cuda(), ea.cuda(), batch.cuda()).float().cpu()
+    got_p = pred(x.cuda(), ei.cuda(), ea.cuda(), batch.cuda(), c.cuda()).float().cpu()
+    assert float((got_e - ref_e).abs().max()) <= tol * max(1.0, float(ref_e.abs().max())) * (1 if dtype == torch.float32 else 1)
+    assert float((got_p - ref_p).abs().max()) <= tol * max(1.0, float(ref_p.abs().max()))
+
+
 def test_gin_edge_cases_vs_oracle():
     """Isolated atoms / a bond-free graph / a single-graph batch / a high-degree hub, f32 engine vs the CPU oracle."""
     from oracle import gin_oracle as go
