@@ -427,3 +427,23 @@ def test_graph_csr_kernel_equals_aten_route():
     assert int(got[1][-1]) == ei.shape[1] - 1                                                        # the bad edge was dropped, the rest kept
     check_graph_errors(wait=True)                                                                    # reported once, then clean
     assert csr_for_engine(x, ei, ea, batch)[8] == 16          # CPU tensors: the ATen route
+
+
+def test_gin_large_batch_vs_oracle():
+    """700 molecule graphs (~19 k nodes, ~45 k edges) in one batch: the global-memory CSR conversion, hundreds of M-tiles in the grouped
+    GEMMs, no split-K -- encoder and predictor (f32 engine) against the CPU oracle."""
+    from oracle import gin_oracle as go
+    name = "gin_l3_h64"
+    L, H, out_dim, _, seed = GIN_CASES[name]
+    x, ei, ea, batch = synth.make_mol_graphs(700, 11, min_atoms=24, max_atoms=32)
+    G = 700
+    enc, pred = _encoder(name), _predictor(name)
+    sd_e, sd_j = synth.make_gin_weights(L, H, "encoder", seed=seed), synth.make_proj_weights(H, seed)
+    sd_p = synth.make_gin_weights(L, H, "predictor", out_dim, seed)
+    c = torch.randn(G, 768, generator=torch.Generator().manual_seed(2))
+    ref_e = go.graphclip_forward(sd_e, sd_j, L, x, ei, ea, batch)
+    ref_p = go.predictor_forward(sd_p, L, x, ei, ea, batch, c)
+    got_e = enc(x.cuda(), ei.cuda(), ea.cuda(), batch.cuda()).cpu()
+    got_p = pred(x.cuda(), ei.cuda(), ea.cuda(), batch.cuda(), c.cuda()).cpu()
+    np.testing.assert_allclose(got_e.numpy(), ref_e.numpy(), rtol=2e-3, atol=5e-4)
+    np.testing.assert_allclose(got_p.numpy(), ref_p.numpy(), rtol=3e-3, atol=2e-3)
