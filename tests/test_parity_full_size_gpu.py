@@ -312,6 +312,76 @@ def test_graphdit_f32_engine_vs_oracle_at_informative_steps(full_dit, oracle_tra
     torch.cuda.empty_cache()
 
 
+def test_graphdit_bf16_n50_T500_vs_oracle():
+    """The reference's class defaults beyond the BASELINE shape: max_n_nodes = 50 (transformer.py:27; the 64-row attention tile, two-chunk
+    q|k|v panels, the 65..224-row panel GEMMs) and T = 500 reverse steps (hoisted tables of 501 x (B+1) rows: 1.1 GB at B = 2), bf16 engine
+    at H = 1024, L = 28: z_T bit-exact, then the same state handed to engine and oracle at s = 499, 498 (the oracle's own steps from z_T), 250 and
+    5 (states the engine reached on the device in between): logits, guided probabilities, race winners under shared noise."""
+    import bench
+    from oracle import graphdit_oracle as do
+    args = types.SimpleNamespace(hidden=1024, depth=28, heads=16, T=500, guide=2.0, nodes=50, dtype="bf16")
+    m, cfg, meta, sd = bench.build_model(args, torch.device("cuda"))
+    sd_cpu = {k: v.detach().to(torch.bfloat16).float().cpu() for k, v in sd.items()}
+    spec = do.build_spec(cfg, meta)
+    N, T, B, seed = spec.N, spec.T, 2, 21
+    assert N == 50 and T == 500
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    props, text, _ = synth.make_dit_inputs(B, seed=seed, max_node=N)
+    n_nodes = torch.tensor([50, 37])
+    y = torch.where(props == -200.0, torch.tensor(float("nan")), props)
+    mask = torch.arange(N).unsqueeze(0).expand(B, -1) < n_nodes.unsqueeze(1)
+    um = _upper(n_nodes, N)
+    m.begin(props, text, -200.0, n_nodes)
+    m.init_state(*synth.exp_noise(seed, T, B, N))
+    with torch.no_grad():
+        X, E = do.initial_state(spec, mask, *synth.exp_noise(seed, T, B, N))
+    Xi, Ei = do.collapse(X, E, mask)
+    gX, gE = m.get_state()
+    offd = ~torch.eye(N, dtype=torch.bool).unsqueeze(0).expand(B, -1, -1)
+    assert torch.equal(gX.cpu().long(), Xi) and torch.equal(gE.cpu().long()[offd], Ei[offd])
+    rec = {}
+    first = True
+    prev = None
+    for s in (499, 498, 250, 5):
+        if prev is not None and prev - s > 1:      # a later state: let the engine run on-device from prev - 1 down to s + 1, then hand ITS state to both
+            for t in range(prev - 1, s, -1):
+                m.step(t, None, None, seed=1000 + t)
+            gX, gE = m.get_state()
+            gX, gE = gX.cpu().long(), gE.cpu().long()
+            X, E = do.to_onehot_masked(gX.clamp_min(0), gE.clamp_min(0), mask)
+        if not first:
+            cX, cE = do.collapse(X.clone(), E.clone(), mask)
+            m.set_state(cX.to(torch.int8), cE.to(torch.int8))
+        first = False
+        prev = s
+        with torch.no_grad():
+            pX, pE, logits = do.guided_probs(sd_cpu, spec, X, E, mask, y, text, s, return_logits=True)
+        lx, le = m.denoise_logits(s)
+        lscale = max(float(logits[0].abs().max()), float(logits[1].abs().max()), 1.0)
+        lerr = max(float(((lx[0].cpu() - logits[0]) * mask.unsqueeze(-1)).abs().max()), float(((le[1].cpu() - logits[3]) * um.unsqueeze(-1)).abs().max())) / lscale
+        px, pe = m.step_probs(s)
+        tvx = float((0.5 * (px.cpu() - pX).abs().sum(-1))[mask].max())
+        tve = float((0.5 * (pe.cpu() - pE).abs().sum(-1))[um].max())
+        qx, qe = synth.exp_noise(seed, s, B, N)
+        with torch.no_grad():
+            Xs, Es = do.sample_features(pX, pE, mask, qx, qe)
+            X, E = do.to_onehot_masked(Xs, Es, mask)
+        oX, oE = do.collapse(X.clone(), E.clone(), mask)
+        m.step(s, qx, qe)
+        gX, gE = m.get_state()
+        agree_x = float((gX.cpu().long()[mask] == oX[mask]).float().mean())
+        agree_e = float((gE.cpu().long()[um] == oE[um]).float().mean())
+        rec[str(s)] = dict(alpha_bar_s=float(spec.alphas_bar[s]), logit_err_rel=lerr, tv_atoms_max=tvx, tv_bonds_max=tve,
+                           race_agree_atoms=agree_x, race_agree_bonds=agree_e)
+    print(f"N=50 T=500 B=2: {json.dumps(rec)}")
+    _report("graphdit_N50_T500_B2", rec)
+    for s, r in rec.items():
+        assert r["logit_err_rel"] <= 2e-2 and r["tv_atoms_max"] <= 6e-2 and r["tv_bonds_max"] <= 6e-2, (s, r)
+        assert r["race_agree_atoms"] >= 0.93 and r["race_agree_bonds"] >= 0.99, (s, r)
+    del m
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------ MFMA attention vs f32-LDS attention
 @pytest.mark.parametrize("N,H,heads", [(32, 128, 4), (32, 256, 4), (50, 128, 4), (50, 256, 4)],
                          ids=["NP32_HD32", "NP32_HD64", "NP64_HD32", "NP64_HD64"])
