@@ -382,6 +382,33 @@ def test_graphdit_bf16_n50_T500_vs_oracle():
     torch.cuda.empty_cache()
 
 
+def test_graphdit_training_forward_full_size_vs_oracle(full_dit):
+    """GraphDiT.forward (the denoiser's training loss -- densify, forward-diffuse every graph to its own timestep incl. t = 0
+    and t = T, one conditional pass with per-graph table rows through ll_dit_denoise_rows, masked cross-entropies) on the BENCHMARKED bf16
+    engine against oracle.train_forward on the same bf16-rounded weights: noisy state bit-exact, logits and loss within bf16 tolerance."""
+    m, spec, sd, do = full_dit
+    B, seed = 6, 13
+    meta = synth.make_data_meta(spec.N, 0, fixed_n_nodes=spec.N)
+    x, ei, ea, batch, props, text, t_int = synth.make_dit_train_batch(meta, B, seed, spec.T)
+    qx, qe = synth.exp_noise(seed, spec.T + 1, B, spec.N)
+    loss = m(x, ei, ea, batch, props, text, -200.0, t_int=t_int, noise=(qx, qe))
+    with torch.no_grad():
+        ref_loss, (X_t, E_t, lx, le) = do.train_forward(sd, spec, x, ei, ea, batch, props, text, -200.0, t_int, qx, qe)
+    lt = m._last_train
+    counts = torch.bincount(batch, minlength=B)
+    mask = torch.arange(spec.N).unsqueeze(0) < counts.unsqueeze(1)
+    um = _upper(counts, spec.N)
+    oX, oE = (X_t.argmax(-1), E_t.argmax(-1)) if X_t.dim() == 3 else (X_t.long(), E_t.long())
+    assert torch.equal(lt["X_t"].cpu().long()[mask], oX[mask]) and torch.equal(lt["E_t"].cpu().long()[um], oE[um]), "noisy state differs from the oracle"
+    lscale = max(float(lx.abs().max()), float(le.abs().max()), 1.0)
+    lerr = max(float(((lt["logX"].cpu() - lx) * mask.unsqueeze(-1)).abs().max()), float(((lt["logE"].cpu() - le) * um.unsqueeze(-1)).abs().max())) / lscale
+    rel = abs(float(loss) - float(ref_loss)) / abs(float(ref_loss))
+    rec = dict(loss=float(loss), loss_ref=float(ref_loss), loss_rel=rel, logit_err_rel=lerr, t_int=t_int.view(-1).tolist())
+    print(f"training forward at the benchmarked size: {rec}")
+    _report("graphdit_train_forward_full_size", rec)
+    assert lerr <= 2e-2 and rel <= 1e-2, rec
+
+
 # ------------------------------------------------------------------------------------------ MFMA attention vs f32-LDS attention
 @pytest.mark.parametrize("N,H,heads", [(32, 128, 4), (32, 256, 4), (50, 128, 4), (50, 256, 4)],
                          ids=["NP32_HD32", "NP32_HD64", "NP64_HD32", "NP64_HD64"])
