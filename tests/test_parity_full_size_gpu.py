@@ -664,3 +664,35 @@ def test_gin_backward_full_size_vs_oracle_autograd():
     assert scale > 0 and torch.isfinite(dc).all()
     assert lerr <= 2e-2, rec
     assert cos >= 0.995 and row_cos >= 0.98 and err <= 0.1, rec
+
+
+def test_gin_encoder_full_size_vs_oracle():
+    """GraphCLIP encoder at the reference's size (5 layers, hidden 512; bf16 engine) on 16 molecule graphs of 32 atoms against the f32 oracle on
+    the same bf16-rounded weights: unit-norm embeddings, worst component and worst cosine."""
+    import sys
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gin_bench import fast_weights
+    from llamole_amd.graph_encoder import GraphCLIP
+    from oracle import gin_oracle as go
+    L, H, G = 5, 512, 16
+    dev = torch.device("cuda")
+    x, ei, ea, batch = synth.make_mol_graphs(G, 2, min_atoms=32, max_atoms=32)
+    sde = fast_weights(synth.gin_weight_shapes(L, H, "encoder"), dev, 1)
+    sdj = fast_weights(synth.proj_weight_shapes(H), dev, 2)
+    enc = GraphCLIP(L, H, 0.0, {})
+    enc.to(dev)
+    enc.molecule_encoder.load_state_dict(sde)
+    enc.molecule_projection.load_state_dict(sdj)
+    for p in enc.parameters():
+        p.data = p.data.to(torch.bfloat16)
+    got = enc(x.to(dev), ei.to(dev), ea.to(dev), batch.to(dev)).float().cpu()
+    r = lambda d: {k: v.detach().to(torch.bfloat16).float().cpu() for k, v in d.items()}      # noqa: E731
+    ref = go.graphclip_forward(r(sde), r(sdj), L, x, ei, ea, batch)
+    err = float((got - ref).abs().max())
+    cos = float(F.cosine_similarity(got, ref, dim=1).min())
+    rec = dict(max_abs_err=err, min_cosine=cos, max_component=float(ref.abs().max()))
+    print(f"GIN encoder full size: {rec}")
+    _report("gin_encoder_full_size", rec)
+    assert torch.allclose(got.norm(dim=1), torch.ones(G), atol=1e-2)
+    assert cos >= 0.999 and err <= 2e-2, rec
