@@ -196,8 +196,14 @@ def run_eval(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> Di
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        # one process per GPU; LLAMOLE_BENCH_SHARED_GPU=1 / LLAMOLE_DIST_BACKEND=gloo are the single-GPU dry-run switches of bench.py (tests)
+        n_dev = torch.cuda.device_count()
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if local >= n_dev and os.environ.get("LLAMOLE_BENCH_SHARED_GPU") != "1":
+            raise RuntimeError(f"rank {rank} needs GPU {local}, this node shows {n_dev}")
+        torch.cuda.set_device(local % n_dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("LLAMOLE_DIST_BACKEND", "nccl"))
     tokenizer = load_tokenizer(model_args)
     gen_kwargs = generating_args.to_dict()
     gen_kwargs["eos_token_id"] = [tokenizer.eos_token_id] + special_token_ids(tokenizer, model_args.new_special_tokens)

@@ -13,8 +13,10 @@ import sys
 import types
 import zlib
 
-SYMBOL_Z = {"*": 0, "H": 1, "B": 5, "C": 6, "N": 7, "O": 8, "F": 9, "Si": 14, "P": 15, "S": 16, "Cl": 17, "Se": 34, "Br": 35, "I": 53}
-ALLOWED = {0: [99], 1: [1], 5: [3], 6: [4], 7: [3], 8: [2], 9: [1], 14: [4], 15: [3, 5], 16: [2, 4, 6], 17: [1], 34: [2, 4, 6], 35: [1], 53: [1]}
+SYMBOL_Z = {"*": 0, "H": 1, "B": 5, "C": 6, "N": 7, "O": 8, "F": 9, "Na": 11, "Si": 14, "P": 15, "S": 16, "Cl": 17, "Ge": 32, "Se": 34, "Br": 35,
+            "Sn": 50, "I": 53}
+ALLOWED = {0: [99], 1: [1], 5: [3], 6: [4], 7: [3], 8: [2], 9: [1], 11: [1], 14: [4], 15: [3, 5], 16: [2, 4, 6], 17: [1], 32: [4], 34: [2, 4, 6],
+           35: [1], 50: [2, 4], 53: [1]}
 
 
 class _BondType:
@@ -282,6 +284,34 @@ def GetMorganFingerprintAsBitVect(mol, radius, nBits=2048):
             bits.add(zlib.crc32(f"{env}|{r}|{a._explicit_valence()}".encode()) % nBits)
             env += "".join(sorted(mol.atoms[b.b if b.a == a.idx else b.a].symbol for b in a.GetBonds()))
     return _Fingerprint(bits, nBits)
+
+
+def split_template_runner(template: str, smiles: str):
+    """A scripted `rdchiralRunText` whose outcomes are molecules of this double: the product with its last bond cut (two reactants when
+    that disconnects it); every seventh template does not apply, every eleventh raises."""
+    i = int("".join(ch for ch in template if ch.isdigit()) or 0)
+    if i % 7 == 0:
+        return []
+    if i % 11 == 0:
+        raise RuntimeError("template does not apply")
+    mol = MolFromSmiles(smiles)
+    if mol is None or not mol.bonds:
+        return []
+    cut = mol.bonds[-1 - (i % len(mol.bonds))]
+    mol.RemoveBond(cut.a, cut.b)
+    return [MolToSmiles(mol)]
+
+
+class _Setter:
+    """monkeypatch.setitem stand-in for processes that install the double for their whole lifetime (rank workers of the eval test)."""
+
+    @staticmethod
+    def setitem(mapping, key, value):
+        mapping[key] = value
+
+
+def install_global(template_outcomes=None):
+    return install(_Setter, template_outcomes)
 
 
 def install(monkeypatch, template_outcomes=None):

@@ -97,3 +97,47 @@ def test_main_eval_cli_and_adapter_merge(tmp_path):
     a = t["base_model.model.model.layers.1.self_attn.v_proj.lora_A.weight"]
     b = t["base_model.model.model.layers.1.self_attn.v_proj.lora_B.weight"]
     torch.testing.assert_close(m.model.layers[1].self_attn.v_proj.weight.detach(), w0 + 2.0 * (b @ a), rtol=1e-5, atol=1e-6)
+
+
+def test_main_eval_two_ranks_with_the_chemistry_double(tmp_path):
+    """`main.py eval` under TWO ranks (shared GPU, gloo; prompt batches claimed from the WorkQueue, records gathered on every rank) with the
+    rdkit / rdchiral double installed in the rank processes: unlike the single-rank test above nothing of the product is monkeypatched --
+    graph_to_smiles (valence repair, fragment joins), check_valid, smiles_to_graph and the template merge run as shipped."""
+    import socket
+    import subprocess
+    import sys
+    from llamole_amd import synth
+    from llamole_amd.modeling_llamole import SPECIAL_TOKENS
+    from tests import fake_rdkit
+    cfg = synth.write_eval_fixture(str(tmp_path), SPECIAL_TOKENS)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LLAMOLE_BENCH_SHARED_GPU="1", LLAMOLE_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "eval_rank_worker.py"), cfg], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-2000:] for o in outs)
+    line = [l for l in outs[0][0].splitlines() if l.startswith("EVAL_STATS ")][-1]
+    summary = json.loads(line[len("EVAL_STATS "):])
+    assert summary["n_results"] == 5                                   # rank 0 holds the gathered records of both ranks
+    assert summary["chemistry"]["graphs"] >= 1                         # rank 0's share of the generated graphs went through the real graph_to_smiles
+    saved = json.load(open(os.path.join(str(tmp_path), "out", "molqa_results.json")))
+    assert [r["qa_idx"] for r in saved] == [0, 1, 2, 3, 4]
+    n_mol = 0
+    for r in saved:
+        assert set(r) == RECORD_FIELDS
+        if r["llm_smiles"]:                                            # a molecule of the double's notation that parses back and is sane
+            mol = fake_rdkit.MolFromSmiles(r["llm_smiles"])
+            assert mol is not None and mol.GetNumAtoms() >= 1 and "." not in r["llm_smiles"]
+            fake_rdkit.SanitizeMol(mol)
+            n_mol += 1
+        for rx in r["llm_reactions"]:
+            assert set(rx) == {"reaction", "template", "cost"} and ">>" in rx["reaction"]
+    assert n_mol == 5, [r["llm_smiles"] for r in saved]
+    assert any(r["llm_reactions"] for r in saved) or all(isinstance(r["response_retro"], str) for r in saved)
