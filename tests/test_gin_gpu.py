@@ -447,3 +447,26 @@ def test_gin_large_batch_vs_oracle():
     got_p = pred(x.cuda(), ei.cuda(), ea.cuda(), batch.cuda(), c.cuda()).cpu()
     np.testing.assert_allclose(got_e.numpy(), ref_e.numpy(), rtol=2e-3, atol=5e-4)
     np.testing.assert_allclose(got_p.numpy(), ref_p.numpy(), rtol=3e-3, atol=2e-3)
+
+
+def test_estimate_cost_from_smiles_with_the_chemistry_double(monkeypatch):
+    """GraphPredictor.estimate_cost (reference graph_predictor/model.py:230-236, 374-391): SMILES -> Morgan bit vector (rdkit: the test double
+    here) -> CostMLP on the device, and the `molecule_cost_weight` term of the A* value estimate that calls it."""
+    import tempfile
+    from tests import fake_rdkit
+    fake_rdkit.install(monkeypatch)
+    m = _predictor("gin_l3_h64")
+    d = tempfile.mkdtemp()
+    w = synth.make_cost_weights(0)
+    torch.save(w, os.path.join(d, "cost_model.pt"))
+    with pytest.raises(ValueError, match="not initialized"):
+        m.estimate_cost("C;C|0-1:1")
+    m.init_neural_cost(d)
+    smiles = "C;C;O;N|0-1:1,1-2:2,1-3:1"
+    got = m.estimate_cost(smiles)
+    fp = torch.from_numpy(m.smiles_to_fp(smiles).astype(np.float32))
+    hid = torch.relu(w["layers.0.weight"].float() @ fp + w["layers.0.bias"].float())
+    ref = float(torch.nn.functional.softplus(w["layers.3.weight"].float() @ hid + w["layers.3.bias"].float()))
+    assert abs(got - ref) <= 1e-4 * max(1.0, abs(ref))
+    with pytest.raises(ValueError, match="Invalid SMILES"):
+        m.estimate_cost("???")
