@@ -14,7 +14,7 @@ code runs under ``gloo`` on CPU tensors, which is how it is tested without GPUs.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
