@@ -785,7 +785,11 @@ def main():
                    "denoiser": {"hidden": args.hidden, "depth": args.depth, "heads": args.heads, "max_nodes": N,
                                 "T": T, "guide_scale": args.guide},
                    "dit_mlp_kernels": (m.mlp_choice() if hasattr(m, "mlp_choice") and args.dtype == "bf16" else None),
-                   "dit_launch": ("launches" if args.no_graph else "graph" if args.graph else "auto (launches alone, graph replay when overlapped with the LLM)"), **e2e_info},
+                   "dit_launch": ("launches" if args.no_graph else "graph" if args.graph else "auto (launches alone, graph replay when overlapped with the LLM)"),
+                   "dit_kernels_under_overlap": ("inside the pipelined region the trajectory runs in overlap mode: <= 64-row panels on the LDS-DMA ring instead of "
+                                                 "gemm_m64_kernel, q|k|v projection + attention as one launch, hipGraph replay (denoise_step_ms_overlapped_with_llm); "
+                                                 "dit_mlp_kernels / denoise_step_ms / step_roofline / roofline_graphdit describe one trajectory on an idle GPU")
+                   if piped else None, **e2e_info},
         "denoise_steps_per_s": world * 1e3 / step_ms,
         "denoise_step_ms": step_ms,
         "denoise_step_ms_overlapped_with_llm": step_ms_overlapped,
