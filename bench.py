@@ -730,8 +730,14 @@ def main():
     dt = time.perf_counter() - t0
     assert len(done) == args.steps * nb * B, (len(done), args.steps, nb, B)
     gathered_n = len(done[-nb * B:])
+    rank_times = [dt]
     if dist is not None:
-        tmax = torch.tensor([dt], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        tdev = device if dist.get_backend() == "nccl" else "cpu"
+        mine = torch.tensor([dt], device=tdev, dtype=torch.float64)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                      # per-rank wall times of the timed region: the imbalance a scaling run would hide
+        rank_times = [float(t.item()) for t in every]
+        tmax = mine.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         # the path's only exchange: ONE all-gather of the generated integer graphs of a step (fixed-size records)
@@ -798,6 +804,7 @@ def main():
                           "mfma_frac": sflops / (step_ms * 1e-3) / (MFMA_BF16_PEAK_TF * 1e12)},
         "roofline": roof,
         "roofline_graphdit": roof_dit,
+        "rank_seconds": [round(t, 4) for t in rank_times],
     }
     if not args.no_cpu_baseline and world == 1:
         log("cpu baseline ...")

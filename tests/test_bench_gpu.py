@@ -40,7 +40,7 @@ def test_bench_gpus_2_starts_two_ranks():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and len(d["rank_seconds"]) == 2 and max(d["rank_seconds"]) * 1e3 / d["steps"] == pytest.approx(d["ms_per_step"], rel=5e-2)
     assert d["config"]["gathered_molecules"] == 2 * 3 and d["config"]["prompts_per_step"] == 6
     assert d["value"] > 0 and "roofline" in d
 
