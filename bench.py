@@ -458,7 +458,7 @@ def run_retro(args, ctx):
     for i in range(args.warmup):
         step_fn(i)
     _barrier(ctx)
-    step_fn.count.update(expansions=0, value_estimates=0)
+    step_fn.count.update(expansions=0, value_estimates=0, value_calls=0)
     t0 = time.perf_counter()
     recs, design_s, retro_s, value_s = [], 0.0, 0.0, 0.0
     for i in range(args.steps):
@@ -498,8 +498,12 @@ def run_retro(args, ctx):
            "expansions_per_s": n_exp / dt, "expansions": n_exp, "value_estimates_per_expansion": n_val / max(1, n_exp),
            "design_share_of_step": design_s / max(1e-9, design_s + retro_s),
            "value_forward_share_of_step": value_s / max(1e-9, design_s + retro_s),
-           "value_forward_note": "A* value estimates: one left-padded LLM prefill per 256 new tree nodes (~100 nodes per expansion, ~130 tokens each) -- "
-                                 "stock HF forward on PyTorch-ROCm / hipBLASLt at M ~ 33 k rows, compute-bound; the reference runs one forward per node",
+           "value_prompts_per_call": n_val * 1.0 / max(1, step_fn.count["value_calls"] * ctx.world),
+           "value_prompt_opening_tokens": info["timing_breakdown"].get("value_prompt_opening_tokens", 0),
+           "value_forward_note": "A* value estimates: the new tree nodes of ALL searches of a round in one call (~100 nodes per expansion, ~140 tokens "
+                                 "each), one left-padded LLM prefill per %d prompts, the tokens every prompt opens with forwarded once per call -- stock "
+                                 "HF forward on PyTorch-ROCm / hipBLASLt at M ~ 100 k rows, compute-bound (~1.05 PFLOP/s over the decoder stack); the "
+                                 "reference runs one forward per node" % orch.value_batch,
            "routes_found": int(gathered[:, 0].sum().item()),
            "roofline": roof}
     if not args.no_cpu_baseline and ctx.world == 1:

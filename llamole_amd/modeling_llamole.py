@@ -538,16 +538,47 @@ class GraphLLMForCausalMLM(nn.Module):
         return cost
 
     # prompts per LLM forward of estimate_synthesis_complexity_batch (env LLAMOLE_VALUE_BATCH overrides).  Measured on the retro workload
-    # (Qwen2-7B, ~130-token prompts, ~1 600 prompts per expansion round): 64 -> 21.4 s per step, 256 -> 18.6 s, 512 -> 18.6 s -- the prefill
-    # GEMMs of stock HF / hipBLASLt want M >= ~32 k rows; 256 prompts x 130 tokens x 18 944 x 2 B = 1.3 GB of MLP activations
-    value_batch = 256
+    # (bench.py --workload retro: Qwen2-7B, ~140-token prompts, ~1 300 prompts per call = the new tree nodes of all 16 lock-step searches
+    # of a round): 256 -> 14.14 s per step, 512 -> 13.75 s, 1024 -> 13.52 s -- the prefill GEMMs of stock HF / hipBLASLt want M >= ~100 k
+    # rows; 1024 prompts x 120 tokens x 18 944 x 2 B = 4.7 GB per MLP activation
+    value_batch = 1024
+    # Every value prompt opens with the same tokens (chat-template header + "Estimate remaining steps for the target"): their keys / values
+    # are computed ONCE per call and every row's forward covers only its own remainder (causal attention: a token's state depends on
+    # nothing after it, so each row still computes what its own full forward computes).  Used when the shared opening has at least this
+    # many tokens; 0 / env LLAMOLE_VALUE_PREFIX=0 = every prompt forwarded whole.
+    value_prefix_min = 8
+
+    @staticmethod
+    def _shared_opening(rows) -> int:
+        """Number of leading tokens common to all rows, leaving every row at least one token of its own."""
+        lo, hi = min(rows), max(rows)           # lexicographic extremes: their common prefix is the common prefix of all rows
+        p = 0
+        for a, b in zip(lo, hi):
+            if a != b:
+                break
+            p += 1
+        return max(0, min(p, min(len(r) for r in rows) - 1))
+
+    def _opening_cache(self, opening):
+        """Per-layer (keys, values) of ONE forward over the shared opening tokens, or None when the LM has no KV-cache interface."""
+        ids = torch.tensor([opening], dtype=torch.long, device=self.device)
+        try:
+            out = self.language_model(input_ids=ids, attention_mask=torch.ones_like(ids), use_cache=True, logits_to_keep=1)
+        except TypeError:
+            return None
+        pkv = getattr(out, "past_key_values", None)
+        layers = getattr(pkv, "layers", None)
+        if not layers or any(getattr(l, "keys", None) is None or getattr(l, "sliding_window", None) for l in layers):
+            return None
+        return [(l.keys, l.values) for l in layers]
 
     @torch.no_grad()
     def estimate_synthesis_complexity_batch(self, items, input_ids=None, molecule_cost_weight=0, language_cost_weight=1,
                                             max_batch: Optional[int] = None) -> List[float]:
         """``estimate_synthesis_complexity`` for many ``(smiles, reaction)`` pairs with ONE LLM forward per ``max_batch``
         prompts instead of one per new tree node: prompts are left-padded, padding is masked and position
-        ids count real tokens only, so every row computes exactly what its own unpadded forward computes."""
+        ids count real tokens only, so every row computes exactly what its own unpadded forward computes; the tokens all
+        prompts open with go through the LLM once per call (``value_prefix_min``)."""
         n = len(items)
         costs = [0.0] * n
         if n == 0:
@@ -567,26 +598,41 @@ class GraphLLMForCausalMLM(nn.Module):
                 add_generation_prompt=True)) for smiles, reaction in items]
             pad = getattr(self.tokenizer, "pad_token_id", None)
             pad = self.tokenizer.eos_token_id if pad is None else pad
+            pmin = int(os.environ.get("LLAMOLE_VALUE_PREFIX", self.value_prefix_min))
+            P = self._shared_opening(rows) if (pmin > 0 and n > 1) else 0
+            opening = self._opening_cache(rows[0][:P]) if P >= max(pmin, 1) else None
+            if opening is None:
+                P = 0
+            self.last_value_opening = P           # tokens per prompt served from the shared keys / values (0 = whole prompts forwarded)
             # prompts of similar length share a forward (less padding; every row still computes exactly its own unpadded forward), and
             # the host never waits between forwards: the per-chunk costs stay on the device until all chunks are enqueued
             order = sorted(range(n), key=lambda i: len(rows[i]))
             pending = []
             for lo in range(0, n, max_batch):
                 sel = order[lo:lo + max_batch]
-                chunk = [rows[i] for i in sel]
+                chunk = [rows[i][P:] for i in sel]
                 L = max(len(r) for r in chunk)
                 ids = torch.full((len(chunk), L), pad, dtype=torch.long)
-                mask = torch.zeros((len(chunk), L), dtype=torch.long)
+                mask = torch.zeros((len(chunk), P + L), dtype=torch.long)
+                mask[:, :P] = 1
                 for j, r in enumerate(chunk):
                     ids[j, L - len(r):] = torch.tensor(r, dtype=torch.long)
-                    mask[j, L - len(r):] = 1
+                    mask[j, P + L - len(r):] = 1
                 ids, mask = ids.to(self.device, non_blocking=True), mask.to(self.device, non_blocking=True)
-                posid = (mask.cumsum(dim=1) - 1).clamp_min(0)
+                posid = (mask.cumsum(dim=1) - 1).clamp_min(0)[:, P:]
                 kw = dict(input_ids=ids, attention_mask=mask, position_ids=posid)
-                try:      # only the last position's logits are read: no [B, L, vocab] product, no KV cache
-                    logits = self.language_model(logits_to_keep=1, use_cache=False, **kw).logits[:, -1, :]
-                except TypeError:
-                    logits = self.language_model(**kw).logits[:, -1, :]
+                if opening is not None:      # [opening keys/values | padding | the row's own tokens]: padding masked, positions count real tokens
+                    from transformers import DynamicCache
+                    B = len(chunk)
+                    cache = DynamicCache(ddp_cache_data=[(k.expand(B, -1, -1, -1), v.expand(B, -1, -1, -1)) for k, v in opening])
+                    logits = self.language_model(logits_to_keep=1, use_cache=True, past_key_values=cache,
+                                                 cache_position=torch.arange(P, P + L, device=self.device), **kw).logits[:, -1, :]
+                    del cache
+                else:
+                    try:      # only the last position's logits are read: no [B, L, vocab] product, no KV cache
+                        logits = self.language_model(logits_to_keep=1, use_cache=False, **kw).logits[:, -1, :]
+                    except TypeError:
+                        logits = self.language_model(**kw).logits[:, -1, :]
                 pending.append((sel, self._cost_from_logits(logits, answer_tokens) * language_cost_weight))
             for sel, c in pending:
                 for i, v in zip(sel, c.tolist()):

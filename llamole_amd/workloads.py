@@ -93,7 +93,7 @@ def build_retro_step(args, graph_decoder, device, rank: int):
     props, _, _ = synth.make_dit_inputs(T, seed=rank, max_node=graph_decoder.max_n_nodes)
     n_nodes = torch.full((T,), graph_decoder.max_n_nodes, dtype=torch.int64)
     last = {}
-    count = {"expansions": 0, "value_estimates": 0}
+    count = {"expansions": 0, "value_estimates": 0, "value_calls": 0}
     expand, values = orch.one_step_reaction_batch, orch.estimate_synthesis_complexity_batch
 
     spans = []      # (start, end) HIP events around every value-estimate call: their GPU time is read after the step's synchronisation
@@ -104,6 +104,7 @@ def build_retro_step(args, graph_decoder, device, rank: int):
 
     def counted_values(items, *a, **k):
         count["value_estimates"] += len(items)
+        count["value_calls"] += 1
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = values(items, *a, **k)
@@ -127,7 +128,8 @@ def build_retro_step(args, graph_decoder, device, rank: int):
             rec[j] = torch.tensor([float(bool(r["success"])), float(r["route_length"] or 0), float(r["cost"] or 0.0)])
         value_s = sum(a.elapsed_time(b) for a, b in spans) * 1e-3
         del spans[:]
-        last.update(design_s=t1 - t0, retro_s=t2 - t1, value_forward_s=value_s)
+        last.update(design_s=t1 - t0, retro_s=t2 - t1, value_forward_s=value_s,
+                    value_prompt_opening_tokens=getattr(orch, "last_value_opening", 0))
         return mols, rec
 
     step_fn.count = count
@@ -140,7 +142,9 @@ def build_retro_step(args, graph_decoder, device, rank: int):
                       "(reference: searches one after the other, one LLM forward per new tree node)",
             "value_estimates": ("constant-cost shortcut (opt-in): the reference-compatible language cost is 15 for every molecule, returned without the "
                                 "LLM forward" if orch.constant_language_cost_shortcut else
-                                f"one left-padded LLM prefill per {orch.value_batch} new tree nodes, every forward executed (the reference: one forward per node)"),
+                                f"one left-padded LLM prefill per {orch.value_batch} new tree nodes, every forward executed (the reference: one forward per node); "
+                                "the tokens every prompt opens with (timing_breakdown.value_prompt_opening_tokens) are forwarded once per call and "
+                                "enter every row as cached keys / values"),
             "llm_acceleration": accel, "timing_breakdown": last}
     return step_fn, info, orch, llm, sd_pred
 

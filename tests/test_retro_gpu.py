@@ -86,3 +86,33 @@ def test_lock_step_retrosynthesis_batch16_depth5():
                 assert p in made
                 made |= set(rs.split("."))
     assert n_ok >= 1
+
+
+def test_value_estimates_shared_opening_vs_whole_prompts_bf16():
+    """The A* value prompts all open with the same tokens; their keys / values are computed once per call and every row's forward covers
+    only its remainder (modeling_llamole.estimate_synthesis_complexity_batch).  bf16 on the device, the intended expectation (where the
+    logits matter): shared-opening == whole prompts == one forward per node (the reference's structure, modeling_llamole.py:891-993)
+    within bf16 rounding of the logits; stated tolerance 2e-2 on costs in [0, 7]."""
+    import numpy as np
+    from llamole_amd import e2e
+    from llamole_amd.planner import ReactionView
+    dev = torch.device("cuda")
+    llm = e2e.build_llm("tiny", dev, torch.bfloat16)
+    orch, tok = e2e.build_orchestrator(llm, types.SimpleNamespace(text_input_size=768, check_valid=lambda s: True), dev)
+    orch.expected_cost_value = True
+    items = []
+    for i in range(70):
+        smi = "C" * (1 + i % 17) + "N" * (i % 5) + f"c{i}"
+        items.append((smi, None if i % 7 == 0 else ReactionView(1 + i % 4, f"[C:{i}]>>[C:{i}]O" * (1 + i % 3), ["CC" * (1 + i % 6), f"N{i}"])))
+    single = [orch.estimate_synthesis_complexity(s, None, r, 0, 1) for s, r in items]
+    assert max(single) - min(single) > 1e-3
+    shared = orch.estimate_synthesis_complexity_batch(items, None, 0, 1, max_batch=32)
+    assert orch.last_value_opening >= 8
+    orch.value_prefix_min = 0
+    whole = orch.estimate_synthesis_complexity_batch(items, None, 0, 1, max_batch=32)
+    assert orch.last_value_opening == 0
+    d_sw = float(np.abs(np.array(shared) - np.array(whole)).max())
+    d_s1 = float(np.abs(np.array(shared) - np.array(single)).max())
+    d_w1 = float(np.abs(np.array(whole) - np.array(single)).max())
+    print(f"value estimates, bf16 tiny Qwen2: |shared - whole| {d_sw:.2e}, |shared - single| {d_s1:.2e}, |whole - single| {d_w1:.2e}")
+    assert max(d_sw, d_s1, d_w1) < 2e-2

@@ -18,14 +18,18 @@ orch, tok = e2e.build_orchestrator(llm, types.SimpleNamespace(text_input_size=76
 orch.enable_mi355x_decode()
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 items = [(f"M{i}", ReactionView(2, f"T{i * 7}", [f"M{i}", f"M{i + 500}"])) for i in range(n)]
-for _ in range(2):
-    orch.estimate_synthesis_complexity_batch(items, None, 0, 1)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(3):
-    out = orch.estimate_synthesis_complexity_batch(items, None, 0, 1)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 3
 L = len(tok.encode(tok.apply_chat_template([{"role": "user", "content": orch._complexity_prompt(*items[0])}], tokenize=False, add_generation_prompt=True)))
 params = sum(p.numel() for n_, p in llm.named_parameters() if "embed_tokens" not in n_ and "lm_head" not in n_)
-print(f"{n} prompts x {L} tokens: {dt * 1e3:.1f} ms per call, {2 * params * n * L / dt / 1e12:.0f} TFLOP/s over the decoder stack, values {out[:2]}")
+for pmin in (type(orch).value_prefix_min, 0):      # the prompts' shared opening served from one set of keys / values | every prompt forwarded whole
+    orch.value_prefix_min = pmin
+    for _ in range(2):
+        orch.estimate_synthesis_complexity_batch(items, None, 0, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        out = orch.estimate_synthesis_complexity_batch(items, None, 0, 1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    P = orch.last_value_opening
+    print(f"{n} prompts x {L} tokens, {P} opening tokens shared: {dt * 1e3:.1f} ms per call, "
+          f"{2 * params * n * (L - P) / dt / 1e12:.0f} TFLOP/s over the decoder stack, values {out[:2]}")
