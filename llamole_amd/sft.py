@@ -99,6 +99,38 @@ def sft_step(model, batch: Dict[str, Any], optimizer=None, bucket_bytes: int = 6
     return log
 
 
+class _LoRAFunction(torch.autograd.Function):
+    """``y = x W^T + b + scale * (x A^T) B^T`` with the rank-r terms folded into GEMM epilogues: the forward adds the adapter term
+    to the base product in place (``addmm_``), the reverse sweep does the same for ``dx``.  Written op by op (`base(x) + (x A^T) B^T *
+    scale`) every wrapped projection pays four extra elementwise passes over [rows, N] / [rows, K] activations per step -- at 6 x 2048
+    tokens through 224 Mistral-7B projections that was ~11 % of the SFT step (profiles/r3_sft_op_by_op_lora_kernel_stats.csv: bf16 add / scalar-mul
+    kernels).  One rounding to bf16 instead of three: not further from the f32 result than the op-by-op form."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, a, b, scale):
+        x2 = x.reshape(-1, x.shape[-1])
+        xa = x2 @ a.t()                                   # [rows, r]
+        y = torch.nn.functional.linear(x2, w, bias)       # [rows, N]
+        y.addmm_(xa, b.t(), alpha=scale)
+        ctx.save_for_backward(x2, xa, w, a, b)
+        ctx.scale, ctx.x_shape = scale, x.shape
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, xa, w, a, b = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        ga = (g2 @ b) * ctx.scale                         # [rows, r]
+        db = (g2.t() @ xa) * ctx.scale                    # [N, r]
+        da = ga.t() @ x2                                  # [r, K]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = g2 @ w
+            dx.addmm_(ga, a)
+            dx = dx.view(ctx.x_shape)
+        return dx, None, None, da, db, None
+
+
 class LoRALinear(torch.nn.Module):
     """``y = W x + b + (alpha / r) * B(A x)`` around a frozen ``nn.Linear`` (Hu et al. 2021) -- the adapter form Llamole's
     SFT trains (reference YAMLs: finetuning_type lora, lora_target all); ``peft`` is not in this image, and the decode-time
@@ -115,6 +147,8 @@ class LoRALinear(torch.nn.Module):
         self.scale = alpha / r
 
     def forward(self, x):
+        if torch.is_grad_enabled() and x.dtype == self.base.weight.dtype and not torch.is_autocast_enabled():
+            return _LoRAFunction.apply(x, self.base.weight, self.base.bias, self.lora_a, self.lora_b, self.scale)
         return self.base(x) + (x @ self.lora_a.t()) @ self.lora_b.t() * self.scale
 
     def merged_weight(self) -> torch.Tensor:
