@@ -5,6 +5,8 @@ cd "$root"
 bash tools/profile_bench.sh r3_e2e_b1 --no-pipeline --steps 2 --warmup 1 > /dev/null 2>&1
 bash tools/profile_bench.sh r3_graphdit_b1 --workload graphdit --batch 1 --steps 3 --warmup 1 > /dev/null 2>&1
 bash tools/profile_bench.sh r3_graphdit_b8 --workload graphdit --steps 3 --warmup 1 > /dev/null 2>&1
+bash tools/profile_bench.sh r3_sft --workload sft --steps 3 --warmup 1 > /dev/null 2>&1
+bash tools/value_forward_profile.sh > "$out/r3_value_forward_probe.txt" 2>&1
 python bench.py 2>/dev/null | grep '^{' > "$out/r3_bench_e2e.json"
 python bench.py --no-pipeline --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{' > "$out/r3_bench_e2e_nopipeline.json"
 python bench.py --workload graphdit --steps 3 --warmup 1 2>/dev/null | grep '^{' > "$out/r3_bench_graphdit_b8.json"

@@ -20,7 +20,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 items = [(f"M{i}", ReactionView(2, f"T{i * 7}", [f"M{i}", f"M{i + 500}"])) for i in range(n)]
 L = len(tok.encode(tok.apply_chat_template([{"role": "user", "content": orch._complexity_prompt(*items[0])}], tokenize=False, add_generation_prompt=True)))
 params = sum(p.numel() for n_, p in llm.named_parameters() if "embed_tokens" not in n_ and "lm_head" not in n_)
-for pmin in (type(orch).value_prefix_min, 0):      # the prompts' shared opening served from one set of keys / values | every prompt forwarded whole
+only_default = len(sys.argv) > 3 and sys.argv[3] == "default"      # under the profiler: the product's configuration alone
+for pmin in ((type(orch).value_prefix_min,) if only_default else (type(orch).value_prefix_min, 0)):      # the prompts' shared opening served from one set of keys / values | every prompt forwarded whole
     orch.value_prefix_min = pmin
     for _ in range(2):
         orch.estimate_synthesis_complexity_batch(items, None, 0, 1)
