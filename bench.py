@@ -449,6 +449,18 @@ def time_template_head(args, graphs: int):
     return roof
 
 
+def value_forward_mfma(llm, tokens: int, seconds: float):
+    """The A* value forwards of the timed steps against the dense bf16 MFMA peak: 2 x (decoder-stack parameters) x (tokens forwarded) flops
+    over the HIP-event time of the calls (host tokenisation between their launches included) -- the step's dominant cost, vendor GEMMs
+    under the stock HF forward, reported next to the hand-written kernel's `roofline`."""
+    if not tokens or seconds <= 0:
+        return None
+    params = sum(p.numel() for n, p in llm.named_parameters() if "embed_tokens" not in n and "lm_head" not in n)
+    tf = 2.0 * params * tokens / seconds / 1e12
+    return {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0, "tokens": int(tokens),
+            "kernel": "hipBLASLt MT256x256x64 GEMMs under the stock HF prefill (77 % of the forward, profiles/r3_value_forward_kernel_stats.csv)"}
+
+
 def run_retro(args, ctx):
     """BASELINE.json configs[2]: design + lock-step A* retrosynthesis for `targets` prompts per GPU (llamole_amd/workloads.py)."""
     from llamole_amd.workloads import build_retro_step
@@ -460,7 +472,7 @@ def run_retro(args, ctx):
     _barrier(ctx)
     step_fn.count.update(expansions=0, value_estimates=0, value_calls=0)
     t0 = time.perf_counter()
-    recs, design_s, retro_s, value_s = [], 0.0, 0.0, 0.0
+    recs, design_s, retro_s, value_s, value_tokens = [], 0.0, 0.0, 0.0, 0
     for i in range(args.steps):
         _maybe_fail(ctx.rank, i)
         mols, rec = step_fn(args.warmup + i)
@@ -468,6 +480,7 @@ def run_retro(args, ctx):
         design_s += info["timing_breakdown"]["design_s"]
         retro_s += info["timing_breakdown"]["retro_s"]
         value_s += info["timing_breakdown"]["value_forward_s"]
+        value_tokens += info["timing_breakdown"].get("value_tokens", 0)
     _barrier(ctx)
     dt = _max_over_ranks(ctx, time.perf_counter() - t0)
     n_exp, n_val = step_fn.count["expansions"], step_fn.count["value_estimates"]
@@ -498,6 +511,7 @@ def run_retro(args, ctx):
            "expansions_per_s": n_exp / dt, "expansions": n_exp, "value_estimates_per_expansion": n_val / max(1, n_exp),
            "design_share_of_step": design_s / max(1e-9, design_s + retro_s),
            "value_forward_share_of_step": value_s / max(1e-9, design_s + retro_s),
+           "value_forward_mfma": value_forward_mfma(llm, value_tokens, value_s),
            "value_prompts_per_call": n_val * 1.0 / max(1, step_fn.count["value_calls"] * ctx.world),
            "value_prompt_opening_tokens": info["timing_breakdown"].get("value_prompt_opening_tokens", 0),
            "value_forward_note": "A* value estimates: the new tree nodes of ALL searches of a round in one call (~100 nodes per expansion, ~140 tokens "

@@ -604,6 +604,7 @@ class GraphLLMForCausalMLM(nn.Module):
             if opening is None:
                 P = 0
             self.last_value_opening = P           # tokens per prompt served from the shared keys / values (0 = whole prompts forwarded)
+            self.value_tokens_forwarded = getattr(self, "value_tokens_forwarded", 0) + sum(len(r) for r in rows) - (n - 1) * P
             # prompts of similar length share a forward (less padding; every row still computes exactly its own unpadded forward), and
             # the host never waits between forwards: the per-chunk costs stay on the device until all chunks are enqueued
             order = sorted(range(n), key=lambda i: len(rows[i]))

@@ -120,6 +120,7 @@ def build_retro_step(args, graph_decoder, device, rank: int):
         mols, _ = graph_decoder.generate_graphs(props, cond.float(), -200.0, n_nodes=n_nodes, seed=1000 * rank + i)
         t1 = time.perf_counter()
         targets = [f"TARGET{rank}_{i}_{j}" for j in range(T)]
+        orch.value_tokens_forwarded = 0
         routes = orch.retrosynthesize_many([None] * T, targets, **kw)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
@@ -128,7 +129,7 @@ def build_retro_step(args, graph_decoder, device, rank: int):
             rec[j] = torch.tensor([float(bool(r["success"])), float(r["route_length"] or 0), float(r["cost"] or 0.0)])
         value_s = sum(a.elapsed_time(b) for a, b in spans) * 1e-3
         del spans[:]
-        last.update(design_s=t1 - t0, retro_s=t2 - t1, value_forward_s=value_s,
+        last.update(design_s=t1 - t0, retro_s=t2 - t1, value_forward_s=value_s, value_tokens=getattr(orch, "value_tokens_forwarded", 0),
                     value_prompt_opening_tokens=getattr(orch, "last_value_opening", 0))
         return mols, rec
 

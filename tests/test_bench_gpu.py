@@ -101,11 +101,15 @@ def test_bench_retro_workload(gpus):
     assert d["config"]["prompts_per_step"] == 3 * gpus and d["config"]["gathered_routes"] == 3 * gpus
     assert d["expansions"] == 3 * 2 * gpus and d["expansions_per_s"] > 0           # every search runs its 2 expansions (nothing is purchasable)
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and "A* retrosynthesis" in d["config"]["workload"]
+    # the value forwards: all searches of a round in one call, the prompts' shared opening forwarded once, their rate against the MFMA peak
+    assert d["value_prompts_per_call"] > 3 and d["value_prompt_opening_tokens"] >= 8
+    assert d["value_forward_mfma"]["bound"] == "mfma" and 0 < d["value_forward_mfma"]["frac"] < 1 and d["value_forward_mfma"]["tokens"] > 0
 
 
 def test_bench_retro_constant_value_shortcut():
     d = _line(_run(["--retro-constant-value"] + RETRO_TINY, {}, workload="retro"))
     assert d["expansions"] == 3 * 2 and "shortcut" in d["config"]["value_estimates"] and d["value_forward_share_of_step"] < 0.2
+    assert d["value_forward_mfma"] is None                                          # no forward ran
 
 
 @pytest.mark.parametrize("gpus", [1, 2])
