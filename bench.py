@@ -526,6 +526,22 @@ def run_retro(args, ctx):
     return out
 
 
+def sft_llm_mfma(model, rows: int, seq: int, step_s: float):
+    """One rank's LLM forward + backward against the dense bf16 MFMA peak: frozen base weights need the forward product and the input-gradient
+    product (4 x parameters x tokens flops; no weight-gradient GEMMs, the rank-r LoRA terms are < 1 %), causal attention 4 x rows x heads x
+    seq^2 x head_dim / 2 forward and 2.5 x that in the reverse sweep, lm_head forward + input gradient -- over the WHOLE step time."""
+    llm = getattr(model, "language_model", model)
+    cfg = llm.config
+    stack = sum(p.numel() for n, p in llm.named_parameters() if "embed_tokens" not in n and "lm_head" not in n and "lora_" not in n)
+    tokens = rows * seq
+    head = cfg.vocab_size * cfg.hidden_size
+    attn = 4.0 * rows * cfg.num_attention_heads * seq * seq * (cfg.hidden_size // cfg.num_attention_heads) / 2 * cfg.num_hidden_layers
+    flops = 4.0 * (stack + head) * tokens + 3.5 * attn
+    tf = flops / step_s / 1e12
+    return {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0, "flops_per_step": flops,
+            "kernel": "hipBLASLt GEMMs + flash attention under the stock HF forward / backward (profiles/r3_sft_kernel_stats.csv)"}
+
+
 def run_sft(args, ctx):
     """BASELINE.json configs[4]: one SFT optimizer step per bench step, data-parallel over the ranks (llamole_amd/workloads.py)."""
     from llamole_amd.workloads import build_sft_step
@@ -560,6 +576,7 @@ def run_sft(args, ctx):
            "tokens_per_s": ctx.world * B * S * args.steps / dt, "graph_side_ms": graph_ms, "graph_side_share": graph_ms / (1e3 * dt / args.steps),
            "loss": logd["loss"], "lm_loss": logd.get("lm_loss"), "retro_loss": logd.get("retro_loss"),
            "max_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+           "llm_mfma": sft_llm_mfma(model, B, S, dt / args.steps),
            "roofline": roof}
     if not args.no_cpu_baseline and ctx.world == 1:
         log("cpu baseline ...")

@@ -118,6 +118,7 @@ def test_bench_sft_workload(gpus):
     assert d["n_gpus"] == gpus and d["unit"] == "samples/s" and d["value"] > 0
     assert d["config"]["global_batch"] == 2 * gpus and d["config"]["parallelism"] == f"dp{gpus}"
     assert d["loss"] == d["loss"] and d["retro_loss"] > 0 and d["graph_side_ms"] > 0 and d["roofline"]["frac"] > 0
+    assert d["llm_mfma"]["bound"] == "mfma" and 0 < d["llm_mfma"]["frac"] < 1
 
 
 def test_bench_under_torch_distributed_run():
