@@ -384,7 +384,9 @@ def gen_gin(name):
 
 # ----------------------------------------------------------------------------- planner goldens
 def gen_planner():
-    """Traces of the reference's molstar on scripted expansion tables (host logic, a20)."""
+    """Traces of the reference's molstar on scripted expansion tables (host logic, a20).  Run as
+    `PYTHONHASHSEED=1 python tests/golden/make_goldens.py planner`: the reference's set() de-duplication makes the "fail" case (a tie
+    between two open nodes) depend on the string hash order; every other case gives the same trace under any seed (planner_cases.py)."""
     import json
     sys.path.insert(0, REF)
     from planner.molstar import molstar
