@@ -60,8 +60,11 @@ class GraphSFTCollator:
         }
         if all("labels" in f for f in features):
             batch["labels"] = self._pad([f["labels"] for f in features], self.label_pad_token_id, L)
-        if "property" in features[0]:
-            batch["molecule_properties"] = torch.tensor([f["property"] for f in features], dtype=torch.float32)
+        # the reference's preprocessing emits "molecule_properties" (processors/mmsupervised.py:286-310), which its collator hands to
+        # tokenizer.pad as is; "property" is the raw dataset column (aligner.py:138), accepted as well
+        pkey = "molecule_properties" if "molecule_properties" in features[0] else ("property" if "property" in features[0] else None)
+        if pkey is not None:
+            batch["molecule_properties"] = torch.tensor([f[pkey] for f in features], dtype=torch.float32)
         batch["molecule_graphs"] = GraphBatch.from_data_list(mol_graphs) if mol_graphs else None
         batch["design_graphs"] = GraphBatch.from_data_list(design_graphs) if design_graphs else None
         batch["retro_product_graphs"] = GraphBatch.from_data_list(retro_graphs) if retro_graphs else None

@@ -332,3 +332,39 @@ def jsonable(o):
     if isinstance(o, float) and o != o:
         return "nan"
     return o
+
+
+# ---- SFT collator (reference src/data/collator.py:31-166): ragged features in the form the reference's preprocessing
+# emits (processors/mmsupervised.py:262-312: input_ids, attention_mask, labels, molecule_ids, molecule_properties, retro_labels,
+# retro_product_ids), for both padding sides and with pad_to_multiple_of
+COLLATOR_MOLS = {3: "CCO", 5: "c1ccccc1", 8: "N", 11: "OCCN", 12: "CC(C)C"}
+
+
+def collator_scenarios():
+    f = lambda n, **k: dict(input_ids=list(range(10, 10 + n)), attention_mask=[1] * n, labels=[-100] * (n // 2) + list(range(50, 50 + n - n // 2)), **k)  # noqa: E731
+    props = lambda i: [float(i), -200.0, 0.5 * i] + [float("nan")] * 0 + [1.0] * 7      # noqa: E731
+    full = [f(7, molecule_ids=[3, 5], molecule_properties=props(1), retro_labels=[4, 9], retro_product_ids=[5, 11]),
+            f(12, molecule_ids=[8], molecule_properties=props(2), retro_labels=[2], retro_product_ids=[12]),
+            f(3, molecule_ids=[11, -100, 99, 12], molecule_properties=props(3), retro_labels=[7, 1, 0], retro_product_ids=[3, -100, 8]),
+            f(9, molecule_ids=[], molecule_properties=props(4), retro_labels=[], retro_product_ids=[])]
+    out = []
+    for side in ("right", "left"):
+        for mult in (None, 8):
+            out.append({"name": f"full_{side}_{mult}", "padding_side": side, "pad_to_multiple_of": mult, "features": full})
+    out.append({"name": "no_graph_keys", "padding_side": "right", "pad_to_multiple_of": None, "features": [f(4), f(6)]})
+    out.append({"name": "first_only", "padding_side": "left", "pad_to_multiple_of": None,
+                "features": [f(5, molecule_ids=[12, 3], retro_labels=[6], retro_product_ids=[5]), f(2)]})
+    return out
+
+
+def collator_record(batch):
+    """The fields both collators produce, as plain data."""
+    rec = {}
+    for k in ("input_ids", "attention_mask", "labels", "retro_labels", "molecule_properties"):
+        v = batch.get(k) if hasattr(batch, "get") else None
+        rec[k] = None if v is None else (v.tolist() if torch.is_tensor(v) else v)
+    for k in ("molecule_graphs", "design_graphs", "retro_product_graphs"):
+        g = batch.get(k) if hasattr(batch, "get") else None
+        rec[k] = None if g is None else {"x": g.x.tolist(), "edge_index": g.edge_index.tolist(), "edge_attr": g.edge_attr.tolist(),
+                                         "batch": g.batch.tolist(), "num_graphs": int(g.num_graphs)}
+    return rec

@@ -8,6 +8,7 @@ returned value and every argument handed to the fakes must agree: token rows, pr
 (incl. the forced max_new_tokens budgets), spliced-embedding checksums, the conditions given to GraphDiT and the predictor,
 costs, reaction routes, text lists, ignore positions.
 """
+import numpy as np
 import json
 import os
 import types
@@ -119,3 +120,28 @@ def test_generate(both, name):
         assert ours["generate"][name]["n_forward"] <= gold["generate"][name]["n_forward"]
         assert ours["generate"][name]["n_generate"] == gold["generate"][name]["n_generate"]
     assert ours["generate"]["neither"] == gold["generate"]["neither"] == "ValueError"
+
+
+def test_sft_collator_matches_reference_collator():
+    """sft.GraphSFTCollator against the reference's own DataCollatorForSeqGraph (src/data/collator.py:31-166) on ragged feature sets --
+    both padding sides, pad_to_multiple_of, -100 / unknown molecule ids, a row without molecules, rows without retro keys
+    (tests/golden/collator_traces.json, written by `make_host_goldens.py collator` from the imported reference)."""
+    from llamole_amd.graph_data import GraphData
+    from llamole_amd.sft import GraphSFTCollator
+    gold = json.load(open(os.path.join(GOLDEN_DIR, "collator_traces.json")))
+    table = {k: hf.fake_smiles_to_graph(GraphData)(v) for k, v in hf.COLLATOR_MOLS.items()}
+    seen = 0
+    for sc in hf.collator_scenarios():
+        coll = GraphSFTCollator(0, table, label_pad_token_id=-100, padding_side=sc["padding_side"], pad_to_multiple_of=sc["pad_to_multiple_of"])
+        g = gold[sc["name"]]
+        if "raises" in g:      # the reference cannot build retro_labels when no row has any (torch.tensor(None)): ours returns None there
+            assert g["raises"] == "TypeError" and coll([dict(f) for f in sc["features"]])["retro_labels"] is None
+            continue
+        rec = hf.jsonable(hf.collator_record(coll([dict(f) for f in sc["features"]])))
+        for k, v in g.items():
+            if k == "molecule_properties" and v is not None:
+                np.testing.assert_allclose(np.array(rec[k], dtype=np.float64), np.array(v, dtype=np.float64), rtol=0, atol=0, err_msg=sc["name"])
+            else:
+                assert rec[k] == v, (sc["name"], k)
+        seen += 1
+    assert seen >= 5
