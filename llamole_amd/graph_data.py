@@ -49,6 +49,21 @@ class GraphBatch:
             off += n
         return out
 
+    def __len__(self):
+        return self.num_graphs
+
+    def __getitem__(self, idx):
+        """PyG's `Batch[idx]`: an int gives one graph, an index tensor / list / slice the list of selected graphs (the reference
+        indexes the retro product batch with the valid-label indices, modeling_llamole.py:396-399)."""
+        graphs = self.to_data_list()
+        if isinstance(idx, int):
+            return graphs[idx]
+        if isinstance(idx, slice):
+            return graphs[idx]
+        if torch.is_tensor(idx):
+            idx = idx.nonzero().view(-1).tolist() if idx.dtype == torch.bool else idx.view(-1).tolist()
+        return [graphs[int(i)] for i in idx]
+
     def to(self, device):
         self.x, self.edge_index = self.x.to(device), self.edge_index.to(device)
         self.edge_attr, self.batch = self.edge_attr.to(device), self.batch.to(device)

@@ -368,3 +368,85 @@ def collator_record(batch):
         rec[k] = None if g is None else {"x": g.x.tolist(), "edge_index": g.edge_index.tolist(), "edge_attr": g.edge_attr.tolist(),
                                          "batch": g.batch.tolist(), "num_graphs": int(g.num_graphs)}
     return rec
+
+
+# ---- SFT forward (reference modeling_llamole.py:299-437) on a REAL tiny HF causal LM with differentiable stand-ins for
+# the graph modules: what enters the loss, which hidden states feed the retro queries, what the connectors' gradients are
+class SFTPred(torch.nn.Module):
+    text_input_size, available = 768, None
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("W", torch.randn(7, 768, generator=torch.Generator().manual_seed(3)) * 0.05)
+
+    def forward(self, x, ei, ea, batch, c):
+        pooled = torch.stack([x[batch == g].float().sum() for g in range(int(batch.max()) + 1)])
+        return c.float() @ self.W.t() + 0.01 * pooled[:, None]
+
+
+class SFTEnc(torch.nn.Module):
+    hidden_size = 32
+
+    def forward(self, x, ei, ea, b):
+        return torch.stack([x[b == g].float().mean().repeat(32) for g in range(int(b.max()) + 1)]) * 0.01
+
+
+class SFTDec(torch.nn.Module):
+    """GraphDiT.forward stand-in: a loss that depends on its condition (the reference computes it and then drops it, :359-381, :421-425)."""
+    text_input_size = 768
+
+    def forward(self, x, ei, ea, batch, props, cond, no_label):
+        return cond.float().pow(2).mean() + 3.0
+
+
+def sft_forward_case(Data, Batch, token_ids, IGNORE_INDEX, NO_LABEL_INDEX):
+    g = torch.Generator().manual_seed(0)
+    B, L = 2, 40
+    ids = torch.randint(5, 1000, (B, L), generator=g)
+    ids[0, 3] = token_ids["<molecule>"]
+    ids[1, 5] = token_ids["<molecule>"]
+    for b, start in ((0, 10), (0, 25), (1, 12)):
+        ids[b, start] = token_ids["<retro_start>"]
+        ids[b, start + 1:start + 9] = token_ids["<retro_body>"]
+    ids[1, 24] = token_ids["<design_start>"]
+    ids[1, 25:33] = token_ids["<design_body>"]
+    labels = ids.clone()
+    labels[:, :4] = IGNORE_INDEX
+    retro_labels = torch.tensor([[4, NO_LABEL_INDEX], [2, IGNORE_INDEX]])
+    mk = lambda n, k: Data(x=torch.arange(n) % 9 + k, edge_index=torch.empty((2, 0), dtype=torch.long), edge_attr=torch.empty((0,), dtype=torch.long), num_nodes=n)  # noqa: E731
+    return dict(input_ids=ids, attention_mask=torch.ones_like(ids), labels=labels, molecule_graphs=Batch.from_data_list([mk(4, 1), mk(6, 2)]),
+                molecule_properties=torch.tensor([[1.0] * 10, [2.0] * 10]), design_graphs=Batch.from_data_list([mk(5, 2)]),
+                retro_labels=retro_labels, retro_product_graphs=Batch.from_data_list([mk(5, 3), mk(3, 1), mk(7, 2)]))
+
+
+def sft_connectors(hidden: int):
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    for name, (i, o) in (("graph_to_lm_connector", (32, hidden)), ("lm_to_graph_decoder", (hidden, 768)), ("lm_to_graph_predictor", (hidden, 768))):
+        lin = torch.nn.Linear(i, o)
+        with torch.no_grad():
+            lin.weight.copy_(torch.randn(o, i, generator=g) * 0.05)
+            lin.bias.copy_(torch.randn(o, generator=g) * 0.05)
+        out[name] = torch.nn.Sequential(lin, torch.nn.SiLU())
+    return out
+
+
+def sft_forward_record(model, batch):
+    """loss, logits digest and gradient norms of one forward + backward of `model` (reference or llamole_amd instance)."""
+    out = model(**batch)
+    loss = out.loss if hasattr(out, "loss") else out["loss"]
+    logits = out.logits if hasattr(out, "logits") else out["logits"]
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    grads = {n: float(p.grad.double().norm()) for n, p in model.named_parameters() if p.grad is not None and
+             (n.startswith(("graph_to_lm_connector", "lm_to_graph_decoder", "lm_to_graph_predictor")) or n.endswith(("layers.0.self_attn.q_proj.weight", "lm_head.weight")))}
+    return {"loss": float(loss.detach()), "logits_sum": float(logits.detach().double().sum()), "logits_abs": float(logits.detach().double().abs().sum()),
+            "grad_norms": {_llm_suffix(k): v for k, v in sorted(grads.items())}}
+
+
+def _llm_suffix(name: str) -> str:
+    """Parameter name without the wrapper prefixes that differ between the two instances (peft shape | plain HF model)."""
+    for key in ("layers.0.", "lm_head."):
+        if key in name:
+            return name[name.index(key):]
+    return name

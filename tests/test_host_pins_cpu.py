@@ -145,3 +145,33 @@ def test_sft_collator_matches_reference_collator():
                 assert rec[k] == v, (sc["name"], k)
         seen += 1
     assert seen >= 5
+
+
+def test_sft_forward_matches_reference_forward():
+    """GraphLLMForCausalMLM.forward against the reference's own forward (modeling_llamole.py:299-437) on a real tiny HF causal LM with
+    shared stand-in graph modules (tests/golden/sft_forward_traces.json, written by `make_host_goldens.py sft_forward`): total loss --
+    incl. the reference's double use of the retro loss and its dropped design loss --, logits, and the gradient norms reaching the LLM and
+    the connectors; with and without retro labels.  The design-loss forward the reference runs and discards is skipped here by default:
+    same loss, same gradients."""
+    from llamole_amd import e2e
+    from llamole_amd.graph_data import GraphBatch, GraphData
+    from llamole_amd.modeling_llamole import IGNORE_INDEX, NO_LABEL_INDEX, SPECIAL_TOKENS, GraphLLMForCausalMLM
+    gold = json.load(open(os.path.join(GOLDEN_DIR, "sft_forward_traces.json")))
+    for compute_design in (False, True):
+        llm = e2e.build_llm("tiny", "cpu", torch.float32, seed=5)
+        for p in llm.parameters():
+            p.requires_grad = True
+        tid = {t: 2000 + i for i, t in enumerate(SPECIAL_TOKENS)}
+        m = GraphLLMForCausalMLM(types.SimpleNamespace(), types.SimpleNamespace(loss_weight_lm=1.0, loss_weight_design=0.5, loss_weight_retro=2.0),
+                                 types.SimpleNamespace(learned_query_size=8), llm, hf.SFTDec(), hf.SFTPred(), hf.SFTEnc(), tid, hf.Tok())
+        m.compute_design_loss = compute_design
+        for k, v in hf.sft_connectors(llm.config.hidden_size).items():
+            setattr(m, k, v)
+        batch = hf.sft_forward_case(GraphData, GraphBatch, tid, IGNORE_INDEX, NO_LABEL_INDEX)
+        for name, b in (("with_retro", batch), ("lm_only", dict(batch, retro_labels=None, design_graphs=None))):
+            rec, g = hf.sft_forward_record(m, b), gold[name]
+            assert abs(rec["loss"] - g["loss"]) <= 1e-5 * abs(g["loss"]), (name, rec["loss"], g["loss"])
+            assert abs(rec["logits_sum"] - g["logits_sum"]) <= 1e-3 and abs(rec["logits_abs"] - g["logits_abs"]) <= 1e-5 * g["logits_abs"]
+            assert set(rec["grad_norms"]) == set(g["grad_norms"]), (name, sorted(rec["grad_norms"]), sorted(g["grad_norms"]))
+            for k, v in g["grad_norms"].items():
+                assert abs(rec["grad_norms"][k] - v) <= 1e-4 * max(v, 1e-6), (name, k, rec["grad_norms"][k], v)
