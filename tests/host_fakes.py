@@ -450,3 +450,12 @@ def _llm_suffix(name: str) -> str:
         if key in name:
             return name[name.index(key):]
     return name
+
+
+# ---- eval dataset rows (reference src/eval/dataset.py:26-78)
+MOLQA_RECORDS = [
+    {"instruction": "Design a polymer with high CO2 permeability.", "input": "It should contain an ether linkage.",
+     "property": {"CO2": 120.5, "O2": 33.0, "SA": 2.5}},
+    {"instruction": "Propose a drug-like molecule.", "input": "", "property": {"BBBP": 1.0, "HIV": 0.0, "BACE": 1.0, "SC": 3.25}},
+    {"instruction": "Make it " + "very " * 60 + "long.", "input": "Truncation applies to this row.", "property": {}},
+]

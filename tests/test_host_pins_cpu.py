@@ -175,3 +175,26 @@ def test_sft_forward_matches_reference_forward():
             assert set(rec["grad_norms"]) == set(g["grad_norms"]), (name, sorted(rec["grad_norms"]), sorted(g["grad_norms"]))
             for k, v in g["grad_norms"].items():
                 assert abs(rec["grad_norms"][k] - v) <= 1e-4 * max(v, 1e-6), (name, k, rec["grad_norms"][k], v)
+
+
+def test_eval_prompt_rows_match_reference_dataset(tmp_path):
+    """eval.encode_batch against the reference's own MolQADataset (src/eval/dataset.py:26-78) with the fixture tokenizer: chat-templated
+    prompt, left padding / truncation to cutoff_len, the 10-slot property row with NaN for absent properties
+    (tests/golden/molqa_dataset_traces.json, written by `make_host_goldens.py molqa_dataset`)."""
+    import math
+    from transformers import AutoTokenizer
+    from llamole_amd import synth
+    from llamole_amd.eval import encode_batch
+    from llamole_amd.modeling_llamole import SPECIAL_TOKENS
+    gold = json.load(open(os.path.join(GOLDEN_DIR, "molqa_dataset_traces.json")))
+    synth.write_llm_dir(str(tmp_path), SPECIAL_TOKENS)
+    tok = AutoTokenizer.from_pretrained(str(tmp_path), padding_side="left")
+    tok.pad_token = tok.eos_token
+    for max_len, rows in gold.items():
+        ids, mask, props = encode_batch(tok, hf.MOLQA_RECORDS, int(max_len))
+        assert ids.shape == (len(rows), int(max_len))
+        for i, r in enumerate(rows):
+            assert ids[i].tolist() == r["input_ids"] and mask[i].tolist() == r["attention_mask"], (max_len, i)
+            for a, b in zip(props[i].tolist(), r["property"]):
+                b_nan = b == "nan" or (isinstance(b, float) and math.isnan(b))
+                assert (math.isnan(a) and b_nan) or (not b_nan and a == pytest.approx(b, rel=1e-6)), (max_len, i, a, b)
