@@ -696,3 +696,50 @@ def test_gin_encoder_full_size_vs_oracle():
     _report("gin_encoder_full_size", rec)
     assert torch.allclose(got.norm(dim=1), torch.ones(G), atol=1e-2)
     assert cos >= 0.999 and err <= 2e-2, rec
+
+
+def test_gin_relabelling_and_batch_order_invariance_full_size():
+    """Size-independent properties of the message-passing stack at the reference's size (5 layers, hidden 512, bf16 engines; predictor with
+    the 180 576-template head): relabelling the atoms of every molecule (edges renamed with them) and reordering the molecules of the batch
+    leave each molecule's embedding / template logits where they were, up to the summation order of the add-aggregation and the pools
+    (reference graph_encoder/model.py:124-176: scatter-add messages, segment max / sum pools; PyG semantics).  48 ragged molecules."""
+    import torch.nn.functional as F
+    from llamole_amd.workloads import build_gin_pair
+    dev = torch.device("cuda")
+    G = 48
+    x, ei, ea, batch = synth.make_mol_graphs(G, 7, min_atoms=3, max_atoms=32)
+    enc, pred, _ = build_gin_pair(dev, 180576, templates=False)
+    c = torch.randn(G, 768, generator=torch.Generator().manual_seed(4))
+    gen = torch.Generator().manual_seed(9)
+    sizes = torch.bincount(batch, minlength=G).tolist()
+    offs = [0]
+    for s in sizes:
+        offs.append(offs[-1] + s)
+    # (1) new atom numbering inside every molecule; (2) new molecule order
+    order = torch.randperm(G, generator=gen).tolist()
+    new_of_old = torch.empty(x.shape[0], dtype=torch.long)
+    xs, bs, pos = [], [], 0
+    for new_g, g in enumerate(order):
+        perm = torch.randperm(sizes[g], generator=gen)                  # new local index -> old local index
+        xs.append(x[offs[g]:offs[g + 1]][perm])
+        new_of_old[offs[g] + perm] = pos + torch.arange(sizes[g])
+        bs.append(torch.full((sizes[g],), new_g, dtype=torch.long))
+        pos += sizes[g]
+    x2, b2 = torch.cat(xs), torch.cat(bs)
+    eperm = torch.randperm(ei.shape[1], generator=gen)                   # edge list order is free as well
+    ei2, ea2 = new_of_old[ei][:, eperm], ea[eperm]
+    with torch.no_grad():
+        e1 = enc(x.to(dev), ei.to(dev), ea.to(dev), batch.to(dev)).float().cpu()
+        e2 = enc(x2.to(dev), ei2.to(dev), ea2.to(dev), b2.to(dev)).float().cpu()
+        p1 = pred(x.to(dev), ei.to(dev), ea.to(dev), batch.to(dev), c.to(dev)).float().cpu()
+        p2 = pred(x2.to(dev), ei2.to(dev), ea2.to(dev), b2.to(dev), c[order].to(dev)).float().cpu()
+    e2b, p2b = torch.empty_like(e1), torch.empty_like(p1)
+    e2b[order], p2b[order] = e2, p2
+    scale = float(p1.abs().max())
+    rec = dict(embedding_max_abs=float((e1 - e2b).abs().max()), embedding_min_cosine=float(F.cosine_similarity(e1, e2b, dim=1).min()),
+               logits_max_abs_rel_to_scale=float((p1 - p2b).abs().max()) / scale,
+               top1_equal=int((p1.argmax(dim=1) == p2b.argmax(dim=1)).sum()), graphs=G)
+    print(f"GIN relabelling / batch order: {rec}")
+    _report("gin_relabelling_invariance", rec)
+    assert rec["embedding_min_cosine"] >= 0.9995 and rec["embedding_max_abs"] <= 1e-2, rec
+    assert rec["logits_max_abs_rel_to_scale"] <= 2e-2 and rec["top1_equal"] >= G - 1, rec
