@@ -119,7 +119,10 @@ struct DevBuf {
         p = nullptr;
         bytes = 0;
         LL_HIP(hipMalloc(&p, n));
-        LL_HIP(hipMemset(p, 0, n));
+        // zeros; LL_DEBUG_POISON=1 fills with 0xFF (NaN / -1) instead: a kernel that counts on the initial zeros -- and would therefore
+        // break once a larger earlier call has left other data behind -- fails the test suite at once
+        static const int fill = getenv("LL_DEBUG_POISON") ? 0xFF : 0;
+        LL_HIP(hipMemset(p, fill, n));
         bytes = n;
         return LL_OK;
     }

@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("LLAMOLE_FILL_UNINIT") == "1":
+        # hunt for reliance on what torch.empty happens to return: every uninitialised allocation is filled (NaN / the largest integer), so
+        # a kernel or wrapper that assumes zeros fails on the first run instead of once the caching allocator hands back used memory
+        import torch
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
 
 
 @pytest.fixture(scope="session")
