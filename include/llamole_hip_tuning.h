@@ -60,6 +60,13 @@ int ll_set_stage_mod(int on);
  * head dimension 64, two elsewhere; bit-identical); returns the previous value. */
 int ll_set_attn_waves(int waves);
 
+/* ll_debug_check_guards : with LL_DEBUG_POISON=1 in the environment the engines' device buffers carry 4 KB of guard bytes behind their
+ * payload; returns how many of the live buffers a kernel has written past the end of (0 = none; always 0 without the variable).
+ * Synchronises the device.  tests/conftest.py calls it after every GPU test in that mode. */
+int ll_debug_check_guards(void);
+/* ll_debug_guard_selftest : 1 = an overrun planted behind a scratch buffer was reported and nothing else was (-1 without LL_DEBUG_POISON). */
+int ll_debug_guard_selftest(void);
+
 /* ll_set_topk_single : 1 = one workgroup per row for any out_dim (the round-1 form); 0 (default) = rows longer than 4096 templates
  * are reduced by (out_dim / 4096) x rows workgroups to per-chunk candidates and merged by one workgroup per row -- same result
  * (set, order, ties to the lowest template index).  Returns the previous setting. */

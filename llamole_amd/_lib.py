@@ -88,6 +88,8 @@ SIGNATURES = {
     "ll_set_lnmod_multiwave": (_I, [_I]),
     "ll_set_stage_mod": (_I, [_I]),
     "ll_set_attn_waves": (_I, [_I]),
+    "ll_debug_check_guards": (_I, []),
+    "ll_debug_guard_selftest": (_I, []),
     "ll_dit_set_overlap": (_I, [_P, _I]),
     "ll_dit_mlp_choice": (_I, [_P, C.POINTER(_F), C.POINTER(_I), C.POINTER(_I)]),
     "ll_dit_set_option": (_I, [_P, _I, _I]),

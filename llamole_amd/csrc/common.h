@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -38,6 +39,45 @@ void set_error(const char *fmt, ...);
         int rc__ = (expr);      \
         if (rc__ != 0) return rc__; \
     } while (0)
+
+// Debug allocation mode of the engines' device buffers (env LL_DEBUG_POISON=1; off = plain zero-filled allocations): the payload starts as
+// 0xFF bytes (NaN / -1) and LL_GUARD_BYTES of 0xA5 follow it; `debug_guard_check` (buffer growth / release) reports any byte a kernel wrote
+// past the end on stderr and aborts -- the GPU test suite run in this mode is the out-of-bounds hunt (no GPU AddressSanitizer on this pool).
+constexpr size_t LL_GUARD_BYTES = 4096;
+inline bool debug_poison() {
+    static const bool on = getenv("LL_DEBUG_POISON") != nullptr;
+    return on;
+}
+void debug_registry_add(const void *p, size_t n);      // graphdit.hip: the live guarded buffers (debug mode only)
+void debug_registry_remove(const void *p);
+inline int debug_alloc(void **p, size_t n) {
+    const bool dbg = debug_poison();
+    hipError_t e = hipMalloc(p, n + (dbg ? LL_GUARD_BYTES : 0));
+    if (e == hipSuccess) e = hipMemset(*p, dbg ? 0xFF : 0, n);
+    if (e == hipSuccess && dbg) e = hipMemset((char *)*p + n, 0xA5, LL_GUARD_BYTES);
+    if (e != hipSuccess) {
+        set_error("device allocation of %zu bytes failed: %s", n, hipGetErrorString(e));
+        return LL_EHIP;
+    }
+    if (dbg) debug_registry_add(*p, n);
+    return LL_OK;
+}
+// number of guard regions a kernel wrote into (0 = intact); the caller has synchronised the device
+inline int debug_guard_damage(const void *p, size_t n, const char *when) {
+    static unsigned char host[LL_GUARD_BYTES];
+    if (hipMemcpy(host, (const char *)p + n, LL_GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    for (size_t i = 0; i < LL_GUARD_BYTES; ++i)
+        if (host[i] != 0xA5) {
+            fprintf(stderr, "LL_GUARD: a kernel wrote past the end of a %zu-byte engine buffer (first damaged byte at +%zu; %s)\n", n, i, when);
+            return 1;
+        }
+    return 0;
+}
+inline void debug_guard_check(const void *p, size_t n, const char *when) {      // buffer growth / release
+    if (!p || !debug_poison()) return;
+    debug_registry_remove(p);
+    if (hipDeviceSynchronize() == hipSuccess && debug_guard_damage(p, n, when)) abort();
+}
 
 #define LL_LAUNCH_CHECK()                                                                   \
     do {                                                                                    \

@@ -1150,18 +1150,18 @@ struct GBuf {
     size_t bytes = 0;
     int ensure(size_t n) {
         if (n <= bytes) return LL_OK;
+        debug_guard_check(p, bytes, "before growing");
         if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
-        LL_HIP(hipMalloc(&p, n));
-        // zeros; LL_DEBUG_POISON=1 fills with 0xFF (NaN / -1) instead: a kernel that counts on the initial zeros -- and would therefore
-        // break once a larger earlier call has left other data behind -- fails the test suite at once
-        static const int fill = getenv("LL_DEBUG_POISON") ? 0xFF : 0;
-        LL_HIP(hipMemset(p, fill, n));
+        // zeros; LL_DEBUG_POISON=1: 0xFF (NaN / -1) instead -- a kernel that counts on the initial zeros, and would therefore break once a
+        // larger earlier call has left other data behind, fails the test suite at once -- plus guard bytes behind the payload (common.h)
+        LL_TRY(debug_alloc(&p, n));
         bytes = n;
         return LL_OK;
     }
     void release() {
+        debug_guard_check(p, bytes, "at release");
         if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;

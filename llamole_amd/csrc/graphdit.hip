@@ -109,24 +109,35 @@ static int check_cfg(const LLDitConfig *c) {
     return LL_OK;
 }
 
+// live guarded engine buffers of BOTH engines (LL_DEBUG_POISON=1 only; common.h)
+static std::vector<std::pair<const void *, size_t>> g_guarded;
+void debug_registry_add(const void *p, size_t n) { g_guarded.emplace_back(p, n); }
+void debug_registry_remove(const void *p) {
+    for (size_t i = 0; i < g_guarded.size(); ++i)
+        if (g_guarded[i].first == p) {
+            g_guarded.erase(g_guarded.begin() + i);
+            return;
+        }
+}
+
 // ------------------------------------------------------------------------------------------ engine
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
     int ensure(size_t n) {
         if (n <= bytes) return LL_OK;
+        debug_guard_check(p, bytes, "before growing");
         if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
-        LL_HIP(hipMalloc(&p, n));
-        // zeros; LL_DEBUG_POISON=1 fills with 0xFF (NaN / -1) instead: a kernel that counts on the initial zeros -- and would therefore
-        // break once a larger earlier call has left other data behind -- fails the test suite at once
-        static const int fill = getenv("LL_DEBUG_POISON") ? 0xFF : 0;
-        LL_HIP(hipMemset(p, fill, n));
+        // zeros; LL_DEBUG_POISON=1: 0xFF (NaN / -1) instead -- a kernel that counts on the initial zeros, and would therefore break once a
+        // larger earlier call has left other data behind, fails the test suite at once -- plus guard bytes behind the payload (common.h)
+        LL_TRY(debug_alloc(&p, n));
         bytes = n;
         return LL_OK;
     }
     void release() {
+        debug_guard_check(p, bytes, "at release");
         if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
@@ -1105,6 +1116,26 @@ int ll_dit_mlp_choice(void *handle, float *us4, int *xw_fc1, int *xw_fc2) {
     if (xw_fc1) *xw_fc1 = xw_fc1_wanted(e) ? 1 : 0;
     if (xw_fc2) *xw_fc2 = xw_fc2_wanted(e) ? 1 : 0;
     return LL_OK;
+}
+
+int ll_debug_check_guards(void) {
+    if (!ll::debug_poison()) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    int bad = 0;
+    for (const auto &b : ll::g_guarded) bad += ll::debug_guard_damage(b.first, b.second, "ll_debug_check_guards");
+    return bad;
+}
+
+int ll_debug_guard_selftest(void) {
+    if (!ll::debug_poison()) return -1;
+    void *p = nullptr;
+    if (ll::debug_alloc(&p, 1000) != LL_OK) return -2;
+    const int clean = ll_debug_check_guards();
+    (void)hipMemset((char *)p + 1000 + 17, 0, 1);      // what an overrunning kernel would do
+    const int after = ll_debug_check_guards();
+    ll::debug_registry_remove(p);
+    (void)hipFree(p);
+    return (clean == 0 && after == 1) ? 1 : 0;
 }
 
 int ll_set_attn_waves(int waves) {

@@ -22,3 +22,14 @@ def pytest_configure(config):
 def hip_available():
     import torch
     return torch.cuda.is_available()
+
+
+@pytest.fixture(autouse=True)
+def _engine_buffer_guards():
+    """LL_DEBUG_POISON=1 (the out-of-bounds hunt): after every test, no kernel may have written past the end of an engine buffer."""
+    yield
+    if os.environ.get("LL_DEBUG_POISON"):
+        import torch
+        if torch.cuda.is_available():
+            from llamole_amd import _lib
+            assert _lib.load().ll_debug_check_guards() == 0, "a kernel wrote past the end of an engine buffer (see LL_GUARD on stderr)"

@@ -470,3 +470,34 @@ def test_estimate_cost_from_smiles_with_the_chemistry_double(monkeypatch):
     assert abs(got - ref) <= 1e-4 * max(1.0, abs(ref))
     with pytest.raises(ValueError, match="Invalid SMILES"):
         m.estimate_cost("???")
+
+
+def test_engine_buffer_guards_detect_an_overrun():
+    """LL_DEBUG_POISON=1 (the out-of-bounds hunt of DESIGN section 3): engine buffers start as 0xFF with guard bytes behind them; a planted
+    overrun is reported, a GIN forward + top-k and a GraphDiT trajectory leave every guard intact -- in a fresh process, the variable is read
+    once per process."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from llamole_amd import _lib, synth
+from tests.test_gin_gpu import _predictor
+lib = _lib.load()
+assert lib.ll_debug_guard_selftest() == 1
+pred = _predictor("gin_l3_h64")
+x, ei, ea, batch = synth.make_mol_graphs(9, 3)
+c = torch.randn(9, 768)
+out = pred(x.cuda(), ei.cuda(), ea.cuda(), batch.cuda(), c.cuda())
+assert torch.isfinite(out).all()
+import bench, types
+m, cfg, meta, sd = bench.build_model(types.SimpleNamespace(hidden=128, depth=2, heads=4, T=6, guide=2.0, nodes=32, dtype="bf16"), torch.device("cuda"))
+props, text, _ = synth.make_dit_inputs(3, seed=0, max_node=32)
+mols, _ = m.generate_graphs(props, text, -200.0, seed=1)
+assert len(mols) == 3 and lib.ll_debug_check_guards() == 0
+print("guards ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LL_DEBUG_POISON="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "guards ok" in r.stdout, r.stderr[-2000:]
+    assert "LL_GUARD" in r.stderr          # the planted overrun was reported on stderr
