@@ -626,8 +626,7 @@ class GraphLLMForCausalMLM(nn.Module):
                     from transformers import DynamicCache
                     B = len(chunk)
                     cache = DynamicCache(ddp_cache_data=[(k.expand(B, -1, -1, -1), v.expand(B, -1, -1, -1)) for k, v in opening])
-                    logits = self.language_model(logits_to_keep=1, use_cache=True, past_key_values=cache,
-                                                 cache_position=torch.arange(P, P + L, device=self.device), **kw).logits[:, -1, :]
+                    logits = self.language_model(logits_to_keep=1, use_cache=True, past_key_values=cache, **kw).logits[:, -1, :]
                     del cache
                 else:
                     try:      # only the last position's logits are read: no [B, L, vocab] product, no KV cache
