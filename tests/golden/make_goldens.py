@@ -16,6 +16,16 @@ Sampling: ``Tensor.multinomial`` is replaced, for the duration of the run, by th
 exponential race argmax(p / q) with q taken from ``synth.exp_noise`` -- after first
 checking that torch's own ``multinomial(1)`` equals that race under a shared generator.
 """
+import os as _os
+import sys as _sys
+
+if __name__ == "__main__" and _os.environ.get("PYTHONHASHSEED") != "1":
+    # The reference's planner de-duplicates reactant sets through set() (planner/molstar.py:54), so one planner trace depends on the
+    # string hash order.  Pin it before any work: re-run this script as a child under the seed the committed fixtures were made with
+    # (no GPU is involved; a child process, not an exec).
+    import subprocess as _sp
+    _sys.exit(_sp.call([_sys.executable] + _sys.argv, env=dict(_os.environ, PYTHONHASHSEED="1")))
+
 import os
 import sys
 import tempfile
@@ -384,8 +394,8 @@ def gen_gin(name):
 
 # ----------------------------------------------------------------------------- planner goldens
 def gen_planner():
-    """Traces of the reference's molstar on scripted expansion tables (host logic, a20).  Run as
-    `PYTHONHASHSEED=1 python tests/golden/make_goldens.py planner`: the reference's set() de-duplication makes the "fail" case (a tie
+    """Traces of the reference's molstar on scripted expansion tables (host logic, a20).  The script re-runs itself under
+    PYTHONHASHSEED=1 (top of the file): the reference's set() de-duplication makes the "fail" case (a tie
     between two open nodes) depend on the string hash order; every other case gives the same trace under any seed (planner_cases.py)."""
     import json
     sys.path.insert(0, REF)
