@@ -146,15 +146,43 @@ class GraphLLMForCausalMLM(nn.Module):
             getattr(model, name).to(device)
         return model
 
-    def save_pretrained(self, save_directory, **kwargs):
-        """Connectors + config (reference :490-515); the LLM adapter itself is saved by peft."""
+    def save_pretrained(self, save_directory, save_graph_modules: bool = False, modules_to_save=(), **kwargs):
+        """Reference :439-519: the language model (its ADAPTER when it carries one -- peft layout, ``save_peft_format``), optionally the
+        three graph modules, the three connectors under ``connector/`` and ``graphllm_config.json``."""
+        if os.path.isfile(save_directory):
+            raise ValueError(f"Provided path ({save_directory}) should be a directory, not a file")
+        os.makedirs(save_directory, exist_ok=True)
+        from .sft import LoRALinear, save_lora_adapter
+        if any(isinstance(m, LoRALinear) for m in self.language_model.modules()):
+            save_lora_adapter(self.language_model, save_directory, modules_to_save=modules_to_save,
+                              base_model_name=getattr(self.model_args, "model_name_or_path", None))
+        elif hasattr(self.language_model, "save_pretrained") and kwargs.get("save_language_model", True):
+            self.language_model.save_pretrained(save_directory)
+        if save_graph_modules:
+            for name in ("graph_decoder", "graph_predictor", "graph_encoder"):
+                mod = getattr(self, name)
+                if hasattr(mod, "save_pretrained"):
+                    mod.save_pretrained(os.path.join(save_directory, name))
         os.makedirs(os.path.join(save_directory, "connector"), exist_ok=True)
         for name in ("graph_to_lm_connector", "lm_to_graph_decoder", "lm_to_graph_predictor"):
             torch.save(getattr(self, name).state_dict(), os.path.join(save_directory, "connector", name + ".pt"))
-        if hasattr(self.language_model, "save_pretrained") and kwargs.get("save_language_model", False):
-            self.language_model.save_pretrained(save_directory)
+
+        def plain(ns):
+            out = {}
+            for k, v in (vars(ns) if hasattr(ns, "__dict__") else {}).items():
+                if isinstance(v, (str, int, float, bool, type(None))):
+                    out[k] = v
+                elif isinstance(v, (list, tuple)) and all(isinstance(x, (str, int, float, bool)) for x in v):
+                    out[k] = list(v)
+                elif isinstance(v, torch.dtype):
+                    out[k] = str(v)
+            return out
+        w = self.finetuning_args
         with open(os.path.join(save_directory, "graphllm_config.json"), "w") as f:
-            json.dump({"num_body_tokens": self.num_body_tokens, "token_id_dict": self.token_id_dict}, f, indent=2)
+            json.dump({"model_args": plain(self.model_args), "finetuning_args": plain(self.finetuning_args), "data_args": plain(self.data_args),
+                       "token_id_dict": self.token_id_dict, "num_body_tokens": self.num_body_tokens,
+                       "loss_weight_lm": getattr(w, "loss_weight_lm", 1), "loss_weight_design": getattr(w, "loss_weight_design", 1),
+                       "loss_weight_retro": getattr(w, "loss_weight_retro", 1)}, f, indent=2)
 
     @property
     def device(self):

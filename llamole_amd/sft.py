@@ -192,7 +192,9 @@ def merge_lora_adapter(model: torch.nn.Module, adapter_dir: str) -> int:
     else:
         tensors = torch.load(os.path.join(adapter_dir, "adapter_model.bin"), map_location="cpu", weights_only=True)
     mods = dict(model.named_modules())
-    params = dict(model.named_parameters())
+    # remove_duplicate=False: with tie_word_embeddings named_parameters() lists the shared tensor once (as embed_tokens), and an adapter
+    # whose modules_to_save carries lm_head.weight as well must still find its target
+    params = dict(model.named_parameters(remove_duplicate=False))
     strip = lambda k: k[len("base_model.model."):] if k.startswith("base_model.model.") else k      # noqa: E731
     merged = 0
     with torch.no_grad():
@@ -220,3 +222,76 @@ def merge_lora_adapter(model: torch.nn.Module, adapter_dir: str) -> int:
                                      "resize the embeddings (resize_vocab) before merging the adapter")
                 tgt.copy_(a.to(device=tgt.device, dtype=tgt.dtype))
     return merged
+
+
+def lora_state_dict(model: torch.nn.Module, modules_to_save: Sequence[str] = ()) -> Dict[str, torch.Tensor]:
+    """The trained adapter of ``model`` (``LoRALinear`` wrappers of ``add_lora``) under peft's key names:
+    ``base_model.model.<module>.lora_A.weight`` [r, in], ``...lora_B.weight`` [out, r]; every module whose last name component is in
+    ``modules_to_save`` contributes its full ``<module>.weight`` (the resized embed_tokens / lm_head, reference adapter.py:224-233).
+    Tied weights are written once per name, as peft does."""
+    out: Dict[str, torch.Tensor] = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, LoRALinear):
+            out[f"base_model.model.{name}.lora_A.weight"] = mod.lora_a.detach().cpu().contiguous()
+            out[f"base_model.model.{name}.lora_B.weight"] = mod.lora_b.detach().cpu().contiguous()
+        elif modules_to_save and name.split(".")[-1] in modules_to_save and getattr(mod, "weight", None) is not None:
+            out[f"base_model.model.{name}.weight"] = mod.weight.detach().cpu().clone().contiguous()
+    return out
+
+
+def save_lora_adapter(model: torch.nn.Module, adapter_dir: str, modules_to_save: Sequence[str] = (), base_model_name: Optional[str] = None) -> int:
+    """Write the adapter ``add_lora`` trained in peft's on-disk layout -- ``adapter_model.safetensors`` + ``adapter_config.json`` -- what
+    ``PeftModel.save_pretrained`` leaves in the reference's output_dir (modeling_llamole.py:463-476 with save_peft_format) and what
+    ``merge_lora_adapter`` / ``PeftModel.from_pretrained`` read back.  Returns the number of adapted Linears."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    wrapped = [(n, m) for n, m in model.named_modules() if isinstance(m, LoRALinear)]
+    if not wrapped:
+        raise ValueError("save_lora_adapter: the model carries no LoRALinear module (call add_lora first)")
+    r = wrapped[0][1].lora_a.shape[0]
+    alpha = wrapped[0][1].scale * r
+    if any(m.lora_a.shape[0] != r or abs(m.scale * r - alpha) > 1e-6 for _, m in wrapped):
+        raise ValueError("save_lora_adapter: mixed ranks / alphas cannot be described by one adapter_config.json")
+    os.makedirs(adapter_dir, exist_ok=True)
+    save_file(lora_state_dict(model, modules_to_save), os.path.join(adapter_dir, "adapter_model.safetensors"))
+    with open(os.path.join(adapter_dir, "adapter_config.json"), "w") as f:
+        json.dump({"peft_type": "LORA", "task_type": "CAUSAL_LM", "base_model_name_or_path": base_model_name, "r": int(r),
+                   "lora_alpha": float(alpha), "lora_dropout": 0.0, "target_modules": sorted({n.split(".")[-1] for n, _ in wrapped}),
+                   "use_rslora": False, "fan_in_fan_out": False, "bias": "none", "inference_mode": True,
+                   "modules_to_save": list(modules_to_save) if modules_to_save else None}, f, indent=2)
+    return len(wrapped)
+
+
+def load_lora_adapter(model: torch.nn.Module, adapter_dir: str) -> int:
+    """Resume: copy a saved adapter's A / B (and modules_to_save weights) into the ``LoRALinear`` wrappers of ``model`` WITHOUT merging,
+    so that training continues on the adapter -- the reference resumes the language-model adapter only (trainer.py:232-234).  Returns
+    the number of adapters restored; raises when a saved pair has no wrapper or another shape."""
+    import os
+    from safetensors.torch import load_file
+    tensors = load_file(os.path.join(adapter_dir, "adapter_model.safetensors"))
+    mods = dict(model.named_modules())
+    params = dict(model.named_parameters(remove_duplicate=False))
+    n = 0
+    with torch.no_grad():
+        for k, v in tensors.items():
+            name = k[len("base_model.model."):] if k.startswith("base_model.model.") else k
+            if name.endswith(".lora_A.weight") or name.endswith(".lora_B.weight"):
+                base, which = name[:-len(".lora_A.weight")], name[-len("lora_A.weight"):-len(".weight")]
+                mod = mods.get(base)
+                if not isinstance(mod, LoRALinear):
+                    raise KeyError(f"adapter tensor {k!r}: {base!r} is not a LoRA-wrapped module of this model")
+                tgt = mod.lora_a if which == "lora_A" else mod.lora_b
+                if tuple(tgt.shape) != tuple(v.shape):
+                    raise ValueError(f"adapter tensor {k!r} has shape {tuple(v.shape)}, the model's adapter {tuple(tgt.shape)}")
+                tgt.copy_(v.to(device=tgt.device, dtype=tgt.dtype))
+                n += which == "lora_A"
+            else:
+                tgt = params.get(name)
+                if tgt is None:       # a wrapped module keeps its Linear under `.base`
+                    head, _, leaf = name.rpartition(".")
+                    tgt = params.get(f"{head}.base.{leaf}")
+                if tgt is None:
+                    raise KeyError(f"adapter tensor {k!r} has no parameter in the model")
+                tgt.copy_(v.to(device=tgt.device, dtype=tgt.dtype))
+    return n

@@ -505,3 +505,64 @@ def write_eval_fixture(root: str, special_tokens, with_adapter: bool = True) -> 
     with open(path, "w") as f:
         yaml.safe_dump(y, f)
     return path
+
+
+def write_molqa_train_dataset(dataset_dir: str, name: str = "molqa_train_synth", n: int = 6, out_dim: int = 512) -> str:
+    """dataset_info.json entry + MolQA training records in the reference's text grammar (data/molqa_train_examples.json): a designed
+    molecule after ``<design_start><design_end>``, one or two numbered retrosynthesis steps with ``<retro_start><retro_end>product>>reactants``,
+    a property dict and one template label per step (``retro``; the last record's second step has none).  Molecule strings are short
+    alphabetic names: whatever ``smiles_to_graph`` the caller installs must read them (tests use the ring-graph maker of tests/host_fakes.py)."""
+    os.makedirs(dataset_dir, exist_ok=True)
+    names = ["CCO", "CCN", "CCC", "COC", "CNC", "CCS", "CCF", "OCO"]
+    step = ("This is step {i} in the retrosynthesis process. To synthesize <mol_start>{p}<mol_end>, follow these procedures: stir and heat. "
+            "The applied reaction is: <retro_start><retro_end>{p}>>{a}.{b} with the template T{i}, which requires the reactants: {a} (available), {b} (available). ")
+    recs = []
+    for k in range(n):
+        p, a, b, c = names[k % 8], names[(k + 1) % 8], names[(k + 2) % 8], names[(k + 3) % 8]
+        out = f"To satisfy the requirements: a small polar scaffold. Therefore, the designed molecule is: <design_start><design_end><mol_start>{p}<mol_end>. "
+        out += step.format(i=1, p=p, a=a, b=b)
+        labels = [(37 * k + 5) % out_dim]
+        if k % 2:
+            out += step.format(i=2, p=a, a=b, b=c)
+            labels.append(None if k == n - 1 else (91 * k + 11) % out_dim)
+        recs.append({"instruction": f"design a molecule number {k} with low synthetic complexity ?", "input": "", "output": out,
+                     "property": {"SA": 2.0 + 0.1 * k, "SC": 2.5, "BBBP": float(k % 2)}, "retro": labels})
+    with open(os.path.join(dataset_dir, name + ".json"), "w") as f:
+        json.dump(recs, f)
+    info_path = os.path.join(dataset_dir, "dataset_info.json")
+    info = {}
+    if os.path.exists(info_path):
+        with open(info_path) as f:
+            info = json.load(f)
+    info[name] = {"file_name": name + ".json"}
+    with open(info_path, "w") as f:
+        json.dump(info, f)
+    return name
+
+
+def write_train_fixture(root: str, special_tokens, **overrides) -> str:
+    """Everything `python main.py train cfg.yaml` reads, synthetic and local, plus the YAML with the reference's training keys
+    (config/train/mistral_lora.yaml)."""
+    import yaml
+    from . import e2e
+    llm_dir = write_llm_dir(os.path.join(root, "llm"), special_tokens)
+    cfg = make_dit_config(hidden_size=128, depth=2, num_heads=4, diffusion_steps=10, guide_scale=2.0)
+    write_dit_dir(os.path.join(root, "graph_decoder"), cfg, make_data_meta(16, 0), make_dit_weights(cfg, 16, 0))
+    write_encoder_dir(os.path.join(root, "graph_encoder"))
+    write_predictor_dir(os.path.join(root, "graph_predictor"))
+    write_connector_dir(os.path.join(root, "connector0"), e2e.LLM_CONFIGS["tiny"]["hidden_size"], 64)
+    ds = write_molqa_train_dataset(os.path.join(root, "data"))
+    y = {"model_name_or_path": llm_dir, "new_special_tokens": ",".join(special_tokens),
+         "graph_decoder_path": os.path.join(root, "graph_decoder"), "graph_encoder_path": os.path.join(root, "graph_encoder"),
+         "graph_predictor_path": os.path.join(root, "graph_predictor"), "graph_lm_connector_path": None,
+         "stage": "mmsft", "do_train": True, "finetuning_type": "lora", "lora_target": "all", "lora_rank": 4, "learned_query_size": 8,
+         "dataset": ds, "dataset_dir": os.path.join(root, "data"), "template": "qwen", "cutoff_len": 256,
+         "output_dir": os.path.join(root, "saves", "adapter"), "logging_steps": 1, "save_steps": 0, "overwrite_output_dir": True,
+         "per_device_train_batch_size": 2, "gradient_accumulation_steps": 2, "learning_rate": 1.0e-3, "num_train_epochs": 2.0,
+         "lr_scheduler_type": "cosine", "warmup_ratio": 0.1, "bf16": True, "pure_bf16": True,
+         "loss_weight_retro": 1, "loss_weight_design": 1, "loss_weight_lm": 1}
+    y.update(overrides)
+    path = os.path.join(root, "train.yaml")
+    with open(path, "w") as f:
+        yaml.safe_dump(y, f)
+    return path

@@ -1,6 +1,7 @@
 """BASELINE.json-sized checks (Qwen2-7B architecture, ref-default GraphDiT denoiser): the oracle cannot run these sizes in
 seconds, so parity is established through size-independent properties -- the fused path against the unfused path of the same
 library (bit-identical by construction), hipGraph replay against eager, determinism, well-formedness of the sampled graphs."""
+import os
 import types
 
 import pytest
@@ -9,43 +10,53 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_qwen2_7b_decode_fused_equals_unfused_at_full_size():
-    """Real shapes (hidden 3584, 28 q / 4 kv heads, intermediate 18944, vocab 152064): greedy decode through the five-launch
+FULL_SIZE = {      # BASELINE.json configs[1..2] (Qwen2-7B), configs[3] (Llama-3.1-8B: head_dim 128, 8 kv heads, vocab 128 256)
+    "qwen2-7b": dict(layers=28, vocab=152064, tok_hi=150000),
+    "llama-3.1-8b": dict(layers=32, vocab=128256, tok_hi=128000),
+}
+
+
+@pytest.mark.parametrize("name", ["qwen2-7b", "llama-3.1-8b"])
+def test_decode_fused_equals_unfused_at_full_size(name):
+    """Real shapes (Qwen2-7B: hidden 3584, 28 q / 4 kv heads, intermediate 18944, vocab 152064; Llama-3.1-8B: hidden 4096, 32 q / 8 kv
+    heads of dimension 128, intermediate 14336, vocab 128256, no q|k|v bias): greedy decode through the five-launch
     layers + one-launch prologue + fused sampler, eager and as a hipGraph, equals the one-launch-per-op accelerated path
     token for token and logit for logit; the sampling path is reproducible."""
     from llamole_amd import e2e
+    spec = FULL_SIZE[name]
     from llamole_amd.llm_accel import (accelerate_elementwise, accelerate_linears, fuse_decoder_layers, fuse_model_decode,
                                        use_decode_attention)
     from llamole_amd.llm_decode import GraphedDecoder
-    llm = e2e.build_llm("qwen2-7b", "cuda", torch.bfloat16)
+    llm = e2e.build_llm(name, "cuda", torch.bfloat16)
     assert accelerate_linears(llm) > 0
     accelerate_elementwise(llm)
     assert use_decode_attention(llm)
     g = torch.Generator().manual_seed(0)
-    prompt = torch.randint(5, 150000, (1, 48), generator=g).cuda()
+    prompt = torch.randint(5, spec["tok_hi"], (1, 48), generator=g).cuda()
     mask = torch.ones_like(prompt)
     kw = dict(max_new_tokens=6, do_sample=False, pad_token_id=0, eos_token_id=[])
     base = GraphedDecoder(llm, use_graph=False, fused_cache=True)
     ref = base.generate(prompt, mask, **kw)
     ref_logits = base.last_logits.clone()
-    assert fuse_decoder_layers(llm) == 28 and fuse_model_decode(llm)
+    assert fuse_decoder_layers(llm) == spec["layers"] and fuse_model_decode(llm)
     d = GraphedDecoder(llm, use_graph=False, fused_cache=True)
     assert torch.equal(d.generate(prompt, mask, **kw), ref) and torch.equal(d.last_logits, ref_logits)
     gdec = GraphedDecoder(llm, use_graph=True, fused_cache=True)
     assert torch.equal(gdec.generate(prompt, mask, **kw), ref) and torch.equal(gdec.last_logits, ref_logits)
-    # greedy == argmax of the logits the torch way (sampler kernel at V = 152064)
+    # greedy == argmax of the logits the torch way (sampler kernel at V = 152064 / 128256)
     assert int(ref[0, -1]) == int(torch.argmax(_last_but_one_logits(llm, ref)))
     gen = torch.Generator(device="cuda").manual_seed(9)
     s1 = gdec.generate(prompt, mask, max_new_tokens=8, do_sample=True, temperature=0.6, top_p=0.9, pad_token_id=0, generator=gen)
     gen.manual_seed(9)
     s2 = gdec.generate(prompt, mask, max_new_tokens=8, do_sample=True, temperature=0.6, top_p=0.9, pad_token_id=0, generator=gen)
-    assert torch.equal(s1, s2) and int(s1.max()) < 152064
+    assert torch.equal(s1, s2) and int(s1.max()) < spec["vocab"]
     from llamole_amd.llm_accel import restore_elementwise      # the rotary patch is module-global: leave HF as we found it
     restore_elementwise(llm)
 
 
-def test_qwen2_7b_batched_decode_on_the_mfma_stream_at_full_size():
-    """8 sequences at the real shapes: the five-launch layers on ll_linear_rows16_bf16 (RMSNorm folded into the stream) against
+@pytest.mark.parametrize("name", ["qwen2-7b", "llama-3.1-8b"])
+def test_batched_decode_on_the_mfma_stream_at_full_size(name):
+    """8 sequences at the real shapes (configs[3] shards 64 prompts as 8 per GPU on Llama-3.1-8B): the five-launch layers on ll_linear_rows16_bf16 (RMSNorm folded into the stream) against
     the one-launch-per-op path after ONE decode step from the same prefill -- logits agree to bf16 rounding (the MFMA stream
     accumulates in another order and places one rounding differently), the argmax token matches wherever the top-2 margin
     exceeds that rounding; hipGraph replay equals eager bit for bit; left padding is honoured."""
@@ -53,13 +64,14 @@ def test_qwen2_7b_batched_decode_on_the_mfma_stream_at_full_size():
     from llamole_amd.llm_accel import (accelerate_elementwise, accelerate_linears, fuse_decoder_layers, fuse_model_decode,
                                        restore_elementwise, use_decode_attention)
     from llamole_amd.llm_decode import GraphedDecoder
-    llm = e2e.build_llm("qwen2-7b", "cuda", torch.bfloat16)
+    spec = FULL_SIZE[name]
+    llm = e2e.build_llm(name, "cuda", torch.bfloat16)
     assert accelerate_linears(llm) > 0
     accelerate_elementwise(llm)
     assert use_decode_attention(llm)
     try:
         g = torch.Generator().manual_seed(1)
-        prompt = torch.randint(5, 150000, (8, 40), generator=g).cuda()
+        prompt = torch.randint(5, spec["tok_hi"], (8, 40), generator=g).cuda()
         mask = torch.ones_like(prompt)
         mask[2, :9] = 0
         mask[7, :25] = 0
@@ -67,7 +79,7 @@ def test_qwen2_7b_batched_decode_on_the_mfma_stream_at_full_size():
         base = GraphedDecoder(llm, use_graph=False, fused_cache=True)
         base.generate(prompt, mask, **kw)
         ref = base.last_logits.float().clone()
-        assert fuse_decoder_layers(llm) == 28 and fuse_model_decode(llm)
+        assert fuse_decoder_layers(llm) == spec["layers"] and fuse_model_decode(llm)
         d = GraphedDecoder(llm, use_graph=False, fused_cache=True)
         d.generate(prompt, mask, **kw)
         got = d.last_logits.float()
@@ -76,7 +88,7 @@ def test_qwen2_7b_batched_decode_on_the_mfma_stream_at_full_size():
         tok1 = base.out_buf[:, :1] if hasattr(base, "out_buf") else None
         seq = torch.cat([prompt, tok1], dim=1)
         m2 = torch.cat([mask, torch.ones_like(tok1)], dim=1)
-        llm32 = e2e.build_llm("qwen2-7b", "cuda", torch.float32)
+        llm32 = e2e.build_llm(name, "cuda", torch.float32)
         llm32.load_state_dict({k: v.float() for k, v in llm.state_dict().items()})
         with torch.no_grad():
             pos = (m2.cumsum(dim=1) - 1).clamp_min(0)
@@ -145,3 +157,70 @@ def test_graphdit_ref_default_trajectory_properties():
     assert any(not torch.equal(a[i][1], other_seed[i][1]) for i in range(8))
     ms, steps = m.last_run_ms()
     assert steps == 50 and ms < 500.0
+
+
+def test_mistral_7b_sft_step_hip_graph_side_equals_oracle_graph_side():
+    """BASELINE configs[4] at the real shapes: one SFT forward + backward of Mistral-7B (hidden 4096, 32 layers, 8 kv heads, vocab 32768;
+    LoRA r = 8 on 224 projections) on 2 x 512 tokens with one spliced molecule and two retro queries per row, the 180 576-template GIN
+    predictor and the GIN encoder on the HIP engines -- against the SAME step with the graph side computed by the f32 CPU oracle under
+    torch.autograd (same bf16-rounded graph weights, same LLM): total / LM / retro loss and the gradients that cross the seam (the three
+    connectors; d loss / d c reaches lm_to_graph_predictor through ll_gin_backward_c) must agree to bf16 rounding."""
+    import torch.nn.functional as F
+    from llamole_amd.workloads import build_sft_step
+    from oracle import gin_oracle as go
+    args = types.SimpleNamespace(llm="mistral-7b", out_dim=180576, sft_batch=2, sft_seq=512)
+    dev = torch.device("cuda")
+    step_fn, info, model, sd_pred, b = build_sft_step(args, dev, 0)
+    assert info["trainable_params"] > 0 and "224" in info["lora"]
+    conn = {n: p for n, p in model.named_parameters() if n.split(".")[0] in ("graph_to_lm_connector", "lm_to_graph_predictor") and p.requires_grad}
+    assert len(conn) == 4
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        out = model(**b)
+        out.loss.backward()
+        return ({k: float(v) for k, v in out.additional_log_info.items()} | {"loss": float(out.loss.detach())},
+                {n: p.grad.detach().float().cpu().clone() for n, p in conn.items()})
+    log_hip, g_hip = run()
+    enc_hip, pred_hip = model.graph_encoder, model.graph_predictor
+    r = lambda d: {k: v.detach().to(torch.bfloat16).float().cpu() for k, v in d.items()}      # noqa: E731
+    sde, sdj = r(enc_hip.molecule_encoder.state_dict()), r(enc_hip.molecule_projection.state_dict())
+    sdp = r(pred_hip.predictor.state_dict())
+    L = 5
+
+    def oracle_encoder(x, ei, ea, batch):
+        return go.graphclip_forward(sde, sdj, L, x.cpu(), ei.cpu(), ea.cpu(), batch.cpu()).to(dev)
+
+    class OraclePredictor(torch.nn.Module):
+        text_input_size = 768
+
+        def forward(self, x, ei, ea, batch, c):
+            return go.predictor_forward(sdp, L, x.cpu(), ei.cpu(), ea.cpu(), batch.cpu(), c.float().cpu()).to(dev)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    model._modules["graph_encoder"] = _Fn(oracle_encoder)
+    model._modules["graph_predictor"] = OraclePredictor()
+    try:
+        log_ref, g_ref = run()
+    finally:
+        model._modules["graph_encoder"] = enc_hip
+        model._modules["graph_predictor"] = pred_hip
+    rec = {"hip": log_hip, "oracle": log_ref}
+    for n in conn:
+        rec[n + ".cos"] = float(F.cosine_similarity(g_hip[n].flatten(), g_ref[n].flatten(), dim=0))
+        rec[n + ".rel"] = float((g_hip[n] - g_ref[n]).abs().max() / g_ref[n].abs().max().clamp_min(1e-12))
+    print("Mistral-7B SFT step, HIP vs oracle graph side:", rec)
+    assert abs(log_hip["lm_loss"] - log_ref["lm_loss"]) <= 2e-2 * abs(log_ref["lm_loss"]), rec
+    assert abs(log_hip["retro_loss"] - log_ref["retro_loss"]) <= 2e-2 * abs(log_ref["retro_loss"]), rec
+    assert abs(log_hip["loss"] - log_ref["loss"]) <= 2e-2 * abs(log_ref["loss"]), rec
+    for n in conn:
+        assert rec[n + ".cos"] >= 0.99, rec
+
+
+class _Fn(torch.nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, *a):
+        return self.fn(*a)

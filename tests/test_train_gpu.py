@@ -1,0 +1,91 @@
+"""`python main.py train cfg.yaml` end to end on the GPU box (reference src/train/mmsft/workflow.py:41-118,
+modeling_llamole.py:439-519, trainer.py:232-234): LoRA SFT of a tiny HF language model with the graph side of the loss on the HIP
+engines, the checkpoint the reference layout prescribes, `main.py eval` loading that checkpoint back, resuming, and two ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fake_chem(monkeypatch):
+    from llamole_amd.graph_data import GraphData
+    from llamole_amd.modeling_llamole import GraphLLMForCausalMLM
+    from tests.host_fakes import fake_smiles_to_graph
+    to_graph = fake_smiles_to_graph(GraphData)
+    monkeypatch.setattr(GraphLLMForCausalMLM, "smiles_to_graph", lambda self, s: to_graph(s))
+
+
+def test_main_train_saves_what_it_trains_and_eval_loads_it(tmp_path, monkeypatch):
+    import yaml
+    from llamole_amd import synth
+    from llamole_amd import train as tr
+    from llamole_amd.modeling_llamole import SPECIAL_TOKENS
+    _fake_chem(monkeypatch)
+    cfg = synth.write_train_fixture(str(tmp_path), SPECIAL_TOKENS, num_train_epochs=10.0)
+    torch.manual_seed(0)
+    out = tr.run_train(cfg)
+    losses = [r["loss"] for r in out["log"]]
+    assert len(losses) == 10 and all(l == l for l in losses)
+    assert min(losses[-3:]) < losses[0], losses                       # it learns something on six records
+    assert all(r["retro_loss"] > 0 and r["lm_loss"] > 0 for r in out["log"])
+    od = out["output_dir"]
+    for f in ("adapter_model.safetensors", "adapter_config.json", "graphllm_config.json", "connector/graph_to_lm_connector.pt",
+              "connector/lm_to_graph_decoder.pt", "connector/lm_to_graph_predictor.pt", "trainer_log.jsonl", "train_results.json"):
+        assert os.path.exists(os.path.join(od, f)), f
+    gcfg = json.load(open(os.path.join(od, "graphllm_config.json")))
+    assert gcfg["num_body_tokens"] == 8 and "<retro_start>" in gcfg["token_id_dict"] and gcfg["loss_weight_retro"] == 1
+    acfg = json.load(open(os.path.join(od, "adapter_config.json")))
+    assert acfg["r"] == 4 and "lm_head" not in acfg["target_modules"] and "q_proj" in acfg["target_modules"]
+
+    # resuming restores the adapter and the connectors: the first loss of the resumed run sits near the end of the first run, not its start
+    cfg2 = synth.write_train_fixture(str(tmp_path / "again"), SPECIAL_TOKENS, max_steps=1, resume_from_checkpoint=od,
+                                     output_dir=str(tmp_path / "again" / "out"))
+    torch.manual_seed(0)
+    out2 = tr.run_train(cfg2)
+    assert out2["log"][0]["loss"] < 0.5 * (losses[0] + min(losses[-3:])), (out2["log"][0]["loss"], losses)
+
+    # the eval driver loads the checkpoint: adapter merged without peft, connectors from <output_dir>/connector
+    from llamole_amd import eval as ev
+    from llamole_amd import molecule_utils
+    from llamole_amd.graph_decoder import GraphDiT
+    from llamole_amd import graph_predictor
+    from tests.cases import fake_template_runner
+    monkeypatch.setattr(molecule_utils, "graph_to_smiles", lambda mols, dec: ["M" + "".join(chr(65 + int(a)) for a in at[:8]) for at, _ in mols])
+    monkeypatch.setattr(GraphDiT, "check_valid", lambda self, s: True)
+    monkeypatch.setattr(graph_predictor, "_default_template_runner", lambda: fake_template_runner)
+    y = yaml.safe_load(open(cfg))
+    ds = synth.write_molqa_dataset(os.path.join(str(tmp_path), "data"))
+    y.update(adapter_name_or_path=od, graph_lm_connector_path=os.path.join(od, "connector"), do_train=False, dataset=ds, cutoff_len=32,
+             max_new_tokens=8, per_device_eval_batch_size=2, output_dir=str(tmp_path / "evalout"))
+    ycfg = str(tmp_path / "generate.yaml")
+    yaml.safe_dump(y, open(ycfg, "w"))
+    try:
+        res = ev.run_eval(ycfg, overrides={"retro_iterations": 2, "retro_max_planning_time": 10})
+    finally:
+        from transformers.models.qwen2 import modeling_qwen2 as mq
+        if hasattr(mq.apply_rotary_pos_emb, "_ll_orig"):
+            mq.apply_rotary_pos_emb = mq.apply_rotary_pos_emb._ll_orig
+    assert len(res["results"]) == 5 and all("llm_smiles" in r for r in res["results"])
+
+
+def test_main_train_two_ranks(tmp_path):
+    """Two processes on the one GPU of the box (gloo between them: one device cannot host two RCCL ranks): the data-parallel step --
+    sharded micro batches, one bucketed gradient all-reduce per optimizer step -- through `python main.py train`'s own code."""
+    from llamole_amd import synth
+    from llamole_amd.modeling_llamole import SPECIAL_TOKENS
+    cfg = synth.write_train_fixture(str(tmp_path), SPECIAL_TOKENS, num_train_epochs=3.0, per_device_train_batch_size=1)
+    env = dict(os.environ, LLAMOLE_DIST_BACKEND="gloo", LLAMOLE_BENCH_SHARED_GPU="1", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29613", os.path.join(ROOT, "tests", "train_rank_worker.py"), cfg]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("TRAIN_LOG ")][-1]
+    log = json.loads(line[len("TRAIN_LOG "):])
+    assert len(log["losses"]) == 3 and all(l == l for l in log["losses"])
+    assert os.path.exists(os.path.join(str(tmp_path), "saves", "adapter", "adapter_model.safetensors"))
