@@ -504,7 +504,8 @@ def run_retro(args, ctx):
            "value": ctx.world * T * args.steps / dt, "unit": "molecules/s", "n_gpus": ctx.n_ranks, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
            "data": "synthetic",
-           "config": {"workload": "%s + GraphDiT + GIN predictor A* retrosynthesis, depth<=%d, batch=%d/GPU" % (LLM_LABEL.get(args.llm, args.llm), args.iterations, T),
+           "config": {"workload": "%s + GraphDiT + GIN predictor A* retrosynthesis, depth<=%d, batch=%d/GPU, %d analysis tokens per expansion (the reference allows 512)"
+                                  % (LLM_LABEL.get(args.llm, args.llm), args.iterations, T, args.retro_tokens),
                       "prompts_per_step": ctx.world * T, "gathered_routes": int(gathered.shape[0]),
                       "denoiser": {"hidden": args.hidden, "depth": args.depth, "heads": args.heads, "max_nodes": args.nodes, "T": args.T,
                                    "guide_scale": args.guide}, **{k: v for k, v in info.items() if k != "timing_breakdown"}},
@@ -519,6 +520,8 @@ def run_retro(args, ctx):
                                  "HF forward on PyTorch-ROCm / hipBLASLt at M ~ 100 k rows, compute-bound (~1.05 PFLOP/s over the decoder stack); the "
                                  "reference runs one forward per node" % orch.value_batch,
            "routes_found": int(gathered[:, 0].sum().item()),
+           "route_lengths": sorted(int(v) for v in gathered[gathered[:, 0] > 0, 1].tolist()),
+           "searches_without_route": int((gathered[:, 0] == 0).sum().item()),
            "roofline": roof}
     if not args.no_cpu_baseline and ctx.world == 1:
         log("cpu baseline ...")
@@ -680,14 +683,16 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    from llamole_amd.distributed import force_dist
+    if world > 1 or force_dist():      # LLAMOLE_FORCE_DIST=1: the collective path with ONE rank (RCCL world-1 smoke; tests/test_rccl_gpu.py)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         backend = os.environ.get("LLAMOLE_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" only for single-GPU dry runs
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if world > 1:
         # N ranks share this node's host cores: keep every rank's intra-op thread pool to its share (an oversubscribed OpenMP pool
@@ -840,6 +845,9 @@ def main():
         "roofline": roof,
         "roofline_graphdit": roof_dit,
         "rank_seconds": [round(t, 4) for t in rank_times],
+        "collectives": ({"backend": dist.get_backend(), "ranks": n_ranks, "forced_single_rank": world == 1,
+                         "issued": ["all_reduce(ones)", "barrier", "all_gather(rank seconds, f64)", "all_reduce(max, f64)",
+                                    "all_gather(int8 graph records)"]} if dist is not None else None),
     }
     if not args.no_cpu_baseline and world == 1:
         log("cpu baseline ...")

@@ -20,6 +20,21 @@ import torch
 import torch.distributed as dist
 
 
+def force_dist() -> bool:
+    """LLAMOLE_FORCE_DIST=1: take the collective code paths even with ONE rank (process group of size 1).  The single-rank shortcuts
+    below otherwise return before any collective is issued, so RCCL would meet this code for the first time on an 8-GPU node; the
+    GPU test suite drives bench.py / main.py eval / the helpers below through backend "nccl" with one rank this way."""
+    import os
+    return os.environ.get("LLAMOLE_FORCE_DIST") == "1"
+
+
+def _solo(group=None) -> bool:
+    """True when there is nothing to exchange: no process group, or one rank and the collectives are not forced."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and not force_dist()
+
+
 def shard_range(n_items: int, rank: int, world: int) -> range:
     """Contiguous, balanced shard of ``range(n_items)`` (first ``n % world`` ranks get one extra)."""
     q, r = divmod(n_items, world)
@@ -54,9 +69,9 @@ def unpack_graphs(rec: torch.Tensor, max_nodes: int):
 
 def all_gather_graphs(mols, max_nodes: int, n_total: int, device=None, group=None):
     """All ranks end up with the molecules of all prompts, in global prompt order."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if _solo(group):
         return list(mols)
+    world = dist.get_world_size(group)
     cap = (n_total + world - 1) // world
     rec = pack_graphs(mols, max_nodes, cap)
     if device is not None:
@@ -71,9 +86,9 @@ def all_gather_graphs(mols, max_nodes: int, n_total: int, device=None, group=Non
 
 def all_gather_topk(idx: torch.Tensor, prob: torch.Tensor, group=None):
     """Retro phase: gather per-rank candidate scores ([G_local,k] int32 / f32, equal G_local on every rank)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if _solo(group):
         return idx, prob
+    world = dist.get_world_size(group)
     bi = [torch.empty_like(idx) for _ in range(world)]
     bp = [torch.empty_like(prob) for _ in range(world)]
     dist.all_gather(bi, idx.contiguous(), group=group)
@@ -86,7 +101,7 @@ def allreduce_gradients(params, bucket_bytes: int = 64 << 20, group=None) -> int
     into flat buckets of up to ``bucket_bytes`` per dtype and each bucket is ONE all-reduce (RCCL over xGMI under backend
     "nccl", gloo in the CPU tests).  Llamole's trainable set (LoRA adapter + connectors) is tens of MB: one or two direct
     all-reduces, not a per-tensor stream of small ones.  Returns the number of collectives issued (0 when not distributed)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _solo(group):
         return 0
     world = dist.get_world_size(group)
     # The bucket layout must be the SAME on every rank, so it is built from the fixed list of trainable parameters, never from
@@ -157,13 +172,14 @@ class WorkQueue:
     no process group) it degenerates to ``range(n_items)``."""
 
     def __init__(self, n_items: int, rank: int = 0, world: int = 1, key: str = "llamole_work", port_offset: int = 17,
-                 store=None, port: Optional[int] = None, timeout_s: float = 600.0):
+                 store=None, port: Optional[int] = None, timeout_s: Optional[float] = None):
         """``port``: TCP port of the counter's store (default: env LLAMOLE_QUEUE_PORT, else MASTER_PORT + ``port_offset``);
         ``store``: an existing ``torch.distributed`` store to use instead (e.g. a ``PrefixStore`` over the process group's)."""
         self.n, self.rank, self.world, self.key = int(n_items), rank, world, key
         self._local = 0
         self.store = store
-        self.timeout_s = float(timeout_s)
+        import os
+        self.timeout_s = float(timeout_s if timeout_s is not None else os.environ.get("LLAMOLE_QUEUE_TIMEOUT_S", 1800.0))
         if world > 1 and store is None:
             import datetime
             import os
@@ -196,10 +212,20 @@ class WorkQueue:
         import time
         self.store.add(self.key + "_done", 1)
         if self.rank == 0:
+            # the deadline counts from the last sign of life, not from the moment rank 0 ran dry: a peer still working on a long last
+            # item (design + planning + rollbacks) bumps the heartbeat key from `beat()`; only `timeout_s` of silence is a dead peer
+            last_seen = (int(self.store.add(self.key + "_done", 0)), int(self.store.add(self.key + "_beat", 0)))
             deadline = time.monotonic() + self.timeout_s
-            while int(self.store.add(self.key + "_done", 0)) < self.world:
-                if time.monotonic() > deadline:
-                    done = int(self.store.add(self.key + "_done", 0))
-                    raise RuntimeError(f"WorkQueue: only {done} of {self.world} ranks reached the end of the queue within "
-                                       f"{self.timeout_s:.0f} s -- a peer has died or hangs")
+            while last_seen[0] < self.world:
+                now = (int(self.store.add(self.key + "_done", 0)), int(self.store.add(self.key + "_beat", 0)))
+                if now != last_seen:
+                    last_seen, deadline = now, time.monotonic() + self.timeout_s
+                elif time.monotonic() > deadline:
+                    raise RuntimeError(f"WorkQueue: only {now[0]} of {self.world} ranks reached the end of the queue and none has "
+                                       f"reported progress for {self.timeout_s:.0f} s -- a peer has died or hangs")
                 time.sleep(0.01)
+
+    def beat(self):
+        """Sign of life from a rank that is still working on an item it claimed (called by the eval driver between the phases of a batch)."""
+        if self.store is not None:
+            self.store.add(self.key + "_beat", 1)

@@ -118,6 +118,8 @@ def run_molqa(model, tokenizer, records: List[dict], cutoff_len: int, batch_size
         ids, mask, props = encode_batch(tokenizer, [records[i] for i in idxs], cutoff_len)
         info = model.generate(input_ids=ids.to(dev), attention_mask=mask.to(dev), molecule_properties=props.to(dev),
                               do_molecular_design=True, do_retrosynthesis=False, rollback=True, **gen_kwargs)
+        if work_queue is not None:
+            work_queue.beat()
         try:
             ms, st = model.graph_decoder.last_run_ms()
             dit_ms, dit_steps = dit_ms + ms, dit_steps + st
@@ -138,6 +140,8 @@ def run_molqa(model, tokenizer, records: List[dict], cutoff_len: int, batch_size
             info = model.generate(input_ids=ids.to(dev), attention_mask=mask.to(dev), do_molecular_design=False,
                                   do_retrosynthesis=True, input_smiles_list=smiles, expansion_topk=expansion_topk,
                                   iterations=iterations, max_planning_time=max_planning_time, **gen_kwargs)
+            if work_queue is not None:
+                work_queue.beat()
             for j in range(len(idxs)):
                 rec = results[lo + j]
                 plan = info["retro_plan_dict"][rec["llm_smiles"]]
@@ -152,7 +156,8 @@ def run_molqa(model, tokenizer, records: List[dict], cutoff_len: int, batch_size
     stats = {"n_prompts": n_mine, "design_s": t1 - t0, "retro_s": t2 - t1,
              "molecules_per_s": n_mine / max(t1 - t0, 1e-9),
              "denoise_steps_per_s": (1e3 * dit_steps / dit_ms) if dit_ms > 0 else None}
-    if world > 1:
+    from .distributed import force_dist
+    if world > 1 or (force_dist() and torch.distributed.is_initialized()):
         import torch.distributed as dist
         gathered = [None] * world
         dist.all_gather_object(gathered, results)
@@ -194,7 +199,8 @@ def run_eval(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> Di
     from .modeling_llamole import GraphLLMForCausalMLM
     model_args, data_args, training_args, finetuning_args, generating_args = load_yaml_args(config_path, overrides)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    from .distributed import force_dist
+    if world > 1 or force_dist():
         import torch.distributed as dist
         # one process per GPU; LLAMOLE_BENCH_SHARED_GPU=1 / LLAMOLE_DIST_BACKEND=gloo are the single-GPU dry-run switches of bench.py (tests)
         n_dev = torch.cuda.device_count()
@@ -203,7 +209,13 @@ def run_eval(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> Di
             raise RuntimeError(f"rank {rank} needs GPU {local}, this node shows {n_dev}")
         torch.cuda.set_device(local % n_dev)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("LLAMOLE_DIST_BACKEND", "nccl"))
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = os.environ.get("LLAMOLE_DIST_BACKEND", "nccl")
+        if not dist.is_initialized():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local % n_dev))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
     tokenizer = load_tokenizer(model_args)
     gen_kwargs = generating_args.to_dict()
     gen_kwargs["eos_token_id"] = [tokenizer.eos_token_id] + special_token_ids(tokenizer, model_args.new_special_tokens)

@@ -69,8 +69,23 @@ def build_retro_step(args, graph_decoder, device, rank: int):
     from .graph_data import GraphBatch
     llm = e2e.build_llm(args.llm, device, torch.bfloat16)
     enc, pred, sd_pred = build_gin_pair(device, args.out_dim)
-    # scripted chemistry: every template yields one two-reactant outcome derived from (template, product)
-    pred.template_runner = lambda t, s: [f"M{zlib.crc32((t + s).encode()) % 997}.M{zlib.crc32((s + t).encode()) % 997}"]
+    # Scripted chemistry (rdkit / rdchiral are in neither image) with a purchasable set, so that the searches PLAN something: molecule names
+    # carry their fate.  `S<D>d<d>_*` lies on a route of D reactions at depth d: every template turns it into one purchasable building
+    # block `B*` plus the next intermediate -- or two building blocks at depth D - 1 -- so the search closes after exactly D expansions
+    # (early exit, route extraction and reaction-list assembly all run inside the timed region).  `U_d<d>_*` decomposes into two
+    # non-purchasable molecules for ever: that search spends its whole expansion budget and fails, like the reference's 30 s / 100
+    # iteration budget running dry (eval/workflow.py:171-173).  Half of a step's targets are of each kind; D cycles through 2, 3, 4.
+    def template_runner(t, s):
+        h = zlib.crc32((t + s).encode())
+        if s[0] == "S":
+            D, d = int(s[1]), int(s[3])
+            if d + 1 >= D:
+                return [f"B{h % 50}.B{(h >> 8) % 50}"]
+            return [f"B{h % 50}.S{D}d{d + 1}_{h % 9973}"]
+        d = int(s[3]) if s[0] == "U" else 0
+        return [f"U_d{d + 1}_{h % 9973}.U_d{d + 1}_{(h >> 8) % 9973}"]
+    pred.template_runner = template_runner
+    purchasable = {f"B{i}" for i in range(50)}
     # the orchestrator only asks its graph decoder for the condition width and for SMILES validity (rdkit: scripted here); the reverse
     # diffusion itself is called on the real engine below
     orch, tok = e2e.build_orchestrator(llm, types.SimpleNamespace(text_input_size=768, check_valid=lambda s: True), device)
@@ -82,7 +97,7 @@ def build_retro_step(args, graph_decoder, device, rank: int):
     accel = orch.enable_mi355x_decode()
     orch.constant_language_cost_shortcut = bool(getattr(args, "retro_constant_value", False))      # opt-in; default: every value forward runs
     T = args.targets
-    kw = dict(expansion_topk=args.topk, iterations=args.iterations, starting_mols={"<none>"}, max_planning_time=1e9, rollback=False,
+    kw = dict(expansion_topk=args.topk, iterations=args.iterations, starting_mols=purchasable, max_planning_time=1e9, rollback=False,
               design_text="Design", do_sample=True, temperature=0.6, top_p=0.9, max_new_tokens=args.retro_tokens,
               eos_token_id=[], pad_token_id=tok.pad_token_id)
     orch.retro_max_new_tokens = args.retro_tokens
@@ -119,14 +134,16 @@ def build_retro_step(args, graph_decoder, device, rank: int):
         _, _, cond = orch.design_hidden(prompt, mask, None, **dkw)
         mols, _ = graph_decoder.generate_graphs(props, cond.float(), -200.0, n_nodes=n_nodes, seed=1000 * rank + i)
         t1 = time.perf_counter()
-        targets = [f"TARGET{rank}_{i}_{j}" for j in range(T)]
+        targets = [(f"S{2 + (j // 2) % 3}d0_{rank}_{i}_{j}" if j % 2 == 0 else f"U_d0_{rank}_{i}_{j}") for j in range(T)]
         orch.value_tokens_forwarded = 0
         routes = orch.retrosynthesize_many([None] * T, targets, **kw)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         rec = torch.zeros(T, 3)
         for j, r in enumerate(routes):
-            rec[j] = torch.tensor([float(bool(r["success"])), float(r["route_length"] or 0), float(r["cost"] or 0.0)])
+            cost = r["cost"]           # exp(-cost) per reaction of the extracted route (SynRoute.get_reaction_list): the record keeps their product
+            prob = float(torch.tensor(cost, dtype=torch.float64).prod()) if isinstance(cost, (list, tuple)) and cost else float(cost or 0.0)
+            rec[j] = torch.tensor([float(bool(r["success"])), float(r["route_length"] or 0), prob])
         value_s = sum(a.elapsed_time(b) for a, b in spans) * 1e-3
         del spans[:]
         last.update(design_s=t1 - t0, retro_s=t2 - t1, value_forward_s=value_s, value_tokens=getattr(orch, "value_tokens_forwarded", 0),
@@ -138,7 +155,9 @@ def build_retro_step(args, graph_decoder, device, rank: int):
     info = {"llm": args.llm, "llm_weights": "random-init (no network)", "targets_per_gpu": T, "max_expansions_per_search": args.iterations,
             "analysis_tokens_per_expansion": args.retro_tokens, "expansion_topk": args.topk, "templates": args.out_dim,
             "chemistry": "scripted (rdkit / rdchiral are not in this image): product -> one of 64 seeded 32-atom graphs, "
-                         "(template, product) -> a two-reactant string",
+                         "(template, product) -> a two-reactant string; 50 purchasable building blocks; every second target has a route of "
+                         "2 / 3 / 4 reactions (the search exits early and its route is extracted inside the timed region), the others have none "
+                         "and spend the whole expansion budget",
             "search": "lock-step A* over the batch: batched GIN encode / LLM decode / predictor + top-k / value forward per expansion round "
                       "(reference: searches one after the other, one LLM forward per new tree node)",
             "value_estimates": ("constant-cost shortcut (opt-in): the reference-compatible language cost is 15 for every molecule, returned without the "

@@ -44,7 +44,11 @@ def test_decode_fused_equals_unfused_at_full_size(name):
     gdec = GraphedDecoder(llm, use_graph=True, fused_cache=True)
     assert torch.equal(gdec.generate(prompt, mask, **kw), ref) and torch.equal(gdec.last_logits, ref_logits)
     # greedy == argmax of the logits the torch way (sampler kernel at V = 152064 / 128256)
-    assert int(ref[0, -1]) == int(torch.argmax(_last_but_one_logits(llm, ref)))
+    # -- exactly, on the logits the sampler was handed; and against a stock HF forward over the whole sequence up to a near-tie (the
+    # recomputed prefill rounds differently from the incremental decode: random-init Llama has top-2 margins below that)
+    assert int(ref[0, -1]) == int(torch.argmax(ref_logits[0].float()))
+    full = _last_but_one_logits(llm, ref)
+    assert float(full[int(ref[0, -1])]) >= float(full.max()) - 0.02 * float(full.abs().max()), (float(full[int(ref[0, -1])]), float(full.max()))
     gen = torch.Generator(device="cuda").manual_seed(9)
     s1 = gdec.generate(prompt, mask, max_new_tokens=8, do_sample=True, temperature=0.6, top_p=0.9, pad_token_id=0, generator=gen)
     gen.manual_seed(9)
