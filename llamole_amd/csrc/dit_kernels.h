@@ -4,6 +4,8 @@
 // X [B,N,16] / E [B,N,N,5], are never materialised): X int8 [B,N], E int8 [B,N,N];
 // -1 encodes the all-zero one-hot vector (masked node / masked pair / the z_T diagonal).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace ll {
@@ -27,6 +29,13 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, float4 o) 
     u.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
     u.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
     *reinterpret_cast<uint2 *>(p) = u;
+}
+
+// Load of data that ANOTHER CU may have written during this launch (dit_team.h: the persistent trajectory kernel): SC1 = L1-bypassing
+// load served by the XCD's L2 (relaxed agent-scope atomic load -> global_load ... sc1); the launch chain reads the same data plainly.
+template <bool SC1, typename T> __device__ __forceinline__ T ldm(const T *p) {
+    if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
 }
 
 // ------------------------------------------------------------------------------------------ x_embedder
@@ -340,11 +349,13 @@ __device__ __forceinline__ void attn_core(const bf16_t *Qs, const bf16_t *Ks, co
 // `ld(row, which, d0)` returns the 8 bf16 at columns [d0, d0 + 8) of this head's q (which = 0), k (1) or v (2) row: from
 // the qkv activation in global memory (attn_mfma_kernel) or from the LDS image the fused q|k|v GEMM left (qkv_attn_kernel);
 // `ohead` = o + first row of the sequence * H + head * HD.  Waves >= WPB of a larger workgroup must not enter.
-template <int NP, int HD, int WPB, typename LD>
+struct AttnBlockSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
+// `sync()` = barrier of the WPB waves that run the body (the whole workgroup in attn_mfma_kernel; the four I/O waves in dit_team.h)
+template <int NP, int HD, int WPB, typename LD, typename SYNC = AttnBlockSync>
 __device__ __forceinline__ void attn_mfma_body(LD ld, bf16_t *__restrict__ ohead, const float *__restrict__ qw,
                                                const float *__restrict__ qb, const float *__restrict__ kw,
                                                const float *__restrict__ kb, int N, int nv, int H, unsigned char *smraw_attn,
-                                               int wave, int lane) {
+                                               int wave, int lane, SYNC sync = SYNC()) {
     constexpr int QLD = HD + 8;           // padded row strides (elements)
     constexpr int PLD = NP + 8;
     constexpr int QK_ELEMS = NP * QLD;
@@ -436,9 +447,10 @@ __device__ __forceinline__ void attn_mfma_body(LD ld, bf16_t *__restrict__ ohead
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     } else {
-        __syncthreads();
+        sync();
     }
     if (PSEP && wave >= CW) return;
+    static_assert(PSEP || WPB == 1 || std::is_same<SYNC, AttnBlockSync>::value, "attn_core synchronises the whole workgroup when P aliases Q");
     attn_core<NP, HD, CW, PSEP>(Qs, Ks, Vt, Ps, ohead, N, nv, H, wave, lane);
 }
 
@@ -909,15 +921,15 @@ struct PostArgs {
     int update_state;
 };
 
-__global__ __launch_bounds__(256) void post_rows_kernel(PostArgs a) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);  // (p*B + b)*N + i
+// one wave per decoder row `row` = (p*B + b)*N + i; s_known >= 0: the reverse step (the caller knows it), else read from the arguments
+template <bool SC1>
+__device__ __forceinline__ void post_rows_body(const PostArgs &a, int row, int lane, int s_known) {
     const int N = a.N, F = a.F, B = a.B;
-    if (row >= 2 * B * N) return;
-    const int lane = threadIdx.x & 63;
+    if (row < 0 || row >= 2 * B * N) return;
     const int p = row / (B * N);
     const int bi = row - p * B * N;
     const int b = bi / N, i = bi - b * N;
-    const int s = a.rowvec ? a.rowvec[b] : *a.step_ptr;
+    const int s = s_known >= 0 ? s_known : (a.rowvec ? a.rowvec[b] : *a.step_ptr);
     const int ci = p == 0 ? b : B;
     const float *ss = a.modo + ((int64_t)s * (B + 1) + ci) * (2 * F);
     float *r = a.out + (int64_t)row * F;
@@ -927,7 +939,7 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostArgs a) {
 #pragma unroll
     for (int e = 0; e < MAXF; ++e) {
         const int f = lane + e * 64;
-        v[e] = f < F ? r[f] : 0.f;
+        v[e] = f < F ? ldm<SC1>(r + f) : 0.f;
         sh[e] = f < F ? ss[f] : 0.f;
         sc[e] = f < F ? ss[F + f] : 0.f;
         sm += v[e];
@@ -948,7 +960,7 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostArgs a) {
     }
     // atom classes live in lanes 0..15 of chunk 0
     const int st_in = (s + 1) & 1;
-    const int xi = a.X[((int64_t)st_in * B + b) * N + i];
+    const int xi = ldm<SC1>(a.X + ((int64_t)st_in * B + b) * N + i);
     const bool valid = i < a.n_nodes[b];
     if (lane < 16) {
         const float l = valid ? ((xi == lane ? 1.f : 0.f) + v[0]) : 0.f;
@@ -967,19 +979,23 @@ __global__ __launch_bounds__(256) void post_rows_kernel(PostArgs a) {
     }
 }
 
-__global__ __launch_bounds__(64) void post_pairs_kernel(PostArgs a) {
-    const int i = blockIdx.x, b = blockIdx.y;
+__global__ __launch_bounds__(256) void post_rows_kernel(PostArgs a) {
+    post_rows_body<false>(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, -1);
+}
+
+// one wave per (graph b, node i); lane j = partner node
+template <bool SC1>
+__device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b, int j, int s_known) {
     const int N = a.N, F = a.F, B = a.B;
-    const int j = threadIdx.x;  // lane = partner node
-    const int s = *a.step_ptr;
+    const int s = s_known >= 0 ? s_known : *a.step_ptr;
     const int nv = a.n_nodes[b];
     const int st_in = (s + 1) & 1, st_out = s & 1;
     const int8_t *Xin = a.X + ((int64_t)st_in * B + b) * N;
     const int8_t *Ein = a.E + ((int64_t)st_in * B + b) * N * N;
     const bool vi = i < nv, vj = j < nv && j < N;
-    const int xi = Xin[i];
-    const int eij = j < N ? (int)Ein[i * N + j] : -1;
-    const int eji = j < N ? (int)Ein[j * N + i] : -1;
+    const int xi = ldm<SC1>(Xin + i);
+    const int eij = j < N ? (int)ldm<SC1>(Ein + i * N + j) : -1;
+    const int eji = j < N ? (int)ldm<SC1>(Ein + j * N + i) : -1;
     const float beta = a.betas[s + 1], ab_s = a.alphas_bar[s], ab_t = a.alphas_bar[s + 1];
     const bool guided = (a.guide != 1.0f);
     const unsigned long long seed = a.seed_ptr ? *a.seed_ptr : 0ull;
@@ -994,7 +1010,7 @@ __global__ __launch_bounds__(64) void post_pairs_kernel(PostArgs a) {
             const float *zi = a.out + ((((int64_t)p * B + b) * N + i) * F) + XD + ED * j;
             const float *zj = a.out + ((((int64_t)p * B + b) * N + j) * F) + XD + ED * i;
 #pragma unroll
-            for (int k = 0; k < ED; ++k) l[k] = 0.5f * (((eij == k ? 1.f : 0.f) + zi[k]) + ((eji == k ? 1.f : 0.f) + zj[k]));
+            for (int k = 0; k < ED; ++k) l[k] = 0.5f * (((eij == k ? 1.f : 0.f) + ldm<SC1>(zi + k)) + ((eji == k ? 1.f : 0.f) + ldm<SC1>(zj + k)));
         } else {
 #pragma unroll
             for (int k = 0; k < ED; ++k) l[k] = 0.f;
@@ -1045,7 +1061,7 @@ __global__ __launch_bounds__(64) void post_pairs_kernel(PostArgs a) {
             float pc[2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const float px = a.predX[((((int64_t)p * B + b) * N + i) * XD) + c];
+                const float px = ldm<SC1>(a.predX + ((((int64_t)p * B + b) * N + i) * XD) + c);
                 const float spx = row16_sum(px);
                 float r = a.x_marg[c] * spx;
 #pragma unroll
@@ -1096,7 +1112,7 @@ __global__ __launch_bounds__(64) void post_pairs_kernel(PostArgs a) {
 #pragma unroll
             for (int k = 0; k < ED; ++k) {
                 const float sek = ((xi >= 0) ? a.u_ex[k * XD + xi] : 0.f) + emsum;
-                const float r = px[k] + a.e_marg[k] * SEt[p];
+                const float r = ldm<SC1>(px + k) + a.e_marg[k] * SEt[p];
                 const float right = ab_s * e5[p][k] + (1.f - ab_s) * r;
                 const float et = (eij == k) ? 1.f : 0.f;
                 const float left = (1.f - beta) * et + beta * sek;
@@ -1179,6 +1195,8 @@ __global__ __launch_bounds__(64) void post_pairs_kernel(PostArgs a) {
         }
     }
 }
+
+__global__ __launch_bounds__(64) void post_pairs_kernel(PostArgs a) { post_pairs_body<false>(a, blockIdx.x, blockIdx.y, threadIdx.x, -1); }
 
 // ------------------------------------------------------------------------------------------ z_T
 // sample_discrete_feature_noise (diffusion_utils.py:495-518): limit marginals, strict upper triangle kept,

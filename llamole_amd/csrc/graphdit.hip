@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "dit_kernels.h"
+#include "dit_team.h"
 
 namespace ll {
 
@@ -157,6 +158,12 @@ struct DitEngine {
     DevBuf wqkvp;                // [depth][3H x H] q|k|v weights in MFMA A-operand order (pack_mfma16), bf16 mode
     DevBuf wfc1p, wfc2p;         // [depth][Hm x H], [depth][H x Hm]: the MLP weights packed the same way (gemm_m64_kernel, gemm_xw_kernel)
     DevBuf wprojp;               // [depth][H x H]
+    DevBuf wout1p, wout2p;       // output layer weights in the same order (dit_team.h)
+    DevBuf team_ctl;             // team::Ctl of the persistent trajectory kernel
+    int team_mode = -1;          // dit_team_kernel under ll_dit_run: -1 = whenever eligible and not in overlap mode, 0 = never, 1 = also under the
+                                 // single-step entry points (step / denoise / step_probs: the parity taps of the team path)
+    int team_last = 0;           // the last denoiser call ran on the team kernel
+    int team_step_s = -1;        // the reverse step the single-step entry points are about to run (the team kernel takes it as an argument)
     std::vector<const void *> packed_keys;   // row-major weights registered with register_packed_weight
     int xw_gemm = 0;             // fc1 / fc2 on gemm_xw_kernel: 0 = never (the fixed default: a seed fixes the molecules on every box), 1 = whenever
                                  // eligible, -1 = whichever ll_dit_begin measures faster on this device (opt-in: env LL_DIT_CALIBRATE=1 or
@@ -439,11 +446,84 @@ static int pick_splits(int M2, int H, int K) {
     return s;
 }
 
+// ------------------------------------------------------------------------------------------ persistent trajectory kernel (dit_team.h)
+static bool team_eligible(const DitEngine *e) {
+    const LLDitConfig &c = e->cfg;
+    const int N = c.max_nodes, F = LL_XDIM + LL_EDIM * N;
+    return c.dtype == LL_BF16 && c.hidden == 1024 && c.heads * 64 == c.hidden && c.mlp_hidden == 4 * c.hidden &&
+           N <= team::NP && F % 16 == 0 && e->wqkvp.p && e->wprojp.p && e->wfc1p.p && e->wfc2p.p && e->wout1p.p && e->wout2p.p && e->rowvec == nullptr;
+}
+static bool team_wanted(const DitEngine *e, bool trajectory) {
+    if (e->team_mode == 0 || e->overlap || !team_eligible(e)) return false;
+    return trajectory || e->team_mode == 1;
+}
+template <int H> static int team_launch_t(DitEngine *e, const team::Args &a, hipStream_t st) {
+    constexpr int lds = team::Geom<H>::PANEL + team::FLAG_BYTES;
+    static bool attr = false;
+    if (!attr) {
+        LL_HIP(hipFuncSetAttribute((const void *)team::dit_team_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL((team::dit_team_kernel<H>), dim3(8 * team::TEAM), dim3(team::THREADS), lds, st, a);
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+// reverse steps s_first, s_first - 1, ... (n_steps) of every graph of the batch; run_post = 0 stops after the output layer (e->outF holds the
+// decoder output, as after denoise_body)
+static int team_launch(DitEngine *e, int s_first, int n_steps, int run_post, const float *qx, const float *qe, hipStream_t st) {
+    const LLDitConfig &c = e->cfg;
+    const int H = c.hidden;
+    LL_TRY(e->team_ctl.ensure(sizeof(team::Ctl)));
+    LL_HIP(hipMemsetAsync(e->team_ctl.p, 0, sizeof(team::Ctl), st));
+    team::Args a;
+    memset(&a, 0, sizeof(a));
+    a.B = e->B; a.N = c.max_nodes; a.F = e->F; a.T = c.T; a.L = c.depth; a.heads = c.heads;
+    a.s_first = s_first; a.n_steps = n_steps; a.run_post = run_post; a.guide = c.guide_scale;
+    a.wqkv = e->wqkvp.as<bf16_t>(); a.wproj = e->wprojp.as<bf16_t>(); a.wfc1 = e->wfc1p.as<bf16_t>(); a.wfc2 = e->wfc2p.as<bf16_t>();
+    a.wout1 = e->wout1p.as<bf16_t>(); a.wout2 = e->wout2p.as<bf16_t>();
+    const DitEngine::BlockW &b0 = e->bw[0];
+    a.proj_b = b0.proj_b; a.fc1_b = b0.fc1_b; a.fc2_b = b0.fc2_b; a.qn_w = b0.qn_w; a.qn_b = b0.qn_b; a.kn_w = b0.kn_w; a.kn_b = b0.kn_b;
+    a.blk_stride = c.depth > 1 ? (int64_t)(e->bw[1].proj_b - b0.proj_b) : 0;
+    a.out1_b = e->b_out1; a.out2_b = e->b_out2; a.WxT = e->wxT.as<float>(); a.xe_w = e->xe_w; a.xe_b = e->xe_b;
+    a.modtab = e->modtab.as<float>(); a.modo = e->modo.as<float>();
+    a.x32 = e->x32.as<float>(); a.xa = e->xa.as<bf16_t>(); a.qkv = e->qkv.as<bf16_t>(); a.ao = e->attn_o.as<bf16_t>();
+    a.h1 = e->h1.as<bf16_t>(); a.ho = e->ho.as<bf16_t>(); a.ybuf = e->ybuf.as<float>(); a.slab_stride = (int64_t)e->M2p * H; a.outF = e->outF.as<float>();
+    PostArgs &p = a.post;
+    p.out = e->outF.as<float>(); p.modo = e->modo.as<float>(); p.predX = e->predX.as<float>(); p.pxe = e->pxe.as<float>();
+    p.X = e->X.as<int8_t>(); p.E = e->E.as<int8_t>(); p.n_nodes = e->n_nodes.as<int>();
+    p.x_marg = e->t_xm(); p.e_marg = e->t_em(); p.u_xe = e->t_uxe(); p.u_ex = e->t_uex(); p.betas = e->t_beta(); p.alphas_bar = e->t_ab();
+    p.qx = qx; p.qe = qe; p.seed_ptr = e->seed_ptr(); p.step_ptr = e->step_scalar(); p.rowvec = nullptr;
+    p.B = e->B; p.N = c.max_nodes; p.F = e->F; p.T = c.T; p.guide = c.guide_scale;
+    p.pX_out = nullptr; p.pE_out = nullptr; p.logX = nullptr; p.logE = nullptr; p.update_state = 1;
+    a.ctl = e->team_ctl.as<team::Ctl>();
+    e->team_last = 1;
+    LL_CHECK(H == 1024, "dit_team_kernel is instantiated for hidden = 1024");
+    return team_launch_t<1024>(e, a, st);
+}
+// after the stream has drained: did every team complete?
+static int team_check(DitEngine *e) {
+    team::Ctl h;
+    LL_HIP(hipMemcpy(&h, e->team_ctl.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.error) {
+        set_error("dit_team_kernel: %s%s (census %u %u %u %u %u %u %u %u)", (h.error & 1) ? "a bounded wait ran out " : "",
+                  (h.error & 2) ? "more than 32 workgroups reported on one XCC" : "", h.census[0][0], h.census[1][0], h.census[2][0],
+                  h.census[3][0], h.census[4][0], h.census[5][0], h.census[6][0], h.census[7][0]);
+        return LL_EHIP;
+    }
+    return LL_OK;
+}
+
 // denoiser on the current state for both passes -> e->outF [2][B][N][F] (decoder output before LN0/modulate)
 static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap_layer) {
     const LLDitConfig &c = e->cfg;
     const int H = c.hidden, Hm = c.mlp_hidden, M2 = e->M2, dt = c.dtype;
     const bool bf = dt == LL_BF16;
+    e->team_last = 0;
+    if (e->team_step_s >= 0 && hidden_tap == nullptr && team_wanted(e, false)) {    // parity taps of the team path: one step, posterior by the launch chain's kernels
+        LL_TRY(team_launch(e, e->team_step_s, 1, 0, nullptr, nullptr, st));
+        LL_HIP(hipStreamSynchronize(st));                                               // (test entry points: report a protocol error at once)
+        return team_check(e);
+    }
     if (e->rowvec == nullptr && g_stage_mod && e->step_host < 0) {
         const int64_t row_floats = (int64_t)(e->B + 1) * c.depth * 6 * H;
         hipLaunchKernelGGL(stage_mod_kernel, dim3(256), dim3(256), 0, st, e->modtab.as<float>(), e->modcur.as<float>(), e->step_ptr(), row_floats);
@@ -688,7 +768,14 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
             if (e->wqkvp.p) reg(p + "attn.qkv.weight", e->wqkvp.as<bf16_t>() + (size_t)3 * H * H * l);
         }
         if (xw_eligible(e)) e->splits_x = Hm / xw_slice(Hm);
+        if (e->F % 16 == 0) {      // output layer in the same order: the persistent trajectory kernel streams it (dit_team.h)
+            CR(e->wout1p.ensure(perh * 2));
+            CR(e->wout2p.ensure((size_t)e->F * H * 2));
+            CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw("output_layer.xedecoder.fc1.weight")), e->wout1p.as<bf16_t>(), H, H, 0));
+            CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw("output_layer.xedecoder.fc2.weight")), e->wout2p.as<bf16_t>(), e->F, H, 0));
+        }
     }
+    if (const char *v = getenv("LL_DIT_TEAM")) e->team_mode = atoi(v) < 0 ? -1 : (atoi(v) ? 1 : 0);
     if (const char *v = getenv("LL_DIT_CALIBRATE")) e->xw_gemm = atoi(v) ? -1 : 0;
     if (const char *v = getenv("LL_XW_GEMM")) e->xw_gemm = atoi(v);
     if (const char *v = getenv("LL_XW_FC2")) e->xw_fc2 = atoi(v) ? 1 : 0;
@@ -717,7 +804,7 @@ int ll_dit_destroy(void *handle) {
     DevBuf *bufs[] = {&e->wop, &e->wxT, &e->wycat, &e->yw0, &e->yb0, &e->tables, &e->n_nodes, &e->X, &e->E, &e->x32,
                       &e->xa, &e->qkv, &e->attn_o, &e->ybuf, &e->h1, &e->ho, &e->outF, &e->ct_in, &e->ct_h, &e->ct,
                       &e->zy, &e->cy, &e->txt_op, &e->ctxt, &e->ynan, &e->tnan, &e->c32, &e->ca, &e->m1, &e->modtab,
-                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wqkvp, &e->wfc1p, &e->wfc2p, &e->wprojp, &e->steps_tab};
+                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wqkvp, &e->wfc1p, &e->wfc2p, &e->wprojp, &e->steps_tab, &e->wout1p, &e->wout2p, &e->team_ctl};
     for (const void *k : e->packed_keys) register_packed_weight(k, nullptr);
     for (DevBuf *b : bufs) b->release();
     if (e->own) (void)hipStreamDestroy(e->own);
@@ -816,7 +903,8 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
     e->M2p = round_up(e->M2, 128);
     e->splits_h = pick_splits(e->M2, H, H);
     e->splits_m = pick_splits(e->M2, H, Hm);
-    const int smax = std::max(std::max(e->splits_h, e->splits_m), e->splits_x);
+    // (the persistent trajectory kernel writes four K-part slabs for proj and fc2 at any batch)
+    const int smax = std::max(std::max(std::max(e->splits_h, e->splits_m), e->splits_x), 4);
     const int Mc = (T + 1) * (B + 1), Mcp = round_up(Mc, 128);   // rows 0..T-1: reverse steps (t = s+1); row T: t = 0 (training)
     const int Tp = round_up(T + 1, 128), Bp = round_up(B, 128);
     const size_t M2p = e->M2p;
@@ -946,7 +1034,10 @@ int ll_dit_step(void *handle, int s, const float *qx, const float *qe, uint64_t 
     LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), s, e->seed_ptr(), (unsigned long long)seed);
     LL_LAUNCH_CHECK();
-    LL_TRY(denoise_body(e, st, nullptr, -1));
+    e->team_step_s = s;
+    const int rc_body = denoise_body(e, st, nullptr, -1);
+    e->team_step_s = -1;
+    LL_TRY(rc_body);
     LL_TRY(posterior_launch(e, qx, qe, 1, nullptr, nullptr, nullptr, nullptr, st));
     e->state_half = s & 1;
     e->state_both = false;
@@ -961,7 +1052,10 @@ int ll_dit_denoise(void *handle, int s, float *logX, float *logE, float *hidden,
     PanelScope panel(e);
     LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), s, e->seed_ptr(), 0ull);
-    LL_TRY(denoise_body(e, st, hidden, tap_layer));
+    e->team_step_s = s;
+    const int rc_body = denoise_body(e, st, hidden, tap_layer);
+    e->team_step_s = -1;
+    LL_TRY(rc_body);
     return posterior_launch(e, nullptr, nullptr, 0, nullptr, nullptr, logX, logE, st);
 }
 
@@ -993,7 +1087,10 @@ int ll_dit_step_probs(void *handle, int s, float *pX, float *pE, void *stream) {
     PanelScope panel(e);
     LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), s, e->seed_ptr(), 0ull);
-    LL_TRY(denoise_body(e, st, nullptr, -1));
+    e->team_step_s = s;
+    const int rc_body = denoise_body(e, st, nullptr, -1);
+    e->team_step_s = -1;
+    LL_TRY(rc_body);
     return posterior_launch(e, nullptr, nullptr, 0, pX, pE, nullptr, nullptr, st);
 }
 
@@ -1021,6 +1118,22 @@ int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream) {
     // workgroups need a whole CU's LDS and keep that stream's workgroups off the CU (and wait for a drained CU themselves), so the
     // panel GEMMs take the 48 KB LDS-DMA ring there: 1.36 instead of 1.17 ms per step alone, but +1.2 % molecules/s end to end
     PanelScope panel(e);      // restored on every exit path: other engines / the GIN path keep the panel kernel
+    if (team_wanted(e, true)) {
+        // the whole trajectory is ONE launch of the persistent per-XCD kernel (dit_team.h); the step index and the state halves are
+        // walked inside it exactly as the launch loop below walks them
+        LL_HIP(hipEventRecord(e->ev_t0, st));
+        LL_TRY(team_launch(e, T - 1, T, 1, nullptr, nullptr, st));
+        hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), -1, e->seed_ptr(), (unsigned long long)seed);
+        LL_HIP(hipEventRecord(e->ev_t1, st));
+        e->last_steps = T;
+        e->timed = true;
+        e->state_half = 0;
+        e->state_both = false;
+        LL_HIP(hipEventRecord(e->ev_out, st));
+        LL_HIP(hipStreamWaitEvent(caller, e->ev_out, 0));
+        return LL_OK;
+    }
+    e->team_last = 0;
     if (use_graph == LL_DIT_RUN_AUTO) {      // env LL_DIT_RUN_MODE = graph | launches overrides the library's choice (e.g. a host too busy to feed launches)
         static const int forced = [] {
             const char *v = getenv("LL_DIT_RUN_MODE");
@@ -1104,6 +1217,7 @@ int ll_dit_set_option(void *handle, int option, int value) {
             }
             e->xw_gemm = value < 0 ? -1 : (value ? 1 : 0);
             break;
+        case LL_DIT_OPT_TEAM: e->team_mode = value < 0 ? -1 : (value ? 1 : 0); break;
         default: LL_CHECK(false, "ll_dit_set_option: unknown option %d", option);
     }
     return LL_OK;
@@ -1163,6 +1277,7 @@ int ll_dit_last_run_ms(void *handle, float *ms, int *steps) {
     LL_HIP(hipEventSynchronize(e->ev_t1));
     LL_HIP(hipEventElapsedTime(ms, e->ev_t0, e->ev_t1));
     *steps = e->last_steps;
+    if (e->team_last) LL_TRY(team_check(e));
     return LL_OK;
 }
 

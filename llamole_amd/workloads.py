@@ -70,18 +70,21 @@ def build_retro_step(args, graph_decoder, device, rank: int):
     llm = e2e.build_llm(args.llm, device, torch.bfloat16)
     enc, pred, sd_pred = build_gin_pair(device, args.out_dim)
     # Scripted chemistry (rdkit / rdchiral are in neither image) with a purchasable set, so that the searches PLAN something: molecule names
-    # carry their fate.  `S<D>d<d>_*` lies on a route of D reactions at depth d: every template turns it into one purchasable building
-    # block `B*` plus the next intermediate -- or two building blocks at depth D - 1 -- so the search closes after exactly D expansions
-    # (early exit, route extraction and reaction-list assembly all run inside the timed region).  `U_d<d>_*` decomposes into two
-    # non-purchasable molecules for ever: that search spends its whole expansion budget and fails, like the reference's 30 s / 100
-    # iteration budget running dry (eval/workflow.py:171-173).  Half of a step's targets are of each kind; D cycles through 2, 3, 4.
+    # carry their fate.  `S<D>d<d>_*` lies on a route of D reactions at depth d: EVERY template turns it into the same pair -- one purchasable
+    # building block `B*` plus the next intermediate, or two building blocks at depth D - 1 -- which sample_templates merges into one
+    # candidate (reactant sets are de-duplicated, graph_predictor/model.py:190-228), so the search closes after exactly D expansions
+    # (early exit, route extraction and reaction-list assembly all run inside the timed region).  `U_d<d>_*` decomposes into a different
+    # pair of non-purchasable molecules under every template, for ever: that search spends its whole expansion budget on a widening tree
+    # and fails, like the reference's 30 s / 100 iteration budget running dry (eval/workflow.py:171-173).  Half of a step's targets are of
+    # each kind; D cycles through 2, 3, 4.
     def template_runner(t, s):
-        h = zlib.crc32((t + s).encode())
         if s[0] == "S":
+            h = zlib.crc32(s.encode())
             D, d = int(s[1]), int(s[3])
             if d + 1 >= D:
                 return [f"B{h % 50}.B{(h >> 8) % 50}"]
             return [f"B{h % 50}.S{D}d{d + 1}_{h % 9973}"]
+        h = zlib.crc32((t + s).encode())
         d = int(s[3]) if s[0] == "U" else 0
         return [f"U_d{d + 1}_{h % 9973}.U_d{d + 1}_{(h >> 8) % 9973}"]
     pred.template_runner = template_runner
