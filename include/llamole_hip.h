@@ -152,11 +152,12 @@ int ll_dit_set_overlap(void *handle, int on);
  * with -1 low-order bits (and through a near-tie of the sampling race, molecules) may differ from run to run, and that ll_dit_begin
  * blocks the host once per batch size. */
 /* LL_DIT_OPT_TEAM = the persistent per-XCD trajectory kernel (csrc/dit_team.h: one launch per trajectory, one graph per XCD, weights
- * streamed through a register FIFO): -1 (default) = ll_dit_run uses it whenever the engine is eligible (bf16, hidden 1024 with
- * 64-wide heads, mlp_hidden = 4 hidden, <= 32 nodes, F a multiple of 16) and not in overlap mode, 0 = never (the launch chain),
- * 1 = also under ll_dit_step / ll_dit_denoise / ll_dit_step_probs (one step of the team kernel, posterior by the chain's kernels):
- * the parity taps of that path.  The team kernel sums K in another order than the chain: within one mode a seed fixes the molecules,
- * and in team mode a graph's trajectory does not depend on its batch or batch size (every graph is processed alone). */
+ * streamed through a register FIFO).  OPT-IN: 0 (default) = never -- the launch chain is faster at every batch measured (round 4:
+ * 1.64 vs 1.50 ms per step at batch 8, 1.37 vs 1.03 at batch 2; DESIGN.md section 4 says why); -1 = ll_dit_run uses it whenever the
+ * engine is eligible (bf16, hidden 1024 with 64-wide heads, mlp_hidden = 4 hidden, 16 | 32 nodes) and not in overlap mode; 1 = also
+ * under ll_dit_step / ll_dit_denoise / ll_dit_step_probs (one step of the team kernel, posterior by the chain's kernels): the parity
+ * taps of that path.  Also env LL_DIT_TEAM.  The team kernel sums K in another order than the chain: within one mode a seed fixes
+ * the molecules, and in team mode a graph's trajectory does not depend on the batch around it (every graph is processed alone). */
 enum { LL_DIT_OPT_OVERLAP = 0, LL_DIT_OPT_GENERIC_ATTN = 1, LL_DIT_OPT_FUSED_QKV_ATTN = 2, LL_DIT_OPT_XW_GEMM = 3, LL_DIT_OPT_TEAM = 4 };
 int ll_dit_set_option(void *handle, int option, int value);
 int ll_dit_last_run_ms(void *handle, float *ms, int *steps);

@@ -39,7 +39,13 @@ struct Ctl {                       // device memory, zeroed by the host before e
     unsigned int bar[8][32];       // [xcc][0]: monotonic team barrier counter
     unsigned int error;            // bit 0: a bounded spin ran out; bit 1: more than TEAM workgroups on one XCC
     unsigned int teams_done;
+    unsigned long long stamps[64]; // LL_TEAM_PROBE: wall-clock ticks (100 MHz) of I/O wave 0 of rank 0 of team 0 through block 3 of the first step
 };
+#ifdef LL_TEAM_PROBE
+#define LL_TSTAMP(i) do { if (w.xcc == 0 && w.rank == 0 && w.iw == 0 && w.lane == 0 && l == 3 && step == 0) a.ctl->stamps[i] = wall_clock64(); } while (0)
+#else
+#define LL_TSTAMP(i) do { } while (0)
+#endif
 
 struct Args {
     // geometry
@@ -178,26 +184,32 @@ __device__ __forceinline__ int grow_of(int r, int g, int B, int N) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- panel staging (I/O waves)
-// [ROWS][KCH] bf16 of `src` (row stride ld elements, K offset k0) -> LDS, XOR-swizzled 16-byte pieces.  256 threads.
+// [ROWS][KCH] bf16 of `src` (row stride ld elements, K offset k0) -> LDS, XOR-swizzled 16-byte pieces.  256 threads; every load of the
+// panel is in flight before the first LDS write.  Thread t owns column piece t % PPR of the rows t / PPR + i * RPI: the per-lane part of
+// the address is ONE VGPR, the row part of step i is wave-uniform (soffset) -- no per-load address registers, no branches (N is a multiple
+// of 16, so whether step i is a padding row is wave-uniform too).
 template <int KCH>
 __device__ __forceinline__ void stage_panel(const Who &w, const bf16_t *src, int ld, int k0, int g, int B, int N) {
     constexpr int PPR = KCH / 8;                       // 16-byte pieces per row
-    constexpr int PIECES = ROWS * PPR;
-    constexpr int PT = PIECES / 256;                   // per thread
-    static_assert(PIECES % 256 == 0, "panel pieces");
-    const int tid = w.iw * 64 + w.lane;
+    constexpr int RPI = 256 / PPR;                     // rows covered by one step of the 256 threads (2 at KCH = 1024, 8 at 256)
+    constexpr int PT = ROWS / RPI;                     // steps = loads per thread
+    static_assert(256 % PPR == 0 && ROWS % RPI == 0 && NP % RPI == 0, "panel pieces");
+    const int tid = w.iw * 64 + w.lane + opaque_zero();      // (per-lane values recomputed per phase: see opaque_zero)
+    const int r0 = tid / PPR, col = tid % PPR;
+    const __amdgpu_buffer_rsrc_t rs = rsrc_of(src);
+    const int voff = (r0 * ld + k0 + col * 8) * 2;     // bytes; row r0 of the sequence
+    const int seq0 = g * N * ld * 2, seq1 = (B * N + g * N) * ld * 2;      // byte offsets of the two sequences (< 2 GB)
     u32x4 v[PT];
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
-        const int pc = tid + i * 256;
-        const int row = pc / PPR, col = pc % PPR;
-        const int gr = grow_of(row, g, B, N);
-        v[i] = gr >= 0 ? ld16_sc1(src, (uint32_t)(((int64_t)gr * ld + k0 + col * 8) * 2)) : (u32x4)(0);
+        const int node0 = (i * RPI) & (NP - 1);        // first node of the step (the step's rows are node0 + r0)
+        // padding rows: an offset beyond the descriptor's range -- the buffer load returns zeros, no branch
+        const int soff = node0 < N ? ((i * RPI) >> 5 ? seq1 : seq0) + node0 * ld * 2 : 0x7ffffff0;
+        v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 16);      // sc1
     }
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
-        const int pc = tid + i * 256;
-        const int row = pc / PPR, col = pc % PPR;
+        const int row = r0 + i * RPI;
         *reinterpret_cast<u32x4 *>(w.lds + row * (KCH * 2) + ((col ^ (row & 15)) << 4)) = v[i];
     }
 }
@@ -267,6 +279,19 @@ __device__ __forceinline__ u32x4 load_frag_at(__amdgpu_buffer_rsrc_t r, uint32_t
 // Output epilogues
 enum { EP_BF16 = 0, EP_BIAS_GELU_BF16 = 1, EP_RAW_F32 = 2, EP_BIAS_F32 = 3 };
 
+// GELU(x) = x Phi(x) with erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, four orders below the bf16 rounding of the result) on the
+// hardware exp / rcp: ~15 instructions against ~40 of the library erff -- the epilogue of fc1 runs on the four MFMA waves only
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);      // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
 // acc tile -> output image in LDS.  acc[mt][r]: token row mt * 16 + (lane & 15), column (lane >> 4) * 4 + r of the 16-column tile.
 template <int EPI>
 __device__ __forceinline__ void put_tile(unsigned char *img, int irow_bytes, int col0, const af32x4 (&acc)[4], const float *bias_lds, int lane) {
@@ -281,7 +306,7 @@ __device__ __forceinline__ void put_tile(unsigned char *img, int irow_bytes, int
         }
         if (EPI == EP_BIAS_GELU_BF16) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
+            for (int r = 0; r < 4; ++r) o[r] = gelu_fast(o[r]);
         }
         unsigned char *dst = img + (mt * 16 + fi) * irow_bytes;
         if (EPI == EP_BF16 || EPI == EP_BIAS_GELU_BF16) {
@@ -320,24 +345,39 @@ __device__ __forceinline__ void gemm_phase_mfma(Who &w, Fifo<H> &ff, const WBase
     const int oz = opaque_zero();
 #pragma unroll
     for (int m = 0; m < 4; ++m) ax[m] = (uint32_t)(fi * ROWB + ((((m << 2) | fq) ^ fi) << 4) + (ks0 >> 2) * 256 + oz);
+    // k-step J: m-tile by m-tile, the TW tiles of an m-tile back to back; as soon as an m-tile's fragment has fed its last MFMA the same
+    // registers receive the fragment of k-step J + 1, so the LDS latency hides behind the MFMAs of the other m-tiles (no second register set)
+    abf16x8 afr[4];
+    {
+        const unsigned char *ap = w.lds + ax[0];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) afr[mt] = *reinterpret_cast<const abf16x8 *>(ap + mt * 16 * ROWB);
+    }
     static_for<NJ>([&](auto jc) {
         constexpr int J = decltype(jc)::value;
-        abf16x8 a[4];
-        const unsigned char *ap = w.lds + ax[J & 3] + (J >> 2) * 256;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const abf16x8 *>(ap + mt * 16 * ROWB);
+        const unsigned char *an = w.lds + ax[(J + 1) & 3] + ((J + 1) >> 2) * 256;
+        static_for<4>([&](auto mc) {
+            constexpr int MT = decltype(mc)::value;
+            static_for<TW>([&](auto tc) {
+                constexpr int T = decltype(tc)::value;
+                constexpr int SLOT = (P::OFF + J * TW + T) % D;
+                acc[T][MT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(abf16x8, ff.s[SLOT]), afr[MT], acc[T][MT], 0, 0, 0);
+            });
+            if constexpr (J + 1 < NJ) afr[MT] = *reinterpret_cast<const abf16x8 *>(an + MT * 16 * ROWB);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // the slots of this k-step are free: each takes the fragment D places further down the wave's sequence
         static_for<TW>([&](auto tc) {
             constexpr int T = decltype(tc)::value;
             constexpr int F = P::OFF + J * TW + T;
             constexpr int SLOT = F % D;
-            const abf16x8 wf = __builtin_bit_cast(abf16x8, ff.s[SLOT]);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[T][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a[mt], acc[T][mt], 0, 0, 0);
-            constexpr int FN = F + D;                                  // the fragment that takes this slot next
+            constexpr int FN = F + D;
+#ifndef LL_TEAM_NOSTREAM     // (probe switch: no weight traffic at all -- results are garbage; what do the phases cost without the stream?)
             if constexpr (FN < G::NF_BLOCK) ff.s[SLOT] = load_frag<H, FN>(wb, layer, lane * 16);
             else ff.s[SLOT] = load_frag<H, FN - G::NF_BLOCK>(wb, layer_next, lane * 16);
+#endif
         });
-        __builtin_amdgcn_sched_barrier(0);             // k-steps stay in order: the unrolled phase must not pile fragment reads up in registers
+        __builtin_amdgcn_sched_barrier(0);
     });
     // every MFMA wave is done with the panel before its LDS turns into the output image
     ++w.m_gen;
@@ -377,7 +417,7 @@ template <int ESZ>
 __device__ __forceinline__ void copy_out(const Who &w, void *dst, int ld, int col0, int icols, int g, int B, int N) {
     const int ppr = icols * ESZ / 16;                                  // 16-byte pieces per row
     const int irow = icols * ESZ + 16;
-    const int tid = w.iw * 64 + w.lane;
+    const int tid = w.iw * 64 + w.lane + opaque_zero();
     for (int pc = tid; pc < ROWS * ppr; pc += 256) {
         const int row = pc / ppr, col = pc - row * ppr;
         const int gr = grow_of(row, g, B, N);
@@ -423,54 +463,67 @@ __device__ __forceinline__ void attn_phase(Who &w, const Args &a, int layer, int
 // (bf16 engine: sum and sum of squares in one exchange), one wave per 256-column chunk of a row.
 template <int H>
 __device__ __forceinline__ void ln_phase(Who &w, const Args &a, const float *bias, int nslab, int layer, int sel, int s, int g) {
-    constexpr int MAXE = H / 256;                      // waves per row
-    constexpr int RPP = 4 / MAXE;                      // rows per pass of the four I/O waves
-    const int e = w.iw % MAXE, lane = w.lane;
-    const int h = (lane + e * 64) * 4;
-    for (int pass = 0; pass < 2 / RPP; ++pass) {
-        const int prow = 2 * w.rank + pass * RPP + w.iw / MAXE;       // panel row
-        const int gr = grow_of(prow, g, a.B, a.N);
-        const int ci = (prow >> 5) == 0 ? g : a.B;
-        const float *mod = a.modtab + (((int64_t)s * (a.B + 1) + ci) * a.L + layer) * (6 * (int64_t)H) + (int64_t)sel * 3 * H;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), xr = v, sh = v, sc = v, ga = v;
+    // both rows of the CU at once: I/O waves 0, 1 take panel row 2 rank, waves 2, 3 row 2 rank + 1; a wave owns half a row (NC float4 chunks per
+    // lane, column chunk (half * NC + k) * 256 + lane * 4), so the whole phase is ONE round of loads and ONE exchange of (sum, sum of squares)
+    constexpr int NC = H / 512;                        // float4 chunks per lane
+    static_assert(H % 512 == 0, "two waves per row");
+    const int lane = w.lane + opaque_zero();
+    const int rsel = w.iw >> 1, half = w.iw & 1;
+    const int prow = 2 * w.rank + rsel;
+    const int gr = grow_of(prow, g, a.B, a.N);
+    const int ci = (prow >> 5) == 0 ? g : a.B;
+    const float *mod = a.modtab + (((int64_t)s * (a.B + 1) + ci) * a.L + layer) * (6 * (int64_t)H) + (int64_t)sel * 3 * H;
+    float4 v[NC], xr[NC], sh[NC], sc[NC], ga[NC];
+    float ps = 0.f, pq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int h = ((half * NC + k) * 64 + lane) * 4;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xr[k] = sh[k] = sc[k] = ga[k] = v[k];
         if (gr >= 0) {
             float4 t[4];
 #pragma unroll
             for (int z = 0; z < 4; ++z)
                 if (z < nslab) t[z] = ldf4_sc1(a.ybuf, z * a.slab_stride + (int64_t)gr * H + h);
             const float4 bb = *reinterpret_cast<const float4 *>(bias + h);
-            xr = ldf4_sc1(a.x32, (int64_t)gr * H + h);
-            sh = *reinterpret_cast<const float4 *>(mod + h);
-            sc = *reinterpret_cast<const float4 *>(mod + H + h);
-            ga = *reinterpret_cast<const float4 *>(mod + 2 * H + h);
+            xr[k] = ldf4_sc1(a.x32, (int64_t)gr * H + h);
+            sh[k] = *reinterpret_cast<const float4 *>(mod + h);
+            sc[k] = *reinterpret_cast<const float4 *>(mod + H + h);
+            ga[k] = *reinterpret_cast<const float4 *>(mod + 2 * H + h);
 #pragma unroll
             for (int z = 0; z < 4; ++z)
-                if (z < nslab) { v.x += t[z].x; v.y += t[z].y; v.z += t[z].z; v.w += t[z].w; }
-            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                if (z < nslab) { v[k].x += t[z].x; v[k].y += t[z].y; v[k].z += t[z].z; v[k].w += t[z].w; }
+            v[k].x += bb.x; v[k].y += bb.y; v[k].z += bb.z; v[k].w += bb.w;
         }
-        const int rslot = w.iw / MAXE;                 // rows in flight use their own exchange rows
-        w.fl->red[0][rslot * MAXE + e][lane] = v.x + v.y + v.z + v.w;
-        w.fl->red[1][rslot * MAXE + e][lane] = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        io_barrier(w);
-        float sum = 0.f, sq = 0.f;
+        ps += v[k].x + v[k].y + v[k].z + v[k].w;
+        pq += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+    }
+    // bf16 engine's form of ln_mod_res_mw_kernel: var = E[y^2] - mean^2 in f32, clamped at 0
+    ps = wave_sum(ps);
+    pq = wave_sum(pq);
+    if (lane == 0) {
+        w.fl->red[0][w.iw][0] = ps;
+        w.fl->red[1][w.iw][0] = pq;
+    }
+    io_barrier(w);
+    const float sum = w.fl->red[0][rsel * 2][0] + w.fl->red[0][rsel * 2 + 1][0];
+    const float sq = w.fl->red[1][rsel * 2][0] + w.fl->red[1][rsel * 2 + 1][0];
+    const float mean = sum / (float)H;
+    const float rstd = rsqrtf(fmaxf(sq / (float)H - mean * mean, 0.f) + 1e-5f);
+    if (gr >= 0) {
 #pragma unroll
-        for (int k = 0; k < MAXE; ++k) {
-            sum += w.fl->red[0][rslot * MAXE + k][lane];
-            sq += w.fl->red[1][rslot * MAXE + k][lane];
-        }
-        const float mean = wave_sum(sum) / (float)H;
-        const float rstd = rsqrtf(fmaxf(wave_sum(sq) / (float)H - mean * mean, 0.f) + 1e-5f);
-        if (gr >= 0) {
+        for (int k = 0; k < NC; ++k) {
+            const int h = ((half * NC + k) * 64 + lane) * 4;
             float4 o;
-            o.x = xr.x + ga.x * ((v.x - mean) * rstd * (1.f + sc.x) + sh.x);
-            o.y = xr.y + ga.y * ((v.y - mean) * rstd * (1.f + sc.y) + sh.y);
-            o.z = xr.z + ga.z * ((v.z - mean) * rstd * (1.f + sc.z) + sh.z);
-            o.w = xr.w + ga.w * ((v.w - mean) * rstd * (1.f + sc.w) + sh.w);
+            o.x = xr[k].x + ga[k].x * ((v[k].x - mean) * rstd * (1.f + sc[k].x) + sh[k].x);
+            o.y = xr[k].y + ga[k].y * ((v[k].y - mean) * rstd * (1.f + sc[k].y) + sh[k].y);
+            o.z = xr[k].z + ga[k].z * ((v[k].z - mean) * rstd * (1.f + sc[k].z) + sh[k].z);
+            o.w = xr[k].w + ga[k].w * ((v[k].w - mean) * rstd * (1.f + sc[k].w) + sh[k].w);
             *reinterpret_cast<float4 *>(a.x32 + (int64_t)gr * H + h) = o;
             store4<bf16_t>(a.xa + (int64_t)gr * H + h, o);
         }
-        io_barrier(w);                                 // the exchange rows are free again
     }
+    io_barrier(w);                                     // the exchange words are free again
 }
 
 // ---------------------------------------------------------------------------------------------------------------- x_embedder (I/O waves)
@@ -479,7 +532,7 @@ __device__ __forceinline__ void ln_phase(Who &w, const Args &a, const float *bia
 template <int H>
 __device__ __forceinline__ void embed_phase(Who &w, const Args &a, int s, int g) {
     const int i = w.rank, N = a.N, B = a.B;
-    const int tid = w.iw * 64 + w.lane;
+    const int tid = w.iw * 64 + w.lane + opaque_zero();
     int *gidx = reinterpret_cast<int *>(w.lds);        // [72] + count at [72]
     float *red = reinterpret_cast<float *>(w.lds + 512);
     const bool live = i < N;
@@ -579,36 +632,59 @@ __device__ __forceinline__ void io_main(Who &w, const Args &a) {
             team_barrier(w);
             for (int l = 0; l < a.L; ++l) {
                 // ------------------------------------------------------------ q|k|v
+                LL_TSTAMP(0);
                 stage_panel<H>(w, a.xa, H, 0, g, B, N);
+                LL_TSTAMP(1);
                 wg_barrier();                                          // (A)
                 wg_barrier();                                          // (B)
+                LL_TSTAMP(2);
                 copy_out<2>(w, a.qkv, 3 * H, c * G::QKV_T * 16, G::QKV_T * 16, g, B, N);
+                LL_TSTAMP(3);
                 team_barrier(w);
+                LL_TSTAMP(4);
                 attn_phase<H>(w, a, l, g);
+                LL_TSTAMP(5);
                 team_barrier(w);
+                LL_TSTAMP(6);
                 // ------------------------------------------------------------ proj (K quarter per CU -> raw slabs)
                 stage_panel<H / 4>(w, a.ao, H, (c >> 3) * (H / 4), g, B, N);
+                LL_TSTAMP(7);
                 wg_barrier();
                 wg_barrier();
+                LL_TSTAMP(8);
                 copy_out<4>(w, a.ybuf + (int64_t)(c >> 3) * a.slab_stride, H, (c & 7) * G::PRJ_T * 16, G::PRJ_T * 16, g, B, N);
+                LL_TSTAMP(9);
                 team_barrier(w);
+                LL_TSTAMP(10);
                 ln_phase<H>(w, a, a.proj_b + l * a.blk_stride, 4, l, 0, s, g);
+                LL_TSTAMP(11);
                 team_barrier(w);
+                LL_TSTAMP(12);
                 // ------------------------------------------------------------ fc1
                 stage_bias(w, a.fc1_b + l * a.blk_stride, c * G::FC_T * 16, G::FC_T * 16);
                 stage_panel<H>(w, a.xa, H, 0, g, B, N);
+                LL_TSTAMP(13);
                 wg_barrier();
                 wg_barrier();
+                LL_TSTAMP(14);
                 copy_out<2>(w, a.h1, G::HM, c * G::FC_T * 16, G::FC_T * 16, g, B, N);
+                LL_TSTAMP(15);
                 team_barrier(w);
+                LL_TSTAMP(16);
                 // ------------------------------------------------------------ fc2 (K chunk per CU -> raw slabs)
                 stage_panel<H>(w, a.h1, G::HM, (c >> 3) * H, g, B, N);
+                LL_TSTAMP(17);
                 wg_barrier();
                 wg_barrier();
+                LL_TSTAMP(18);
                 copy_out<4>(w, a.ybuf + (int64_t)(c >> 3) * a.slab_stride, H, (c & 7) * G::FC_T * 16, G::FC_T * 16, g, B, N);
+                LL_TSTAMP(19);
                 team_barrier(w);
+                LL_TSTAMP(20);
                 ln_phase<H>(w, a, a.fc2_b + l * a.blk_stride, 4, l, 1, s, g);
+                LL_TSTAMP(21);
                 team_barrier(w);
+                LL_TSTAMP(22);
             }
             // ================================================================ output layer: Linear(H, H) + GELU, Linear(H, F)
             stage_bias(w, a.out1_b, c * T1 * 16, T1 * 16);

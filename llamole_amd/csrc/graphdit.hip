@@ -160,8 +160,9 @@ struct DitEngine {
     DevBuf wprojp;               // [depth][H x H]
     DevBuf wout1p, wout2p;       // output layer weights in the same order (dit_team.h)
     DevBuf team_ctl;             // team::Ctl of the persistent trajectory kernel
-    int team_mode = -1;          // dit_team_kernel under ll_dit_run: -1 = whenever eligible and not in overlap mode, 0 = never, 1 = also under the
-                                 // single-step entry points (step / denoise / step_probs: the parity taps of the team path)
+    int team_mode = 0;           // dit_team_kernel (opt-in: measured slower than the launch chain at every batch): 0 = never (default),
+                                 // -1 = under ll_dit_run whenever eligible and not in overlap mode, 1 = also under the single-step entry points
+                                 // (step / denoise / step_probs: the parity taps of the team path)
     int team_last = 0;           // the last denoiser call ran on the team kernel
     int team_step_s = -1;        // the reverse step the single-step entry points are about to run (the team kernel takes it as an argument)
     std::vector<const void *> packed_keys;   // row-major weights registered with register_packed_weight
@@ -454,7 +455,8 @@ static bool team_eligible(const DitEngine *e) {
            N <= team::NP && F % 16 == 0 && e->wqkvp.p && e->wprojp.p && e->wfc1p.p && e->wfc2p.p && e->wout1p.p && e->wout2p.p && e->rowvec == nullptr;
 }
 static bool team_wanted(const DitEngine *e, bool trajectory) {
-    if (e->team_mode == 0 || e->overlap || !team_eligible(e)) return false;
+    static const bool in_overlap = getenv("LL_DIT_TEAM_OVERLAP") && atoi(getenv("LL_DIT_TEAM_OVERLAP")) != 0;      // A/B switch: the persistent kernel next to the LLM decode
+    if (e->team_mode == 0 || (e->overlap && !in_overlap) || !team_eligible(e)) return false;
     return trajectory || e->team_mode == 1;
 }
 template <int H> static int team_launch_t(DitEngine *e, const team::Args &a, hipStream_t st) {
@@ -504,6 +506,16 @@ static int team_launch(DitEngine *e, int s_first, int n_steps, int run_post, con
 static int team_check(DitEngine *e) {
     team::Ctl h;
     LL_HIP(hipMemcpy(&h, e->team_ctl.p, sizeof(h), hipMemcpyDeviceToHost));
+#ifdef LL_TEAM_PROBE
+    {
+        static const char *names[] = {"stage qkv", "K loop qkv (A..B)", "copy qkv", "barrier", "attention", "barrier", "stage proj", "K loop proj", "copy proj",
+                                      "barrier", "LN1", "barrier", "stage fc1", "K loop fc1", "copy fc1", "barrier", "stage fc2", "K loop fc2", "copy fc2",
+                                      "barrier", "LN2", "barrier"};
+        fprintf(stderr, "LL_TEAM_PROBE block 3 of the first step, us:");
+        for (int i = 0; i < 22; ++i) fprintf(stderr, " %s %.2f |", names[i], (double)(h.stamps[i + 1] - h.stamps[i]) / 100.0);
+        fprintf(stderr, " total %.2f\n", (double)(h.stamps[22] - h.stamps[0]) / 100.0);
+    }
+#endif
     if (h.error) {
         set_error("dit_team_kernel: %s%s (census %u %u %u %u %u %u %u %u)", (h.error & 1) ? "a bounded wait ran out " : "",
                   (h.error & 2) ? "more than 32 workgroups reported on one XCC" : "", h.census[0][0], h.census[1][0], h.census[2][0],

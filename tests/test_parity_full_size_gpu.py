@@ -190,7 +190,7 @@ def _rows_noise(step, rows, B0, N):
     return qx, qe
 
 
-@pytest.mark.parametrize("mode", ["default", "overlap_default"])
+@pytest.mark.parametrize("mode", ["default", "overlap_default", "team"])
 @pytest.mark.parametrize("B", [1, 8, 16])
 def test_graphdit_bf16_vs_oracle_at_informative_steps(full_dit, oracle_traj, B, mode):
     """The two engine configurations bench.py runs (`default`: what --workload graphdit and the back-to-back e2e run;
@@ -207,6 +207,7 @@ def test_graphdit_bf16_vs_oracle_at_informative_steps(full_dit, oracle_traj, B, 
     n_x, n_e = int(mask.sum()), int(um.sum())
     m.begin(props, text, -200.0, n_nodes)
     m.set_option("overlap", int(mode == "overlap_default"))
+    m.set_option("team", int(mode == "team"))          # the persistent per-XCD trajectory kernel (opt-in; csrc/dit_team.h)
     per_step = {}
     try:
         for s in PROBE_STEPS:
@@ -248,6 +249,7 @@ def test_graphdit_bf16_vs_oracle_at_informative_steps(full_dit, oracle_traj, B, 
                 free[s] = eq / (n_x + n_e)
     finally:
         m.set_option("overlap", 0)
+        m.set_option("team", 0)
     rec = dict(per_step={str(k): v for k, v in per_step.items()}, free_running_equal_frac={str(k): v for k, v in free.items()},
                n_atoms=n_x, n_pairs=n_e, mlp_kernels=m.mlp_choice())
     print(f"B={B} {mode}: " + json.dumps(rec))

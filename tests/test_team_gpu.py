@@ -46,7 +46,7 @@ def test_team_step_matches_the_launch_chain(B):
             X, E = m.get_state()
             per.append((lx.cpu(), le.cpu(), px.cpu(), pe.cpu(), X.cpu().long(), E.cpu().long()))
         out[mode] = per
-    m.set_option("team", -1)
+    m.set_option("team", 0)
     for (lx0, le0, px0, pe0, X0, E0), (lx1, le1, px1, pe1, X1, E1) in zip(out[0], out[1]):
         scale = max(float(lx0.abs().max()), float(le0.abs().max()), 1.0)
         ex = float(((lx1 - lx0) * mask.view(1, B, N, 1)).abs().max()) / scale
@@ -74,22 +74,22 @@ def test_team_trajectory_properties():
         m.begin(props[rows], text[rows], -200.0, n_nodes[rows])
         m.set_option("team", team)
         return m.generate_graphs(props[rows], text[rows], -200.0, n_nodes=n_nodes[rows], seed=seed)[0]
-    a = run(list(range(B)), -1)
-    b = run(list(range(B)), -1)
+    a = run(list(range(B)), 1)
+    b = run(list(range(B)), 1)
     assert m.last_run_ms()[1] == 10                      # also checks the kernel's error word (ll_dit_last_run_ms)
     for i, (x, e) in enumerate(a):
         n = int(n_nodes[i])
         assert x.shape == (n,) and e.shape == (n, n) and torch.equal(e, e.t()) and int(torch.diagonal(e).abs().sum()) == 0
         assert int(x.min()) >= 0 and int(x.max()) < 16 and int(e.min()) >= 0 and int(e.max()) < 5
         assert torch.equal(x, b[i][0]) and torch.equal(e, b[i][1])
-    other = run(list(range(B)), -1, seed=43)
+    other = run(list(range(B)), 1, seed=43)
     assert any(not torch.equal(a[i][1], other[i][1]) for i in range(B))
     # graphs 0..2 alone (batch 3) walk exactly the trajectories they walk inside the batch of 8: same position, same seed, own XCD
-    sub = run([0, 1, 2], -1)
+    sub = run([0, 1, 2], 1)
     for i in range(3):
         assert torch.equal(sub[i][0], a[i][0]) and torch.equal(sub[i][1], a[i][1])
     # the chain's trajectories are a different rounding of the same model: most entries agree after 10 steps of a 2-block denoiser
     c = run(list(range(B)), 0)
     agree = sum(float((c[i][1] == a[i][1]).float().mean()) for i in range(B) if int(n_nodes[i]) > 1) / sum(int(n) > 1 for n in n_nodes)
     assert agree >= 0.9, agree
-    m.set_option("team", -1)
+    m.set_option("team", 0)
