@@ -29,6 +29,14 @@ int ll_linear_xw(const void *A, int lda, const void *W, const float *bias, void 
  * every variant can be checked against a reference.  splits > 1: C receives `splits` raw f32 slabs (stride M * ldc). */
 int ll_linear_cfg(int cfg, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, int M, int N, int K,
                   int splits, int epi, int out_f32, void *stream);
+/* In-situ kernel timing of the GraphDiT launch chain: ll_dit_class_probe(handle, cls) makes the NEXT ll_dit_run in launch mode record a HIP
+ * event pair around every launch of one class of the block's kernels (cls = -1: off), i.e. the kernel is timed where it runs -- behind
+ * the launch that feeds it, on the weights of its own layer -- not back to back in a micro-benchmark; ll_dit_class_probe_read returns the sum
+ * of the pairs' elapsed times and the number of launches (and synchronises the device).  bench.py's roofline_graphdit comes from it. */
+enum { LL_DIT_CLS_QKV = 0, LL_DIT_CLS_ATTN = 1, LL_DIT_CLS_PROJ = 2, LL_DIT_CLS_LNMOD = 3, LL_DIT_CLS_FC1 = 4, LL_DIT_CLS_FC2 = 5, LL_DIT_CLS_COUNT = 6 };
+int ll_dit_class_probe(void *handle, int cls);
+int ll_dit_class_probe_read(void *handle, float *total_us, int *launches);
+
 /* Tuning: waves per workgroup of the <= 64-row panel GEMM (4 | 8; default 8); returns the previous value. */
 int ll_set_m64_waves(int waves);
 /* Tuning: 1 (default) = the <= 64-row panel GEMM reads the GraphDiT engine's MFMA-operand-order weight copies where they exist (one

@@ -93,6 +93,8 @@ SIGNATURES = {
     "ll_dit_set_overlap": (_I, [_P, _I]),
     "ll_dit_mlp_choice": (_I, [_P, C.POINTER(_F), C.POINTER(_I), C.POINTER(_I)]),
     "ll_dit_set_option": (_I, [_P, _I, _I]),
+    "ll_dit_class_probe": (_I, [_P, _I]),
+    "ll_dit_class_probe_read": (_I, [_P, C.POINTER(_F), C.POINTER(_I)]),
     "ll_linear_rows16_bf16": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "ll_set_rows16_geometry": (_I, [_I, _I, _I]),
     "ll_rows16_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),

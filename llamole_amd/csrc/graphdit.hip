@@ -163,6 +163,10 @@ struct DitEngine {
     int team_mode = 0;           // dit_team_kernel (opt-in: measured slower than the launch chain at every batch): 0 = never (default),
                                  // -1 = under ll_dit_run whenever eligible and not in overlap mode, 1 = also under the single-step entry points
                                  // (step / denoise / step_probs: the parity taps of the team path)
+    // in-situ kernel timing (ll_dit_class_probe): HIP events around every launch of ONE class of the block's kernels inside a real trajectory
+    int time_class = -1;
+    std::vector<hipEvent_t> tev;
+    size_t tev_n = 0;
     int team_last = 0;           // the last denoiser call ran on the team kernel
     int team_step_s = -1;        // the reverse step the single-step entry points are about to run (the team kernel takes it as an argument)
     std::vector<const void *> packed_keys;   // row-major weights registered with register_packed_weight
@@ -432,6 +436,20 @@ static void launch_lnmod(DitEngine *e, int layer, int sel, int nslab, const floa
 #undef LL_LNMOD
 }
 
+// Events around one launch class inside the trajectory loop of ll_dit_run (launch mode only: events cannot be recorded into a captured step)
+struct ClassTimer {
+    DitEngine *e;
+    hipStream_t st;
+    bool on;
+    ClassTimer(DitEngine *e_, int cls, hipStream_t st_) : e(e_), st(st_) {
+        on = e->time_class == cls && e->step_host >= 0 && e->tev_n + 2 <= e->tev.size();
+        if (on) (void)hipEventRecord(e->tev[e->tev_n++], st);
+    }
+    ~ClassTimer() {
+        if (on) (void)hipEventRecord(e->tev[e->tev_n++], st);
+    }
+};
+
 static int pick_splits(int M2, int H, int K) {
     if (M2 >= 2048 || (M2 >= 1024 && K >= 2048)) {
         // 128 x 128 tiles on sixteen-wave workgroups (gemm_dispatch): split K until the launch has ~256 of them
@@ -549,36 +567,56 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
     for (int l = 0; l < c.depth; ++l) {
         const DitEngine::BlockW &w = e->bw[l];
         if (fused_qkv) {
+            ClassTimer tm(e, LL_DIT_CLS_QKV, st);
             launch_qkv_attn(e, l, st);
         } else {
-            LL_TRY(linear_launch(dt, e->xa.p, H, w.qkv, H, nullptr, e->qkv.p, 3 * H, M2, 3 * H, H, 0, 0, st));
+            {
+                ClassTimer tm(e, LL_DIT_CLS_QKV, st);
+                LL_TRY(linear_launch(dt, e->xa.p, H, w.qkv, H, nullptr, e->qkv.p, 3 * H, M2, 3 * H, H, 0, 0, st));
+            }
+            ClassTimer tm(e, LL_DIT_CLS_ATTN, st);
             if (bf) launch_attn<bf16_t>(e, l, st); else launch_attn<float>(e, l, st);
         }
         LL_LAUNCH_CHECK();
-        if (e->splits_h > 1)
-            LL_TRY(linear_splitk_launch(dt, e->attn_o.p, H, w.proj, H, e->ybuf.as<float>(), H, slab, M2, H, H, e->splits_h, st));
-        else
-            LL_TRY(linear_launch(dt, e->attn_o.p, H, w.proj, H, nullptr, e->ybuf.p, H, M2, H, H, 0, 1, st));
-        if (bf) launch_lnmod<bf16_t>(e, l, 0, e->splits_h, w.proj_b, st);
-        else launch_lnmod<float>(e, l, 0, e->splits_h, w.proj_b, st);
+        {
+            ClassTimer tm(e, LL_DIT_CLS_PROJ, st);
+            if (e->splits_h > 1)
+                LL_TRY(linear_splitk_launch(dt, e->attn_o.p, H, w.proj, H, e->ybuf.as<float>(), H, slab, M2, H, H, e->splits_h, st));
+            else
+                LL_TRY(linear_launch(dt, e->attn_o.p, H, w.proj, H, nullptr, e->ybuf.p, H, M2, H, H, 0, 1, st));
+        }
+        {
+            ClassTimer tm(e, LL_DIT_CLS_LNMOD, st);
+            if (bf) launch_lnmod<bf16_t>(e, l, 0, e->splits_h, w.proj_b, st);
+            else launch_lnmod<float>(e, l, 0, e->splits_h, w.proj_b, st);
+        }
         LL_LAUNCH_CHECK();
         int nslab_m = e->splits_m;
-        if (xw) {
-            LL_TRY(linear_xw_launch(e->xa.p, H, e->wfc1p.as<bf16_t>() + (size_t)l * Hm * H, w.fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, 1, 0, st));
-        } else {
-            LL_TRY(linear_launch(dt, e->xa.p, H, w.fc1, H, w.fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, st));
+        {
+            ClassTimer tm(e, LL_DIT_CLS_FC1, st);
+            if (xw) {
+                LL_TRY(linear_xw_launch(e->xa.p, H, e->wfc1p.as<bf16_t>() + (size_t)l * Hm * H, w.fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, 1, 0, st));
+            } else {
+                LL_TRY(linear_launch(dt, e->xa.p, H, w.fc1, H, w.fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, st));
+            }
         }
-        if (xw2) {
-            LL_TRY(linear_xw_launch(e->h1.p, Hm, e->wfc2p.as<bf16_t>() + (size_t)l * Hm * H, nullptr, e->ybuf.p, H, M2, H, Hm, e->splits_x, slab, 0, 1, st));
-            nslab_m = e->splits_x;
-        } else {
-            if (e->splits_m > 1)
-                LL_TRY(linear_splitk_launch(dt, e->h1.p, Hm, w.fc2, Hm, e->ybuf.as<float>(), H, slab, M2, H, Hm, e->splits_m, st));
-            else
-                LL_TRY(linear_launch(dt, e->h1.p, Hm, w.fc2, Hm, nullptr, e->ybuf.p, H, M2, H, Hm, 0, 1, st));
+        {
+            ClassTimer tm(e, LL_DIT_CLS_FC2, st);
+            if (xw2) {
+                LL_TRY(linear_xw_launch(e->h1.p, Hm, e->wfc2p.as<bf16_t>() + (size_t)l * Hm * H, nullptr, e->ybuf.p, H, M2, H, Hm, e->splits_x, slab, 0, 1, st));
+                nslab_m = e->splits_x;
+            } else {
+                if (e->splits_m > 1)
+                    LL_TRY(linear_splitk_launch(dt, e->h1.p, Hm, w.fc2, Hm, e->ybuf.as<float>(), H, slab, M2, H, Hm, e->splits_m, st));
+                else
+                    LL_TRY(linear_launch(dt, e->h1.p, Hm, w.fc2, Hm, nullptr, e->ybuf.p, H, M2, H, Hm, 0, 1, st));
+            }
         }
-        if (bf) launch_lnmod<bf16_t>(e, l, 1, nslab_m, w.fc2_b, st);
-        else launch_lnmod<float>(e, l, 1, nslab_m, w.fc2_b, st);
+        {
+            ClassTimer tm(e, LL_DIT_CLS_LNMOD, st);
+            if (bf) launch_lnmod<bf16_t>(e, l, 1, nslab_m, w.fc2_b, st);
+            else launch_lnmod<float>(e, l, 1, nslab_m, w.fc2_b, st);
+        }
         LL_LAUNCH_CHECK();
         if (hidden_tap && tap_layer == l + 1)
             LL_HIP(hipMemcpyAsync(hidden_tap, e->x32.p, (size_t)M2 * H * 4, hipMemcpyDeviceToDevice, st));
@@ -824,6 +862,7 @@ int ll_dit_destroy(void *handle) {
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
     if (e->ev_t0) (void)hipEventDestroy(e->ev_t0);
     if (e->ev_t1) (void)hipEventDestroy(e->ev_t1);
+    for (hipEvent_t ev : e->tev) (void)hipEventDestroy(ev);
     delete e;
     return LL_OK;
 }
@@ -1241,6 +1280,36 @@ int ll_dit_mlp_choice(void *handle, float *us4, int *xw_fc1, int *xw_fc2) {
     if (us4) memcpy(us4, e->cal_us, sizeof(e->cal_us));
     if (xw_fc1) *xw_fc1 = xw_fc1_wanted(e) ? 1 : 0;
     if (xw_fc2) *xw_fc2 = xw_fc2_wanted(e) ? 1 : 0;
+    return LL_OK;
+}
+
+int ll_dit_class_probe(void *handle, int cls) {
+    DitEngine *e = (DitEngine *)handle;
+    LL_CHECK(e, "ll_dit_class_probe: null handle");
+    LL_CHECK(cls >= -1 && cls < LL_DIT_CLS_COUNT, "ll_dit_class_probe: unknown class %d", cls);
+    e->time_class = cls;
+    e->tev_n = 0;
+    if (cls >= 0 && e->tev.empty()) {
+        const size_t n = (size_t)2 * 2 * e->cfg.depth * e->cfg.T;        // at most two launches of a class per block
+        e->tev.resize(n);
+        for (size_t i = 0; i < n; ++i) LL_HIP(hipEventCreate(&e->tev[i]));
+    }
+    return LL_OK;
+}
+
+int ll_dit_class_probe_read(void *handle, float *total_us, int *launches) {
+    DitEngine *e = (DitEngine *)handle;
+    LL_CHECK(e && total_us && launches, "ll_dit_class_probe_read: null argument");
+    LL_HIP(hipDeviceSynchronize());
+    double us = 0.0;
+    for (size_t i = 0; i + 1 < e->tev_n; i += 2) {
+        float ms = 0.f;
+        LL_HIP(hipEventElapsedTime(&ms, e->tev[i], e->tev[i + 1]));
+        us += 1e3 * ms;
+    }
+    *total_us = (float)us;
+    *launches = (int)(e->tev_n / 2);
+    e->tev_n = 0;
     return LL_OK;
 }
 

@@ -403,8 +403,10 @@ class GraphDiT(nn.Module):
         family = ("gemm_m64_kernel (64-row panel, all loads in flight)" if rows <= 64 else
                   "gemm_m128_kernel (64-row panels)" if rows <= 224 else
                   "gemm_bf16_pipeu_kernel<64,64> (LDS-DMA ring, 16 waves)" if rows < 1024 else "gemm_bf16_pipe_kernel (LDS-DMA ring, 128/256-row tiles)")
-        return {"fc1": "panel" if a.value else "ring", "fc2": "panel" if b.value else "ring", "calibrated": max(us) > 0,
-                "token_rows": rows, "kernel": family if not (a.value or b.value) else "gemm_xw_kernel (packed-weight panel)",
+        # "xw_panel": whether the OPT-IN packed-weight panel kernel (gemm_xw_kernel) replaces the dispatch's kernel under fc1 / fc2 --
+        # False / False by default at every batch; `kernel` names what actually runs
+        return {"kernel": family if not (a.value or b.value) else "gemm_xw_kernel (packed-weight panel)",
+                "xw_panel": {"fc1": bool(a.value), "fc2": bool(b.value)}, "calibrated": max(us) > 0, "token_rows": rows,
                 "chain_us": {"ring/ring": round(us[0], 2), "panel/ring": round(us[1], 2), "ring/panel": round(us[2], 2),
                              "panel/panel": round(us[3], 2)}}
 

@@ -526,7 +526,7 @@ def test_packed_weight_mlp_vs_ring_gemms(N, H, heads, B):
     n_nodes = torch.tensor(([N, 1, max(2, N // 2 + 1)])[:B])
     m.begin(props, text, -200.0, n_nodes)
     choice = m.mlp_choice()            # default: no stopwatch, the LDS-DMA ring under both GEMMs (a seed fixes the molecules)
-    assert choice["fc1"] == "ring" and choice["fc2"] == "ring" and choice["calibrated"] is False, choice
+    assert choice["xw_panel"] == {"fc1": False, "fc2": False} and choice["calibrated"] is False, choice
     m.set_option("xw_gemm", -1)        # opt-in: ll_dit_begin times both kernels on this device for this batch
     m.begin(props, text, -200.0, n_nodes)
     choice = m.mlp_choice()
