@@ -487,7 +487,7 @@ def run_retro(args, ctx):
     """BASELINE.json configs[2]: design + lock-step A* retrosynthesis for `targets` prompts per GPU (llamole_amd/workloads.py)."""
     from llamole_amd.workloads import build_retro_step
     m, cfg, meta, sd = build_model(args, ctx.device)
-    step_fn, info, orch, llm, sd_pred = build_retro_step(args, m, ctx.device, ctx.rank)
+    step_fn, info, orch, llm, sd_pred = build_retro_step(args, m, ctx.device, ctx.rank, ctx.world)
     log("retro workload built")
     for i in range(args.warmup):
         step_fn(i)
@@ -516,19 +516,26 @@ def run_retro(args, ctx):
         cnt = torch.tensor([n_exp, n_val], device=dev, dtype=torch.float64)
         ctx.dist.all_reduce(cnt)
         n_exp, n_val = int(cnt[0].item()), int(cnt[1].item())
+        if getattr(args, "total_targets", 0):          # replicated A*: every rank counted every expansion / value prompt of the job
+            n_exp, n_val = n_exp // ctx.world, n_val // ctx.world
     if ctx.rank != 0:
         return None
-    T = args.targets
-    roof = time_template_head(args, T)
+    strong = bool(getattr(args, "total_targets", 0))
+    T = args.total_targets if strong else args.targets
+    if strong:
+        gathered = recs[-1]                  # every rank holds all routes already (replicated A*)
+    roof = time_template_head(args, T if not strong else max(3, T // ctx.world))
     roof["note"] = ("dominant HAND-WRITTEN kernel of the workload; the step's dominant kernel overall is hipBLASLt's MT256x256x64 GEMM under the stock "
                     "HF forward of the A* value estimates (78 % of that forward, profiles/r3_value_forward_kernel_stats.csv; see value_forward_share_of_step)")
     out = {"metric": "retrosynthesis-planned molecules/sec (design + A* search, depth <= %d)" % args.iterations,
-           "value": ctx.world * T * args.steps / dt, "unit": "molecules/s", "n_gpus": ctx.n_ranks, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+           "value": (T if strong else ctx.world * T) * args.steps / dt, "unit": "molecules/s", "n_gpus": ctx.n_ranks, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16",
            "data": "synthetic",
-           "config": {"workload": "%s + GraphDiT + GIN predictor A* retrosynthesis, depth<=%d, batch=%d/GPU, %d analysis tokens per expansion (the reference allows 512)"
-                                  % (LLM_LABEL.get(args.llm, args.llm), args.iterations, T, args.retro_tokens),
-                      "prompts_per_step": ctx.world * T, "gathered_routes": int(gathered.shape[0]),
+           "config": {"workload": "%s + GraphDiT + GIN predictor A* retrosynthesis, depth<=%d, %s, %d analysis tokens per expansion (the reference allows 512)"
+                                  % (LLM_LABEL.get(args.llm, args.llm), args.iterations,
+                                     ("%d searches per step as ONE lock-step problem, expansions / value prompts of every round split over %d GPU(s)" % (T, ctx.n_ranks))
+                                     if strong else "batch=%d/GPU" % T, args.retro_tokens),
+                      "prompts_per_step": T if strong else ctx.world * T, "gathered_routes": int(gathered.shape[0]),
                       "denoiser": {"hidden": args.hidden, "depth": args.depth, "heads": args.heads, "max_nodes": args.nodes, "T": args.T,
                                    "guide_scale": args.guide}, **{k: v for k, v in info.items() if k != "timing_breakdown"}},
            "expansions_per_s": n_exp / dt, "expansions": n_exp, "value_estimates_per_expansion": n_val / max(1, n_exp),
@@ -641,6 +648,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--llm", default=None, help="LLM architecture (default: qwen2-7b; mistral-7b for --workload sft)")
     ap.add_argument("--targets", type=int, default=16, help="retro: target molecules (prompts) per GPU per step")
+    ap.add_argument("--total-targets", type=int, default=0,
+                    help="retro, strong scaling: this many searches per step for the WHOLE job -- one lock-step A* replicated on every rank, each "
+                         "round's expansions and value prompts split over the ranks (one all-gather of top-k records / costs per round)")
     ap.add_argument("--iterations", type=int, default=5, help="retro: expansions per A* search (search depth <= this)")
     ap.add_argument("--retro-tokens", type=int, default=64, help="retro: analysis tokens decoded per expansion (the reference allows 512)")
     ap.add_argument("--topk", type=int, default=50, help="retro: templates kept per expansion")

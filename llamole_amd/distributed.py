@@ -86,14 +86,21 @@ def all_gather_graphs(mols, max_nodes: int, n_total: int, device=None, group=Non
 
 def all_gather_topk(idx: torch.Tensor, prob: torch.Tensor, group=None):
     """Retro phase: gather per-rank candidate scores ([G_local,k] int32 / f32, equal G_local on every rank)."""
+    return gather_rows(idx, group), gather_rows(prob, group)
+
+
+def gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather of equally shaped [rows, ...] tensors, rank-major ([world * rows, ...]); one collective.  Device tensors go through
+    RCCL as they are under backend "nccl"; under gloo (CPU tests, single-GPU dry runs) they are staged through the host."""
     if _solo(group):
-        return idx, prob
+        return t
     world = dist.get_world_size(group)
-    bi = [torch.empty_like(idx) for _ in range(world)]
-    bp = [torch.empty_like(prob) for _ in range(world)]
-    dist.all_gather(bi, idx.contiguous(), group=group)
-    dist.all_gather(bp, prob.contiguous(), group=group)
-    return torch.cat(bi), torch.cat(bp)
+    host = t.is_cuda and dist.get_backend(group) == "gloo"
+    src = t.cpu() if host else t.contiguous()
+    bufs = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(bufs, src, group=group)
+    out = torch.cat(bufs)
+    return out.to(t.device) if host else out
 
 
 def allreduce_gradients(params, bucket_bytes: int = 64 << 20, group=None) -> int:

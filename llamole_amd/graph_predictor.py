@@ -183,10 +183,19 @@ class GraphPredictor(_GinModule):
         """``sample_templates`` for several products with ONE GIN forward + one top-k launch (batched
         expansions of concurrent A* searches); the host tail (template application, merge) runs per product.
         product_graphs: list of GraphData; c [G, text_input_size]; returns a list of (reactants, scores, templates)."""
+        probs, idx = self.topk_templates_batch(product_graphs, c, topk)
+        return self.merge_topk(probs.float().cpu().numpy(), idx.cpu().numpy(), product_smiles_list)
+
+    @torch.no_grad()
+    def topk_templates_batch(self, product_graphs, c, topk=10):
+        """Device half of ``sample_templates_batch``: one GIN forward + one top-k launch -> (probs [G, k] f32, idx [G, k] int32) on the
+        device -- the fixed-size per-expansion record ranks exchange when a lock-step round is sharded (distributed.all_gather_topk)."""
         from .graph_data import GraphBatch
         gb = GraphBatch.from_data_list(list(product_graphs))
-        probs, idx = self.topk_templates(gb.x, gb.edge_index, gb.edge_attr, gb.batch, c, topk)
-        probs, idx = probs.float().cpu().numpy(), idx.cpu().numpy()
+        return self.topk_templates(gb.x, gb.edge_index, gb.edge_attr, gb.batch, c, topk)
+
+    def merge_topk(self, probs, idx, product_smiles_list):
+        """Host half: template application and the reference's merge (model.py:190-228) per product; probs / idx numpy [G, k]."""
         run = self.template_runner or _default_template_runner()
         out = []
         for g, smiles in enumerate(product_smiles_list):

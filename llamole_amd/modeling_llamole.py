@@ -455,6 +455,62 @@ class GraphLLMForCausalMLM(nn.Module):
             live.append(i)
         if not live:
             return results
+        smiles = [requests[i]["product_smiles"] for i in live]
+        shard = self._expansion_shard()
+        if shard is not None and hasattr(self.graph_predictor, "topk_templates_batch"):
+            # Expansion-level split (second alternative; north_star: "RCCL all-gather of candidate scores"): the host A* is
+            # replicated, every rank sees the same requests; rank r decodes and scores requests r, r + world, ..., then ONE all-gather of
+            # the fixed-size records -- (topk_idx int32[k], topk_prob f32[k]) and the analysis tokens -- gives every rank every expansion;
+            # template application and the merge (host) run on every rank for every request, so the trees stay identical.
+            rank, world, group = shard
+            mine = list(range(rank, len(live), world))
+            cap = (len(live) + world - 1) // world
+            nt = int(self.retro_max_new_tokens)
+            idx = torch.zeros((cap, topk), dtype=torch.int32, device=self.device)
+            prob = torch.zeros((cap, topk), dtype=torch.float32, device=self.device)
+            toks = torch.full((cap, nt), -1, dtype=torch.int32, device=self.device)
+            if mine:
+                analysis, cond = self._decode_analysis([prompts[j] for j in mine], [graph_lists[j] for j in mine], kwargs)
+                p_, i_ = self.graph_predictor.topk_templates_batch([products[j] for j in mine], cond, topk)
+                k_ = min(topk, p_.shape[1])
+                idx[:len(mine), :k_], prob[:len(mine), :k_] = i_[:, :k_].to(torch.int32), p_[:, :k_].float()
+                toks[:len(mine), :min(nt, analysis.shape[1])] = analysis[:, :nt].to(torch.int32)
+            from .distributed import all_gather_topk, gather_rows
+            g_idx, g_prob = all_gather_topk(idx, prob, group=group)          # [world * cap, k], rank-major
+            g_tok = gather_rows(toks, group=group)
+            pos = [(j % world) * cap + j // world for j in range(len(live))]  # where request j of `live` sits in the gathered rows
+            sel = torch.tensor(pos, dtype=torch.long, device=g_idx.device)
+            probs_np, idx_np = g_prob[sel].float().cpu().numpy(), g_idx[sel].cpu().numpy()
+            tok_rows = g_tok[sel].cpu()
+            triples = self.graph_predictor.merge_topk(probs_np, idx_np, smiles)
+            analyses = [[int(t) for t in row.tolist() if t >= 0] for row in tok_rows]
+        else:
+            analysis, cond = self._decode_analysis(prompts, graph_lists, kwargs)
+            if hasattr(self.graph_predictor, "sample_templates_batch"):
+                triples = self.graph_predictor.sample_templates_batch(products, cond, smiles, topk)
+            else:
+                triples = [self.graph_predictor.sample_templates(g, cond[j:j + 1], s, topk) for j, (g, s) in enumerate(zip(products, smiles))]
+            analyses = [analysis[j].cpu().tolist() for j in range(len(live))]
+        for j, i in enumerate(live):
+            reactants, scores, templates = triples[j]
+            head = self.tokenizer.encode(f"To synthesize {smiles[j]}, follow these procedures: ")
+            results[i] = {"reactants": reactants, "scores": scores, "templates": templates, "analysis": head + analyses[j]}
+        return results
+
+    def _expansion_shard(self):
+        """(rank, world, group) when a lock-step round's expansions / value estimates are split over the ranks (``expansion_shard``
+        attribute, set by the driver: every rank then runs the SAME searches), else None."""
+        sh = getattr(self, "expansion_shard", None)
+        if sh is None:
+            return None
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        return sh
+
+    def _decode_analysis(self, prompts, graph_lists, kwargs):
+        """Device part of an expansion round for `prompts` (one per request): GIN-encode every spliced graph, ONE batched LLM decode over
+        the left-padded prompts, one query-token forward -> (analysis tokens [n, new], predictor condition [n, 768])."""
         # ---- one encoder forward for every <molecule> slot of every prompt
         emb_layer = self.language_model.get_input_embeddings()
         all_graphs = GraphBatch.from_data_list([g for gl in graph_lists for g in gl])
@@ -476,6 +532,7 @@ class GraphLLMForCausalMLM(nn.Module):
             mask[j, L - p.shape[1]:] = 1
             embeds.append(e)
         embeds = torch.cat(embeds, dim=0)
+        kwargs = dict(kwargs)
         if "max_new_tokens" in kwargs:
             kwargs["max_new_tokens"] = self.retro_max_new_tokens
         analysis = self._llm_generate(attention_mask=mask, inputs_embeds=embeds, **kwargs)
@@ -483,17 +540,7 @@ class GraphLLMForCausalMLM(nn.Module):
                                                  start_token_id=self.token_id_dict["<retro_start>"])
         hidden = self._query_hidden(retro_ids)
         cond = self.lm_to_graph_predictor(hidden.to(next(self.lm_to_graph_predictor.parameters()).dtype))
-        smiles = [requests[i]["product_smiles"] for i in live]
-        if hasattr(self.graph_predictor, "sample_templates_batch"):
-            triples = self.graph_predictor.sample_templates_batch(products, cond, smiles, topk)
-        else:
-            triples = [self.graph_predictor.sample_templates(g, cond[j:j + 1], s, topk) for j, (g, s) in enumerate(zip(products, smiles))]
-        for j, i in enumerate(live):
-            reactants, scores, templates = triples[j]
-            head = self.tokenizer.encode(f"To synthesize {smiles[j]}, follow these procedures: ")
-            results[i] = {"reactants": reactants, "scores": scores, "templates": templates,
-                          "analysis": head + analysis[j].cpu().tolist()}
-        return results
+        return analysis, cond
 
     _ANSWERS = ["All readily available", "Some commercial, some need 1-2 steps",
                 "Mix of commercial and multi-step synthesis", "Mostly require complex synthesis",
@@ -611,6 +658,24 @@ class GraphLLMForCausalMLM(nn.Module):
         costs = [0.0] * n
         if n == 0:
             return costs
+        shard = self._expansion_shard()
+        if shard is not None and not getattr(self, "_in_value_shard", False) and not self._language_cost_is_constant():
+            # the round's value prompts split over the ranks (item i on rank i % world), ONE all-gather of the float64 costs
+            rank, world, group = shard
+            mine = list(range(rank, n, world))
+            cap = (n + world - 1) // world
+            self._in_value_shard = True
+            try:
+                local = self.estimate_synthesis_complexity_batch([items[i] for i in mine], input_ids, molecule_cost_weight,
+                                                                 language_cost_weight, max_batch) if mine else []
+            finally:
+                self._in_value_shard = False
+            buf = torch.zeros((cap, 1), dtype=torch.float64, device=self.device)
+            if local:
+                buf[:len(local), 0] = torch.tensor(local, dtype=torch.float64)
+            from .distributed import gather_rows
+            allc = gather_rows(buf, group=group).cpu()
+            return [float(allc[(i % world) * cap + i // world, 0]) for i in range(n)]
         if max_batch is None:
             max_batch = int(os.environ.get("LLAMOLE_VALUE_BATCH", self.value_batch))
         if molecule_cost_weight is not None and molecule_cost_weight > 0:

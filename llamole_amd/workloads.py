@@ -61,7 +61,7 @@ def build_gin_pair(device, out_dim: int, layers: int = 5, hidden: int = 512, tem
 
 
 # ------------------------------------------------------------------------------------------------------------ retro (configs[2])
-def build_retro_step(args, graph_decoder, device, rank: int):
+def build_retro_step(args, graph_decoder, device, rank: int, world: int = 1):
     """step_fn(i) -> (designed molecule graphs, per-target records [targets, 3] f32 = (succeeded, route length, route cost)).  One step = the design phase for `targets` prompts as ONE batch (LLM decode of the analysis, query forward,
     GraphDiT reverse diffusion) + `targets` A* searches run in lock step (reference: one after the other, :1173-1190) with at most
     `iterations` expansions each (search depth <= iterations)."""
@@ -99,17 +99,24 @@ def build_retro_step(args, graph_decoder, device, rank: int):
     orch.smiles_to_graph = lambda s: type(pool[0])(*(t.clone() for t in (lambda g: (g.x, g.edge_index, g.edge_attr))(pool[zlib.crc32(s.encode()) % 64])))
     accel = orch.enable_mi355x_decode()
     orch.constant_language_cost_shortcut = bool(getattr(args, "retro_constant_value", False))      # opt-in; default: every value forward runs
-    T = args.targets
+    # --total-targets N (strong scaling): the N searches of a step are ONE lock-step problem for all ranks -- every rank runs the same
+    # host A*, each round's expansions and value prompts are split over the ranks (expansion_shard: one all-gather of top-k records +
+    # one of costs per round); the design phase of the step is split by prompt.  Default (weak scaling): `targets` searches per GPU.
+    total = int(getattr(args, "total_targets", 0) or 0)
+    T = total if total else args.targets
+    Td = len(range(rank, T, world)) if total else T          # prompts this rank designs
+    if total and world > 1:
+        orch.expansion_shard = (rank, world, None)
     kw = dict(expansion_topk=args.topk, iterations=args.iterations, starting_mols=purchasable, max_planning_time=1e9, rollback=False,
               design_text="Design", do_sample=True, temperature=0.6, top_p=0.9, max_new_tokens=args.retro_tokens,
               eos_token_id=[], pad_token_id=tok.pad_token_id)
     orch.retro_max_new_tokens = args.retro_tokens
     g = torch.Generator().manual_seed(100 + rank)
-    prompt = torch.randint(5, 1000, (T, args.cutoff_len), generator=g).to(device)
+    prompt = torch.randint(5, 1000, (max(Td, 1), args.cutoff_len), generator=g).to(device)
     mask = torch.ones_like(prompt)
     dkw = e2e.gen_kwargs(tok, args.new_tokens)
-    props, _, _ = synth.make_dit_inputs(T, seed=rank, max_node=graph_decoder.max_n_nodes)
-    n_nodes = torch.full((T,), graph_decoder.max_n_nodes, dtype=torch.int64)
+    props, _, _ = synth.make_dit_inputs(max(Td, 1), seed=rank, max_node=graph_decoder.max_n_nodes)
+    n_nodes = torch.full((max(Td, 1),), graph_decoder.max_n_nodes, dtype=torch.int64)
     last = {}
     count = {"expansions": 0, "value_estimates": 0, "value_calls": 0}
     expand, values = orch.one_step_reaction_batch, orch.estimate_synthesis_complexity_batch
@@ -137,7 +144,8 @@ def build_retro_step(args, graph_decoder, device, rank: int):
         _, _, cond = orch.design_hidden(prompt, mask, None, **dkw)
         mols, _ = graph_decoder.generate_graphs(props, cond.float(), -200.0, n_nodes=n_nodes, seed=1000 * rank + i)
         t1 = time.perf_counter()
-        targets = [(f"S{2 + (j // 2) % 3}d0_{rank}_{i}_{j}" if j % 2 == 0 else f"U_d0_{rank}_{i}_{j}") for j in range(T)]
+        tr = 0 if total else rank                                   # strong scaling: the same targets on every rank
+        targets = [(f"S{2 + (j // 2) % 3}d0_{tr}_{i}_{j}" if j % 2 == 0 else f"U_d0_{tr}_{i}_{j}") for j in range(T)]
         orch.value_tokens_forwarded = 0
         routes = orch.retrosynthesize_many([None] * T, targets, **kw)
         torch.cuda.synchronize()

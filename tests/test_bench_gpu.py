@@ -99,11 +99,24 @@ def test_bench_retro_workload(gpus):
     d = _line(_run(["--gpus", str(gpus)] + RETRO_TINY, SHARED if gpus > 1 else {}, workload="retro"))
     assert d["n_gpus"] == gpus and d["unit"] == "molecules/s" and d["value"] > 0
     assert d["config"]["prompts_per_step"] == 3 * gpus and d["config"]["gathered_routes"] == 3 * gpus
-    assert d["expansions"] == 3 * 2 * gpus and d["expansions_per_s"] > 0           # every search runs its 2 expansions (nothing is purchasable)
+    assert d["expansions"] == 3 * 2 * gpus and d["expansions_per_s"] > 0           # every search runs its 2 expansions (one closes at the second)
+    assert d["routes_found"] == gpus and d["route_lengths"] == [2] * gpus and d["searches_without_route"] == 2 * gpus      # scripted chemistry: S2 / U / S3
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and "A* retrosynthesis" in d["config"]["workload"]
     # the value forwards: all searches of a round in one call, the prompts' shared opening forwarded once, their rate against the MFMA peak
     assert d["value_prompts_per_call"] > 3 and d["value_prompt_opening_tokens"] >= 8
     assert d["value_forward_mfma"]["bound"] == "mfma" and 0 < d["value_forward_mfma"]["frac"] < 1 and d["value_forward_mfma"]["tokens"] > 0
+
+
+def test_bench_retro_strong_scaling_splits_every_round():
+    """--total-targets: ONE lock-step A* for the whole job, replicated on every rank, each round's expansions and value prompts split over
+    the ranks (one all-gather of top-k records + analysis tokens, one of the costs): the routes of two ranks equal those of one."""
+    one = _line(_run(["--gpus", "1", "--total-targets", "4"] + RETRO_TINY, {}, workload="retro"))
+    two = _line(_run(["--gpus", "2", "--total-targets", "4"] + RETRO_TINY, SHARED, workload="retro"))
+    for d, n in ((one, 1), (two, 2)):
+        assert d["n_gpus"] == n and d["scaling"] == "strong" and d["config"]["prompts_per_step"] == 4 and d["config"]["gathered_routes"] == 4
+        assert d["expansions"] == 4 * 2                                            # counted once, not once per rank
+    assert one["routes_found"] == two["routes_found"] == 1 and one["route_lengths"] == two["route_lengths"] == [2]
+    assert "split over 2 GPU(s)" in two["config"]["workload"]
 
 
 def test_bench_retro_constant_value_shortcut():

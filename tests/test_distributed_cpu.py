@@ -266,3 +266,116 @@ def test_work_queue_rank0_raises_instead_of_hanging_when_a_peer_dies():
     for p in procs:
         p.join(timeout=30)
     assert res[1] == "left" and res[0].startswith("raised") and "1 of 2 ranks" in res[0], res
+
+
+# ------------------------------------------------------------------------------------------------ expansion-level split
+def _sharded_world(rank, world):
+    """A scripted orchestrator whose every device-side answer is a function of the request alone (never of its batch mates), so that
+    the sharded and the unsharded run must agree exactly: the LM 'decodes' tokens derived from the prompt embedding, its forward is a
+    masked running mean, the predictor's top-k comes from a digest of (graph, condition)."""
+    import types
+    import zlib
+    from llamole_amd.graph_data import GraphData
+    from llamole_amd.modeling_llamole import GraphLLMForCausalMLM, make_connector
+    from tests import host_fakes as hf
+
+    class RowLM(hf.FakeLM):
+        def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, position_ids=None, **kw):
+            h = self.emb(input_ids) if inputs_embeds is None else inputs_embeds
+            m = torch.ones(h.shape[:2]) if attention_mask is None else attention_mask[:, -h.shape[1]:].float()
+            h = torch.cumsum(h * m[..., None], dim=1) / torch.cumsum(m, dim=1).clamp_min(1.0)[..., None]
+            return types.SimpleNamespace(logits=self.head(h), hidden_states=(h, h))
+
+        def generate(self, inputs=None, attention_mask=None, inputs_embeds=None, max_new_tokens=4, **kw):
+            src = inputs_embeds if inputs_embeds is not None else self.emb(inputs)
+            m = torch.ones(src.shape[:2]) if attention_mask is None else attention_mask.float()
+            key = (src * m[..., None]).sum(dim=(1, 2))
+            n = min(int(max_new_tokens), 6)
+            new = torch.stack([(torch.arange(n) * 3 + int(abs(float(k)) * 1000) % 11) % 7 + 20 for k in key])
+            return new if inputs is None else torch.cat([inputs, new], dim=1)
+
+    class TopkPredictor(hf.FakePredictor):
+        label_to_template = {i: f"T{i}" for i in range(64)}
+
+        def topk_templates_batch(self, graphs, c, topk):
+            idx, prob = [], []
+            for g, row in zip(graphs, c):
+                h = zlib.crc32(bytes(g.x.tolist())) ^ (int(abs(float(row.float().sum())) * 997) & 0xffff)
+                idx.append([(h + 7 * k) % 64 for k in range(topk)])
+                p = torch.softmax(torch.arange(topk, 0, -1).float() * 0.3, 0)
+                prob.append(p.tolist())
+            return torch.tensor(prob), torch.tensor(idx, dtype=torch.int32)
+
+        def sample_templates_batch(self, graphs, c, smiles_list, topk):
+            p, i = self.topk_templates_batch(graphs, c, topk)
+            return self.merge_topk(p.numpy(), i.numpy(), smiles_list)
+
+        def merge_topk(self, probs, idx, smiles_list):
+            out = []
+            for pr, ix, s in zip(probs, idx, smiles_list):
+                d = int(s[1]) if s[0] == "P" else 0
+                seen, reactants, scores, temps = {}, [], [], []
+                for p, i in zip(pr, ix):
+                    h = zlib.crc32(f"T{int(i)}{s}".encode())
+                    r = ".".join(sorted([f"B{h % 5}" if (h >> 8) % 4 <= d else f"P{d + 1}_{h % 97}", f"B{(h >> 4) % 5}"]))
+                    if r in seen:
+                        scores[seen[r]] += float(p)
+                    else:
+                        seen[r] = len(reactants)
+                        reactants.append(r); scores.append(float(p)); temps.append(f"T{int(i)}")
+                tot = sum(scores)
+                out.append((reactants, [v / tot for v in scores], temps))
+            return out
+
+    m = GraphLLMForCausalMLM(types.SimpleNamespace(), types.SimpleNamespace(), types.SimpleNamespace(learned_query_size=8), RowLM(),
+                             hf.FakeDecoder([]), TopkPredictor({}, []), hf.FakeEncoder(), dict(hf.TOKEN_IDS), hf.Tok())
+    for k, v in hf.seeded_connectors(make_connector).items():
+        setattr(m, k, v)
+    m.smiles_to_graph = hf.fake_smiles_to_graph(GraphData)
+    m.expected_cost_value = True                      # every value forward counts (not the constant 15 of the reference's broadcast)
+    m.retro_max_new_tokens = 6
+    return m
+
+
+def _plan(m, n_targets):
+    kw = dict(expansion_topk=6, iterations=4, starting_mols={f"B{i}" for i in range(5)}, max_planning_time=1e9, rollback=False,
+              design_text="Design", max_new_tokens=6)
+    targets = [f"P0_{i}" for i in range(n_targets)]
+    out = m.retrosynthesize_many([None] * n_targets, targets, **kw)
+    return [(o["success"], o["route_length"], o["reaction_list"], None if o["cost"] is None else [round(c, 9) for c in o["cost"]],
+             o["templates"]) for o in out]
+
+
+def _split_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        solo = _plan(_sharded_world(rank, world), 7)                 # every rank alone, no exchange
+        m = _sharded_world(rank, world)
+        m.expansion_shard = (rank, world, None)
+        gen, fwd = m.language_model.generate_calls, m.language_model.forward_calls
+        split = _plan(m, 7)
+        q.put((rank, solo == split, sum(o[0] for o in solo), len(gen), len(fwd)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_expansion_level_split_world2_equals_solo():
+    """A lock-step round's expansions and value prompts split over two ranks with a replicated host A*: one all-gather of
+    (topk_idx, topk_prob) + analysis tokens per round, one of the costs per value call -- routes, costs and templates identical to
+    the unsharded searches on every rank (SURVEY.md 8e second alternative; modeling_llamole.one_step_reaction_batch)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert [r[1] for r in res] == [True, True], res
+    assert res[0][2] >= 1 and res[0][2] == res[1][2]                 # some searches succeed, the same ones on both ranks
