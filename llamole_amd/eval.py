@@ -239,6 +239,8 @@ def run_eval(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> Di
                     training_args.per_device_eval_batch_size, gen_kwargs, rank=rank, world=world, work_queue=queue,
                     expansion_topk=data_args.expansion_topk, iterations=data_args.retro_iterations,
                     max_planning_time=data_args.retro_max_planning_time)
+    from .graph_encoder import check_graph_errors
+    check_graph_errors(wait=True)          # nothing malformed may leave the run unreported (the flag of the last GIN call)
     if rank == 0:
         print(json.dumps(out["stats"]))
         if training_args.output_dir:

@@ -49,6 +49,7 @@ _CSR_ERRORS = {1: "`batch` must be sorted (PyG Batch convention) with ids in [0,
                2: "edge_index refers to a node outside the batch",
                3: "atom type outside [0, 118) or bond type outside [0, 5)"}
 _pending_csr_flags = []       # slots of the pinned flag ring whose conversion kernel may not have finished yet
+_flag_origin = {}             # slot -> "file:line (function)" of the call that converted the batch (named in the error message)
 _flag_ring = None             # pinned int32[256]: the conversion kernel's LAST instruction stores its error flag straight into host memory
 _flag_next = 0
 
@@ -62,26 +63,46 @@ def _flag_slot():
     slot = _flag_next
     _flag_next = (_flag_next + 1) % 256
     _flag_ring[slot] = -1         # "not run yet"; the kernel overwrites it with 0 (ok) or an error code when it is done
+    _flag_origin[slot] = _caller()
     return slot
+
+
+def _caller() -> str:
+    """First frame outside the graph wrappers: the call that handed over the batch (a late error must name IT, not the call that finds the flag)."""
+    import sys
+    f = sys._getframe(2)
+    here = ("graph_encoder.py", "graph_predictor.py")
+    while f is not None and f.f_code.co_filename.endswith(here):
+        f = f.f_back
+    return "?" if f is None else f"{f.f_code.co_filename.rsplit('/', 1)[-1]}:{f.f_lineno} ({f.f_code.co_name})"
 
 
 def check_graph_errors(wait: bool = False):
     """Raise ValueError if an earlier ``graph_csr_device`` call saw a malformed batch.  The conversion kernel clamps every id it
     writes (so the GIN kernels never index out of bounds) and, as its last instruction, stores a flag into pinned host memory;
-    this looks at the flags that have ARRIVED (``wait=True``: synchronises the device first) -- no copy, no event and no
-    synchronisation on the hot path (an event record between the conversion and the forward cost ~6 us of idle GPU per call)."""
-    if wait and _pending_csr_flags:
-        torch.cuda.synchronize()
-    keep, code = [], 0
-    for slot in _pending_csr_flags:
-        v = int(_flag_ring[slot])
-        if v < 0:
-            keep.append(slot)
-        else:
-            code = max(code, v)
-    _pending_csr_flags[:] = keep
-    if code:
-        raise ValueError(_CSR_ERRORS.get(code, f"malformed graph batch (code {code})"))
+    this looks at the flags that have ARRIVED -- no copy, no event and no synchronisation on the hot path (an event record between
+    the conversion and the forward cost ~6 us of idle GPU per call).  ``wait=True`` (end of an eval / generation entry point, before
+    outputs are read on the host, reverse sweeps): flags still outstanding after the poll are waited for -- every device that has one
+    pending is synchronised, and only then; a conversion that has long finished never drains a queue.  The message names the call
+    that converted the offending batch."""
+    def poll():
+        keep, bad = [], None
+        for slot in _pending_csr_flags:
+            v = int(_flag_ring[slot])
+            if v < 0:
+                keep.append(slot)
+            elif v > 0 and (bad is None or v > bad[0]):
+                bad = (v, _flag_origin.get(slot, "?"))
+        _pending_csr_flags[:] = keep
+        return bad
+    bad = poll()
+    if bad is None and wait and _pending_csr_flags:
+        for d in range(torch.cuda.device_count()):
+            torch.cuda.synchronize(d)
+        bad = poll()
+    if bad is not None:
+        code, origin = bad
+        raise ValueError(_CSR_ERRORS.get(code, f"malformed graph batch (code {code})") + f" [batch converted at {origin}]")
 
 
 def graph_csr_device(x, edge_index, edge_attr, batch, num_graphs=None):

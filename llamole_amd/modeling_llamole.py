@@ -701,9 +701,19 @@ class GraphLLMForCausalMLM(nn.Module):
             # prompts of similar length share a forward (less padding; every row still computes exactly its own unpadded forward), and
             # the host never waits between forwards: the per-chunk costs stay on the device until all chunks are enqueued
             order = sorted(range(n), key=lambda i: len(rows[i]))
+            # chunks are capped by TOKENS as well as by prompts: with the shared opening every row of a chunk keeps keys / values for
+            # P + L positions in every layer during its forward (value_batch was tuned on ~140-token prompts of Qwen2-7B: ~8 GB; longer
+            # prompts or more KV heads must not grow that without bound).  LLAMOLE_VALUE_TOKENS / value_token_cap overrides.
+            tok_cap = int(os.environ.get("LLAMOLE_VALUE_TOKENS", getattr(self, "value_token_cap", 160 * 1024)))
+            chunks, lo = [], 0
+            while lo < n:
+                hi = lo + 1
+                while hi < n and hi - lo < max_batch and (hi - lo + 1) * len(rows[order[hi]]) <= tok_cap:
+                    hi += 1
+                chunks.append(order[lo:hi])
+                lo = hi
             pending = []
-            for lo in range(0, n, max_batch):
-                sel = order[lo:lo + max_batch]
+            for sel in chunks:
                 chunk = [rows[i][P:] for i in sel]
                 L = max(len(r) for r in chunk)
                 ids = torch.full((len(chunk), L), pad, dtype=torch.long)
@@ -719,7 +729,24 @@ class GraphLLMForCausalMLM(nn.Module):
                     from transformers import DynamicCache
                     B = len(chunk)
                     cache = DynamicCache(ddp_cache_data=[(k.expand(B, -1, -1, -1), v.expand(B, -1, -1, -1)) for k, v in opening])
-                    logits = self.language_model(logits_to_keep=1, use_cache=True, past_key_values=cache, **kw).logits[:, -1, :]
+                    try:
+                        logits = self.language_model(logits_to_keep=1, use_cache=True, past_key_values=cache, **kw).logits[:, -1, :]
+                    except torch.OutOfMemoryError:
+                        # the cached form keeps every layer's keys / values of the chunk resident: forward the WHOLE prompts without a
+                        # cache instead (same costs; what the path did before the shared opening)
+                        del cache
+                        torch.cuda.empty_cache()
+                        full = [rows[i] for i in sel]
+                        Lf = max(len(r) for r in full)
+                        idf = torch.full((len(full), Lf), pad, dtype=torch.long)
+                        mf = torch.zeros((len(full), Lf), dtype=torch.long)
+                        for j, r in enumerate(full):
+                            idf[j, Lf - len(r):] = torch.tensor(r, dtype=torch.long)
+                            mf[j, Lf - len(r):] = 1
+                        idf, mf = idf.to(self.device), mf.to(self.device)
+                        logits = self.language_model(input_ids=idf, attention_mask=mf, position_ids=(mf.cumsum(dim=1) - 1).clamp_min(0),
+                                                     logits_to_keep=1, use_cache=False).logits[:, -1, :]
+                        cache = None
                     del cache
                 else:
                     try:      # only the last position's logits are read: no [B, L, vocab] product, no KV cache
@@ -903,4 +930,9 @@ class GraphLLMForCausalMLM(nn.Module):
             info["text_lists"].append(texts)
             info[f"batch_{b}_ignore_positions"] = ignore
         info["IGNORE_INDEX"] = IGNORE_INDEX
+        try:      # a malformed graph batch of the LAST GIN call of this run must not go unreported (the flag is otherwise found by the next call)
+            from .graph_encoder import check_graph_errors
+            check_graph_errors(wait=True)
+        except ImportError:
+            pass
         return info
