@@ -530,7 +530,7 @@ def test_packed_weight_mlp_vs_ring_gemms(N, H, heads, B):
     m.set_option("xw_gemm", -1)        # opt-in: ll_dit_begin times both kernels on this device for this batch
     m.begin(props, text, -200.0, n_nodes)
     choice = m.mlp_choice()
-    assert choice["fc1"] in ("ring", "panel") and choice["fc2"] in ("ring", "panel") and choice["calibrated"] is True
+    assert set(choice["xw_panel"]) == {"fc1", "fc2"} and choice["calibrated"] is True
     assert min(choice["chain_us"].values()) > 0, choice
     m.init_state(*synth.exp_noise(seed, m.T, B, N))
     s = m.T - 1
