@@ -1,0 +1,27 @@
+#!/bin/bash
+# GPU box: the round-4 bench lines and kernel statistics at HEAD (copied from gpurun_out/ into profiles/ afterwards).
+root=$GRAFT_REPO_ROOT; out=$root/gpurun_out; mkdir -p "$out"
+cd "$root"
+bash tools/profile_bench.sh r4_graphdit_b1_step --workload graphdit --batch 1 --steps 3 --warmup 1 > /dev/null 2>&1
+bash tools/profile_bench.sh r4_graphdit_b8_step --workload graphdit --steps 3 --warmup 1 > /dev/null 2>&1
+python bench.py 2>/dev/null | grep '^{' > "$out/r4_bench_e2e.json"
+python bench.py --no-pipeline --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{' > "$out/r4_bench_e2e_nopipeline.json"
+python bench.py --workload graphdit --steps 3 --warmup 1 2>/dev/null | grep '^{' > "$out/r4_bench_graphdit_b8.json"
+python bench.py --workload graphdit --batch 1 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{' > "$out/r4_bench_graphdit_b1.json"
+python bench.py --workload graphdit --batch 16 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{' > "$out/r4_bench_graphdit_b16.json"
+LL_DIT_TEAM=-1 python bench.py --workload graphdit --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{' > "$out/r4_bench_graphdit_b8_team.json"
+python bench.py --workload sft 2>/dev/null | grep '^{' > "$out/r4_bench_sft.json"
+python bench.py --llm llama-3.1-8b --total-prompts 64 --batch 8 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{' > "$out/r4_bench_llama_total64_n1.json"
+for f in r4_bench_e2e r4_bench_e2e_nopipeline r4_bench_graphdit_b8 r4_bench_graphdit_b1 r4_bench_graphdit_b16 r4_bench_graphdit_b8_team r4_bench_sft r4_bench_llama_total64_n1; do python - <<PY
+import json
+try:
+    d = json.loads(open("$out/$f.json").read().strip().splitlines()[-1])
+    rd = d.get("roofline_graphdit") or {}
+    print("$f", round(d["value"], 3), d["unit"], "ms/step", round(d["ms_per_step"], 2), "dit_step_ms", round(d.get("denoise_step_ms") or 0, 4),
+          "roof", round(d["roofline"]["frac"], 3), "roof_dit", round(rd.get("frac", 0) or 0, 3), "insitu_ms", rd.get("kernel_ms"), "b2b_ms", rd.get("kernel_ms_back_to_back"),
+          (d.get("cpu_baseline") or {}).get("value"))
+except Exception as e:
+    print("$f", "ERR", e)
+PY
+done
+grep -i "gemm_m64_kernel<8, 8, unsigned short, true>\|gemm_bf16_pipeu_kernel<64, 64, 4, 4, 4, unsigned short>" "$out"/r4_graphdit_b1_step_kernel_stats.csv "$out"/r4_graphdit_b8_step_kernel_stats.csv
