@@ -379,3 +379,16 @@ def test_expansion_level_split_world2_equals_solo():
         p.join(60)
     assert [r[1] for r in res] == [True, True], res
     assert res[0][2] >= 1 and res[0][2] == res[1][2]                 # some searches succeed, the same ones on both ranks
+
+
+def test_work_queue_heartbeat_is_harmless_without_a_store():
+    q = D.WorkQueue(3)
+    q.beat()
+    assert list(q) == [0, 1, 2]
+
+
+def test_gather_rows_and_topk_are_identity_without_a_group():
+    t = torch.arange(12).view(3, 4)
+    assert D.gather_rows(t) is t
+    i, p = D.all_gather_topk(t.int(), t.float())
+    assert torch.equal(i, t.int()) and torch.equal(p, t.float())

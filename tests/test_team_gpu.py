@@ -13,9 +13,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _model(depth=2, T=10):
+def _model(depth=2, T=10, nodes=32):
     import bench
-    args = types.SimpleNamespace(hidden=1024, depth=depth, heads=16, T=T, guide=2.0, nodes=32, dtype="bf16")
+    args = types.SimpleNamespace(hidden=1024, depth=depth, heads=16, T=T, guide=2.0, nodes=nodes, dtype="bf16")
     return bench.build_model(args, torch.device("cuda"))[0]
 
 
@@ -92,4 +92,32 @@ def test_team_trajectory_properties():
     c = run(list(range(B)), 0)
     agree = sum(float((c[i][1] == a[i][1]).float().mean()) for i in range(B) if int(n_nodes[i]) > 1) / sum(int(n) > 1 for n in n_nodes)
     assert agree >= 0.9, agree
+    m.set_option("team", 0)
+
+
+def test_team_kernel_with_sixteen_node_graphs_and_padding_rows():
+    """max_nodes = 16: half of every 32-row sequence panel is padding (zero rows staged through out-of-range buffer offsets), F = 96 = six
+    output tiles; one teacher-forced step against the chain, then a trajectory."""
+    from llamole_amd import synth
+    N, T, B = 16, 10, 5
+    m = _model(nodes=N)
+    props, text, _ = synth.make_dit_inputs(B, seed=4, max_node=N)
+    n_nodes = torch.tensor([16, 9, 1, 16, 4])
+    mask = torch.arange(N).unsqueeze(0) < n_nodes.unsqueeze(1)
+    um = _upper(n_nodes, N)
+    m.begin(props, text, -200.0, n_nodes)
+    out = {}
+    for mode in (0, 1):
+        m.set_option("team", mode)
+        m.init_state(*synth.exp_noise(6, T, B, N))
+        out[mode] = [t.cpu() for t in m.denoise_logits(T - 1)]
+    scale = max(float(out[0][0].abs().max()), float(out[0][1].abs().max()), 1.0)
+    assert float(((out[1][0] - out[0][0]) * mask.view(1, B, N, 1)).abs().max()) / scale <= 2e-2
+    assert float(((out[1][1] - out[0][1]) * um.view(1, B, N, N, 1)).abs().max()) / scale <= 2e-2
+    torch.manual_seed(1)
+    a = m.generate_graphs(props, text, -200.0, n_nodes=n_nodes, seed=9)[0]
+    assert m.last_run_ms()[1] == T
+    for i, (x, e) in enumerate(a):
+        n = int(n_nodes[i])
+        assert x.shape == (n,) and torch.equal(e, e.t()) and int(x.min()) >= 0 and int(x.max()) < 16 and int(e.max()) < 5
     m.set_option("team", 0)

@@ -164,3 +164,35 @@ def test_merge_lora_adapter_with_modules_to_save(tmp_path):
     small.resize_token_embeddings(small.config.vocab_size - 64)          # the base model was NOT resized to the adapter's vocabulary
     with pytest.raises(ValueError, match="resize"):
         merge_lora_adapter(small, str(tmp_path / "ad"))
+
+
+def test_csr_error_names_the_call_that_converted_the_batch(monkeypatch):
+    """a malformed batch is reported by a LATER call; the message must name the call that handed the batch over, and a flag
+    that has already arrived must not cost a device synchronisation."""
+    from llamole_amd import graph_encoder as ge
+    ring = torch.zeros(256, dtype=torch.int32)
+    monkeypatch.setattr(ge, "_flag_ring", ring)
+    monkeypatch.setattr(ge, "_pending_csr_flags", [])
+    monkeypatch.setattr(ge, "_flag_origin", {})
+    syncs = []
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: syncs.append(a))
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+
+    def convert():                       # stands in for graph_csr_device: takes a slot, the "kernel" answers later
+        slot = ge._flag_slot()
+        ge._pending_csr_flags.append(slot)
+        return slot
+    s0 = convert()
+    ring[s0] = 0                         # fine batch, flag arrived
+    ge.check_graph_errors(wait=True)
+    assert not syncs and not ge._pending_csr_flags
+    s1 = convert()
+    ge.check_graph_errors()              # not arrived yet, no wait: nothing happens
+    assert ge._pending_csr_flags == [s1] and not syncs
+    ring[s1] = 2                         # the kernel found an edge outside the batch
+    with pytest.raises(ValueError, match=r"outside the batch.*\[batch converted at test_wrappers_cpu.py:\d+ \(convert\)\]"):
+        ge.check_graph_errors(wait=True)
+    assert not syncs                     # the flag was there: polled, not waited for
+    s2 = convert()                       # still -1 after the poll: only now the devices are synchronised
+    ge.check_graph_errors(wait=True)
+    assert len(syncs) == 1 and ge._pending_csr_flags == [s2]
