@@ -158,7 +158,12 @@ int ll_dit_set_overlap(void *handle, int on);
  * under ll_dit_step / ll_dit_denoise / ll_dit_step_probs (one step of the team kernel, posterior by the chain's kernels): the parity
  * taps of that path.  Also env LL_DIT_TEAM.  The team kernel sums K in another order than the chain: within one mode a seed fixes
  * the molecules, and in team mode a graph's trajectory does not depend on the batch around it (every graph is processed alone). */
-enum { LL_DIT_OPT_OVERLAP = 0, LL_DIT_OPT_GENERIC_ATTN = 1, LL_DIT_OPT_FUSED_QKV_ATTN = 2, LL_DIT_OPT_XW_GEMM = 3, LL_DIT_OPT_TEAM = 4 };
+/* LL_DIT_OPT_PROJ_LN = the block's attention projection and its AdaLN epilogue as ONE launch on per-XCD teams (proj_ln_team_kernel: the
+ * 2 MB projection weight replicated across the XCDs, one graph's rows per XCD, LayerNorm behind a same-L2 team barrier): 0 (default) =
+ * never (two launches: measured faster at every batch), 1 = whenever eligible (bf16, hidden 1024, <= 32 nodes in multiples of 4, not in
+ * overlap mode).  Sums K in another order than the two launches (full K per tile, no split-K slabs). */
+enum { LL_DIT_OPT_OVERLAP = 0, LL_DIT_OPT_GENERIC_ATTN = 1, LL_DIT_OPT_FUSED_QKV_ATTN = 2, LL_DIT_OPT_XW_GEMM = 3, LL_DIT_OPT_TEAM = 4,
+       LL_DIT_OPT_PROJ_LN = 5 };
 int ll_dit_set_option(void *handle, int option, int value);
 int ll_dit_last_run_ms(void *handle, float *ms, int *steps);
 /* What ll_dit_begin's calibration measured for the current batch (us per fc1 -> fc2 -> AdaLN chain with fc1 / fc2 on ring/ring,

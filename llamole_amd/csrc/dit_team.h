@@ -142,6 +142,7 @@ struct Who {
     Ctl *ctl;
     unsigned int bar_gen;          // team barriers passed so far
     int io_gen, m_gen, p_tgt;      // uses of the LDS group barriers (p_tgt: expected value of the partial-tile counter)
+    unsigned int *err;             // error word of the launch's control block
     bool ok;
 };
 
@@ -149,7 +150,7 @@ struct Who {
 __device__ __forceinline__ void io_barrier(Who &w) {
     ++w.io_gen;
     lds_signal(&w.fl->io_bar, w.lane);
-    lds_wait(&w.fl->io_bar, 4 * w.io_gen, w.ok, &w.ctl->error);
+    lds_wait(&w.fl->io_bar, 4 * w.io_gen, w.ok, w.err);
 }
 
 // Team barrier, called by the four I/O waves: every global store of this workgroup that the next phase's readers need was issued by
@@ -159,7 +160,7 @@ __device__ __forceinline__ void team_barrier(Who &w) {
     ++w.bar_gen;
     lds_signal(&w.fl->io_drain, w.lane);
     if (w.iw == 0) {
-        lds_wait(&w.fl->io_drain, 4 * (int)w.bar_gen, w.ok, &w.ctl->error);
+        lds_wait(&w.fl->io_drain, 4 * (int)w.bar_gen, w.ok, w.err);
         unsigned int *ctr = &w.ctl->bar[w.xcc][0];
         if (w.lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned int target = w.bar_gen * TEAM;
@@ -167,13 +168,13 @@ __device__ __forceinline__ void team_barrier(Who &w) {
         while (w.ok && (unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > 20000000u) {                                 // seconds: a team member never arrived
-                atomicOr(&w.ctl->error, 1u);
+                atomicOr(w.err, 1u);
                 w.ok = false;
             }
         }
         if (w.lane == 0) __hip_atomic_store(as_lds(&w.fl->io_go), (int)w.bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    lds_wait(&w.fl->io_go, (int)w.bar_gen, w.ok, &w.ctl->error);
+    lds_wait(&w.fl->io_go, (int)w.bar_gen, w.ok, w.err);
 }
 
 // global row of panel row r of graph g: rows [0, NP) conditional, [NP, 2 NP) unconditional; -1 for padding rows
@@ -203,9 +204,11 @@ __device__ __forceinline__ void stage_panel(const Who &w, const bf16_t *src, int
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
         const int node0 = (i * RPI) & (NP - 1);        // first node of the step (the step's rows are node0 + r0)
-        // padding rows: an offset beyond the descriptor's range -- the buffer load returns zeros, no branch
-        const int soff = node0 < N ? ((i * RPI) >> 5 ? seq1 : seq0) + node0 * ld * 2 : 0x7ffffff0;
-        v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 16);      // sc1
+        // padding rows: a lane offset beyond the descriptor's range -- the buffer load returns zeros, no branch
+        // (2 GB in the VGPR offset: the range check compares the START of the access, voffset + inst_offset, with num_records = 2 GB - 1;
+        // measured: 0x7ffffff0 in either offset register is served, and faults)
+        const int soff = ((i * RPI) >> 5 ? seq1 : seq0) + (node0 < N ? node0 : 0) * ld * 2;
+        v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, node0 < N ? voff : (int)0x80000000u, soff, 16);      // sc1
     }
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
@@ -382,7 +385,7 @@ __device__ __forceinline__ void gemm_phase_mfma(Who &w, Fifo<H> &ff, const WBase
     // every MFMA wave is done with the panel before its LDS turns into the output image
     ++w.m_gen;
     lds_signal(&w.fl->m_done, lane);
-    lds_wait(&w.fl->m_done, 4 * w.m_gen, w.ok, &w.ctl->error);
+    lds_wait(&w.fl->m_done, 4 * w.m_gen, w.ok, w.err);
     const int irow = icols * ESZ + 16;                               // padded row pitch of the image
     if (KW == 2) {
         // partial tiles of the upper K half go through LDS (behind the image), summed lower + upper
@@ -395,7 +398,7 @@ __device__ __forceinline__ void gemm_phase_mfma(Who &w, Fifo<H> &ff, const WBase
                 for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<af32x4 *>(part + ((t * 4 + mt) * 64 + lane) * 4) = acc[t][mt];
             lds_signal(&w.fl->m_part, lane);
         } else {
-            lds_wait(&w.fl->m_part, w.p_tgt, w.ok, &w.ctl->error);
+            lds_wait(&w.fl->m_part, w.p_tgt, w.ok, w.err);
 #pragma unroll
             for (int t = 0; t < TW; ++t) {
 #pragma unroll
@@ -742,7 +745,7 @@ __device__ __forceinline__ void direct_gemm(Who &w, const bf16_t *wp, int tile, 
     }
     ++w.m_gen;
     lds_signal(&w.fl->m_done, lane);
-    lds_wait(&w.fl->m_done, 4 * w.m_gen, w.ok, &w.ctl->error);
+    lds_wait(&w.fl->m_done, 4 * w.m_gen, w.ok, w.err);
     // K parts through LDS (behind the image), summed in order by part 0
     float *part = reinterpret_cast<float *>(w.lds + 48 * 1024) + (size_t)mw * (4 * 64 * 4);
     if (kpart != 0) {
@@ -751,7 +754,7 @@ __device__ __forceinline__ void direct_gemm(Who &w, const bf16_t *wp, int tile, 
     }
     w.p_tgt += 4;
     lds_signal(&w.fl->m_part, lane);
-    lds_wait(&w.fl->m_part, w.p_tgt, w.ok, &w.ctl->error);
+    lds_wait(&w.fl->m_part, w.p_tgt, w.ok, w.err);
     if (kpart == 0 && tile >= 0) {
         for (int k = 1; k < kparts; ++k) {
             const float *op = part + (size_t)k * (4 * 64 * 4);
@@ -841,6 +844,7 @@ __global__ __launch_bounds__(THREADS) void dit_team_kernel(Args a) {
     w.lds = lds_team;
     w.fl = reinterpret_cast<Flags *>(lds_team + G::PANEL);
     w.ctl = a.ctl;
+    w.err = &a.ctl->error;
     w.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     w.lane = threadIdx.x & 63;
     w.io = w.wave >= 4;
@@ -874,6 +878,192 @@ __global__ __launch_bounds__(THREADS) void dit_team_kernel(Args a) {
     __syncthreads();
     if (w.io) io_main<H>(w, a);
     else mfma_main<H>(w, a);
+}
+
+
+// ================================================================================================ attention projection + AdaLN epilogue, one launch
+// The launch chain's proj GEMM (split-K slabs) and its `ln_mod_res` launch are two dependent launches per block; LayerNorm needs whole rows, i.e.
+// every column tile of the GEMM, which is what forces the boundary.  proj's weight is small (2 MB of bf16 per block), so it can be REPLICATED
+// across the XCDs at no cost that matters (16 MB of L2 misses per launch at batch 8) -- and then one graph's 64 token rows x all 1024 columns can
+// be produced by the 32 CUs of ONE XCD, whose hand-off goes through their own L2: GEMM tile -> plain stores -> 1.1 us team barrier -> LayerNorm of two
+// rows per CU from sc1 loads.  Graphs of the batch go to the teams round robin.  Unlike dit_team_kernel this launch is short, runs inside the chain
+// (after the attention launch, before fc1) and resets its own counters, so the chain needs no memset between launches.
+struct Ctl2 {
+    unsigned int census[8][32];
+    unsigned int bar[8][32];
+    unsigned int leave[8][32];       // workgroups of the XCC that are done: the last one zeroes the three counters of its XCC
+    unsigned int error;
+    unsigned int pad_;
+    unsigned long long stamps[16];   // LL_TEAM_PROBE: 100 MHz clock of XCC 0's first workgroup at the phase boundaries of block 3
+    unsigned long long span[2][256]; // LL_TEAM_PROBE: every workgroup's first and last clock of that launch
+};
+#ifdef LL_TEAM_PROBE
+#define LL_PSTAMP(i) do { if (w.xcc == 0 && c == 0 && threadIdx.x == 0 && p.layer == 3) ctl->stamps[i] = wall_clock64(); } while (0)
+#else
+#define LL_PSTAMP(i) do { } while (0)
+#endif
+
+struct ProjLnArgs {
+    int B, N, L, layer;
+    const bf16_t *ao;                // [2 B N][H] attention output
+    const bf16_t *wproj;             // packed weight of this layer
+    const float *bias;
+    const float *modrows;            // this step's modulation rows [(B + 1)][L][6 H]
+    float *y;                        // [2 B N][H] f32 scratch (slab 0 of the chain's split-K buffer)
+    float *x32;
+    bf16_t *xa;
+    Ctl2 *ctl;
+};
+
+// 512-thread panel staging from data a PREVIOUS launch wrote (plain policy)
+template <int KCH>
+__device__ __forceinline__ void stage_panel512(unsigned char *lds, int tid, const bf16_t *src, int ld, int g, int B, int N) {
+    constexpr int PPR = KCH / 8, RPI = 512 / PPR, PT = ROWS / RPI;
+    static_assert(512 % PPR == 0 && ROWS % RPI == 0 && NP % RPI == 0, "panel pieces");
+    const int r0 = tid / PPR, col = tid % PPR;
+    const __amdgpu_buffer_rsrc_t rs = rsrc_of(src);
+    const int voff = (r0 * ld + col * 8) * 2;
+    const int seq0 = g * N * ld * 2, seq1 = (B * N + g * N) * ld * 2;
+    u32x4 v[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int node0 = (i * RPI) & (NP - 1);
+        const int soff = ((i * RPI) >> 5 ? seq1 : seq0) + (node0 < N ? node0 : 0) * ld * 2;
+        v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, node0 < N ? voff : (int)0x80000000u, soff, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int row = r0 + i * RPI;
+        *reinterpret_cast<u32x4 *>(lds + row * (KCH * 2) + ((col ^ (row & 15)) << 4)) = v[i];
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(THREADS) void proj_ln_team_kernel(ProjLnArgs p) {
+    using G = Geom<H>;
+    static_assert(H / 16 / TEAM == 2, "two 16-column tiles per CU");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_pl[];
+    Who w;
+    w.lds = lds_pl;
+    w.fl = reinterpret_cast<Flags *>(lds_pl + G::PANEL);
+    w.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    w.lane = threadIdx.x & 63;
+    w.io = true;
+    w.iw = w.wave;                                     // ln_phase / io_barrier see waves 0..3
+    w.bar_gen = 0;
+    w.io_gen = w.m_gen = w.p_tgt = 0;
+    w.ok = true;
+    w.xcc = (int)xcc_id();
+    Ctl2 *ctl = p.ctl;
+    w.ctl = nullptr;
+    w.err = &ctl->error;
+    __shared__ int s_rank2;
+    if (threadIdx.x == 0) {
+        s_rank2 = (int)atomicAdd(&ctl->census[w.xcc][0], 1u);
+        Flags *f = w.fl;
+        f->io_drain = f->io_go = f->io_bar = f->m_done = f->m_part = 0;
+    }
+    __syncthreads();
+    w.rank = s_rank2;
+    const int c = w.rank, B = p.B, N = p.N, lane = w.lane, wave = w.wave;
+    unsigned int *err = &ctl->error;
+    LL_PSTAMP(0);
+#ifdef LL_TEAM_PROBE
+    if (threadIdx.x == 0 && p.layer == 3) ctl->span[0][blockIdx.x] = wall_clock64();
+#endif
+    if (c < TEAM && w.xcc < B) {
+        if (threadIdx.x == 0) {                        // the whole team is here (bounded)
+            unsigned int spins = 0;
+            while (__hip_atomic_load(&ctl->census[w.xcc][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < TEAM) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > 4000000u) { atomicOr(err, 1u); break; }
+            }
+        }
+        __syncthreads();
+        LL_PSTAMP(1);
+        Args a;                                        // what ln_phase reads
+        a.B = B; a.N = N; a.L = p.L;
+        a.modtab = p.modrows; a.ybuf = p.y; a.slab_stride = 0; a.x32 = p.x32; a.xa = p.xa;
+        const __amdgpu_buffer_rsrc_t wr = rsrc_of(p.wproj);
+        const int tile = 2 * c + (wave & 1), kq = wave >> 1;           // this wave: one 16-column tile, one K quarter (8 k-steps)
+        const int fi = lane & 15, fq = lane >> 4;
+        constexpr int ROWB = H * 2;
+        unsigned int bar_gen = 0;
+        for (int g = w.xcc; g < B; g += NTEAMS) {
+            u32x4 wf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wf[j] = load_frag_at(wr, (uint32_t)((tile * G::KS + kq * 8 + j) * 1024), lane * 16);
+            stage_panel512<H>(w.lds, threadIdx.x, p.ao, H, g, B, N);
+            __syncthreads();
+            LL_PSTAMP(2);
+            af32x4 acc[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = af32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ks = kq * 8 + j;
+                const unsigned char *ap = w.lds + fi * ROWB + (((((ks & 3) << 2) | fq) ^ fi) << 4) + (ks >> 2) * 256;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(abf16x8, wf[j]), *reinterpret_cast<const abf16x8 *>(ap + mt * 16 * ROWB), acc[mt], 0, 0, 0);
+            }
+            __syncthreads();                           // the panel is consumed: its LDS takes the K-quarter partials
+            float *part = reinterpret_cast<float *>(w.lds);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<af32x4 *>(part + (((wave * 4) + mt) * 64 + lane) * 4) = acc[mt];
+            __syncthreads();
+            {
+                // wave v finishes block (tile v & 1, m-tile v >> 1): quarters summed in order 0..3; lane: row mt * 16 + fi, columns fq * 4 ..
+                const int t = wave & 1, mt = wave >> 1;
+                af32x4 o = *reinterpret_cast<const af32x4 *>(part + ((((0 * 2 + t) * 4) + mt) * 64 + lane) * 4);
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    const af32x4 u = *reinterpret_cast<const af32x4 *>(part + ((((q * 2 + t) * 4) + mt) * 64 + lane) * 4);
+                    o[0] += u[0]; o[1] += u[1]; o[2] += u[2]; o[3] += u[3];
+                }
+                const int gr = grow_of(mt * 16 + fi, g, B, N);
+                if (gr >= 0) *reinterpret_cast<float4 *>(p.y + (int64_t)gr * H + (2 * c + t) * 16 + fq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            // ---- team barrier over all eight waves
+            LL_PSTAMP(3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            LL_PSTAMP(4);
+            ++bar_gen;
+            if (wave == 0) {
+                unsigned int *ctr = &ctl->bar[w.xcc][0];
+                if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int target = bar_gen * TEAM;
+                unsigned int spins = 0;
+                bool alive = true;
+                while (alive && (unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > 20000000u) { atomicOr(err, 1u); alive = false; }
+                }
+            }
+            __syncthreads();
+            LL_PSTAMP(5);
+            // ---- AdaLN epilogue of rows 2 c, 2 c + 1 on waves 0..3
+            if (wave < 4) ln_phase<H>(w, a, p.bias, 1, p.layer, 0, 0, g);
+            __syncthreads();
+            LL_PSTAMP(6);
+        }
+    } else if (c >= TEAM && threadIdx.x == 0) {
+        atomicOr(err, 2u);
+    }
+    // ---- the last workgroup of the XCC to leave zeroes the XCC's counters: the next launch starts from a clean block without a memset
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int n = __hip_atomic_fetch_add(&ctl->leave[w.xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n == TEAM - 1) {
+            __hip_atomic_store(&ctl->census[w.xcc][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->bar[w.xcc][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->leave[w.xcc][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#ifdef LL_TEAM_PROBE
+        if (p.layer == 3) ctl->span[1][blockIdx.x] = wall_clock64();
+#endif
+    }
 }
 
 }  // namespace team

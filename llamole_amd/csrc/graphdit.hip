@@ -160,6 +160,9 @@ struct DitEngine {
     DevBuf wprojp;               // [depth][H x H]
     DevBuf wout1p, wout2p;       // output layer weights in the same order (dit_team.h)
     DevBuf team_ctl;             // team::Ctl of the persistent trajectory kernel
+    DevBuf team_ctl2;            // team::Ctl2 of proj_ln_team_kernel (zeroed once: the kernel leaves it clean)
+    bool proj_ln_used = false;   // some launch of this engine went through proj_ln_team_kernel (its error word is read by ll_dit_last_run_ms)
+    int proj_ln_team = 0;        // attention projection + AdaLN epilogue as ONE launch on per-XCD teams: 0 = never (default: measured slower, 15.3 vs 9.5 + 5.1 us), 1 = whenever eligible
     int team_mode = 0;           // dit_team_kernel (opt-in: measured slower than the launch chain at every batch): 0 = never (default),
                                  // -1 = under ll_dit_run whenever eligible and not in overlap mode, 1 = also under the single-step entry points
                                  // (step / denoise / step_probs: the parity taps of the team path)
@@ -477,6 +480,37 @@ static bool team_wanted(const DitEngine *e, bool trajectory) {
     if (e->team_mode == 0 || (e->overlap && !in_overlap) || !team_eligible(e)) return false;
     return trajectory || e->team_mode == 1;
 }
+// proj + ln_mod_res of block `layer` as one launch (dit_team.h: proj_ln_team_kernel): bf16, hidden 1024, graphs of <= 32 nodes (a multiple
+// of 4), not next to another stream's kernels (its 256 workgroups want one CU each), not the per-graph-timestep training forward.
+// Opt-in (LL_DIT_OPT_PROJ_LN): measured 15.3 us per launch at batch 8 against 9.5 + 5.1 us of the two launches it replaces (HISTORY.md R4.4)
+static bool proj_ln_team_wanted(const DitEngine *e) {
+    const LLDitConfig &c = e->cfg;
+    if (e->proj_ln_team == 0 || c.dtype != LL_BF16 || c.hidden != 1024 || c.max_nodes > team::NP || c.max_nodes % 4 != 0 || e->overlap ||
+        e->rowvec != nullptr || e->wprojp.p == nullptr || e->team_ctl2.p == nullptr)
+        return false;
+    return true;
+}
+static int launch_proj_ln_team(DitEngine *e, int layer, const float *modrows, hipStream_t st) {
+    constexpr int H = 1024;
+    constexpr int lds = team::Geom<H>::PANEL + team::FLAG_BYTES;
+    static bool attr = false;
+    if (!attr) {
+        LL_HIP(hipFuncSetAttribute((const void *)team::proj_ln_team_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    team::ProjLnArgs p;
+    p.B = e->B; p.N = e->cfg.max_nodes; p.L = e->cfg.depth; p.layer = layer;
+    p.ao = e->attn_o.as<bf16_t>();
+    p.wproj = e->wprojp.as<bf16_t>() + (size_t)layer * H * H;
+    p.bias = e->bw[layer].proj_b;
+    p.modrows = modrows;
+    p.y = e->ybuf.as<float>(); p.x32 = e->x32.as<float>(); p.xa = e->xa.as<bf16_t>();
+    p.ctl = e->team_ctl2.as<team::Ctl2>();
+    e->proj_ln_used = true;
+    hipLaunchKernelGGL((team::proj_ln_team_kernel<H>), dim3(8 * team::TEAM), dim3(team::THREADS), lds, st, p);
+    return LL_OK;
+}
+
 template <int H> static int team_launch_t(DitEngine *e, const team::Args &a, hipStream_t st) {
     constexpr int lds = team::Geom<H>::PANEL + team::FLAG_BYTES;
     static bool attr = false;
@@ -564,6 +598,8 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
         LL_HIP(hipMemcpyAsync(hidden_tap, e->x32.p, (size_t)M2 * H * 4, hipMemcpyDeviceToDevice, st));
     const int64_t slab = (int64_t)e->M2p * H;
     const bool fused_qkv = qkv_attn_wanted(e), xw = xw_fc1_wanted(e), xw2 = xw_fc2_wanted(e);
+    // (captured steps read the step's modulation rows from the staged copy, which exists only with g_stage_mod)
+    const bool use_proj_ln = proj_ln_team_wanted(e) && (e->step_host >= 0 || g_stage_mod);
     for (int l = 0; l < c.depth; ++l) {
         const DitEngine::BlockW &w = e->bw[l];
         if (fused_qkv) {
@@ -578,14 +614,20 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
             if (bf) launch_attn<bf16_t>(e, l, st); else launch_attn<float>(e, l, st);
         }
         LL_LAUNCH_CHECK();
-        {
+        const float *pl_rows = !use_proj_ln ? nullptr
+                               : e->step_host >= 0 ? e->modtab.as<float>() + (int64_t)e->step_host * (e->B + 1) * c.depth * 6 * H
+                                                   : e->modcur.as<float>();
+        if (use_proj_ln) {
+            ClassTimer tm(e, LL_DIT_CLS_PROJ, st);
+            LL_TRY(launch_proj_ln_team(e, l, pl_rows, st));
+        } else {
             ClassTimer tm(e, LL_DIT_CLS_PROJ, st);
             if (e->splits_h > 1)
                 LL_TRY(linear_splitk_launch(dt, e->attn_o.p, H, w.proj, H, e->ybuf.as<float>(), H, slab, M2, H, H, e->splits_h, st));
             else
                 LL_TRY(linear_launch(dt, e->attn_o.p, H, w.proj, H, nullptr, e->ybuf.p, H, M2, H, H, 0, 1, st));
         }
-        {
+        if (!use_proj_ln) {
             ClassTimer tm(e, LL_DIT_CLS_LNMOD, st);
             if (bf) launch_lnmod<bf16_t>(e, l, 0, e->splits_h, w.proj_b, st);
             else launch_lnmod<float>(e, l, 0, e->splits_h, w.proj_b, st);
@@ -826,6 +868,9 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
         }
     }
     if (const char *v = getenv("LL_DIT_TEAM")) e->team_mode = atoi(v) < 0 ? -1 : (atoi(v) ? 1 : 0);
+    CR(e->team_ctl2.ensure(sizeof(team::Ctl2)));
+    CRH(hipMemset(e->team_ctl2.p, 0, sizeof(team::Ctl2)));          // once: proj_ln_team_kernel leaves its counters zeroed
+    if (const char *v = getenv("LL_DIT_PROJ_LN")) e->proj_ln_team = atoi(v) ? 1 : 0;
     if (const char *v = getenv("LL_DIT_CALIBRATE")) e->xw_gemm = atoi(v) ? -1 : 0;
     if (const char *v = getenv("LL_XW_GEMM")) e->xw_gemm = atoi(v);
     if (const char *v = getenv("LL_XW_FC2")) e->xw_fc2 = atoi(v) ? 1 : 0;
@@ -854,7 +899,7 @@ int ll_dit_destroy(void *handle) {
     DevBuf *bufs[] = {&e->wop, &e->wxT, &e->wycat, &e->yw0, &e->yb0, &e->tables, &e->n_nodes, &e->X, &e->E, &e->x32,
                       &e->xa, &e->qkv, &e->attn_o, &e->ybuf, &e->h1, &e->ho, &e->outF, &e->ct_in, &e->ct_h, &e->ct,
                       &e->zy, &e->cy, &e->txt_op, &e->ctxt, &e->ynan, &e->tnan, &e->c32, &e->ca, &e->m1, &e->modtab,
-                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wqkvp, &e->wfc1p, &e->wfc2p, &e->wprojp, &e->steps_tab, &e->wout1p, &e->wout2p, &e->team_ctl};
+                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wqkvp, &e->wfc1p, &e->wfc2p, &e->wprojp, &e->steps_tab, &e->wout1p, &e->wout2p, &e->team_ctl, &e->team_ctl2};
     for (const void *k : e->packed_keys) register_packed_weight(k, nullptr);
     for (DevBuf *b : bufs) b->release();
     if (e->own) (void)hipStreamDestroy(e->own);
@@ -1269,6 +1314,10 @@ int ll_dit_set_option(void *handle, int option, int value) {
             e->xw_gemm = value < 0 ? -1 : (value ? 1 : 0);
             break;
         case LL_DIT_OPT_TEAM: e->team_mode = value < 0 ? -1 : (value ? 1 : 0); break;
+        case LL_DIT_OPT_PROJ_LN:
+            if (e->proj_ln_team != (value ? 1 : 0)) drop_graph(e);
+            e->proj_ln_team = value ? 1 : 0;
+            break;
         default: LL_CHECK(false, "ll_dit_set_option: unknown option %d", option);
     }
     return LL_OK;
@@ -1359,6 +1408,28 @@ int ll_dit_last_run_ms(void *handle, float *ms, int *steps) {
     LL_HIP(hipEventElapsedTime(ms, e->ev_t0, e->ev_t1));
     *steps = e->last_steps;
     if (e->team_last) LL_TRY(team_check(e));
+    if (e->proj_ln_used) {
+        team::Ctl2 h;
+        LL_HIP(hipMemcpy(&h.error, &e->team_ctl2.as<team::Ctl2>()->error, sizeof(h.error), hipMemcpyDeviceToHost));
+#ifdef LL_TEAM_PROBE
+        LL_HIP(hipMemcpy(&h, e->team_ctl2.p, sizeof(h), hipMemcpyDeviceToHost));
+        static const char *names[] = {"census", "loads + stage", "mfma + reduce + y", "vmcnt(0)", "team barrier", "LN"};
+        fprintf(stderr, "LL_TEAM_PROBE proj_ln block 3, us:");
+        for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.2f |", names[i], (double)(h.stamps[i + 1] - h.stamps[i]) / 100.0);
+        fprintf(stderr, " total %.2f", (double)(h.stamps[6] - h.stamps[0]) / 100.0);
+        unsigned long long t0 = ~0ull, t0x = 0, t1 = 0, t1n = ~0ull;
+        for (int i = 0; i < 256; ++i) {
+            t0 = std::min(t0, h.span[0][i]); t0x = std::max(t0x, h.span[0][i]);
+            t1 = std::max(t1, h.span[1][i]); t1n = std::min(t1n, h.span[1][i]);
+        }
+        fprintf(stderr, " | workgroups: first start -> last start %.2f, first start -> first end %.2f, -> last end %.2f\n", (double)(t0x - t0) / 100.0,
+                (double)(t1n - t0) / 100.0, (double)(t1 - t0) / 100.0);
+#endif
+        if (h.error) {
+            set_error("proj_ln_team_kernel: %s%s", (h.error & 1) ? "a bounded wait ran out " : "", (h.error & 2) ? "more than 32 workgroups reported on one XCC" : "");
+            return LL_EHIP;
+        }
+    }
     return LL_OK;
 }
 

@@ -410,7 +410,7 @@ class GraphDiT(nn.Module):
                 "chain_us": {"ring/ring": round(us[0], 2), "panel/ring": round(us[1], 2), "ring/panel": round(us[2], 2),
                              "panel/panel": round(us[3], 2)}}
 
-    ENGINE_OPTIONS = {"overlap": 0, "generic_attn": 1, "fused_qkv_attn": 2, "xw_gemm": 3, "team": 4}
+    ENGINE_OPTIONS = {"overlap": 0, "generic_attn": 1, "fused_qkv_attn": 2, "xw_gemm": 3, "team": 4, "proj_ln": 5}
 
     def set_option(self, name: str, value: int):
         """Per-engine switch (include/llamole_hip.h: ll_dit_set_option), effective for every later denoiser call."""

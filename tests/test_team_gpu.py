@@ -121,3 +121,60 @@ def test_team_kernel_with_sixteen_node_graphs_and_padding_rows():
         n = int(n_nodes[i])
         assert x.shape == (n,) and torch.equal(e, e.t()) and int(x.min()) >= 0 and int(x.max()) < 16 and int(e.max()) < 5
     m.set_option("team", 0)
+
+
+@pytest.mark.parametrize("B,N", [(1, 32), (3, 32), (8, 32), (11, 32), (5, 16), (9, 12)])
+def test_proj_ln_team_launch_matches_the_two_launches(B, N):
+    """The block's attention projection + AdaLN epilogue as one launch on per-XCD teams (dit_team.h: proj_ln_team_kernel, the default from
+    batch 3) against the projection GEMM + ln_mod_res pair of the same library: logits up to the bf16 summation order (full K per tile
+    instead of split-K slabs), the sampled state under the same injected noise, and -- launched back to back 3 x depth x 2 times on one
+    zero-initialised control block -- that the kernel leaves its counters clean."""
+    from llamole_amd import synth
+    T = 10
+    m = _model(nodes=N)
+    props, text, _ = synth.make_dit_inputs(B, seed=3, max_node=N)
+    n_nodes = torch.tensor([min(N, v) for v in ([32, 17, 5, 32, 1, 29, 32, 8, 32, 2, 31] * 2)[:B]])
+    mask = torch.arange(N).unsqueeze(0) < n_nodes.unsqueeze(1)
+    um = _upper(n_nodes, N)
+    m.begin(props, text, -200.0, n_nodes)
+    out = {}
+    for mode in (0, 1):
+        m.set_option("proj_ln", mode)
+        m.init_state(*synth.exp_noise(5, T, B, N))
+        per = []
+        for s in (T - 1, T - 2, 3):
+            lx, le = m.denoise_logits(s)
+            m.step(s, *synth.exp_noise(5, s, B, N))
+            X, E = m.get_state()
+            per.append((lx.cpu(), le.cpu(), X.cpu().long(), E.cpu().long()))
+        out[mode] = per
+    m.set_option("proj_ln", 0)
+    for (lx0, le0, X0, E0), (lx1, le1, X1, E1) in zip(out[0], out[1]):
+        scale = max(float(lx0.abs().max()), float(le0.abs().max()), 1.0)
+        ex = float(((lx1 - lx0) * mask.view(1, B, N, 1)).abs().max()) / scale
+        ee = float(((le1 - le0) * um.view(1, B, N, N, 1)).abs().max()) / scale
+        assert ex <= 2e-2 and ee <= 2e-2, (ex, ee)
+        assert torch.equal(E1, E1.transpose(1, 2)) and torch.equal(X1[~mask], X0[~mask])
+        assert float((X1 == X0)[mask].float().mean()) >= 0.9
+        if int(um.sum()):
+            assert float((E1 == E0)[um].float().mean()) >= 0.97
+
+
+def test_proj_ln_team_trajectories_are_fixed_by_the_seed():
+    from llamole_amd import synth
+    m = _model(depth=2, T=10)
+    N, B = 32, 8
+    props, text, _ = synth.make_dit_inputs(B, seed=0, max_node=N)
+    n_nodes = torch.tensor([32, 32, 17, 5, 32, 1, 29, 32])
+
+    def run(mode, seed=42):
+        torch.manual_seed(5)
+        m.set_option("proj_ln", mode)
+        return m.generate_graphs(props, text, -200.0, n_nodes=n_nodes, seed=seed)[0]
+    a, b, c = run(1), run(1), run(0)
+    assert m.last_run_ms()[1] == 10
+    for i, (x, e) in enumerate(a):
+        assert torch.equal(x, b[i][0]) and torch.equal(e, b[i][1]) and torch.equal(e, e.t())
+    agree = sum(float((c[i][1] == a[i][1]).float().mean()) for i in range(B) if int(n_nodes[i]) > 1) / sum(int(n) > 1 for n in n_nodes)
+    assert agree >= 0.9, agree
+    m.set_option("proj_ln", 0)
