@@ -803,6 +803,10 @@ def main():
     if getattr(step_fn, "pipeline", False):
         step_fn.finish()                 # no trajectory of a warm-up prompt is left for the timed region
     barrier()
+    trace_on = os.environ.get("LLAMOLE_E2E_TRACE") == "1"      # host timeline of the e2e step (llamole_amd/_trace.py), folded on stderr
+    if trace_on:
+        from llamole_amd import _trace
+        _trace.start()
     t0 = time.perf_counter()
     dit_ms = []
     piped = bool(getattr(step_fn, "pipeline", False))
@@ -820,6 +824,15 @@ def main():
         dit_ms = list(step_fn.dit_ms)[-args.steps * nb:]
     barrier()
     dt = time.perf_counter() - t0
+    if trace_on:
+        ev = _trace.stop()
+        agg = {}
+        for (a, ta), (b, tb) in zip(ev, ev[1:]):
+            k = f"{a}  ->  {b}"
+            n, tot = agg.get(k, (0, 0.0))
+            agg[k] = (n + 1, tot + tb - ta)
+        for k, (n, tot) in agg.items():
+            log(f"host timeline: {1e3 * tot / n:9.3f} ms x {n:4d}  {k}")
     assert len(done) == args.steps * nb * B, (len(done), args.steps, nb, B)
     gathered_n = len(done[-nb * B:])
     rank_times = [dt]

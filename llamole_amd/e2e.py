@@ -195,6 +195,8 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
         overlaps the LLM decode of batch i+1 (independent prompts); with ``dit_group`` = k the trajectories of k consecutive
         prompt batches are ONE batched trajectory enqueued after the k-th decode.  Returns the molecules that completed since
         the last call (or None), the rest is collected by ``step_fn.finish()`` inside the timed region."""
+        from ._trace import mark
+        mark("step: enter")
         torch.manual_seed(1000 * rank + i)
         t0 = time.perf_counter()
         analysis, design_ids, cond = orch.design_hidden(prompt, mask, None, **kw)
@@ -206,7 +208,9 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
             prev = None
             if len(waiting) >= group:
                 prev = collect()
+                mark("step: previous molecules collected")
                 launch_group()
+                mark("step: trajectory enqueued")
             last.update(llm_enqueue_s=t1 - t0, new_tokens=int(analysis.shape[1]), **orch.timings)
             return prev
         mols, _ = graph_decoder.generate_graphs(props, cond.float(), -200.0, n_nodes=n_nodes, seed=1000 * rank + i,

@@ -207,6 +207,8 @@ class GraphedDecoder:
                  temperature: float = 1.0, top_p: float = 1.0, eos_token_id: Optional[Sequence[int]] = None,
                  pad_token_id: Optional[int] = None, generator=None, top_k: Optional[int] = None, **other) -> torch.Tensor:
         _reject_unsupported_generation_options(other)
+        from ._trace import mark
+        mark("generate: enter")
         top_k = int(top_k) if top_k else 0
         from .llm_accel import refresh_weight_copies
         refresh_weight_copies(self.model)       # concatenated / converted weight copies follow their sources (in place)
@@ -239,6 +241,7 @@ class GraphedDecoder:
         except TypeError:                                   # a model class without that argument
             out = self.model(**pre)
         logits = out.logits[:, -1, :]
+        mark("generate: prefill enqueued")
         for layer in self.cache.layers:          # the next free slot is P whichever update path the prefill took (a short
             if hasattr(layer, "cumulative_length"):   # prompt on a re-used cache goes through the fused append, which
                 layer.cumulative_length.fill_(P)      # leaves advancing layer 0's shared counter to its caller)
@@ -253,6 +256,7 @@ class GraphedDecoder:
             temp = 1.0 if temperature is None else float(temperature)
             sp = (not do_sample, float(np.float32(1.0) / np.float32(temp)), 1.0 if top_p is None else float(top_p), int(pad), top_k)
             new_tokens = self._generate_hip(logits, sp, P, plen, eos.tolist(), max_new_tokens, generator, device)
+            mark("generate: decode loop done")
             return torch.cat([input_ids, new_tokens], dim=1) if input_ids is not None else new_tokens
         if self._sample_key is not None:     # a graph captured with the fused sampler does not fit the torch-sampler loop
             self._sample_key = None

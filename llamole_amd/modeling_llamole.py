@@ -332,15 +332,19 @@ class GraphLLMForCausalMLM(nn.Module):
             embeds = self._splice_molecules(input_ids, molecule_graphs)
             analysis = self._llm_generate(attention_mask=attention_mask, inputs_embeds=embeds, **kwargs)
         t1 = time.perf_counter()
+        from ._trace import mark
         design_ids = self.add_special_body_tokens(analysis, self.token_id_dict["<design_body>"], self.num_body_tokens,
                                                   start_token_id=self.token_id_dict["<design_start>"])
         design_ids = torch.cat([input_ids, design_ids], dim=1)
+        mark("design: body tokens added")
         hidden = None
         if molecule_graphs is None and self.reuse_query_kv:
             hidden = self._query_hidden_from_cache(input_ids, attention_mask, analysis, design_ids)
         if hidden is None:
             hidden = self._query_hidden(design_ids)
+        mark("design: query forward enqueued")
         cond = self.lm_to_graph_decoder(hidden.to(next(self.lm_to_graph_decoder.parameters()).dtype))
+        mark("design: connector enqueued")
         self.timings.update(llm_decode_s=t1 - t0, llm_query_s=time.perf_counter() - t1)
         return analysis, design_ids, cond
 
