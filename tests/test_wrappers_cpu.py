@@ -196,3 +196,14 @@ def test_csr_error_names_the_call_that_converted_the_batch(monkeypatch):
     s2 = convert()                       # still -1 after the poll: only now the devices are synchronised
     ge.check_graph_errors(wait=True)
     assert len(syncs) == 1 and ge._pending_csr_flags == [s2]
+
+
+def test_host_timeline_marks_are_off_unless_started():
+    from llamole_amd import _trace
+    _trace.mark("ignored")
+    assert _trace.events is None
+    _trace.start()
+    _trace.mark("a")
+    _trace.mark("b")
+    ev = _trace.stop()
+    assert [n for n, _ in ev] == ["a", "b"] and ev[0][1] <= ev[1][1] and _trace.events is None
