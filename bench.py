@@ -932,6 +932,12 @@ def main():
         "step_roofline": {"hbm_bytes": sbytes, "flops": sflops,
                           "hbm_frac": sbytes / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
                           "mfma_frac": sflops / (step_ms * 1e-3) / (MFMA_BF16_PEAK_TF * 1e12)},
+        # the same bytes / flops over the step as it runs INSIDE the pipelined region (sharing the GPU with the next prompt's decode)
+        "step_roofline_overlapped": ({"hbm_bytes": sbytes, "flops": sflops, "step_ms": step_ms_overlapped,
+                                      "hbm_frac": sbytes / (step_ms_overlapped * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                                      "mfma_frac": sflops / (step_ms_overlapped * 1e-3) / (MFMA_BF16_PEAK_TF * 1e12),
+                                      "note": "the trajectory is off the critical path there: it runs in the dispatch gaps of the decode stream"}
+                                     if step_ms_overlapped else None),
         "roofline": roof,
         "roofline_graphdit": roof_dit,
         "rank_seconds": [round(t, 4) for t in rank_times],
