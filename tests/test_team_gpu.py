@@ -173,6 +173,14 @@ def test_proj_ln_team_trajectories_are_fixed_by_the_seed():
         return m.generate_graphs(props, text, -200.0, n_nodes=n_nodes, seed=seed)[0]
     a, b, c = run(1), run(1), run(0)
     assert m.last_run_ms()[1] == 10
+    # replayed as a hipGraph the kernel meets its control block exactly as the previous launch left it (the last workgroup of every XCC
+    # zeroes the counters): the same trajectory as from the launch loop
+    torch.manual_seed(5)
+    m.set_option("proj_ln", 1)
+    g = m.generate_graphs(props, text, -200.0, n_nodes=n_nodes, seed=42, use_graph=True)[0]
+    assert m.last_run_ms()[1] == 10
+    for i, (x, e) in enumerate(a):
+        assert torch.equal(x, g[i][0]) and torch.equal(e, g[i][1])
     for i, (x, e) in enumerate(a):
         assert torch.equal(x, b[i][0]) and torch.equal(e, b[i][1]) and torch.equal(e, e.t())
     agree = sum(float((c[i][1] == a[i][1]).float().mean()) for i in range(B) if int(n_nodes[i]) > 1) / sum(int(n) > 1 for n in n_nodes)
