@@ -167,6 +167,43 @@ __device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
 // Exp(1) variate from 32 random bits: -log(u), u uniform in (0,1].
 __device__ __forceinline__ float exp1_from_bits(uint32_t r) { return -__logf(((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f)); }
 
+// sum of squared deviations of the four columns [k, k + 4) of a row chunk, counting only columns below `width` (the true row width: engines
+// pad rows to a multiple of 64 with zeros, and LayerNorm statistics are over the checkpoint's own width); same order as the plain form
+__device__ __forceinline__ float sq_dev4(const float4 v, float mean, int k, int width) {
+    if (k + 4 <= width) {
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        return d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    float r = 0.f;
+    if (k < width) { const float d = v.x - mean; r += d * d; }
+    if (k + 1 < width) { const float d = v.y - mean; r += d * d; }
+    if (k + 2 < width) { const float d = v.z - mean; r += d * d; }
+    return r;
+}
+
+
+// ---------------------------------------------------------------- zero-padded internal weight layouts (graphdit.hip, gin.hip)
+// dst[(r / rg2) * rgp2 + (r % rg2 / rg) * rgp + r % rg][(c / cg) * cgp + c % cg] = src[r][c]: how a checkpoint tensor lands in an engine's arena
+struct PadMap {
+    int rg2 = 0, rgp2 = 0, rg = 0, rgp = 0, cg = 0, cgp = 0;      // 0 = one group (identity)
+};
+// A checkpoint tensor [R][C] into its zero-padded internal form (engine creation; the destination was zeroed):
+//   dst[(r / rg2) * rgp2 + (r % rg2 / rg) * rgp + r % rg][(c / cg) * cgp + c % cg] = src[r][c],   destination row pitch ldd
+// rows: sections of rg2 rows (q | k | v of the qkv weight) made of groups of rg rows (heads, the six chunks of an adaLN output);
+// columns: groups of cg columns (heads on the K side of proj).  A group count of one (rg = R, cg = C) is the identity.
+static __global__ void pad_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, int R, int C, int ldd, int rg2, int rgp2, int rg,
+                                int rgp, int cg, int cgp) {
+    const int64_t n = (int64_t)R * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / C), c = (int)(i - (int64_t)r * C);
+        const int rr = r % rg2;
+        const int64_t dr = (int64_t)(r / rg2) * rgp2 + (rr / rg) * rgp + rr % rg;
+        const int dc = (c / cg) * cgp + c % cg;
+        dst[dr * ldd + dc] = src[i];
+    }
+}
+
+
 // ---------------------------------------------------------------- host helpers
 int linear_launch(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
                   int M, int N, int K, int epi, int out_f32, hipStream_t stream);

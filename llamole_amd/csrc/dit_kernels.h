@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256) void embed_kernel(const int8_t *__restrict__ X
                                                      const float *__restrict__ WxT, const float *__restrict__ lnw,
                                                      const float *__restrict__ lnb, float *__restrict__ x32,
                                                      T *__restrict__ xa, const int *__restrict__ step_ptr, int B,
-                                                     int N, int H) {
+                                                     int N, int H, int Ht) {
+    // H = row pitch (the engine's padded width, a multiple of 64), Ht = the checkpoint's hidden_size: columns [Ht, H) of W_x^T and of
+    // the LayerNorm weight / bias are zero, the statistics run over the Ht true columns, the padded columns come out as exact zeros
     __shared__ float red[4];
     __shared__ int gidx[72];
     __shared__ int ng;
@@ -94,17 +96,12 @@ __global__ __launch_bounds__(256) void embed_kernel(const int8_t *__restrict__ X
     }
     float ls = 0.f;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) ls += v[e].x + v[e].y + v[e].z + v[e].w;  // zero beyond H
-    const float mean = block_sum_256(ls, red) / (float)H;
+    for (int e = 0; e < MAXE; ++e) ls += v[e].x + v[e].y + v[e].z + v[e].w;  // zero beyond Ht
+    const float mean = block_sum_256(ls, red) / (float)Ht;
     float lv = 0.f;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-        if ((threadIdx.x + e * 256) * 4 < H) {
-            const float d0 = v[e].x - mean, d1 = v[e].y - mean, d2 = v[e].z - mean, d3 = v[e].w - mean;
-            lv += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        }
-    }
-    const float rstd = rsqrtf(block_sum_256(lv, red) / (float)H + 1e-5f);
+    for (int e = 0; e < MAXE; ++e) lv += sq_dev4(v[e], mean, (threadIdx.x + e * 256) * 4, Ht);
+    const float rstd = rsqrtf(block_sum_256(lv, red) / (float)Ht + 1e-5f);
     const int64_t M = (int64_t)B * N;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
@@ -128,13 +125,15 @@ __global__ __launch_bounds__(256) void embed_kernel(const int8_t *__restrict__ X
 // ------------------------------------------------------------------------------------------ attention (generic)
 // Per (sequence, head): LayerNorm(hd, affine) on q and k rows, key mask valid_i & valid_j with padded
 // query rows opened to all keys, softmax(q k^T / sqrt(hd)) v     (layers.py:56-87).
-// Generic f32 LDS kernel for any N <= 64, hd <= 128; the MFMA variant below covers the production shapes.
+// Generic f32 LDS kernel for any N <= 64, hd <= 128; the MFMA variant below covers the bf16 engine.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_generic_kernel(const T *__restrict__ qkv, T *__restrict__ o,
                                                             const float *__restrict__ qw, const float *__restrict__ qb,
                                                             const float *__restrict__ kw, const float *__restrict__ kb,
                                                             const int *__restrict__ n_nodes, int B, int N, int H,
-                                                            int hd) {
+                                                            int hd, int hdp) {
+    // H = width of each of the q | k | v sections of a qkv row (and of an output row), hdp = column pitch of a head inside a section,
+    // hd = the checkpoint's head dimension (hd <= hdp; columns [hd, hdp) of a head are the engine's zero padding and are not touched)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int head = blockIdx.x;
     const int seq = blockIdx.y;  // pass*B + b
@@ -149,7 +148,7 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const T *__restrict__
     const int64_t rbase = (int64_t)seq * N;
     for (int idx = tid; idx < N * hd; idx += 256) {
         const int i = idx / hd, d = idx - i * hd;
-        const T *r = qkv + (rbase + i) * (3 * (int64_t)H) + head * hd + d;
+        const T *r = qkv + (rbase + i) * (3 * (int64_t)H) + head * hdp + d;
         q[i * ld + d] = to_f32<T>(r[0]);
         k[i * ld + d] = to_f32<T>(r[H]);
         v[i * ld + d] = to_f32<T>(r[2 * H]);
@@ -199,7 +198,7 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const T *__restrict__
         const int i = idx / hd, d = idx - i * hd;
         float acc = 0.f;
         for (int j = 0; j < N; ++j) acc = fmaf(S[i * (N + 1) + j], v[j * ld + d], acc);
-        o[(rbase + i) * (int64_t)H + head * hd + d] = from_f32<T>(acc);
+        o[(rbase + i) * (int64_t)H + head * hdp + d] = from_f32<T>(acc);
     }
 }
 
@@ -231,7 +230,7 @@ struct AttnNoWait { __device__ __forceinline__ void operator()() const {} };
 // first one, the second follows N rows later): a query attends only to the keys of its own half.
 template <int NP, int HD, int WPB, bool PSEP, typename BeforePV = AttnNoWait, bool PAIR = false>
 __device__ __forceinline__ void attn_core(const bf16_t *Qs, const bf16_t *Ks, const bf16_t *Vt, bf16_t *Ps,
-                                          bf16_t *__restrict__ ohead, int N, int nv, int H, int wave, int lane,
+                                          bf16_t *__restrict__ ohead, int N, int nv, int H, int wave, int lane, float scale2,
                                           BeforePV before_pv = BeforePV(), int nv1 = 0) {
     static_assert(!PAIR || NP == 64, "two sequences per workgroup: 2 x 32 token rows");
     constexpr int QLD = HD + 8, PLD = NP + 8;
@@ -268,7 +267,7 @@ __device__ __forceinline__ void attn_core(const bf16_t *Qs, const bf16_t *Ks, co
     }
 
     // ---- mask + softmax in the C layout: element r of tile (mt,nt): i = mt*16 + (lane>>4)*4 + r, j = nt*16 + (lane&15)
-    const float scale2 = rsqrtf((float)HD) * 1.44269504088896340736f;       // softmax(s / sqrt(hd)) through exp2
+    // scale2 = log2(e) / sqrt(hd): softmax(s / sqrt(hd)) through exp2, hd = the checkpoint's head dimension (HD is the padded tile)
 #pragma unroll
     for (int mt = 0; mt < MQ; ++mt) {
 #pragma unroll
@@ -354,14 +353,18 @@ struct AttnBlockSync { __device__ __forceinline__ void operator()() const { __sy
 template <int NP, int HD, int WPB, typename LD, typename SYNC = AttnBlockSync>
 __device__ __forceinline__ void attn_mfma_body(LD ld, bf16_t *__restrict__ ohead, const float *__restrict__ qw,
                                                const float *__restrict__ qb, const float *__restrict__ kw,
-                                               const float *__restrict__ kb, int N, int nv, int H, unsigned char *smraw_attn,
+                                               const float *__restrict__ kb, int N, int nv, int H, int hd, unsigned char *smraw_attn,
                                                int wave, int lane, SYNC sync = SYNC()) {
+    // HD = the head's column pitch (32 | 64 | 96 | 128), hd <= HD = the checkpoint's head dimension: columns [hd, HD) of q | k | v are the
+    // engine's zero padding (zero weight rows, zero LayerNorm weight / bias) -- they take no part in the LayerNorm statistics and
+    // contribute exact zeros to QK^T and to the output
     constexpr int QLD = HD + 8;           // padded row strides (elements)
     constexpr int PLD = NP + 8;
     constexpr int QK_ELEMS = NP * QLD;
     constexpr int P_ELEMS = NP * PLD;
     constexpr int R0 = QK_ELEMS > P_ELEMS ? QK_ELEMS : P_ELEMS;   // region 0: Q, later P
     static_assert(WPB == 1 || WPB == 2 || WPB == 4, "one, two or four waves per (sequence, head)");
+    static_assert(HD % 32 == 0 && HD >= 32 && HD <= 128, "head pitch: a multiple of the MFMA k-step up to 128");
     constexpr int CW = WPB > NP / 16 ? NP / 16 : WPB;             // waves of the QK^T / softmax / PV part: at most one per query tile
     constexpr bool PSEP = CW != WPB;                              // then P gets its own region (no barrier inside the core)
     bf16_t *Qs = reinterpret_cast<bf16_t *>(smraw_attn);
@@ -369,35 +372,39 @@ __device__ __forceinline__ void attn_mfma_body(LD ld, bf16_t *__restrict__ ohead
     bf16_t *Vt = Ks + QK_ELEMS;
     bf16_t *Ps = PSEP ? Vt + HD * PLD : Qs;
 
-    // ---- load + LayerNorm (q, k), transpose (v).  HD/8 lanes cover one row with 16-B loads (full 128-B
+    // ---- load + LayerNorm (q, k), transpose (v).  LPR lanes cover one row with 16-B loads (full 128-B
     //      lines for hd = 64); every global load of the wave (3 tensors x PASSES + LN parameters) is issued
     //      before the first use, so the phase costs one memory round trip.
     {
-        constexpr int LPR8 = HD / 8;            // lanes per row
-        constexpr int RPP = 64 / LPR8;          // rows per pass
+        constexpr int LPRA = HD / 8;            // lanes per row that hold data
+        constexpr int LPR = HD <= 32 ? 4 : HD <= 64 ? 8 : 16;   // lanes per row (a power of two: HD = 96 leaves four of sixteen idle)
+        constexpr int RPP = 64 / LPR;           // rows per pass
         constexpr int PASSES = NP / RPP / WPB;   // passes of THIS wave: wave w takes rows [w * NP / WPB, (w + 1) * NP / WPB)
         static_assert(PASSES >= 1, "too few rows for this many waves");
-        const int sub = lane % LPR8, rin = lane / LPR8 + wave * (NP / WPB);
+        const int sub = lane % LPR, rin = lane / LPR + wave * (NP / WPB);
+        const bool act = LPRA == LPR || sub < LPRA;
         const int d0 = sub * 8;
         uint4 rq[PASSES], rk[PASSES], rv[PASSES];
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int row = p * RPP + rin, srow = row < N ? row : 0;
-            rq[p] = ld(srow, 0, d0);
-            rk[p] = ld(srow, 1, d0);
-            rv[p] = ld(srow, 2, d0);
+            rq[p] = act ? ld(srow, 0, d0) : make_uint4(0u, 0u, 0u, 0u);
+            rk[p] = act ? ld(srow, 1, d0) : make_uint4(0u, 0u, 0u, 0u);
+            rv[p] = act ? ld(srow, 2, d0) : make_uint4(0u, 0u, 0u, 0u);
         }
         float wq[8], bq[8], wk[8], bk[8];
         {
-            const float4 a0 = *reinterpret_cast<const float4 *>(qw + d0), a1 = *reinterpret_cast<const float4 *>(qw + d0 + 4);
-            const float4 b0 = *reinterpret_cast<const float4 *>(qb + d0), b1 = *reinterpret_cast<const float4 *>(qb + d0 + 4);
-            const float4 c0 = *reinterpret_cast<const float4 *>(kw + d0), c1 = *reinterpret_cast<const float4 *>(kw + d0 + 4);
-            const float4 e0 = *reinterpret_cast<const float4 *>(kb + d0), e1 = *reinterpret_cast<const float4 *>(kb + d0 + 4);
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 a0 = act ? *reinterpret_cast<const float4 *>(qw + d0) : z4, a1 = act ? *reinterpret_cast<const float4 *>(qw + d0 + 4) : z4;
+            const float4 b0 = act ? *reinterpret_cast<const float4 *>(qb + d0) : z4, b1 = act ? *reinterpret_cast<const float4 *>(qb + d0 + 4) : z4;
+            const float4 c0 = act ? *reinterpret_cast<const float4 *>(kw + d0) : z4, c1 = act ? *reinterpret_cast<const float4 *>(kw + d0 + 4) : z4;
+            const float4 e0 = act ? *reinterpret_cast<const float4 *>(kb + d0) : z4, e1 = act ? *reinterpret_cast<const float4 *>(kb + d0 + 4) : z4;
             wq[0] = a0.x; wq[1] = a0.y; wq[2] = a0.z; wq[3] = a0.w; wq[4] = a1.x; wq[5] = a1.y; wq[6] = a1.z; wq[7] = a1.w;
             bq[0] = b0.x; bq[1] = b0.y; bq[2] = b0.z; bq[3] = b0.w; bq[4] = b1.x; bq[5] = b1.y; bq[6] = b1.z; bq[7] = b1.w;
             wk[0] = c0.x; wk[1] = c0.y; wk[2] = c0.z; wk[3] = c0.w; wk[4] = c1.x; wk[5] = c1.y; wk[6] = c1.z; wk[7] = c1.w;
             bk[0] = e0.x; bk[1] = e0.y; bk[2] = e0.z; bk[3] = e0.w; bk[4] = e1.x; bk[5] = e1.y; bk[6] = e1.z; bk[7] = e1.w;
         }
+        const float inv_hd = 1.f / (float)hd;
         auto norm_store = [&](const uint4 r, const float *w, const float *bvec, bf16_t *dst, int row) {
             const bool live = row < N;
             float f[8];
@@ -410,16 +417,16 @@ __device__ __forceinline__ void attn_mfma_body(LD ld, bf16_t *__restrict__ ohead
             float sm = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) sm += f[e];
-            sm = (LPR8 == 8) ? row8_sum(sm) : row4_sum(sm);
-            const float mean = sm / (float)HD;
+            sm = (LPR == 16) ? row16_sum(sm) : (LPR == 8) ? row8_sum(sm) : row4_sum(sm);
+            const float mean = sm * inv_hd;
             float vr = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float d = f[e] - mean;
-                vr += d * d;
+                vr += (d0 + e < hd) ? d * d : 0.f;
             }
-            vr = (LPR8 == 8) ? row8_sum(vr) : row4_sum(vr);
-            const float rstd = rsqrtf(vr / (float)HD + 1e-5f);
+            vr = (LPR == 16) ? row16_sum(vr) : (LPR == 8) ? row8_sum(vr) : row4_sum(vr);
+            const float rstd = rsqrtf(vr * inv_hd + 1e-5f);
             uint32_t pk[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -427,7 +434,7 @@ __device__ __forceinline__ void attn_mfma_body(LD ld, bf16_t *__restrict__ ohead
                 const float a1 = live ? (f[2 * t + 1] - mean) * rstd * w[2 * t + 1] + bvec[2 * t + 1] : 0.f;
                 pk[t] = (uint32_t)f32_to_bf16(a0) | ((uint32_t)f32_to_bf16(a1) << 16);
             }
-            *reinterpret_cast<uint4 *>(dst + row * QLD + d0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            if (act) *reinterpret_cast<uint4 *>(dst + row * QLD + d0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         };
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
@@ -436,10 +443,12 @@ __device__ __forceinline__ void attn_mfma_body(LD ld, bf16_t *__restrict__ ohead
             norm_store(rk[p], wk, bk, Ks, row);
             const bool live = row < N;
             const uint32_t u[4] = {rv[p].x, rv[p].y, rv[p].z, rv[p].w};
+            if (act) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                Vt[(d0 + 2 * t) * PLD + row] = live ? (bf16_t)(u[t] & 0xffffu) : (bf16_t)0;
-                Vt[(d0 + 2 * t + 1) * PLD + row] = live ? (bf16_t)(u[t] >> 16) : (bf16_t)0;
+                for (int t = 0; t < 4; ++t) {
+                    Vt[(d0 + 2 * t) * PLD + row] = live ? (bf16_t)(u[t] & 0xffffu) : (bf16_t)0;
+                    Vt[(d0 + 2 * t + 1) * PLD + row] = live ? (bf16_t)(u[t] >> 16) : (bf16_t)0;
+                }
             }
         }
     }
@@ -451,7 +460,7 @@ __device__ __forceinline__ void attn_mfma_body(LD ld, bf16_t *__restrict__ ohead
     }
     if (PSEP && wave >= CW) return;
     static_assert(PSEP || WPB == 1 || std::is_same<SYNC, AttnBlockSync>::value, "attn_core synchronises the whole workgroup when P aliases Q");
-    attn_core<NP, HD, CW, PSEP>(Qs, Ks, Vt, Ps, ohead, N, nv, H, wave, lane);
+    attn_core<NP, HD, CW, PSEP>(Qs, Ks, Vt, Ps, ohead, N, nv, H, wave, lane, rsqrtf((float)hd) * 1.44269504088896340736f);
 }
 
 template <int NP, int HD, int WPB>
@@ -459,7 +468,8 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_kernel(const bf16_t *__res
                                                          const float *__restrict__ qw, const float *__restrict__ qb,
                                                          const float *__restrict__ kw, const float *__restrict__ kb,
                                                          const int *__restrict__ n_nodes, int B, int N, int H,
-                                                         int heads) {
+                                                         int heads, int hd) {
+    // H = width of each of the q | k | v sections of a qkv row (heads * HD, padded to a multiple of 64), hd = the true head dimension
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw_attn[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int head = blockIdx.x;
@@ -471,7 +481,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_kernel(const bf16_t *__res
         [&](int row, int which, int d0) {
             return *reinterpret_cast<const uint4 *>(base + (int64_t)row * (3 * (int64_t)H) + (int64_t)which * H + d0);
         },
-        o + (int64_t)seq * N * H + head * HD, qw, qb, kw, kb, N, nv, H, smraw_attn, wave, lane);
+        o + (int64_t)seq * N * H + head * HD, qw, qb, kw, kb, N, nv, H, hd, smraw_attn, wave, lane);
 }
 
 template <int NP, int HD, int WPB = 2> static constexpr size_t attn_mfma_lds_bytes() {
@@ -725,7 +735,8 @@ __global__ __launch_bounds__(768) void qkv_attn_kernel(const bf16_t *__restrict_
     qa_wait(ctr + 2, 4);
     qa_wait(ctr + 3, 4);
     auto wait_v = [&]() { qa_wait(ctr + 4, 4); };
-    attn_core<NP, HD, MT, true, decltype(wait_v), PAIR>(Qs, Ks, Vt, Ps, o + (int64_t)seq * N * H + head * HD, N, nv, H, wid, lane, wait_v, nv1);
+    attn_core<NP, HD, MT, true, decltype(wait_v), PAIR>(Qs, Ks, Vt, Ps, o + (int64_t)seq * N * H + head * HD, N, nv, H, wid, lane,
+                                                        rsqrtf((float)HD) * 1.44269504088896340736f, wait_v, nv1);
     LL_QA_STAMP(7);
 }
 
@@ -740,7 +751,7 @@ __global__ __launch_bounds__(64) void ln_mod_res_kernel(const float *__restrict_
                                                           const int *__restrict__ step_ptr,
                                                           const int *__restrict__ rowvec /*[B] table rows or null*/,
                                                           const float *__restrict__ modcur /*[B+1][L][6H] rows of the current step or null*/,
-                                                          int layer, int sel, int B, int N, int H, int L, int M2) {
+                                                          int layer, int sel, int B, int N, int H, int L, int M2, int Ht) {
     // one 64-lane wave = one token row = one workgroup: rows spread over as many CUs as possible, because the
     // per-CU load path (~25-40 GB/s), not HBM, bounds these small row kernels
     const int row = blockIdx.x;
@@ -783,16 +794,13 @@ __global__ __launch_bounds__(64) void ln_mod_res_kernel(const float *__restrict_
     float sum = 0.f;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) sum += v[e].x + v[e].y + v[e].z + v[e].w;
-    const float mean = wave_sum(sum) / (float)H;
+    // H = row pitch (padded width), Ht = the checkpoint's hidden_size: the padded columns of y are exact zeros (zero weight rows and bias)
+    // and have zero gates, so they stay zero in the residual stream; the statistics run over the Ht true columns
+    const float mean = wave_sum(sum) / (float)Ht;
     float var = 0.f;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-        if ((lane + e * 64) * 4 < H) {
-            const float d0 = v[e].x - mean, d1 = v[e].y - mean, d2 = v[e].z - mean, d3 = v[e].w - mean;
-            var += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(var) / (float)H + 1e-5f);
+    for (int e = 0; e < MAXE; ++e) var += sq_dev4(v[e], mean, (lane + e * 64) * 4, Ht);
+    const float rstd = rsqrtf(wave_sum(var) / (float)Ht + 1e-5f);
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
         const int h = (lane + e * 64) * 4;
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(64 * MAXE) void ln_mod_res_mw_kernel(const float *_
                                                                    T *__restrict__ xa, const float *__restrict__ modtab,
                                                                    const int *__restrict__ step_ptr, const int *__restrict__ rowvec,
                                                                    const float *__restrict__ modcur,
-                                                                   int layer, int sel, int B, int N, int H, int L, int M2) {
+                                                                   int layer, int sel, int B, int N, int H, int L, int M2, int Ht) {
     __shared__ float part[2][MAXE][64];
     const int row = blockIdx.x;
     if (row >= M2) return;
@@ -861,26 +869,21 @@ __global__ __launch_bounds__(64 * MAXE) void ln_mod_res_mw_kernel(const float *_
             sum += part[0][k][lane];
             sq += part[1][k][lane];
         }
-        mean = wave_sum(sum) / (float)H;
-        rstd = rsqrtf(fmaxf(wave_sum(sq) / (float)H - mean * mean, 0.f) + 1e-5f);
+        mean = wave_sum(sum) / (float)Ht;       // (padded columns are exact zeros: they add nothing to either sum)
+        rstd = rsqrtf(fmaxf(wave_sum(sq) / (float)Ht - mean * mean, 0.f) + 1e-5f);
     } else {
         part[0][e][lane] = v.x + v.y + v.z + v.w;
         __syncthreads();
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < MAXE; ++k) sum += part[0][k][lane];
-        mean = wave_sum(sum) / (float)H;
-        float d2 = 0.f;
-        if (ok) {
-            const float d0 = v.x - mean, d1 = v.y - mean, d2a = v.z - mean, d3 = v.w - mean;
-            d2 = d0 * d0 + d1 * d1 + d2a * d2a + d3 * d3;
-        }
-        part[1][e][lane] = d2;
+        mean = wave_sum(sum) / (float)Ht;
+        part[1][e][lane] = sq_dev4(v, mean, h, Ht);
         __syncthreads();
         float var = 0.f;
 #pragma unroll
         for (int k = 0; k < MAXE; ++k) var += part[1][k][lane];
-        rstd = rsqrtf(wave_sum(var) / (float)H + 1e-5f);
+        rstd = rsqrtf(wave_sum(var) / (float)Ht + 1e-5f);
     }
     if (ok) {
         float4 o;
@@ -1277,7 +1280,9 @@ __global__ void tfreq_kernel(T *out, int Tsteps) {
 template <typename T>
 __global__ __launch_bounds__(256) void yfeat_kernel(const float *__restrict__ props, const float *__restrict__ w0,
                                                      const float *__restrict__ b0, T *__restrict__ Z,
-                                                     int8_t *__restrict__ ynan, int H) {
+                                                     int8_t *__restrict__ ynan, int H, int Ht) {
+    // H = row pitch of Z / w0 / b0 (padded width), Ht = the checkpoint's hidden_size: the softmax runs over the Ht true columns
+    // (conditions.py:68, Softmax(dim=1) of a [n, hidden_size] tensor); the padded columns of Z are zeros
     __shared__ float red[4];
     const int b = blockIdx.x, d = blockIdx.y;
     const float y = props[b * LL_YDIM + d];
@@ -1291,17 +1296,17 @@ __global__ __launch_bounds__(256) void yfeat_kernel(const float *__restrict__ pr
     const float *w = w0 + (int64_t)d * H;
     const float *bb = b0 + (int64_t)d * H;
     float mx = -INFINITY;
-    for (int h = threadIdx.x; h < H; h += 256) mx = fmaxf(mx, fmaf(y, w[h], bb[h]));
+    for (int h = threadIdx.x; h < Ht; h += 256) mx = fmaxf(mx, fmaf(y, w[h], bb[h]));
     mx = wave_max(mx);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sm = 0.f;
-    for (int h = threadIdx.x; h < H; h += 256) sm += expf(fmaf(y, w[h], bb[h]) - mx);
+    for (int h = threadIdx.x; h < Ht; h += 256) sm += expf(fmaf(y, w[h], bb[h]) - mx);
     sm = block_sum_256(sm, red);
     const float inv = 1.f / sm;
-    for (int h = threadIdx.x; h < H; h += 256) z[h] = from_f32<T>(expf(fmaf(y, w[h], bb[h]) - mx) * inv);
+    for (int h = threadIdx.x; h < H; h += 256) z[h] = from_f32<T>(h < Ht ? expf(fmaf(y, w[h], bb[h]) - mx) * inv : 0.f);
 }
 
 // text rows -> operand dtype, flagging rows that contain a NaN (conditions.py:112)

@@ -458,7 +458,7 @@ __device__ __forceinline__ void attn_phase(Who &w, const Args &a, int layer, int
             const u32x4 v = ld16_sc1(qkv, (uint32_t)((((int64_t)(row0 + row)) * ld3 + (int64_t)which * H + head * 64 + d0) * 2));
             return make_uint4(v[0], v[1], v[2], v[3]);
         },
-        a.ao + (int64_t)row0 * H + head * 64, qw, qb, kw, kb, a.N, nv, H, w.lds, w.iw, w.lane, IoSync{&w});
+        a.ao + (int64_t)row0 * H + head * 64, qw, qb, kw, kb, a.N, nv, H, 64, w.lds, w.iw, w.lane, IoSync{&w});
 }
 
 // ---------------------------------------------------------------------------------------------------------------- AdaLN epilogue (I/O waves)

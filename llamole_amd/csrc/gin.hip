@@ -18,76 +18,101 @@
 
 namespace ll {
 
+// The reference classes take any sizes (graph_encoder/model.py:87-112, graph_predictor/model.py:231-278: num_layer, hidden_size, text_input_size,
+// out_dim come from the checkpoint's config); the kernels want row pitches that are multiples of 64.  As in the GraphDiT engine
+// (graphdit.hip: DitDims) the engine keeps a zero-padded INTERNAL copy of the weights when the checkpoint's widths are not of that form:
+//   Hp = hidden rounded up to 64 (the MLPs' inner width is 4 Hp), Dp = text_dim rounded up to 64.
+// Zero weight rows / columns, biases, LayerNorm affine parameters and adapter rows (shift = scale = gate = 0) keep every padded column of
+// every activation an exact zero (GELU(0) = 0; max / sum pooling of zeros is zero); the LayerNorm statistics take the true width.
+struct GinDims {
+    int Ht, Hp, Dt, Dp;
+    bool padded;
+};
+static GinDims gin_dims(const LLGinConfig &c) {
+    GinDims d;
+    d.Ht = c.hidden; d.Hp = round_up(c.hidden, 64);
+    d.Dt = c.kind == 1 ? c.text_dim : 0; d.Dp = round_up(d.Dt, 64);
+    d.padded = d.Hp != d.Ht || d.Dp != d.Dt;
+    return d;
+}
+
 struct GinParam {
     std::string name;
-    int64_t numel, offset;
+    int64_t numel, offset;          // checkpoint tensor in the caller's arena (f32 elements)
+    int rows, cols;                 // its shape as [rows][cols]
+    int64_t inumel, ioffset;        // internal (padded) tensor; == numel / offset when nothing is padded
+    int irows, icols;
+    PadMap map;
 };
 
 static std::vector<GinParam> gin_layout(const LLGinConfig &c) {
     std::vector<GinParam> v;
-    int64_t off = 0;
-    auto add = [&](const std::string &n, int64_t ne) {
-        v.push_back({n, ne, off});
+    int64_t off = 0, ioff = 0;
+    const GinDims d = gin_dims(c);
+    auto add = [&](const std::string &n, int r, int cc, int ir, int ic, PadMap m = PadMap()) {
+        const int64_t ne = (int64_t)r * cc, ine = (int64_t)ir * ic;
+        v.push_back({n, ne, off, r, cc, ine, ioff, ir, ic, m});
         off += (ne + 63) / 64 * 64;
+        ioff += (ine + 63) / 64 * 64;
     };
-    const int64_t H = c.hidden;
-    add("atom_encoder.weight", 118 * H);
-    add("virtualnode_embedding.weight", H);
-    if (c.kind == 1) add("text_dropping.weight", c.text_dim);
+    const int H = d.Ht, Hp = d.Hp, D = d.Dt, Dp = d.Dp;
+    PadMap rows3;  rows3.rg = H; rows3.rgp = Hp;       // (shift | scale | gate) chunks of H rows -> chunks of Hp rows
+    auto mlp = [&](const std::string &p0, const std::string &p1, const std::string &p4) {
+        add(p0 + "weight", 4 * H, H, 4 * Hp, Hp);
+        add(p0 + "bias", 4 * H, 1, 4 * Hp, 1);
+        add(p1 + "weight", 4 * H, 1, 4 * Hp, 1);
+        add(p1 + "bias", 4 * H, 1, 4 * Hp, 1);
+        add(p4 + "weight", H, 4 * H, Hp, 4 * Hp);
+        add(p4 + "bias", H, 1, Hp, 1);
+    };
+    add("atom_encoder.weight", 118, H, 118, Hp);
+    add("virtualnode_embedding.weight", 1, H, 1, Hp);
+    if (c.kind == 1) add("text_dropping.weight", 1, D, 1, Dp);
     for (int i = 0; i < c.num_layer; ++i) {
         const std::string p = "convs." + std::to_string(i) + ".";
-        add(p + "eps", 1);
-        add(p + "mlp.0.weight", 4 * H * H);
-        add(p + "mlp.0.bias", 4 * H);
-        add(p + "mlp.1.weight", 4 * H);
-        add(p + "mlp.1.bias", 4 * H);
-        add(p + "mlp.4.weight", H * 4 * H);
-        add(p + "mlp.4.bias", H);
-        add(p + "bond_encoder.weight", 5 * H);
+        add(p + "eps", 1, 1, 1, 1);
+        mlp(p + "mlp.0.", p + "mlp.1.", p + "mlp.4.");
+        add(p + "bond_encoder.weight", 5, H, 5, Hp);
         if (c.kind == 0) {
-            add("norms." + std::to_string(i) + ".weight", H);
-            add("norms." + std::to_string(i) + ".bias", H);
+            add("norms." + std::to_string(i) + ".weight", H, 1, Hp, 1);
+            add("norms." + std::to_string(i) + ".bias", H, 1, Hp, 1);
         } else {
-            add("adapters." + std::to_string(i) + ".1.weight", 3 * H * c.text_dim);
-            add("adapters." + std::to_string(i) + ".1.bias", 3 * H);
+            add("adapters." + std::to_string(i) + ".1.weight", 3 * H, D, 3 * Hp, Dp, rows3);
+            add("adapters." + std::to_string(i) + ".1.bias", 3 * H, 1, 3 * Hp, 1, rows3);
         }
         if (i < c.num_layer - 1) {
             const std::string q = "mlp_virtualnode_list." + std::to_string(i) + ".";
-            add(q + "0.weight", 4 * H * H);
-            add(q + "0.bias", 4 * H);
-            add(q + "1.weight", 4 * H);
-            add(q + "1.bias", 4 * H);
-            add(q + "4.weight", H * 4 * H);
-            add(q + "4.bias", H);
+            mlp(q + "0.", q + "1.", q + "4.");
         }
     }
     if (c.kind == 0) {  // ProjectionHead, keys prefixed "proj."
-        add("proj.fc1.weight", H * H);
-        add("proj.fc1.bias", H);
-        add("proj.norm1.weight", H);
-        add("proj.norm1.bias", H);
-        add("proj.fc2.weight", H * H);
-        add("proj.fc2.bias", H);
+        add("proj.fc1.weight", H, H, Hp, Hp);
+        add("proj.fc1.bias", H, 1, Hp, 1);
+        add("proj.norm1.weight", H, 1, Hp, 1);
+        add("proj.norm1.bias", H, 1, Hp, 1);
+        add("proj.fc2.weight", H, H, Hp, Hp);
+        add("proj.fc2.bias", H, 1, Hp, 1);
     } else {
-        add("decoder.0.weight", 4 * H * H);
-        add("decoder.0.bias", 4 * H);
-        add("decoder.1.weight", 4 * H);
-        add("decoder.1.bias", 4 * H);
-        add("decoder.4.weight", (int64_t)c.out_dim * 4 * H);
-        add("decoder.4.bias", c.out_dim);
+        add("decoder.0.weight", 4 * H, H, 4 * Hp, Hp);
+        add("decoder.0.bias", 4 * H, 1, 4 * Hp, 1);
+        add("decoder.1.weight", 4 * H, 1, 4 * Hp, 1);
+        add("decoder.1.bias", 4 * H, 1, 4 * Hp, 1);
+        add("decoder.4.weight", c.out_dim, 4 * H, c.out_dim, 4 * Hp);
+        add("decoder.4.bias", c.out_dim, 1, c.out_dim, 1);
     }
     return v;
 }
 
+// hidden <= 2048 bounds the per-row register footprint of the row kernels (the Python wrappers report it as a ValueError naming the limit)
 static int gin_check(const LLGinConfig *c) {
     LL_CHECK(c != nullptr, "config is null");
     LL_CHECK(c->num_layer >= 2, "Number of GNN layers must be greater than 1.");
-    LL_CHECK(c->hidden >= 64 && c->hidden % 64 == 0 && c->hidden <= 2048, "hidden=%d must be a multiple of 64 in [64,2048]", c->hidden);
+    LL_CHECK(c->hidden >= 1 && c->hidden <= 2048, "hidden=%d must be in [1,2048]", c->hidden);
     LL_CHECK(c->kind == 0 || c->kind == 1, "kind must be 0 (encoder) or 1 (predictor)");
     LL_CHECK(c->dtype == LL_F32 || c->dtype == LL_BF16, "unknown dtype %d", c->dtype);
     if (c->kind == 1) {
         LL_CHECK(c->out_dim >= 1, "predictor needs out_dim >= 1");
-        LL_CHECK(c->text_dim >= 64 && c->text_dim % 64 == 0, "text_dim=%d must be a multiple of 64", c->text_dim);
+        LL_CHECK(c->text_dim >= 1 && c->text_dim <= 16384, "text_dim=%d must be in [1,16384]", c->text_dim);
     }
     return LL_OK;
 }
@@ -114,7 +139,9 @@ template <typename T>
 __global__ __launch_bounds__(64) void rows_ln_act_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                           const float *__restrict__ b, T *__restrict__ out, int R,
                                                           int C, int gelu, int n1, int r2, const float *__restrict__ w2,
-                                                          const float *__restrict__ b2) {
+                                                          const float *__restrict__ b2, int Ct) {
+    // C = row pitch, Ct <= C = the checkpoint's width: the statistics run over the Ct true columns; the padded ones are zeros going in
+    // and (zero LayerNorm weight / bias) zeros coming out
     const int r = blockIdx.x;   // one wave = one row = one workgroup
     if (r >= R || (r >= n1 && r < r2)) return;
     if (r >= r2) { w = w2; b = b2; }
@@ -129,16 +156,11 @@ __global__ __launch_bounds__(64) void rows_ln_act_kernel(const float *__restrict
         v[e] = k < C ? *reinterpret_cast<const float4 *>(x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += v[e].x + v[e].y + v[e].z + v[e].w;
     }
-    const float mean = wave_sum(s) / (float)C;
+    const float mean = wave_sum(s) / (float)Ct;
     float vr = 0.f;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-        if ((lane + e * 64) * 4 < C) {
-            const float d0 = v[e].x - mean, d1 = v[e].y - mean, d2 = v[e].z - mean, d3 = v[e].w - mean;
-            vr += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(vr) / (float)C + 1e-5f);
+    for (int e = 0; e < MAXE; ++e) vr += sq_dev4(v[e], mean, (lane + e * 64) * 4, Ct);
+    const float rstd = rsqrtf(wave_sum(vr) / (float)Ct + 1e-5f);
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
         const int k = (lane + e * 64) * 4;
@@ -160,7 +182,7 @@ template <typename T, int WAVES, int CH>
 __global__ __launch_bounds__(64 * WAVES) void rows_ln_act_mw_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                                     const float *__restrict__ b, T *__restrict__ out, int R, int C,
                                                                     int gelu, int n1, int r2, const float *__restrict__ w2,
-                                                                    const float *__restrict__ b2) {
+                                                                    const float *__restrict__ b2, int Ct) {
     __shared__ float part[2][WAVES];
     const int r = blockIdx.x;
     if (r >= R || (r >= n1 && r < r2)) return;
@@ -184,20 +206,17 @@ __global__ __launch_bounds__(64 * WAVES) void rows_ln_act_mw_kernel(const float 
     float tot = 0.f;
 #pragma unroll
     for (int i = 0; i < WAVES; ++i) tot += part[0][i];
-    const float mean = tot / (float)C;
+    const float mean = tot / (float)Ct;
     float vr = 0.f;
 #pragma unroll
-    for (int e = 0; e < CH; ++e) {
-        const float d0 = v[e].x - mean, d1 = v[e].y - mean, d2 = v[e].z - mean, d3 = v[e].w - mean;
-        vr += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-    }
+    for (int e = 0; e < CH; ++e) vr += sq_dev4(v[e], mean, (tid + e * 64 * WAVES) * 4, Ct);
     vr = wave_sum(vr);
     if (lane == 0) part[1][wave] = vr;
     __syncthreads();
     float tv = 0.f;
 #pragma unroll
     for (int i = 0; i < WAVES; ++i) tv += part[1][i];
-    const float rstd = rsqrtf(tv / (float)C + 1e-5f);
+    const float rstd = rsqrtf(tv / (float)Ct + 1e-5f);
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
         const int k = (tid + e * 64 * WAVES) * 4;
@@ -209,9 +228,9 @@ __global__ __launch_bounds__(64 * WAVES) void rows_ln_act_mw_kernel(const float 
 }
 
 template <typename T>
-static void launch_rows_ln_act2(const float *in, const float *w, const float *b, T *out, int R, int C, int gelu, int n1, int r2,
+static void launch_rows_ln_act2(const float *in, const float *w, const float *b, T *out, int R, int C, int Ct, int gelu, int n1, int r2,
                                 const float *w2, const float *b2, hipStream_t st) {
-#define LL_RLA(W, CH, BLK) hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, W, CH>), dim3(R), dim3(BLK), 0, st, in, w, b, out, R, C, gelu, n1, r2, w2, b2)
+#define LL_RLA(W, CH, BLK) hipLaunchKernelGGL((rows_ln_act_mw_kernel<T, W, CH>), dim3(R), dim3(BLK), 0, st, in, w, b, out, R, C, gelu, n1, r2, w2, b2, Ct)
     if (C % 1024 == 0 && C / 1024 <= 4) {            // 4 waves per row, 1..4 float4 per lane
         switch (C / 1024) {
             case 1: LL_RLA(4, 1, 256); return;
@@ -228,11 +247,11 @@ static void launch_rows_ln_act2(const float *in, const float *w, const float *b,
         }
     }
 #undef LL_RLA
-    hipLaunchKernelGGL((rows_ln_act_kernel<T>), dim3(R), dim3(64), 0, st, in, w, b, out, R, C, gelu, n1, r2, w2, b2);
+    hipLaunchKernelGGL((rows_ln_act_kernel<T>), dim3(R), dim3(64), 0, st, in, w, b, out, R, C, gelu, n1, r2, w2, b2, Ct);
 }
 template <typename T>
-static void launch_rows_ln_act(const float *in, const float *w, const float *b, T *out, int R, int C, int gelu, hipStream_t st) {
-    launch_rows_ln_act2<T>(in, w, b, out, R, C, gelu, R, R, nullptr, nullptr, st);
+static void launch_rows_ln_act(const float *in, const float *w, const float *b, T *out, int R, int C, int Ct, int gelu, hipStream_t st) {
+    launch_rows_ln_act2<T>(in, w, b, out, R, C, Ct, gelu, R, R, nullptr, nullptr, st);
 }
 
 // Layer tail (gin_post2_kernel below).  Encoder: z = LN_affine(z); predictor: z = LN0(z) * (1 + scale) + shift, residual gated.
@@ -253,7 +272,8 @@ __global__ __launch_bounds__(256) void gin_prologue_kernel(const int *__restrict
                                                             const float *__restrict__ drop, float *__restrict__ h, float *__restrict__ vn,
                                                             T *__restrict__ csilu, const int *__restrict__ rowptr, const int *__restrict__ src,
                                                             const int *__restrict__ attr, const int *__restrict__ batch, int *__restrict__ ell,
-                                                            int n, int G, int H, int D) {
+                                                            int n, int G, int H, int D, int Dt) {
+    // H, D: row pitches of the engine (multiples of 64); Dt = width of the caller's `c` rows (the checkpoint's text_dim)
     const int H4 = H / 4, D4 = D / 4;
     const int64_t n4 = (int64_t)n * H4, g4 = (int64_t)G * H4, c4 = csilu ? (int64_t)G * D4 : 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4 + g4 + c4 + n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -265,7 +285,17 @@ __global__ __launch_bounds__(256) void gin_prologue_kernel(const int *__restrict
             *reinterpret_cast<float4 *>(vn + j * 4) = *reinterpret_cast<const float4 *>(vemb + (j % H4) * 4);
         } else if (i < n4 + g4 + c4) {
             const int64_t j = i - n4 - g4;
-            const float4 v = c ? *reinterpret_cast<const float4 *>(c + j * 4) : *reinterpret_cast<const float4 *>(drop + (j % D4) * 4);
+            float4 v;
+            if (!c) {
+                v = *reinterpret_cast<const float4 *>(drop + (j % D4) * 4);
+            } else if (Dt == D) {
+                v = *reinterpret_cast<const float4 *>(c + j * 4);
+            } else {      // padded text width: element-wise from the caller's narrower rows, zeros behind them (SiLU(0) = 0)
+                const int64_t g = j / D4;
+                const int k = (int)(j % D4) * 4;
+                const float *cr = c + g * Dt;
+                v = make_float4(k < Dt ? cr[k] : 0.f, k + 1 < Dt ? cr[k + 1] : 0.f, k + 2 < Dt ? cr[k + 2] : 0.f, k + 3 < Dt ? cr[k + 3] : 0.f);
+            }
             gin_store4<T>(csilu + j * 4, make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w)));
         } else {
             const int v = (int)(i - n4 - g4 - c4);
@@ -378,7 +408,8 @@ __global__ __launch_bounds__(64) void gin_post2_kernel(const float *__restrict__
                                                         const float *__restrict__ lnw, const float *__restrict__ lnb,
                                                         const float *__restrict__ mod, int modld, const int *__restrict__ batch,
                                                         float *__restrict__ h, float *__restrict__ z_keep, int n, int H, int gelu,
-                                                        float *__restrict__ vn, const float *__restrict__ vbias, int vrow0) {
+                                                        float *__restrict__ vn, const float *__restrict__ vbias, int vrow0, int Ht) {
+    // H = row pitch, Ht = the checkpoint's hidden_size (LayerNorm statistics); padded columns: zero in, zero out (zero affine / zero gate)
     const int lane = threadIdx.x;
     constexpr int MAXE = 8;   // H <= 2048
     if ((int)blockIdx.x >= n) {
@@ -423,16 +454,11 @@ __global__ __launch_bounds__(64) void gin_post2_kernel(const float *__restrict__
         }
         s += t[e].x + t[e].y + t[e].z + t[e].w;
     }
-    const float mean = wave_sum(s) / (float)H;
+    const float mean = wave_sum(s) / (float)Ht;
     float vr = 0.f;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-        if ((lane + e * 64) * 4 < H) {
-            const float d0 = t[e].x - mean, d1 = t[e].y - mean, d2 = t[e].z - mean, d3 = t[e].w - mean;
-            vr += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(vr) / (float)H + 1e-5f);
+    for (int e = 0; e < MAXE; ++e) vr += sq_dev4(t[e], mean, (lane + e * 64) * 4, Ht);
+    const float rstd = rsqrtf(wave_sum(vr) / (float)Ht + 1e-5f);
     const float *m = mod ? mod + (int64_t)batch[v] * modld : nullptr;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
@@ -465,7 +491,7 @@ __global__ __launch_bounds__(64 * WAVES) void gin_post2_mw_kernel(const float *_
                                                                   const float *__restrict__ lnw, const float *__restrict__ lnb,
                                                                   const float *__restrict__ mod, int modld, const int *__restrict__ batch,
                                                                   float *__restrict__ h, float *__restrict__ z_keep, int n, int H, int gelu,
-                                                                  float *__restrict__ vn, const float *__restrict__ vbias, int vrow0) {
+                                                                  float *__restrict__ vn, const float *__restrict__ vbias, int vrow0, int Ht) {
     __shared__ float part[2][WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = tid * 4;
@@ -510,15 +536,15 @@ __global__ __launch_bounds__(64 * WAVES) void gin_post2_mw_kernel(const float *_
     float tot = 0.f;
 #pragma unroll
     for (int i = 0; i < WAVES; ++i) tot += part[0][i];
-    const float mean = tot / (float)H;
+    const float mean = tot / (float)Ht;
     const float d0 = t.x - mean, d1 = t.y - mean, d2 = t.z - mean, d3 = t.w - mean;
-    float vr = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+    float vr = wave_sum(sq_dev4(t, mean, k, Ht));
     if (lane == 0) part[1][wave] = vr;
     __syncthreads();
     float tv = 0.f;
 #pragma unroll
     for (int i = 0; i < WAVES; ++i) tv += part[1][i];
-    const float rstd = rsqrtf(tv / (float)H + 1e-5f);
+    const float rstd = rsqrtf(tv / (float)Ht + 1e-5f);
     float4 y = make_float4(d0 * rstd, d1 * rstd, d2 * rstd, d3 * rstd);
     if (m) y = make_float4(y.x * (1.f + p1.x) + p0.x, y.y * (1.f + p1.y) + p0.y, y.z * (1.f + p1.z) + p0.z, y.w * (1.f + p1.w) + p0.w);
     else y = make_float4(y.x * p0.x + p1.x, y.y * p0.y + p1.y, y.z * p0.z + p1.z, y.w * p0.w + p1.w);
@@ -590,17 +616,18 @@ __global__ __launch_bounds__(256) void segment_pool_kernel(const float *__restri
 __global__ void add_rows_kernel(float *__restrict__ dst, const float *__restrict__ src, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] += src[i];
 }
-__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float *__restrict__ in, float *__restrict__ out, int R, int C) {
+// rows of C columns: `in` has row pitch ldi (the engine's padded width), `out` is the caller's dense [R][C]
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float *__restrict__ in, float *__restrict__ out, int R, int C, int ldi) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     const int lane = threadIdx.x & 63;
     float s = 0.f;
     for (int k = lane; k < C; k += 64) {
-        const float v = in[(int64_t)r * C + k];
+        const float v = in[(int64_t)r * ldi + k];
         s += v * v;
     }
     const float inv = 1.f / sqrtf(wave_sum(s));
-    for (int k = lane; k < C; k += 64) out[(int64_t)r * C + k] = in[(int64_t)r * C + k] * inv;
+    for (int k = lane; k < C; k += 64) out[(int64_t)r * C + k] = in[(int64_t)r * ldi + k] * inv;
 }
 
 // ------------------------------------------------------------------------------------------ softmax + top-k
@@ -1171,8 +1198,10 @@ struct GBuf {
 
 struct GinEngine {
     LLGinConfig cfg;
+    GinDims d;                   // checkpoint widths and the engine's padded pitches
     std::vector<GinParam> layout;
-    const float *w32 = nullptr;
+    const float *w32 = nullptr;  // f32 master arena in the INTERNAL layout: the caller's arena itself when no width needs padding, else `wpad`
+    GBuf wpad;                   // zero-padded f32 copy of the caller's arena (only when d.padded)
     GBuf wop;
     GBuf adcat, adbcat;          // predictor: the L adapter Linears concatenated along N ([L * 3H, text_dim] operand dtype, [L * 3H] f32 bias): one GEMM
     GBuf h, h_in, a0, t1, t1a, zs, vn, pool32, poola, mod, csilu, head1, head1a, head2, ell;
@@ -1185,12 +1214,12 @@ struct GinEngine {
         g_dhead1, g_dlog, g_slabs, g_dcs;
     const float *pf(const std::string &n) const {
         for (auto &p : layout)
-            if (p.name == n) return w32 + p.offset;
+            if (p.name == n) return w32 + p.ioffset;
         return nullptr;
     }
     const void *pw(const std::string &n) const {
         for (auto &p : layout)
-            if (p.name == n) return cfg.dtype == LL_BF16 ? (const void *)(wop.as<bf16_t>() + p.offset) : (const void *)(w32 + p.offset);
+            if (p.name == n) return cfg.dtype == LL_BF16 ? (const void *)(wop.as<bf16_t>() + p.ioffset) : (const void *)(w32 + p.ioffset);
         return nullptr;
     }
     // the layer's parameters, resolved once (pf / pw compare strings; the forward makes ~15 lookups per layer)
@@ -1247,7 +1276,7 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
                          const int *batch, const int *gptr, int n, int ne, int G, const float *c, float *out,
                          float *pooled, hipStream_t st) {
     const LLGinConfig &cf = e->cfg;
-    const int H = cf.hidden, L = cf.num_layer, dt = cf.dtype, es = sizeof(T);
+    const int H = e->d.Hp, Ht = e->d.Ht, D = e->d.Dp, L = cf.num_layer, dt = cf.dtype, es = sizeof(T);      // H, D: row pitches (multiples of 64)
     const int n64 = round_up(n, 64), MR = n64 + round_up(G, 64), Gp = round_up(G, 128);
     const int ks = gin_k_splits(n64 + G, H);
     const int64_t zstride = (int64_t)MR * H;
@@ -1265,19 +1294,19 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
     const int modld = L * 3 * H;
     T *csilu = nullptr;
     if (cf.kind == 1) {
-        LL_TRY(e->csilu.ensure((size_t)Gp * cf.text_dim * es));
+        LL_TRY(e->csilu.ensure((size_t)Gp * D * es));
         LL_TRY(e->mod.ensure((size_t)Gp * modld * 4));
         csilu = e->csilu.as<T>();
     }
     {
-        const int64_t items = ((int64_t)n * H + (int64_t)G * H + (csilu ? (int64_t)G * cf.text_dim : 0)) / 4 + n;
+        const int64_t items = ((int64_t)n * H + (int64_t)G * H + (csilu ? (int64_t)G * D : 0)) / 4 + n;
         hipLaunchKernelGGL((gin_prologue_kernel<T>), dim3((unsigned)std::min<int64_t>((items + 255) / 256, 2048)), blk, 0, st,
                            x, e->atom_emb, e->vn_emb, c, e->text_drop, e->h.as<float>(), e->vn.as<float>(), csilu, rowptr, src, attr, batch,
-                           e->ell.as<int>(), n, G, H, cf.text_dim);
+                           e->ell.as<int>(), n, G, H, D, e->d.Dt);
         LL_LAUNCH_CHECK();
     }
     if (cf.kind == 1)   // (shift, scale, gate) of every layer: ONE GEMM over the N-concatenated adapters -> mod [G][L * 3H]
-        LL_TRY(linear_launch(dt, e->csilu.p, cf.text_dim, e->adcat.p, cf.text_dim, e->adbcat.as<float>(), e->mod.p, modld, G, modld, cf.text_dim, 0, 1, st));
+        LL_TRY(linear_launch(dt, e->csilu.p, D, e->adcat.p, D, e->adbcat.as<float>(), e->mod.p, modld, G, modld, D, 0, 1, st));
     const int npw = H >= 1024 ? 4 : H >= 512 ? 2 : 1;      // waves per node of the aggregation launch: one pass over the row
     const int nbn = cdiv(n, 4 / npw), chunks = cdiv(H, 256);
     const int post_waves = (H % 256 == 0 && H / 256 <= 8 && ((H / 256) & (H / 256 - 1)) == 0) ? H / 256 : 0;
@@ -1299,14 +1328,14 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
 #undef LL_AGG
         LL_LAUNCH_CHECK();
         LL_TRY(linear_grouped2_launch(dt, e->a0.p, H, w.w0, last ? nullptr : w.vw0, H, w.b0, w.vb0, t1, 4 * H, M, n64, 4 * H, H, 1, 0, 0, 1, st));
-        launch_rows_ln_act2<T>(t1, w.ln_w, w.ln_b, e->t1a.as<T>(), M, 4 * H, 1, n, last ? M : n64, w.vln_w, w.vln_b, st);
+        launch_rows_ln_act2<T>(t1, w.ln_w, w.ln_b, e->t1a.as<T>(), M, 4 * H, 4 * Ht, 1, n, last ? M : n64, w.vln_w, w.vln_b, st);
         LL_LAUNCH_CHECK();
         LL_TRY(linear_grouped2_launch(dt, e->t1a.p, 4 * H, w.w4, last ? nullptr : w.vw4, 4 * H, nullptr, nullptr, e->zs.p, H, M, n64, H, 4 * H, ks,
                                       zstride, 0, 1, st));
         const float *mod = cf.kind == 1 ? e->mod.as<float>() + (size_t)l * 3 * H : nullptr;
 #define LL_POST(KERNEL, BLK)                                                                                                       \
     hipLaunchKernelGGL(KERNEL, dim3(n + (last ? 0 : G)), dim3(BLK), 0, st, e->zs.as<float>(), zstride, ks, w.b4, h_in, w.norm_w, w.norm_b, \
-                       mod, modld, batch, e->h.as<float>(), z_keep, n, H, last ? 0 : 1, e->vn.as<float>(), w.vb4, n64)
+                       mod, modld, batch, e->h.as<float>(), z_keep, n, H, last ? 0 : 1, e->vn.as<float>(), w.vb4, n64, Ht)
         switch (post_waves) {
             case 1: LL_POST(gin_post2_mw_kernel<1>, 64); break;
             case 2: LL_POST(gin_post2_mw_kernel<2>, 128); break;
@@ -1319,16 +1348,16 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
     }
     hipLaunchKernelGGL((gin_pool_add_kernel<T>), dim3(G * chunks), blk, 0, st, e->h.as<float>(), gptr, e->pool32.as<float>(), e->poola.as<T>(), H);
     LL_LAUNCH_CHECK();
-    if (pooled) LL_HIP(hipMemcpyAsync(pooled, e->pool32.p, (size_t)G * H * 4, hipMemcpyDeviceToDevice, st));
+    if (pooled) LL_HIP(hipMemcpy2DAsync(pooled, (size_t)Ht * 4, e->pool32.p, (size_t)H * 4, (size_t)Ht * 4, G, hipMemcpyDeviceToDevice, st));
     if (cf.kind == 0) {  // ProjectionHead + L2 normalise (model.py:37-41,198-205)
         LL_TRY(e->head1.ensure((size_t)Gp * H * 4));
         LL_TRY(e->head1a.ensure((size_t)Gp * H * es));
         LL_TRY(e->head2.ensure((size_t)Gp * H * 4));
         LL_TRY(linear_launch(dt, e->poola.p, H, e->w_h0, H, e->b_h0, e->head1.p, H, G, H, H, 0, 1, st));
-        launch_rows_ln_act<T>(e->head1.as<float>(), e->hln_w, e->hln_b, e->head1a.as<T>(), G, H, 1, st);
+        launch_rows_ln_act<T>(e->head1.as<float>(), e->hln_w, e->hln_b, e->head1a.as<T>(), G, H, Ht, 1, st);
         LL_LAUNCH_CHECK();
         LL_TRY(linear_launch(dt, e->head1a.p, H, e->w_h2, H, e->b_h2, e->head2.p, H, G, H, H, 0, 1, st));
-        hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cdiv(G, 4)), blk, 0, st, e->head2.as<float>(), out, G, H);
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3(cdiv(G, 4)), blk, 0, st, e->head2.as<float>(), out, G, Ht, H);
         LL_LAUNCH_CHECK();
     } else {  // decoder: Linear(H,4H) -> LN -> GELU -> Linear(4H,out_dim)  (model.py:272-278)
         LL_TRY(e->head1a.ensure((size_t)Gp * 4 * H * es));
@@ -1343,7 +1372,7 @@ static int gin_forward_t(GinEngine *e, const int *x, const int *rowptr, const in
             head1 = e->head1.as<float>();
         }
         LL_TRY(linear_launch(dt, e->poola.p, H, e->w_h0, H, e->b_h0, head1, 4 * H, G, 4 * H, H, 0, 1, st));
-        launch_rows_ln_act<T>(head1, e->hln_w, e->hln_b, e->head1a.as<T>(), G, 4 * H, 1, st);
+        launch_rows_ln_act<T>(head1, e->hln_w, e->hln_b, e->head1a.as<T>(), G, 4 * H, 4 * Ht, 1, st);
         LL_LAUNCH_CHECK();
         // template head [G, 4H] x [out_dim, 4H]^T (740 MB of bf16 weights at out_dim = 180 576): 3..16 graphs stream it through the
         // 16-row MFMA Linear (line-contiguous loads, wave-private LDS transpose), anything else through the GEMM dispatch
@@ -1370,7 +1399,9 @@ __device__ __forceinline__ float gelu_grad(float u) {
 template <typename T>
 __global__ __launch_bounds__(64) void ln_gelu_bwd_kernel(const float *__restrict__ t, const float *__restrict__ w,
                                                           const float *__restrict__ b, const float *__restrict__ g,
-                                                          T *__restrict__ dt, int R, int C) {
+                                                          T *__restrict__ dt, int R, int C, int Ct) {
+    // C = row pitch, Ct = the checkpoint's width: statistics over the Ct true columns; the padded columns (zero LayerNorm weight: no
+    // gradient passes through them) get dt = 0
     const int r = blockIdx.x;
     if (r >= R) return;
     const int lane = threadIdx.x;
@@ -1384,16 +1415,11 @@ __global__ __launch_bounds__(64) void ln_gelu_bwd_kernel(const float *__restrict
         v[e] = k < C ? *reinterpret_cast<const float4 *>(x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += v[e].x + v[e].y + v[e].z + v[e].w;
     }
-    const float mean = wave_sum(s) / (float)C;
+    const float mean = wave_sum(s) / (float)Ct;
     float vr = 0.f;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-        if ((lane + e * 64) * 4 < C) {
-            const float d0 = v[e].x - mean, d1 = v[e].y - mean, d2 = v[e].z - mean, d3 = v[e].w - mean;
-            vr += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(vr) / (float)C + 1e-5f);
+    for (int e = 0; e < MAXE; ++e) vr += sq_dev4(v[e], mean, (lane + e * 64) * 4, Ct);
+    const float rstd = rsqrtf(wave_sum(vr) / (float)Ct + 1e-5f);
     float m1 = 0.f, m2 = 0.f;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {     // v[e] <- xhat; accumulate mean(dxhat), mean(dxhat * xhat)
@@ -1412,8 +1438,8 @@ __global__ __launch_bounds__(64) void ln_gelu_bwd_kernel(const float *__restrict
             v[e] = make_float4(xh[0], xh[1], xh[2], xh[3]);
         }
     }
-    m1 = wave_sum(m1) / (float)C;
-    m2 = wave_sum(m2) / (float)C;
+    m1 = wave_sum(m1) / (float)Ct;
+    m2 = wave_sum(m2) / (float)Ct;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
         const int k = (lane + e * 64) * 4;
@@ -1426,7 +1452,7 @@ __global__ __launch_bounds__(64) void ln_gelu_bwd_kernel(const float *__restrict
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float dx = gv[q] * gelu_grad(xh[q] * wv[q] + bv[q]) * wv[q];
-                o[q] = rstd * (dx - m1 - xh[q] * m2);
+                o[q] = k + q < Ct ? rstd * (dx - m1 - xh[q] * m2) : 0.f;
             }
             gin_store4<T>(dt + (int64_t)r * C + k, make_float4(o[0], o[1], o[2], o[3]));
         }
@@ -1440,7 +1466,7 @@ template <typename T>
 __global__ __launch_bounds__(64) void gin_post_bwd_kernel(const float *__restrict__ z, const float *__restrict__ mod, int modld,
                                                            const int *__restrict__ batch, const float *__restrict__ dh,
                                                            T *__restrict__ dz, float *__restrict__ c3 /*[3][n][H]*/, int n,
-                                                           int H, int gelu) {
+                                                           int H, int gelu, int Ht) {
     const int v = blockIdx.x;
     if (v >= n) return;
     const int lane = threadIdx.x;
@@ -1454,16 +1480,11 @@ __global__ __launch_bounds__(64) void gin_post_bwd_kernel(const float *__restric
         t[e] = k < H ? *reinterpret_cast<const float4 *>(x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += t[e].x + t[e].y + t[e].z + t[e].w;
     }
-    const float mean = wave_sum(s) / (float)H;
+    const float mean = wave_sum(s) / (float)Ht;
     float vr = 0.f;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-        if ((lane + e * 64) * 4 < H) {
-            const float d0 = t[e].x - mean, d1 = t[e].y - mean, d2 = t[e].z - mean, d3 = t[e].w - mean;
-            vr += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(vr) / (float)H + 1e-5f);
+    for (int e = 0; e < MAXE; ++e) vr += sq_dev4(t[e], mean, (lane + e * 64) * 4, Ht);
+    const float rstd = rsqrtf(wave_sum(vr) / (float)Ht + 1e-5f);
     const float *m = mod + (int64_t)batch[v] * modld;
     float4 dxh[MAXE];
     float m1 = 0.f, m2 = 0.f;
@@ -1499,15 +1520,15 @@ __global__ __launch_bounds__(64) void gin_post_bwd_kernel(const float *__restric
             *reinterpret_cast<float4 *>(c3 + 2 * plane + (int64_t)v * H + k) = make_float4(cg[0], cg[1], cg[2], cg[3]);
         }
     }
-    m1 = wave_sum(m1) / (float)H;
-    m2 = wave_sum(m2) / (float)H;
+    m1 = wave_sum(m1) / (float)Ht;
+    m2 = wave_sum(m2) / (float)Ht;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
         const int k = (lane + e * 64) * 4;
-        if (k < H)
+        if (k < H)      // (padded columns: d h = 0 there, and no gradient leaves through them)
             gin_store4<T>(dz + (int64_t)v * H + k,
-                          make_float4(rstd * (dxh[e].x - m1 - t[e].x * m2), rstd * (dxh[e].y - m1 - t[e].y * m2),
-                                      rstd * (dxh[e].z - m1 - t[e].z * m2), rstd * (dxh[e].w - m1 - t[e].w * m2)));
+                          make_float4(k < Ht ? rstd * (dxh[e].x - m1 - t[e].x * m2) : 0.f, k + 1 < Ht ? rstd * (dxh[e].y - m1 - t[e].y * m2) : 0.f,
+                                      k + 2 < Ht ? rstd * (dxh[e].z - m1 - t[e].z * m2) : 0.f, k + 3 < Ht ? rstd * (dxh[e].w - m1 - t[e].w * m2) : 0.f));
     }
 }
 
@@ -1581,10 +1602,11 @@ __global__ void sum_slabs_kernel(const float *__restrict__ slabs, int64_t stride
         out[i] = a;
     }
 }
-__global__ void silu_bwd_kernel(const float *__restrict__ c, const float *__restrict__ g, float *__restrict__ dc, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+// c, dc: the caller's dense [G][D] rows; g: rows of pitch ldg (the engine's padded text width)
+__global__ void silu_bwd_kernel(const float *__restrict__ c, const float *__restrict__ g, float *__restrict__ dc, int G, int D, int ldg) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)G * D; i += (int64_t)gridDim.x * blockDim.x) {
         const float x = c[i], sg = 1.f / (1.f + expf(-x));
-        dc[i] = g[i] * sg * (1.f + x * (1.f - sg));
+        dc[i] = g[(i / D) * ldg + i % D] * sg * (1.f + x * (1.f - sg));
     }
 }
 
@@ -1596,26 +1618,26 @@ static int64_t head_kp(int out_dim) { return (int64_t)round_up(out_dim, 64 * HEA
 template <typename T>
 static int gin_build_transposes(GinEngine *e, hipStream_t st) {
     const LLGinConfig &cf = e->cfg;
-    const int H = cf.hidden, L = cf.num_layer;
+    const int H = e->d.Hp, D = e->d.Dp, L = cf.num_layer;      // padded pitches: the transposes are taken of the internal arena
     int64_t total = 0;
-    for (auto &p : e->layout) total = std::max<int64_t>(total, p.offset + (p.numel + 63) / 64 * 64);
+    for (auto &p : e->layout) total = std::max<int64_t>(total, p.ioffset + (p.inumel + 63) / 64 * 64);
     const int64_t kp = head_kp(cf.out_dim);
     LL_TRY(e->wT.ensure((size_t)(total + (int64_t)4 * H * kp) * sizeof(T)));     // head copy appended after the arena image
-    LL_TRY(e->adT.ensure((size_t)cf.text_dim * L * 3 * H * sizeof(T)));
+    LL_TRY(e->adT.ensure((size_t)D * L * 3 * H * sizeof(T)));
     auto tr = [&](const std::string &name, int N, int K, T *dst, int64_t ldo) {
         dim3 grid(cdiv(K, 32), cdiv(N, 32)), blk(32, 8);
         hipLaunchKernelGGL((transpose_w_kernel<T>), grid, blk, 0, st, e->pf(name), dst, N, K, ldo);
     };
     auto slot = [&](const std::string &name) -> T * {
         for (auto &p : e->layout)
-            if (p.name == name) return e->wT.as<T>() + p.offset;
+            if (p.name == name) return e->wT.as<T>() + p.ioffset;
         return nullptr;
     };
     for (int l = 0; l < L; ++l) {
         const std::string p = "convs." + std::to_string(l) + ".";
         tr(p + "mlp.0.weight", 4 * H, H, slot(p + "mlp.0.weight"), 4 * H);       // [H][4H]
         tr(p + "mlp.4.weight", H, 4 * H, slot(p + "mlp.4.weight"), H);           // [4H][H]
-        tr("adapters." + std::to_string(l) + ".1.weight", 3 * H, cf.text_dim, e->adT.as<T>() + (int64_t)l * 3 * H, (int64_t)L * 3 * H);
+        tr("adapters." + std::to_string(l) + ".1.weight", 3 * H, D, e->adT.as<T>() + (int64_t)l * 3 * H, (int64_t)L * 3 * H);
         if (l < L - 1) {
             const std::string q = "mlp_virtualnode_list." + std::to_string(l) + ".";
             tr(q + "0.weight", 4 * H, H, slot(q + "0.weight"), 4 * H);
@@ -1633,15 +1655,15 @@ template <typename T>
 static int gin_backward_c_t(GinEngine *e, const int *rowptr_s, const int *dst_s, const int *attr_s, const int *batch,
                             const int *gptr, int n, int G, const float *c, const float *dlogits, float *dc, hipStream_t st) {
     const LLGinConfig &cf = e->cfg;
-    const int H = cf.hidden, L = cf.num_layer, dt = cf.dtype, es = sizeof(T);
+    const int H = e->d.Hp, Ht = e->d.Ht, D = e->d.Dp, L = cf.num_layer, dt = cf.dtype, es = sizeof(T);
     const int np = round_up(n, 128), Gp = round_up(G, 128);
     const int64_t kp = head_kp(cf.out_dim);
     if (!e->wT.p) LL_TRY(gin_build_transposes<T>(e, st));
     int64_t total = 0;
-    for (auto &p : e->layout) total = std::max<int64_t>(total, p.offset + (p.numel + 63) / 64 * 64);
+    for (auto &p : e->layout) total = std::max<int64_t>(total, p.ioffset + (p.inumel + 63) / 64 * 64);
     auto wt = [&](const std::string &name) -> const void * {
         for (auto &p : e->layout)
-            if (p.name == name) return (const void *)(e->wT.as<T>() + p.offset);
+            if (p.name == name) return (const void *)(e->wT.as<T>() + p.ioffset);
         return nullptr;
     };
     LL_TRY(e->g_dh.ensure((size_t)np * H * 4));
@@ -1662,7 +1684,7 @@ static int gin_backward_c_t(GinEngine *e, const int *rowptr_s, const int *dst_s,
     LL_TRY(e->g_dhead1.ensure((size_t)Gp * 4 * H * es));
     LL_TRY(e->g_dlog.ensure((size_t)Gp * kp * es));
     LL_TRY(e->g_slabs.ensure((size_t)HEAD_SPLITS * Gp * 4 * H * 4));
-    LL_TRY(e->g_dcs.ensure((size_t)Gp * cf.text_dim * 4));
+    LL_TRY(e->g_dcs.ensure((size_t)Gp * D * 4));
     const dim3 blk(256), w_n(n), w_g(G), wblk(64);
     auto ew = [](int64_t cnt) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((cnt + 255) / 256, 4096))); };
 
@@ -1675,7 +1697,7 @@ static int gin_backward_c_t(GinEngine *e, const int *rowptr_s, const int *dst_s,
     hipLaunchKernelGGL(sum_slabs_kernel, ew((int64_t)G * 4 * H), blk, 0, st, e->g_slabs.as<float>(), (int64_t)Gp * 4 * H, HEAD_SPLITS,
                        e->g_dhead1a.as<float>(), (int64_t)G * 4 * H);
     hipLaunchKernelGGL((ln_gelu_bwd_kernel<T>), w_g, wblk, 0, st, e->sv_head1.as<float>(), e->pf("decoder.1.weight"), e->pf("decoder.1.bias"),
-                       e->g_dhead1a.as<float>(), e->g_dhead1.as<T>(), G, 4 * H);
+                       e->g_dhead1a.as<float>(), e->g_dhead1.as<T>(), G, 4 * H, 4 * Ht);
     LL_LAUNCH_CHECK();
     LL_TRY(linear_launch(dt, e->g_dhead1.p, 4 * H, wt("decoder.0.weight"), 4 * H, nullptr, e->g_dpool.p, H, G, H, 4 * H, 0, 1, st));
     hipLaunchKernelGGL(gather_rows_kernel, ew((int64_t)n * H), blk, 0, st, e->g_dh.as<float>(), e->g_dpool.as<float>(), batch, n, H);
@@ -1688,7 +1710,7 @@ static int gin_backward_c_t(GinEngine *e, const int *rowptr_s, const int *dst_s,
         const float *mod = e->mod.as<float>() + (size_t)l * 3 * H;      // rows of pitch L * 3H (one GEMM over all layers' adapters)
         // tail: h = gate * act(LN0(z)(1+scale)+shift) + h_in
         hipLaunchKernelGGL((gin_post_bwd_kernel<T>), w_n, wblk, 0, st, e->sv_z[l].as<float>(), mod, L * 3 * H, batch, e->g_dh.as<float>(), e->g_dz.as<T>(),
-                           e->g_c3.as<float>(), n, H, last ? 0 : 1);
+                           e->g_c3.as<float>(), n, H, last ? 0 : 1, Ht);
         LL_LAUNCH_CHECK();
         for (int q = 0; q < 3; ++q) {   // d(shift | scale | gate)[g] = sum over the graph's nodes
             hipLaunchKernelGGL((segment_pool_kernel<float, false>), dim3(G, cdiv(H, 1024)), blk, 0, st, e->g_c3.as<float>() + (size_t)q * n * H, gptr,
@@ -1700,7 +1722,7 @@ static int gin_backward_c_t(GinEngine *e, const int *rowptr_s, const int *dst_s,
         // MLP: z = GELU(LN(z0 W0^T + b0)) W4^T + b4
         LL_TRY(linear_launch(dt, e->g_dz.p, H, wt(p + "mlp.4.weight"), H, nullptr, e->g_dt1a.p, 4 * H, n, 4 * H, H, 0, 1, st));
         hipLaunchKernelGGL((ln_gelu_bwd_kernel<T>), w_n, wblk, 0, st, e->sv_t1[l].as<float>(), e->pf(p + "mlp.1.weight"), e->pf(p + "mlp.1.bias"),
-                           e->g_dt1a.as<float>(), e->g_dt1.as<T>(), n, 4 * H);
+                           e->g_dt1a.as<float>(), e->g_dt1.as<T>(), n, 4 * H, 4 * Ht);
         LL_LAUNCH_CHECK();
         LL_TRY(linear_launch(dt, e->g_dt1.p, 4 * H, wt(p + "mlp.0.weight"), 4 * H, nullptr, e->g_dz0.p, H, n, H, 4 * H, 0, 1, st));
         // aggregation: z0 = (1+eps) h_in + sum GELU(h_in[src] + bond)
@@ -1713,7 +1735,7 @@ static int gin_backward_c_t(GinEngine *e, const int *rowptr_s, const int *dst_s,
             LL_LAUNCH_CHECK();
             LL_TRY(linear_launch(dt, e->g_dvna.p, H, wt(q + "4.weight"), H, nullptr, e->g_dvt1a.p, 4 * H, G, 4 * H, H, 0, 1, st));
             hipLaunchKernelGGL((ln_gelu_bwd_kernel<T>), w_g, wblk, 0, st, e->sv_t1[l].as<float>() + (size_t)round_up(n, 64) * 4 * H, e->pf(q + "1.weight"), e->pf(q + "1.bias"),
-                               e->g_dvt1a.as<float>(), e->g_dvt1.as<T>(), G, 4 * H);
+                               e->g_dvt1a.as<float>(), e->g_dvt1.as<T>(), G, 4 * H, 4 * Ht);
             LL_LAUNCH_CHECK();
             LL_TRY(linear_launch(dt, e->g_dvt1.p, 4 * H, wt(q + "0.weight"), 4 * H, nullptr, e->g_dpool.p, H, G, H, 4 * H, 0, 1, st));
             hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(G, cdiv(H, 256)), blk, 0, st, e->sv_hin[l].as<float>(), gptr, e->g_dpool.as<float>(), e->g_dh.as<float>(), H);
@@ -1727,8 +1749,8 @@ static int gin_backward_c_t(GinEngine *e, const int *rowptr_s, const int *dst_s,
         }
     }
     // ---- (shift, scale, gate)_l = Linear_l(SiLU(c)): one GEMM over the K-concatenated adapters, then SiLU'
-    LL_TRY(linear_launch(dt, e->g_dmoda.p, L * 3 * H, e->adT.p, L * 3 * H, nullptr, e->g_dcs.p, cf.text_dim, G, cf.text_dim, L * 3 * H, 0, 1, st));
-    hipLaunchKernelGGL(silu_bwd_kernel, ew((int64_t)G * cf.text_dim), blk, 0, st, c, e->g_dcs.as<float>(), dc, (int64_t)G * cf.text_dim);
+    LL_TRY(linear_launch(dt, e->g_dmoda.p, L * 3 * H, e->adT.p, L * 3 * H, nullptr, e->g_dcs.p, D, G, D, L * 3 * H, 0, 1, st));
+    hipLaunchKernelGGL(silu_bwd_kernel, ew((int64_t)G * cf.text_dim), blk, 0, st, c, e->g_dcs.as<float>(), dc, G, cf.text_dim, D);
     LL_LAUNCH_CHECK();
     return LL_OK;
 }
@@ -1770,29 +1792,49 @@ int ll_gin_create(const LLGinConfig *cfg, const float *d_weights_f32, void **han
     GinEngine *e = new GinEngine();
     e->cfg = *cfg;
     e->layout = gin_layout(*cfg);
+    e->d = gin_dims(*cfg);
     e->w32 = d_weights_f32;
     e->sv_hin.resize(cfg->num_layer);
     e->sv_t1.resize(cfg->num_layer);
     e->sv_z.resize(cfg->num_layer);
-    if (cfg->dtype == LL_BF16) {
-        const int64_t elems = ll_gin_arena_elems(cfg);
-        int rc = e->wop.ensure((size_t)elems * 2);
-        if (rc == LL_OK) rc = convert_f32_to_bf16(d_weights_f32, e->wop.as<bf16_t>(), elems, 0);
+    const int64_t elems = e->layout.back().ioffset + (e->layout.back().inumel + 63) / 64 * 64;
+    if (e->d.padded) {      // the checkpoint's tensors into the zero-padded internal arena
+        int rc = e->wpad.ensure((size_t)elems * 4);
+        if (rc == LL_OK && hipMemset(e->wpad.p, 0, (size_t)elems * 4) != hipSuccess) { set_error("ll_gin_create: hipMemset failed"); rc = LL_EHIP; }
+        for (size_t i = 0; i < e->layout.size() && rc == LL_OK; ++i) {
+            const GinParam &pi = e->layout[i];
+            const PadMap &m = pi.map;
+            const int R = pi.rows, Cc = pi.cols;
+            hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)std::min<int64_t>((pi.numel + 255) / 256, 4096)), dim3(256), 0, 0,
+                               d_weights_f32 + pi.offset, e->wpad.as<float>() + pi.ioffset, R, Cc, pi.icols, m.rg2 ? m.rg2 : R, m.rgp2 ? m.rgp2 : R,
+                               m.rg ? m.rg : R, m.rgp ? m.rgp : R, m.cg ? m.cg : Cc, m.cgp ? m.cgp : Cc);
+        }
+        if (rc == LL_OK && (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess)) { set_error("ll_gin_create: padding the weights failed"); rc = LL_EHIP; }
         if (rc != LL_OK) {
-            delete e;
+            ll_gin_destroy(e);
+            return rc;
+        }
+        e->w32 = e->wpad.as<float>();
+    }
+    if (cfg->dtype == LL_BF16) {
+        int rc = e->wop.ensure((size_t)elems * 2);
+        if (rc == LL_OK) rc = convert_f32_to_bf16(e->w32, e->wop.as<bf16_t>(), elems, 0);
+        if (rc != LL_OK) {
+            ll_gin_destroy(e);
             return rc;
         }
     }
     e->cache_params();
     if (cfg->kind == 1) {      // the L adapter Linears as one [L * 3H, text_dim] weight (+ bias): their slots are not adjacent in the arena
         const int L = cfg->num_layer, es = cfg->dtype == LL_BF16 ? 2 : 4;
-        const size_t per = (size_t)3 * cfg->hidden * cfg->text_dim;
+        const int Hp = e->d.Hp;
+        const size_t per = (size_t)3 * Hp * e->d.Dp;
         int rc = e->adcat.ensure(per * L * es);
-        if (rc == LL_OK) rc = e->adbcat.ensure((size_t)L * 3 * cfg->hidden * 4);
+        if (rc == LL_OK) rc = e->adbcat.ensure((size_t)L * 3 * Hp * 4);
         for (int l = 0; l < L && rc == LL_OK; ++l) {
             const std::string p = "adapters." + std::to_string(l) + ".1.";
             if (hipMemcpy((char *)e->adcat.p + per * l * es, e->pw(p + "weight"), per * es, hipMemcpyDeviceToDevice) != hipSuccess ||
-                hipMemcpy(e->adbcat.as<float>() + (size_t)l * 3 * cfg->hidden, e->pf(p + "bias"), (size_t)3 * cfg->hidden * 4,
+                hipMemcpy(e->adbcat.as<float>() + (size_t)l * 3 * Hp, e->pf(p + "bias"), (size_t)3 * Hp * 4,
                           hipMemcpyDeviceToDevice) != hipSuccess) {
                 set_error("ll_gin_create: copying the adapter weights failed");
                 rc = LL_EHIP;
@@ -1815,7 +1857,7 @@ int ll_gin_destroy(void *handle) {
     GinEngine *e = (GinEngine *)handle;
     if (!e) return LL_OK;
     (void)hipDeviceSynchronize();
-    GBuf *bufs[] = {&e->ell, &e->wop, &e->adcat, &e->adbcat, &e->h, &e->h_in, &e->a0, &e->t1, &e->t1a, &e->zs, &e->vn, &e->pool32, &e->poola,
+    GBuf *bufs[] = {&e->ell, &e->wpad, &e->wop, &e->adcat, &e->adbcat, &e->h, &e->h_in, &e->a0, &e->t1, &e->t1a, &e->zs, &e->vn, &e->pool32, &e->poola,
                     &e->mod, &e->csilu, &e->head1, &e->head1a, &e->head2};
     for (GBuf *b : bufs) b->release();
     GBuf *tb[] = {&e->sv_head1, &e->wT, &e->adT, &e->g_dh, &e->g_dz, &e->g_dt1a, &e->g_dt1, &e->g_dz0, &e->g_c3, &e->g_dmod, &e->g_dmoda,

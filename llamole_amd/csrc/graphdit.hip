@@ -35,76 +35,116 @@ void set_error(const char *fmt, ...) {
     g_err = buf;
 }
 
+// ------------------------------------------------------------------------------------------ widths
+// The reference classes take any sizes (transformer.py:24-37: hidden_size, num_heads, mlp_ratio come from the checkpoint's config.yaml).
+// The kernels want row pitches that are multiples of 64 and a head pitch that is a multiple of the MFMA k-step, so the engine keeps an
+// INTERNAL copy of the weights zero-padded to such pitches whenever the checkpoint's widths are not already of that form:
+//   Hp  = hidden rounded up to 64                    (residual stream, every H-wide vector and weight dimension)
+//   Hmp = mlp_hidden rounded up to 64
+//   hdp = head_dim rounded up to 32, Ha = heads * hdp rounded up to 64   (q | k | v sections of a qkv row, attention output, K of proj)
+// Zero weight rows / columns, zero biases and zero LayerNorm affine parameters make every padded column of every activation an exact
+// zero (GELU(0) = SiLU(0) = Softsign(0) = 0: zero gates keep the residual stream's padding zero); the only places the true width
+// matters are the row statistics -- LayerNorm over hidden / head_dim columns, the Softmax(dim=1) of ConditionEmbedder (conditions.py:68)
+// and the attention scale 1 / sqrt(head_dim) -- and those kernels take it as an argument.  The public arena layout
+// (ll_dit_param_info) is the checkpoint's own: callers never see the padding.
+struct DitDims {
+    int Ht, Hp, Hmt, Hmp, hd, hdp, Ha;
+    bool padded;
+};
+static DitDims dit_dims(const LLDitConfig &c) {
+    DitDims d;
+    d.Ht = c.hidden; d.Hp = round_up(c.hidden, 64);
+    d.Hmt = c.mlp_hidden; d.Hmp = round_up(c.mlp_hidden, 64);
+    d.hd = c.hidden / c.heads; d.hdp = round_up(d.hd, 32);
+    d.Ha = round_up(c.heads * d.hdp, 64);
+    d.padded = d.Hp != d.Ht || d.Hmp != d.Hmt || d.hdp != d.hd || d.Ha != d.Ht;
+    return d;
+}
+
 // ------------------------------------------------------------------------------------------ parameter layout
 struct ParamInfo {
     std::string name;
-    int64_t numel;
-    int64_t offset;
+    int64_t numel;   // checkpoint tensor
+    int64_t offset;  // in the caller's arena (f32 elements)
     int rows, cols;  // cols == 0 for vectors
+    int64_t inumel, ioffset;   // internal (padded) tensor and its offset in the engine's arena; == numel / offset when nothing is padded
+    int irows, icols;
+    PadMap map;
 };
 
 static std::vector<ParamInfo> dit_layout(const LLDitConfig &c) {
     std::vector<ParamInfo> v;
-    int64_t off = 0;
-    auto add = [&](const std::string &n, int r, int cc) {
-        const int64_t ne = (int64_t)r * (cc ? cc : 1);
-        v.push_back({n, ne, off, r, cc});
+    int64_t off = 0, ioff = 0;
+    const DitDims d = dit_dims(c);
+    // (r, cc): checkpoint shape; (ir, ic): internal shape; vectors: cc = ic = 0
+    auto add = [&](const std::string &n, int r, int cc, int ir, int ic, PadMap m = PadMap()) {
+        const int64_t ne = (int64_t)r * (cc ? cc : 1), ine = (int64_t)ir * (ic ? ic : 1);
+        v.push_back({n, ne, off, r, cc, ine, ioff, ir, ic, m});
         off += (ne + 63) / 64 * 64;  // 256-B aligned slots
+        ioff += (ine + 63) / 64 * 64;
     };
-    const int H = c.hidden, F = LL_XDIM + LL_EDIM * c.max_nodes, Hm = c.mlp_hidden, hd = c.hidden / c.heads;
-    add("x_embedder.0.weight", H, F);
-    add("x_embedder.1.weight", H, 0);
-    add("x_embedder.1.bias", H, 0);
-    add("t_embedder.mlp.0.weight", H, 256);
-    add("t_embedder.mlp.0.bias", H, 0);
-    add("t_embedder.mlp.2.weight", H, H);
-    add("t_embedder.mlp.2.bias", H, 0);
-    add("y_embedder.embedding_drop.weight", LL_YDIM, H);
-    for (int d = 0; d < LL_YDIM; ++d) {
-        const std::string p = "y_embedder.mlps." + std::to_string(d) + ".";
-        add(p + "0.weight", H, 1);
-        add(p + "0.bias", H, 0);
-        add(p + "2.weight", H, H);
+    const int H = d.Ht, Hp = d.Hp, F = LL_XDIM + LL_EDIM * c.max_nodes, Hm = d.Hmt, Hmp = d.Hmp, hd = d.hd, hdp = d.hdp, Ha = d.Ha;
+    auto vecH = [&](const std::string &n) { add(n, H, 0, Hp, 0); };
+    auto matHH = [&](const std::string &n) { add(n, H, H, Hp, Hp); };
+    PadMap rows6;  rows6.rg = H; rows6.rgp = Hp;                                         // k chunks of H rows -> chunks of Hp rows
+    PadMap qkvm;   qkvm.rg2 = H; qkvm.rgp2 = Ha; qkvm.rg = hd; qkvm.rgp = hdp;          // (section, head, d) -> section * Ha + head * hdp + d
+    PadMap projm;  projm.cg = hd; projm.cgp = hdp;                                       // columns (head, d) -> head * hdp + d
+    add("x_embedder.0.weight", H, F, Hp, F);
+    vecH("x_embedder.1.weight");
+    vecH("x_embedder.1.bias");
+    add("t_embedder.mlp.0.weight", H, 256, Hp, 256);
+    vecH("t_embedder.mlp.0.bias");
+    matHH("t_embedder.mlp.2.weight");
+    vecH("t_embedder.mlp.2.bias");
+    add("y_embedder.embedding_drop.weight", LL_YDIM, H, LL_YDIM, Hp);
+    for (int i = 0; i < LL_YDIM; ++i) {
+        const std::string p = "y_embedder.mlps." + std::to_string(i) + ".";
+        add(p + "0.weight", H, 1, Hp, 1);
+        vecH(p + "0.bias");
+        matHH(p + "2.weight");
     }
-    add("txt_embedder.embedding_drop.weight", 1, H);
-    add("txt_embedder.linear.weight", H, LL_TEXT_DIM);
-    add("txt_embedder.linear.bias", H, 0);
+    add("txt_embedder.embedding_drop.weight", 1, H, 1, Hp);
+    add("txt_embedder.linear.weight", H, LL_TEXT_DIM, Hp, LL_TEXT_DIM);
+    vecH("txt_embedder.linear.bias");
     for (int i = 0; i < c.depth; ++i) {
         const std::string p = "blocks." + std::to_string(i) + ".";
-        add(p + "attn.qkv.weight", 3 * H, H);
-        add(p + "attn.q_norm.weight", hd, 0);
-        add(p + "attn.q_norm.bias", hd, 0);
-        add(p + "attn.k_norm.weight", hd, 0);
-        add(p + "attn.k_norm.bias", hd, 0);
-        add(p + "attn.proj.weight", H, H);
-        add(p + "attn.proj.bias", H, 0);
-        add(p + "mlp.fc1.weight", Hm, H);
-        add(p + "mlp.fc1.bias", Hm, 0);
-        add(p + "mlp.fc2.weight", H, Hm);
-        add(p + "mlp.fc2.bias", H, 0);
-        add(p + "adaLN_modulation.0.weight", H, H);
-        add(p + "adaLN_modulation.0.bias", H, 0);
-        add(p + "adaLN_modulation.2.weight", 6 * H, H);
-        add(p + "adaLN_modulation.2.bias", 6 * H, 0);
+        add(p + "attn.qkv.weight", 3 * H, H, 3 * Ha, Hp, qkvm);
+        add(p + "attn.q_norm.weight", hd, 0, hdp, 0);
+        add(p + "attn.q_norm.bias", hd, 0, hdp, 0);
+        add(p + "attn.k_norm.weight", hd, 0, hdp, 0);
+        add(p + "attn.k_norm.bias", hd, 0, hdp, 0);
+        add(p + "attn.proj.weight", H, H, Hp, Ha, projm);
+        vecH(p + "attn.proj.bias");
+        add(p + "mlp.fc1.weight", Hm, H, Hmp, Hp);
+        add(p + "mlp.fc1.bias", Hm, 0, Hmp, 0);
+        add(p + "mlp.fc2.weight", H, Hm, Hp, Hmp);
+        vecH(p + "mlp.fc2.bias");
+        matHH(p + "adaLN_modulation.0.weight");
+        vecH(p + "adaLN_modulation.0.bias");
+        add(p + "adaLN_modulation.2.weight", 6 * H, H, 6 * Hp, Hp, rows6);
+        add(p + "adaLN_modulation.2.bias", 6 * H, 0, 6 * Hp, 0, rows6);
     }
-    add("output_layer.xedecoder.fc1.weight", H, H);
-    add("output_layer.xedecoder.fc1.bias", H, 0);
-    add("output_layer.xedecoder.fc2.weight", F, H);
-    add("output_layer.xedecoder.fc2.bias", F, 0);
-    add("output_layer.adaLN_modulation.0.weight", H, H);
-    add("output_layer.adaLN_modulation.0.bias", H, 0);
-    add("output_layer.adaLN_modulation.2.weight", 2 * F, H);
-    add("output_layer.adaLN_modulation.2.bias", 2 * F, 0);
+    matHH("output_layer.xedecoder.fc1.weight");
+    vecH("output_layer.xedecoder.fc1.bias");
+    add("output_layer.xedecoder.fc2.weight", F, H, F, Hp);
+    add("output_layer.xedecoder.fc2.bias", F, 0, F, 0);
+    matHH("output_layer.adaLN_modulation.0.weight");
+    vecH("output_layer.adaLN_modulation.0.bias");
+    add("output_layer.adaLN_modulation.2.weight", 2 * F, H, 2 * F, Hp);
+    add("output_layer.adaLN_modulation.2.bias", 2 * F, 0, 2 * F, 0);
     return v;
 }
 
+// max_nodes <= 64 is the one bound the reference does not have (one 64-lane wave = one row of bond partners in the posterior, one
+// 64-row tile in the attention); hidden <= 2048 and head_dim <= 128 bound the per-row register / LDS footprints of the row kernels.
+// The Python wrapper reports all three as ValueError naming the limit (graph_decoder.py).
 static int check_cfg(const LLDitConfig *c) {
     LL_CHECK(c != nullptr, "config is null");
-    LL_CHECK(c->hidden >= 64 && c->hidden % 64 == 0 && c->hidden <= 2048, "hidden=%d must be a multiple of 64 in [64,2048]", c->hidden);
+    LL_CHECK(c->hidden >= 1 && c->hidden <= 2048, "hidden=%d must be in [1,2048]", c->hidden);
     LL_CHECK(c->heads > 0 && c->hidden % c->heads == 0, "hidden %d not divisible by heads %d", c->hidden, c->heads);
     LL_CHECK(c->hidden / c->heads <= 128, "head_dim %d > 128 unsupported", c->hidden / c->heads);
-    LL_CHECK(c->mlp_hidden >= 64 && c->mlp_hidden % 64 == 0, "mlp_hidden=%d must be a multiple of 64", c->mlp_hidden);
-    LL_CHECK(c->max_nodes >= 2 && c->max_nodes <= 64, "max_nodes=%d must be in [2,64]", c->max_nodes);
+    LL_CHECK(c->mlp_hidden >= 1 && c->mlp_hidden <= 16384, "mlp_hidden=%d must be in [1,16384]", c->mlp_hidden);
+    LL_CHECK(c->max_nodes >= 1 && c->max_nodes <= 64, "max_nodes=%d must be in [1,64]", c->max_nodes);
     LL_CHECK(c->depth >= 1 && c->T >= 1, "depth/T must be positive");
     LL_CHECK(c->dtype == LL_F32 || c->dtype == LL_BF16, "unknown dtype %d", c->dtype);
     return LL_OK;
@@ -148,10 +188,13 @@ struct DevBuf {
 
 struct DitEngine {
     LLDitConfig cfg;
+    DitDims d;                   // checkpoint widths and the engine's padded pitches
     std::vector<ParamInfo> layout;
     int F, hd, esz;  // esz = operand element size
     // weights
-    const float *w32 = nullptr;  // caller-owned f32 master arena (kept alive by the Python wrapper)
+    const float *w32 = nullptr;  // f32 master arena in the INTERNAL layout: the caller's arena itself (kept alive by the Python wrapper) when no
+                                 // width needs padding, else `wpad`
+    DevBuf wpad;                 // zero-padded f32 copy of the caller's arena (only when d.padded)
     DevBuf wop;                  // operand-dtype copy of the arena (bf16 mode)
     DevBuf wxT;                  // x_embedder weight transposed [F][H] f32
     DevBuf wycat;                // [H][10H] operand dtype
@@ -216,14 +259,14 @@ struct DitEngine {
     }
     const float *pfs(const std::string &name) const {
         auto it = index.find(name);
-        return it == index.end() ? nullptr : w32 + layout[it->second].offset;
+        return it == index.end() ? nullptr : w32 + layout[it->second].ioffset;
     }
     const float *pf(const char *name) const { return pfs(std::string(name)); }
     const void *pw(const std::string &name) const {  // operand-dtype weight
         auto it = index.find(name);
         if (it == index.end()) return nullptr;
         const auto &p = layout[it->second];
-        return cfg.dtype == LL_BF16 ? (const void *)(wop.as<bf16_t>() + p.offset) : (const void *)(w32 + p.offset);
+        return cfg.dtype == LL_BF16 ? (const void *)(wop.as<bf16_t>() + p.ioffset) : (const void *)(w32 + p.ioffset);
     }
     // the block's parameters the per-step loop needs, resolved once (the loop launches ~200 kernels per millisecond: no string work there)
     struct BlockW {
@@ -292,7 +335,7 @@ static void drop_graph(DitEngine *e) {
 template <typename T> static void launch_embed(DitEngine *e, hipStream_t st) {
     hipLaunchKernelGGL((embed_kernel<T>), dim3(e->B * e->cfg.max_nodes), dim3(256), 0, st, e->X.as<int8_t>(),
                        e->E.as<int8_t>(), e->wxT.as<float>(), e->xe_w, e->xe_b,
-                       e->x32.as<float>(), e->xa.as<T>(), e->step_ptr(), e->B, e->cfg.max_nodes, e->cfg.hidden);
+                       e->x32.as<float>(), e->xa.as<T>(), e->step_ptr(), e->B, e->cfg.max_nodes, e->d.Hp, e->d.Ht);
 }
 static int g_attn_waves = 4;     // waves per (sequence, head) of attn_mfma_kernel (1 | 2 | 4; four only at head dimension 64)
 static int g_fuse_qkv_pair_wgs = 320, g_fuse_qkv_pair_max_wgs = 768;   // between these many (sequence, head) pairs two sequences share a workgroup (batch 11..24 at 16 heads)
@@ -304,27 +347,29 @@ static void launch_attn_mfma_t(DitEngine *e, const DitEngine::BlockW &w, hipStre
     hipLaunchKernelGGL((attn_mfma_kernel<NP, HD, W>), dim3(e->cfg.heads, 2 * e->B), dim3(64 * W), (attn_mfma_lds_bytes<NP, HD, W>()), st, \
                        e->qkv.as<bf16_t>(), e->attn_o.as<bf16_t>(), w.qn_w, w.qn_b,                                            \
                        w.kn_w, w.kn_b, e->n_nodes.as<int>(), e->B, e->cfg.max_nodes,                                           \
-                       e->cfg.hidden, e->cfg.heads)
+                       e->d.Ha, e->cfg.heads, e->d.hd)
     if (g_attn_waves == 4 && HD == 64) LL_ATTN((HD == 64 ? 4 : 2));      // LayerNorm / transpose rows on four waves (eight rows each per pass)
     else if (g_attn_waves >= 2) LL_ATTN(2);
     else LL_ATTN(1);
 #undef LL_ATTN
 }
 template <typename T> static void launch_attn(DitEngine *e, int layer, hipStream_t st) {
-    const int N = e->cfg.max_nodes, hd = e->hd;
+    const int N = e->cfg.max_nodes, hd = e->d.hd, hdp = e->d.hdp;
     const DitEngine::BlockW &w = e->bw[layer];
-    if (sizeof(T) == 2 && (hd == 32 || hd == 64) && !e->force_generic_attn) {
+    if (sizeof(T) == 2 && !e->force_generic_attn) {      // bf16: the MFMA kernel at head pitch 32 | 64 | 96 | 128 (any head_dim <= 128)
         const int NP = N <= 32 ? 32 : 64;
-        if (NP == 32 && hd == 32) launch_attn_mfma_t<32, 32>(e, w, st);
-        else if (NP == 32 && hd == 64) launch_attn_mfma_t<32, 64>(e, w, st);
-        else if (NP == 64 && hd == 32) launch_attn_mfma_t<64, 32>(e, w, st);
-        else launch_attn_mfma_t<64, 64>(e, w, st);
+#define LL_ATTN_HD(HD) do { if (NP == 32) launch_attn_mfma_t<32, HD>(e, w, st); else launch_attn_mfma_t<64, HD>(e, w, st); } while (0)
+        if (hdp == 32) LL_ATTN_HD(32);
+        else if (hdp == 64) LL_ATTN_HD(64);
+        else if (hdp == 96) LL_ATTN_HD(96);
+        else LL_ATTN_HD(128);
+#undef LL_ATTN_HD
         return;
     }
     const size_t lds = (size_t)(3 * N * (hd + 1) + N * (N + 1)) * 4;
     hipLaunchKernelGGL((attn_generic_kernel<T>), dim3(e->cfg.heads, 2 * e->B), dim3(256), lds, st, e->qkv.as<T>(),
                        e->attn_o.as<T>(), w.qn_w, w.qn_b, w.kn_w, w.kn_b, e->n_nodes.as<int>(), e->B, N,
-                       e->cfg.hidden, hd);
+                       e->d.Ha, hd, hdp);
 }
 // q|k|v projection + attention of block `layer` as ONE launch (qkv_attn_kernel); false = not eligible, run the two launches
 static bool qkv_attn_eligible(const DitEngine *e) {
@@ -361,7 +406,7 @@ static bool qkv_attn_wanted(const DitEngine *e) { return qkv_attn_mode(e) != 0; 
 // MLP of the block on the packed-weight panel GEMM (gemm.hip gemm_xw_kernel): fc1 with K = H in one slice, fc2 split over K
 static int xw_slice(int K) { return K % 1024 == 0 ? 1024 : 512; }
 static bool xw_eligible(const DitEngine *e) {
-    const int H = e->cfg.hidden, Hm = e->cfg.mlp_hidden;
+    const int H = e->d.Hp, Hm = e->d.Hmp;
     if (e->cfg.dtype != LL_BF16 || (H != 512 && H != 1024) || Hm % 512 != 0) return false;
     const int sp = Hm / xw_slice(Hm);
     return (sp == 1 || sp == 2 || sp == 4 || sp == 8) && Hm % 128 == 0 && H % 128 == 0;
@@ -404,11 +449,12 @@ static int g_lnmod_multiwave = 1;     // one wave per 256-column chunk of a row 
 template <typename T>
 static void launch_lnmod(DitEngine *e, int layer, int sel, int nslab, const float *bias, hipStream_t st) {
     const dim3 grid(e->M2), blk(64);
-    const int64_t ss = (int64_t)e->M2p * e->cfg.hidden;
+    const int H = e->d.Hp;      // row pitch; the kernels take the checkpoint's width for the statistics
+    const int64_t ss = (int64_t)e->M2p * H;
     // the step's modulation rows at an address known at launch time: the slice of the hoisted table itself when the host knows the step
     // (ll_dit_run launching), else the copy stage_mod_kernel made (denoise_body)
     const float *mc = e->rowvec != nullptr ? nullptr
-                      : e->step_host >= 0  ? e->modtab.as<float>() + (int64_t)e->step_host * (e->B + 1) * e->cfg.depth * 6 * e->cfg.hidden
+                      : e->step_host >= 0  ? e->modtab.as<float>() + (int64_t)e->step_host * (e->B + 1) * e->cfg.depth * 6 * H
                       : g_stage_mod        ? e->modcur.as<float>()
                                            : nullptr;
 #define LL_LNMOD2(NS, ME)                                                                                              \
@@ -416,17 +462,17 @@ static void launch_lnmod(DitEngine *e, int layer, int sel, int nslab, const floa
         if (ME > 1 && g_lnmod_multiwave)                                                                               \
             hipLaunchKernelGGL((ln_mod_res_mw_kernel<T, NS, ME>), grid, dim3(64 * ME), 0, st, e->ybuf.as<float>(), ss, bias, \
                                e->x32.as<float>(), e->xa.as<T>(), e->modtab.as<float>(), e->step_ptr(), e->rowvec, mc, layer, sel, \
-                               e->B, e->cfg.max_nodes, e->cfg.hidden, e->cfg.depth, e->M2);                            \
+                               e->B, e->cfg.max_nodes, H, e->cfg.depth, e->M2, e->d.Ht);                               \
         else                                                                                                           \
             hipLaunchKernelGGL((ln_mod_res_kernel<T, NS, ME>), grid, blk, 0, st, e->ybuf.as<float>(), ss, bias,         \
                                e->x32.as<float>(), e->xa.as<T>(), e->modtab.as<float>(), e->step_ptr(), e->rowvec, mc, layer, sel, \
-                               e->B, e->cfg.max_nodes, e->cfg.hidden, e->cfg.depth, e->M2);                            \
+                               e->B, e->cfg.max_nodes, H, e->cfg.depth, e->M2, e->d.Ht);                               \
     } while (0)
 #define LL_LNMOD(NS)                                                                                                   \
     do {                                                                                                               \
-        if (e->cfg.hidden <= 256) LL_LNMOD2(NS, 1);                                                                    \
-        else if (e->cfg.hidden <= 512) LL_LNMOD2(NS, 2);                                                               \
-        else if (e->cfg.hidden <= 1024) LL_LNMOD2(NS, 4);                                                              \
+        if (H <= 256) LL_LNMOD2(NS, 1);                                                                                \
+        else if (H <= 512) LL_LNMOD2(NS, 2);                                                                           \
+        else if (H <= 1024) LL_LNMOD2(NS, 4);                                                                          \
         else LL_LNMOD2(NS, 8);                                                                                         \
     } while (0)
     switch (nslab) {
@@ -580,7 +626,7 @@ static int team_check(DitEngine *e) {
 // denoiser on the current state for both passes -> e->outF [2][B][N][F] (decoder output before LN0/modulate)
 static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap_layer) {
     const LLDitConfig &c = e->cfg;
-    const int H = c.hidden, Hm = c.mlp_hidden, M2 = e->M2, dt = c.dtype;
+    const int H = e->d.Hp, Hm = e->d.Hmp, Ha = e->d.Ha, M2 = e->M2, dt = c.dtype;      // row pitches (multiples of 64)
     const bool bf = dt == LL_BF16;
     e->team_last = 0;
     if (e->team_step_s >= 0 && hidden_tap == nullptr && team_wanted(e, false)) {    // parity taps of the team path: one step, posterior by the launch chain's kernels
@@ -595,7 +641,7 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
     if (bf) launch_embed<bf16_t>(e, st); else launch_embed<float>(e, st);
     LL_LAUNCH_CHECK();
     if (hidden_tap && tap_layer == 0)
-        LL_HIP(hipMemcpyAsync(hidden_tap, e->x32.p, (size_t)M2 * H * 4, hipMemcpyDeviceToDevice, st));
+        LL_HIP(hipMemcpy2DAsync(hidden_tap, (size_t)e->d.Ht * 4, e->x32.p, (size_t)H * 4, (size_t)e->d.Ht * 4, M2, hipMemcpyDeviceToDevice, st));
     const int64_t slab = (int64_t)e->M2p * H;
     const bool fused_qkv = qkv_attn_wanted(e), xw = xw_fc1_wanted(e), xw2 = xw_fc2_wanted(e);
     // (captured steps read the step's modulation rows from the staged copy, which exists only with g_stage_mod)
@@ -608,7 +654,7 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
         } else {
             {
                 ClassTimer tm(e, LL_DIT_CLS_QKV, st);
-                LL_TRY(linear_launch(dt, e->xa.p, H, w.qkv, H, nullptr, e->qkv.p, 3 * H, M2, 3 * H, H, 0, 0, st));
+                LL_TRY(linear_launch(dt, e->xa.p, H, w.qkv, H, nullptr, e->qkv.p, 3 * Ha, M2, 3 * Ha, H, 0, 0, st));
             }
             ClassTimer tm(e, LL_DIT_CLS_ATTN, st);
             if (bf) launch_attn<bf16_t>(e, l, st); else launch_attn<float>(e, l, st);
@@ -623,9 +669,9 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
         } else {
             ClassTimer tm(e, LL_DIT_CLS_PROJ, st);
             if (e->splits_h > 1)
-                LL_TRY(linear_splitk_launch(dt, e->attn_o.p, H, w.proj, H, e->ybuf.as<float>(), H, slab, M2, H, H, e->splits_h, st));
+                LL_TRY(linear_splitk_launch(dt, e->attn_o.p, Ha, w.proj, Ha, e->ybuf.as<float>(), H, slab, M2, H, Ha, e->splits_h, st));
             else
-                LL_TRY(linear_launch(dt, e->attn_o.p, H, w.proj, H, nullptr, e->ybuf.p, H, M2, H, H, 0, 1, st));
+                LL_TRY(linear_launch(dt, e->attn_o.p, Ha, w.proj, Ha, nullptr, e->ybuf.p, H, M2, H, Ha, 0, 1, st));
         }
         if (!use_proj_ln) {
             ClassTimer tm(e, LL_DIT_CLS_LNMOD, st);
@@ -661,7 +707,7 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
         }
         LL_LAUNCH_CHECK();
         if (hidden_tap && tap_layer == l + 1)
-            LL_HIP(hipMemcpyAsync(hidden_tap, e->x32.p, (size_t)M2 * H * 4, hipMemcpyDeviceToDevice, st));
+            LL_HIP(hipMemcpy2DAsync(hidden_tap, (size_t)e->d.Ht * 4, e->x32.p, (size_t)H * 4, (size_t)e->d.Ht * 4, M2, hipMemcpyDeviceToDevice, st));
     }
     LL_TRY(linear_launch(dt, e->xa.p, H, e->w_out1, H, e->b_out1, e->ho.p, H, M2, H, H, 1, 0, st));
     LL_TRY(linear_launch(dt, e->ho.p, H, e->w_out2, H, e->b_out2, e->outF.p, e->F, M2, e->F, H, 0, 1, st));
@@ -750,17 +796,34 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
     e->layout = dit_layout(*cfg);
     e->index_params();
     e->F = LL_XDIM + LL_EDIM * cfg->max_nodes;
-    e->hd = cfg->hidden / cfg->heads;
+    e->d = dit_dims(*cfg);
+    e->hd = e->d.hd;
     e->esz = cfg->dtype == LL_BF16 ? 2 : 4;
-    e->w32 = d_weights_f32;
-    const int H = cfg->hidden, T = cfg->T;
-    const int64_t elems = ll_dit_arena_elems(cfg);
+    const int H = e->d.Hp, T = cfg->T;      // H: row pitch of every hidden-wide vector from here on
+    const int64_t elems = e->layout.back().ioffset + (e->layout.back().inumel + 63) / 64 * 64;
     auto fail = [&](int rc) { ll_dit_destroy(e); return rc; };
 #define CR(x) do { int rc_ = (x); if (rc_ != LL_OK) return fail(rc_); } while (0)
 #define CRH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(e_)); return fail(LL_EHIP); } } while (0)
+    if (e->d.padded) {
+        // the checkpoint's tensors into the zero-padded internal arena (rows / columns / heads spread out as their PadMap says)
+        CR(e->wpad.ensure((size_t)elems * 4));
+        CRH(hipMemset(e->wpad.p, 0, (size_t)elems * 4));
+        for (const ParamInfo &pi : e->layout) {
+            const int R = pi.rows, Cc = pi.cols ? pi.cols : 1, ldd = pi.icols ? pi.icols : 1;
+            const PadMap &m = pi.map;
+            hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)std::min<int64_t>((pi.numel + 255) / 256, 4096)), dim3(256), 0, 0,
+                               d_weights_f32 + pi.offset, e->wpad.as<float>() + pi.ioffset, R, Cc, ldd, m.rg2 ? m.rg2 : R, m.rgp2 ? m.rgp2 : R,
+                               m.rg ? m.rg : R, m.rgp ? m.rgp : R, m.cg ? m.cg : Cc, m.cgp ? m.cgp : Cc);
+        }
+        CRH(hipGetLastError());
+        CRH(hipDeviceSynchronize());
+        e->w32 = e->wpad.as<float>();
+    } else {
+        e->w32 = d_weights_f32;
+    }
     if (cfg->dtype == LL_BF16) {
         CR(e->wop.ensure((size_t)elems * 2));
-        CR(convert_f32_to_bf16(d_weights_f32, e->wop.as<bf16_t>(), elems, 0));
+        CR(convert_f32_to_bf16(e->w32, e->wop.as<bf16_t>(), elems, 0));
     }
     e->cache_block_params();          // after wop exists: pw() resolves into it
     // x_embedder weight transposed to [F][H] (gather-sum form)
@@ -838,10 +901,10 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
             CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw("blocks." + std::to_string(l) + ".attn.qkv.weight")),
                            e->wqkvp.as<bf16_t>() + per * l, 3 * H, H, 0));
     }
-    if (cfg->dtype == LL_BF16 && H % 32 == 0 && cfg->mlp_hidden % 32 == 0) {
+    if (cfg->dtype == LL_BF16) {
         // MFMA-operand-order copies of the MLP and proj weights: the batch-1 panel GEMM (gemm_m64_kernel) reads fragments from them
-        const int Hm = cfg->mlp_hidden;
-        const size_t per = (size_t)Hm * H, perh = (size_t)H * H;
+        const int Hm = e->d.Hmp, Ha = e->d.Ha;
+        const size_t per = (size_t)Hm * H, perh = (size_t)H * Ha, perh1 = (size_t)H * H;
         CR(e->wfc1p.ensure(per * cfg->depth * 2));
         CR(e->wfc2p.ensure(per * cfg->depth * 2));
         CR(e->wprojp.ensure(perh * cfg->depth * 2));
@@ -853,7 +916,7 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
             const std::string p = "blocks." + std::to_string(l) + ".";
             CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw(p + "mlp.fc1.weight")), e->wfc1p.as<bf16_t>() + per * l, Hm, H, 0));
             CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw(p + "mlp.fc2.weight")), e->wfc2p.as<bf16_t>() + per * l, H, Hm, 0));
-            CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw(p + "attn.proj.weight")), e->wprojp.as<bf16_t>() + perh * l, H, H, 0));
+            CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw(p + "attn.proj.weight")), e->wprojp.as<bf16_t>() + perh * l, H, Ha, 0));
             reg(p + "mlp.fc1.weight", e->wfc1p.as<bf16_t>() + per * l);
             reg(p + "mlp.fc2.weight", e->wfc2p.as<bf16_t>() + per * l);
             reg(p + "attn.proj.weight", e->wprojp.as<bf16_t>() + perh * l);
@@ -861,7 +924,7 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
         }
         if (xw_eligible(e)) e->splits_x = Hm / xw_slice(Hm);
         if (e->F % 16 == 0) {      // output layer in the same order: the persistent trajectory kernel streams it (dit_team.h)
-            CR(e->wout1p.ensure(perh * 2));
+            CR(e->wout1p.ensure(perh1 * 2));
             CR(e->wout2p.ensure((size_t)e->F * H * 2));
             CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw("output_layer.xedecoder.fc1.weight")), e->wout1p.as<bf16_t>(), H, H, 0));
             CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw("output_layer.xedecoder.fc2.weight")), e->wout2p.as<bf16_t>(), e->F, H, 0));
@@ -899,7 +962,7 @@ int ll_dit_destroy(void *handle) {
     DevBuf *bufs[] = {&e->wop, &e->wxT, &e->wycat, &e->yw0, &e->yb0, &e->tables, &e->n_nodes, &e->X, &e->E, &e->x32,
                       &e->xa, &e->qkv, &e->attn_o, &e->ybuf, &e->h1, &e->ho, &e->outF, &e->ct_in, &e->ct_h, &e->ct,
                       &e->zy, &e->cy, &e->txt_op, &e->ctxt, &e->ynan, &e->tnan, &e->c32, &e->ca, &e->m1, &e->modtab,
-                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wqkvp, &e->wfc1p, &e->wfc2p, &e->wprojp, &e->steps_tab, &e->wout1p, &e->wout2p, &e->team_ctl, &e->team_ctl2};
+                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wpad, &e->wqkvp, &e->wfc1p, &e->wfc2p, &e->wprojp, &e->steps_tab, &e->wout1p, &e->wout2p, &e->team_ctl, &e->team_ctl2};
     for (const void *k : e->packed_keys) register_packed_weight(k, nullptr);
     for (DevBuf *b : bufs) b->release();
     if (e->own) (void)hipStreamDestroy(e->own);
@@ -921,7 +984,7 @@ int ll_dit_destroy(void *handle) {
 // The activation buffers hold no state yet at this point (ll_dit_begin precedes ll_dit_init_state).
 static int calibrate_mlp(DitEngine *e, hipStream_t st) {
     const LLDitConfig &c = e->cfg;
-    const int H = c.hidden, Hm = c.mlp_hidden, M2 = e->M2, dt = c.dtype;
+    const int H = e->d.Hp, Hm = e->d.Hmp, M2 = e->M2, dt = c.dtype;
     e->xw_cal_B = e->B;
     e->xw_fc1_auto = e->xw_fc2_auto = false;
     if (e->xw_gemm != -1 || dt != LL_BF16 || e->wfc1p.p == nullptr || !xw_eligible(e) || M2 < 128) {
@@ -991,13 +1054,13 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
     LL_CHECK(B >= 1 && B <= 4096, "batch %d out of range", B);
     hipStream_t st = (hipStream_t)stream;
     const LLDitConfig &c = e->cfg;
-    const int H = c.hidden, Hm = c.mlp_hidden, N = c.max_nodes, T = c.T, L = c.depth, F = e->F, dt = c.dtype, es = e->esz;
+    const int H = e->d.Hp, Hm = e->d.Hmp, Ha = e->d.Ha, N = c.max_nodes, T = c.T, L = c.depth, F = e->F, dt = c.dtype, es = e->esz;
     const bool bf = dt == LL_BF16;
     if (B != e->B) drop_graph(e);
     e->B = B;
     e->M2 = 2 * B * N;
     e->M2p = round_up(e->M2, 128);
-    e->splits_h = pick_splits(e->M2, H, H);
+    e->splits_h = pick_splits(e->M2, H, Ha);
     e->splits_m = pick_splits(e->M2, H, Hm);
     // (the persistent trajectory kernel writes four K-part slabs for proj and fc2 at any batch)
     const int smax = std::max(std::max(std::max(e->splits_h, e->splits_m), e->splits_x), 4);
@@ -1012,8 +1075,10 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
     LL_TRY(e->pxe.ensure((size_t)2 * B * N * 8 * 4));
     LL_TRY(e->x32.ensure(M2p * H * 4));
     LL_TRY(e->xa.ensure(M2p * H * es));
-    LL_TRY(e->qkv.ensure(M2p * 3 * H * es));
-    LL_TRY(e->attn_o.ensure(M2p * H * es));
+    LL_TRY(e->qkv.ensure(M2p * 3 * Ha * es));
+    LL_TRY(e->attn_o.ensure(M2p * Ha * es));
+    // the generic attention kernel writes only the true head columns: the padded ones (zero columns of proj) must not hold NaN patterns
+    if (e->d.padded) LL_HIP(hipMemsetAsync(e->attn_o.p, 0, M2p * Ha * es, st));
     LL_TRY(e->ybuf.ensure((size_t)smax * M2p * H * 4));
     LL_TRY(e->h1.ensure(M2p * Hm * es));
     LL_TRY(e->ho.ensure(M2p * H * es));
@@ -1050,8 +1115,8 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
     LL_TRY(linear_launch(dt, e->ct_in.p, 256, e->pw("t_embedder.mlp.0.weight"), 256, e->pf("t_embedder.mlp.0.bias"), e->ct_h.p, H, T + 1, H, 256, 2, 0, st));
     LL_TRY(linear_launch(dt, e->ct_h.p, H, e->pw("t_embedder.mlp.2.weight"), H, e->pf("t_embedder.mlp.2.bias"), e->ct.p, H, T + 1, H, H, 0, 1, st));
     // ---- c_y: softmax features -> one GEMM over the K-concatenated property MLPs      (conditions.py:60-98)
-    if (bf) hipLaunchKernelGGL((yfeat_kernel<bf16_t>), dim3(B, LL_YDIM), dim3(256), 0, st, props, e->yw0.as<float>(), e->yb0.as<float>(), e->zy.as<bf16_t>(), e->ynan.as<int8_t>(), H);
-    else hipLaunchKernelGGL((yfeat_kernel<float>), dim3(B, LL_YDIM), dim3(256), 0, st, props, e->yw0.as<float>(), e->yb0.as<float>(), e->zy.as<float>(), e->ynan.as<int8_t>(), H);
+    if (bf) hipLaunchKernelGGL((yfeat_kernel<bf16_t>), dim3(B, LL_YDIM), dim3(256), 0, st, props, e->yw0.as<float>(), e->yb0.as<float>(), e->zy.as<bf16_t>(), e->ynan.as<int8_t>(), H, e->d.Ht);
+    else hipLaunchKernelGGL((yfeat_kernel<float>), dim3(B, LL_YDIM), dim3(256), 0, st, props, e->yw0.as<float>(), e->yb0.as<float>(), e->zy.as<float>(), e->ynan.as<int8_t>(), H, e->d.Ht);
     LL_LAUNCH_CHECK();
     LL_TRY(linear_launch(dt, e->zy.p, LL_YDIM * H, e->wycat.p, LL_YDIM * H, nullptr, e->cy.p, H, B, H, LL_YDIM * H, 0, 1, st));
     // ---- c_txt                                                                        (conditions.py:100-123)
@@ -1194,8 +1259,10 @@ int ll_dit_cvec(void *handle, int s, float *c, void *stream) {
     DitEngine *e = (DitEngine *)handle;
     LL_TRY(check_ready(e, false));
     LL_CHECK(s >= 0 && s < e->cfg.T && c, "bad argument");
-    const size_t row = (size_t)(e->B + 1) * e->cfg.hidden;
-    LL_HIP(hipMemcpyAsync(c, e->c32.as<float>() + (size_t)s * row, row * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    // c [B + 1][hidden] in the checkpoint's width (the engine's rows have pitch Hp)
+    const size_t Ht = (size_t)e->d.Ht, Hp = (size_t)e->d.Hp;
+    LL_HIP(hipMemcpy2DAsync(c, Ht * 4, e->c32.as<float>() + (size_t)s * (e->B + 1) * Hp, Hp * 4, Ht * 4, (size_t)e->B + 1, hipMemcpyDeviceToDevice,
+                            (hipStream_t)stream));
     return LL_OK;
 }
 

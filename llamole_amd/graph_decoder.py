@@ -132,6 +132,8 @@ class PendingGraphs:
 
 
 class GraphDiT(nn.Module):
+    MAX_NODES, MAX_HIDDEN, MAX_HEAD_DIM = 64, 2048, 128     # csrc/graphdit.hip: check_cfg
+
     def __init__(self, model_config_path, data_info_path, model_dtype):
         super().__init__()
         dm_cfg, data_info = load_config(model_config_path, data_info_path)
@@ -151,6 +153,17 @@ class GraphDiT(nn.Module):
         self.node_hist = data_info.n_nodes.clone()
         cfgd = dict(hidden_size=self.hidden_size, depth=int(dm_cfg.depth), num_heads=int(dm_cfg.num_heads),
                     mlp_ratio=float(getattr(dm_cfg, "mlp_ratio", 4.0)))
+        # Every hidden_size / num_heads / mlp_ratio / depth the reference Transformer constructs (transformer.py:24-37) runs: widths that
+        # are not multiples of 64 and head dimensions that are not 32 / 64 are zero-padded inside the engine (csrc/graphdit.hip: DitDims).
+        # What the kernels do bound is said here, by name, instead of as a failure code at engine creation:
+        if cfgd["hidden_size"] % cfgd["num_heads"] != 0:
+            raise ValueError("dim should be divisible by num_heads")          # the reference's own assertion (layers.py:37)
+        if self.max_n_nodes > self.MAX_NODES:
+            raise ValueError(f"data.meta.json max_node={self.max_n_nodes}: the MI355X engine handles graphs of up to {self.MAX_NODES} "
+                             "atoms (one 64-lane wavefront per row of bond partners, one 64-row attention tile)")
+        if cfgd["hidden_size"] > self.MAX_HIDDEN or cfgd["hidden_size"] // cfgd["num_heads"] > self.MAX_HEAD_DIM:
+            raise ValueError(f"hidden_size={cfgd['hidden_size']} / num_heads={cfgd['num_heads']}: the MI355X engine handles "
+                             f"hidden_size <= {self.MAX_HIDDEN} and head_dim <= {self.MAX_HEAD_DIM}")
         self._cfgd = cfgd
         self.denoiser = WeightBag(dit_weight_shapes(cfgd, self.max_n_nodes))
         self.tables = transition_tables(data_info, self.T)

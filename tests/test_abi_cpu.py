@@ -54,18 +54,24 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_version_and_error_string(lib):
     assert lib.ll_version() >= 100
-    bad = _lib.LLDitConfig(100, 2, 4, 400, 32, 50, 2.0, 0)      # hidden not a multiple of 64
+    odd = _lib.LLDitConfig(100, 2, 4, 250, 32, 50, 2.0, 0)      # any width the reference constructs is a valid config (padded inside the engine)
+    assert lib.ll_dit_param_count(C.byref(odd)) > 0
+    bad = _lib.LLDitConfig(4096, 2, 32, 400, 32, 50, 2.0, 0)    # the documented bounds: hidden <= 2048, head_dim <= 128, max_nodes <= 64
     assert lib.ll_dit_param_count(C.byref(bad)) < 0
     assert b"hidden" in lib.ll_last_error()
     with pytest.raises(RuntimeError, match="hidden"):
         _lib.check(lib.ll_dit_param_info(C.byref(bad), 0, None, 0, None, None))
+    assert lib.ll_dit_param_count(C.byref(_lib.LLDitConfig(512, 2, 2, 2048, 32, 50, 2.0, 0))) < 0 and b"head_dim" in lib.ll_last_error()
+    assert lib.ll_dit_param_count(C.byref(_lib.LLDitConfig(128, 2, 4, 512, 65, 50, 2.0, 0))) < 0 and b"max_nodes" in lib.ll_last_error()
 
 
-@pytest.mark.parametrize("H,L,heads,N", [(128, 2, 4, 32), (256, 2, 4, 50), (1024, 28, 16, 32)])
-def test_dit_layout_matches_reference_state_dict(lib, H, L, heads, N):
-    cfg = _lib.LLDitConfig(H, L, heads, 4 * H, N, 50, 2.0, 1)
+@pytest.mark.parametrize("H,L,heads,N,ratio", [(128, 2, 4, 32, 4.0), (256, 2, 4, 50, 4.0), (1024, 28, 16, 32, 4.0),
+                                               (1152, 3, 16, 38, 4.0), (600, 3, 8, 9, 2.0), (300, 2, 4, 17, 2.5), (48, 1, 3, 6, 4.0)])
+def test_dit_layout_matches_reference_state_dict(lib, H, L, heads, N, ratio):
+    """The public arena layout is the checkpoint's own at every width (the engine's zero padding is internal)."""
+    cfg = _lib.LLDitConfig(H, L, heads, int(H * ratio), N, 50, 2.0, 1)
     table = _lib.param_table("dit", cfg)
-    shapes = synth.dit_weight_shapes(synth.make_dit_config(H, L, heads), N)
+    shapes = synth.dit_weight_shapes(synth.make_dit_config(H, L, heads, mlp_ratio=ratio), N)
     assert [t[0] for t in table] == list(shapes.keys())
     end = 0
     for (name, numel, off), shp in zip(table, shapes.values()):
