@@ -34,6 +34,13 @@ int ll_linear_cfg(int cfg, const void *A, int lda, const void *W, int ldw, const
  * the launch that feeds it, on the weights of its own layer -- not back to back in a micro-benchmark; ll_dit_class_probe_read returns the sum
  * of the pairs' elapsed times and the number of launches (and synchronises the device).  bench.py's roofline_graphdit comes from it. */
 enum { LL_DIT_CLS_QKV = 0, LL_DIT_CLS_ATTN = 1, LL_DIT_CLS_PROJ = 2, LL_DIT_CLS_LNMOD = 3, LL_DIT_CLS_FC1 = 4, LL_DIT_CLS_FC2 = 5, LL_DIT_CLS_COUNT = 6 };
+/* Two calibrations of that bracket, OR-ed into `cls` (round 5: bench.py prices roofline_graphdit with what it measures in its own run):
+ *   LL_DIT_PROBE_EMPTY : the pair is recorded back to back AT the launch site (before the launch), i.e. it times what an event pair itself
+ *                        adds there -- subtracted from the bracketed figure;
+ *   LL_DIT_PROBE_SKIP  : no events; the class (fc1 only) is simply NOT launched, so the trajectory's run time against a normal one is the
+ *                        class's marginal cost inside the dependent chain (kernel + its launch boundary).  The trajectory's results are
+ *                        meaningless in that mode: timing only. */
+enum { LL_DIT_PROBE_EMPTY = 0x100, LL_DIT_PROBE_SKIP = 0x200 };
 int ll_dit_class_probe(void *handle, int cls);
 int ll_dit_class_probe_read(void *handle, float *total_us, int *launches);
 

@@ -211,6 +211,9 @@ struct DitEngine {
                                  // (step / denoise / step_probs: the parity taps of the team path)
     // in-situ kernel timing (ll_dit_class_probe): HIP events around every launch of ONE class of the block's kernels inside a real trajectory
     int time_class = -1;
+    int time_mode = 0;           // 0 = the pair brackets the launch; LL_DIT_PROBE_EMPTY = an EMPTY pair is recorded at the launch site (what a pair
+                                 // itself costs there); LL_DIT_PROBE_SKIP = no events, and the class is NOT launched (timing only: the trajectory's
+                                 // results are meaningless; its run time against a normal one is the class's marginal cost inside the step)
     std::vector<hipEvent_t> tev;
     size_t tev_n = 0;
     int team_last = 0;           // the last denoiser call ran on the team kernel
@@ -489,11 +492,18 @@ static void launch_lnmod(DitEngine *e, int layer, int sel, int nslab, const floa
 struct ClassTimer {
     DitEngine *e;
     hipStream_t st;
-    bool on;
+    bool on, skip;
     ClassTimer(DitEngine *e_, int cls, hipStream_t st_) : e(e_), st(st_) {
-        on = e->time_class == cls && e->step_host >= 0 && e->tev_n + 2 <= e->tev.size();
+        const bool mine = e->time_class == cls && e->step_host >= 0;
+        skip = mine && e->time_mode == LL_DIT_PROBE_SKIP;
+        on = mine && !skip && e->tev_n + 2 <= e->tev.size();
         if (on) (void)hipEventRecord(e->tev[e->tev_n++], st);
+        if (on && e->time_mode == LL_DIT_PROBE_EMPTY) {      // the pair closes before the launch: it times itself
+            (void)hipEventRecord(e->tev[e->tev_n++], st);
+            on = false;
+        }
     }
+    bool run() const { return !skip; }       // false: the probe asked for this class to be left out of the trajectory
     ~ClassTimer() {
         if (on) (void)hipEventRecord(e->tev[e->tev_n++], st);
     }
@@ -682,7 +692,8 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
         int nslab_m = e->splits_m;
         {
             ClassTimer tm(e, LL_DIT_CLS_FC1, st);
-            if (xw) {
+            if (!tm.run()) {
+            } else if (xw) {
                 LL_TRY(linear_xw_launch(e->xa.p, H, e->wfc1p.as<bf16_t>() + (size_t)l * Hm * H, w.fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, 1, 0, st));
             } else {
                 LL_TRY(linear_launch(dt, e->xa.p, H, w.fc1, H, w.fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, st));
@@ -1402,8 +1413,13 @@ int ll_dit_mlp_choice(void *handle, float *us4, int *xw_fc1, int *xw_fc2) {
 int ll_dit_class_probe(void *handle, int cls) {
     DitEngine *e = (DitEngine *)handle;
     LL_CHECK(e, "ll_dit_class_probe: null handle");
+    const int mode = cls < 0 ? 0 : (cls & (LL_DIT_PROBE_EMPTY | LL_DIT_PROBE_SKIP));
+    if (cls >= 0) cls &= ~(LL_DIT_PROBE_EMPTY | LL_DIT_PROBE_SKIP);
     LL_CHECK(cls >= -1 && cls < LL_DIT_CLS_COUNT, "ll_dit_class_probe: unknown class %d", cls);
+    LL_CHECK(mode != LL_DIT_PROBE_SKIP || cls == LL_DIT_CLS_FC1, "ll_dit_class_probe: only the fc1 class can be left out");
+    LL_CHECK(mode != (LL_DIT_PROBE_EMPTY | LL_DIT_PROBE_SKIP), "ll_dit_class_probe: EMPTY and SKIP exclude each other");
     e->time_class = cls;
+    e->time_mode = mode;
     e->tev_n = 0;
     if (cls >= 0 && e->tev.empty()) {
         const size_t n = (size_t)2 * 2 * e->cfg.depth * e->cfg.T;        // at most two launches of a class per block

@@ -8,9 +8,9 @@ small all-gather of fixed-size records per phase:
   design phase   per molecule  int8 [1 + N + N*N]  = n_nodes, atom classes, bond classes   (~1.1 KB at N=32)
   retro phase    per expansion int32[k] + f32[k]   = top-k template ids and probabilities  (400 B at k=50)
 
-Messages are KB-scale and latency-bound: a single direct all-gather (every GPU writes its slice to its 7 xGMI
-peers in parallel) is used, never a ring of many small steps.  ``backend="nccl"`` is RCCL on ROCm; the same
-code runs under ``gloo`` on CPU tensors, which is how it is tested without GPUs.
+Messages are KB-scale and latency-bound, so the design issues ONE ``dist.all_gather`` per phase (never one per molecule or per
+expansion); which algorithm RCCL runs under that call (direct, ring, tree) is RCCL's choice and is not set here.
+``backend="nccl"`` is RCCL on ROCm; the same code runs under ``gloo`` on CPU tensors, which is how it is tested without GPUs.
 """
 from __future__ import annotations
 

@@ -84,9 +84,9 @@ def dit_graph_mode(args):
     library's choice (launches when the trajectory runs alone, the replay when it overlaps the LLM decode)."""
     return False if getattr(args, "no_graph", False) else (True if getattr(args, "graph", False) else None)
 
-def build_llm(name: str, device, dtype=torch.bfloat16, seed: int = 0):
+def build_llm(name: str, device, dtype=torch.bfloat16, seed: int = 0, **overrides):
     import transformers
-    spec = dict(LLM_CONFIGS[name])
+    spec = dict(LLM_CONFIGS[name], **overrides)
     kind = spec.pop("cls")
     cfg_cls = getattr(transformers, kind + "Config")
     model_cls = getattr(transformers, kind + "ForCausalLM")

@@ -171,11 +171,15 @@ def load_tokenizer(model_args):
     from transformers import AutoTokenizer
     tokenizer = AutoTokenizer.from_pretrained(model_args.model_name_or_path, padding_side="left")
     new = list(model_args.new_special_tokens or [])
+    before = len(tokenizer)
     if new:
         try:
             tokenizer.add_special_tokens({"additional_special_tokens": new}, replace_additional_special_tokens=False)
         except TypeError:       # transformers >= 5 renamed the keyword
             tokenizer.add_tokens(new, special_tokens=True)
+    # the reference flips model_args.resize_vocab when tokens were added (loader.py:121-126); the SFT driver reads it to decide whether the
+    # embedding matrices are trained and saved with the adapter (adapter.py:224-233)
+    model_args.resize_vocab = bool(getattr(model_args, "resize_vocab", False)) or len(tokenizer) > before
     tokenizer.pad_token = tokenizer.eos_token
     return tokenizer
 

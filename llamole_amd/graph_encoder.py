@@ -227,6 +227,8 @@ class GraphCLIP(_GinModule):
         super().__init__()
         if graph_num_layer < 2:
             raise ValueError("Number of GNN layers must be greater than 1.")
+        if not 1 <= int(graph_hidden_size) <= 2048:      # any width runs (zero-padded to a multiple of 64 inside the engine, csrc/gin.hip: GinDims) up to:
+            raise ValueError(f"hidden_size={graph_hidden_size}: the MI355X GIN engine handles hidden_size <= 2048")
         self.model_config = model_config
         self.hidden_size = graph_hidden_size
         self.num_layer = graph_num_layer

@@ -84,6 +84,8 @@ class GraphPredictor(_GinModule):
         super().__init__()
         if num_layer < 2:
             raise ValueError("Number of GNN layers must be greater than 1.")
+        if not 1 <= int(hidden_size) <= 2048:      # any width runs (zero-padded to a multiple of 64 inside the engine, csrc/gin.hip: GinDims) up to:
+            raise ValueError(f"hidden_size={hidden_size}: the MI355X GIN engine handles hidden_size <= 2048")
         self.model_config = model_config
         self.text_input_size = model_config.get("text_input_size", 768)
         self.available = available

@@ -172,6 +172,42 @@ def add_lora(model: torch.nn.Module, r: int = 8, alpha: int = 16, targets=("q_pr
     return n
 
 
+def embedding_module_names(model: torch.nn.Module) -> set:
+    """Last name components of the input / output embedding modules (reference adapter.py:224-230): {"embed_tokens", "lm_head"} for the
+    Llama / Mistral / Qwen2 families."""
+    emb = [m for m in (model.get_input_embeddings(), model.get_output_embeddings()) if m is not None]
+    return {n.split(".")[-1] for n, m in model.named_modules() if any(m is e for e in emb)}
+
+
+def _untie_output_embedding(model: torch.nn.Module) -> bool:
+    """peft's ModulesToSaveWrapper trains and stores a private copy of each module, so embed_tokens and lm_head stop sharing one tensor
+    the moment both are in modules_to_save; same here."""
+    inp, out = model.get_input_embeddings(), model.get_output_embeddings()
+    if inp is None or out is None or out.weight is not inp.weight:
+        return False
+    out.weight = torch.nn.Parameter(inp.weight.detach().clone(), requires_grad=inp.weight.requires_grad)
+    if getattr(model, "config", None) is not None:
+        model.config.tie_word_embeddings = False
+    return True
+
+
+def enable_modules_to_save(model: torch.nn.Module, names) -> List[str]:
+    """Make every module whose last name component is in ``names`` fully trainable next to the LoRA adapters (peft ``modules_to_save``;
+    the reference puts the resized embed_tokens / lm_head there, adapter.py:224-233).  Returns the module names."""
+    names = set(names)
+    if not names:
+        return []
+    if names >= embedding_module_names(model) and len(embedding_module_names(model)) == 2:
+        _untie_output_embedding(model)
+    hit = []
+    for n, mod in model.named_modules():
+        if n.split(".")[-1] in names and not isinstance(mod, LoRALinear) and getattr(mod, "weight", None) is not None:
+            for p in mod.parameters(recurse=False):
+                p.requires_grad = True
+            hit.append(n)
+    return hit
+
+
 def merge_lora_adapter(model: torch.nn.Module, adapter_dir: str) -> int:
     """Merge a LoRA adapter stored in peft's on-disk layout into ``model`` in place: ``W += (alpha / r) * B A`` for every
     ``<module>.lora_A/lora_B`` pair, ``modules_to_save`` weights (the resized embed_tokens / lm_head the reference trains,
@@ -191,11 +227,14 @@ def merge_lora_adapter(model: torch.nn.Module, adapter_dir: str) -> int:
         tensors = load_file(st_path)
     else:
         tensors = torch.load(os.path.join(adapter_dir, "adapter_model.bin"), map_location="cpu", weights_only=True)
+    strip = lambda k: k[len("base_model.model."):] if k.startswith("base_model.model.") else k      # noqa: E731
+    saved = {strip(k).replace(".modules_to_save.default", "").replace(".modules_to_save", "").split(".")[-2] for k in tensors if ".lora_" not in k and "." in strip(k)}
+    if len(embedding_module_names(model)) == 2 and saved >= embedding_module_names(model):
+        _untie_output_embedding(model)     # the adapter trained both matrices separately (peft copies): keep both
     mods = dict(model.named_modules())
     # remove_duplicate=False: with tie_word_embeddings named_parameters() lists the shared tensor once (as embed_tokens), and an adapter
     # whose modules_to_save carries lm_head.weight as well must still find its target
     params = dict(model.named_parameters(remove_duplicate=False))
-    strip = lambda k: k[len("base_model.model."):] if k.startswith("base_model.model.") else k      # noqa: E731
     merged = 0
     with torch.no_grad():
         for k, a in tensors.items():
@@ -270,6 +309,9 @@ def load_lora_adapter(model: torch.nn.Module, adapter_dir: str) -> int:
     import os
     from safetensors.torch import load_file
     tensors = load_file(os.path.join(adapter_dir, "adapter_model.safetensors"))
+    saved = {k.split(".")[-2] for k in tensors if ".lora_" not in k and k.count(".") >= 1}
+    if len(embedding_module_names(model)) == 2 and saved >= embedding_module_names(model):
+        _untie_output_embedding(model)
     mods = dict(model.named_modules())
     params = dict(model.named_parameters(remove_duplicate=False))
     n = 0

@@ -257,10 +257,10 @@ def proj_weight_shapes(H: int) -> "OrderedDict[str, tuple]":
     return s
 
 
-def make_gin_weights(num_layer: int, H: int, kind: str, out_dim: int = 0, seed: int = 0):
+def make_gin_weights(num_layer: int, H: int, kind: str, out_dim: int = 0, seed: int = 0, text_dim: int = TEXT_DIM):
     rs = np.random.RandomState(3000 + seed + (0 if kind == "encoder" else 500))
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
-    for k, shp in gin_weight_shapes(num_layer, H, kind, out_dim).items():
+    for k, shp in gin_weight_shapes(num_layer, H, kind, out_dim, text_dim).items():
         if k.endswith("eps"):
             sd[k] = torch.from_numpy(rs.uniform(-0.2, 0.2, 1).astype(np.float32))
         else:
@@ -398,7 +398,7 @@ def write_predictor_dir(path: str, num_layer: int = 3, H: int = 64, out_dim: int
     return path
 
 
-def write_llm_dir(path: str, special_tokens, name: str = "tiny", seed: int = 0) -> str:
+def write_llm_dir(path: str, special_tokens, name: str = "tiny", seed: int = 0, exact_vocab: bool = False) -> str:
     """A local `model_name_or_path`: tiny random-init HF causal LM (llamole_amd.e2e.LLM_CONFIGS[name]) saved with
     save_pretrained, plus a byte-level BPE tokenizer trained on a few sentences (the form AutoTokenizer resolves for a Qwen2 /
     Llama directory) with a chat template and an eos/pad token; the nine Llamole special tokens are NOT added yet (the driver
@@ -419,8 +419,10 @@ def write_llm_dir(path: str, special_tokens, name: str = "tiny", seed: int = 0) 
     fast.chat_template = ("{% for m in messages %}<|{{ m['role'] }}|> {{ m['content'] }} {% endfor %}"
                           "{% if add_generation_prompt %}<|assistant|> {% endif %}")
     fast.save_pretrained(path)
-    llm = e2e.build_llm(name, "cpu", torch.bfloat16, seed=seed)
-    assert llm.config.vocab_size >= len(fast) + len(list(special_tokens))
+    # exact_vocab: the embedding matrices end where the base tokenizer ends, as a real base checkpoint's do -- adding the Llamole special
+    # tokens then RESIZES them (reference patcher / adapter.py:224-233: the new rows are trained and saved with the adapter)
+    llm = e2e.build_llm(name, "cpu", torch.bfloat16, seed=seed, **({"vocab_size": len(fast)} if exact_vocab else {}))
+    assert exact_vocab or llm.config.vocab_size >= len(fast) + len(list(special_tokens))
     llm.save_pretrained(path, safe_serialization=True)
     return path
 
@@ -545,7 +547,7 @@ def write_train_fixture(root: str, special_tokens, **overrides) -> str:
     (config/train/mistral_lora.yaml)."""
     import yaml
     from . import e2e
-    llm_dir = write_llm_dir(os.path.join(root, "llm"), special_tokens)
+    llm_dir = write_llm_dir(os.path.join(root, "llm"), special_tokens, exact_vocab=bool(overrides.pop("exact_vocab", False)))
     cfg = make_dit_config(hidden_size=128, depth=2, num_heads=4, diffusion_steps=10, guide_scale=2.0)
     write_dit_dir(os.path.join(root, "graph_decoder"), cfg, make_data_meta(16, 0), make_dit_weights(cfg, 16, 0))
     write_encoder_dir(os.path.join(root, "graph_encoder"))

@@ -151,7 +151,7 @@ def run_train(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> D
     import yaml
     from .distributed import shard_range
     from .modeling_llamole import GraphLLMForCausalMLM
-    from .sft import GraphSFTCollator, add_lora, load_lora_adapter, sft_step, to_device
+    from .sft import GraphSFTCollator, add_lora, embedding_module_names, enable_modules_to_save, load_lora_adapter, to_device
     with open(config_path) as f:
         cfg = yaml.safe_load(f) or {}
     cfg.update(overrides or {})
@@ -164,6 +164,10 @@ def run_train(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> D
     if not out_dir:
         raise ValueError("output_dir is required")
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    # every rank checks the output directory BEFORE a process group exists: a refusal on rank 0 alone would leave the others waiting in
+    # their first collective
+    if os.path.isdir(out_dir) and os.listdir(out_dir) and not cfg.get("overwrite_output_dir", False) and not cfg.get("resume_from_checkpoint"):
+        raise ValueError(f"Output directory ({out_dir}) already exists and is not empty. Use overwrite_output_dir to overcome.")
     if world > 1:
         import torch.distributed as dist
         n_dev = torch.cuda.device_count()
@@ -174,9 +178,13 @@ def run_train(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> D
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if not dist.is_initialized():
             dist.init_process_group(os.environ.get("LLAMOLE_DIST_BACKEND", "nccl"))
-    if rank == 0 and os.path.isdir(out_dir) and os.listdir(out_dir) and not cfg.get("overwrite_output_dir", False) \
-            and not cfg.get("resume_from_checkpoint"):
-        raise ValueError(f"Output directory ({out_dir}) already exists and is not empty. Use overwrite_output_dir to overcome.")
+    # `seed` fixes every random draw of the run on every rank -- the resized embedding rows, the connector and LoRA-A initialisations, the
+    # data permutation -- (the reference: transformers.set_seed(training_args.seed) in the Trainer); the replicas are made identical
+    # below by a broadcast from rank 0 whatever the RNG streams did
+    seed = int(cfg.get("seed", 42))
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
     tokenizer = load_tokenizer(model_args)
     tokenizer.padding_side = "right"
     model = GraphLLMForCausalMLM.from_pretrained(tokenizer, model_args, data_args, training_args, finetuning_args, load_adapter=False)
@@ -184,6 +192,17 @@ def run_train(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> D
     targets = lora_targets(model.language_model, cfg.get("lora_target", "all"))
     r = int(cfg.get("lora_rank", 8))
     n_lora = add_lora(model.language_model, r=r, alpha=int(cfg.get("lora_alpha", 2 * r)), targets=targets)
+    # modules trained in full next to the adapters (peft modules_to_save).  When special tokens were added to the tokenizer and
+    # additional_target is unset the reference puts the input and output embeddings there (adapter.py:224-233): the rows of
+    # <design_body> / <retro_body> ARE the learned queries, and <design_start> / <retro_start> stay in the labels
+    if cfg.get("additional_target"):
+        at = cfg["additional_target"]
+        extra_modules = {t.strip() for t in (at.split(",") if isinstance(at, str) else at) if t.strip()}
+    elif getattr(model_args, "resize_vocab", False):
+        extra_modules = embedding_module_names(model.language_model)
+    else:
+        extra_modules = set()
+    trained_modules = enable_modules_to_save(model.language_model, extra_modules)
     resume = cfg.get("resume_from_checkpoint") or (model_args.adapter_name_or_path or [None])[0]
     if resume:
         load_lora_adapter(model.language_model, resume)
@@ -205,16 +224,20 @@ def run_train(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> D
     total = int(cfg.get("max_steps", 0)) or int(math.ceil(float(cfg.get("num_train_epochs", 1.0)) * steps_per_epoch))
     warmup = int(cfg.get("warmup_steps", 0)) or int(float(cfg.get("warmup_ratio", 0.0)) * total)
     params = [p for p in model.parameters() if p.requires_grad]
+    if world > 1:      # identical replicas whatever each process drew: only rank 0's copy is saved, and only gradients are averaged
+        import torch.distributed as dist
+        for p in params:
+            dist.broadcast(p.data, src=0)
     lr = float(cfg.get("learning_rate", 1e-4))
     opt = torch.optim.AdamW(params, lr=lr, weight_decay=float(cfg.get("weight_decay", 0.0)))
-    gen = torch.Generator().manual_seed(int(cfg.get("seed", 42)))
+    gen = torch.Generator().manual_seed(seed)
     log: List[Dict[str, Any]] = []
     logging_steps, save_steps = int(cfg.get("logging_steps", 10)), int(cfg.get("save_steps", 0))
     order: List[int] = []
 
     def save(where):
         if rank == 0:
-            model.save_pretrained(where, modules_to_save=tuple(cfg.get("additional_target", "").split(",")) if cfg.get("additional_target") else ())
+            model.save_pretrained(where, modules_to_save=tuple(sorted(extra_modules)))
             tokenizer.save_pretrained(where)
 
     t0 = time.perf_counter()
@@ -249,11 +272,11 @@ def run_train(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> D
                 f.write(json.dumps(row) + "\n")
         with open(os.path.join(out_dir, "train_results.json"), "w") as f:
             json.dump({"train_steps": total, "train_runtime": time.perf_counter() - t0, "train_loss": sum(r["loss"] for r in log) / max(1, len(log)),
-                       "lora_modules": n_lora, "lora_targets": list(targets), "world_size": world}, f, indent=1)
+                       "lora_modules": n_lora, "lora_targets": list(targets), "modules_to_save": trained_modules, "world_size": world}, f, indent=1)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
-    return {"log": log, "output_dir": out_dir, "lora_modules": n_lora}
+    return {"log": log, "output_dir": out_dir, "lora_modules": n_lora, "modules_to_save": trained_modules}
 
 
 def _micro_step(model, batch, params, accum: int, reduce: bool) -> Dict[str, float]:

@@ -137,3 +137,87 @@ def test_dit_limits_are_value_errors():
             json.dump(synth.make_data_meta(N, 0), f)
         with pytest.raises(ValueError, match=pat):
             GraphDiT(os.path.join(d, "config.yaml"), os.path.join(d, "data.meta.json"), torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------------------------------ GIN
+# name: (hidden, layers, out_dim, text_dim)
+GIN_CASES = {
+    "h300_l2": (300, 2, 1001, 768),              # the de-facto width of pretrained molecular GINs; out_dim not a multiple of 8
+    "h600_l7": (600, 7, 37, 768),
+    "h320_l2": (320, 2, 640, 768),               # a multiple of 64 that is not a multiple of 256
+    "h300_l3_text500": (300, 3, 999, 500),       # text width padded too
+    "h50_l2": (50, 2, 10, 70),                   # narrower than one tile
+}
+
+
+def _gin_graphs(seed):
+    G = 5
+    x, ei, ea, batch = synth.make_mol_graphs(G, seed)
+    n0 = x.numel()                                          # one more graph: a hub with 9 neighbours (more than a neighbour record holds)
+    x = torch.cat([x, torch.tensor([6] + [1] * 9)])
+    hub_e = torch.tensor([[n0] * 9 + list(range(n0 + 1, n0 + 10)), list(range(n0 + 1, n0 + 10)) + [n0] * 9])
+    ei = torch.cat([ei, hub_e], dim=1)
+    ea = torch.cat([ea, torch.tensor([1 + (i % 4) for i in range(9)] * 2)])
+    batch = torch.cat([batch, torch.full((10,), G, dtype=torch.long)])
+    return x, ei, ea, batch, G + 1
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("name", list(GIN_CASES))
+def test_gin_any_width_vs_oracle(name, dtype, tol):
+    import torch.nn.functional as F
+    from llamole_amd.graph_encoder import GraphCLIP
+    from llamole_amd.graph_predictor import GraphPredictor
+    from oracle import gin_oracle as go
+    H, L, out_dim, D = GIN_CASES[name]
+    seed = sum(map(ord, name)) % 100
+    x, ei, ea, batch, G = _gin_graphs(seed)
+    sd_e, sd_j = synth.make_gin_weights(L, H, "encoder", seed=seed), synth.make_proj_weights(H, seed)
+    sd_p = synth.make_gin_weights(L, H, "predictor", out_dim, seed, text_dim=D)
+    if dtype != torch.float32:
+        sd_e, sd_j, sd_p = ({k: v.to(dtype).float() for k, v in d.items()} for d in (sd_e, sd_j, sd_p))
+    enc = GraphCLIP(L, H, 0.0, {})
+    enc.molecule_encoder.load_state_dict(sd_e)
+    enc.molecule_projection.load_state_dict(sd_j)
+    pred = GraphPredictor(L, H, 0.0, out_dim, {"text_input_size": D}, {})
+    pred.predictor.load_state_dict(sd_p)
+    for m in (enc, pred):
+        m.to("cuda")
+        for p in m.parameters():
+            p.data = p.data.to(dtype)
+    g = torch.Generator().manual_seed(seed)
+    c0 = torch.randn(G, D, generator=g)
+    labels = torch.randint(0, out_dim, (G,), generator=g)
+    c_ref = c0.clone().requires_grad_(True)
+    ref_e = go.graphclip_forward(sd_e, sd_j, L, x, ei, ea, batch)
+    ref_p = go.predictor_forward(sd_p, L, x, ei, ea, batch, c_ref)
+    ref_n = go.predictor_forward(sd_p, L, x, ei, ea, batch, None).detach()
+    (dc_ref,) = torch.autograd.grad(F.cross_entropy(ref_p, labels), c_ref)
+    ref_p = ref_p.detach()
+    xs = [t.cuda() for t in (x, ei, ea, batch)]
+    got_e = enc(*xs).float().cpu()
+    assert got_e.shape == (G, H)
+    assert float((got_e - ref_e).abs().max()) <= tol * max(1.0, float(ref_e.abs().max()))
+    np.testing.assert_allclose(np.linalg.norm(got_e.numpy(), axis=-1), 1.0, rtol=1e-4 if dtype == torch.float32 else 3e-3)      # (bf16 output rounding)
+    pooled = enc.pooled(*xs).float().cpu()
+    assert pooled.shape == (G, H)
+    # predictor with and without a text condition, the top-k of its logits, and the reverse sweep to the condition
+    c = c0.clone().cuda().requires_grad_(True)
+    got_p = pred(*xs, c)
+    assert got_p.shape == (G, out_dim)
+    assert float((got_p.detach().float().cpu() - ref_p).abs().max()) <= tol * max(1.0, float(ref_p.abs().max()))
+    F.cross_entropy(got_p.float(), labels.cuda()).backward()
+    dc = c.grad.float().cpu()
+    assert dc.shape == (G, D)
+    cos = F.cosine_similarity(dc.flatten(), dc_ref.flatten(), dim=0).item()
+    assert cos > (0.9999 if dtype == torch.float32 else 0.99), cos
+    assert float((dc - dc_ref).abs().max()) <= (3e-3 if dtype == torch.float32 else 0.15) * float(dc_ref.abs().max())
+    with torch.no_grad():
+        got_n = pred(*xs, None).float().cpu()
+    assert float((got_n - ref_n).abs().max()) <= tol * max(1.0, float(ref_n.abs().max()))
+    if dtype == torch.float32:
+        k = min(10, out_dim)
+        pk, ik = pred.topk_templates(*xs, c.detach(), k)
+        rp, ri = torch.topk(torch.softmax(ref_p.double(), dim=1), k, dim=1)
+        np.testing.assert_allclose(pk.cpu().numpy(), rp.numpy(), rtol=2e-2, atol=1e-7)
+        assert (ik.cpu().numpy() == ri.numpy()).mean() > 0.9

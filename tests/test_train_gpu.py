@@ -89,3 +89,54 @@ def test_main_train_two_ranks(tmp_path):
     log = json.loads(line[len("TRAIN_LOG "):])
     assert len(log["losses"]) == 3 and all(l == l for l in log["losses"])
     assert os.path.exists(os.path.join(str(tmp_path), "saves", "adapter", "adapter_model.safetensors"))
+
+
+def test_main_train_trains_and_saves_the_new_token_embeddings(tmp_path, monkeypatch):
+    """with a base vocabulary that lacks the Llamole special tokens the embedding matrices are RESIZED, and the reference
+    then trains and saves them with the adapter (adapter.py:224-233: modules_to_save = {embed_tokens, lm_head} when resize_vocab and no
+    additional_target) -- the rows of <design_body> / <retro_body> are the learned queries.  Here: the rows move during training, they are
+    in the checkpoint, a second run with the same seed reproduces them bit for bit, and the eval-side loader ends up with exactly them."""
+    from safetensors.torch import load_file
+    from llamole_amd import eval as ev
+    from llamole_amd import synth
+    from llamole_amd import train as tr
+    from llamole_amd.modeling_llamole import SPECIAL_TOKENS, GraphLLMForCausalMLM
+    _fake_chem(monkeypatch)
+
+    def run(tag, **kw):
+        cfg = synth.write_train_fixture(str(tmp_path / tag), SPECIAL_TOKENS, exact_vocab=True, num_train_epochs=4.0, seed=7, **kw)
+        out = tr.run_train(cfg)
+        return cfg, out, load_file(os.path.join(out["output_dir"], "adapter_model.safetensors"))
+
+    cfg0, out0, frozen = run("lr0", learning_rate=0.0)          # nothing moves: the checkpoint holds the seeded initial rows
+    cfg1, out1, trained = run("lr", learning_rate=2.0e-3)
+    _, _, again = run("lr_again", learning_rate=2.0e-3)
+    assert sorted(m.split(".")[-1] for m in out1["modules_to_save"]) == ["embed_tokens", "lm_head"]
+    ek = [k for k in trained if k.endswith("embed_tokens.weight")][0]
+    hk = [k for k in trained if k.endswith("lm_head.weight")][0]
+    model_args = ev.load_yaml_args(cfg1)[0]
+    tok = ev.load_tokenizer(model_args)
+    assert model_args.resize_vocab and trained[ek].shape[0] == len(tok) == trained[hk].shape[0]      # the resized matrices, not the base ones
+    ids = [tok.convert_tokens_to_ids(t) for t in SPECIAL_TOKENS]
+    body = [tok.convert_tokens_to_ids(t) for t in ("<design_body>", "<retro_body>")]
+    kept = [tok.convert_tokens_to_ids(t) for t in ("<design_start>", "<retro_start>")]
+    assert min(ids) >= trained[ek].shape[0] - len(SPECIAL_TOKENS)                                     # they are the new rows
+    assert torch.equal(frozen[ek], load_file(os.path.join(out0["output_dir"], "adapter_model.safetensors"))[ek])
+    d_in = (trained[ek].float() - frozen[ek].float()).abs().amax(dim=1)
+    d_out = (trained[hk].float() - frozen[hk].float()).abs().amax(dim=1)
+    assert all(float(d_in[i]) > 0 for i in body), d_in[body]          # the learned queries were trained
+    assert all(float(d_out[i]) > 0 for i in kept), d_out[kept]        # <design_start> / <retro_start> stay in the labels: their output rows move
+    for k in trained:                                                  # `seed` fixes the run: same seed, same checkpoint
+        assert torch.equal(trained[k], again[k]), k
+    # eval-side load: resize + merge ends with exactly the trained rows (a fresh resize alone would redraw them)
+    import yaml
+    y = yaml.safe_load(open(cfg1))
+    y.update(adapter_name_or_path=out1["output_dir"], graph_lm_connector_path=os.path.join(out1["output_dir"], "connector"), do_train=False)
+    ycfg = str(tmp_path / "gen.yaml")
+    yaml.safe_dump(y, open(ycfg, "w"))
+    margs, dargs, targs, fargs, _ = ev.load_yaml_args(ycfg)
+    tok = ev.load_tokenizer(margs)
+    m = GraphLLMForCausalMLM.from_pretrained(tok, margs, dargs, targs, fargs, load_adapter=True)
+    w_in = m.language_model.get_input_embeddings().weight.detach().cpu()
+    w_out = m.language_model.get_output_embeddings().weight.detach().cpu()
+    assert torch.equal(w_in[ids], trained[ek][ids].to(w_in.dtype)) and torch.equal(w_out[ids], trained[hk][ids].to(w_out.dtype))
