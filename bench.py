@@ -369,7 +369,6 @@ def time_kernel_class_in_situ(m, cls: str, props, text, n_nodes, mode: str = "br
     lib = _lib.load()
     classes = {"qkv": 0, "attn": 1, "proj": 2, "lnmod": 3, "fc1": 4, "fc2": 5}
     try:
-        m.set_option("team", 0)
         _lib.check(lib.ll_dit_class_probe(m._handle, classes[cls] | (0x100 if mode == "empty" else 0)), "ll_dit_class_probe")
         m.generate_graphs(props, text, -200.0, n_nodes=n_nodes, seed=777, use_graph=False)
         us, n = C.c_float(), C.c_int()
@@ -390,7 +389,6 @@ def time_fc1_marginal(m, props, text, n_nodes, depth: int, T: int, reps: int = 3
     from llamole_amd import _lib
     lib = _lib.load()
     try:
-        m.set_option("team", 0)
 
         def traj(skip):
             _lib.check(lib.ll_dit_class_probe(m._handle, (4 | 0x200) if skip else -1), "ll_dit_class_probe")
@@ -789,6 +787,7 @@ def main():
         ctx = types.SimpleNamespace(rank=rank, world=world, device=device, dist=dist, n_ranks=n_ranks)
         out = run_retro(args, ctx) if args.workload == "retro" else run_sft(args, ctx)
         if out is not None:
+            out["host_threads_per_rank"] = torch.get_num_threads()
             print(json.dumps(out))
         if dist is not None:
             dist.destroy_process_group()
@@ -974,6 +973,7 @@ def main():
         "roofline": roof,
         "roofline_graphdit": roof_dit,
         "rank_seconds": [round(t, 4) for t in rank_times],
+        "host_threads_per_rank": torch.get_num_threads(),
         "collectives": ({"backend": dist.get_backend(), "ranks": n_ranks, "forced_single_rank": world == 1,
                          "issued": ["all_reduce(ones)", "barrier", "all_gather(rank seconds, f64)", "all_reduce(max, f64)",
                                     "all_gather(int8 graph records)"]} if dist is not None else None),

@@ -143,33 +143,12 @@ int ll_dit_set_overlap(void *handle, int on);
  * LL_DIT_OPT_FUSED_QKV_ATTN = the block's q|k|v projection and attention as ONE launch per (sequence, head) (bf16, head
  * dimension 64, hidden 256 | 512 | a multiple of 1024): -1 = above 128 token rows when the launch has 64..512 such workgroups, i.e. batch 3..16
  * at 16 heads and 32 nodes -- two sequences per workgroup from batch 11 to 24 -- and always in overlap mode (default), 0 = never,
- * 1 = whenever eligible, 2 = two sequences per workgroup whenever eligible (graphs of <= 32 nodes);
- * LL_DIT_OPT_XW_GEMM = the block's MLP GEMMs on the packed-weight panel kernel (gemm_xw_kernel; bf16, hidden 512 | 1024): 1 = fc1
- * whenever eligible, 0 (default) = never: the kernels of a step are a pure function of (config, batch, options), so a seed fixes the
- * molecules across processes and boxes; -1 = opt-in per-device calibration (also env LL_DIT_CALIBRATE=1): ll_dit_begin times the MLP
- * chain fc1 -> fc2 -> AdaLN epilogue with either kernel under each GEMM once per batch size (>= 128 token rows) and keeps the fastest
- * pair -- the LDS-DMA ring and the panel kernel trade places between MI355X boxes; the alternatives sum K in different orders, so
- * with -1 low-order bits (and through a near-tie of the sampling race, molecules) may differ from run to run, and that ll_dit_begin
- * blocks the host once per batch size. */
-/* LL_DIT_OPT_TEAM = the persistent per-XCD trajectory kernel (csrc/dit_team.h: one launch per trajectory, one graph per XCD, weights
- * streamed through a register FIFO).  OPT-IN: 0 (default) = never -- the launch chain is faster at every batch measured (round 4:
- * 1.64 vs 1.50 ms per step at batch 8, 1.37 vs 1.03 at batch 2; DESIGN.md section 4 says why); -1 = ll_dit_run uses it whenever the
- * engine is eligible (bf16, hidden 1024 with 64-wide heads, mlp_hidden = 4 hidden, 16 | 32 nodes) and not in overlap mode; 1 = also
- * under ll_dit_step / ll_dit_denoise / ll_dit_step_probs (one step of the team kernel, posterior by the chain's kernels): the parity
- * taps of that path.  Also env LL_DIT_TEAM.  The team kernel sums K in another order than the chain: within one mode a seed fixes
- * the molecules, and in team mode a graph's trajectory does not depend on the batch around it (every graph is processed alone). */
-/* LL_DIT_OPT_PROJ_LN = the block's attention projection and its AdaLN epilogue as ONE launch on per-XCD teams (proj_ln_team_kernel: the
- * 2 MB projection weight replicated across the XCDs, one graph's rows per XCD, LayerNorm behind a same-L2 team barrier): 0 (default) =
- * never (two launches: measured faster at every batch), 1 = whenever eligible (bf16, hidden 1024, <= 32 nodes in multiples of 4, not in
- * overlap mode).  Sums K in another order than the two launches (full K per tile, no split-K slabs). */
-enum { LL_DIT_OPT_OVERLAP = 0, LL_DIT_OPT_GENERIC_ATTN = 1, LL_DIT_OPT_FUSED_QKV_ATTN = 2, LL_DIT_OPT_XW_GEMM = 3, LL_DIT_OPT_TEAM = 4,
-       LL_DIT_OPT_PROJ_LN = 5 };
+ * 1 = whenever eligible, 2 = two sequences per workgroup whenever eligible (graphs of <= 32 nodes).
+ * The launch chain is the one GraphDiT step this library has: the per-XCD persistent trajectory kernel, the per-XCD projection + AdaLN
+ * launch and the packed-weight panel MLP GEMM of rounds 2-4 were measured slower at every batch and have been removed (HISTORY.md). */
+enum { LL_DIT_OPT_OVERLAP = 0, LL_DIT_OPT_GENERIC_ATTN = 1, LL_DIT_OPT_FUSED_QKV_ATTN = 2 };
 int ll_dit_set_option(void *handle, int option, int value);
 int ll_dit_last_run_ms(void *handle, float *ms, int *steps);
-/* What ll_dit_begin's calibration measured for the current batch (us per fc1 -> fc2 -> AdaLN chain with fc1 / fc2 on ring/ring,
- * panel/ring, ring/panel, panel/panel; zeros when it did not run) and which kernels the step uses. */
-int ll_dit_mlp_choice(void *handle, float *us4, int *xw_fc1, int *xw_fc2);
-
 /* ------------------------------------------------------------------ GIN encoder / predictor
  * Replaces GNNEncoder.forward + ProjectionHead (src/model/graph_encoder/model.py:124-205) and
  * GNNRetrosynthsizer.forward (src/model/graph_predictor/model.py:306-353). */

@@ -20,11 +20,6 @@ int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f32, int ite
 /* ll_host_launch_probe : HOST time per enqueued launch (wall time of the issuing loop): kind 0 = empty kernel, 1 = two-argument kernel,
  * 2 = linear_launch onto the <= 64-row panel GEMM, 3 = linear_launch onto the LDS-DMA ring. */
 int ll_host_launch_probe(int kind, int n, float *us_per_launch);
-/* ll_linear_xw : test hook of the packed-weight panel GEMM (gemm_xw_kernel: 64 token rows in LDS, the weight streamed from a copy in
- * MFMA operand order; K / splits = 512 | 1024, N % 128 == 0): packs the row-major W [N, K] into a temporary and runs it; splits > 1
- * writes raw f32 slabs of M x ldc.  ll_gemm_bench(cfg = -2) times the same kernel. */
-int ll_linear_xw(const void *A, int lda, const void *W, const float *bias, void *C, int ldc, int M, int N, int K, int splits,
-                 int epi, int out_f32, void *stream);
 /* ll_linear_cfg : ll_linear (bf16 operands) through ONE kernel configuration of the tuning table (gemm.hip: g_pipe_cfgs), so that
  * every variant can be checked against a reference.  splits > 1: C receives `splits` raw f32 slabs (stride M * ldc). */
 int ll_linear_cfg(int cfg, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, int M, int N, int K,

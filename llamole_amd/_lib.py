@@ -40,7 +40,6 @@ SIGNATURES = {
     "ll_linear_splitk_bf16": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ll_host_launch_probe": (_I, [_I, _I, C.POINTER(_F)]),
     "ll_gemm_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
-    "ll_linear_xw": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ll_linear_cfg": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ll_launch_bench": (_I, [_I, _I, _I, C.POINTER(_F)]),
     "ll_launch_bench_set_buffers": (_I, [_P, _P]),
@@ -91,7 +90,6 @@ SIGNATURES = {
     "ll_debug_check_guards": (_I, []),
     "ll_debug_guard_selftest": (_I, []),
     "ll_dit_set_overlap": (_I, [_P, _I]),
-    "ll_dit_mlp_choice": (_I, [_P, C.POINTER(_F), C.POINTER(_I), C.POINTER(_I)]),
     "ll_dit_set_option": (_I, [_P, _I, _I]),
     "ll_dit_class_probe": (_I, [_P, _I]),
     "ll_dit_class_probe_read": (_I, [_P, C.POINTER(_F), C.POINTER(_I)]),

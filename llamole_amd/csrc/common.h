@@ -219,14 +219,10 @@ int linear_grouped2_launch(int dtype, const void *A, int lda, const void *W1, co
 
 int convert_f32_to_bf16(const float *src, bf16_t *dst, int64_t n, hipStream_t stream);
 
-// [Nout, K] bf16 weight -> MFMA A-operand order (fragment blocks of 16 rows x 32 k, 1 KB contiguous each, row-tile major); and the
-// Linear that streams such a copy against a 64-row token panel held in LDS (gemm.hip: gemm_xw_kernel)
+// [Nout, K] bf16 weight -> MFMA A-operand order (fragment blocks of 16 rows x 32 k, 1 KB contiguous each, row-tile major)
 int pack_mfma16(const bf16_t *W, bf16_t *out, int Nout, int K, hipStream_t stream);
 // tell the <= 64-row panel GEMM that `packed` is the pack_mfma16 copy of the row-major weight `w` (packed = nullptr: forget it)
 void register_packed_weight(const void *w, const void *packed);
-bool linear_xw_supported(int M, int N, int K, int splits, int lda, int ldc);
-int linear_xw_launch(const void *A, int lda, const void *Wp, const float *bias, void *C, int ldc, int M, int N, int K, int splits,
-                     int64_t slab_stride, int epi, int out_f32, hipStream_t stream);
 
 // <= 64-row panels: gemm_m64_kernel (a whole CU's LDS per workgroup; fastest alone) or, when off, the LDS-DMA ring (48 KB: leaves room for
 // the workgroups of a concurrent stream).  Consulted at launch / capture time by linear_launch and linear_splitk_launch.

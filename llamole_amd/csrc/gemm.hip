@@ -1478,19 +1478,10 @@ static int launch_pp(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C
 }
 
 static int g_gemm_variant = -1;  // LL_GEMM_VARIANT=0 forces the 2-stage register-staged kernels (A/B testing)
-// ---------------------------------------------------------------- 64-row token panel in LDS x packed weight stream
-// The GraphDiT block GEMMs at 128..1024 token rows (batch 2..16) are bound by what a CU can take in -- about 40 B per clock,
-// a latency x in-flight product (tools/qkv_attn_probe.hip), the same for L2-hot and HBM-cold operands and for 32 or 256
-// workgroups -- not by MFMA.  A 64 x 64 tile of the LDS-DMA ring kernel takes in 2 K (64 + 64) bytes for 4096 outputs; this
-// kernel's workgroup owns 64 token rows x 128 output columns and takes in 2 K (64 + 128) for 8192, a quarter less per output,
-// and none of it passes through the ring (whose depth bounds the bytes in flight):
-//   * the weight comes from a copy packed once in MFMA A-operand order (pack_mfma16: the 16 rows x 32 k block of a fragment is
-//     1 KB contiguous, lane l's 16 bytes at offset 16 l); wave w owns output columns [16 w, 16 w + 16) of the workgroup's 128
-//     and streams its 2 K x 16 bytes contiguously STRAIGHT INTO the operand registers, two blocks of eight k-steps in flight;
-//   * the 64 x K token panel is staged in LDS once (XOR-swizzled 16-byte pieces: conflict-free fragment reads); K = 512 | 1024
-//     per launch slice (split-K over blockIdx.y for longer K: raw f32 slabs, summed in order by the consumer);
-//   * workgroup id = m-tile * (N / 128) + n-group: the m-tiles that share a weight group land on one XCD (one L2 copy), and
-//     they start their K loops at different blocks so that between them the whole group is requested in the first round trip.
+// ---------------------------------------------------------------- weights in MFMA A-operand order
+// pack_mfma16: the 16 rows x 32 k block one fragment instruction consumes becomes 1 KB contiguous (lane l's 16 bytes at offset 16 l),
+// row-tile major: the <= 64-row panel kernels (gemm_m64 / gemm_m128) and qkv_attn_kernel stream such copies straight into operand
+// registers with full-line wave instructions.
 __global__ __launch_bounds__(256) void pack_mfma16_kernel(const bf16_t *__restrict__ W, bf16_t *__restrict__ out, int Nout, int K) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;        // one 16-byte piece per thread
     const int kts = K / 32;
@@ -1509,135 +1500,6 @@ int pack_mfma16(const bf16_t *W, bf16_t *out, int Nout, int K, hipStream_t strea
     hipLaunchKernelGGL(pack_mfma16_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, W, out, Nout, K);
     LL_LAUNCH_CHECK();
     return LL_OK;
-}
-
-template <int KC, typename OutT>
-__global__ __launch_bounds__(512) void gemm_xw_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ Wp, int kts_total,
-                                                      OutT *__restrict__ C, int ldc, const float *__restrict__ bias, int M, int N,
-                                                      int64_t slab_stride, int epi, int ngroups) {
-    constexpr int MT = 4, KPB = 8, XPITCH = 2 * KC, NBLK = KC / (32 * KPB);   // two blocks of eight k-steps in flight per lane (all 32 at once measured slower)
-    constexpr int PPR = KC / 8, XPT = 64 * PPR / 512;                 // 16-byte pieces per panel row / per thread
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm_xw[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ng = blockIdx.x % ngroups, mtile = blockIdx.x / ngroups;
-    const int m0 = mtile * 64, n0 = ng * 128 + wid * 16, kbeg = blockIdx.y * KC;
-    const int fr = lane & 15, fq = lane >> 4;
-    const unsigned char *wtile = reinterpret_cast<const unsigned char *>(Wp) + ((int64_t)(n0 / 16) * kts_total + kbeg / 32) * 1024;   // uniform
-    f32x4 acc[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) acc[i] = (f32x4)(0.f);
-    bf16x8 wa[KPB], wb[KPB];
-    auto loadw = [&](bf16x8 (&r)[KPB], int blk) {
-        const unsigned char *pb = wtile + blk * (KPB * 1024);
-#pragma unroll
-        for (int q = 0; q < KPB; ++q) r[q] = *reinterpret_cast<const bf16x8 *>(pb + lane * 16 + q * 1024);
-    };
-    // fragment (token row mt * 16 + fr, 16-byte piece A + fq) with A a multiple of 4 sits at piece (A ^ (fr & 12)) + (fq ^ (fr & 3))
-    const int flo = fr * XPITCH + ((fq ^ (fr & 3)) << 4), fhi = fr & 12;
-    auto mulblk = [&](const bf16x8 (&r)[KPB], int blk) {
-        const unsigned char *xb = sm_xw + flo + blk * (KPB * 64);
-#pragma unroll
-        for (int ks = 0; ks < KPB; ++ks) {
-            const unsigned char *xk = xb + (((ks * 4) ^ fhi) << 4);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r[ks], *reinterpret_cast<const bf16x8 *>(xk + mt * 16 * XPITCH), acc[mt], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);                            // the loads that follow stay behind these MFMAs, and ahead of the next block's
-    };
-    const int rot = mtile % NBLK;
-    auto blkid = [&](int i) { return (rot + i) % NBLK; };
-    {
-        u4 xr[XPT];
-        const bf16_t *arow = A + (int64_t)m0 * lda + kbeg;
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int pc = tid + i * 512, row = pc / PPR, col = pc % PPR;
-            xr[i] = *reinterpret_cast<const u4 *>(arow + (int64_t)(m0 + row < M ? row : 0) * lda + col * 8);
-        }
-        asm volatile("s_barrier" ::: "memory");                       // every wave's panel pieces are queued ahead of anybody's weight blocks
-        loadw(wa, blkid(0));
-        loadw(wb, blkid(1));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int pc = tid + i * 512, row = pc / PPR, col = pc % PPR;
-            *reinterpret_cast<u4 *>(sm_xw + row * XPITCH + ((col ^ (row & 15)) << 4)) = m0 + row < M ? xr[i] : (u4)(0);
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS writes visible; the weight blocks stay in flight
-#pragma unroll
-    for (int i = 0; i < NBLK - 2; i += 2) {
-        mulblk(wa, blkid(i));
-        loadw(wa, blkid(i + 2));
-        __builtin_amdgcn_sched_barrier(0);
-        mulblk(wb, blkid(i + 1));
-        loadw(wb, blkid(i + 3));
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    mulblk(wa, blkid(NBLK - 2));
-    mulblk(wb, blkid(NBLK - 1));
-    // acc[mt][j] = C[token m0 + mt * 16 + fr][column n0 + fq * 4 + j]
-    const bool raw = gridDim.y > 1;
-    const int col = n0 + fq * 4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias && !raw) bv = *reinterpret_cast<const float4 *>(bias + col);
-    OutT *Cz = C + (int64_t)blockIdx.y * slab_stride;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int row = m0 + mt * 16 + fr;
-        if (row < M) {
-            float o0 = acc[mt][0] + bv.x, o1 = acc[mt][1] + bv.y, o2 = acc[mt][2] + bv.z, o3 = acc[mt][3] + bv.w;
-            if (!raw) {
-                o0 = apply_epi(o0, epi); o1 = apply_epi(o1, epi); o2 = apply_epi(o2, epi); o3 = apply_epi(o3, epi);
-            }
-            if (sizeof(OutT) == 4) {
-                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(Cz) + (int64_t)row * ldc + col) = make_float4(o0, o1, o2, o3);
-            } else {
-                *reinterpret_cast<uint2 *>(reinterpret_cast<bf16_t *>(Cz) + (int64_t)row * ldc + col) =
-                    make_uint2((uint32_t)f32_to_bf16(o0) | ((uint32_t)f32_to_bf16(o1) << 16), (uint32_t)f32_to_bf16(o2) | ((uint32_t)f32_to_bf16(o3) << 16));
-            }
-        }
-    }
-}
-
-// out[M, N] = epi(A[M, K] . W^T + bias) with W given PACKED (pack_mfma16 of the [N, K] weight); splits > 1: `splits` raw f32 slabs.
-// Shapes: K / splits = 512 | 1024, N % 128 == 0, lda % 8 == 0, ldc % 4 == 0.  LL_EINVAL otherwise (the caller falls back).
-bool linear_xw_supported(int M, int N, int K, int splits, int lda, int ldc) {
-    if (splits < 1 || K % splits != 0) return false;
-    const int kc = K / splits;
-    return (kc == 512 || kc == 1024) && N % 128 == 0 && lda % 8 == 0 && ldc % 4 == 0 && M >= 1;
-}
-
-template <int KC>
-static int launch_xw(const bf16_t *A, int lda, const bf16_t *Wp, const float *bias, void *C, int ldc, int M, int N, int K, int splits,
-                     int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
-    constexpr int lds = 64 * 2 * KC;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LL_HIP(hipFuncSetAttribute((const void *)gemm_xw_kernel<KC, float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        LL_HIP(hipFuncSetAttribute((const void *)gemm_xw_kernel<KC, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
-    const int ngroups = N / 128;
-    const dim3 grid(cdiv(M, 64) * ngroups, splits);
-    if (out_f32)
-        hipLaunchKernelGGL((gemm_xw_kernel<KC, float>), grid, dim3(512), lds, s, A, lda, Wp, K / 32, (float *)C, ldc, bias, M, N, slab_stride, epi, ngroups);
-    else
-        hipLaunchKernelGGL((gemm_xw_kernel<KC, bf16_t>), grid, dim3(512), lds, s, A, lda, Wp, K / 32, (bf16_t *)C, ldc, bias, M, N, slab_stride, epi, ngroups);
-    LL_LAUNCH_CHECK();
-    return LL_OK;
-}
-
-int linear_xw_launch(const void *A, int lda, const void *Wp, const float *bias, void *C, int ldc, int M, int N, int K, int splits,
-                     int64_t slab_stride, int epi, int out_f32, hipStream_t stream) {
-    LL_CHECK(linear_xw_supported(M, N, K, splits, lda, ldc), "linear_xw: unsupported shape M=%d N=%d K=%d splits=%d", M, N, K, splits);
-    LL_CHECK(splits == 1 || out_f32, "linear_xw: split-K writes f32 slabs");
-    if (K / splits == 1024)
-        return launch_xw<1024>((const bf16_t *)A, lda, (const bf16_t *)Wp, bias, C, ldc, M, N, K, splits, slab_stride, epi, out_f32, stream);
-    return launch_xw<512>((const bf16_t *)A, lda, (const bf16_t *)Wp, bias, C, ldc, M, N, K, splits, slab_stride, epi, out_f32, stream);
 }
 
 static thread_local int g_no_panel_gemm = 0;  // per host thread; set_panel_gemm(false): <= 64-row panels take the LDS-DMA ring (48 KB of LDS) instead of gemm_m64_kernel
@@ -1922,8 +1784,7 @@ static const PipeCfg g_pipe_cfgs[] = {
 extern "C" int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f32, int iters, int nweights, float *ms) {
     using namespace ll;
     const int ncfg = (int)(sizeof(g_pipe_cfgs) / sizeof(g_pipe_cfgs[0]));
-    LL_CHECK(cfg >= -2 && cfg < ncfg, "cfg %d out of range [-2,%d)", cfg, ncfg);      // -1: the dispatch; -2: gemm_xw_kernel (weights taken as packed)
-    LL_CHECK(cfg != -2 || linear_xw_supported(M, N, K, splits, K, N), "gemm_xw_kernel does not take M=%d N=%d K=%d splits=%d", M, N, K, splits);
+    LL_CHECK(cfg >= -1 && cfg < ncfg, "cfg %d out of range [-1,%d)", cfg, ncfg);      // -1: the dispatch
     LL_CHECK(ms && iters > 0 && nweights > 0 && splits >= 1 && K % (64 * splits) == 0, "bad argument");
     const int Mp = round_up(M, 256);
     bf16_t *A = nullptr, *W = nullptr;
@@ -1948,9 +1809,7 @@ extern "C" int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f
         if (pass == 1) (void)hipEventRecord(e0, st);
         for (int i = 0; i < (pass ? iters : nweights) && rc == LL_OK; ++i) {
             const bf16_t *w = W + (size_t)(i % nweights) * N * K;
-            if (cfg == -2)
-                rc = linear_xw_launch(A, K, w, nullptr, C, N, M, N, K, splits, (int64_t)Mp * N, 0, splits > 1 ? 1 : out_f32, st);
-            else if (cfg < 0)
+            if (cfg < 0)
                 rc = gemm_dispatch(LL_BF16, A, K, w, K, nullptr, C, N, M, N, K, splits, (int64_t)Mp * N, 0, splits > 1 ? 1 : out_f32, st);
             else
                 rc = g_pipe_cfgs[cfg].fn(A, K, w, K, C, N, nullptr, M, N, K, splits, (int64_t)Mp * N, 0, splits > 1 ? 1 : out_f32, st);
@@ -1986,23 +1845,6 @@ extern "C" int ll_linear_cfg(int cfg, const void *A, int lda, const void *W, int
                                splits > 1 ? 1 : out_f32, (hipStream_t)stream));
     LL_LAUNCH_CHECK();
     return LL_OK;
-}
-
-// gemm_xw_kernel on caller-provided row-major operands (tests): packs W [N, K] into a temporary and runs the packed-weight panel GEMM.
-// splits > 1: C receives `splits` raw f32 slabs of M x ldc (slab stride M * ldc), bias / epilogue skipped.
-extern "C" int ll_linear_xw(const void *A, int lda, const void *W, const float *bias, void *C, int ldc, int M, int N, int K, int splits,
-                            int epi, int out_f32, void *stream) {
-    using namespace ll;
-    LL_CHECK(A && W && C, "ll_linear_xw: null operand");
-    LL_CHECK(linear_xw_supported(M, N, K, splits, lda, ldc), "ll_linear_xw: unsupported shape M=%d N=%d K=%d splits=%d", M, N, K, splits);
-    bf16_t *Wp = nullptr;
-    LL_HIP(hipMalloc(&Wp, (size_t)N * K * 2));
-    int rc = pack_mfma16((const bf16_t *)W, Wp, N, K, (hipStream_t)stream);
-    if (rc == LL_OK)
-        rc = linear_xw_launch(A, lda, Wp, bias, C, ldc, M, N, K, splits, (int64_t)M * ldc, epi, splits > 1 ? 1 : out_f32, (hipStream_t)stream);
-    (void)hipStreamSynchronize((hipStream_t)stream);
-    (void)hipFree(Wp);
-    return rc;
 }
 
 namespace ll {

@@ -1559,19 +1559,25 @@ __global__ __launch_bounds__(64) void gin_aggregate_bwd_kernel(const float *__re
     }
 }
 
-// segment-max backward: the gradient of pool[g][k] goes to the FIRST node of graph g holding the maximum of feature k
+// segment-max backward: the gradient of pool[g][k] is shared EVENLY by the nodes of graph g that hold the maximum of feature k -- the
+// backward of torch's scatter_reduce(amax), which is what torch_geometric 2.6.1's global_max_pool runs without torch_scatter (the
+// reference's requirements.txt has none).  Ties are common: atoms with identical k-hop neighbourhoods carry identical features at depth k.
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restrict__ h_in, const int *__restrict__ gptr,
                                                            const float *__restrict__ dpool, float *__restrict__ dh, int H) {
     const int g = blockIdx.x;
     const int v0 = gptr[g], v1 = gptr[g + 1];
     for (int k = blockIdx.y * 256 + threadIdx.x; k < H; k += gridDim.y * 256) {
         float best = -INFINITY;
-        int arg = v0;
+        int ties = 0;
         for (int v = v0; v < v1; ++v) {
             const float x = h_in[(int64_t)v * H + k];
-            if (x > best) { best = x; arg = v; }
+            if (x > best) { best = x; ties = 1; }
+            else if (x == best) ++ties;
         }
-        if (v1 > v0) dh[(int64_t)arg * H + k] += dpool[(int64_t)g * H + k];
+        if (ties == 0) continue;
+        const float share = dpool[(int64_t)g * H + k] / (float)ties;
+        for (int v = v0; v < v1; ++v)
+            if (h_in[(int64_t)v * H + k] == best) dh[(int64_t)v * H + k] += share;
     }
 }
 

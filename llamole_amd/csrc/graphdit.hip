@@ -21,7 +21,6 @@
 #include <vector>
 
 #include "dit_kernels.h"
-#include "dit_team.h"
 
 namespace ll {
 
@@ -199,16 +198,8 @@ struct DitEngine {
     DevBuf wxT;                  // x_embedder weight transposed [F][H] f32
     DevBuf wycat;                // [H][10H] operand dtype
     DevBuf wqkvp;                // [depth][3H x H] q|k|v weights in MFMA A-operand order (pack_mfma16), bf16 mode
-    DevBuf wfc1p, wfc2p;         // [depth][Hm x H], [depth][H x Hm]: the MLP weights packed the same way (gemm_m64_kernel, gemm_xw_kernel)
+    DevBuf wfc1p, wfc2p;         // [depth][Hm x H], [depth][H x Hm]: the MLP weights packed the same way (gemm_m64_kernel)
     DevBuf wprojp;               // [depth][H x H]
-    DevBuf wout1p, wout2p;       // output layer weights in the same order (dit_team.h)
-    DevBuf team_ctl;             // team::Ctl of the persistent trajectory kernel
-    DevBuf team_ctl2;            // team::Ctl2 of proj_ln_team_kernel (zeroed once: the kernel leaves it clean)
-    bool proj_ln_used = false;   // some launch of this engine went through proj_ln_team_kernel (its error word is read by ll_dit_last_run_ms)
-    int proj_ln_team = 0;        // attention projection + AdaLN epilogue as ONE launch on per-XCD teams: 0 = never (default: measured slower, 15.3 vs 9.5 + 5.1 us), 1 = whenever eligible
-    int team_mode = 0;           // dit_team_kernel (opt-in: measured slower than the launch chain at every batch): 0 = never (default),
-                                 // -1 = under ll_dit_run whenever eligible and not in overlap mode, 1 = also under the single-step entry points
-                                 // (step / denoise / step_probs: the parity taps of the team path)
     // in-situ kernel timing (ll_dit_class_probe): HIP events around every launch of ONE class of the block's kernels inside a real trajectory
     int time_class = -1;
     int time_mode = 0;           // 0 = the pair brackets the launch; LL_DIT_PROBE_EMPTY = an EMPTY pair is recorded at the launch site (what a pair
@@ -216,18 +207,7 @@ struct DitEngine {
                                  // results are meaningless; its run time against a normal one is the class's marginal cost inside the step)
     std::vector<hipEvent_t> tev;
     size_t tev_n = 0;
-    int team_last = 0;           // the last denoiser call ran on the team kernel
-    int team_step_s = -1;        // the reverse step the single-step entry points are about to run (the team kernel takes it as an argument)
     std::vector<const void *> packed_keys;   // row-major weights registered with register_packed_weight
-    int xw_gemm = 0;             // fc1 / fc2 on gemm_xw_kernel: 0 = never (the fixed default: a seed fixes the molecules on every box), 1 = whenever
-                                 // eligible, -1 = whichever ll_dit_begin measures faster on this device (opt-in: env LL_DIT_CALIBRATE=1 or
-                                 // ll_dit_set_option(LL_DIT_OPT_XW_GEMM, -1); the alternatives sum K in different orders, so the choice changes low-order bits)
-    int splits_x = 1;            // split-K of fc2 on gemm_xw_kernel (K slices of 512 | 1024)
-    int xw_fc2 = 0;              // with xw_gemm = 1: fc2 too (env LL_XW_FC2)
-    int xw_cal_B = -1;           // batch the choice below was measured for (ll_dit_begin measures once per batch size)
-    std::unordered_map<int, std::pair<bool, bool>> xw_cal_cache;   // batch -> (fc1 on the panel kernel, fc2 on the panel kernel)
-    float cal_us[4] = {0, 0, 0, 0};  // us per fc1 -> fc2 -> AdaLN chain at the last calibration: ring/ring | panel/ring | ring/panel | panel/panel
-    bool xw_fc1_auto = false, xw_fc2_auto = false;   // xw_gemm = -1: gemm_xw_kernel beat the LDS-DMA ring on THIS device at this batch
     DevBuf yw0, yb0;             // packed [10][H] f32
     DevBuf tables;               // x_marg16 e_marg8 u_xe80 u_ex80 betas[T+1] alphas_bar[T+1]
     // per-batch
@@ -406,22 +386,6 @@ static int qkv_attn_mode(const DitEngine *e) {
     return wgs <= g_fuse_qkv_max_wgs ? 1 : 0;
 }
 static bool qkv_attn_wanted(const DitEngine *e) { return qkv_attn_mode(e) != 0; }
-// MLP of the block on the packed-weight panel GEMM (gemm.hip gemm_xw_kernel): fc1 with K = H in one slice, fc2 split over K
-static int xw_slice(int K) { return K % 1024 == 0 ? 1024 : 512; }
-static bool xw_eligible(const DitEngine *e) {
-    const int H = e->d.Hp, Hm = e->d.Hmp;
-    if (e->cfg.dtype != LL_BF16 || (H != 512 && H != 1024) || Hm % 512 != 0) return false;
-    const int sp = Hm / xw_slice(Hm);
-    return (sp == 1 || sp == 2 || sp == 4 || sp == 8) && Hm % 128 == 0 && H % 128 == 0;
-}
-static bool xw_fc1_wanted(const DitEngine *e) {
-    if (e->wfc1p.p == nullptr || !xw_eligible(e) || e->xw_gemm == 0) return false;
-    return e->xw_gemm == 1 || (e->xw_cal_B == e->B && e->xw_fc1_auto);
-}
-static bool xw_fc2_wanted(const DitEngine *e) {
-    if (e->wfc1p.p == nullptr || !xw_eligible(e) || e->xw_gemm == 0) return false;
-    return e->xw_gemm == 1 ? e->xw_fc2 != 0 : (e->xw_cal_B == e->B && e->xw_fc2_auto);
-}
 static void launch_qkv_attn(DitEngine *e, int layer, hipStream_t st) {
     const DitEngine::BlockW &w = e->bw[layer];
     const int N = e->cfg.max_nodes;
@@ -524,126 +488,11 @@ static int pick_splits(int M2, int H, int K) {
     return s;
 }
 
-// ------------------------------------------------------------------------------------------ persistent trajectory kernel (dit_team.h)
-static bool team_eligible(const DitEngine *e) {
-    const LLDitConfig &c = e->cfg;
-    const int N = c.max_nodes, F = LL_XDIM + LL_EDIM * N;
-    return c.dtype == LL_BF16 && c.hidden == 1024 && c.heads * 64 == c.hidden && c.mlp_hidden == 4 * c.hidden &&
-           N <= team::NP && F % 16 == 0 && e->wqkvp.p && e->wprojp.p && e->wfc1p.p && e->wfc2p.p && e->wout1p.p && e->wout2p.p && e->rowvec == nullptr;
-}
-static bool team_wanted(const DitEngine *e, bool trajectory) {
-    static const bool in_overlap = getenv("LL_DIT_TEAM_OVERLAP") && atoi(getenv("LL_DIT_TEAM_OVERLAP")) != 0;      // A/B switch: the persistent kernel next to the LLM decode
-    if (e->team_mode == 0 || (e->overlap && !in_overlap) || !team_eligible(e)) return false;
-    return trajectory || e->team_mode == 1;
-}
-// proj + ln_mod_res of block `layer` as one launch (dit_team.h: proj_ln_team_kernel): bf16, hidden 1024, graphs of <= 32 nodes (a multiple
-// of 4), not next to another stream's kernels (its 256 workgroups want one CU each), not the per-graph-timestep training forward.
-// Opt-in (LL_DIT_OPT_PROJ_LN): measured 15.3 us per launch at batch 8 against 9.5 + 5.1 us of the two launches it replaces (HISTORY.md R4.4)
-static bool proj_ln_team_wanted(const DitEngine *e) {
-    const LLDitConfig &c = e->cfg;
-    if (e->proj_ln_team == 0 || c.dtype != LL_BF16 || c.hidden != 1024 || c.max_nodes > team::NP || c.max_nodes % 4 != 0 || e->overlap ||
-        e->rowvec != nullptr || e->wprojp.p == nullptr || e->team_ctl2.p == nullptr)
-        return false;
-    return true;
-}
-static int launch_proj_ln_team(DitEngine *e, int layer, const float *modrows, hipStream_t st) {
-    constexpr int H = 1024;
-    constexpr int lds = team::Geom<H>::PANEL + team::FLAG_BYTES;
-    static bool attr = false;
-    if (!attr) {
-        LL_HIP(hipFuncSetAttribute((const void *)team::proj_ln_team_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
-    team::ProjLnArgs p;
-    p.B = e->B; p.N = e->cfg.max_nodes; p.L = e->cfg.depth; p.layer = layer;
-    p.ao = e->attn_o.as<bf16_t>();
-    p.wproj = e->wprojp.as<bf16_t>() + (size_t)layer * H * H;
-    p.bias = e->bw[layer].proj_b;
-    p.modrows = modrows;
-    p.y = e->ybuf.as<float>(); p.x32 = e->x32.as<float>(); p.xa = e->xa.as<bf16_t>();
-    p.ctl = e->team_ctl2.as<team::Ctl2>();
-    e->proj_ln_used = true;
-    hipLaunchKernelGGL((team::proj_ln_team_kernel<H>), dim3(8 * team::TEAM), dim3(team::THREADS), lds, st, p);
-    return LL_OK;
-}
-
-template <int H> static int team_launch_t(DitEngine *e, const team::Args &a, hipStream_t st) {
-    constexpr int lds = team::Geom<H>::PANEL + team::FLAG_BYTES;
-    static bool attr = false;
-    if (!attr) {
-        LL_HIP(hipFuncSetAttribute((const void *)team::dit_team_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
-    hipLaunchKernelGGL((team::dit_team_kernel<H>), dim3(8 * team::TEAM), dim3(team::THREADS), lds, st, a);
-    LL_LAUNCH_CHECK();
-    return LL_OK;
-}
-// reverse steps s_first, s_first - 1, ... (n_steps) of every graph of the batch; run_post = 0 stops after the output layer (e->outF holds the
-// decoder output, as after denoise_body)
-static int team_launch(DitEngine *e, int s_first, int n_steps, int run_post, const float *qx, const float *qe, hipStream_t st) {
-    const LLDitConfig &c = e->cfg;
-    const int H = c.hidden;
-    LL_TRY(e->team_ctl.ensure(sizeof(team::Ctl)));
-    LL_HIP(hipMemsetAsync(e->team_ctl.p, 0, sizeof(team::Ctl), st));
-    team::Args a;
-    memset(&a, 0, sizeof(a));
-    a.B = e->B; a.N = c.max_nodes; a.F = e->F; a.T = c.T; a.L = c.depth; a.heads = c.heads;
-    a.s_first = s_first; a.n_steps = n_steps; a.run_post = run_post; a.guide = c.guide_scale;
-    a.wqkv = e->wqkvp.as<bf16_t>(); a.wproj = e->wprojp.as<bf16_t>(); a.wfc1 = e->wfc1p.as<bf16_t>(); a.wfc2 = e->wfc2p.as<bf16_t>();
-    a.wout1 = e->wout1p.as<bf16_t>(); a.wout2 = e->wout2p.as<bf16_t>();
-    const DitEngine::BlockW &b0 = e->bw[0];
-    a.proj_b = b0.proj_b; a.fc1_b = b0.fc1_b; a.fc2_b = b0.fc2_b; a.qn_w = b0.qn_w; a.qn_b = b0.qn_b; a.kn_w = b0.kn_w; a.kn_b = b0.kn_b;
-    a.blk_stride = c.depth > 1 ? (int64_t)(e->bw[1].proj_b - b0.proj_b) : 0;
-    a.out1_b = e->b_out1; a.out2_b = e->b_out2; a.WxT = e->wxT.as<float>(); a.xe_w = e->xe_w; a.xe_b = e->xe_b;
-    a.modtab = e->modtab.as<float>(); a.modo = e->modo.as<float>();
-    a.x32 = e->x32.as<float>(); a.xa = e->xa.as<bf16_t>(); a.qkv = e->qkv.as<bf16_t>(); a.ao = e->attn_o.as<bf16_t>();
-    a.h1 = e->h1.as<bf16_t>(); a.ho = e->ho.as<bf16_t>(); a.ybuf = e->ybuf.as<float>(); a.slab_stride = (int64_t)e->M2p * H; a.outF = e->outF.as<float>();
-    PostArgs &p = a.post;
-    p.out = e->outF.as<float>(); p.modo = e->modo.as<float>(); p.predX = e->predX.as<float>(); p.pxe = e->pxe.as<float>();
-    p.X = e->X.as<int8_t>(); p.E = e->E.as<int8_t>(); p.n_nodes = e->n_nodes.as<int>();
-    p.x_marg = e->t_xm(); p.e_marg = e->t_em(); p.u_xe = e->t_uxe(); p.u_ex = e->t_uex(); p.betas = e->t_beta(); p.alphas_bar = e->t_ab();
-    p.qx = qx; p.qe = qe; p.seed_ptr = e->seed_ptr(); p.step_ptr = e->step_scalar(); p.rowvec = nullptr;
-    p.B = e->B; p.N = c.max_nodes; p.F = e->F; p.T = c.T; p.guide = c.guide_scale;
-    p.pX_out = nullptr; p.pE_out = nullptr; p.logX = nullptr; p.logE = nullptr; p.update_state = 1;
-    a.ctl = e->team_ctl.as<team::Ctl>();
-    e->team_last = 1;
-    LL_CHECK(H == 1024, "dit_team_kernel is instantiated for hidden = 1024");
-    return team_launch_t<1024>(e, a, st);
-}
-// after the stream has drained: did every team complete?
-static int team_check(DitEngine *e) {
-    team::Ctl h;
-    LL_HIP(hipMemcpy(&h, e->team_ctl.p, sizeof(h), hipMemcpyDeviceToHost));
-#ifdef LL_TEAM_PROBE
-    {
-        static const char *names[] = {"stage qkv", "K loop qkv (A..B)", "copy qkv", "barrier", "attention", "barrier", "stage proj", "K loop proj", "copy proj",
-                                      "barrier", "LN1", "barrier", "stage fc1", "K loop fc1", "copy fc1", "barrier", "stage fc2", "K loop fc2", "copy fc2",
-                                      "barrier", "LN2", "barrier"};
-        fprintf(stderr, "LL_TEAM_PROBE block 3 of the first step, us:");
-        for (int i = 0; i < 22; ++i) fprintf(stderr, " %s %.2f |", names[i], (double)(h.stamps[i + 1] - h.stamps[i]) / 100.0);
-        fprintf(stderr, " total %.2f\n", (double)(h.stamps[22] - h.stamps[0]) / 100.0);
-    }
-#endif
-    if (h.error) {
-        set_error("dit_team_kernel: %s%s (census %u %u %u %u %u %u %u %u)", (h.error & 1) ? "a bounded wait ran out " : "",
-                  (h.error & 2) ? "more than 32 workgroups reported on one XCC" : "", h.census[0][0], h.census[1][0], h.census[2][0],
-                  h.census[3][0], h.census[4][0], h.census[5][0], h.census[6][0], h.census[7][0]);
-        return LL_EHIP;
-    }
-    return LL_OK;
-}
-
 // denoiser on the current state for both passes -> e->outF [2][B][N][F] (decoder output before LN0/modulate)
 static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap_layer) {
     const LLDitConfig &c = e->cfg;
     const int H = e->d.Hp, Hm = e->d.Hmp, Ha = e->d.Ha, M2 = e->M2, dt = c.dtype;      // row pitches (multiples of 64)
     const bool bf = dt == LL_BF16;
-    e->team_last = 0;
-    if (e->team_step_s >= 0 && hidden_tap == nullptr && team_wanted(e, false)) {    // parity taps of the team path: one step, posterior by the launch chain's kernels
-        LL_TRY(team_launch(e, e->team_step_s, 1, 0, nullptr, nullptr, st));
-        LL_HIP(hipStreamSynchronize(st));                                               // (test entry points: report a protocol error at once)
-        return team_check(e);
-    }
     if (e->rowvec == nullptr && g_stage_mod && e->step_host < 0) {
         const int64_t row_floats = (int64_t)(e->B + 1) * c.depth * 6 * H;
         hipLaunchKernelGGL(stage_mod_kernel, dim3(256), dim3(256), 0, st, e->modtab.as<float>(), e->modcur.as<float>(), e->step_ptr(), row_floats);
@@ -653,9 +502,7 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
     if (hidden_tap && tap_layer == 0)
         LL_HIP(hipMemcpy2DAsync(hidden_tap, (size_t)e->d.Ht * 4, e->x32.p, (size_t)H * 4, (size_t)e->d.Ht * 4, M2, hipMemcpyDeviceToDevice, st));
     const int64_t slab = (int64_t)e->M2p * H;
-    const bool fused_qkv = qkv_attn_wanted(e), xw = xw_fc1_wanted(e), xw2 = xw_fc2_wanted(e);
-    // (captured steps read the step's modulation rows from the staged copy, which exists only with g_stage_mod)
-    const bool use_proj_ln = proj_ln_team_wanted(e) && (e->step_host >= 0 || g_stage_mod);
+    const bool fused_qkv = qkv_attn_wanted(e);
     for (int l = 0; l < c.depth; ++l) {
         const DitEngine::BlockW &w = e->bw[l];
         if (fused_qkv) {
@@ -670,46 +517,30 @@ static int denoise_body(DitEngine *e, hipStream_t st, float *hidden_tap, int tap
             if (bf) launch_attn<bf16_t>(e, l, st); else launch_attn<float>(e, l, st);
         }
         LL_LAUNCH_CHECK();
-        const float *pl_rows = !use_proj_ln ? nullptr
-                               : e->step_host >= 0 ? e->modtab.as<float>() + (int64_t)e->step_host * (e->B + 1) * c.depth * 6 * H
-                                                   : e->modcur.as<float>();
-        if (use_proj_ln) {
-            ClassTimer tm(e, LL_DIT_CLS_PROJ, st);
-            LL_TRY(launch_proj_ln_team(e, l, pl_rows, st));
-        } else {
+        {
             ClassTimer tm(e, LL_DIT_CLS_PROJ, st);
             if (e->splits_h > 1)
                 LL_TRY(linear_splitk_launch(dt, e->attn_o.p, Ha, w.proj, Ha, e->ybuf.as<float>(), H, slab, M2, H, Ha, e->splits_h, st));
             else
                 LL_TRY(linear_launch(dt, e->attn_o.p, Ha, w.proj, Ha, nullptr, e->ybuf.p, H, M2, H, Ha, 0, 1, st));
         }
-        if (!use_proj_ln) {
+        {
             ClassTimer tm(e, LL_DIT_CLS_LNMOD, st);
             if (bf) launch_lnmod<bf16_t>(e, l, 0, e->splits_h, w.proj_b, st);
             else launch_lnmod<float>(e, l, 0, e->splits_h, w.proj_b, st);
         }
         LL_LAUNCH_CHECK();
-        int nslab_m = e->splits_m;
+        const int nslab_m = e->splits_m;
         {
             ClassTimer tm(e, LL_DIT_CLS_FC1, st);
-            if (!tm.run()) {
-            } else if (xw) {
-                LL_TRY(linear_xw_launch(e->xa.p, H, e->wfc1p.as<bf16_t>() + (size_t)l * Hm * H, w.fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, 1, 0, st));
-            } else {
-                LL_TRY(linear_launch(dt, e->xa.p, H, w.fc1, H, w.fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, st));
-            }
+            if (tm.run()) LL_TRY(linear_launch(dt, e->xa.p, H, w.fc1, H, w.fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, st));
         }
         {
             ClassTimer tm(e, LL_DIT_CLS_FC2, st);
-            if (xw2) {
-                LL_TRY(linear_xw_launch(e->h1.p, Hm, e->wfc2p.as<bf16_t>() + (size_t)l * Hm * H, nullptr, e->ybuf.p, H, M2, H, Hm, e->splits_x, slab, 0, 1, st));
-                nslab_m = e->splits_x;
-            } else {
-                if (e->splits_m > 1)
-                    LL_TRY(linear_splitk_launch(dt, e->h1.p, Hm, w.fc2, Hm, e->ybuf.as<float>(), H, slab, M2, H, Hm, e->splits_m, st));
-                else
-                    LL_TRY(linear_launch(dt, e->h1.p, Hm, w.fc2, Hm, nullptr, e->ybuf.p, H, M2, H, Hm, 0, 1, st));
-            }
+            if (e->splits_m > 1)
+                LL_TRY(linear_splitk_launch(dt, e->h1.p, Hm, w.fc2, Hm, e->ybuf.as<float>(), H, slab, M2, H, Hm, e->splits_m, st));
+            else
+                LL_TRY(linear_launch(dt, e->h1.p, Hm, w.fc2, Hm, nullptr, e->ybuf.p, H, M2, H, Hm, 0, 1, st));
         }
         {
             ClassTimer tm(e, LL_DIT_CLS_LNMOD, st);
@@ -915,7 +746,7 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
     if (cfg->dtype == LL_BF16) {
         // MFMA-operand-order copies of the MLP and proj weights: the batch-1 panel GEMM (gemm_m64_kernel) reads fragments from them
         const int Hm = e->d.Hmp, Ha = e->d.Ha;
-        const size_t per = (size_t)Hm * H, perh = (size_t)H * Ha, perh1 = (size_t)H * H;
+        const size_t per = (size_t)Hm * H, perh = (size_t)H * Ha;
         CR(e->wfc1p.ensure(per * cfg->depth * 2));
         CR(e->wfc2p.ensure(per * cfg->depth * 2));
         CR(e->wprojp.ensure(perh * cfg->depth * 2));
@@ -933,21 +764,7 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
             reg(p + "attn.proj.weight", e->wprojp.as<bf16_t>() + perh * l);
             if (e->wqkvp.p) reg(p + "attn.qkv.weight", e->wqkvp.as<bf16_t>() + (size_t)3 * H * H * l);
         }
-        if (xw_eligible(e)) e->splits_x = Hm / xw_slice(Hm);
-        if (e->F % 16 == 0) {      // output layer in the same order: the persistent trajectory kernel streams it (dit_team.h)
-            CR(e->wout1p.ensure(perh1 * 2));
-            CR(e->wout2p.ensure((size_t)e->F * H * 2));
-            CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw("output_layer.xedecoder.fc1.weight")), e->wout1p.as<bf16_t>(), H, H, 0));
-            CR(pack_mfma16(reinterpret_cast<const bf16_t *>(e->pw("output_layer.xedecoder.fc2.weight")), e->wout2p.as<bf16_t>(), e->F, H, 0));
-        }
     }
-    if (const char *v = getenv("LL_DIT_TEAM")) e->team_mode = atoi(v) < 0 ? -1 : (atoi(v) ? 1 : 0);
-    CR(e->team_ctl2.ensure(sizeof(team::Ctl2)));
-    CRH(hipMemset(e->team_ctl2.p, 0, sizeof(team::Ctl2)));          // once: proj_ln_team_kernel leaves its counters zeroed
-    if (const char *v = getenv("LL_DIT_PROJ_LN")) e->proj_ln_team = atoi(v) ? 1 : 0;
-    if (const char *v = getenv("LL_DIT_CALIBRATE")) e->xw_gemm = atoi(v) ? -1 : 0;
-    if (const char *v = getenv("LL_XW_GEMM")) e->xw_gemm = atoi(v);
-    if (const char *v = getenv("LL_XW_FC2")) e->xw_fc2 = atoi(v) ? 1 : 0;
     e->force_generic_attn = getenv("LL_GENERIC_ATTN") != nullptr;
     if (const char *v = getenv("LL_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v);
     if (const char *v = getenv("LL_FUSE_PAIR_WGS")) g_fuse_qkv_pair_wgs = atoi(v);
@@ -973,7 +790,7 @@ int ll_dit_destroy(void *handle) {
     DevBuf *bufs[] = {&e->wop, &e->wxT, &e->wycat, &e->yw0, &e->yb0, &e->tables, &e->n_nodes, &e->X, &e->E, &e->x32,
                       &e->xa, &e->qkv, &e->attn_o, &e->ybuf, &e->h1, &e->ho, &e->outF, &e->ct_in, &e->ct_h, &e->ct,
                       &e->zy, &e->cy, &e->txt_op, &e->ctxt, &e->ynan, &e->tnan, &e->c32, &e->ca, &e->m1, &e->modtab,
-                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wpad, &e->wqkvp, &e->wfc1p, &e->wfc2p, &e->wprojp, &e->steps_tab, &e->wout1p, &e->wout2p, &e->team_ctl, &e->team_ctl2};
+                      &e->modo, &e->scal, &e->predX, &e->pxe, &e->rows, &e->modcur, &e->wpad, &e->wqkvp, &e->wfc1p, &e->wfc2p, &e->wprojp, &e->steps_tab};
     for (const void *k : e->packed_keys) register_packed_weight(k, nullptr);
     for (DevBuf *b : bufs) b->release();
     if (e->own) (void)hipStreamDestroy(e->own);
@@ -983,79 +800,6 @@ int ll_dit_destroy(void *handle) {
     if (e->ev_t1) (void)hipEventDestroy(e->ev_t1);
     for (hipEvent_t ev : e->tev) (void)hipEventDestroy(ev);
     delete e;
-    return LL_OK;
-}
-
-// OPT-IN (xw_gemm == -1: env LL_DIT_CALIBRATE=1 or ll_dit_set_option(LL_DIT_OPT_XW_GEMM, -1)); by default the MLP GEMMs run the LDS-DMA ring
-// on every device, no stopwatch is consulted and ll_dit_begin never blocks the host -- a kernel choice made by timing would let the same seed
-// give different molecules in two processes (the alternatives accumulate K in different orders).
-// Which MLP GEMM kernels for this batch on THIS device?  The LDS-DMA ring and the packed-weight panel kernel trade places from one MI355X
-// box to the next (same image, same clocks reported): fc1 at 512 rows 11.4 vs 10.4 us on most, 16.7-19 vs 10.5 on some -- so the
-// engine times both once per batch size (one pass over every layer's weights per variant, ~4 ms in all) and keeps the fastest pair.
-// The activation buffers hold no state yet at this point (ll_dit_begin precedes ll_dit_init_state).
-static int calibrate_mlp(DitEngine *e, hipStream_t st) {
-    const LLDitConfig &c = e->cfg;
-    const int H = e->d.Hp, Hm = e->d.Hmp, M2 = e->M2, dt = c.dtype;
-    e->xw_cal_B = e->B;
-    e->xw_fc1_auto = e->xw_fc2_auto = false;
-    if (e->xw_gemm != -1 || dt != LL_BF16 || e->wfc1p.p == nullptr || !xw_eligible(e) || M2 < 128) {
-        for (float &u : e->cal_us) u = 0.f;      // nothing was timed for this batch
-        return LL_OK;
-    }
-    auto hit = e->xw_cal_cache.find(e->B);
-    if (hit != e->xw_cal_cache.end()) {
-        e->xw_fc1_auto = hit->second.first;
-        e->xw_fc2_auto = hit->second.second;
-        return LL_OK;
-    }
-    const int64_t slab = (int64_t)e->M2p * H;
-    PanelScope panel(e);      // time the kernels the run will use (overlap mode keeps <= 64-row panels off gemm_m64_kernel)
-    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), 0, e->seed_ptr(), 0ull);
-    auto timeit = [&](auto &&fn, float &us) -> int {
-        for (int i = 0; i < 2; ++i) LL_TRY(fn(i % c.depth));
-        LL_HIP(hipEventRecord(e->ev_t0, st));
-        const int reps = std::max(8, c.depth);      // once over every layer: the weights must come from HBM as in the step, not from the Infinity Cache
-        for (int i = 0; i < reps; ++i) LL_TRY(fn((i + 2) % c.depth));
-        LL_HIP(hipEventRecord(e->ev_t1, st));
-        LL_HIP(hipEventSynchronize(e->ev_t1));
-        float ms = 0.f;
-        LL_HIP(hipEventElapsedTime(&ms, e->ev_t0, e->ev_t1));
-        us = ms * 1000.f / reps;
-        return LL_OK;
-    };
-    // the whole MLP chain fc1 -> fc2 -> AdaLN epilogue (which rewrites the panel fc1 reads next): every GEMM meets its input as fresh as
-    // inside the step -- timed alone on a resident panel the panel kernel looks ~10 % better than it is there
-    auto chain = [&](bool x1, bool x2) {
-        return [=, &e](int l) -> int {
-            const DitEngine::BlockW &w = e->bw[l];
-            if (x1) LL_TRY(linear_xw_launch(e->xa.p, H, e->wfc1p.as<bf16_t>() + (size_t)l * Hm * H, w.fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, 1, 0, st));
-            else LL_TRY(linear_launch(dt, e->xa.p, H, w.fc1, H, w.fc1_b, e->h1.p, Hm, M2, Hm, H, 1, 0, st));
-            int ns = e->splits_m;
-            if (x2) {
-                LL_TRY(linear_xw_launch(e->h1.p, Hm, e->wfc2p.as<bf16_t>() + (size_t)l * Hm * H, nullptr, e->ybuf.p, H, M2, H, Hm, e->splits_x, slab, 0, 1, st));
-                ns = e->splits_x;
-            } else if (e->splits_m > 1) {
-                LL_TRY(linear_splitk_launch(dt, e->h1.p, Hm, w.fc2, Hm, e->ybuf.as<float>(), H, slab, M2, H, Hm, e->splits_m, st));
-            } else {
-                LL_TRY(linear_launch(dt, e->h1.p, Hm, w.fc2, Hm, nullptr, e->ybuf.p, H, M2, H, Hm, 0, 1, st));
-            }
-            launch_lnmod<bf16_t>(e, l, 1, ns, w.fc2_b, st);
-            return (int)LL_OK;
-        };
-    };
-    float rr = 0, xr = 0, rx = 0, xx = 0;      // ring/ring, panel/ring, ring/panel, panel/panel
-    LL_TRY(timeit(chain(false, false), rr));
-    LL_TRY(timeit(chain(true, false), xr));
-    LL_TRY(timeit(chain(false, true), rx));
-    LL_TRY(timeit(chain(true, true), xx));
-    // 3 % in favour of the ring pair (run-to-run noise of the measurement); on the boxes where the ring is slow the margin is 10 % and more
-    float best = rr * 0.97f;
-    if (xr < best) { best = xr; e->xw_fc1_auto = true; e->xw_fc2_auto = false; }
-    if (rx < best) { best = rx; e->xw_fc1_auto = false; e->xw_fc2_auto = true; }
-    if (xx < best) { best = xx; e->xw_fc1_auto = true; e->xw_fc2_auto = true; }
-    e->xw_cal_cache[e->B] = std::make_pair(e->xw_fc1_auto, e->xw_fc2_auto);
-    const float ring1 = rr, xw1 = xr, ring2 = rx, xw2 = xx;
-    e->cal_us[0] = ring1; e->cal_us[1] = xw1; e->cal_us[2] = ring2; e->cal_us[3] = xw2;
     return LL_OK;
 }
 
@@ -1073,8 +817,7 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
     e->M2p = round_up(e->M2, 128);
     e->splits_h = pick_splits(e->M2, H, Ha);
     e->splits_m = pick_splits(e->M2, H, Hm);
-    // (the persistent trajectory kernel writes four K-part slabs for proj and fc2 at any batch)
-    const int smax = std::max(std::max(std::max(e->splits_h, e->splits_m), e->splits_x), 4);
+    const int smax = std::max(e->splits_h, e->splits_m);
     const int Mc = (T + 1) * (B + 1), Mcp = round_up(Mc, 128);   // rows 0..T-1: reverse steps (t = s+1); row T: t = 0 (training)
     const int Tp = round_up(T + 1, 128), Bp = round_up(B, 128);
     const size_t M2p = e->M2p;
@@ -1113,11 +856,6 @@ int ll_dit_begin(void *handle, int B, const float *props, const float *text, con
     for (size_t i = 0; i < sizeof(oldp) / sizeof(oldp[0]); ++i)
         if (oldp[i] != newp[i]) { drop_graph(e); break; }
 
-    if (e->xw_cal_B != B) {
-        const bool f1 = e->xw_fc1_auto, f2 = e->xw_fc2_auto;
-        LL_TRY(calibrate_mlp(e, st));
-        if (f1 != e->xw_fc1_auto || f2 != e->xw_fc2_auto) drop_graph(e);
-    }
     LL_HIP(hipMemcpyAsync(e->n_nodes.p, n_nodes, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     // ---- c_t for every step: sinusoid -> Linear(256,H)+SiLU -> Linear(H,H)          (conditions.py:53-58)
     if (bf) hipLaunchKernelGGL((tfreq_kernel<bf16_t>), dim3(T + 1), dim3(128), 0, st, e->ct_in.as<bf16_t>(), T);
@@ -1206,10 +944,7 @@ int ll_dit_step(void *handle, int s, const float *qx, const float *qe, uint64_t 
     LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), s, e->seed_ptr(), (unsigned long long)seed);
     LL_LAUNCH_CHECK();
-    e->team_step_s = s;
-    const int rc_body = denoise_body(e, st, nullptr, -1);
-    e->team_step_s = -1;
-    LL_TRY(rc_body);
+    LL_TRY(denoise_body(e, st, nullptr, -1));
     LL_TRY(posterior_launch(e, qx, qe, 1, nullptr, nullptr, nullptr, nullptr, st));
     e->state_half = s & 1;
     e->state_both = false;
@@ -1224,10 +959,7 @@ int ll_dit_denoise(void *handle, int s, float *logX, float *logE, float *hidden,
     PanelScope panel(e);
     LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), s, e->seed_ptr(), 0ull);
-    e->team_step_s = s;
-    const int rc_body = denoise_body(e, st, hidden, tap_layer);
-    e->team_step_s = -1;
-    LL_TRY(rc_body);
+    LL_TRY(denoise_body(e, st, hidden, tap_layer));
     return posterior_launch(e, nullptr, nullptr, 0, nullptr, nullptr, logX, logE, st);
 }
 
@@ -1259,10 +991,7 @@ int ll_dit_step_probs(void *handle, int s, float *pX, float *pE, void *stream) {
     PanelScope panel(e);
     LL_TRY(ensure_state_half(e, (s + 1) & 1, st));
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), s, e->seed_ptr(), 0ull);
-    e->team_step_s = s;
-    const int rc_body = denoise_body(e, st, nullptr, -1);
-    e->team_step_s = -1;
-    LL_TRY(rc_body);
+    LL_TRY(denoise_body(e, st, nullptr, -1));
     return posterior_launch(e, nullptr, nullptr, 0, pX, pE, nullptr, nullptr, st);
 }
 
@@ -1292,22 +1021,6 @@ int ll_dit_run(void *handle, uint64_t seed, int use_graph, void *stream) {
     // workgroups need a whole CU's LDS and keep that stream's workgroups off the CU (and wait for a drained CU themselves), so the
     // panel GEMMs take the 48 KB LDS-DMA ring there: 1.36 instead of 1.17 ms per step alone, but +1.2 % molecules/s end to end
     PanelScope panel(e);      // restored on every exit path: other engines / the GIN path keep the panel kernel
-    if (team_wanted(e, true)) {
-        // the whole trajectory is ONE launch of the persistent per-XCD kernel (dit_team.h); the step index and the state halves are
-        // walked inside it exactly as the launch loop below walks them
-        LL_HIP(hipEventRecord(e->ev_t0, st));
-        LL_TRY(team_launch(e, T - 1, T, 1, nullptr, nullptr, st));
-        hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, e->step_scalar(), -1, e->seed_ptr(), (unsigned long long)seed);
-        LL_HIP(hipEventRecord(e->ev_t1, st));
-        e->last_steps = T;
-        e->timed = true;
-        e->state_half = 0;
-        e->state_both = false;
-        LL_HIP(hipEventRecord(e->ev_out, st));
-        LL_HIP(hipStreamWaitEvent(caller, e->ev_out, 0));
-        return LL_OK;
-    }
-    e->team_last = 0;
     if (use_graph == LL_DIT_RUN_AUTO) {      // env LL_DIT_RUN_MODE = graph | launches overrides the library's choice (e.g. a host too busy to feed launches)
         static const int forced = [] {
             const char *v = getenv("LL_DIT_RUN_MODE");
@@ -1384,29 +1097,8 @@ int ll_dit_set_option(void *handle, int option, int value) {
             if (e->fuse_qkv_attn != value) drop_graph(e);
             e->fuse_qkv_attn = value < 0 ? -1 : (value >= 2 ? 2 : value ? 1 : 0);
             break;
-        case LL_DIT_OPT_XW_GEMM:
-            if (e->xw_gemm != value) {
-                drop_graph(e);
-                e->xw_cal_B = -1;        // the next ll_dit_begin looks the per-device choice up (or measures it) again
-            }
-            e->xw_gemm = value < 0 ? -1 : (value ? 1 : 0);
-            break;
-        case LL_DIT_OPT_TEAM: e->team_mode = value < 0 ? -1 : (value ? 1 : 0); break;
-        case LL_DIT_OPT_PROJ_LN:
-            if (e->proj_ln_team != (value ? 1 : 0)) drop_graph(e);
-            e->proj_ln_team = value ? 1 : 0;
-            break;
         default: LL_CHECK(false, "ll_dit_set_option: unknown option %d", option);
     }
-    return LL_OK;
-}
-
-int ll_dit_mlp_choice(void *handle, float *us4, int *xw_fc1, int *xw_fc2) {
-    DitEngine *e = (DitEngine *)handle;
-    LL_CHECK(e, "ll_dit_mlp_choice: null handle");
-    if (us4) memcpy(us4, e->cal_us, sizeof(e->cal_us));
-    if (xw_fc1) *xw_fc1 = xw_fc1_wanted(e) ? 1 : 0;
-    if (xw_fc2) *xw_fc2 = xw_fc2_wanted(e) ? 1 : 0;
     return LL_OK;
 }
 
@@ -1490,29 +1182,6 @@ int ll_dit_last_run_ms(void *handle, float *ms, int *steps) {
     LL_HIP(hipEventSynchronize(e->ev_t1));
     LL_HIP(hipEventElapsedTime(ms, e->ev_t0, e->ev_t1));
     *steps = e->last_steps;
-    if (e->team_last) LL_TRY(team_check(e));
-    if (e->proj_ln_used) {
-        team::Ctl2 h;
-        LL_HIP(hipMemcpy(&h.error, &e->team_ctl2.as<team::Ctl2>()->error, sizeof(h.error), hipMemcpyDeviceToHost));
-#ifdef LL_TEAM_PROBE
-        LL_HIP(hipMemcpy(&h, e->team_ctl2.p, sizeof(h), hipMemcpyDeviceToHost));
-        static const char *names[] = {"census", "loads + stage", "mfma + reduce + y", "vmcnt(0)", "team barrier", "LN"};
-        fprintf(stderr, "LL_TEAM_PROBE proj_ln block 3, us:");
-        for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.2f |", names[i], (double)(h.stamps[i + 1] - h.stamps[i]) / 100.0);
-        fprintf(stderr, " total %.2f", (double)(h.stamps[6] - h.stamps[0]) / 100.0);
-        unsigned long long t0 = ~0ull, t0x = 0, t1 = 0, t1n = ~0ull;
-        for (int i = 0; i < 256; ++i) {
-            t0 = std::min(t0, h.span[0][i]); t0x = std::max(t0x, h.span[0][i]);
-            t1 = std::max(t1, h.span[1][i]); t1n = std::min(t1n, h.span[1][i]);
-        }
-        fprintf(stderr, " | workgroups: first start -> last start %.2f, first start -> first end %.2f, -> last end %.2f\n", (double)(t0x - t0) / 100.0,
-                (double)(t1n - t0) / 100.0, (double)(t1 - t0) / 100.0);
-#endif
-        if (h.error) {
-            set_error("proj_ln_team_kernel: %s%s", (h.error & 1) ? "a bounded wait ran out " : "", (h.error & 2) ? "more than 32 workgroups reported on one XCC" : "");
-            return LL_EHIP;
-        }
-    }
     return LL_OK;
 }
 

@@ -401,29 +401,17 @@ class GraphDiT(nn.Module):
         _lib.check(lib.ll_dit_run(self._handle, C.c_uint64(seed), mode, _lib.current_stream_ptr()), "ll_dit_run")
 
     def mlp_choice(self) -> dict:
-        """Which kernels the block MLP runs at the current batch.  Default: the LDS-DMA ring under both GEMMs on every device
-        (``calibrated`` False, no timings) -- the kernels of a step are a pure function of (config, batch, options), so a seed
-        fixes the molecules.  With the opt-in per-device calibration (``set_option("xw_gemm", -1)`` / env LL_DIT_CALIBRATE=1):
-        the timings behind the choice, us per fc1 -> fc2 -> AdaLN chain by fc1 / fc2 kernel
-        (include/llamole_hip.h: ll_dit_mlp_choice)."""
-        us = (C.c_float * 4)()
-        a, b = C.c_int(), C.c_int()
-        _lib.check(_lib.load().ll_dit_mlp_choice(self._handle, us, C.byref(a), C.byref(b)), "ll_dit_mlp_choice")
-        # which GEMM family the dispatch runs under the block Linears at this batch (gemm.hip: gemm_dispatch): up to 64 token rows the
-        # all-in-flight panel kernel, up to 224 its two-/four-panel form, beyond that the LDS-DMA ring (or, opt-in, the packed-weight
-        # panel kernel); a trajectory overlapped with the LLM decode keeps <= 64-row panels on the ring (ll_dit_set_overlap)
+        """Which GEMM family the dispatch runs under the block Linears at the current batch (gemm.hip: gemm_dispatch): a pure function of
+        (config, batch, overlap mode) -- no stopwatch anywhere, so a seed fixes the molecules on every box.  Up to 64 token rows the
+        all-in-flight panel kernel, up to 224 its two- / four-panel form (row pitches of 256 | 512 | 1024 only), beyond that the LDS-DMA
+        ring; a trajectory overlapped with the LLM decode keeps <= 64-row panels on the ring (ll_dit_set_overlap)."""
         rows = 2 * int(getattr(self, "_B", 0) or 0) * self.max_n_nodes
         family = ("gemm_m64_kernel (64-row panel, all loads in flight)" if rows <= 64 else
                   "gemm_m128_kernel (64-row panels)" if rows <= 224 else
                   "gemm_bf16_pipeu_kernel<64,64> (LDS-DMA ring, 16 waves)" if rows < 1024 else "gemm_bf16_pipe_kernel (LDS-DMA ring, 128/256-row tiles)")
-        # "xw_panel": whether the OPT-IN packed-weight panel kernel (gemm_xw_kernel) replaces the dispatch's kernel under fc1 / fc2 --
-        # False / False by default at every batch; `kernel` names what actually runs
-        return {"kernel": family if not (a.value or b.value) else "gemm_xw_kernel (packed-weight panel)",
-                "xw_panel": {"fc1": bool(a.value), "fc2": bool(b.value)}, "calibrated": max(us) > 0, "token_rows": rows,
-                "chain_us": {"ring/ring": round(us[0], 2), "panel/ring": round(us[1], 2), "ring/panel": round(us[2], 2),
-                             "panel/panel": round(us[3], 2)}}
+        return {"kernel": family, "token_rows": rows}
 
-    ENGINE_OPTIONS = {"overlap": 0, "generic_attn": 1, "fused_qkv_attn": 2, "xw_gemm": 3, "team": 4, "proj_ln": 5}
+    ENGINE_OPTIONS = {"overlap": 0, "generic_attn": 1, "fused_qkv_attn": 2}
 
     def set_option(self, name: str, value: int):
         """Per-engine switch (include/llamole_hip.h: ll_dit_set_option), effective for every later denoiser call."""

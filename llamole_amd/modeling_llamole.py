@@ -467,6 +467,7 @@ class GraphLLMForCausalMLM(nn.Module):
             # the fixed-size records -- (topk_idx int32[k], topk_prob f32[k]) and the analysis tokens -- gives every rank every expansion;
             # template application and the merge (host) run on every rank for every request, so the trees stay identical.
             rank, world, group = shard
+            self._assert_ranks_agree(len(live), group, "expansion requests of a lock-step round")
             mine = list(range(rank, len(live), world))
             cap = (len(live) + world - 1) // world
             nt = int(self.retro_max_new_tokens)
@@ -511,6 +512,31 @@ class GraphLLMForCausalMLM(nn.Module):
         if not (dist.is_available() and dist.is_initialized()):
             return None
         return sh
+
+    def _assert_ranks_agree(self, n: int, group, what: str) -> None:
+        """The expansion split issues collectives from inside a host A* that every rank replicates: it is only safe while all ranks take
+        the same host decisions.  Before a gather whose buffer size depends on such a decision, check it (ONE 2-element all-reduce per
+        round, next to an LLM decode): a disagreement raises on every rank instead of hanging some of them in RCCL."""
+        import torch.distributed as dist
+        backend = dist.get_backend(group)
+        t = torch.tensor([n, -n], dtype=torch.int64, device=self.device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        if int(t[0]) != n or int(t[1]) != -n:
+            raise RuntimeError(f"expansion_shard: the ranks disagree on the number of {what} ({n} here, {-int(t[1])}..{int(t[0])} elsewhere): "
+                               "the replicated searches have diverged")
+
+    def _shared_clock(self):
+        """time.time() of rank 0, on every rank (expansion split only): the searches' max_planning_time is judged by ONE clock, so all ranks
+        stop in the same round."""
+        shard = self._expansion_shard()
+        if shard is None:
+            return time.time()
+        import torch.distributed as dist
+        _, _, group = shard
+        backend = dist.get_backend(group)
+        t = torch.tensor([time.time()], dtype=torch.float64, device=self.device if backend == "nccl" else "cpu")
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return float(t[0])
 
     def _decode_analysis(self, prompts, graph_lists, kwargs):
         """Device part of an expansion round for `prompts` (one per request): GIN-encode every spliced graph, ONE batched LLM decode over
@@ -666,6 +692,7 @@ class GraphLLMForCausalMLM(nn.Module):
         if shard is not None and not getattr(self, "_in_value_shard", False) and not self._language_cost_is_constant():
             # the round's value prompts split over the ranks (item i on rank i % world), ONE all-gather of the float64 costs
             rank, world, group = shard
+            self._assert_ranks_agree(n, group, "value prompts of a lock-step round")
             mine = list(range(rank, n, world))
             cap = (n + world - 1) // world
             self._in_value_shard = True
@@ -841,7 +868,8 @@ class GraphLLMForCausalMLM(nn.Module):
                 value_fn=lambda s, r: self.estimate_synthesis_complexity(s, None, r, molecule_cost_weight, language_cost_weight),
                 iterations=iterations, max_time=max_planning_time,
                 value_batch_fn=lambda items: self.estimate_synthesis_complexity_batch(items, None, molecule_cost_weight,
-                                                                                      language_cost_weight))
+                                                                                      language_cost_weight),
+                clock=self._shared_clock if self._expansion_shard() is not None else None)
             total = time.time() - t0
             for k, (success, route, _) in enumerate(outcomes):
                 i, target = where[k], targets[k]

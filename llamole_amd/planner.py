@@ -337,14 +337,17 @@ class MolStarSearch:
         self.finished = self.tree.succ
         self._node = None
 
-    def select(self) -> Optional[Molecule]:
+    def select(self, now: Optional[float] = None) -> Optional[Molecule]:
+        """``now``: the wall-clock reading to judge ``max_time`` by (default: this process's own clock).  ``molstar_many`` reads the
+        clock ONCE per round for all its searches, and a driver that replicates the searches on several ranks hands in a clock
+        every rank agrees on -- a rank that timed out one round before the others would skip a collective they are waiting in."""
         if self.finished:
             return None
         if self.done_iters >= self.iterations:
             self.finished = True
             return None
         self.done_iters += 1          # iterations ENTERED, like the reference's `for done in range(iterations)` + 1
-        if time.time() - self.t0 > self.max_time:
+        if (time.time() if now is None else now) - self.t0 > self.max_time:
             self.finished = True
             return None
         best_node, best_score = None, INF
@@ -401,11 +404,12 @@ def molstar(target_mol, target_mol_id, starting_mols, expand_fn, value_fn, itera
 
 
 def molstar_many(target_mols: Sequence[str], starting_mols, expand_batch_fn, value_fn, iterations, max_time=300,
-                 value_batch_fn=None) -> List[Tuple[bool, Optional[Route], int]]:
+                 value_batch_fn=None, clock=None) -> List[Tuple[bool, Optional[Route], int]]:
     """Independent A* searches advanced in lock step: each round every unfinished search nominates its best open
     molecule and ``expand_batch_fn([(search_index, mol), ...]) -> [result, ...]`` expands them together.  Every search
     sees exactly the expansions and estimates a solo ``molstar`` would, so with deterministic callbacks the routes are the
-    same; ``max_time`` is measured on the shared wall clock.  With ``value_batch_fn`` the new tree nodes of ALL searches of a
+    same; ``max_time`` is measured on the shared wall clock, read once per round through ``clock`` (default ``time.time``; a
+    replicated run passes a clock all ranks agree on).  With ``value_batch_fn`` the new tree nodes of ALL searches of a
     round are evaluated in ONE call (the targets themselves in one call before the first round): ~16 x 100 prompts per LLM
     value forward of BASELINE configs[2] instead of 100."""
     known = starting_mols if isinstance(starting_mols, (set, frozenset)) else set(starting_mols)
@@ -413,8 +417,13 @@ def molstar_many(target_mols: Sequence[str], starting_mols, expand_batch_fn, val
     if value_batch_fn is not None and len(target_mols) > 0:
         roots = [float(v) for v in value_batch_fn([(t, None) for t in target_mols])]
     searches = [MolStarSearch(t, known, value_fn, iterations, max_time, value_batch_fn, r) for t, r in zip(target_mols, roots)]
+    if clock is not None:
+        t0 = clock()
+        for s in searches:
+            s.t0 = t0
     while True:
-        picks = [(i, s.select()) for i, s in enumerate(searches)]
+        now = clock() if clock is not None else time.time()
+        picks = [(i, s.select(now)) for i, s in enumerate(searches)]
         picks = [(i, n) for i, n in picks if n is not None]
         if not picks:
             break

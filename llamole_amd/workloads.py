@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import time
 import types
+import re
 import zlib
 
 import torch
@@ -80,12 +81,12 @@ def build_retro_step(args, graph_decoder, device, rank: int, world: int = 1):
     def template_runner(t, s):
         if s[0] == "S":
             h = zlib.crc32(s.encode())
-            D, d = int(s[1]), int(s[3])
+            D, d = (int(v) for v in re.match(r"S(\d+)d(\d+)_", s).groups())
             if d + 1 >= D:
                 return [f"B{h % 50}.B{(h >> 8) % 50}"]
             return [f"B{h % 50}.S{D}d{d + 1}_{h % 9973}"]
         h = zlib.crc32((t + s).encode())
-        d = int(s[3]) if s[0] == "U" else 0
+        d = int(re.match(r"U_d(\d+)_", s).group(1)) if s[0] == "U" else 0
         return [f"U_d{d + 1}_{h % 9973}.U_d{d + 1}_{(h >> 8) % 9973}"]
     pred.template_runner = template_runner
     purchasable = {f"B{i}" for i in range(50)}

@@ -37,12 +37,12 @@ def _mlp4(sd, p, x):
 
 
 def _segment_sum(h, batch, G):
-    out = torch.zeros(G, h.shape[1])
+    out = torch.zeros(G, h.shape[1], dtype=h.dtype)
     return out.index_add_(0, batch, h)
 
 
 def _segment_max(h, batch, G):
-    out = torch.full((G, h.shape[1]), float("-inf"))
+    out = torch.full((G, h.shape[1]), float("-inf"), dtype=h.dtype)
     return out.scatter_reduce(0, batch[:, None].expand_as(h), h, reduce="amax", include_self=True)
 
 

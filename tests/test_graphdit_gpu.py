@@ -259,36 +259,6 @@ def test_graph_replay_equals_eager_and_is_deterministic(case):
     m.begin(case["props"], case["text"], -200.0, case["n_nodes"])   # leave the fixture in 'begun' state
 
 
-def test_packed_weight_panel_gemm_matches_torch():
-    """gemm_xw_kernel through ll_linear_xw (packs W into MFMA operand order, 64-row token panel in LDS): ragged and tiny M, both K
-    slices (512 | 1024), split-K slabs, bias + GELU epilogue to f32 and plain bf16 output."""
-    from llamole_amd import _lib
-    lib = _lib.load()
-    torch.manual_seed(3)
-    for (M, N, K, splits) in [(512, 4096, 1024, 1), (512, 1024, 4096, 4), (200, 256, 512, 1), (1, 128, 1024, 1), (330, 1024, 2048, 4),
-                              (640, 384, 2048, 2), (1024, 512, 1024, 1)]:
-        A = torch.randn(M, K, device="cuda").bfloat16()
-        W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
-        bias = torch.randn(N, device="cuda")
-        lin = A.double() @ W.double().t()
-        if splits == 1:
-            out = torch.empty(M, N, device="cuda")
-            _lib.check(lib.ll_linear_xw(_lib.dptr(A), K, _lib.dptr(W), _lib.dptr(bias), _lib.dptr(out), N, M, N, K, 1, 1, 1, None))
-            torch.cuda.synchronize()
-            ref = torch.nn.functional.gelu(lin + bias.double()).float()
-            assert torch.allclose(out, ref, rtol=2e-3, atol=2e-3), (M, N, K, (out - ref).abs().max())
-            outh = torch.full((M + 1, N), 7.0, device="cuda", dtype=torch.bfloat16)      # one guard row: nothing is written past M
-            _lib.check(lib.ll_linear_xw(_lib.dptr(A), K, _lib.dptr(W), None, _lib.dptr(outh), N, M, N, K, 1, 0, 0, None))
-            torch.cuda.synchronize()
-            assert torch.allclose(outh[:M].float(), lin.float(), rtol=2e-2, atol=2e-2), (M, N, K)
-            assert bool((outh[M] == 7.0).all())
-        else:
-            slabs = torch.empty(splits, M, N, device="cuda")
-            _lib.check(lib.ll_linear_xw(_lib.dptr(A), K, _lib.dptr(W), None, _lib.dptr(slabs), N, M, N, K, splits, 0, 1, None))
-            torch.cuda.synchronize()
-            assert torch.allclose(slabs.sum(0), lin.float(), rtol=2e-3, atol=2e-3), (M, N, K, splits)
-
-
 @pytest.mark.parametrize("name", list(DIT_CASES))
 def test_bf16_engine_close_to_f32_oracle(name):
     g = load_golden(name)

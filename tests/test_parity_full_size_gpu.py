@@ -37,7 +37,7 @@ def _report(key, val):
     try:
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "r4_parity_full_size.json"), "w") as f:
+        with open(os.path.join(out, "r5_parity_full_size.json"), "w") as f:
             json.dump(REPORT, f, indent=1, sort_keys=True)
     except OSError:
         pass
@@ -66,13 +66,12 @@ def _upper(n_nodes, N):
     return um
 
 
-@pytest.mark.parametrize("mode", ["panel", "overlap", "fused", "overlap_default", "fused_xw"])
+@pytest.mark.parametrize("mode", ["panel", "overlap", "fused", "overlap_default"])
 @pytest.mark.parametrize("B", [1, 2, 8])
 def test_graphdit_ref_default_bf16_vs_oracle(full_dit, B, mode):
     """panel / overlap: seven launches per block with the synchronous or the overlap-mode GEMMs; fused: q|k|v projection +
     attention as one launch per (sequence, head) (qkv_attn_kernel; the engine's default for batch 2..16); overlap_default: the
-    overlap mode as the pipelined bench runs it (ring GEMMs + the fused launch at any batch); fused_xw: fused plus the MLP
-    fc1 GEMM on the packed-weight panel kernel (gemm_xw_kernel; opt-in, it did not beat the ring)."""
+    overlap mode as the pipelined bench runs it (ring GEMMs + the fused launch at any batch)."""
     m, spec, sd, do = full_dit
     overlap = int(mode.startswith("overlap"))
     N, T, seed = spec.N, spec.T, 11
@@ -97,7 +96,6 @@ def test_graphdit_ref_default_bf16_vs_oracle(full_dit, B, mode):
     m.begin(props, text, -200.0, n_nodes)
     m.set_option("overlap", overlap)
     m.set_option("fused_qkv_attn", -1 if mode == "overlap_default" else int(mode.startswith("fused")))
-    m.set_option("xw_gemm", int(mode == "fused_xw"))
     try:
         m.init_state(*qT)
         X, E = m.get_state()
@@ -133,7 +131,6 @@ def test_graphdit_ref_default_bf16_vs_oracle(full_dit, B, mode):
     finally:
         m.set_option("overlap", 0)
         m.set_option("fused_qkv_attn", -1)
-        m.set_option("xw_gemm", 0)
     rec = dict(hidden_drift_rel={str(k): v for k, v in drift.items()}, logit_err_rel=lerr, tv_atoms=tvx, tv_bonds=tve,
                race_agree_atoms=agree_x, race_agree_bonds=agree_e, n_atoms=n_x, n_pairs=n_e)
     print(f"B={B} {mode}: {rec}")
@@ -190,7 +187,7 @@ def _rows_noise(step, rows, B0, N):
     return qx, qe
 
 
-@pytest.mark.parametrize("mode", ["default", "overlap_default", "team"])
+@pytest.mark.parametrize("mode", ["default", "overlap_default"])
 @pytest.mark.parametrize("B", [1, 8, 16])
 def test_graphdit_bf16_vs_oracle_at_informative_steps(full_dit, oracle_traj, B, mode):
     """The two engine configurations bench.py runs (`default`: what --workload graphdit and the back-to-back e2e run;
@@ -207,7 +204,6 @@ def test_graphdit_bf16_vs_oracle_at_informative_steps(full_dit, oracle_traj, B, 
     n_x, n_e = int(mask.sum()), int(um.sum())
     m.begin(props, text, -200.0, n_nodes)
     m.set_option("overlap", int(mode == "overlap_default"))
-    m.set_option("team", int(mode == "team"))          # the persistent per-XCD trajectory kernel (opt-in; csrc/dit_team.h)
     per_step = {}
     try:
         for s in PROBE_STEPS:
@@ -249,7 +245,6 @@ def test_graphdit_bf16_vs_oracle_at_informative_steps(full_dit, oracle_traj, B, 
                 free[s] = eq / (n_x + n_e)
     finally:
         m.set_option("overlap", 0)
-        m.set_option("team", 0)
     rec = dict(per_step={str(k): v for k, v in per_step.items()}, free_running_equal_frac={str(k): v for k, v in free.items()},
                n_atoms=n_x, n_pairs=n_e, mlp_kernels=m.mlp_choice())
     print(f"B={B} {mode}: " + json.dumps(rec))
@@ -482,7 +477,6 @@ def test_fused_qkv_attention_vs_separate_launches(N, H, heads, B):
     m.init_state(*synth.exp_noise(seed, m.T, B, N))
     s = m.T - 1
     out = {}
-    m.set_option("xw_gemm", 0)
     modes = (0, 1, 2) if N <= 32 and H % 512 == 0 else (0, 1)      # 2: two sequences per workgroup (graphs of <= 32 nodes)
     for fused in modes:
         m.set_option("fused_qkv_attn", fused)
@@ -509,52 +503,6 @@ def test_fused_qkv_attention_vs_separate_launches(N, H, heads, B):
         assert err2 <= 1e-2 and lerr2 <= 1e-2, (err2, lerr2)
     print(f"fused qkv+attn vs separate N={N} H={H}: hidden {err:.3e} logits {lerr:.3e}")
     _report(f"fused_qkv_attn_N{N}_H{H}", dict(hidden_rel=err, logits_rel=lerr))
-    assert err <= 1e-2 and lerr <= 1e-2, (err, lerr)
-
-
-@pytest.mark.parametrize("N,H,heads,B", [(32, 512, 8, 3), (50, 1024, 16, 2)], ids=["H512", "H1024"])
-def test_packed_weight_mlp_vs_ring_gemms(N, H, heads, B):
-    """fc1 + GELU of the block on gemm_xw_kernel against the LDS-DMA ring GEMM on the same state: same bf16 operands and f32
-    accumulation, only the summation order differs."""
-    from llamole_amd.graph_decoder import GraphDiT
-    seed = 9
-    cfg = synth.make_dit_config(H, 2, heads, 10, 2.0)
-    meta = synth.make_data_meta(N, seed)
-    sd = synth.make_dit_weights(cfg, N, seed)
-    d = tempfile.mkdtemp()
-    synth.write_dit_dir(d, cfg, meta, sd)
-    m = GraphDiT(os.path.join(d, "config.yaml"), os.path.join(d, "data.meta.json"), torch.bfloat16)
-    m.init_model(d)
-    m.to("cuda")
-    for p in m.parameters():
-        p.data = p.data.to(torch.bfloat16)
-    props, text, _ = synth.make_dit_inputs(B, seed, N)
-    n_nodes = torch.tensor(([N, 1, max(2, N // 2 + 1)])[:B])
-    m.begin(props, text, -200.0, n_nodes)
-    choice = m.mlp_choice()            # default: no stopwatch, the LDS-DMA ring under both GEMMs (a seed fixes the molecules)
-    assert choice["xw_panel"] == {"fc1": False, "fc2": False} and choice["calibrated"] is False, choice
-    m.set_option("xw_gemm", -1)        # opt-in: ll_dit_begin times both kernels on this device for this batch
-    m.begin(props, text, -200.0, n_nodes)
-    choice = m.mlp_choice()
-    assert set(choice["xw_panel"]) == {"fc1", "fc2"} and choice["calibrated"] is True
-    assert min(choice["chain_us"].values()) > 0, choice
-    m.init_state(*synth.exp_noise(seed, m.T, B, N))
-    s = m.T - 1
-    out = {}
-    m.set_option("fused_qkv_attn", 0)
-    for xw in (0, 1):
-        m.set_option("xw_gemm", xw)
-        lx, le, h = m.denoise_logits(s, tap_layer=2)
-        out[xw] = (h.cpu(), lx.cpu(), le.cpu())
-    m.set_option("xw_gemm", 0)
-    m.set_option("fused_qkv_attn", -1)
-    valid = (torch.arange(N).unsqueeze(0) < n_nodes.unsqueeze(1)).unsqueeze(0).unsqueeze(-1)
-    scale = float((out[0][0] * valid).abs().max())
-    err = float(((out[0][0] - out[1][0]) * valid).abs().max()) / scale
-    lerr = max(float((out[0][1] - out[1][1]).abs().max()), float((out[0][2] - out[1][2]).abs().max()))
-    lerr /= max(1.0, float(out[0][1].abs().max()), float(out[0][2].abs().max()))
-    print(f"packed-weight MLP vs ring GEMMs N={N} H={H}: hidden {err:.3e} logits {lerr:.3e}")
-    _report(f"xw_mlp_N{N}_H{H}", dict(hidden_rel=err, logits_rel=lerr))
     assert err <= 1e-2 and lerr <= 1e-2, (err, lerr)
 
 
