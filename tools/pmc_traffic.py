@@ -26,6 +26,6 @@ except FileNotFoundError:
 d[key] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "kernel": sub, "dispatches_averaged": nf,
           "hbm_bytes_per_launch": (2 * f + w) * 1024, "algorithmic_bytes": int(alg),
           "shape": dict(zip("MNK", shape), dtype="bf16"),
-          "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no trace domains) over tools/gemm_one.py; timed half of the dispatches"}
+          "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no trace domains) over tools/gemm_one.py; timed half of the dispatches (" + __import__("os").environ.get("LL_PMC_ROUND", "r5") + ")"}
 json.dump(d, open(jpath, "w"), indent=1)
 print(key, d[key]["hbm_bytes_per_launch"], "vs algorithmic", alg)
