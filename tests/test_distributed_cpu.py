@@ -392,3 +392,65 @@ def test_gather_rows_and_topk_are_identity_without_a_group():
     assert D.gather_rows(t) is t
     i, p = D.all_gather_topk(t.int(), t.float())
     assert torch.equal(i, t.int()) and torch.equal(p, t.float())
+
+
+def _diverge_worker(rank, world, port, q):
+    """Rank 1 'decides' differently from rank 0 (one live request fewer): the agreement check must raise on BOTH ranks, not hang one of
+    them in the gather; and the shared clock hands every rank rank 0's reading."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = _sharded_world(rank, world)
+        m.expansion_shard = (rank, world, None)
+        t = m._shared_clock()
+        tt = torch.tensor([t], dtype=torch.float64)
+        both = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(both, tt)
+        same_clock = bool(both[0] == both[1])
+        m._assert_ranks_agree(5, None, "requests")                   # agreement: silent
+        try:
+            m._assert_ranks_agree(5 - rank, None, "requests")
+            raised = False
+        except RuntimeError as e:
+            raised = "disagree" in str(e)
+        q.put((rank, same_clock, raised))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_expansion_split_detects_diverged_ranks_and_shares_one_clock():
+    """the expansion split issues collectives from inside a replicated host A*.  max_planning_time is judged by ONE clock (rank
+    0's, broadcast per round) and a rank whose request count differs raises on every rank instead of hanging its peers."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_diverge_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True, True), (1, True, True)], res
+
+
+def test_molstar_many_reads_the_clock_once_per_round():
+    """All searches of a lock-step run stop in the same round when the (shared) clock runs out -- none of them a round earlier."""
+    from llamole_amd.planner import molstar_many
+    ticks = {"n": 0}
+
+    def clock():
+        ticks["n"] += 1
+        return float(ticks["n"])            # one "second" per reading: t0 = 1, round k is judged at 1 + k
+
+    rounds = []
+
+    def expand(picks):
+        rounds.append([i for i, _ in picks])
+        return [{"reactants": [f"X{mol}a.X{mol}b"], "scores": [0.9], "templates": ["T"], "analysis": [1]} for _, mol in picks]
+
+    out = molstar_many(["A", "B", "C"], {"Z"}, expand, value_fn=lambda s, r: 1.0, iterations=50, max_time=2.5, clock=clock)
+    assert rounds == [[0, 1, 2], [0, 1, 2]]                          # rounds judged at elapsed 1 and 2 run, the one at 3 > 2.5 does not
+    assert all(not ok for ok, _, _ in out) and ticks["n"] == 4
