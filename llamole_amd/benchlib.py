@@ -154,8 +154,9 @@ def time_graphdit_kernel(args, batch: int):
     lib = _lib.load()
     H, Hm = args.hidden, int(args.hidden * 4)
     M, N, K = 2 * batch * args.nodes, Hm, H
-    panel = K in (256, 512, 1024)          # the all-in-flight panel kernels exist for these K chunks (gemm.hip: gemm_dispatch)
-    kern = ("gemm_m64_kernel<8,8,bf16,packed>" if M <= 64 and panel else "gemm_m128_kernel" if 64 < M <= 224 and panel else
+    panel64 = K in (256, 384, 512, 768, 1024, 1152)          # K chunks the all-in-flight panel kernels exist for (gemm.hip: gemm_dispatch)
+    panel = K in (256, 512, 1024)
+    kern = (f"gemm_m64_kernel<{K // 128},{8 if (K // 128) % 2 == 0 else 4},bf16,packed>" if M <= 64 and panel64 else "gemm_m128_kernel" if 64 < M <= 224 and panel else
             "gemm_bf16_pipe_kernel<32,32,2,2,8>" if M <= 32 else
             "gemm_bf16_pipeu_kernel<64,64,4,4,4>" if 64 < M < 1024 else "gemm_bf16_pipe_kernel<64,*> (LDS-DMA ring)" if M <= 64 else
             "gemm_bf16_pipe_kernel<128,128,4,4,3>" if M < 2048 else "gemm_bf16_pipe_kernel<256,128,4,4,3>")

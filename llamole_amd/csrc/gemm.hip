@@ -847,7 +847,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_m64_kernel(const bf16_t *__re
     constexpr int CPR = KC / 8;                    // 16-byte chunks per row (a multiple of 16)
     constexpr int NA = 64 * CPR / THREADS;         // A chunks per thread
     constexpr int KS = NS * 4 / WAVES;             // MFMA k-steps (32 k each) per wave
-    static_assert(KS >= 1 && NA >= 1, "K chunk too small for this many waves");
+    static_assert(KS >= 1 && NA >= 1 && KS * WAVES == NS * 4 && NA * THREADS == 64 * CPR, "the K chunk must divide evenly among the waves / threads");
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_m64[];
     unsigned char *As = sm_m64;                                        // [64][ROWB], chunk c of row r at chunk c ^ (r & 15)
@@ -1096,7 +1096,11 @@ static int launch_m64_w(const bf16_t *A, int lda, const bf16_t *W, int ldw, void
 template <int NS>
 static int launch_m64(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M, int N,
                       int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
-    if (g_m64_waves == 8) return launch_m64_w<NS, 8>(A, lda, W, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s);
+    // eight waves need an even number of 128-element K slices (each wave takes NS / 2 MFMA k-steps); odd NS (K chunks of 384 | 1152:
+    // hidden 1152, the upstream Graph-DiT width) run on four waves
+    if constexpr (NS % 2 == 0) {
+        if (g_m64_waves == 8) return launch_m64_w<NS, 8>(A, lda, W, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s);
+    }
     return launch_m64_w<NS, 4>(A, lda, W, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s);
 }
 
@@ -1531,12 +1535,19 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
             LL_LAUNCH_CHECK();
             return LL_OK;
         }
-        if (g_gemm_variant != 0 && g_gemm_variant != 2 && !g_no_panel_gemm && M <= 64 && (kchunk == 256 || kchunk == 512 || kchunk == 1024) &&
+        if (g_gemm_variant != 0 && g_gemm_variant != 2 && !g_no_panel_gemm && M <= 64 &&
+            (kchunk == 256 || kchunk == 384 || kchunk == 512 || kchunk == 768 || kchunk == 1024 || kchunk == 1152) &&
             (long)cdiv(N, 16) * splits >= 8) {      // even 11 workgroups (the GraphDiT output layer, N = 176): 4.1 us against 6.5 us on the ring -- the phase is one round trip either way
-            // one molecule's token panel (GraphDiT at batch 1, small GIN batches): everything in flight at once
-            if (kchunk == 1024) LL_TRY((launch_m64<8>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));
-            else if (kchunk == 512) LL_TRY((launch_m64<4>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));
-            else LL_TRY((launch_m64<2>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s)));
+            // one molecule's token panel (GraphDiT at batch 1, small GIN batches): everything in flight at once.  K chunks of 384 / 768 /
+            // 1152 (round 5) are the slices of hidden 768 and 1152 (q|k|v, fc1 and the output layer in one piece, proj / fc2 as split-K slabs)
+            switch (kchunk) {
+                case 1152: LL_TRY((launch_m64<9>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s))); break;
+                case 1024: LL_TRY((launch_m64<8>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s))); break;
+                case 768: LL_TRY((launch_m64<6>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s))); break;
+                case 512: LL_TRY((launch_m64<4>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s))); break;
+                case 384: LL_TRY((launch_m64<3>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s))); break;
+                default: LL_TRY((launch_m64<2>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s))); break;
+            }
             LL_LAUNCH_CHECK();
             return LL_OK;
         }

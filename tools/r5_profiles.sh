@@ -23,7 +23,7 @@ try:
     rd = d.get("roofline_graphdit") or {}
     print("$f", round(d["value"], 3), d["unit"], "ms/step", round(d["ms_per_step"], 2), "dit_step_ms", round(d.get("denoise_step_ms") or 0, 4),
           "roof", round(d["roofline"]["frac"], 3), "roof_dit", round(rd.get("frac", 0) or 0, 3), "live_ms", rd.get("kernel_ms"), "bracket", rd.get("kernel_ms_event_bracketed"),
-          "pair", rd.get("event_pair_ms"), "marginal", rd.get("kernel_ms_marginal_in_chain"), "trace", rd.get("kernel_ms_committed_trace"), "b2b", rd.get("kernel_ms_back_to_back"),
+          "pair", rd.get("event_pair_ms"), "trace", rd.get("kernel_ms_committed_trace"), "b2b", rd.get("kernel_ms_back_to_back"),
           (d.get("cpu_baseline") or {}).get("value"))
 except Exception as e:
     print("$f", "ERR", e)
