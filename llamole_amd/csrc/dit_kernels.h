@@ -31,13 +31,6 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, float4 o) 
     *reinterpret_cast<uint2 *>(p) = u;
 }
 
-// Load of data that ANOTHER CU may have written during this launch (dit_team.h: the persistent trajectory kernel): SC1 = L1-bypassing
-// load served by the XCD's L2 (relaxed agent-scope atomic load -> global_load ... sc1); the launch chain reads the same data plainly.
-template <bool SC1, typename T> __device__ __forceinline__ T ldm(const T *p) {
-    if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
-}
-
 // ------------------------------------------------------------------------------------------ x_embedder
 // h = LayerNorm_affine(W_x . [onehot(x_i) | onehot(e_i0) .. onehot(e_i,N-1)])   (transformer.py:41-44, 95-96)
 // The input row has at most N+1 non-zeros, so the Linear is a gather-sum of rows of W_x^T [F,H].
@@ -349,7 +342,7 @@ __device__ __forceinline__ void attn_core(const bf16_t *Qs, const bf16_t *Ks, co
 // the qkv activation in global memory (attn_mfma_kernel) or from the LDS image the fused q|k|v GEMM left (qkv_attn_kernel);
 // `ohead` = o + first row of the sequence * H + head * HD.  Waves >= WPB of a larger workgroup must not enter.
 struct AttnBlockSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
-// `sync()` = barrier of the WPB waves that run the body (the whole workgroup in attn_mfma_kernel; the four I/O waves in dit_team.h)
+// `sync()` = barrier of the WPB waves that run the body (the whole workgroup in attn_mfma_kernel)
 template <int NP, int HD, int WPB, typename LD, typename SYNC = AttnBlockSync>
 __device__ __forceinline__ void attn_mfma_body(LD ld, bf16_t *__restrict__ ohead, const float *__restrict__ qw,
                                                const float *__restrict__ qb, const float *__restrict__ kw,
@@ -925,7 +918,6 @@ struct PostArgs {
 };
 
 // one wave per decoder row `row` = (p*B + b)*N + i; s_known >= 0: the reverse step (the caller knows it), else read from the arguments
-template <bool SC1>
 __device__ __forceinline__ void post_rows_body(const PostArgs &a, int row, int lane, int s_known) {
     const int N = a.N, F = a.F, B = a.B;
     if (row < 0 || row >= 2 * B * N) return;
@@ -942,7 +934,7 @@ __device__ __forceinline__ void post_rows_body(const PostArgs &a, int row, int l
 #pragma unroll
     for (int e = 0; e < MAXF; ++e) {
         const int f = lane + e * 64;
-        v[e] = f < F ? ldm<SC1>(r + f) : 0.f;
+        v[e] = f < F ? *(r + f) : 0.f;
         sh[e] = f < F ? ss[f] : 0.f;
         sc[e] = f < F ? ss[F + f] : 0.f;
         sm += v[e];
@@ -963,7 +955,7 @@ __device__ __forceinline__ void post_rows_body(const PostArgs &a, int row, int l
     }
     // atom classes live in lanes 0..15 of chunk 0
     const int st_in = (s + 1) & 1;
-    const int xi = ldm<SC1>(a.X + ((int64_t)st_in * B + b) * N + i);
+    const int xi = *(a.X + ((int64_t)st_in * B + b) * N + i);
     const bool valid = i < a.n_nodes[b];
     if (lane < 16) {
         const float l = valid ? ((xi == lane ? 1.f : 0.f) + v[0]) : 0.f;
@@ -983,11 +975,10 @@ __device__ __forceinline__ void post_rows_body(const PostArgs &a, int row, int l
 }
 
 __global__ __launch_bounds__(256) void post_rows_kernel(PostArgs a) {
-    post_rows_body<false>(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, -1);
+    post_rows_body(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, -1);
 }
 
 // one wave per (graph b, node i); lane j = partner node
-template <bool SC1>
 __device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b, int j, int s_known) {
     const int N = a.N, F = a.F, B = a.B;
     const int s = s_known >= 0 ? s_known : *a.step_ptr;
@@ -996,9 +987,9 @@ __device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b,
     const int8_t *Xin = a.X + ((int64_t)st_in * B + b) * N;
     const int8_t *Ein = a.E + ((int64_t)st_in * B + b) * N * N;
     const bool vi = i < nv, vj = j < nv && j < N;
-    const int xi = ldm<SC1>(Xin + i);
-    const int eij = j < N ? (int)ldm<SC1>(Ein + i * N + j) : -1;
-    const int eji = j < N ? (int)ldm<SC1>(Ein + j * N + i) : -1;
+    const int xi = *(Xin + i);
+    const int eij = j < N ? (int)*(Ein + i * N + j) : -1;
+    const int eji = j < N ? (int)*(Ein + j * N + i) : -1;
     const float beta = a.betas[s + 1], ab_s = a.alphas_bar[s], ab_t = a.alphas_bar[s + 1];
     const bool guided = (a.guide != 1.0f);
     const unsigned long long seed = a.seed_ptr ? *a.seed_ptr : 0ull;
@@ -1013,7 +1004,7 @@ __device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b,
             const float *zi = a.out + ((((int64_t)p * B + b) * N + i) * F) + XD + ED * j;
             const float *zj = a.out + ((((int64_t)p * B + b) * N + j) * F) + XD + ED * i;
 #pragma unroll
-            for (int k = 0; k < ED; ++k) l[k] = 0.5f * (((eij == k ? 1.f : 0.f) + ldm<SC1>(zi + k)) + ((eji == k ? 1.f : 0.f) + ldm<SC1>(zj + k)));
+            for (int k = 0; k < ED; ++k) l[k] = 0.5f * (((eij == k ? 1.f : 0.f) + *(zi + k)) + ((eji == k ? 1.f : 0.f) + *(zj + k)));
         } else {
 #pragma unroll
             for (int k = 0; k < ED; ++k) l[k] = 0.f;
@@ -1064,7 +1055,7 @@ __device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b,
             float pc[2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const float px = ldm<SC1>(a.predX + ((((int64_t)p * B + b) * N + i) * XD) + c);
+                const float px = *(a.predX + ((((int64_t)p * B + b) * N + i) * XD) + c);
                 const float spx = row16_sum(px);
                 float r = a.x_marg[c] * spx;
 #pragma unroll
@@ -1115,7 +1106,7 @@ __device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b,
 #pragma unroll
             for (int k = 0; k < ED; ++k) {
                 const float sek = ((xi >= 0) ? a.u_ex[k * XD + xi] : 0.f) + emsum;
-                const float r = ldm<SC1>(px + k) + a.e_marg[k] * SEt[p];
+                const float r = *(px + k) + a.e_marg[k] * SEt[p];
                 const float right = ab_s * e5[p][k] + (1.f - ab_s) * r;
                 const float et = (eij == k) ? 1.f : 0.f;
                 const float left = (1.f - beta) * et + beta * sek;
@@ -1199,7 +1190,7 @@ __device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b,
     }
 }
 
-__global__ __launch_bounds__(64) void post_pairs_kernel(PostArgs a) { post_pairs_body<false>(a, blockIdx.x, blockIdx.y, threadIdx.x, -1); }
+__global__ __launch_bounds__(64) void post_pairs_kernel(PostArgs a) { post_pairs_body(a, blockIdx.x, blockIdx.y, threadIdx.x, -1); }
 
 // ------------------------------------------------------------------------------------------ z_T
 // sample_discrete_feature_noise (diffusion_utils.py:495-518): limit marginals, strict upper triangle kept,

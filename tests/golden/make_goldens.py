@@ -165,15 +165,7 @@ class NoiseFeed:
 
 
 # ----------------------------------------------------------------------------- GraphDiT goldens
-from tests.cases import DIT_CASES, GIN_CASES  # noqa: E402
-
-
-def dit_case(name):
-    N, H, L, heads, T, guide, B, seed = DIT_CASES[name]
-    cfg = synth.make_dit_config(H, L, heads, T, guide)
-    meta = synth.make_data_meta(N, seed)
-    sd = synth.make_dit_weights(cfg, N, seed)
-    return cfg, meta, sd, B, seed
+from tests.cases import DIT_CASES, GIN_CASES, dit_case  # noqa: E402,F401
 
 
 def gen_dit(name):

@@ -38,7 +38,7 @@ def test_tuning_hooks_are_fenced_off_the_product_header():
     assert all(n.startswith(("ll_set_", "ll_debug_")) or "bench" in n or "probe" in n or n in ("ll_linear_cfg",) for n in tuning), tuning
     pkg = os.path.join(ROOT, "llamole_amd")
     for f in os.listdir(pkg):
-        if f.endswith(".py") and f != "_lib.py":
+        if f.endswith(".py") and f not in ("_lib.py", "benchlib.py"):      # benchlib.py = bench.py's measurement helpers (round-5 split), not a product path
             text = open(os.path.join(pkg, f)).read()
             used = [n for n in tuning if re.search(r"\b" + n + r"\b", text)]
             assert not used, f"{f} (product path) calls tuning hooks {used}"
