@@ -532,8 +532,7 @@ def test_panel_gemm_on_packed_weights_is_bit_identical(full_dit):
 # ------------------------------------------------------------------------------------------ GIN predictor at configs[2] size
 def test_gin_predictor_full_size_vs_oracle():
     import sys
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from gin_bench import fast_weights
+    from llamole_amd.workloads import device_gin_weights as fast_weights
     from llamole_amd.graph_predictor import GraphPredictor
     from oracle import gin_oracle as go
     L, H, G, D, k = 5, 512, 16, 180576, 50
@@ -582,8 +581,7 @@ def test_gin_backward_full_size_vs_oracle_autograd():
     torch.autograd through the f32 CPU oracle on the same bf16-rounded weights: loss and d(retro cross-entropy)/d c."""
     import sys
     import torch.nn.functional as F
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from gin_bench import fast_weights
+    from llamole_amd.workloads import device_gin_weights as fast_weights
     from llamole_amd.graph_predictor import GraphPredictor
     from oracle import gin_oracle as go
     L, H, G, D = 5, 512, 16, 180576
@@ -627,8 +625,7 @@ def test_gin_encoder_full_size_vs_oracle():
     the same bf16-rounded weights: unit-norm embeddings, worst component and worst cosine."""
     import sys
     import torch.nn.functional as F
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from gin_bench import fast_weights
+    from llamole_amd.workloads import device_gin_weights as fast_weights
     from llamole_amd.graph_encoder import GraphCLIP
     from oracle import gin_oracle as go
     L, H, G = 5, 512, 16

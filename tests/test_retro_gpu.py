@@ -15,8 +15,7 @@ def test_lock_step_retrosynthesis_batch16_depth5():
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "tools"))
-    from gin_bench import fast_weights
+    from llamole_amd.workloads import device_gin_weights as fast_weights
     from llamole_amd import e2e, synth
     from llamole_amd.graph_data import GraphBatch
     from llamole_amd.graph_encoder import GraphCLIP
