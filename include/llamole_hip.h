@@ -58,6 +58,10 @@ int ll_linear_splitk_bf16(const void *A, int lda, const void *W, int ldw, const 
  * Replaces reference GraphDiT.generate / sample_p_zs_given_zt / Transformer.forward
  * (src/model/graph_decoder/diffusion_model.py:252-399, transformer.py:93-187,
  *  diffusion_utils.py:273-349,376-413,476-518). */
+/* Any sizes the reference Transformer constructs are valid (transformer.py:24-37): hidden, heads (dividing hidden) and mlp_hidden need
+ * not be multiples of anything -- the engine zero-pads its internal copy of the weights to row pitches of 64 and a head pitch of 32 and
+ * takes the true widths for every row statistic; the arena layout below is the checkpoint's own.  Bounds (LL_EINVAL beyond them):
+ * hidden <= 2048, hidden / heads <= 128, max_nodes <= 64. */
 typedef struct LLDitConfig {
     int hidden;        /* H            (config.yaml hidden_size)      */
     int depth;         /* L            (depth)                        */
@@ -152,6 +156,8 @@ int ll_dit_last_run_ms(void *handle, float *ms, int *steps);
 /* ------------------------------------------------------------------ GIN encoder / predictor
  * Replaces GNNEncoder.forward + ProjectionHead (src/model/graph_encoder/model.py:124-205) and
  * GNNRetrosynthsizer.forward (src/model/graph_predictor/model.py:306-353). */
+/* hidden (<= 2048) and text_dim need not be multiples of 64 either: zero-padded inside the engine (graph_encoder/model.py:87-112,
+ * graph_predictor/model.py:231-278 take them from the checkpoint's config); out_dim is any positive number of templates. */
 typedef struct LLGinConfig {
     int num_layer;
     int hidden;     /* H_gin                                   */

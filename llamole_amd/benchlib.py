@@ -154,7 +154,7 @@ def time_graphdit_kernel(args, batch: int):
     lib = _lib.load()
     H, Hm = args.hidden, int(args.hidden * 4)
     M, N, K = 2 * batch * args.nodes, Hm, H
-    panel64 = K in (256, 384, 512, 768, 1024, 1152)          # K chunks the all-in-flight panel kernels exist for (gemm.hip: gemm_dispatch)
+    panel64 = K in (256, 512, 768, 1024)          # K chunks the all-in-flight panel kernels exist for (gemm.hip: gemm_dispatch)
     panel = K in (256, 512, 1024)
     kern = (f"gemm_m64_kernel<{K // 128},{8 if (K // 128) % 2 == 0 else 4},bf16,packed>" if M <= 64 and panel64 else "gemm_m128_kernel" if 64 < M <= 224 and panel else
             "gemm_bf16_pipe_kernel<32,32,2,2,8>" if M <= 32 else

@@ -1096,11 +1096,7 @@ static int launch_m64_w(const bf16_t *A, int lda, const bf16_t *W, int ldw, void
 template <int NS>
 static int launch_m64(const bf16_t *A, int lda, const bf16_t *W, int ldw, void *C, int ldc, const float *bias, int M, int N,
                       int splits, int64_t slab_stride, int epi, int out_f32, hipStream_t s) {
-    // eight waves need an even number of 128-element K slices (each wave takes NS / 2 MFMA k-steps); odd NS (K chunks of 384 | 1152:
-    // hidden 1152, the upstream Graph-DiT width) run on four waves
-    if constexpr (NS % 2 == 0) {
-        if (g_m64_waves == 8) return launch_m64_w<NS, 8>(A, lda, W, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s);
-    }
+    if (g_m64_waves == 8) return launch_m64_w<NS, 8>(A, lda, W, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s);
     return launch_m64_w<NS, 4>(A, lda, W, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s);
 }
 
@@ -1536,16 +1532,16 @@ static int gemm_dispatch(int dtype, const void *A, int lda, const void *W, int l
             return LL_OK;
         }
         if (g_gemm_variant != 0 && g_gemm_variant != 2 && !g_no_panel_gemm && M <= 64 &&
-            (kchunk == 256 || kchunk == 384 || kchunk == 512 || kchunk == 768 || kchunk == 1024 || kchunk == 1152) &&
+            (kchunk == 256 || kchunk == 512 || kchunk == 768 || kchunk == 1024) &&
             (long)cdiv(N, 16) * splits >= 8) {      // even 11 workgroups (the GraphDiT output layer, N = 176): 4.1 us against 6.5 us on the ring -- the phase is one round trip either way
-            // one molecule's token panel (GraphDiT at batch 1, small GIN batches): everything in flight at once.  K chunks of 384 / 768 /
-            // 1152 (round 5) are the slices of hidden 768 and 1152 (q|k|v, fc1 and the output layer in one piece, proj / fc2 as split-K slabs)
+            // one molecule's token panel (GraphDiT at batch 1, small GIN batches): everything in flight at once.  K chunks of 768 (round 5:
+            // hidden 768 -- q|k|v, fc1 and the output layer in one piece, fc2 as split-K slabs) run on eight waves like the others.  The odd
+            // slice counts of hidden 1152 (1152 = 9 x 128, its proj slabs 3 x 128) only divide among FOUR waves, each then holds 36 panel
+            // loads in flight, and that form measured slower than the LDS-DMA ring (1.53 vs 1.37 ms per step at batch 1, same box): not kept
             switch (kchunk) {
-                case 1152: LL_TRY((launch_m64<9>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s))); break;
                 case 1024: LL_TRY((launch_m64<8>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s))); break;
                 case 768: LL_TRY((launch_m64<6>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s))); break;
                 case 512: LL_TRY((launch_m64<4>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s))); break;
-                case 384: LL_TRY((launch_m64<3>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s))); break;
                 default: LL_TRY((launch_m64<2>(a, lda, w, ldw, C, ldc, bias, M, N, splits, slab_stride, epi, out_f32, s))); break;
             }
             LL_LAUNCH_CHECK();

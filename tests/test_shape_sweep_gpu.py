@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 # name: (H, heads, mlp_ratio, N, depth, n_nodes)
 DIT_CASES = {
     "h1152_hd72": (1152, 16, 4.0, 38, 3, [38, 21, 5]),            # the upstream Graph-DiT width
-    "h1152_one_molecule": (1152, 16, 4.0, 32, 2, [29]),           # 64 token rows: the all-in-flight panel GEMM at K chunks of 1152 / 384 (four waves)
+    "h1152_one_molecule": (1152, 16, 4.0, 32, 2, [29]),           # 64 token rows at a width whose K is no panel-kernel chunk: the ring under every Linear
     "h768_hd48_mlp2_n9": (768, 16, 2.0, 9, 1, [9, 4]),           # 36 token rows: the panel GEMM at K chunks of 768
     "h1280_hd80_n50": (1280, 16, 4.0, 50, 3, [50, 33, 1]),
     "h2048_hd128_mlp2_n64": (2048, 16, 2.0, 64, 1, [64, 40]),
