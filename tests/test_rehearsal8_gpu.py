@@ -80,16 +80,25 @@ def test_main_eval_8_ranks_on_the_work_queue(tmp_path):
     from llamole_amd.modeling_llamole import SPECIAL_TOKENS
     cfg = synth.write_eval_fixture(str(tmp_path), SPECIAL_TOKENS)
     synth.write_molqa_dataset(os.path.join(str(tmp_path), "data"), n=20)
-    socks = [socket.socket() for _ in range(2)]          # two free ports held together: the rendezvous and the WorkQueue's counter store
-    for s in socks:
-        s.bind(("127.0.0.1", 0))
-    port, qport = (s.getsockname()[1] for s in socks)
-    for s in socks:
-        s.close()
+    port = None
+    for _ in range(50):          # a rendezvous port whose WorkQueue neighbour (MASTER_PORT + 17, distributed.WorkQueue) is free as well
+        a, b = socket.socket(), socket.socket()
+        try:
+            a.bind(("127.0.0.1", 0))
+            b.bind(("127.0.0.1", a.getsockname()[1] + 17))
+            port = a.getsockname()[1]
+        except OSError:
+            pass
+        finally:
+            a.close()
+            b.close()
+        if port is not None:
+            break
+    assert port is not None
     procs = []
     for r in range(8):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   LLAMOLE_QUEUE_PORT=str(qport), **SHARED)
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **SHARED)
+        env.pop("LLAMOLE_QUEUE_PORT", None)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "eval_rank_worker.py"), cfg], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=1200) for p in procs]
