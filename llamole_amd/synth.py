@@ -549,11 +549,12 @@ def write_train_fixture(root: str, special_tokens, **overrides) -> str:
     import yaml
     from . import e2e
     llm_dir = write_llm_dir(os.path.join(root, "llm"), special_tokens, exact_vocab=bool(overrides.pop("exact_vocab", False)))
+    gin_hidden = int(overrides.pop("gin_hidden", 64))          # the GIN checkpoints' own width (any; 300 is the usual one of pretrained GINs)
     cfg = make_dit_config(hidden_size=128, depth=2, num_heads=4, diffusion_steps=10, guide_scale=2.0)
     write_dit_dir(os.path.join(root, "graph_decoder"), cfg, make_data_meta(16, 0), make_dit_weights(cfg, 16, 0))
-    write_encoder_dir(os.path.join(root, "graph_encoder"))
-    write_predictor_dir(os.path.join(root, "graph_predictor"))
-    write_connector_dir(os.path.join(root, "connector0"), e2e.LLM_CONFIGS["tiny"]["hidden_size"], 64)
+    write_encoder_dir(os.path.join(root, "graph_encoder"), H=gin_hidden)
+    write_predictor_dir(os.path.join(root, "graph_predictor"), H=gin_hidden)
+    write_connector_dir(os.path.join(root, "connector0"), e2e.LLM_CONFIGS["tiny"]["hidden_size"], gin_hidden)
     ds = write_molqa_train_dataset(os.path.join(root, "data"))
     y = {"model_name_or_path": llm_dir, "new_special_tokens": ",".join(special_tokens),
          "graph_decoder_path": os.path.join(root, "graph_decoder"), "graph_encoder_path": os.path.join(root, "graph_encoder"),

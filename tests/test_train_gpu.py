@@ -140,3 +140,17 @@ def test_main_train_trains_and_saves_the_new_token_embeddings(tmp_path, monkeypa
     w_in = m.language_model.get_input_embeddings().weight.detach().cpu()
     w_out = m.language_model.get_output_embeddings().weight.detach().cpu()
     assert torch.equal(w_in[ids], trained[ek][ids].to(w_in.dtype)) and torch.equal(w_out[ids], trained[hk][ids].to(w_out.dtype))
+
+
+def test_main_train_with_a_gin_width_that_needs_padding(tmp_path, monkeypatch):
+    """SFT with GIN encoder / predictor checkpoints of hidden_size 100 (zero-padded to 128 inside the engines): the HIP forward and the
+    reverse sweep through the predictor run at the checkpoint's width, the loss is finite and moves."""
+    from llamole_amd import synth
+    from llamole_amd import train as tr
+    from llamole_amd.modeling_llamole import SPECIAL_TOKENS
+    _fake_chem(monkeypatch)
+    cfg = synth.write_train_fixture(str(tmp_path), SPECIAL_TOKENS, gin_hidden=100, num_train_epochs=6.0, seed=3)
+    out = tr.run_train(cfg)
+    losses = [r["loss"] for r in out["log"]]
+    assert len(losses) == 6 and all(l == l for l in losses) and all(r["retro_loss"] > 0 for r in out["log"])
+    assert min(losses[-2:]) < losses[0], losses
