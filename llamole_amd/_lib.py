@@ -82,6 +82,7 @@ SIGNATURES = {
     "ll_gemv_fused_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "ll_set_gemv_nt": (_I, [_I]),
     "ll_set_chain_tuning": (_I, [_I, _I]),
+    "ll_weight_touch_probe": (_I, [_P, _I64, _I, _I, _P, _P]),
     "ll_set_gemv_stage": (_I, [_I]),
     "ll_set_m64_waves": (_I, [_I]),
     "ll_set_m128_panel": (_I, [_I]),

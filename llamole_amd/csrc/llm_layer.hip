@@ -599,6 +599,23 @@ __global__ __launch_bounds__(256) void decode_prologue_kernel(const long long *_
     for (int j = tid; j < maxlen; j += 256) mask_o[(int64_t)b * maxlen + j] = (j <= p && mask2d[b * ms + j] != 0) ? 1 : 0;
 }
 
+// Reads [p, p + n16 * 16) once and drops it: the lines pass through the memory-side cache (Infinity Cache), nothing else happens.
+__global__ __launch_bounds__(256) void weight_touch_kernel(const u32x4 *__restrict__ p, int64_t n16, unsigned *sink, int nt) {
+    u32x4 acc = (u32x4)(0);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride * 4) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = i + u * stride;
+            v[u] = j < n16 ? (nt ? __builtin_nontemporal_load(p + j) : p[j]) : (u32x4)(0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc ^= v[u];
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u && sink) *sink = 1u;       // keeps the loads alive
+}
+
 static int g_gemv_nt = 1;   // non-temporal weight loads (tools/gemv_fused_sweep.py)
 static int g_gemv_stage = 1;   // one-row GEMVs without RMSNorm stage x in LDS (gemv_stage_kernel)
 
@@ -797,6 +814,13 @@ int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iter
     (void)hipFree(R);
     if (rc != LL_OK) return rc;
     LL_HIP(he);
+    return LL_OK;
+}
+
+int ll_weight_touch_probe(const void *p, int64_t bytes, int workgroups, int nt, void *sink, void *stream) {
+    LL_CHECK(p && bytes >= 16 && workgroups > 0, "ll_weight_touch_probe: bad argument");
+    hipLaunchKernelGGL(weight_touch_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const u32x4 *)p, bytes / 16, (unsigned *)sink, nt);
+    LL_LAUNCH_CHECK();
     return LL_OK;
 }
 
