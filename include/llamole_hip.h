@@ -256,20 +256,6 @@ int ll_gemv_fused_bf16(const void *x, int ldx, const void *W, int ldw, const flo
 int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, const void *sin, int64_t cs_stride, void *Kc,
                              void *Vc, const int64_t *pos, const void *mask, int64_t mask_stride, void *out, int B, int nh,
                              int nkv, int maxlen, int D, float scale, void *stream);
-/* ll_decode_chain_bf16 : the four GEMV phases between two attentions of a decode step for ONE token row as ONE launch --
- *     h1 = res + (att . wo^T + bo) ; act = silu(g) * u of rmsnorm(h1, norm2) . wgu^T ; h2 = h1 + act . wdown^T ; and, when nqkv_next > 0,
- *     qkv_next = rmsnorm(h2, norm1_next) . wqkv_next^T + bqkv_next of the NEXT decoder layer -- bit-identical to the four
- *     ll_gemv_fused_bf16 calls it replaces (Qwen2DecoderLayer.forward, transformers modeling_qwen2.py).  The launch's workgroups take
- *     the phases in blockIdx order; a later phase requests its first weights before it waits for its input (counter + write-through
- *     stores), so the weight stream does not drain at the phase boundaries.  h1 / act / h2 / qkv_next must be buffers that nothing else
- *     writes during the launch; counters: >= 1 KB of device memory, zeroed once by the caller (the launch leaves it zeroed).
- *     H (hidden) <= 8192, I (intermediate) <= 20480, multiples of 8.  ll_decode_chain_error: the error word of the counters block
- *     (non-zero: a bounded wait ran out; synchronises on the copy). */
-int ll_decode_chain_bf16(const void *att, const void *wo, const float *bo, const void *res, void *h1, int H, int nq, const void *wgu,
-                         const void *norm2, float eps2, void *act, int I, const void *wdown, void *h2, const void *wqkv_next,
-                         const float *bqkv_next, const void *norm1_next, float eps1_next, void *qkv_next, int nqkv_next, void *counters,
-                         void *stream);
-int ll_decode_chain_error(const void *counters, unsigned *error);
 /* ll_decode_prologue : per-token prologue of a decode step in one launch: cos/sin [B,D] bf16 of Qwen2RotaryEmbedding.forward
  *     (transformers modeling_qwen2.py: inv_freq * position in f32, cos/sin, * attention_scaling, cast) for position_ids [B],
  *     and the boolean key mask [B,maxlen] of create_causal_mask (masking_utils.py) for one new query at cache slot *pos:

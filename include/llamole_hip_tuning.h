@@ -90,13 +90,6 @@ int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iter
 int ll_set_rows16_geometry(int seg, int waves, int ksplit);
 int ll_rows16_bench(int M, int N, int K, int epi, int norm, int iters, int nweights, float *ms);
 int ll_set_gemv_nt(int on);
-/* Tuning of ll_decode_chain_bf16's phase hand-over: sleep = s_sleep(8) repetitions between two polls of a phase counter; mode bits:
- * 1 = completions go through 32 sub-counters (the last arriver of each adds to the phase counter), 2 = consumers do not wait and
- * 4 = producers do not signal (TIMING ONLY: results are wrong).  Returns the previous sleep | mode << 16. */
-int ll_set_chain_tuning(int sleep, int mode);
-/* Probe: read [p, p + bytes) once with `workgroups` workgroups and drop it (nt != 0: non-temporal loads) -- what a later kernel finds in the
- * memory-side cache (tools/mall_probe.py). */
-int ll_weight_touch_probe(const void *p, int64_t bytes, int workgroups, int nt, void *sink, void *stream);
 /* Tuning: one-row GEMVs without RMSNorm and K >= 8192 (down_proj) stage x in LDS once per workgroup (default on; bit-identical). */
 int ll_set_gemv_stage(int on);
 

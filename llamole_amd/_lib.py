@@ -76,13 +76,9 @@ SIGNATURES = {
     "ll_decode_attn_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, C.POINTER(_I64), C.POINTER(_I64), _P]),
     "ll_gemv_fused_bf16": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "ll_decode_attn_rope_bf16": (_I, [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _I, _F, _P]),
-    "ll_decode_chain_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _P, _I, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P]),
-    "ll_decode_chain_error": (_I, [_P, C.POINTER(C.c_uint)]),
     "ll_decode_prologue": (_I, [_P, _P, _F, _P, _I64, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ll_gemv_fused_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "ll_set_gemv_nt": (_I, [_I]),
-    "ll_set_chain_tuning": (_I, [_I, _I]),
-    "ll_weight_touch_probe": (_I, [_P, _I64, _I, _I, _P, _P]),
     "ll_set_gemv_stage": (_I, [_I]),
     "ll_set_m64_waves": (_I, [_I]),
     "ll_set_m128_panel": (_I, [_I]),

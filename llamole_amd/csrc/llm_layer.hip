@@ -7,8 +7,6 @@
 // is the one of the unfused kernels (gemv_bf16_kernel, rmsnorm/rope/silu_mul/kv_append/decode_attn in llm_ops.hip),
 // so results are bit-identical to them; what goes away is seven launch boundaries and seven HBM/L2 round trips of
 // [B, hidden]-sized vectors per layer.
-#include <algorithm>
-
 #include "common.h"
 #include "attn_decode.h"
 
@@ -273,243 +271,6 @@ __global__ __launch_bounds__(256) void gemv_stage_kernel(const bf16_t *__restric
     }
 }
 
-// ------------------------------------------------------------------------------------------ decode chain: four GEMV phases, one launch
-// o_proj + residual -> RMSNorm + gate|up + SiLU*mul -> down_proj + residual -> RMSNorm + q|k|v of the NEXT layer, for ONE token row, as
-// ONE launch whose workgroups take the four phases in blockIdx order (round 5).  A phase depends on the COMPLETE vector of the phase
-// before it, so as separate launches each pays a launch boundary during which HBM idles (3.1 us of fixed cost per GEMV in the fit of
-// HISTORY.md section 7: dispatch gap, ramp, tail).  Here a workgroup of a later phase is dispatched as soon as a slot frees, requests its
-// first block of weights -- which do not depend on anything -- and only then waits for the phase counter of its input: the weight stream
-// never drains across a phase boundary.
-//   producer: results as sc1 (write-through) stores -> s_waitcnt vmcnt(0) -> workgroup barrier -> one relaxed agent-scope atomic add;
-//   consumer: one lane polls the counter (relaxed agent-scope loads, s_sleep), workgroup barrier, then PLAIN loads of the input vector
-//             -- every activation address is written exactly once per launch and read only after its counter is complete, and the
-//             launch's own start invalidated the caches (the protocol tools/archive/soft_dep_probe.hip verified across XCDs: 2000
-//             phases x 512 workgroups, every word checked, with plain as well as sc1 loads on the consumer side).
-// Forward progress: the workgroups of ONE launch are handed to each XCD in blockIdx order, so when a consumer is placed all its
-// producers have been placed (running or done) and need nothing more to finish: the smallest unfinished workgroup can always run.
-// Every wait is bounded all the same: a timeout sets the error word, the launch runs on, and the host reports it.
-// Arithmetic: the bodies are gemv_fused_kernel<1, ...> / gemv_stage_kernel with the weight request moved ahead of the wait -- the
-// same FMA chains in the same order, so the chain is bit-identical to the four launches it replaces.
-struct ChainArgs {
-    const bf16_t *xa, *wa, *resa;  const float *ba;  bf16_t *outa;  int Na, Ka;          // A: outa = resa + (xa . wa^T + ba)        [o_proj]
-    const bf16_t *wb, *normb;  float epsb;  bf16_t *outb;  int Nb;                       // B: outb = silu(g) * u of rmsnorm(outa) . wb^T  [gate|up]
-    const bf16_t *wc;  bf16_t *outc;                                                     // C: outc = outa + outb . wc^T             [down_proj]
-    const bf16_t *wd, *normd;  const float *bd;  float epsd;  bf16_t *outd;  int Nd;     // D: outd = rmsnorm(outc) . wd^T + bd      [next q|k|v]; Nd = 0: absent
-    unsigned *ctr;                                                                       // [32 r]: completions of phase r (own 128-byte lines); [128]: error
-    int sleep, mode;                                                                     // tuning (ll_set_chain_tuning)
-};
-constexpr unsigned long long CHAIN_WAIT_TICKS = 2000000ull;      // 20 ms of the 100 MHz wall clock: a bound, never reached in a healthy launch
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t chain_rsrc(const void *p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000);
-}
-// bf16 result(s) of a wave's lane 0 as write-through stores (aux 16 = sc1): they are in memory, not in this XCD's L2, when vmcnt drains
-__device__ __forceinline__ void chain_store1(bf16_t *C, int n, bf16_t v) {
-    __builtin_amdgcn_raw_buffer_store_b16((short)v, chain_rsrc(C), n * 2, 0, 16);
-}
-__device__ __forceinline__ void chain_wait(const unsigned *ctr, unsigned target, unsigned *err, int sleep) {
-    if (threadIdx.x == 0) {
-        const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            for (int i = 0; i < sleep; ++i) __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > CHAIN_WAIT_TICKS) {
-                atomicOr(err, 1u);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    asm volatile("" ::: "memory");
-}
-// fan-in: workgroup `wg` of `n` adds to sub-counter wg % 32 (own line); the last arriver of a sub-counter zeroes it and adds 1 to the phase counter
-__device__ __forceinline__ void chain_signal(unsigned *ctr, unsigned *sub, int wg, int n, bool fanin) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (fanin) {
-            const int j = wg & 31;
-            const unsigned expect = (unsigned)((n - j + 31) >> 5);
-            unsigned *sc = sub + j * 32;
-            if (__hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1u) {
-                __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-// One workgroup of a GEMV phase (ONE token row).  NORM: RMSNorm prologue into LDS (gemv_fused_kernel<1, true, EPI>); STAGE: x staged in LDS
-// (gemv_stage_kernel); neither: x from L1 / L2 next to the weight stream (gemv_fused_kernel<1, false, EPI>).  wait_ctr != nullptr: the
-// first weight block is requested, THEN the phase counter is awaited, then x is read.
-template <bool NORM, bool STAGE, int EPI, int XC>
-__device__ __forceinline__ void chain_gemv(int wg, const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, int ldw,
-                                           const float *__restrict__ bias, const bf16_t *__restrict__ normw, float eps,
-                                           const bf16_t *__restrict__ res, bf16_t *__restrict__ C, int N, int K, bf16_t *xs,
-                                           float (*red)[4], const unsigned *wait_ctr, unsigned wait_target, unsigned *err, int sleep) {
-    constexpr int R = 2, UNR = STAGE ? LL_GEMV_STAGE_UNR : LL_GEMV_UNR;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = wg * 4 + (tid >> 6);
-    const int n0 = EPI == GEMV_SILU_MUL ? wave : wave * R;
-    const bool active = n0 < N;
-    const bf16_t *wr[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int64_t row = EPI == GEMV_SILU_MUL ? (int64_t)(n0 < N ? n0 : N - 1) + (int64_t)r * N : (n0 + r < N ? n0 + r : N - 1);
-        wr[r] = W + row * ldw;
-    }
-    const int nchunk = K / 8;
-    u32x4 wv[UNR][R];
-    if (NORM || STAGE) gemv_load_w<UNR, true>(wv, wr, lane, nchunk, active);      // nothing in this block depends on the phase before
-    if (wait_ctr) chain_wait(wait_ctr, wait_target, err, sleep);
-    float acc[1][R] = {{0.f, 0.f}};
-    if (NORM) {
-        u32x4 xv0[XC], nw0[XC];
-#pragma unroll
-        for (int c = 0; c < XC; ++c) {
-            const int ch = tid + c * 256;
-            const bool ok = ch < nchunk;
-            xv0[c] = ok ? *reinterpret_cast<const u32x4 *>(X + ch * 8) : (u32x4)(0);
-            nw0[c] = ok ? *reinterpret_cast<const u32x4 *>(normw + ch * 8) : (u32x4)(0);
-        }
-        // same summation order as rmsnorm_bf16_kernel / gemv_fused_kernel: per-thread fmaf chain over its chunks, wave_sum, 4 partials
-        float ss = 0.f;
-#pragma unroll
-        for (int c = 0; c < XC; ++c)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float a = __uint_as_float(xv0[c][t] << 16), b = __uint_as_float(xv0[c][t] & 0xffff0000u);
-                ss = fmaf(a, a, ss);
-                ss = fmaf(b, b, ss);
-            }
-        ss = wave_sum(ss);
-        if (lane == 0) red[0][tid >> 6] = ss;
-        __syncthreads();
-        const float var = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)K;
-        const float rstd = rsqrtf(var + eps);
-#pragma unroll
-        for (int c = 0; c < XC; ++c) {
-            const int ch = tid + c * 256;
-            if (ch < nchunk) {
-                u32x4 o;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float a = bfr2(__uint_as_float(xv0[c][t] << 16) * rstd) * __uint_as_float(nw0[c][t] << 16);
-                    const float b = bfr2(__uint_as_float(xv0[c][t] & 0xffff0000u) * rstd) * __uint_as_float(nw0[c][t] & 0xffff0000u);
-                    o[t] = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
-                }
-                *reinterpret_cast<u32x4 *>(xs + ch * 8) = o;
-            }
-        }
-        __syncthreads();
-    } else if (STAGE) {
-        constexpr int XCS = 10;       // 16-byte chunks of x per thread: K <= 20480
-#pragma unroll
-        for (int c = 0; c < XCS; ++c) {
-            const int ch = tid + c * 256;
-            if (ch < nchunk) *reinterpret_cast<u32x4 *>(xs + ch * 8) = *reinterpret_cast<const u32x4 *>(X + ch * 8);
-        }
-        __syncthreads();
-    }
-    if (active) {
-        if (NORM || STAGE) {
-            gemv_fma<1, UNR, true>(acc, wv, xs, K, lane, nchunk);
-            for (int c0 = lane + 64 * UNR; c0 < nchunk; c0 += 64 * UNR) {
-                gemv_load_w<UNR, true>(wv, wr, c0, nchunk, true);
-                gemv_fma<1, UNR, true>(acc, wv, xs, K, c0, nchunk);
-            }
-        } else {
-            for (int c0 = lane; c0 < nchunk; c0 += 64 * UNR) {
-                // x chunk u right behind weight chunk u, as in gemv_fused_kernel<1, false, ...>
-                u32x4 xv[UNR][1];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int c = c0 + u * 64;
-                    const bool ok = c < nchunk;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) wv[u][r] = ok ? ldw16<true>(wr[r] + c * 8) : (u32x4)(0);
-                    xv[u][0] = ok ? *reinterpret_cast<const u32x4 *>(X + c * 8) : (u32x4)(0);
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        float a = acc[0][r];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            a = fmaf(__uint_as_float(wv[u][r][t] << 16), __uint_as_float(xv[u][0][t] << 16), a);
-                            a = fmaf(__uint_as_float(wv[u][r][t] & 0xffff0000u), __uint_as_float(xv[u][0][t] & 0xffff0000u), a);
-                        }
-                        acc[0][r] = a;
-                    }
-                }
-            }
-        }
-        float v[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = wave_sum(acc[0][r]);
-        if (lane == 0) {
-            if (EPI == GEMV_SILU_MUL) {
-                const float g = bfr2(v[0] + (bias ? bias[n0] : 0.f)), up = bfr2(v[1] + (bias ? bias[n0 + N] : 0.f));
-                chain_store1(C, n0, f32_to_bf16(bfr2(silu(g)) * up));
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (n0 + r < N) {
-                        float o = v[r] + (bias ? bias[n0 + r] : 0.f);
-                        if (EPI == GEMV_RESIDUAL) o = bf16_to_f32(res[n0 + r]) + bfr2(o);
-                        chain_store1(C, n0 + r, f32_to_bf16(o));
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int XC>
-__global__ __launch_bounds__(256) void decode_chain_kernel(ChainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm_chain[];
-    bf16_t *xs = reinterpret_cast<bf16_t *>(sm_chain);
-    __shared__ float red[1][4];
-    const int nA = cdiv(a.Na, 8), nB = cdiv(a.Nb, 4), nC = nA, nD = cdiv(a.Nd, 8);
-    unsigned *err = a.ctr + 128;
-    const bool fanin = a.mode & 1, nowait = a.mode & 2, nosignal = a.mode & 4;
-    const unsigned tA = fanin ? (unsigned)min(nA, 32) : (unsigned)nA, tB = fanin ? (unsigned)min(nB, 32) : (unsigned)nB,
-                   tC = fanin ? (unsigned)min(nC, 32) : (unsigned)nC;
-    int bid = blockIdx.x, n;
-    unsigned *mine;
-    if (bid < nA) {
-        chain_gemv<false, false, GEMV_RESIDUAL, XC>(bid, a.xa, a.wa, a.Ka, a.ba, nullptr, 0.f, a.resa, a.outa, a.Na, a.Ka, xs, red, nullptr, 0u, err, a.sleep);
-        mine = a.ctr;  n = nA;
-    } else if ((bid -= nA) < nB) {
-        chain_gemv<true, false, GEMV_SILU_MUL, XC>(bid, a.outa, a.wb, a.Na, nullptr, a.normb, a.epsb, nullptr, a.outb, a.Nb, a.Na, xs, red, nowait ? nullptr : a.ctr, tA, err, a.sleep);
-        mine = a.ctr + 32;  n = nB;
-    } else if ((bid -= nB) < nC) {
-        chain_gemv<false, true, GEMV_RESIDUAL, XC>(bid, a.outb, a.wc, a.Nb, nullptr, nullptr, 0.f, a.outa, a.outc, a.Na, a.Nb, xs, red, nowait ? nullptr : a.ctr + 32, tB, err, a.sleep);
-        mine = a.ctr + 64;  n = nC;
-    } else {
-        bid -= nC;
-        chain_gemv<true, false, GEMV_PLAIN, XC>(bid, a.outc, a.wd, a.Na, a.bd, a.normd, a.epsd, nullptr, a.outd, a.Nd, a.Na, xs, red, nowait ? nullptr : a.ctr + 64, tC, err, a.sleep);
-        mine = a.ctr + 96;  n = nD;
-    }
-    if (nosignal) return;
-    chain_signal(mine, a.ctr + 256 + (int)(mine - a.ctr) * 32, bid, n, fanin);
-    // the last workgroup of the last phase leaves the counters zeroed for the next launch (everybody else is past its wait by then)
-    const bool last_phase = nD > 0 ? mine == a.ctr + 96 : mine == a.ctr + 64;
-    if (last_phase && threadIdx.x == 0) {
-        const unsigned total = nD > 0 ? (unsigned)nD : (unsigned)nC;
-        const unsigned t = __hip_atomic_fetch_add(a.ctr + 160, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == total - 1u) {
-            __hip_atomic_store(a.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.ctr + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.ctr + 64, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.ctr + 96, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.ctr + 160, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
 // Rotary embedding + KV append + GQA decode attention for ONE new position per sequence.
 // grid (nh, B).  qkv row b = [q: nh*D | k: nkv*D | v: nkv*D] (output of the fused q/k/v GEMV).  The new key / value of
 // the head's KV group is rotated in LDS and used from there; the first query head of each group also stores it to the
@@ -597,23 +358,6 @@ __global__ __launch_bounds__(256) void decode_prologue_kernel(const long long *_
     }
     const long long p = *pos_ptr;
     for (int j = tid; j < maxlen; j += 256) mask_o[(int64_t)b * maxlen + j] = (j <= p && mask2d[b * ms + j] != 0) ? 1 : 0;
-}
-
-// Reads [p, p + n16 * 16) once and drops it: the lines pass through the memory-side cache (Infinity Cache), nothing else happens.
-__global__ __launch_bounds__(256) void weight_touch_kernel(const u32x4 *__restrict__ p, int64_t n16, unsigned *sink, int nt) {
-    u32x4 acc = (u32x4)(0);
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride * 4) {
-        u32x4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t j = i + u * stride;
-            v[u] = j < n16 ? (nt ? __builtin_nontemporal_load(p + j) : p[j]) : (u32x4)(0);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc ^= v[u];
-    }
-    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u && sink) *sink = 1u;       // keeps the loads alive
 }
 
 static int g_gemv_nt = 1;   // non-temporal weight loads (tools/gemv_fused_sweep.py)
@@ -715,51 +459,6 @@ int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, c
     return LL_OK;
 }
 
-
-static int g_chain_sleep = 1, g_chain_mode = 0;   // ll_set_chain_tuning
-int ll_set_chain_tuning(int sleep, int mode) {
-    const int old = g_chain_sleep | (g_chain_mode << 16);
-    g_chain_sleep = sleep < 0 ? 0 : sleep;
-    g_chain_mode = mode;
-    return old;
-}
-
-int ll_decode_chain_bf16(const void *att, const void *wo, const float *bo, const void *res, void *h1, int H, int nq, const void *wgu,
-                         const void *norm2, float eps2, void *act, int I, const void *wdown, void *h2, const void *wqkv_next,
-                         const float *bqkv_next, const void *norm1_next, float eps1_next, void *qkv_next, int nqkv_next, void *counters,
-                         void *stream) {
-    LL_CHECK(att && wo && res && h1 && wgu && norm2 && act && wdown && h2 && counters, "ll_decode_chain_bf16: null argument");
-    LL_CHECK(H >= 8 && H % 8 == 0 && H <= 8192 && nq >= 8 && nq % 8 == 0 && I >= 8 && I % 8 == 0 && I <= 20480,
-             "ll_decode_chain_bf16: unsupported shape H=%d nq=%d I=%d", H, nq, I);
-    LL_CHECK(nqkv_next == 0 || (wqkv_next && norm1_next && qkv_next), "ll_decode_chain_bf16: next-layer q|k|v phase without its operands");
-    ChainArgs a;
-    a.xa = (const bf16_t *)att; a.wa = (const bf16_t *)wo; a.resa = (const bf16_t *)res; a.ba = bo; a.outa = (bf16_t *)h1; a.Na = H; a.Ka = nq;
-    a.wb = (const bf16_t *)wgu; a.normb = (const bf16_t *)norm2; a.epsb = eps2; a.outb = (bf16_t *)act; a.Nb = I;
-    a.wc = (const bf16_t *)wdown; a.outc = (bf16_t *)h2;
-    a.wd = (const bf16_t *)wqkv_next; a.normd = (const bf16_t *)norm1_next; a.bd = bqkv_next; a.epsd = eps1_next; a.outd = (bf16_t *)qkv_next;
-    a.Nd = nqkv_next;
-    a.ctr = (unsigned *)counters;
-    a.sleep = g_chain_sleep; a.mode = g_chain_mode;
-    const int grid = 2 * cdiv(H, 8) + cdiv(I, 4) + cdiv(nqkv_next, 8);
-    const size_t lds = (size_t)std::max(std::max(H, I), nq) * 2;
-    static bool attr = false;
-    if (!attr) {
-        LL_HIP(hipFuncSetAttribute((const void *)decode_chain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        LL_HIP(hipFuncSetAttribute((const void *)decode_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr = true;
-    }
-    if (H <= 4096) hipLaunchKernelGGL(decode_chain_kernel<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(decode_chain_kernel<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
-    LL_LAUNCH_CHECK();
-    return LL_OK;
-}
-
-int ll_decode_chain_error(const void *counters, unsigned *error) {
-    LL_CHECK(counters && error, "ll_decode_chain_error: null argument");
-    LL_HIP(hipMemcpy(error, (const unsigned *)counters + 128, sizeof(unsigned), hipMemcpyDeviceToHost));
-    return LL_OK;
-}
-
 int ll_decode_prologue(const int64_t *position_ids, const float *inv_freq, float attention_scaling, const int64_t *mask2d,
                        int64_t mask_stride, const int64_t *pos, void *cos, void *sin, void *mask_out, int B, int D, int maxlen,
                        void *stream) {
@@ -814,13 +513,6 @@ int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iter
     (void)hipFree(R);
     if (rc != LL_OK) return rc;
     LL_HIP(he);
-    return LL_OK;
-}
-
-int ll_weight_touch_probe(const void *p, int64_t bytes, int workgroups, int nt, void *sink, void *stream) {
-    LL_CHECK(p && bytes >= 16 && workgroups > 0, "ll_weight_touch_probe: bad argument");
-    hipLaunchKernelGGL(weight_touch_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const u32x4 *)p, bytes / 16, (unsigned *)sink, nt);
-    LL_LAUNCH_CHECK();
     return LL_OK;
 }
 

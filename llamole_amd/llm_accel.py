@@ -23,10 +23,6 @@ MAX_STREAM_ROWS = 16    # ll_linear_rows16_bf16: one MFMA column block of token 
 # stream does (tools/batch_sweep.sh: batch 4 = 603 ms per step on the FMA path vs 467 ms, batch 2 = 456 vs 439 ms -- the default
 # stays at 2 so that two-sequence decode keeps the bit-identity with HF's op order; LLAMOLE_FMA_GEMV_ROWS=1 trades it for the 4 %)
 FMA_GEMV_ROWS = int(os.environ.get("LLAMOLE_FMA_GEMV_ROWS", "2"))
-# One-row decode: o_proj -> gate|up -> down_proj -> the NEXT layer's q|k|v as ONE launch per layer (ll_decode_chain_bf16: the phases take the
-# launch's workgroups in order and hand over through counters, so the weight stream does not drain at the three launch boundaries it
-# removes).  Bit-identical to the separate launches; LLAMOLE_DECODE_CHAIN=0 keeps the five launches per layer.
-DECODE_CHAIN = os.environ.get("LLAMOLE_DECODE_CHAIN", "1") != "0"
 MAX_APPEND_ROWS = 16     # new positions per call served by the fused KV append / decode attention (decode, query tail)
 # row-parallel elementwise kernels (RMSNorm, rotary, SiLU*mul) also serve prefill-sized calls.  Round 3: the A* value estimates push
 # 256 prompts x ~144 tokens = 37 k rows through the model per forward; above the old 16 k-row limit HF's op-by-op RMSNorm (pow, mean, rsqrt,
@@ -493,13 +489,6 @@ class _FusedLayer:
         self.n1, self.n2 = layer.input_layernorm, layer.post_attention_layernorm
         self.eps1, self.eps2 = float(self.n1.variance_epsilon), float(self.n2.variance_epsilon)
         self.stream_ok = self.H % 32 == 0 and self.nq % 32 == 0 and self.I % 32 == 0 and self.n1.weight.dtype == torch.bfloat16
-        # decode chain (one token row): the next decoder layer (its q|k|v runs as this layer's fourth phase), buffers that every launch writes
-        # exactly once, the phase counters, and the q|k|v row the PREVIOUS layer's chain left for this one
-        self.next = None
-        self.chain_ok = (self.H % 8 == 0 and self.H <= 8192 and self.nq % 8 == 0 and self.I % 8 == 0 and self.I <= 20480
-                         and self.n1.weight.dtype == torch.bfloat16 and self.n2.weight.dtype == torch.bfloat16)
-        self._chain_bufs = None
-        self._carry = None          # (source tensor, q|k|v row) written by the previous layer's chain launch
 
     def eligible(self, h, mask, cache, pe) -> bool:
         if not (h.is_cuda and h.dtype == torch.bfloat16 and h.dim() == 3 and h.shape[1] == 1
@@ -538,63 +527,14 @@ class _FusedLayer:
             _lib.check(rc, "ll_gemv_fused_bf16")
         return out
 
-    def _bufs(self, device):
-        if self._chain_bufs is None:
-            mk = lambda n: torch.empty(1, n, dtype=torch.bfloat16, device=device)      # noqa: E731
-            self._chain_bufs = dict(qkv=mk(self.nq + 2 * self.nkv_dim), att=mk(self.nq), h1=mk(self.H), act=mk(self.I), h2=mk(self.H),
-                                    ctr=torch.zeros(8192, dtype=torch.int32, device=device))
-        return self._chain_bufs
-
-    def chain_error(self) -> int:
-        """Error word of this layer's chain launches (non-zero: a bounded wait ran out); synchronises."""
-        if self._chain_bufs is None:
-            return 0
-        import ctypes as C
-        e = C.c_uint(0)
-        _lib.check(self.lib.ll_decode_chain_error(self._chain_bufs["ctr"].data_ptr(), C.byref(e)), "ll_decode_chain_error")
-        return int(e.value)
-
-    def run(self, h, mask, cache, pe, chain=False):
-        """One decode step of this layer.  ``chain``: the caller runs the fused layers back to back and consumes only the last one's output
-        before the next token (``_model_forward``), so the chain launch may keep its rows in per-layer buffers and hand the next layer its
-        q|k|v; a layer called on its own by HF's forward (hidden-state taps, hooks) takes the five launches with fresh outputs."""
+    def run(self, h, mask, cache, pe):
         B, H = h.shape[0], self.H
         x = h.view(B, H)
         cl = cache.layers[self.layer_idx]
         pos = cache.layers[0].cumulative_length
         cos, sin = pe
         nqkv = self.nq + 2 * self.nkv_dim
-        chain = chain and DECODE_CHAIN and B == 1 and self.chain_ok and (self.next is None or self.next.chain_ok)
-        carry, self._carry = self._carry, None
-        if chain and carry is not None and carry[0].data_ptr() == h.data_ptr():
-            qkv = carry[1]                      # the previous layer's chain launch computed this layer's q|k|v from the same hidden state
-        else:
-            qkv = self._gemv(x, self.wqkv, self.bqkv, self.n1.weight, self.eps1, None, nqkv, H, 0)
-        if chain:
-            bufs = self._bufs(h.device)
-            att = bufs["att"]
-            rc = self.lib.ll_decode_attn_rope_bf16(qkv.data_ptr(), nqkv, cos.data_ptr(), sin.data_ptr(),
-                                                   0 if cos.shape[0] == 1 else cos.stride(0), cl.keys.data_ptr(), cl.values.data_ptr(),
-                                                   pos.data_ptr(), mask.data_ptr(), mask.stride(0), att.data_ptr(), B, self.nh, self.nkv,
-                                                   cl.keys.shape[2], self.D, self.scaling, torch.cuda.current_stream().cuda_stream)
-            if rc != 0:
-                _lib.check(rc, "ll_decode_attn_rope_bf16")
-            nxt = self.next
-            nb = nxt._bufs(h.device) if nxt is not None else None
-            rc = self.lib.ll_decode_chain_bf16(
-                att.data_ptr(), self.wo.data_ptr(), self.bo.data_ptr() if self.bo is not None else None, x.data_ptr(), bufs["h1"].data_ptr(),
-                H, self.nq, self.wgu.data_ptr(), self.n2.weight.data_ptr(), self.eps2, bufs["act"].data_ptr(), self.I, self.wdown.data_ptr(),
-                bufs["h2"].data_ptr(),
-                nxt.wqkv.data_ptr() if nxt is not None else None, (nxt.bqkv.data_ptr() if nxt.bqkv is not None else None) if nxt is not None else None,
-                nxt.n1.weight.data_ptr() if nxt is not None else None, nxt.eps1 if nxt is not None else 0.0,
-                nb["qkv"].data_ptr() if nxt is not None else None, (nxt.nq + 2 * nxt.nkv_dim) if nxt is not None else 0,
-                bufs["ctr"].data_ptr(), torch.cuda.current_stream().cuda_stream)
-            if rc != 0:
-                _lib.check(rc, "ll_decode_chain_bf16")
-            out = bufs["h2"].view(B, 1, H)
-            if nxt is not None:
-                nxt._carry = (out, nb["qkv"])
-            return out
+        qkv = self._gemv(x, self.wqkv, self.bqkv, self.n1.weight, self.eps1, None, nqkv, H, 0)
         att = torch.empty(B, self.nq, dtype=torch.bfloat16, device=h.device)
         rc = self.lib.ll_decode_attn_rope_bf16(qkv.data_ptr(), nqkv, cos.data_ptr(), sin.data_ptr(),
                                                0 if cos.shape[0] == 1 else cos.stride(0), cl.keys.data_ptr(), cl.values.data_ptr(),
@@ -646,12 +586,6 @@ def fuse_decoder_layers(model: nn.Module) -> int:
         layer._ll_layer_orig = layer.forward
         layer.forward = types.MethodType(_layer_forward, layer)
         n += 1
-    prev = None
-    for layer in layers:          # consecutive patched layers: the decode chain of layer l ends with layer l + 1's q|k|v
-        st = layer.__dict__.get("_ll_fused")
-        if prev is not None and st is not None:
-            prev.next = st
-        prev = st
     return n
 
 
@@ -701,7 +635,7 @@ def _model_forward(self, input_ids=None, attention_mask=None, position_ids=None,
             pe = (cos, sin)
             if layers[0]._ll_fused.eligible(h, mask, past_key_values, pe):
                 for layer in layers:
-                    h = layer._ll_fused.run(h, mask, past_key_values, pe, chain=True)
+                    h = layer._ll_fused.run(h, mask, past_key_values, pe)
                 h = self.norm(h)
                 from transformers.modeling_outputs import BaseModelOutputWithPast
                 return BaseModelOutputWithPast(last_hidden_state=h, past_key_values=past_key_values if use_cache else None)
