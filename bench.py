@@ -393,10 +393,10 @@ def main():
     if getattr(step_fn, "pipeline", False):
         step_fn.finish()                 # no trajectory of a warm-up prompt is left for the timed region
     barrier()
-    trace_on = os.environ.get("LLAMOLE_E2E_TRACE") == "1"      # host timeline of the e2e step (llamole_amd/_trace.py), folded on stderr
+    trace_on = os.environ.get("LLAMOLE_E2E_TRACE") in ("1", "2")      # host timeline of the e2e step (llamole_amd/_trace.py), folded on stderr
     if trace_on:
         from llamole_amd import _trace
-        _trace.start()
+        _trace.start(device=os.environ.get("LLAMOLE_E2E_TRACE") == "2")
     t0 = time.perf_counter()
     dit_ms = []
     piped = bool(getattr(step_fn, "pipeline", False))
@@ -416,6 +416,15 @@ def main():
     dt = time.perf_counter() - t0
     if trace_on:
         ev = _trace.stop()
+        if isinstance(ev, tuple):          # LLAMOLE_E2E_TRACE=2: where the DEVICE is at each mark, per step, relative to the step's first mark
+            ev, dev = ev
+            first = dev[0][1]
+            starts = [i for i, (n, _) in enumerate(dev) if n == "step: enter"]
+            for a, b in list(zip(starts, starts[1:] + [len(dev)]))[1:4]:
+                base = dev[a][1]
+                log(f"device timeline of the step that starts {first.elapsed_time(base):9.2f} ms into the timed region:")
+                for n, e in dev[a:b]:
+                    log(f"    {base.elapsed_time(e):9.3f} ms  {n}")
         agg = {}
         for (a, ta), (b, tb) in zip(ev, ev[1:]):
             k = f"{a}  ->  {b}"

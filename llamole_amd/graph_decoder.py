@@ -509,7 +509,9 @@ class GraphDiT(nn.Module):
             self._side_stream = torch.cuda.Stream(device=dev)
         side = self._side_stream
         side.wait_stream(torch.cuda.current_stream(dev))
+        from ._trace import mark
         with torch.cuda.stream(side):
+            mark("dit: trajectory begins (side stream)")
             n_nodes = self.begin(properties, text_embedding, no_label_index, n_nodes)
             B, N = self._B, self.max_n_nodes
             qx = torch.empty(B * N, XDIM).exponential_()
@@ -519,6 +521,7 @@ class GraphDiT(nn.Module):
             self.init_state(qx, qe, seed)
             self.run(seed, use_graph, overlap=getattr(self, "async_overlap_mode", True))
             X, E = self.get_state()
+            mark("dit: trajectory ends (side stream)")
         for t in (properties, text_embedding):
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(side)

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
+import os
+
 import torch
 
 
@@ -80,6 +82,15 @@ class GraphedDecoder:
         # bookkeeping are ONE launch inside the captured step (ll_sample_token_bf16); "torch": op-by-op PyTorch sampler
         self.sampler = sampler
         self.len_bucket = 64
+        # the eager query-token forward over the decode's KV cache (continue_hidden: <= 16 new positions, so the attention is this
+        # library's decode kernel and HF's mask is the explicit one either way) is host-bound -- 28 layers x ~20 Python-dispatched ops,
+        # 7.4 ms of host time for 3.7 ms of kernels at Qwen2-7B: a (batch, length) shape seen a second time is captured as a hipGraph
+        # and replayed from then on (LLAMOLE_GRAPH_SUFFIX=0: always eager).  The prompt prefill is NOT captured: transformers takes
+        # other mask decisions while a stream is capturing (masking_utils.is_tracing), i.e. other SDPA kernels and roundings than the
+        # eager prefill, and under the overlapped trajectory the prefill is device-bound anyway (HISTORY R5.8).
+        self.graph_suffix = self.use_graph and os.environ.get("LLAMOLE_GRAPH_SUFFIX", "1") != "0"
+        self.max_side_graphs = 4
+        self._side_graphs = {}
         self._sample_key = None
         self._cache_fused = False
         self._key = None
@@ -107,6 +118,41 @@ class GraphedDecoder:
         self.logits = None
         self._graph = None
         self._cache_fused = False
+        self._side_graphs = {}          # captured against the buffers above
+
+    def _captured(self, key, statics, fn):
+        """``fn(*static buffers)`` eager the first time ``key`` is seen, captured the second time, replayed afterwards; ``statics`` are
+        (static buffer factory, current value) pairs.  Returns fn's output (a tensor that the next replay overwrites).  A capture that
+        fails (an op that synchronises) switches the shape back to eager for good."""
+        values = [v for _, v in statics]
+        st = self._side_graphs.get(key)
+        if not self.graph_suffix or st == "eager":
+            return fn(*values)
+        if st is None:
+            if len(self._side_graphs) >= self.max_side_graphs:      # shapes that do not repeat (A* expansion prompts) stay eager
+                self._side_graphs.pop(next(iter(self._side_graphs)))
+            self._side_graphs[key] = "seen"
+            return fn(*values)
+        if st == "seen":
+            bufs = [mk(v) for (mk, _), v in zip(statics, values)]
+            for b, v in zip(bufs, values):
+                b.copy_(v)
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    out = fn(*bufs)
+            except Exception as e:          # noqa: BLE001 -- whatever the capture refuses: this shape runs eager from now on
+                import warnings
+                warnings.warn(f"hipGraph capture of the {key[0]} forward failed ({type(e).__name__}: {e}); it stays eager")
+                self._side_graphs[key] = "eager"
+                torch.cuda.synchronize()
+                return fn(*values)
+            st = self._side_graphs[key] = (g, bufs, out)
+        g, bufs, out = st
+        for b, v in zip(bufs, values):
+            b.copy_(v)
+        g.replay()
+        return out
 
     def _step(self):
         out = self.model(input_ids=self.tok, attention_mask=self.mask, past_key_values=self.cache,
@@ -138,11 +184,15 @@ class GraphedDecoder:
         pos = torch.arange(start, start + S, device=device)
         posid = info["plen"] + (start - P) + torch.arange(S, device=device).unsqueeze(0)
         base = getattr(self.model, "model", self.model)
-        out = base(input_ids=tail_ids, attention_mask=self.mask, past_key_values=self.cache, cache_position=pos,
-                   position_ids=posid, use_cache=True, return_dict=True)
+
+        def fwd(ids, cache_pos, pos_ids):
+            return base(input_ids=ids, attention_mask=self.mask, past_key_values=self.cache, cache_position=cache_pos,
+                        position_ids=pos_ids, use_cache=True, return_dict=True).last_hidden_state
+
+        hidden = self._captured(("suffix", B, S), [(torch.empty_like, tail_ids), (torch.empty_like, pos), (torch.empty_like, posid)], fwd)
         if self._cache_fused:
             self.cache.layers[0].cumulative_length.add_(S)
-        return out.last_hidden_state
+        return hidden
 
     def _hip_sample(self, logits: torch.Tensor, sp, advance: int):
         """One launch: sample (or argmax) from bf16 logits [B,V], write tok / out_buf[:, step], update done / step and,
@@ -175,10 +225,14 @@ class GraphedDecoder:
             self._sample_key = sp
             self._graph = None
         self._hip_sample(logits, sp, 0)
+        from ._trace import mark
+        mark("generate: first token sampled")
         n = 1
         for t in range(1, max_new_tokens):
-            if eos_list and t % self.sync_every == 0 and bool(self.done.all()):
-                break
+            if eos_list and t % self.sync_every == 0:
+                if bool(self.done.all()):
+                    break
+                mark("generate: rendezvous")
             if self.use_graph:
                 if self._graph is None:
                     s = torch.cuda.Stream()

@@ -469,6 +469,50 @@ def test_query_forward_reuses_decode_cache_gpu():
     restore_elementwise(llm)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ["tiny", "tiny-llama"])
+def test_captured_query_forward_equals_the_eager_one(arch, monkeypatch):
+    """The query-token forward over the decode's KV cache is captured as a hipGraph the second time a (batch, length) shape is seen: same
+    kernels in the same order -> the same KV cache and [1,768] condition as the eager forward, on new prompt contents and other prompt
+    lengths (the cache position is a device buffer of the graph) every call; LLAMOLE_GRAPH_SUFFIX=0 stays eager."""
+    from llamole_amd.llm_accel import (accelerate_elementwise, accelerate_linears, fuse_decoder_layers, fuse_model_decode, restore_elementwise,
+                                       use_decode_attention)
+    llm = e2e.build_llm(arch, "cuda", torch.bfloat16)
+    accelerate_linears(llm, min_weight_elems=1)
+    accelerate_elementwise(llm)
+    assert use_decode_attention(llm)
+    fuse_decoder_layers(llm)
+    fuse_model_decode(llm)
+    try:
+        orch_g, _ = _orchestrator(llm, "cuda", torch.bfloat16)
+        orch_g.enable_graphed_decode(use_graph=True, fused_cache=True, reuse_query_kv=True)
+        monkeypatch.setenv("LLAMOLE_GRAPH_SUFFIX", "0")
+        orch_e, _ = _orchestrator(llm, "cuda", torch.bfloat16)
+        orch_e.enable_graphed_decode(use_graph=True, fused_cache=True, reuse_query_kv=True)
+        monkeypatch.delenv("LLAMOLE_GRAPH_SUFFIX")
+        assert orch_g.decoder.graph_suffix and not orch_e.decoder.graph_suffix
+        orch_g.lm_to_graph_decoder.load_state_dict(orch_e.lm_to_graph_decoder.state_dict())      # each orchestrator drew its own connector
+        kw = dict(do_sample=False, max_new_tokens=24, eos_token_id=[], pad_token_id=0)
+        g = torch.Generator().manual_seed(5)
+        for i, P in enumerate([16, 16, 16, 16, 40, 40, 40, 16]):
+            prompt = torch.randint(5, 1000, (1, P), generator=g).cuda()
+            mask = torch.ones_like(prompt)
+            a0, ids0, c0 = orch_e.design_hidden(prompt, mask, None, **kw)
+            logits0 = orch_e.decoder.last_logits.clone()
+            kv0 = [(l.keys.clone(), l.values.clone()) for l in orch_e.decoder.cache.layers]
+            a1, ids1, c1 = orch_g.design_hidden(prompt, mask, None, **kw)
+            assert torch.equal(a0, a1) and torch.equal(ids0, ids1), (i, P)
+            assert torch.equal(orch_g.decoder.last_logits, logits0), (i, P)
+            assert torch.equal(c0, c1), (i, P)
+            for (k, v), l in zip(kv0, orch_g.decoder.cache.layers):
+                assert torch.equal(l.keys, k) and torch.equal(l.values, v), (i, P)
+        states = orch_g.decoder._side_graphs
+        assert list(states) == [("suffix", 1, 9)] and isinstance(states[("suffix", 1, 9)], tuple), states
+        assert all(v == "seen" for v in orch_e.decoder._side_graphs.values())
+    finally:
+        restore_elementwise(llm)
+
+
 def test_enable_mi355x_decode_on_cpu_model_is_a_plain_static_cache_decoder():
     llm = e2e.build_llm("tiny", "cpu", torch.float32)
     orch, tok = _orchestrator(llm, "cpu", torch.float32)
