@@ -120,7 +120,8 @@ class PendingGraphs:
         if self._out is None:
             self.stream.synchronize()
             self.run_ms = self.owner.last_run_ms()[0]
-            X, E = self.X.cpu().long(), self.E.cpu().long()
+            with torch.cuda.stream(self.stream):       # the copies wait for the trajectory's stream only, not for what the caller has queued since
+                X, E = self.X.cpu().long(), self.E.cpu().long()
             mols = []
             for i in range(X.shape[0]):
                 n = int(self.n_nodes[i])
@@ -347,8 +348,9 @@ class GraphDiT(nn.Module):
         return torch.multinomial(p, batch_size, replacement=True)
 
     @torch.no_grad()
-    def begin(self, properties: torch.Tensor, text_embedding: torch.Tensor, no_label_index, n_nodes=None):
-        """Start a batch on the engine; returns n_nodes (CPU int64)."""
+    def begin(self, properties: torch.Tensor, text_embedding: torch.Tensor, no_label_index, n_nodes=None, n_nodes_dev=None):
+        """Start a batch on the engine; returns n_nodes (CPU int64).  ``n_nodes_dev``: the int32 device copy of ``n_nodes`` when the caller
+        staged it already (generate_graphs_async)."""
         if getattr(self, "_pending", None) is not None:
             # the engine's tables, state and captured step belong to the trajectory still in flight on the side stream
             raise RuntimeError("a generate_graphs_async trajectory is still pending on this engine: call .result() on it first")
@@ -365,7 +367,7 @@ class GraphDiT(nn.Module):
         n_nodes = torch.as_tensor(n_nodes).to("cpu", torch.int64)
         if int(n_nodes.max()) > self.max_n_nodes or int(n_nodes.min()) < 0:
             raise ValueError("n_nodes out of range")
-        self._n_nodes_dev = n_nodes.to(device=dev, dtype=torch.int32).contiguous()
+        self._n_nodes_dev = n_nodes.to(device=dev, dtype=torch.int32).contiguous() if n_nodes_dev is None else n_nodes_dev
         self._B = B
         _lib.check(_lib.load().ll_dit_begin(self._handle, B, _lib.dptr(props), _lib.dptr(text),
                                             _lib.dptr(self._n_nodes_dev), _lib.current_stream_ptr()), "ll_dit_begin")
@@ -508,16 +510,26 @@ class GraphDiT(nn.Module):
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=dev)
         side = self._side_stream
-        side.wait_stream(torch.cuda.current_stream(dev))
         from ._trace import mark
+        properties = torch.as_tensor(properties)
+        B, N = int(properties.shape[0]), self.max_n_nodes
         with torch.cuda.stream(side):
-            mark("dit: trajectory begins (side stream)")
-            n_nodes = self.begin(properties, text_embedding, no_label_index, n_nodes)
-            B, N = self._B, self.max_n_nodes
-            qx = torch.empty(B * N, XDIM).exponential_()
-            qe = torch.empty(B * N * N, EDIM).exponential_()
+            # host inputs first: a copy from pageable memory holds the host until the stream reaches it, so they go AHEAD of the wait for the
+            # caller's stream (which may still be running the forward that produces text_embedding)
+            if not properties.is_cuda:
+                properties = properties.to(dev)
+            if n_nodes is None:
+                n_nodes = self.sample_n_nodes(B)
+            n_nodes = torch.as_tensor(n_nodes).to("cpu", torch.int64)
+            nn_dev = n_nodes.to(device=dev, dtype=torch.int32).contiguous()
+            qx = torch.empty(B * N, XDIM).exponential_().to(dev)
+            qe = torch.empty(B * N * N, EDIM).exponential_().to(dev)
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            mark("dit: trajectory begins (side stream)")
+            n_nodes = self.begin(properties, text_embedding, no_label_index, n_nodes, n_nodes_dev=nn_dev)
             self.init_state(qx, qe, seed)
             self.run(seed, use_graph, overlap=getattr(self, "async_overlap_mode", True))
             X, E = self.get_state()
