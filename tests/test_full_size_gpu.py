@@ -115,6 +115,40 @@ def test_batched_decode_on_the_mfma_stream_at_full_size(name):
         restore_elementwise(llm)
 
 
+def test_captured_query_forward_at_full_size():
+    """Qwen2-7B shapes: the query-token forward over the decode's KV cache (9 rows; rows16 Linears, fused KV append, the library's attention
+    for <= 16 new positions) as a replayed hipGraph equals the eager forward bit for bit -- hidden states and the 9 cache slots it writes --
+    on three prompts in a row (eager, captured, replayed) with a cache position that differs per call."""
+    from llamole_amd import e2e
+    from llamole_amd.llm_accel import accelerate_llm, restore_elementwise
+    from llamole_amd.llm_decode import GraphedDecoder
+    llm = e2e.build_llm("qwen2-7b", "cuda", torch.bfloat16)
+    info = accelerate_llm(llm)
+    try:
+        dg = GraphedDecoder(llm, use_graph=True, fused_cache=bool(info.get("decode_attention")))
+        de = GraphedDecoder(llm, use_graph=True, fused_cache=bool(info.get("decode_attention")))
+        de.graph_suffix = False
+        assert dg.graph_suffix
+        g = torch.Generator().manual_seed(3)
+        tail = torch.randint(5, 150000, (1, 9), generator=g).cuda()
+        for i, (P, new) in enumerate([(48, 16), (48, 12), (48, 16), (30, 14)]):
+            prompt = torch.randint(5, 150000, (1, P), generator=g).cuda()
+            mask = torch.ones_like(prompt)
+            kw = dict(max_new_tokens=new, do_sample=False, pad_token_id=0, eos_token_id=[])
+            outs = []
+            for d in (de, dg):
+                d.generate(prompt, mask, **kw)
+                h = d.continue_hidden(tail, P + new - 9).clone()
+                outs.append((h, [(l.keys.clone(), l.values.clone()) for l in d.cache.layers[:3]]))
+            assert torch.equal(outs[0][0], outs[1][0]), (i, float((outs[0][0].float() - outs[1][0].float()).abs().max()))
+            for (k0, v0), (k1, v1) in zip(outs[0][1], outs[1][1]):
+                assert torch.equal(k0, k1) and torch.equal(v0, v1), i
+            assert torch.isfinite(outs[1][0].float()).all()
+        assert isinstance(dg._side_graphs[("suffix", 1, 9)], tuple) and not de._side_graphs
+    finally:
+        restore_elementwise(llm)
+
+
 def _last_but_one_logits(llm, seq):
     with torch.no_grad():
         return llm(input_ids=seq[:, :-1]).logits[0, -1].float()
