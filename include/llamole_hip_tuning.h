@@ -90,11 +90,6 @@ int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iter
 int ll_set_rows16_geometry(int seg, int waves, int ksplit);
 int ll_rows16_bench(int M, int N, int K, int epi, int norm, int iters, int nweights, float *ms);
 int ll_set_gemv_nt(int on);
-/* Probe (tools/attn_oproj_probe.py): ll_decode_attn_rope_bf16 for ONE sequence (head_dim 128) and the o_proj GEMV + residual of ll_gemv_fused_bf16
- * behind it as one launch; counters: >= 2 KB of zeroed device memory (word 256: a wait ran out). */
-int ll_decode_attn_oproj_probe(const void *qkv, int64_t ld_qkv, const void *cos, const void *sin, void *Kc, void *Vc, const int64_t *pos,
-                               const void *mask, void *att, int nh, int nkv, int maxlen, int D, float scale, const void *wo, const float *bo,
-                               const void *res, void *h1, int H, void *counters, int sleep, void *stream);
 /* Tuning: one-row GEMVs without RMSNorm and K >= 8192 (down_proj) stage x in LDS once per workgroup (default on; bit-identical). */
 int ll_set_gemv_stage(int on);
 

@@ -79,7 +79,6 @@ SIGNATURES = {
     "ll_decode_prologue": (_I, [_P, _P, _F, _P, _I64, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ll_gemv_fused_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "ll_set_gemv_nt": (_I, [_I]),
-    "ll_decode_attn_oproj_probe": (_I, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _I, _P, _I, _P]),
     "ll_set_gemv_stage": (_I, [_I]),
     "ll_set_m64_waves": (_I, [_I]),
     "ll_set_m128_panel": (_I, [_I]),

@@ -89,7 +89,7 @@ __device__ __forceinline__ void attn_axpy8(float (&acc)[8], float p, au32x4 vv) 
 
 // qs [D] f32 query, part [ATTN_WAVES][RPI][D], sc [maxlen], red [2 * ATTN_WAVES] in LDS; the caller has synchronised after writing qs (and kn /
 // vn).  NEWKV: key / value `p` are taken from kn / vn (LDS, bf16) instead of the cache.  Writes D outputs to outp.
-template <int D, bool NEWKV, bool WT = false>
+template <int D, bool NEWKV>
 __device__ __forceinline__ void attn_finish(AttnTile0<D> &t, const float *qs, float *part, float *sc, float *red,
                                             const bf16_t *__restrict__ Kb, const bf16_t *__restrict__ Vb,
                                             const unsigned char *__restrict__ mrow, int maxlen, long long p,
@@ -171,10 +171,7 @@ __device__ __forceinline__ void attn_finish(AttnTile0<D> &t, const float *qs, fl
         float o = 0.f;
 #pragma unroll
         for (int g = 0; g < ATTN_WAVES * RPI; ++g) o += part[g * D + tid];
-        if (WT)      // write-through (sc1): in memory, not in this XCD's L2, once vmcnt drains -- readers on other XCDs of the same launch
-            __builtin_amdgcn_raw_buffer_store_b16((short)f32_to_bf16(o * inv),
-                                                  __builtin_amdgcn_make_buffer_rsrc(outp, 0, 0x7fffffff, 0x00020000), tid * 2, 0, 16);
-        else outp[tid] = f32_to_bf16(o * inv);
+        outp[tid] = f32_to_bf16(o * inv);
     }
 }
 

@@ -275,11 +275,13 @@ __global__ __launch_bounds__(256) void gemv_stage_kernel(const bf16_t *__restric
 // grid (nh, B).  qkv row b = [q: nh*D | k: nkv*D | v: nkv*D] (output of the fused q/k/v GEMV).  The new key / value of
 // the head's KV group is rotated in LDS and used from there; the first query head of each group also stores it to the
 // cache at *pos.  Nobody reads cache slot *pos in this launch, so there is no cross-workgroup dependency.
-template <int D, bool WT>
-__device__ __forceinline__ void attn_rope_body(const bf16_t *__restrict__ qkv, int64_t ld_qkv, const bf16_t *__restrict__ cs,
-                                               const bf16_t *__restrict__ sn, int64_t cs0, bf16_t *__restrict__ K, bf16_t *__restrict__ V,
-                                               const long long *__restrict__ pos_ptr, const unsigned char *__restrict__ mask, int64_t ms0,
-                                               bf16_t *__restrict__ out, int nh, int nkv, int maxlen, float scale, int h, int b) {
+template <int D>
+__global__ __launch_bounds__(ATTN_THREADS) void decode_attn_rope_kernel(const bf16_t *__restrict__ qkv, int64_t ld_qkv,
+                                                               const bf16_t *__restrict__ cs, const bf16_t *__restrict__ sn,
+                                                               int64_t cs0, bf16_t *__restrict__ K, bf16_t *__restrict__ V,
+                                                               const long long *__restrict__ pos_ptr,
+                                                               const unsigned char *__restrict__ mask, int64_t ms0,
+                                                               bf16_t *__restrict__ out, int nh, int nkv, int maxlen, float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm_attn2[];
     float *qs = sm_attn2;                 // [D]     rotated query, f32 of its bf16 value
     float *part = qs + D;                 // [waves][rows per load][D] partial outputs = ATTN_PART_FLOATS for either D
@@ -287,6 +289,7 @@ __device__ __forceinline__ void attn_rope_body(const bf16_t *__restrict__ qkv, i
     bf16_t *vn = kn + D;                  // [D] new value
     float *sc = reinterpret_cast<float *>(vn + D);           // [maxlen] scores -> probabilities
     __shared__ float red[2 * ATTN_WAVES];
+    const int h = blockIdx.x, b = blockIdx.y;
     const int group = nh / nkv, kvh = h / group;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long p = *pos_ptr;
@@ -331,86 +334,8 @@ __device__ __forceinline__ void attn_rope_body(const bf16_t *__restrict__ qkv, i
         }
     }
     __syncthreads();
-    attn_finish<D, true, WT>(t0, qs, part, sc, red, Kb, Vb, mrow, maxlen, pvalid ? p : -1, kn, vn, scale,
-                             out + ((int64_t)b * nh + h) * D, tid, lane, wave);
-}
-
-template <int D>
-__global__ __launch_bounds__(ATTN_THREADS) void decode_attn_rope_kernel(const bf16_t *__restrict__ qkv, int64_t ld_qkv,
-                                                               const bf16_t *__restrict__ cs, const bf16_t *__restrict__ sn,
-                                                               int64_t cs0, bf16_t *__restrict__ K, bf16_t *__restrict__ V,
-                                                               const long long *__restrict__ pos_ptr,
-                                                               const unsigned char *__restrict__ mask, int64_t ms0,
-                                                               bf16_t *__restrict__ out, int nh, int nkv, int maxlen, float scale) {
-    attn_rope_body<D, false>(qkv, ld_qkv, cs, sn, cs0, K, V, pos_ptr, mask, ms0, out, nh, nkv, maxlen, scale, blockIdx.x, blockIdx.y);
-}
-
-// PROBE (tools/attn_oproj_probe.py): rope + append + attention of ONE sequence and the o_proj GEMV + residual behind it as ONE launch.  The
-// first nh workgroups are the heads (attention output written through, then a completion count on 8 replicated counter lines); the
-// others are 8-wave o_proj workgroups that request their first weight block, wait for the count, then run gemv_fused_kernel<1, false,
-// GEMV_RESIDUAL>'s arithmetic.  28 producers, every consumer resident: the one pair of the layer whose hand-over is cheap.
-struct AttnOprojArgs {
-    const bf16_t *qkv; int64_t ld_qkv; const bf16_t *cs, *sn; int64_t cs0; bf16_t *K, *V; const long long *pos; const unsigned char *mask;
-    int64_t ms0; bf16_t *att; int nh, nkv, maxlen; float scale;
-    const bf16_t *wo; const float *bo; const bf16_t *res; bf16_t *h1; int H, nq; unsigned *ctr; int sleep;
-};
-template <int D>
-__global__ __launch_bounds__(ATTN_THREADS) void decode_attn_oproj_kernel(AttnOprojArgs a) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    if ((int)blockIdx.x < a.nh) {
-        attn_rope_body<D, true>(a.qkv, a.ld_qkv, a.cs, a.sn, a.cs0, a.K, a.V, a.pos, a.mask, a.ms0, a.att, a.nh, a.nkv, a.maxlen, a.scale,
-                                blockIdx.x, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid < 8) __hip_atomic_fetch_add(a.ctr + tid * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    constexpr int UNR = LL_GEMV_UNR;
-    const int wg = blockIdx.x - a.nh;
-    const int wave = wg * ATTN_WAVES + (tid >> 6);
-    const int n0 = wave * 2, N = a.H, K = a.nq;
-    const bool active = n0 < N;
-    const bf16_t *wr[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) wr[r] = a.wo + (int64_t)(n0 + r < N ? n0 + r : N - 1) * K;
-    const int nchunk = K / 8;
-    u32x4 wv[UNR][2];
-    gemv_load_w<UNR, true>(wv, wr, lane, nchunk, active);
-    if (tid == 0) {
-        const unsigned long long t0 = wall_clock64();
-        const unsigned *c = a.ctr + (wg & 7) * 32;
-        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.nh) {
-            for (int i = 0; i < a.sleep; ++i) __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 2000000ull) { atomicOr(a.ctr + 256, 1u); break; }
-        }
-    }
-    __syncthreads();
-    asm volatile("" ::: "memory");
-    if (active) {
-        float acc[1][2] = {{0.f, 0.f}};
-        gemv_fma<1, UNR, false>(acc, wv, a.att, 0, lane, nchunk);
-        for (int c0 = lane + 64 * UNR; c0 < nchunk; c0 += 64 * UNR) {
-            gemv_load_w<UNR, true>(wv, wr, c0, nchunk, true);
-            gemv_fma<1, UNR, false>(acc, wv, a.att, 0, c0, nchunk);
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const float v = wave_sum(acc[0][r]);
-            if (lane == 0 && n0 + r < N) {
-                const float o = v + (a.bo ? a.bo[n0 + r] : 0.f);
-                a.h1[n0 + r] = f32_to_bf16(bf16_to_f32(a.res[n0 + r]) + bfr2(o));
-            }
-        }
-    }
-    // the last o_proj workgroup leaves the counters zeroed for the next launch
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned total = gridDim.x - a.nh;
-        if (__hip_atomic_fetch_add(a.ctr + 288, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1u) {
-            for (int r = 0; r < 8; ++r) __hip_atomic_store(a.ctr + r * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.ctr + 288, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    attn_finish<D, true>(t0, qs, part, sc, red, Kb, Vb, mrow, maxlen, pvalid ? p : -1, kn, vn, scale,
+                         out + ((int64_t)b * nh + h) * D, tid, lane, wave);
 }
 
 // Per-token prologue of the decode step: what Qwen2RotaryEmbedding.forward (freqs = inv_freq * position, cos/sin in f32,
@@ -530,22 +455,6 @@ int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, c
         hipLaunchKernelGGL((decode_attn_rope_kernel<64>), grid, dim3(ATTN_THREADS), lds, (hipStream_t)stream, (const bf16_t *)qkv, ld_qkv,
                            (const bf16_t *)cos, (const bf16_t *)sin, cs_stride, (bf16_t *)Kc, (bf16_t *)Vc, (const long long *)pos,
                            (const unsigned char *)mask, mask_stride, (bf16_t *)out, nh, nkv, maxlen, scale);
-    LL_LAUNCH_CHECK();
-    return LL_OK;
-}
-
-int ll_decode_attn_oproj_probe(const void *qkv, int64_t ld_qkv, const void *cos, const void *sin, void *Kc, void *Vc, const int64_t *pos,
-                               const void *mask, void *att, int nh, int nkv, int maxlen, int D, float scale, const void *wo, const float *bo,
-                               const void *res, void *h1, int H, void *counters, int sleep, void *stream) {
-    LL_CHECK(qkv && cos && sin && Kc && Vc && pos && mask && att && wo && res && h1 && counters, "ll_decode_attn_oproj_probe: null argument");
-    LL_CHECK(D == 128 && nh % nkv == 0 && maxlen >= 1 && maxlen <= 16384 && H % 8 == 0 && (nh * D) % 8 == 0, "ll_decode_attn_oproj_probe: unsupported shape");
-    AttnOprojArgs a;
-    a.qkv = (const bf16_t *)qkv; a.ld_qkv = ld_qkv; a.cs = (const bf16_t *)cos; a.sn = (const bf16_t *)sin; a.cs0 = 0; a.K = (bf16_t *)Kc;
-    a.V = (bf16_t *)Vc; a.pos = (const long long *)pos; a.mask = (const unsigned char *)mask; a.ms0 = 0; a.att = (bf16_t *)att; a.nh = nh;
-    a.nkv = nkv; a.maxlen = maxlen; a.scale = scale; a.wo = (const bf16_t *)wo; a.bo = bo; a.res = (const bf16_t *)res; a.h1 = (bf16_t *)h1;
-    a.H = H; a.nq = nh * D; a.ctr = (unsigned *)counters; a.sleep = sleep;
-    const size_t lds = (size_t)(D + ATTN_PART_FLOATS) * 4 + (size_t)2 * D * 2 + (size_t)maxlen * 4;
-    hipLaunchKernelGGL((decode_attn_oproj_kernel<128>), dim3(nh + cdiv(H, 2 * ATTN_WAVES)), dim3(ATTN_THREADS), lds, (hipStream_t)stream, a);
     LL_LAUNCH_CHECK();
     return LL_OK;
 }
