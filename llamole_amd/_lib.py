@@ -96,6 +96,12 @@ SIGNATURES = {
     "ll_linear_rows16_bf16": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "ll_set_rows16_geometry": (_I, [_I, _I, _I]),
     "ll_rows16_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
+    "ll_rows64_packed_elems": (_I64, [_I, _I]),
+    "ll_rows64_pack_bf16": (_I, [_P, _I, _I, _I, _P, _P]),
+    "ll_linear_rows64_bf16": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _F, _P, _I, _P, _I64, _P]),
+    "ll_linear_rows64_workspace_bytes": (_I64, [_I, _I]),
+    "ll_set_rows64_ksplit": (_I, [_I]),
+    "ll_rows64_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "ll_gin_forward_train": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "ll_gin_backward_c": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "ll_sample_token_bf16": (_I, [_P, _I64, _I, _I, _F, _F, _I, _P, _P, _I, _I64, _P, _P, _P, _I64, _I, _P, _P, _P, _I, _P, _P]),

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libllamole_hip.so")
-SOURCES = ["gemm.hip", "graphdit.hip", "gin.hip", "llm_ops.hip", "llm_layer.hip", "llm_rows16.hip", "llm_sample.hip"]
+SOURCES = ["gemm.hip", "graphdit.hip", "gin.hip", "llm_ops.hip", "llm_layer.hip", "llm_rows16.hip", "llm_rows64.hip", "llm_sample.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 

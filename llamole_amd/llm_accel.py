@@ -18,11 +18,13 @@ import torch.nn.functional as F
 from . import _lib
 
 MAX_ROWS = 128           # GEMV / skinny-GEMM path under nn.Linear (128-token prefill: 8.7 ms vs 10.0 ms on hipBLASLt, tools/prefill_probe.py)
-MAX_STREAM_ROWS = 16    # ll_linear_rows16_bf16: one MFMA column block of token rows (batched decode: 3..16 sequences)
+MAX_ROWS16 = 16         # ll_linear_rows16_bf16: one MFMA column block of token rows (batched decode: 3..16 sequences)
+MAX_STREAM_ROWS = 64    # ll_linear_rows64_bf16: up to four column blocks per weight fragment (17..64 sequences per GPU, BASELINE configs[3])
 # up to here the f32-FMA GEMVs run (RMSNorm prologue fused, bit-identical to the op-by-op path); from the next row count on the MFMA
 # stream does (tools/batch_sweep.sh: batch 4 = 603 ms per step on the FMA path vs 467 ms, batch 2 = 456 vs 439 ms -- the default
 # stays at 2 so that two-sequence decode keeps the bit-identity with HF's op order; LLAMOLE_FMA_GEMV_ROWS=1 trades it for the 4 %)
 FMA_GEMV_ROWS = int(os.environ.get("LLAMOLE_FMA_GEMV_ROWS", "2"))
+PACK64_MIN_N = 32768    # nn.Linear modules at least this wide (lm_head) keep a packed copy for 17..64 rows
 MAX_APPEND_ROWS = 16     # new positions per call served by the fused KV append / decode attention (decode, query tail)
 # row-parallel elementwise kernels (RMSNorm, rotary, SiLU*mul) also serve prefill-sized calls.  Round 3: the A* value estimates push
 # 256 prompts x ~144 tokens = 37 k rows through the model per forward; above the old 16 k-row limit HF's op-by-op RMSNorm (pow, mean, rsqrt,
@@ -37,6 +39,51 @@ def _versions(*tensors):
     return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
 
 
+class _Packed64:
+    """A weight in MFMA operand order for ll_linear_rows64_bf16 (made once by ll_rows64_pack_bf16; the same size as the weight).  The copy
+    follows its source: ``sync`` re-packs IN PLACE when (data_ptr, _version) of the sources changed (captured graphs hold its address)."""
+
+    def __init__(self, lib, w: torch.Tensor, key):
+        self.rows, self.K = w.shape
+        n = int(lib.ll_rows64_packed_elems(self.rows, self.K))
+        if n < 0:
+            raise ValueError(f"ll_rows64_pack_bf16: K={self.K} must be a multiple of 32")
+        self.t = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+        self.key = None
+        self.sync(lib, w, key)
+
+    def sync(self, lib, w: torch.Tensor, key) -> bool:
+        if self.key == key:
+            return False
+        assert w.shape == (self.rows, self.K) and w.stride(1) == 1
+        rc = lib.ll_rows64_pack_bf16(w.data_ptr(), w.stride(0), self.rows, self.K, self.t.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "ll_rows64_pack_bf16")
+        self.key = key
+        return True
+
+
+def _rows64(lib, x2, ldx, wp: "_Packed64", bias, res, N, epi, next_norm=None, eps=0.0):
+    """17..64 token rows through ll_linear_rows64_bf16 on a packed weight; matrices with few 64-row groups (o_proj, down_proj) get scratch
+    for the cross-workgroup K split (f32 slabs summed in slice order by a second launch on the same stream).  ``next_norm``: also return
+    RMSNorm(out) * next_norm for the next Linear (computed by that second launch, which owns whole rows)."""
+    M, K = x2.shape[0], wp.K
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device)
+    xn = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device) if next_norm is not None else None
+    ws, wsb = None, 0
+    if epi != 2 and (next_norm is not None or N < 224 * 64):
+        wsb = int(lib.ll_linear_rows64_workspace_bytes(M, N))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=x2.device)
+    rc = lib.ll_linear_rows64_bf16(x2.data_ptr(), ldx, wp.t.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                   res.data_ptr() if res is not None else None, res.stride(0) if res is not None else 0,
+                                   out.data_ptr(), N, M, N, K, epi, next_norm.data_ptr() if next_norm is not None else None, eps,
+                                   xn.data_ptr() if xn is not None else None, N, ws.data_ptr() if ws is not None else None, wsb,
+                                   torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        _lib.check(rc, "ll_linear_rows64_bf16")
+    return out if next_norm is None else (out, xn)
+
+
 def _hip_linear_forward(self: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     K = self.in_features
     if (x.is_cuda and x.dtype == torch.bfloat16 and self.weight.dtype == torch.bfloat16 and not torch.is_grad_enabled()
@@ -47,30 +94,26 @@ def _hip_linear_forward(self: nn.Linear, x: torch.Tensor) -> torch.Tensor:
             x2 = x2.contiguous()
         M, N = x2.shape[0], self.out_features
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
-        if FMA_GEMV_ROWS < M <= MAX_STREAM_ROWS and K % 32 == 0:
-            # 3..16 token rows (batched decode): the weight-streaming MFMA Linear, every wave streaming its own 16 weight rows
+        if (FMA_GEMV_ROWS < M <= MAX_ROWS16 or (MAX_ROWS16 < M <= MAX_STREAM_ROWS and N >= PACK64_MIN_N)) and K % 32 == 0:
+            # 3..16 token rows (batched decode): the weight-streaming MFMA Linear, every wave streaming its own 16 weight rows;
+            # 17..64 rows x a vocabulary-sized matrix (lm_head): ll_linear_rows64_bf16 on a packed copy (the decoder layers' own
+            # Linears get theirs in _FusedLayer; any other module keeps the ring GEMM below rather than a second copy of its weight)
             bias = None
             if self.bias is not None:
                 bias = getattr(self, "_ll_bias_f32", None)
                 if bias is None or bias.device != x.device:
                     bias = self.bias.detach().float().contiguous()
                     self._ll_bias_f32, self._ll_bias_key = bias, _versions(self.bias)
+            if M > MAX_ROWS16:
+                wp = self.__dict__.get("_ll_w64")
+                if wp is None:
+                    wp = self._ll_w64 = _Packed64(self._ll_lib, self.weight.detach(), _versions(self.weight))
+                return _rows64(self._ll_lib, x2, K, wp, bias, None, N, 0).reshape(*x.shape[:-1], N)
             rc = self._ll_lib.ll_linear_rows16_bf16(x2.data_ptr(), K, self.weight.data_ptr(), K, bias.data_ptr() if bias is not None else None,
                                                     None, 0.0, None, 0, out.data_ptr(), N, M, N, K, 0, torch.cuda.current_stream().cuda_stream)
             if rc != 0:
                 _lib.check(rc, "ll_linear_rows16_bf16")
             return out.reshape(*x.shape[:-1], N)
-        if MAX_STREAM_ROWS < M <= 32 and K >= 8192 and N <= 8192 and self.bias is None and K % 256 == 0:
-            # 17..32 rows x a short, wide matrix (down_proj; up to 16 rows the stream above serves it): split K so that >= 256
-            # workgroups stream it
-            splits = 4 if K % 512 == 0 and (N + 31) // 32 * 2 < 256 else 2
-            if K % (64 * splits) == 0:
-                ws = torch.empty(splits * M * N, dtype=torch.float32, device=x.device)
-                rc = self._ll_lib.ll_linear_splitk_bf16(x2.data_ptr(), K, self.weight.data_ptr(), K, None, out.data_ptr(), N, M, N, K, 0,
-                                                        splits, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
-                if rc != 0:
-                    _lib.check(rc, "ll_linear_splitk_bf16")
-                return out.reshape(*x.shape[:-1], N)
         bias = None
         if self.bias is not None:
             bias = getattr(self, "_ll_bias_f32", None)
@@ -142,13 +185,21 @@ def refresh_weight_copies(model: nn.Module) -> int:
                     st.bo.copy_(mod.self_attn.o_proj.bias.detach().float())
                     st.bo_key = key
                     n += 1
+            wp = d.get("_ll_w64")
+            if wp is not None and getattr(mod, "weight", None) is not None:
+                n += int(wp.sync(mod._ll_lib, mod.weight.detach(), _versions(mod.weight)))
+        # the packed copies of the fused layers are made from the concatenated copies refreshed above
+        for mod in model.modules():
+            st = mod.__dict__.get("_ll_fused")
+            if st is not None and st.p64 is not None:
+                n += int(st.packed64(sync=True))
     return n
 
 
 def drop_weight_copies(model: nn.Module) -> None:
     """Forget the concatenated / converted weight copies (restore_* paths): the next install rebuilds them."""
     for mod in model.modules():
-        for k in ("_ll_gate_up", "_ll_gate_up_key", "_ll_bias_f32", "_ll_bias_key", "_ll_qkv"):
+        for k in ("_ll_gate_up", "_ll_gate_up_key", "_ll_bias_f32", "_ll_bias_key", "_ll_qkv", "_ll_w64"):
             mod.__dict__.pop(k, None)
 
 
@@ -489,6 +540,23 @@ class _FusedLayer:
         self.n1, self.n2 = layer.input_layernorm, layer.post_attention_layernorm
         self.eps1, self.eps2 = float(self.n1.variance_epsilon), float(self.n2.variance_epsilon)
         self.stream_ok = self.H % 32 == 0 and self.nq % 32 == 0 and self.I % 32 == 0 and self.n1.weight.dtype == torch.bfloat16
+        self._mods = (q, k, v, o, mlp.gate_proj, mlp.up_proj, mlp.down_proj)
+        self.p64 = None         # packed copies of the four matrices for 17..64 rows (made at the first such step)
+
+    def _keys64(self):
+        q, k, v, o, g, u, d = self._mods
+        return (_versions(q.weight, k.weight, v.weight), _versions(o.weight), _versions(g.weight, u.weight), _versions(d.weight))
+
+    def packed64(self, sync: bool = False):
+        """[q|k|v], o_proj, [gate|up], down_proj in MFMA operand order (ll_rows64_pack_bf16) -- one more copy of the layer's weights,
+        made the first time 17..64 sequences are decoded together; ``sync`` re-packs in place what changed at the source."""
+        keys = self._keys64()
+        srcs = (self.wqkv, self.wo, self.wgu, self.wdown)
+        if self.p64 is None:
+            self.p64 = tuple(_Packed64(self.lib, w, key) for w, key in zip(srcs, keys))
+        elif sync:
+            return sum(p.sync(self.lib, w, key) for p, w, key in zip(self.p64, srcs, keys))
+        return 0
 
     def eligible(self, h, mask, cache, pe) -> bool:
         if not (h.is_cuda and h.dtype == torch.bfloat16 and h.dim() == 3 and h.shape[1] == 1
@@ -527,8 +595,47 @@ class _FusedLayer:
             _lib.check(rc, "ll_gemv_fused_bf16")
         return out
 
+    def _attn(self, qkv, nqkv, mask, cache, pe, B, device):
+        cl = cache.layers[self.layer_idx]
+        pos = cache.layers[0].cumulative_length
+        cos, sin = pe
+        att = torch.empty(B, self.nq, dtype=torch.bfloat16, device=device)
+        rc = self.lib.ll_decode_attn_rope_bf16(qkv.data_ptr(), nqkv, cos.data_ptr(), sin.data_ptr(),
+                                               0 if cos.shape[0] == 1 else cos.stride(0), cl.keys.data_ptr(), cl.values.data_ptr(),
+                                               pos.data_ptr(), mask.data_ptr(), mask.stride(0), att.data_ptr(), B, self.nh, self.nkv,
+                                               cl.keys.shape[2], self.D, self.scaling, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "ll_decode_attn_rope_bf16")
+        return att
+
+    def run64(self, h, mask, cache, pe, xn=None, next_norm=None, next_eps=0.0):
+        """17..64 sequences: seven launches on the packed weights -- q|k|v, rope + append + attention, o_proj (K split into f32 slabs),
+        slab sum + residual + post-attention RMSNorm, gate|up + SiLU*mul, down_proj (K split), slab sum + residual + the NEXT layer's
+        input RMSNorm.  ``xn`` = input_layernorm(h) when the previous layer already produced it; returns (h_out, xn_next or None)."""
+        B, H = h.shape[0], self.H
+        x = h.view(B, H)
+        self.packed64()
+        pqkv, po, pgu, pdown = self.p64
+        if xn is None:
+            xn = torch.empty_like(x)
+            rc = self.lib.ll_rmsnorm_bf16(x.data_ptr(), self.n1.weight.data_ptr(), xn.data_ptr(), B, H, self.eps1,
+                                          torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                _lib.check(rc, "ll_rmsnorm_bf16")
+        nqkv = self.nq + 2 * self.nkv_dim
+        qkv = _rows64(self.lib, xn, xn.stride(0), pqkv, self.bqkv, None, nqkv, 0)
+        att = self._attn(qkv, nqkv, mask, cache, pe, B, h.device)
+        h1, xn2 = _rows64(self.lib, att, att.stride(0), po, self.bo, x, H, 1, next_norm=self.n2.weight, eps=self.eps2)
+        act = _rows64(self.lib, xn2, xn2.stride(0), pgu, None, None, self.I, 2)
+        if next_norm is None:
+            return _rows64(self.lib, act, act.stride(0), pdown, None, h1, H, 1).view(B, 1, H), None
+        h2, xn_next = _rows64(self.lib, act, act.stride(0), pdown, None, h1, H, 1, next_norm=next_norm, eps=next_eps)
+        return h2.view(B, 1, H), xn_next
+
     def run(self, h, mask, cache, pe):
         B, H = h.shape[0], self.H
+        if B > MAX_ROWS16:
+            return self.run64(h, mask, cache, pe)[0]
         x = h.view(B, H)
         cl = cache.layers[self.layer_idx]
         pos = cache.layers[0].cumulative_length
@@ -634,8 +741,16 @@ def _model_forward(self, input_ids=None, attention_mask=None, position_ids=None,
                 _lib.check(rc, "ll_decode_prologue")
             pe = (cos, sin)
             if layers[0]._ll_fused.eligible(h, mask, past_key_values, pe):
-                for layer in layers:
-                    h = layer._ll_fused.run(h, mask, past_key_values, pe)
+                if B > MAX_ROWS16:
+                    # 17..64 sequences: every layer's closing launch also produces the next layer's input RMSNorm
+                    xn = None
+                    for i, layer in enumerate(layers):
+                        nxt = layers[i + 1]._ll_fused if i + 1 < len(layers) else None
+                        h, xn = layer._ll_fused.run64(h, mask, past_key_values, pe, xn, nxt.n1.weight if nxt is not None else None,
+                                                      nxt.eps1 if nxt is not None else 0.0)
+                else:
+                    for layer in layers:
+                        h = layer._ll_fused.run(h, mask, past_key_values, pe)
                 h = self.norm(h)
                 from transformers.modeling_outputs import BaseModelOutputWithPast
                 return BaseModelOutputWithPast(last_hidden_state=h, past_key_values=past_key_values if use_cache else None)

@@ -58,9 +58,10 @@ def test_decode_fused_equals_unfused_at_full_size(name):
     restore_elementwise(llm)
 
 
-@pytest.mark.parametrize("name", ["qwen2-7b", "llama-3.1-8b"])
-def test_batched_decode_on_the_mfma_stream_at_full_size(name):
-    """8 sequences at the real shapes (configs[3] shards 64 prompts as 8 per GPU on Llama-3.1-8B): the five-launch layers on ll_linear_rows16_bf16 (RMSNorm folded into the stream) against
+@pytest.mark.parametrize("name,rows", [("qwen2-7b", 8), ("llama-3.1-8b", 8), ("llama-3.1-8b", 32), ("llama-3.1-8b", 64), ("qwen2-7b", 64)])
+def test_batched_decode_on_the_mfma_stream_at_full_size(name, rows):
+    """8 / 32 / 64 sequences at the real shapes (configs[3]: 64 prompts, 8 per GPU at 8 GPUs, all 64 on one): the five-launch layers on
+    ll_linear_rows16_bf16 / ll_linear_rows64_bf16 (RMSNorm folded into the stream) against
     the one-launch-per-op path after ONE decode step from the same prefill -- logits agree to bf16 rounding (the MFMA stream
     accumulates in another order and places one rounding differently), the argmax token matches wherever the top-2 margin
     exceeds that rounding; hipGraph replay equals eager bit for bit; left padding is honoured."""
@@ -75,10 +76,10 @@ def test_batched_decode_on_the_mfma_stream_at_full_size(name):
     assert use_decode_attention(llm)
     try:
         g = torch.Generator().manual_seed(1)
-        prompt = torch.randint(5, spec["tok_hi"], (8, 40), generator=g).cuda()
+        prompt = torch.randint(5, spec["tok_hi"], (rows, 40), generator=g).cuda()
         mask = torch.ones_like(prompt)
         mask[2, :9] = 0
-        mask[7, :25] = 0
+        mask[rows - 1, :25] = 0
         kw = dict(max_new_tokens=2, do_sample=False, pad_token_id=0, eos_token_id=[])
         base = GraphedDecoder(llm, use_graph=False, fused_cache=True)
         base.generate(prompt, mask, **kw)

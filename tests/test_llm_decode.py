@@ -356,9 +356,105 @@ def test_linear_rows16_epilogues_vs_torch(M):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows", [6, 16])
+@pytest.mark.parametrize("M", [17, 32, 33, 50, 64])
+def test_linear_rows64_epilogues_vs_torch(M):
+    """ll_linear_rows64_bf16 (weight-streaming MFMA Linear for 17..64 token rows on a weight copy in MFMA operand order: 64 weight rows x
+    all token rows per workgroup, K split over its waves and, for matrices with few row groups, over workgroups through f32 slabs) through
+    the C ABI against op-by-op PyTorch with the same bf16 roundings: every epilogue, every K split, with and without the workspace, the
+    output RMSNorm for the next Linear as HF evaluates it; N not a multiple of the row group, K not a multiple of an x stage or of the
+    slice count; a strided x; and its error behaviour."""
+    import torch.nn.functional as F
+    from llamole_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M)
+    s = torch.cuda.current_stream().cuda_stream
+    eps = 1e-6
+    for K, N in ((4640, 1003), (96, 24), (14336, 528), (4096, 4096), (512, 80)):
+        Np = N if N % 16 == 0 else None                     # SILU_MUL needs whole tiles
+        xfull = torch.randn(M, K + 64, generator=g).bfloat16().cuda()
+        x = xfull[:, :K] if K % 64 == 0 else xfull[:, :K].contiguous()      # a row stride that is not K
+        ldx = x.stride(0)
+        w = (torch.randn(2 * N, K, generator=g) * 0.02).bfloat16().cuda()
+        bias = torch.randn(2 * N, generator=g).float().cuda()
+        nw = (1 + 0.1 * torch.randn(N, generator=g)).bfloat16().cuda()
+        res = torch.randn(M, N, generator=g).bfloat16().cuda()
+        wsb = int(lib.ll_linear_rows64_workspace_bytes(M, N))
+        assert wsb == 8 * M * N * 4
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+
+        def pack(wt):
+            n = int(lib.ll_rows64_packed_elems(wt.shape[0], K))
+            assert n == (wt.shape[0] + 15) // 16 * 16 * K
+            out = torch.full((n,), float("nan"), dtype=torch.bfloat16, device="cuda")
+            _lib.check(lib.ll_rows64_pack_bf16(wt.data_ptr(), wt.stride(0), wt.shape[0], K, out.data_ptr(), s), "ll_rows64_pack_bf16")
+            return out
+
+        wp1, wp2 = pack(w[:N]), (pack(w) if Np else None)
+        # the packed layout is the documented one: fragment (tile, k-step) is 1 KB, lane l holds row l & 15, k (l >> 4) * 8 .. + 8
+        t, ks, lane = (N - 1) // 16, K // 32 - 1, 37
+        row = t * 16 + (lane & 15)
+        want_piece = w[row, ks * 32 + (lane >> 4) * 8: ks * 32 + (lane >> 4) * 8 + 8] if row < N else torch.zeros(8, dtype=torch.bfloat16, device="cuda")
+        off = ((t * (K // 32) + ks) * 64 + lane) * 8
+        assert torch.equal(wp1[off:off + 8], want_piece)
+
+        def rms(v):
+            f = v.float()
+            f = f * torch.rsqrt(f.pow(2).mean(-1, keepdim=True) + eps)
+            return nw * f.to(torch.bfloat16)
+
+        for ksg in (0, 1, 2, 4, 8):
+            for use_bias in ((False, True) if ksg == 0 else (False,)):
+                b = bias if use_bias else torch.zeros_like(bias)
+                full = (x.float() @ w.float().t() + b).to(torch.bfloat16)
+                want = {0: full[:, :N], 1: res + full[:, :N], 2: F.silu(full[:, :N]) * full[:, N:]}
+                for epi in ((0, 1, 2) if Np else (0, 1)):
+                    for use_ws, norm in (((True, False), (False, False), (True, True)) if ksg == 0 else ((True, False), (True, True))):
+                        if norm and epi == 2:
+                            continue
+                        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+                        xn = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+                        lib.ll_set_rows64_ksplit(ksg)
+                        try:
+                            _lib.check(lib.ll_linear_rows64_bf16(x.data_ptr(), ldx, (wp2 if epi == 2 else wp1).data_ptr(),
+                                                                 bias.data_ptr() if use_bias else None, res.data_ptr() if epi == 1 else None, N,
+                                                                 out.data_ptr(), N, M, N, K, epi, nw.data_ptr() if norm else None, eps,
+                                                                 xn.data_ptr() if norm else None, N, ws.data_ptr() if use_ws else None,
+                                                                 wsb if use_ws else 0, s), "ll_linear_rows64_bf16")
+                        finally:
+                            lib.ll_set_rows64_ksplit(0)
+                        scale = want[epi].float().abs().max().item()
+                        tag = f"K={K} N={N} ksg={ksg} epi={epi} ws={use_ws} norm={norm} bias={use_bias}"
+                        torch.testing.assert_close(out.float(), want[epi].float(), rtol=3e-2, atol=max(3e-2, 0.01 * scale), msg=lambda m: f"{tag}: {m}")
+                        if norm:        # the RMSNorm of the ROUNDED output row, op by op as Qwen2RMSNorm: one bf16 ulp of the kernel's own row
+                            torch.testing.assert_close(xn.float(), rms(out).float(), rtol=1.6e-2, atol=1e-2, msg=lambda m: f"{tag} (norm): {m}")
+    # the K split over workgroups sums its slabs in slice order: two runs are bit-identical
+    K, N = 14336, 512
+    x = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.02).bfloat16().cuda()
+    res = torch.randn(M, N, generator=g).bfloat16().cuda()
+    wp = torch.empty(int(lib.ll_rows64_packed_elems(N, K)), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.ll_rows64_pack_bf16(w.data_ptr(), K, N, K, wp.data_ptr(), s))
+    ws = torch.empty(int(lib.ll_linear_rows64_workspace_bytes(M, N)), dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(2):
+        o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.ll_linear_rows64_bf16(x.data_ptr(), K, wp.data_ptr(), None, res.data_ptr(), N, o.data_ptr(), N, M, N, K, 1, None, eps, None, 0,
+                                             ws.data_ptr(), ws.numel(), s))
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    bad = lambda *a: lib.ll_linear_rows64_bf16(*a) == -1       # LL_EINVAL
+    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N, 65, N, K, 0, None, eps, None, 0, None, 0, s)          # rows
+    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N, M, N, K - 8, 0, None, eps, None, 0, None, 0, s)       # K % 32
+    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N, M, N, K, 1, None, eps, None, 0, None, 0, s)           # no residual
+    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N, M, N, K, 0, res.data_ptr(), eps, o.data_ptr(), N, None, 0, s)   # norm without workspace
+    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N - 8, M, N - 8, K, 2, None, eps, None, 0, None, 0, s)   # SILU_MUL, N % 16
+    assert lib.ll_rows64_packed_elems(16, 40) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [6, 16, 24, 64])
 def test_fused_decoder_layers_batched_rows(rows):
-    """Batched decode (3..16 sequences): the five-launch layer on ll_linear_rows16_bf16 against the one-launch-per-op path.
+    """Batched decode (3..64 sequences): the five-launch layer on ll_linear_rows16_bf16 / ll_linear_rows64_bf16 against the one-launch-per-op path.
     MFMA accumulation order differs from the ring GEMM's, so logits agree to bf16 rounding rather than bit for bit; the
     captured graph replays the eager result exactly."""
     from llamole_amd.llm_accel import (accelerate_elementwise, accelerate_linears, fuse_decoder_layers, fuse_model_decode,
@@ -381,8 +477,10 @@ def test_fused_decoder_layers_batched_rows(rows):
         ref_kv = [(l.keys.clone(), l.values.clone()) for l in base.cache.layers]
         assert fuse_decoder_layers(llm) == llm.config.num_hidden_layers and fuse_model_decode(llm)
         calls = []
-        orig_run = llm.model.layers[0]._ll_fused.run
-        llm.model.layers[0]._ll_fused.run = lambda *a, **k: (calls.append(1), orig_run(*a, **k))[1]
+        st0 = llm.model.layers[0]._ll_fused
+        name = "run64" if rows > 16 else "run"                   # 17..64 rows: seven launches on the packed weights
+        orig_run = getattr(st0, name)
+        setattr(st0, name, lambda *a, **k: (calls.append(1), orig_run(*a, **k))[1])
         dec = GraphedDecoder(llm, use_graph=False, fused_cache=True)
         dec.generate(prompt, mask, **kw)
         assert len(calls) == 1                                   # the batched rows went through the fused layer
