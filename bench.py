@@ -73,6 +73,9 @@ def cpu_baseline_e2e(args, llm, cfg, meta, sd, props, text, n_nodes):
     """Reference CPU path of the e2e workload on this box's host cores, bounded sample: the same HF LLM moved
     to the CPU (bf16) timed on the prompt pass + 2 decode tokens, and the GraphDiT oracle on a few reverse
     steps; both extrapolated to the full budget (max_new_tokens decode steps, T reverse steps)."""
+    full_B = props.shape[0]
+    if full_B > 8:      # bounded sample: the first 8 prompts of the batch (a 64-prompt CPU prefill alone would take minutes)
+        props, text, n_nodes = props[:8], text[:8], n_nodes[:8]
     dit = cpu_baseline(args, cfg, meta, sd, props, text, n_nodes)
     cores = dit["cores"]
     torch.set_num_threads(cores)
@@ -92,7 +95,8 @@ def cpu_baseline_e2e(args, llm, cfg, meta, sd, props, text, n_nodes):
     dit_s = args.T / dit["denoise_steps_per_s"]
     total = prefill + args.new_tokens * per_tok + requery + dit_s
     return {"value": B / total, "unit": "molecules/s", "cores": cores, "kind": "port",
-            "sample": f"HF {args.llm} (random-init, bf16) on {cores} CPU threads: prompt pass {prefill:.2f} s, "
+            "sample": (f"the first {B} of the {full_B} prompts of a step; " if full_B != B else "") +
+                      f"HF {args.llm} (random-init, bf16) on {cores} CPU threads: prompt pass {prefill:.2f} s, "
                       f"{per_tok:.3f} s/token over 2 decode tokens, extrapolated to {args.new_tokens} tokens + query re-forward; "
                       f"GraphDiT oracle {dit['sample']}",
             "llm_s": prefill + args.new_tokens * per_tok + requery, "graphdit_s": dit_s,
@@ -305,13 +309,21 @@ def main():
         # `python bench.py --gpus N` without a launcher: this parent starts the N ranks itself, BEFORE it makes any GPU call
         # (a process that has initialised the GPU must not exec/replace itself on this pool; device_count() does not initialise)
         raise SystemExit(spawn_ranks(args.gpus))
-    if args.batch is None:
-        args.batch = 8 if (args.workload == "graphdit" or args.total_prompts) else args.targets if args.workload == "retro" else 1
-    if args.workload == "retro":
-        args.batch = args.targets
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    batch_given = args.batch is not None
+    if args.batch is None:
+        if args.total_prompts and args.workload == "e2e":
+            # strong scaling: a rank decodes its whole share together, up to the 64 sequences the fused decode path serves (the reference
+            # hands language_model.generate one per_device_eval_batch_size batch, eval/workflow.py:89-91)
+            share = args.total_prompts // max(1, world)
+            args.batch = max(1, min(share, 64))
+            while share % args.batch:
+                args.batch -= 1
+        else:
+            args.batch = 8 if (args.workload == "graphdit" or args.total_prompts) else args.targets if args.workload == "retro" else 1
+    if args.workload == "retro":
+        args.batch = args.targets
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "WORLD_SIZE" in os.environ and args.gpus != world:
         log(f"--gpus {args.gpus} overridden by the launcher's WORLD_SIZE={world}")
@@ -529,6 +541,14 @@ def main():
                                  if args.total_prompts else "batch=%d/GPU" % B)) if args.workload == "e2e"
                    else "GraphDiT %d-step reverse diffusion on %d synthetic %d-node graphs/GPU, no LLM" % (T, nb * B, N),
                    "prompts_per_step": world * nb * B, "gathered_molecules": gathered_n,
+                   "per_rank_batch": B, "per_rank_batches_per_step": nb,
+                   "per_rank_batch_source": "--batch" if batch_given else ("min(share of --total-prompts, 64)" if args.total_prompts else "default"),
+                   "scaling_baseline": (("strong scaling over --total-prompts %d: every rank decodes its share in batches of min(share, 64) sequences, so the "
+                                         "N = 1 line of this command is the BEST single-GPU configuration of the same job (all %d prompts in %d batch(es) "
+                                         "of %d); a ratio against it is not inflated by an under-batched baseline (with --batch 8 at N = 1 the same job "
+                                         "runs as %d sequential batches and an 8-GPU run looks ~8x by construction)")
+                                        % (args.total_prompts, args.total_prompts, max(1, args.total_prompts // max(1, min(args.total_prompts, 64))),
+                                           min(args.total_prompts, 64), max(1, args.total_prompts // 8))) if args.total_prompts else None,
                    "denoiser": {"hidden": args.hidden, "depth": args.depth, "heads": args.heads, "max_nodes": N,
                                 "T": T, "guide_scale": args.guide},
                    "dit_mlp_kernels": (m.mlp_choice() if hasattr(m, "mlp_choice") and args.dtype == "bf16" else None),

@@ -280,19 +280,26 @@ int ll_linear_rows16_bf16(const void *x, int ldx, const void *W, int ldw, const 
  *     modeling_llamole.py:599-603; BASELINE configs[3] is 64 prompts).  Wp is a copy of the [N, K] weight ([2N, K] gate rows then up rows
  *     for LL_GEMV_SILU_MUL, N % 16 == 0) in MFMA operand order made ONCE by ll_rows64_pack_bf16 into ll_rows64_packed_elems(rows, K)
  *     bf16 elements (rows padded to a multiple of 16): weight fragments go from HBM straight into operand registers, x through an LDS
- *     ring; a workgroup owns 64 weight rows x all token rows, so weights are read once per launch and x once per workgroup.
- *     K % 32 == 0.  Epilogues as ll_gemv_fused_bf16.  Matrices with few row groups (o_proj, down_proj) also split K over workgroups when
- *     `workspace` holds ll_linear_rows64_workspace_bytes(M, N) bytes of device scratch (f32 partial slabs, summed in slice order by a
- *     second launch on the same stream: deterministic); workspace = NULL keeps one launch.  next_norm_w != NULL (plain / residual
- *     epilogue, N <= 16384, needs the workspace): that second launch also writes normed_out[M, N] (row stride ldn) =
- *     next_norm_w * bf16(out_row * rsqrt(mean(out_row^2) + eps)), the Qwen2RMSNorm / LlamaRMSNorm (transformers modeling_qwen2.py) that
- *     feeds the next Linear of the decoder layer. */
+ *     ring; a persistent workgroup owns 64 weight rows x all token rows at a time, so weights are read once per launch and x once per
+ *     workgroup.  K % 32 == 0.  Epilogues as ll_gemv_fused_bf16.  Matrices with few row groups (o_proj, down_proj) also split K over
+ *     workgroups when `workspace` holds ll_linear_rows64_workspace_bytes(M, N) bytes of device scratch (f32 partial slabs, summed in
+ *     slice order by a second launch on the same stream: deterministic); workspace = NULL keeps one launch.
+ *     The RMSNorm between two Linears of a decoder layer (Qwen2RMSNorm / LlamaRMSNorm, transformers modeling_qwen2.py) is split over
+ *     the two calls, so that no normalisation arithmetic sits in a GEMM's main loop:
+ *       producer (plain / residual epilogue, needs the workspace): next_norm_w != NULL -> the second launch also writes
+ *           scaled_out[M, N] (row stride ldn) = bf16(out * next_norm_w) and ssq_out[M, ll_rows64_ssq_chunks(N)] = per-1024-column sums
+ *           of out^2;
+ *       consumer: row_ssq != NULL -> x is such a scaled_out and the accumulator of token row m is multiplied by
+ *           rsqrt(sum(row_ssq[m, 0..ssq_chunks)) / K + eps) before bias / epilogue (the ll_linear_rows16_bf16 form of the prologue).
+ *     ll_rows64_prenorm_bf16 : scaled_out / ssq_out of a given x[M, N] alone (the embedding rows ahead of the first layer). */
 int64_t ll_rows64_packed_elems(int N, int K);
 int ll_rows64_pack_bf16(const void *W, int ldw, int N, int K, void *packed, void *stream);
 int ll_linear_rows64_bf16(const void *x, int ldx, const void *Wp, const float *bias, const void *residual, int ldr, void *out, int ldc, int M,
-                          int N, int K, int epi, const void *next_norm_w, float eps, void *normed_out, int ldn, void *workspace,
-                          int64_t workspace_bytes, void *stream);
+                          int N, int K, int epi, const float *row_ssq, int ssq_chunks, float eps, const void *next_norm_w, void *scaled_out,
+                          int ldn, float *ssq_out, void *workspace, int64_t workspace_bytes, void *stream);
 int64_t ll_linear_rows64_workspace_bytes(int M, int N);
+int ll_rows64_ssq_chunks(int N);
+int ll_rows64_prenorm_bf16(const void *x, int ldx, const void *norm_w, void *scaled_out, int ldn, float *ssq_out, int M, int N, void *stream);
 
 /* ll_sample_token_bf16 : one decode-loop sampling step per row in ONE launch -- HF TemperatureLogitsWarper + TopPLogitsWarper
  *     + softmax + multinomial (transformers generation/logits_process.py, generation/utils.py _sample; the reference reaches

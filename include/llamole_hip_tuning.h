@@ -91,7 +91,7 @@ int ll_set_rows16_geometry(int seg, int waves, int ksplit);
 int ll_rows16_bench(int M, int N, int K, int epi, int norm, int iters, int nweights, float *ms);
 int ll_set_gemv_nt(int on);
 /* ll_rows64_bench : timing utility of ll_linear_rows64_bf16 (HIP events, `nweights` distinct packed weight matrices, own workspace;
- * norm != 0: with the output RMSNorm).  ll_set_rows64_ksplit : K slices over workgroups (1..8; 0 = chosen by shape); returns the
+ * norm & 1: with the output pre-norm, norm & 2: with the input row scale).  ll_set_rows64_ksplit : K slices over workgroups (1..8; 0 = chosen by shape); returns the
  * previous setting. */
 int ll_set_rows64_ksplit(int ksg);
 int ll_rows64_bench(int M, int N, int K, int epi, int norm, int iters, int nweights, float *ms);

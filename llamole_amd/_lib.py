@@ -98,7 +98,9 @@ SIGNATURES = {
     "ll_rows16_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "ll_rows64_packed_elems": (_I64, [_I, _I]),
     "ll_rows64_pack_bf16": (_I, [_P, _I, _I, _I, _P, _P]),
-    "ll_linear_rows64_bf16": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _F, _P, _I, _P, _I64, _P]),
+    "ll_linear_rows64_bf16": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _F, _P, _P, _I, _P, _P, _I64, _P]),
+    "ll_rows64_ssq_chunks": (_I, [_I]),
+    "ll_rows64_prenorm_bf16": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _P]),
     "ll_linear_rows64_workspace_bytes": (_I64, [_I, _I]),
     "ll_set_rows64_ksplit": (_I, [_I]),
     "ll_rows64_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),

@@ -124,6 +124,16 @@ def time_dominant_kernel(args, device):
                     f"+ SiLU*mul epilogue (batched decode step)")
             nbytes = rows * K * 2 + M * K * 2 + K * 2 + M * N * 2
             return ms.value, nbytes, 2.0 * M * rows * K, name, f"llm_rows16_m{M}_n{rows}_k{K}"
+        if args.llm_fuse and args.llm_layer_fuse and args.llm_decode != "hf" and 16 < M <= 64 and K % 32 == 0 and N % 16 == 0:
+            # 17..64 sequences: the same projection on the packed-weight stream (ll_linear_rows64_bf16; its RMSNorm input comes from
+            # the preceding reduce launch, so the kernel itself is GEMM + SiLU*mul)
+            rows = 2 * N
+            nw = max(2, int(600e6 // (rows * K * 2)))
+            _lib.check(lib.ll_rows64_bench(M, N, K, 2, 0, 8 * nw, nw, C.byref(ms)), "ll_rows64_bench")
+            name = (f"rows64_kernel<silu_mul,{2 if M <= 32 else 4}>, LLM gated-MLP gate|up projection [{M}x{K}]x[{rows}x{K}]^T bf16 on weights in "
+                    f"MFMA operand order + SiLU*mul epilogue (batched decode step)")
+            nbytes = rows * K * 2 + M * K * 2 + M * N * 2
+            return ms.value, nbytes, 2.0 * M * rows * K, name, f"llm_rows64_m{M}_n{rows}_k{K}"
         if args.llm_fuse and args.llm_layer_fuse and args.llm_decode != "hf" and M <= 2:
             # the fused layer's gated-MLP kernel: RMSNorm prologue, gate|up rows streamed once, SiLU*mul epilogue
             rows = 2 * N

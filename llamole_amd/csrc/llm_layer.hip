@@ -338,6 +338,193 @@ __global__ __launch_bounds__(ATTN_THREADS) void decode_attn_rope_kernel(const bf
                          out + ((int64_t)b * nh + h) * D, tid, lane, wave);
 }
 
+// The same for MANY sequences per step (17..64: BASELINE configs[3] on one GPU): one workgroup per (KV head, sequence) serves all G = nh / nkv
+// query heads of the group, so a key / value row is fetched once instead of G times (at 64 sequences x 32 heads the per-head kernel took
+// 55 us per layer, most of it G-fold re-reads through L2: profiles/r6_llama64_kernel_stats.csv).  Same access pattern as attn_decode.h --
+// a wave instruction covers RPI whole rows, lane (r, c) holds 16 bytes of row r -- with G query pieces in registers per lane: G dot
+// products per loaded key piece, G axpys per value piece.  Softmax statistics in f32 per head.  The first 256 keys / values are requested
+// before the rotary arithmetic.  Arithmetic per head as decode_attn_rope_kernel up to the f32 summation order of P.V.
+template <int D, int G>
+__global__ __launch_bounds__(ATTN_THREADS) void decode_attn_rope_gqa_kernel(const bf16_t *__restrict__ qkv, int64_t ld_qkv,
+                                                                   const bf16_t *__restrict__ cs, const bf16_t *__restrict__ sn,
+                                                                   int64_t cs0, bf16_t *__restrict__ K, bf16_t *__restrict__ V,
+                                                                   const long long *__restrict__ pos_ptr,
+                                                                   const unsigned char *__restrict__ mask, int64_t ms0,
+                                                                   bf16_t *__restrict__ out, int nh, int nkv, int maxlen, float scale) {
+    constexpr int LPR = AttnGeom<D>::LPR, RPI = AttnGeom<D>::RPI, NI = AttnGeom<D>::NI, half = D / 2;
+    extern __shared__ __attribute__((aligned(16))) float sm_attn3[];
+    float *qs = sm_attn3;                         // [G][D] rotated queries, f32 of their bf16 values
+    float *part = qs + G * D;                     // [waves][G][D] partial outputs
+    bf16_t *kn = reinterpret_cast<bf16_t *>(part + ATTN_WAVES * G * D);      // [D] rotated new key (bf16)
+    bf16_t *vn = kn + D;                          // [D] new value
+    float *sc = reinterpret_cast<float *>(vn + D);                           // [G][maxlen] scores -> probabilities
+    __shared__ float red[2 * G * ATTN_WAVES];
+    const int kvh = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long p = *pos_ptr;
+    const bool pvalid = p >= 0 && p < maxlen;
+    const bf16_t *row = qkv + b * ld_qkv;
+    const bf16_t *c = cs + b * cs0, *sv = sn + b * cs0;
+    bf16_t *Kb = K + ((int64_t)b * nkv + kvh) * maxlen * D;
+    bf16_t *Vb = V + ((int64_t)b * nkv + kvh) * maxlen * D;
+    const unsigned char *mrow = mask + b * ms0;
+    AttnTile0<D> t0;
+    attn_prefetch<D>(t0, Kb, Vb, mrow, maxlen, tid, lane, wave);
+    for (int role = wave; role < G + 2; role += ATTN_WAVES) {        // roles 0..G-1: query heads; G: the new key; G+1: the new value
+        if (role < G) {
+            if (lane < half) {
+                const bf16_t *src = row + (kvh * G + role) * D;
+                const float x1 = bf16_to_f32(src[lane]), x2 = bf16_to_f32(src[lane + half]);
+                const float c1 = bf16_to_f32(c[lane]), c2 = bf16_to_f32(c[lane + half]);
+                const float s1 = bf16_to_f32(sv[lane]), s2 = bf16_to_f32(sv[lane + half]);
+                qs[role * D + lane] = bfr2(bfr2(x1 * c1) + bfr2(-x2 * s1));
+                qs[role * D + lane + half] = bfr2(bfr2(x2 * c2) + bfr2(x1 * s2));
+            }
+        } else if (role == G) {
+            if (lane < half) {
+                const bf16_t *src = row + (nh + kvh) * D;
+                const float x1 = bf16_to_f32(src[lane]), x2 = bf16_to_f32(src[lane + half]);
+                const float c1 = bf16_to_f32(c[lane]), c2 = bf16_to_f32(c[lane + half]);
+                const float s1 = bf16_to_f32(sv[lane]), s2 = bf16_to_f32(sv[lane + half]);
+                const bf16_t k1 = f32_to_bf16(bfr2(x1 * c1) + bfr2(-x2 * s1)), k2 = f32_to_bf16(bfr2(x2 * c2) + bfr2(x1 * s2));
+                kn[lane] = k1;
+                kn[lane + half] = k2;
+                if (pvalid) {
+                    Kb[p * D + lane] = k1;
+                    Kb[p * D + lane + half] = k2;
+                }
+            }
+        } else {
+            if (lane < half) {
+                const bf16_t *src = row + (nh + nkv + kvh) * D;
+                const uint32_t v2 = *reinterpret_cast<const uint32_t *>(src + lane * 2);
+                *reinterpret_cast<uint32_t *>(vn + lane * 2) = v2;
+                if (pvalid) *reinterpret_cast<uint32_t *>(Vb + p * D + lane * 2) = v2;
+            }
+        }
+    }
+    __syncthreads();
+    const int cc = lane % LPR, r = lane / LPR;
+    const long long pn = pvalid ? p : -1;
+    float q[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[g][e] = qs[g * D + cc * 8 + e];
+    // ---- scores
+    for (int j0 = 0; j0 < maxlen; j0 += 256) {
+        au32x4 kk[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = attn_key<D>(j0, wave, i, lane);
+            if (j0 == 0) kk[i] = t0.k[i];
+            else kk[i] = (j < maxlen && mrow[j] != 0) ? *reinterpret_cast<const au32x4 *>(Kb + (int64_t)j * D + cc * 8) : (au32x4)(0);
+            if (j == pn) kk[i] = *reinterpret_cast<const au32x4 *>(kn + cc * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = attn_key<D>(j0, wave, i, lane);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float d = attn_row_sum<LPR>(attn_dot8(q[g], kk[i]));
+                if (cc == 0 && j < maxlen) sc[g * maxlen + j] = d * scale;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- softmax statistics per head over the unmasked keys
+    float mx[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
+    for (int j = tid; j < maxlen; j += ATTN_THREADS) {
+        const bool ok = (j == tid ? t0.mk : mrow[j]) != 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float s = ok ? sc[g * maxlen + j] : -INFINITY;
+            sc[g * maxlen + j] = s;
+            mx[g] = fmaxf(mx[g], s);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float m = wave_max(mx[g]);
+        if (lane == 0) red[g * ATTN_WAVES + wave] = m;
+    }
+    __syncthreads();
+    float sum[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float m = red[g * ATTN_WAVES];
+#pragma unroll
+        for (int w = 1; w < ATTN_WAVES; ++w) m = fmaxf(m, red[g * ATTN_WAVES + w]);
+        mx[g] = m;
+        sum[g] = 0.f;
+    }
+    for (int j = tid; j < maxlen; j += ATTN_THREADS) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float s = sc[g * maxlen + j];
+            const float e = (s == -INFINITY) ? 0.f : expf(s - mx[g]);
+            sc[g * maxlen + j] = e;
+            sum[g] += e;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float t = wave_sum(sum[g]);
+        if (lane == 0) red[(G + g) * ATTN_WAVES + wave] = t;
+    }
+    __syncthreads();
+    // ---- out = P V: lane (r, c) accumulates columns 8c..8c+7 of every head over the rows it sees
+    float acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+    for (int j0 = 0; j0 < maxlen; j0 += 256) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = attn_key<D>(j0, wave, i, lane);
+            const bool live = j < maxlen && mrow[j < maxlen ? j : 0] != 0;
+            au32x4 vv;
+            if (j0 == 0) vv = t0.v[i];
+            else vv = live ? *reinterpret_cast<const au32x4 *>(Vb + (int64_t)j * D + cc * 8) : (au32x4)(0);
+            if (j == pn) vv = *reinterpret_cast<const au32x4 *>(vn + cc * 8);
+            if (!live) vv = (au32x4)(0);          // masked rows may hold anything (NaN from padded positions)
+#pragma unroll
+            for (int g = 0; g < G; ++g) attn_axpy8(acc[g], live ? sc[g * maxlen + j] : 0.f, vv);
+        }
+    }
+    // rows of one wave instruction -> one partial per wave (lanes c, c + LPR, ...), then across waves through LDS
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = acc[g][e];
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            acc[g][e] = v;
+        }
+    if (r == 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part[(wave * G + g) * D + cc * 8 + e] = acc[g][e];
+    }
+    __syncthreads();
+    for (int i = tid; i < G * D; i += ATTN_THREADS) {
+        const int g = i / D, d = i % D;
+        float o = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATTN_WAVES; ++w) o += part[(w * G + g) * D + d];
+        float den = red[(G + g) * ATTN_WAVES];
+#pragma unroll
+        for (int w = 1; w < ATTN_WAVES; ++w) den += red[(G + g) * ATTN_WAVES + w];
+        const float inv = den > 0.f ? 1.f / den : 0.f;      // a fully masked query row (left padding) yields zeros, not NaN
+        out[((int64_t)b * nh + kvh * G + g) * D + d] = f32_to_bf16(o * inv);
+    }
+}
+
 // Per-token prologue of the decode step: what Qwen2RotaryEmbedding.forward (freqs = inv_freq * position, cos/sin in f32,
 // * attention_scaling, cast to bf16) and create_causal_mask (key j visible iff j <= query position and not padding) compute
 // with ~12 small ATen launches, as one.  grid B.
@@ -445,6 +632,34 @@ int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, c
     LL_CHECK(qkv && cos && sin && Kc && Vc && pos && mask && out, "ll_decode_attn_rope_bf16: null argument");
     LL_CHECK((D == 64 || D == 128) && B >= 1 && nkv >= 1 && nh % nkv == 0 && maxlen >= 1 && maxlen <= 16384 && ld_qkv % 8 == 0,
              "ll_decode_attn_rope_bf16: unsupported shape");
+    // many sequences: one workgroup per (KV head, sequence) for the group sizes of the supported models (Llama-3.1-8B / Mistral-7B 4,
+    // Qwen2-7B 7, the toy models 2); up to 16 sequences keep the per-head kernel (bit-identical to the op-by-op path)
+    const int G = nh / nkv;
+    if (B > 16 && (G == 2 || G == 4 || G == 7)) {
+        const size_t l3 = (size_t)(G * D + ATTN_WAVES * G * D) * 4 + (size_t)2 * D * 2 + (size_t)G * maxlen * 4;
+        if (l3 <= 150 * 1024) {
+            dim3 g3(nkv, B);
+#define LL_GQA(D_, G_)                                                                                                                   \
+    do {                                                                                                                                 \
+        static size_t attr = 0;                                                                                                          \
+        if (l3 > attr) {                                                                                                                 \
+            LL_HIP(hipFuncSetAttribute((const void *)decode_attn_rope_gqa_kernel<D_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3)); \
+            attr = l3;                                                                                                                   \
+        }                                                                                                                                \
+        hipLaunchKernelGGL((decode_attn_rope_gqa_kernel<D_, G_>), g3, dim3(ATTN_THREADS), l3, (hipStream_t)stream, (const bf16_t *)qkv, ld_qkv, \
+                           (const bf16_t *)cos, (const bf16_t *)sin, cs_stride, (bf16_t *)Kc, (bf16_t *)Vc, (const long long *)pos,      \
+                           (const unsigned char *)mask, mask_stride, (bf16_t *)out, nh, nkv, maxlen, scale);                            \
+    } while (0)
+            if (D == 128) {
+                if (G == 2) LL_GQA(128, 2); else if (G == 4) LL_GQA(128, 4); else LL_GQA(128, 7);
+            } else {
+                if (G == 2) LL_GQA(64, 2); else if (G == 4) LL_GQA(64, 4); else LL_GQA(64, 7);
+            }
+#undef LL_GQA
+            LL_LAUNCH_CHECK();
+            return LL_OK;
+        }
+    }
     const size_t lds = (size_t)(D + ATTN_PART_FLOATS) * 4 + (size_t)2 * D * 2 + (size_t)maxlen * 4;
     dim3 grid(nh, B);
     if (D == 128)

@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void rows64_pack_kernel(const bf16_t *__restri
 template <int EPI, int MB>
 __global__ __launch_bounds__(512) void rows64_kernel(const bf16_t *__restrict__ X, int ldx, const bf16_t *__restrict__ Wp,
                                                      const float *__restrict__ bias, const bf16_t *__restrict__ res, int ldr,
-                                                     bf16_t *__restrict__ C, int ldc, float *__restrict__ slab, int M, int N, int K,
+                                                     bf16_t *__restrict__ C, int ldc, float *__restrict__ slab,
+                                                     const float *__restrict__ row_ssq, int ssq_chunks, float eps, int M, int N, int K,
                                                      int tiles_n, int units, int ksg) {
     constexpr int NX = MB * 16 * (R64_KS / 8) / 512;            // 16-byte x loads per thread per stage (8 | 4)
     constexpr int SLOT = MB * 16 * R64_XPITCH;
@@ -167,6 +168,13 @@ __global__ __launch_bounds__(512) void rows64_kernel(const bf16_t *__restrict__ 
                 s1 += *reinterpret_cast<const r64_f32x4 *>(part + (((w * 2 + 1) * MB + cb) * 64 + lane) * 4);
             }
             // s0[j] / s1[j] = C[weight row tile * 16 + (lane>>4)*4 + j][token cb*16 + (lane & 15)] of the wave's first / second tile
+            if (row_ssq) {          // x was bf16(h * w_norm): rsqrt(mean(h^2) + eps) of the token row scales the accumulator (rows16 form)
+                float t = 0.f;
+                for (int c = 0; c < ssq_chunks; ++c) t += row_ssq[m * ssq_chunks + c];
+                const float rstd = rsqrtf(t / (float)K + eps);
+                s0 *= rstd;
+                s1 *= rstd;
+            }
             const int otile = otile_of(u), slice = u % ksg;
             constexpr int NOUT = EPI == R64_SILU_MUL ? 1 : 2;
 #pragma unroll
@@ -246,64 +254,54 @@ __global__ __launch_bounds__(512) void rows64_kernel(const bf16_t *__restrict__ 
     }
 }
 
-// One workgroup per token row: out[m][n] = epilogue(sum over slices (in slice order) of slab[z][m][n] + bias[n]); normw != nullptr:
-// also xn[m][:] = normw * bf16(out[m][:] * rsqrt(mean(out[m][:]^2) + eps)) -- Qwen2RMSNorm / LlamaRMSNorm of the rounded output row.
-template <int EPI, int NV>      // NV: float4 groups per thread (N <= NV * 1024)
+// grid (token rows, 1024-column chunks), 256 threads x 4 columns: out[m][n] = epilogue(sum over slices (in slice order) of slab[z][m][n]
+// + bias[n]).  normw != nullptr: also XS[m][n] = bf16(out[m][n] * normw[n]) and ssq[m][chunk] = sum over the chunk of out[m][n]^2 (of the
+// ROUNDED output) -- the two halves of the next Linear's RMSNorm: the consumer multiplies its accumulator by rsqrt(sum(ssq) / N + eps).
+// splits == 0, C == nullptr: the pre-norm of the residual rows alone (the embedding rows ahead of the first layer).
+template <int EPI>
 __global__ __launch_bounds__(256) void rows64_reduce_kernel(const float *__restrict__ slab, int splits, const float *__restrict__ bias,
                                                             const bf16_t *__restrict__ res, int ldr, bf16_t *__restrict__ C, int ldc,
-                                                            const bf16_t *__restrict__ normw, float eps, bf16_t *__restrict__ XN, int ldn,
-                                                            int M, int N) {
+                                                            const bf16_t *__restrict__ normw, bf16_t *__restrict__ XS, int ldn,
+                                                            float *__restrict__ ssq, int M, int N) {
     __shared__ float red[4];
     const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    float o[NV][4];
+    const int n = (blockIdx.y * 256 + tid) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
     float ss = 0.f;
+    if (n < N) {
+        const bool full = n + 3 < N && (N & 3) == 0;
+        if (full) {
+            float4 t[8];
 #pragma unroll
-    for (int g = 0; g < NV; ++g) {
-        const int n = (g * 256 + tid) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (n < N) {
-            const bool full = n + 3 < N && (N & 3) == 0;
-            for (int z = 0; z < splits; ++z) {
-                const float *p = slab + ((int64_t)z * M + m) * N + n;
-                if (full) {
-                    const float4 t = *reinterpret_cast<const float4 *>(p);
-                    v[0] += t.x, v[1] += t.y, v[2] += t.z, v[3] += t.w;
-                } else {
+            for (int z = 0; z < 8; ++z)
+                if (z < splits) t[z] = *reinterpret_cast<const float4 *>(slab + ((int64_t)z * M + m) * N + n);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (n + j < N) v[j] += p[j];
-                }
-            }
+            for (int z = 0; z < 8; ++z)
+                if (z < splits) v[0] += t[z].x, v[1] += t[z].y, v[2] += t[z].z, v[3] += t[z].w;
+        } else {
+            for (int z = 0; z < splits; ++z)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n + j < N) v[j] += slab[((int64_t)z * M + m) * N + n + j];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float r = 0.f;
-            if (n + j < N) {
-                r = v[j] + (bias ? bias[n + j] : 0.f);
-                if (EPI == R64_RESIDUAL) r = bf16_to_f32(res[(int64_t)m * ldr + n + j]) + r64_bfr(r);
-                const bf16_t ob = f32_to_bf16(r);
-                C[(int64_t)m * ldc + n + j] = ob;
-                r = bf16_to_f32(ob);
-            }
-            o[g][j] = r;
+            if (n + j >= N) break;
+            float r = v[j] + (bias ? bias[n + j] : 0.f);
+            if (EPI == R64_RESIDUAL) r = bf16_to_f32(res[(int64_t)m * ldr + n + j]) + r64_bfr(r);
+            const bf16_t ob = f32_to_bf16(r);
+            if (C) C[(int64_t)m * ldc + n + j] = ob;
+            r = bf16_to_f32(ob);
             ss = fmaf(r, r, ss);
+            if (normw) XS[(int64_t)m * ldn + n + j] = f32_to_bf16(r * bf16_to_f32(normw[n + j]));
         }
     }
     if (!normw) return;
     ss = wave_sum(ss);
     if (lane == 0) red[tid >> 6] = ss;
     __syncthreads();
-    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)N + eps);
-#pragma unroll
-    for (int g = 0; g < NV; ++g) {
-        const int n = (g * 256 + tid) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n + j < N) XN[(int64_t)m * ldn + n + j] = f32_to_bf16(r64_bfr(o[g][j] * rstd) * bf16_to_f32(normw[n + j]));
-    }
+    if (tid == 0) ssq[m * gridDim.y + blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-
-
 
 static int g_rows64_ksg = 0;      // 0: by shape; else K slices over workgroups (tuning)
 
@@ -320,7 +318,7 @@ static int r64_cus() {
 
 template <int EPI, int MB>
 static int launch_rows64_mb(int ksg, hipStream_t s, const bf16_t *X, int ldx, const bf16_t *Wp, const float *bias, const bf16_t *res, int ldr,
-                            bf16_t *C, int ldc, float *slab, int M, int N, int K) {
+                            bf16_t *C, int ldc, float *slab, const float *row_ssq, int ssq_chunks, float eps, int M, int N, int K) {
     const size_t lds = (size_t)2 * MB * 16 * R64_XPITCH;
     static bool attr_set = false;
     if (!attr_set) {
@@ -333,24 +331,21 @@ static int launch_rows64_mb(int ksg, hipStream_t s, const bf16_t *X, int ldx, co
     // workgroups resident at once: one per CU (133 KB of LDS at 64 rows; 136..180 VGPRs x 8 waves)
     const int slots = r64_cus();
     const dim3 grid(units < slots ? units : slots);
-    hipLaunchKernelGGL((rows64_kernel<EPI, MB>), grid, dim3(512), lds, s, X, ldx, Wp, bias, res, ldr, C, ldc, slab, M, N, K, tiles_n, units, ksg);
+    hipLaunchKernelGGL((rows64_kernel<EPI, MB>), grid, dim3(512), lds, s, X, ldx, Wp, bias, res, ldr, C, ldc, slab, row_ssq, ssq_chunks, eps, M, N, K,
+                       tiles_n, units, ksg);
     return LL_OK;
 }
 
 template <int EPI>
 static int launch_reduce(hipStream_t s, const float *slab, int ksg, const float *bias, const bf16_t *res, int ldr, bf16_t *C, int ldc,
-                         const bf16_t *normw, float eps, bf16_t *XN, int ldn, int M, int N) {
-#define LL_R64R(NV_) hipLaunchKernelGGL((rows64_reduce_kernel<EPI, NV_>), dim3(M), dim3(256), 0, s, slab, ksg, bias, res, ldr, C, ldc, normw, eps, XN, ldn, M, N)
-    if (N <= 4096) LL_R64R(4);
-    else if (N <= 8192) LL_R64R(8);
-    else LL_R64R(16);
-#undef LL_R64R
+                         const bf16_t *normw, bf16_t *XS, int ldn, float *ssq, int M, int N) {
+    hipLaunchKernelGGL((rows64_reduce_kernel<EPI>), dim3(M, cdiv(N, 1024)), dim3(256), 0, s, slab, ksg, bias, res, ldr, C, ldc, normw, XS, ldn, ssq, M, N);
     return LL_OK;
 }
 
 int linear_rows64_launch(const void *x, int ldx, const void *Wp, const float *bias, const void *residual, int ldr, void *out, int ldc, int M,
-                         int N, int K, int epi, const void *next_norm_w, float eps, void *normed_out, int ldn, void *workspace,
-                         size_t workspace_bytes, hipStream_t s) {
+                         int N, int K, int epi, const float *row_ssq, int ssq_chunks, float eps, const void *next_norm_w, void *scaled_out, int ldn,
+                         float *ssq_out, void *workspace, size_t workspace_bytes, hipStream_t s) {
     LL_CHECK(x && Wp && out, "ll_linear_rows64_bf16: null argument");
     LL_CHECK(M >= 1 && M <= 64, "ll_linear_rows64_bf16: M=%d rows (1..64)", M);
     LL_CHECK(N >= 1 && K >= 32 && K % 32 == 0 && ldx % 8 == 0, "ll_linear_rows64_bf16: K must be a multiple of 32, ldx of 8");
@@ -359,34 +354,35 @@ int linear_rows64_launch(const void *x, int ldx, const void *Wp, const float *bi
     LL_CHECK(epi != R64_SILU_MUL || N % 16 == 0, "ll_linear_rows64_bf16: SILU_MUL needs N %% 16 == 0 (N=%d)", N);
     LL_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)Wp & 15) == 0 && (!workspace || ((uintptr_t)workspace & 15) == 0),
              "ll_linear_rows64_bf16: operands must be 16-byte aligned");
+    LL_CHECK(!row_ssq || ssq_chunks >= 1, "ll_linear_rows64_bf16: row_ssq needs ssq_chunks >= 1");
     const bool norm = next_norm_w != nullptr;
-    LL_CHECK(!norm || (normed_out && epi != R64_SILU_MUL && N <= 16384 && ldn >= N),
-             "ll_linear_rows64_bf16: the output RMSNorm needs normed_out, a plain / residual epilogue and N <= 16384");
+    LL_CHECK(!norm || (scaled_out && ssq_out && epi != R64_SILU_MUL && ldn >= N),
+             "ll_linear_rows64_bf16: the output pre-norm needs scaled_out, ssq_out and a plain / residual epilogue");
     const bf16_t *X = (const bf16_t *)x, *W = (const bf16_t *)Wp, *rs = (const bf16_t *)residual;
     bf16_t *C = (bf16_t *)out;
     int ksg = 1;
-    if (epi != R64_SILU_MUL) {
+    if (epi != R64_SILU_MUL && !row_ssq) {          // the SiLU and the row scale need complete sums
         if (g_rows64_ksg) {
             ksg = g_rows64_ksg;
         } else {
-            // few row groups (o_proj, down_proj): split K over workgroups until every CU has a unit; a slice keeps >= 2 x-stages
+            // few row groups (o_proj, down_proj: 64 on 256 CUs): split K over workgroups until every CU has a unit; a slice keeps >= 2
+            // x-stages.  (q|k|v, 72..96 groups: 20.4 us in one piece against 23.4 split in two + the second launch)
             const int groups = cdiv(N, 64), nst = cdiv(K, R64_KS);
-            while (ksg < 8 && groups * ksg < r64_cus() && nst / (ksg * 2) >= 2) ksg *= 2;
+            while (ksg < 8 && groups * ksg * 4 < r64_cus() * 3 && groups < r64_cus() / 3 && nst / (ksg * 2) >= 2) ksg *= 2;
         }
-        if (N > 16384) ksg = 1;                                      // the reduce kernel holds a row in registers
     }
     const size_t need = (size_t)ksg * M * N * 4;
     const bool two = ksg > 1 || norm;
     if (two && (!workspace || workspace_bytes < need)) {
-        LL_CHECK(!norm, "ll_linear_rows64_bf16: the output RMSNorm needs %zu bytes of workspace", need);
+        LL_CHECK(!norm, "ll_linear_rows64_bf16: the output pre-norm needs %zu bytes of workspace", need);
         ksg = 1;
     }
     float *slab = (ksg > 1 || norm) ? (float *)workspace : nullptr;
     const int mb = M <= 32 ? 2 : 4;
-#define LL_R64(EPI_)                                                                                                            \
-    do {                                                                                                                        \
-        if (mb == 2) LL_TRY((launch_rows64_mb<EPI_, 2>(ksg, s, X, ldx, W, bias, rs, ldr, C, ldc, slab, M, N, K)));              \
-        else LL_TRY((launch_rows64_mb<EPI_, 4>(ksg, s, X, ldx, W, bias, rs, ldr, C, ldc, slab, M, N, K)));                      \
+#define LL_R64(EPI_)                                                                                                                     \
+    do {                                                                                                                                 \
+        if (mb == 2) LL_TRY((launch_rows64_mb<EPI_, 2>(ksg, s, X, ldx, W, bias, rs, ldr, C, ldc, slab, row_ssq, ssq_chunks, eps, M, N, K))); \
+        else LL_TRY((launch_rows64_mb<EPI_, 4>(ksg, s, X, ldx, W, bias, rs, ldr, C, ldc, slab, row_ssq, ssq_chunks, eps, M, N, K)));        \
     } while (0)
     if (epi == R64_PLAIN) LL_R64(R64_PLAIN);
     else if (epi == R64_RESIDUAL) LL_R64(R64_RESIDUAL);
@@ -394,9 +390,9 @@ int linear_rows64_launch(const void *x, int ldx, const void *Wp, const float *bi
 #undef LL_R64
     if (slab) {
         if (epi == R64_RESIDUAL)
-            LL_TRY((launch_reduce<R64_RESIDUAL>(s, slab, ksg, bias, rs, ldr, C, ldc, (const bf16_t *)next_norm_w, eps, (bf16_t *)normed_out, ldn, M, N)));
+            LL_TRY((launch_reduce<R64_RESIDUAL>(s, slab, ksg, bias, rs, ldr, C, ldc, (const bf16_t *)next_norm_w, (bf16_t *)scaled_out, ldn, ssq_out, M, N)));
         else
-            LL_TRY((launch_reduce<R64_PLAIN>(s, slab, ksg, bias, rs, ldr, C, ldc, (const bf16_t *)next_norm_w, eps, (bf16_t *)normed_out, ldn, M, N)));
+            LL_TRY((launch_reduce<R64_PLAIN>(s, slab, ksg, bias, rs, ldr, C, ldc, (const bf16_t *)next_norm_w, (bf16_t *)scaled_out, ldn, ssq_out, M, N)));
     }
     LL_LAUNCH_CHECK();
     return LL_OK;
@@ -421,10 +417,21 @@ int ll_rows64_pack_bf16(const void *W, int ldw, int N, int K, void *packed, void
 }
 
 int ll_linear_rows64_bf16(const void *x, int ldx, const void *Wp, const float *bias, const void *residual, int ldr, void *out, int ldc, int M,
-                          int N, int K, int epi, const void *next_norm_w, float eps, void *normed_out, int ldn, void *workspace,
-                          int64_t workspace_bytes, void *stream) {
-    return linear_rows64_launch(x, ldx, Wp, bias, residual, ldr, out, ldc, M, N, K, epi, next_norm_w, eps, normed_out, ldn, workspace,
-                                workspace_bytes > 0 ? (size_t)workspace_bytes : 0, (hipStream_t)stream);
+                          int N, int K, int epi, const float *row_ssq, int ssq_chunks, float eps, const void *next_norm_w, void *scaled_out,
+                          int ldn, float *ssq_out, void *workspace, int64_t workspace_bytes, void *stream) {
+    return linear_rows64_launch(x, ldx, Wp, bias, residual, ldr, out, ldc, M, N, K, epi, row_ssq, ssq_chunks, eps, next_norm_w, scaled_out, ldn,
+                                ssq_out, workspace, workspace_bytes > 0 ? (size_t)workspace_bytes : 0, (hipStream_t)stream);
+}
+
+int ll_rows64_ssq_chunks(int N) { return N >= 1 ? (N + 1023) / 1024 : 0; }
+
+int ll_rows64_prenorm_bf16(const void *x, int ldx, const void *norm_w, void *scaled_out, int ldn, float *ssq_out, int M, int N, void *stream) {
+    LL_CHECK(x && norm_w && scaled_out && ssq_out && M >= 1 && N >= 1 && ldn >= N, "ll_rows64_prenorm_bf16: bad argument");
+    // no slabs, no output row: XS = bf16(x * norm_w), ssq = per-chunk sums of squares of x
+    LL_TRY((launch_reduce<R64_RESIDUAL>((hipStream_t)stream, nullptr, 0, nullptr, (const bf16_t *)x, ldx, nullptr, 0, (const bf16_t *)norm_w,
+                                        (bf16_t *)scaled_out, ldn, ssq_out, M, N)));
+    LL_LAUNCH_CHECK();
+    return LL_OK;
 }
 
 int64_t ll_linear_rows64_workspace_bytes(int M, int N) { return (int64_t)8 * (M > 0 ? M : 0) * (N > 0 ? N : 0) * 4; }
@@ -436,14 +443,16 @@ int ll_set_rows64_ksplit(int ksg) {
 }
 
 // Times ll_linear_rows64_bf16 on synthetic operands over `nweights` distinct packed weight matrices (defeats the Infinity Cache);
-// norm != 0: with the output RMSNorm (two launches).
+// norm & 1: with the output pre-norm (two launches); norm & 2: with the input row scale.
 int ll_rows64_bench(int M, int N, int K, int epi, int norm, int iters, int nweights, float *ms) {
     LL_CHECK(ms && iters > 0 && nweights > 0 && M >= 1 && M <= 64, "bad argument");
     const int rowsW = epi == R64_SILU_MUL ? 2 * N : N;
     const size_t welems = (size_t)ll_rows64_packed_elems(rowsW, K);
     bf16_t *X = nullptr, *W = nullptr, *C = nullptr, *R = nullptr, *XN = nullptr;
-    float *ws = nullptr;
+    float *ws = nullptr, *SS = nullptr;
     const size_t wsb = (size_t)ll_linear_rows64_workspace_bytes(M, N);
+    LL_HIP(hipMalloc(&SS, (size_t)64 * 64 * 4));
+    LL_HIP(hipMemset(SS, 0x3c, (size_t)64 * 64 * 4));
     LL_HIP(hipMalloc(&X, (size_t)64 * K * 2));
     LL_HIP(hipMalloc(&W, (size_t)nweights * welems * 2));
     LL_HIP(hipMalloc(&C, (size_t)64 * N * 2));
@@ -462,8 +471,8 @@ int ll_rows64_bench(int M, int N, int K, int epi, int norm, int iters, int nweig
     for (int pass = 0; pass < 2 && rc == LL_OK; ++pass) {
         if (pass == 1) (void)hipEventRecord(e0, st);
         for (int i = 0; i < (pass ? iters : nweights) && rc == LL_OK; ++i)
-            rc = linear_rows64_launch(X, K, W + (size_t)(i % nweights) * welems, nullptr, R, N, C, N, M, N, K, epi, (norm && epi != R64_SILU_MUL) ? X : nullptr,
-                                      1e-6f, XN, N, ws, wsb, st);
+            rc = linear_rows64_launch(X, K, W + (size_t)(i % nweights) * welems, nullptr, R, N, C, N, M, N, K, epi, (norm & 2) ? SS : nullptr, 4, 1e-6f,
+                                      ((norm & 1) && epi != R64_SILU_MUL) ? X : nullptr, XN, N, SS, ws, wsb, st);
     }
     (void)hipEventRecord(e1, st);
     hipError_t he = hipEventSynchronize(e1);
@@ -479,6 +488,7 @@ int ll_rows64_bench(int M, int N, int K, int epi, int norm, int iters, int nweig
     (void)hipFree(XN);
     (void)hipFree(R);
     (void)hipFree(ws);
+    (void)hipFree(SS);
     if (rc != LL_OK) return rc;
     LL_HIP(he);
     return LL_OK;

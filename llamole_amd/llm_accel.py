@@ -63,25 +63,43 @@ class _Packed64:
         return True
 
 
-def _rows64(lib, x2, ldx, wp: "_Packed64", bias, res, N, epi, next_norm=None, eps=0.0):
+def _rows64(lib, x2, ldx, wp: "_Packed64", bias, res, N, epi, row_ssq=None, eps=0.0, next_norm=None):
     """17..64 token rows through ll_linear_rows64_bf16 on a packed weight; matrices with few 64-row groups (o_proj, down_proj) get scratch
-    for the cross-workgroup K split (f32 slabs summed in slice order by a second launch on the same stream).  ``next_norm``: also return
-    RMSNorm(out) * next_norm for the next Linear (computed by that second launch, which owns whole rows)."""
+    for the cross-workgroup K split (f32 slabs summed in slice order by a second launch on the same stream).
+    ``row_ssq`` [M, chunks] f32: x2 is a pre-scaled row bf16(h * w_norm) and the accumulator is multiplied by rsqrt(mean(h^2) + eps).
+    ``next_norm``: also return (bf16(out * next_norm), per-chunk sums of out^2) -- the two halves of the NEXT Linear's RMSNorm."""
     M, K = x2.shape[0], wp.K
     out = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device)
-    xn = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device) if next_norm is not None else None
+    xs = ssq = None
+    if next_norm is not None:
+        xs = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device)
+        ssq = torch.empty(M, int(lib.ll_rows64_ssq_chunks(N)), dtype=torch.float32, device=x2.device)
     ws, wsb = None, 0
-    if epi != 2 and (next_norm is not None or N < 224 * 64):
+    if epi != 2 and row_ssq is None and (next_norm is not None or N < 128 * 64):
         wsb = int(lib.ll_linear_rows64_workspace_bytes(M, N))
         ws = torch.empty(wsb, dtype=torch.uint8, device=x2.device)
     rc = lib.ll_linear_rows64_bf16(x2.data_ptr(), ldx, wp.t.data_ptr(), bias.data_ptr() if bias is not None else None,
                                    res.data_ptr() if res is not None else None, res.stride(0) if res is not None else 0,
-                                   out.data_ptr(), N, M, N, K, epi, next_norm.data_ptr() if next_norm is not None else None, eps,
-                                   xn.data_ptr() if xn is not None else None, N, ws.data_ptr() if ws is not None else None, wsb,
+                                   out.data_ptr(), N, M, N, K, epi, row_ssq.data_ptr() if row_ssq is not None else None,
+                                   row_ssq.shape[1] if row_ssq is not None else 0, eps,
+                                   next_norm.data_ptr() if next_norm is not None else None, xs.data_ptr() if xs is not None else None, N,
+                                   ssq.data_ptr() if ssq is not None else None, ws.data_ptr() if ws is not None else None, wsb,
                                    torch.cuda.current_stream().cuda_stream)
     if rc != 0:
         _lib.check(rc, "ll_linear_rows64_bf16")
-    return out if next_norm is None else (out, xn)
+    return out if next_norm is None else (out, xs, ssq)
+
+
+def _prenorm64(lib, x2, norm_w):
+    """(bf16(x * norm_w), per-chunk sums of x^2) of rows that no ll_linear_rows64_bf16 call produced (the embedding rows)."""
+    M, N = x2.shape
+    xs = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device)
+    ssq = torch.empty(M, int(lib.ll_rows64_ssq_chunks(N)), dtype=torch.float32, device=x2.device)
+    rc = lib.ll_rows64_prenorm_bf16(x2.data_ptr(), x2.stride(0), norm_w.data_ptr(), xs.data_ptr(), N, ssq.data_ptr(), M, N,
+                                    torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        _lib.check(rc, "ll_rows64_prenorm_bf16")
+    return xs, ssq
 
 
 def _hip_linear_forward(self: nn.Linear, x: torch.Tensor) -> torch.Tensor:
@@ -608,29 +626,26 @@ class _FusedLayer:
             _lib.check(rc, "ll_decode_attn_rope_bf16")
         return att
 
-    def run64(self, h, mask, cache, pe, xn=None, next_norm=None, next_eps=0.0):
-        """17..64 sequences: seven launches on the packed weights -- q|k|v, rope + append + attention, o_proj (K split into f32 slabs),
-        slab sum + residual + post-attention RMSNorm, gate|up + SiLU*mul, down_proj (K split), slab sum + residual + the NEXT layer's
-        input RMSNorm.  ``xn`` = input_layernorm(h) when the previous layer already produced it; returns (h_out, xn_next or None)."""
+    def run64(self, h, mask, cache, pe, pre=None, next_norm=None):
+        """17..64 sequences: seven launches on the packed weights -- q|k|v (row scale in its epilogue), rope + append + attention, o_proj
+        (K split into f32 slabs), slab sum + residual + the post-attention pre-norm, gate|up (row scale) + SiLU*mul, down_proj (K
+        split), slab sum + residual + the NEXT layer's input pre-norm.  A "pre-norm" is the pair (bf16(h * w_norm), per-chunk sums of
+        h^2): the RMSNorm is finished by the consuming Linear's epilogue.  ``pre`` = that pair for this layer's input when the previous
+        layer already produced it; returns (h_out, pre_next or None)."""
         B, H = h.shape[0], self.H
         x = h.view(B, H)
         self.packed64()
         pqkv, po, pgu, pdown = self.p64
-        if xn is None:
-            xn = torch.empty_like(x)
-            rc = self.lib.ll_rmsnorm_bf16(x.data_ptr(), self.n1.weight.data_ptr(), xn.data_ptr(), B, H, self.eps1,
-                                          torch.cuda.current_stream().cuda_stream)
-            if rc != 0:
-                _lib.check(rc, "ll_rmsnorm_bf16")
+        xs, ssq = pre if pre is not None else _prenorm64(self.lib, x, self.n1.weight)
         nqkv = self.nq + 2 * self.nkv_dim
-        qkv = _rows64(self.lib, xn, xn.stride(0), pqkv, self.bqkv, None, nqkv, 0)
+        qkv = _rows64(self.lib, xs, xs.stride(0), pqkv, self.bqkv, None, nqkv, 0, row_ssq=ssq, eps=self.eps1)
         att = self._attn(qkv, nqkv, mask, cache, pe, B, h.device)
-        h1, xn2 = _rows64(self.lib, att, att.stride(0), po, self.bo, x, H, 1, next_norm=self.n2.weight, eps=self.eps2)
-        act = _rows64(self.lib, xn2, xn2.stride(0), pgu, None, None, self.I, 2)
+        h1, xs2, ssq2 = _rows64(self.lib, att, att.stride(0), po, self.bo, x, H, 1, next_norm=self.n2.weight)
+        act = _rows64(self.lib, xs2, xs2.stride(0), pgu, None, None, self.I, 2, row_ssq=ssq2, eps=self.eps2)
         if next_norm is None:
             return _rows64(self.lib, act, act.stride(0), pdown, None, h1, H, 1).view(B, 1, H), None
-        h2, xn_next = _rows64(self.lib, act, act.stride(0), pdown, None, h1, H, 1, next_norm=next_norm, eps=next_eps)
-        return h2.view(B, 1, H), xn_next
+        h2, xs3, ssq3 = _rows64(self.lib, act, act.stride(0), pdown, None, h1, H, 1, next_norm=next_norm)
+        return h2.view(B, 1, H), (xs3, ssq3)
 
     def run(self, h, mask, cache, pe):
         B, H = h.shape[0], self.H
@@ -742,12 +757,11 @@ def _model_forward(self, input_ids=None, attention_mask=None, position_ids=None,
             pe = (cos, sin)
             if layers[0]._ll_fused.eligible(h, mask, past_key_values, pe):
                 if B > MAX_ROWS16:
-                    # 17..64 sequences: every layer's closing launch also produces the next layer's input RMSNorm
-                    xn = None
+                    # 17..64 sequences: every layer's closing launch also produces the next layer's input pre-norm
+                    pre = None
                     for i, layer in enumerate(layers):
                         nxt = layers[i + 1]._ll_fused if i + 1 < len(layers) else None
-                        h, xn = layer._ll_fused.run64(h, mask, past_key_values, pe, xn, nxt.n1.weight if nxt is not None else None,
-                                                      nxt.eps1 if nxt is not None else 0.0)
+                        h, pre = layer._ll_fused.run64(h, mask, past_key_values, pe, pre, nxt.n1.weight if nxt is not None else None)
                 else:
                     for layer in layers:
                         h = layer._ll_fused.run(h, mask, past_key_values, pe)

@@ -78,6 +78,23 @@ def test_bench_e2e_two_ranks_total_prompts():
     assert d["config"]["prompts_per_step"] == 8 and d["config"]["gathered_molecules"] == 8
 
 
+def test_bench_total_prompts_picks_the_whole_share_as_one_batch():
+    """without --batch a rank decodes its share of --total-prompts together, up to the 64 sequences the fused decode
+    path serves (ll_linear_rows64_bf16 + the seven-launch layer), and the line says which batch ran and what an N = 1 baseline means."""
+    d = _line(_run(["--total-prompts", "48", "--steps", "2"] + E2E_TINY, {}, workload="e2e"))
+    c = d["config"]
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and c["prompts_per_step"] == 48 and c["gathered_molecules"] == 48
+    assert c["per_rank_batch"] == 48 and c["per_rank_batches_per_step"] == 1 and "min(share" in c["per_rank_batch_source"]
+    assert "BEST single-GPU configuration" in c["scaling_baseline"]
+    assert "rows64_kernel" in d["roofline"]["kernel"] and d["roofline"]["bound"] == "hbm"
+    assert c["llm_fused_elementwise"]["decoder_layers_5_launches"] == 2
+    # 128 prompts on one rank: two batches of 64; --batch still wins when given
+    d = _line(_run(["--total-prompts", "128", "--steps", "1"] + E2E_TINY, {}, workload="e2e"))
+    assert d["config"]["per_rank_batch"] == 64 and d["config"]["per_rank_batches_per_step"] == 2 and d["config"]["gathered_molecules"] == 128
+    d = _line(_run(["--total-prompts", "16", "--batch", "4", "--steps", "1"] + E2E_TINY, {}, workload="e2e"))
+    assert d["config"]["per_rank_batch"] == 4 and d["config"]["per_rank_batches_per_step"] == 4 and d["config"]["per_rank_batch_source"] == "--batch"
+
+
 def test_bench_rank_failure_ends_the_job():
     """One rank raising inside the timed region: the launcher must end every rank and exit non-zero -- not hang in the barrier."""
     import time

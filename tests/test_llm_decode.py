@@ -361,7 +361,7 @@ def test_linear_rows64_epilogues_vs_torch(M):
     """ll_linear_rows64_bf16 (weight-streaming MFMA Linear for 17..64 token rows on a weight copy in MFMA operand order: 64 weight rows x
     all token rows per workgroup, K split over its waves and, for matrices with few row groups, over workgroups through f32 slabs) through
     the C ABI against op-by-op PyTorch with the same bf16 roundings: every epilogue, every K split, with and without the workspace, the
-    output RMSNorm for the next Linear as HF evaluates it; N not a multiple of the row group, K not a multiple of an x stage or of the
+    RMSNorm between two Linears split over producer (pre-scaled rows + sums of squares) and consumer (row scale in the epilogue); N not a multiple of the row group, K not a multiple of an x stage or of the
     slice count; a strided x; and its error behaviour."""
     import torch.nn.functional as F
     from llamole_amd import _lib
@@ -402,31 +402,56 @@ def test_linear_rows64_epilogues_vs_torch(M):
             f = f * torch.rsqrt(f.pow(2).mean(-1, keepdim=True) + eps)
             return nw * f.to(torch.bfloat16)
 
+        nch = int(lib.ll_rows64_ssq_chunks(N))
+        assert nch == (N + 1023) // 1024
+        # input side of a split RMSNorm: x is bf16(h * w_in) and the accumulator is scaled by rsqrt(mean(h^2) + eps)
+        win = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().cuda()
+        hrow = torch.randn(M, K, generator=g).bfloat16().cuda()
+        xs_in = torch.empty(M, K, dtype=torch.bfloat16, device="cuda")
+        kch = int(lib.ll_rows64_ssq_chunks(K))
+        ssq_in = torch.full((M, kch), float("nan"), dtype=torch.float32, device="cuda")
+        _lib.check(lib.ll_rows64_prenorm_bf16(hrow.data_ptr(), K, win.data_ptr(), xs_in.data_ptr(), K, ssq_in.data_ptr(), M, K, s), "ll_rows64_prenorm_bf16")
+        assert torch.equal(xs_in, (hrow.float() * win.float()).to(torch.bfloat16))
+        torch.testing.assert_close(ssq_in.sum(1), hrow.float().pow(2).sum(1), rtol=1e-5, atol=1e-3)
+        for c in range(kch):
+            torch.testing.assert_close(ssq_in[:, c], hrow[:, c * 1024:(c + 1) * 1024].float().pow(2).sum(1), rtol=1e-5, atol=1e-3)
+
+        def hf_rms(v, wn):      # Qwen2RMSNorm as HF evaluates it
+            f = v.float()
+            f = f * torch.rsqrt(f.pow(2).mean(-1, keepdim=True) + eps)
+            return wn * f.to(torch.bfloat16)
+
         for ksg in (0, 1, 2, 4, 8):
             for use_bias in ((False, True) if ksg == 0 else (False,)):
                 b = bias if use_bias else torch.zeros_like(bias)
-                full = (x.float() @ w.float().t() + b).to(torch.bfloat16)
-                want = {0: full[:, :N], 1: res + full[:, :N], 2: F.silu(full[:, :N]) * full[:, N:]}
-                for epi in ((0, 1, 2) if Np else (0, 1)):
-                    for use_ws, norm in (((True, False), (False, False), (True, True)) if ksg == 0 else ((True, False), (True, True))):
-                        if norm and epi == 2:
-                            continue
-                        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-                        xn = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-                        lib.ll_set_rows64_ksplit(ksg)
-                        try:
-                            _lib.check(lib.ll_linear_rows64_bf16(x.data_ptr(), ldx, (wp2 if epi == 2 else wp1).data_ptr(),
-                                                                 bias.data_ptr() if use_bias else None, res.data_ptr() if epi == 1 else None, N,
-                                                                 out.data_ptr(), N, M, N, K, epi, nw.data_ptr() if norm else None, eps,
-                                                                 xn.data_ptr() if norm else None, N, ws.data_ptr() if use_ws else None,
-                                                                 wsb if use_ws else 0, s), "ll_linear_rows64_bf16")
-                        finally:
-                            lib.ll_set_rows64_ksplit(0)
-                        scale = want[epi].float().abs().max().item()
-                        tag = f"K={K} N={N} ksg={ksg} epi={epi} ws={use_ws} norm={norm} bias={use_bias}"
-                        torch.testing.assert_close(out.float(), want[epi].float(), rtol=3e-2, atol=max(3e-2, 0.01 * scale), msg=lambda m: f"{tag}: {m}")
-                        if norm:        # the RMSNorm of the ROUNDED output row, op by op as Qwen2RMSNorm: one bf16 ulp of the kernel's own row
-                            torch.testing.assert_close(xn.float(), rms(out).float(), rtol=1.6e-2, atol=1e-2, msg=lambda m: f"{tag} (norm): {m}")
+                for scaled in ((False, True) if ksg in (0, 1) else (False,)):
+                    xin = hf_rms(hrow, win) if scaled else x
+                    full = (xin.float() @ w.float().t() + b).to(torch.bfloat16)
+                    want = {0: full[:, :N], 1: res + full[:, :N], 2: F.silu(full[:, :N]) * full[:, N:]}
+                    for epi in ((0, 1, 2) if Np else (0, 1)):
+                        for use_ws, norm in (((True, False), (False, False), (True, True)) if ksg == 0 else ((True, False), (True, True))):
+                            if norm and (epi == 2 or scaled):
+                                continue
+                            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+                            xs = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+                            ssq = torch.full((M, nch), float("nan"), dtype=torch.float32, device="cuda")
+                            xa, lda = (xs_in, K) if scaled else (x, ldx)
+                            lib.ll_set_rows64_ksplit(ksg)
+                            try:
+                                _lib.check(lib.ll_linear_rows64_bf16(xa.data_ptr(), lda, (wp2 if epi == 2 else wp1).data_ptr(),
+                                                                     bias.data_ptr() if use_bias else None, res.data_ptr() if epi == 1 else None, N,
+                                                                     out.data_ptr(), N, M, N, K, epi, ssq_in.data_ptr() if scaled else None,
+                                                                     kch if scaled else 0, eps, nw.data_ptr() if norm else None,
+                                                                     xs.data_ptr() if norm else None, N, ssq.data_ptr() if norm else None,
+                                                                     ws.data_ptr() if use_ws else None, wsb if use_ws else 0, s), "ll_linear_rows64_bf16")
+                            finally:
+                                lib.ll_set_rows64_ksplit(0)
+                            scale = want[epi].float().abs().max().item()
+                            tag = f"K={K} N={N} ksg={ksg} epi={epi} ws={use_ws} norm={norm} bias={use_bias} scaled={scaled}"
+                            torch.testing.assert_close(out.float(), want[epi].float(), rtol=3e-2, atol=max(3e-2, 0.01 * scale), msg=lambda m: f"{tag}: {m}")
+                            if norm:        # the two halves of the next RMSNorm, exactly, from the kernel's own rounded output row
+                                assert torch.equal(xs, (out.float() * nw.float()).to(torch.bfloat16)), tag
+                                torch.testing.assert_close(ssq.sum(1), out.float().pow(2).sum(1), rtol=1e-5, atol=1e-3, msg=lambda m: f"{tag} (ssq): {m}")
     # the K split over workgroups sums its slabs in slice order: two runs are bit-identical
     K, N = 14336, 512
     x = torch.randn(M, K, generator=g).bfloat16().cuda()
@@ -438,17 +463,66 @@ def test_linear_rows64_epilogues_vs_torch(M):
     outs = []
     for _ in range(2):
         o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-        _lib.check(lib.ll_linear_rows64_bf16(x.data_ptr(), K, wp.data_ptr(), None, res.data_ptr(), N, o.data_ptr(), N, M, N, K, 1, None, eps, None, 0,
-                                             ws.data_ptr(), ws.numel(), s))
+        _lib.check(lib.ll_linear_rows64_bf16(x.data_ptr(), K, wp.data_ptr(), None, res.data_ptr(), N, o.data_ptr(), N, M, N, K, 1, None, 0, eps, None, None, 0,
+                                             None, ws.data_ptr(), ws.numel(), s))
         outs.append(o)
     assert torch.equal(outs[0], outs[1])
     bad = lambda *a: lib.ll_linear_rows64_bf16(*a) == -1       # LL_EINVAL
-    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N, 65, N, K, 0, None, eps, None, 0, None, 0, s)          # rows
-    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N, M, N, K - 8, 0, None, eps, None, 0, None, 0, s)       # K % 32
-    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N, M, N, K, 1, None, eps, None, 0, None, 0, s)           # no residual
-    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N, M, N, K, 0, res.data_ptr(), eps, o.data_ptr(), N, None, 0, s)   # norm without workspace
-    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N - 8, M, N - 8, K, 2, None, eps, None, 0, None, 0, s)   # SILU_MUL, N % 16
+    tail = (None, 0, eps, None, None, 0, None, None, 0, s)
+    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N, 65, N, K, 0, *tail)          # rows
+    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N, M, N, K - 8, 0, *tail)       # K % 32
+    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N, M, N, K, 1, *tail)           # no residual
+    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N, M, N, K, 0, None, 0, eps, res.data_ptr(), o.data_ptr(), N, ws.data_ptr(),
+               None, 0, s)                                                                                   # pre-norm without workspace
+    assert bad(x.data_ptr(), K, wp.data_ptr(), None, None, 0, o.data_ptr(), N - 8, M, N - 8, K, 2, *tail)   # SILU_MUL, N % 16
     assert lib.ll_rows64_packed_elems(16, 40) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,nh,nkv", [(128, 32, 8), (128, 28, 4), (64, 4, 2), (64, 16, 4), (128, 6, 2)])
+def test_gqa_decode_attention_equals_the_per_head_kernel(D, nh, nkv):
+    """ll_decode_attn_rope_bf16 with more than 16 sequences runs one workgroup per (KV head, sequence) for group sizes 2 / 4 / 7 (a key /
+    value row fetched once per group); the same call in chunks of <= 16 sequences runs the per-head kernel.  Same rotary arithmetic, same
+    appended cache rows bit for bit, outputs equal up to the f32 summation order of P.V (one bf16 ulp); left padding, a fully masked
+    row, a context longer than one 256-key tile."""
+    from llamole_amd import _lib
+    lib = _lib.load()
+    B, maxlen, p = 40, 320, 291
+    g = torch.Generator().manual_seed(D + nh)
+    nqkv = (nh + 2 * nkv) * D
+    qkv = torch.randn(B, nqkv, generator=g).bfloat16().cuda()
+    cos = torch.randn(B, D, generator=g).bfloat16().cuda()
+    sin = torch.randn(B, D, generator=g).bfloat16().cuda()
+    Kc = torch.randn(B, nkv, maxlen, D, generator=g).bfloat16().cuda()
+    Vc = torch.randn(B, nkv, maxlen, D, generator=g).bfloat16().cuda()
+    mask = torch.zeros(B, maxlen, dtype=torch.bool)
+    mask[:, :p + 1] = True
+    mask[3, :17] = False            # left padding
+    mask[7, :200] = False
+    mask[11] = False                # a fully masked query row yields zeros
+    Kc[3, :, :17] = float("nan")    # padded cache rows may hold anything
+    mask = mask.cuda()
+    pos = torch.tensor([p], dtype=torch.long, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    scale = D ** -0.5
+
+    def run(lo, hi, K, V, out):
+        n = hi - lo
+        _lib.check(lib.ll_decode_attn_rope_bf16(qkv[lo:hi].data_ptr(), nqkv, cos[lo:hi].data_ptr(), sin[lo:hi].data_ptr(), D, K[lo:hi].data_ptr(),
+                                                V[lo:hi].data_ptr(), pos.data_ptr(), mask[lo:hi].data_ptr(), maxlen, out[lo:hi].data_ptr(), n, nh, nkv,
+                                                maxlen, D, scale, s), "ll_decode_attn_rope_bf16")
+
+    K1, V1, K2, V2 = Kc.clone(), Vc.clone(), Kc.clone(), Vc.clone()
+    o1 = torch.full((B, nh * D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    o2 = o1.clone()
+    run(0, B, K1, V1, o1)                       # 40 sequences: the grouped kernel (the per-head one when the group size has no instance)
+    for lo in range(0, B, 16):
+        run(lo, min(lo + 16, B), K2, V2, o2)    # <= 16 sequences: the per-head kernel
+    ok = ~torch.isnan(Kc.float()).any(-1)       # compare outside the poisoned padding rows
+    assert torch.equal(K1[:, :, p], K2[:, :, p]) and torch.equal(V1[:, :, p], V2[:, :, p])
+    assert torch.equal(torch.nan_to_num(K1.float()), torch.nan_to_num(K2.float())) and torch.equal(V1, V2) and ok.any()
+    assert not torch.isnan(o1.float()).any() and float(o1[11].float().abs().max()) == 0.0
+    torch.testing.assert_close(o1.float(), o2.float(), rtol=1.6e-2, atol=2e-3)
 
 
 @pytest.mark.gpu
