@@ -32,10 +32,10 @@ enum { R64_PLAIN = 0, R64_RESIDUAL = 1, R64_SILU_MUL = 2 };
 
 __device__ __forceinline__ float r64_bfr(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 
-constexpr int R64_KS = 512;                     // k per x stage (16 MFMA k-steps)
-constexpr int R64_XPITCH = R64_KS * 2 + 16;     // LDS row pitch of a stage: 260 dwords = 4 mod 64
-constexpr int R64_WAVES = 8, R64_KP = 4, R64_KPW = 16 / R64_KP;      // waves; k-parts; k-steps per wave per stage
-constexpr int R64_NW = R64_KPW * 2;             // weight loads per wave per stage (two tiles)
+constexpr int R64_WAVES = 8, R64_KP = 4;        // waves per workgroup; k-parts
+// KS = k per x stage (512: 16 MFMA k-steps; LDS row pitch KS * 2 + 16 bytes = 260 dwords = 4 mod 64).  KS = 256 halves the ring (67 KB)
+// and the registers (<= 128: two workgroups per CU): measured level with 512 on every decode shape (47.3 vs 47.9 us on gate|up at 64
+// rows), so only 512 is instantiated
 
 // [N, K] row-major (row pitch ldw) -> MFMA A-operand order, rows padded to a multiple of 16 with zeros:
 // out[((tile * K/32 + kstep) * 64 + lane) * 8 + e] = W[tile * 16 + (lane & 15)][kstep * 32 + (lane >> 4) * 8 + e]
@@ -61,21 +61,25 @@ __global__ __launch_bounds__(256) void rows64_pack_kernel(const bf16_t *__restri
 // prologue + drain of every workgroup cost 11 of 49 us on gate|up at 64 rows).
 // slab != nullptr: raw f32 partial sums [ksg][M][N] (no bias / epilogue).  tiles_n = padded weight tiles per matrix half (SILU_MUL: the up
 // tiles follow the gate tiles at +tiles_n).
-template <int EPI, int MB>
-__global__ __launch_bounds__(512) void rows64_kernel(const bf16_t *__restrict__ X, int ldx, const bf16_t *__restrict__ Wp,
+template <int EPI, int MB, int KS>
+__global__ __launch_bounds__(512, KS == 256 ? 4 : 2) void rows64_kernel(const bf16_t *__restrict__ X, int ldx, const bf16_t *__restrict__ Wp,
                                                      const float *__restrict__ bias, const bf16_t *__restrict__ res, int ldr,
                                                      bf16_t *__restrict__ C, int ldc, float *__restrict__ slab,
                                                      const float *__restrict__ row_ssq, int ssq_chunks, float eps, int M, int N, int K,
                                                      int tiles_n, int units, int ksg) {
-    constexpr int NX = MB * 16 * (R64_KS / 8) / 512;            // 16-byte x loads per thread per stage (8 | 4)
+    constexpr int R64_KS = KS, R64_XPITCH = KS * 2 + 16;
+    constexpr int R64_KPW = KS / 32 / R64_KP;                   // k-steps per wave per stage (4 | 2)
+    constexpr int R64_NW = R64_KPW * 2;                         // weight loads per wave per stage (two tiles)
+    constexpr int NX = MB * 16 * (R64_KS / 8) / 512;            // 16-byte x loads per thread per stage
+    constexpr int XLPR = KS / 8;                                // lanes per x row of a stage (64 | 32)
     constexpr int SLOT = MB * 16 * R64_XPITCH;
-    static_assert(R64_WAVES * 2 * MB * 1024 <= SLOT, "the partial-tile exchange of a unit uses the ring slot its last stage was read from");
+    static_assert(R64_WAVES * MB * 1024 <= SLOT, "the partial-tile exchange of a unit (one tile at a time) uses the ring slot its last stage was read from");
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_r64[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tp = wid & 1, kp = wid >> 1;
     const int kts = K / 32;
-    const int nst = (K + R64_KS - 1) / R64_KS;          // x stages of K
+    const int nst = (K + KS - 1) / KS;                  // x stages of K
     const int sper = (nst + ksg - 1) / ksg;             // stages per K slice (a trailing slice may run past nst: empty stages)
     const int nmine = (int)blockIdx.x < units ? (units - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int P = nmine * sper;                         // positions of this workgroup
@@ -91,39 +95,51 @@ __global__ __launch_bounds__(512) void rows64_kernel(const bf16_t *__restrict__ 
 #pragma unroll
         for (int b = 0; b < MB; ++b) acc[t][b] = (r64_f32x4)(0.f);
     r64_u32x4 wr[2][R64_NW], xr[NX];
-    // x chunk c = tid + 512 i of a stage: token row c >> 6, 16-byte piece c & 63 (one wave instruction = one whole row of the stage)
-    const int xrow0 = tid >> 6, xpiece = tid & 63;
+    // x chunk c = tid + 512 i of a stage: token row c / XLPR, 16-byte piece c % XLPR (one wave instruction = one or two whole rows of the stage).
+    // Loads are `global_load_dwordx4 vdst, voffset, sbase`: the per-lane part of an address is a loop-invariant 32-bit offset, everything
+    // that changes per stage is wave-uniform and lives in the scalar base -- no vector address arithmetic in the loop (the first version,
+    // with 64-bit per-lane pointers and zero-selects, spent 188 VALU instructions per stage next to 32 MFMAs).  Token rows >= M re-read row
+    // M - 1 (their results are never stored); k-steps past K are never multiplied.
+    const int xrow0 = tid / XLPR, xpiece = tid % XLPR;
+    constexpr int XRS = 512 / XLPR;                             // token rows per pass of the workgroup (8 | 16)
+    uint32_t xoff[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xoff[i] = (uint32_t)min(xrow0 + i * XRS, M - 1) * (uint32_t)ldx * 2u + (uint32_t)xpiece * 16u;
+    const uint32_t woff = (uint32_t)lane * 16u;
     auto xload = [&](int p) {
         const int st = stage_of(p);
+        if ((st + 1) * KS <= K) {
+            const unsigned char *base = reinterpret_cast<const unsigned char *>(X) + (int64_t)st * (KS * 2);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int row = xrow0 + i * 8, k = st * R64_KS + xpiece * 8;
-            const bool ok = row < M && k < K;
-            const bf16_t *q = X + (int64_t)(ok ? row : 0) * ldx + (ok ? k : 0);
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[i]) : "v"(q) : "memory");
+            for (int i = 0; i < NX; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xr[i]) : "v"(xoff[i]), "s"(base) : "memory");
+        } else {            // the stage that straddles K (K % KS != 0) or lies past it: columns clamped per lane
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int k = min(st * KS + xpiece * 8, K - 8);
+                const bf16_t *q = X + (int64_t)min(xrow0 + i * XRS, M - 1) * ldx + k;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[i]) : "v"(q) : "memory");
+            }
         }
     };
     auto xwrite = [&](int p, int slot) {
-        const int st = stage_of(p);
-        unsigned char *b = sm_r64 + slot * SLOT;
+        unsigned char *b = sm_r64 + slot * SLOT + xrow0 * R64_XPITCH + xpiece * 16;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int row = xrow0 + i * 8, k = st * R64_KS + xpiece * 8;
             asm volatile("" : "+v"(xr[i]));
-            *reinterpret_cast<r64_u32x4 *>(b + row * R64_XPITCH + xpiece * 16) = (row < M && k < K) ? xr[i] : (r64_u32x4)(0);
+            *reinterpret_cast<r64_u32x4 *>(b + i * XRS * R64_XPITCH) = xr[i];
         }
     };
-    auto wload = [&](int set, int p) {          // k-steps kp*4 .. kp*4+3 of position p, both tiles; k-steps past K re-read the last one (unused)
+    auto wload = [&](int set, int p) {          // k-steps kp*KPW .. of position p, both tiles; k-steps past K re-read the last one (unused)
         const int st = stage_of(p), ot = otile_of(unit_of(p));
         const int t0 = min(ot, tiles_n - 1);
         const int t1 = EPI == R64_SILU_MUL ? t0 + tiles_n : min(ot + 1, tiles_n - 1);
-        const bf16_t *w0 = Wp + ((int64_t)t0 * kts * 64 + lane) * 8;
-        const bf16_t *w1 = Wp + ((int64_t)t1 * kts * 64 + lane) * 8;
+        const unsigned char *w0 = reinterpret_cast<const unsigned char *>(Wp) + (int64_t)t0 * kts * 1024;
+        const unsigned char *w1 = reinterpret_cast<const unsigned char *>(Wp) + (int64_t)t1 * kts * 1024;
 #pragma unroll
         for (int i = 0; i < R64_KPW; ++i) {
-            const int ks = min(st * 16 + kp * R64_KPW + i, kts - 1);
-            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(wr[set][2 * i]) : "v"(w0 + (int64_t)ks * 512) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(wr[set][2 * i + 1]) : "v"(w1 + (int64_t)ks * 512) : "memory");
+            const int ks = min(st * (KS / 32) + kp * R64_KPW + i, kts - 1);
+            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(wr[set][2 * i]) : "v"(woff), "s"(w0 + (int64_t)ks * 1024) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(wr[set][2 * i + 1]) : "v"(woff), "s"(w1 + (int64_t)ks * 1024) : "memory");
         }
     };
     const int fr = lane & 15, fq = lane >> 4;
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(512) void rows64_kernel(const bf16_t *__restrict__ 
 #pragma unroll
         for (int i = 0; i < R64_KPW; ++i) {
             const int ksl = kp * R64_KPW + i;           // k-step within the stage
-            if (st * 16 + ksl >= kts) break;            // wave-uniform: past K
+            if (st * (KS / 32) + ksl >= kts) break;     // wave-uniform: past K
             asm volatile("" : "+v"(wr[set][2 * i]), "+v"(wr[set][2 * i + 1]));
             r64_bf16x8 bf[MB];
 #pragma unroll
@@ -149,24 +165,26 @@ __global__ __launch_bounds__(512) void rows64_kernel(const bf16_t *__restrict__ 
     // end of a unit (the barrier behind its last stage has passed: ring slot `slot` is free until the next stage's x write): the partial
     // tiles of the four k-parts -> LDS; k-part wave kp finishes column block kp of its tile pair (summed in k-part order); accumulators reset
     auto finish = [&](int u, int slot) {
-        float *part = reinterpret_cast<float *>(sm_r64 + slot * SLOT);        // [waves][2 tiles][MB][64 lanes][4]
+        float *part = reinterpret_cast<float *>(sm_r64 + slot * SLOT);        // [waves][MB][64 lanes][4], one tile of the pair at a time
+        const int cb = kp, m = cb * 16 + (lane & 15);
+        r64_f32x4 s0 = (r64_f32x4)(0.f), s1 = (r64_f32x4)(0.f);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int c = 0; c < MB; ++c) {
-                *reinterpret_cast<r64_f32x4 *>(part + (((wid * 2 + t) * MB + c) * 64 + lane) * 4) = acc[t][c];
+                *reinterpret_cast<r64_f32x4 *>(part + ((wid * MB + c) * 64 + lane) * 4) = acc[t][c];
                 acc[t][c] = (r64_f32x4)(0.f);
             }
-        __syncthreads();
-        const int cb = kp, m = cb * 16 + (lane & 15);
-        if (kp < MB && m < M) {
-            r64_f32x4 s0 = (r64_f32x4)(0.f), s1 = (r64_f32x4)(0.f);
+            __syncthreads();
+            if (kp < MB) {
+                r64_f32x4 sum = (r64_f32x4)(0.f);
 #pragma unroll
-            for (int q = 0; q < R64_KP; ++q) {
-                const int w = q * 2 + tp;
-                s0 += *reinterpret_cast<const r64_f32x4 *>(part + (((w * 2 + 0) * MB + cb) * 64 + lane) * 4);
-                s1 += *reinterpret_cast<const r64_f32x4 *>(part + (((w * 2 + 1) * MB + cb) * 64 + lane) * 4);
+                for (int q = 0; q < R64_KP; ++q) sum += *reinterpret_cast<const r64_f32x4 *>(part + (((q * 2 + tp) * MB + cb) * 64 + lane) * 4);
+                if (t == 0) s0 = sum; else s1 = sum;
             }
+            __syncthreads();        // the exchange buffer is free again (the second tile; then a ring slot)
+        }
+        if (kp < MB && m < M) {
             // s0[j] / s1[j] = C[weight row tile * 16 + (lane>>4)*4 + j][token cb*16 + (lane & 15)] of the wave's first / second tile
             if (row_ssq) {          // x was bf16(h * w_norm): rsqrt(mean(h^2) + eps) of the token row scales the accumulator (rows16 form)
                 float t = 0.f;
@@ -218,7 +236,6 @@ __global__ __launch_bounds__(512) void rows64_kernel(const bf16_t *__restrict__ 
                 }
             }
         }
-        __syncthreads();            // the exchange buffer is a ring slot again
     };
     if (P == 0) return;
     // VMEM issue order: X(0) W(0) X(1) W(1), then per position p: X(p+2) at its top, W(p+2) behind its MFMAs.  At the top of position p
@@ -255,14 +272,15 @@ __global__ __launch_bounds__(512) void rows64_kernel(const bf16_t *__restrict__ 
 }
 
 // grid (token rows, 1024-column chunks), 256 threads x 4 columns: out[m][n] = epilogue(sum over slices (in slice order) of slab[z][m][n]
-// + bias[n]).  normw != nullptr: also XS[m][n] = bf16(out[m][n] * normw[n]) and ssq[m][chunk] = sum over the chunk of out[m][n]^2 (of the
+// x the optional input row scale + bias[n]).  normw != nullptr: also XS[m][n] = bf16(out[m][n] * normw[n]) and ssq[m][chunk] = sum over the chunk of out[m][n]^2 (of the
 // ROUNDED output) -- the two halves of the next Linear's RMSNorm: the consumer multiplies its accumulator by rsqrt(sum(ssq) / N + eps).
 // splits == 0, C == nullptr: the pre-norm of the residual rows alone (the embedding rows ahead of the first layer).
 template <int EPI>
 __global__ __launch_bounds__(256) void rows64_reduce_kernel(const float *__restrict__ slab, int splits, const float *__restrict__ bias,
                                                             const bf16_t *__restrict__ res, int ldr, bf16_t *__restrict__ C, int ldc,
                                                             const bf16_t *__restrict__ normw, bf16_t *__restrict__ XS, int ldn,
-                                                            float *__restrict__ ssq, int M, int N) {
+                                                            float *__restrict__ ssq, const float *__restrict__ row_ssq, int ssq_chunks,
+                                                            float eps, int K, int M, int N) {
     __shared__ float red[4];
     const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int n = (blockIdx.y * 256 + tid) * 4;
@@ -283,6 +301,13 @@ __global__ __launch_bounds__(256) void rows64_reduce_kernel(const float *__restr
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (n + j < N) v[j] += slab[((int64_t)z * M + m) * N + n + j];
+        }
+        if (row_ssq) {          // the input row scale of a split RMSNorm (see rows64_kernel), applied to the complete sum
+            float t = 0.f;
+            for (int c = 0; c < ssq_chunks; ++c) t += row_ssq[m * ssq_chunks + c];
+            const float rstd = rsqrtf(t / (float)K + eps);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= rstd;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -316,30 +341,37 @@ static int r64_cus() {
     return cus;
 }
 
-template <int EPI, int MB>
-static int launch_rows64_mb(int ksg, hipStream_t s, const bf16_t *X, int ldx, const bf16_t *Wp, const float *bias, const bf16_t *res, int ldr,
+template <int EPI, int MB, int KS>
+static int launch_rows64_ks(int ksg, hipStream_t s, const bf16_t *X, int ldx, const bf16_t *Wp, const float *bias, const bf16_t *res, int ldr,
                             bf16_t *C, int ldc, float *slab, const float *row_ssq, int ssq_chunks, float eps, int M, int N, int K) {
-    const size_t lds = (size_t)2 * MB * 16 * R64_XPITCH;
+    const size_t lds = (size_t)2 * MB * 16 * (KS * 2 + 16);
     static bool attr_set = false;
     if (!attr_set) {
-        LL_HIP(hipFuncSetAttribute((const void *)rows64_kernel<EPI, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LL_HIP(hipFuncSetAttribute((const void *)rows64_kernel<EPI, MB, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int tiles_n = (N + 15) / 16;
     const int groups = EPI == R64_SILU_MUL ? cdiv(tiles_n, 2) : cdiv(tiles_n, 4);
     const int units = groups * ksg;
-    // workgroups resident at once: one per CU (133 KB of LDS at 64 rows; 136..180 VGPRs x 8 waves)
-    const int slots = r64_cus();
+    // workgroups resident at once: one per CU with 512-k stages (133 KB of LDS at 64 rows), two with 256-k stages (<= 128 VGPRs)
+    const int slots = r64_cus() * (KS == 256 ? 2 : 1);
     const dim3 grid(units < slots ? units : slots);
-    hipLaunchKernelGGL((rows64_kernel<EPI, MB>), grid, dim3(512), lds, s, X, ldx, Wp, bias, res, ldr, C, ldc, slab, row_ssq, ssq_chunks, eps, M, N, K,
-                       tiles_n, units, ksg);
+    hipLaunchKernelGGL((rows64_kernel<EPI, MB, KS>), grid, dim3(512), lds, s, X, ldx, Wp, bias, res, ldr, C, ldc, slab, row_ssq, ssq_chunks, eps, M, N,
+                       K, tiles_n, units, ksg);
     return LL_OK;
+}
+
+template <int EPI, int MB>
+static int launch_rows64_mb(int ksg, hipStream_t s, const bf16_t *X, int ldx, const bf16_t *Wp, const float *bias, const bf16_t *res, int ldr,
+                            bf16_t *C, int ldc, float *slab, const float *row_ssq, int ssq_chunks, float eps, int M, int N, int K) {
+    return launch_rows64_ks<EPI, MB, 512>(ksg, s, X, ldx, Wp, bias, res, ldr, C, ldc, slab, row_ssq, ssq_chunks, eps, M, N, K);
 }
 
 template <int EPI>
 static int launch_reduce(hipStream_t s, const float *slab, int ksg, const float *bias, const bf16_t *res, int ldr, bf16_t *C, int ldc,
-                         const bf16_t *normw, bf16_t *XS, int ldn, float *ssq, int M, int N) {
-    hipLaunchKernelGGL((rows64_reduce_kernel<EPI>), dim3(M, cdiv(N, 1024)), dim3(256), 0, s, slab, ksg, bias, res, ldr, C, ldc, normw, XS, ldn, ssq, M, N);
+                         const bf16_t *normw, bf16_t *XS, int ldn, float *ssq, const float *row_ssq, int ssq_chunks, float eps, int K, int M, int N) {
+    hipLaunchKernelGGL((rows64_reduce_kernel<EPI>), dim3(M, cdiv(N, 1024)), dim3(256), 0, s, slab, ksg, bias, res, ldr, C, ldc, normw, XS, ldn, ssq,
+                       row_ssq, ssq_chunks, eps, K, M, N);
     return LL_OK;
 }
 
@@ -361,14 +393,15 @@ int linear_rows64_launch(const void *x, int ldx, const void *Wp, const float *bi
     const bf16_t *X = (const bf16_t *)x, *W = (const bf16_t *)Wp, *rs = (const bf16_t *)residual;
     bf16_t *C = (bf16_t *)out;
     int ksg = 1;
-    if (epi != R64_SILU_MUL && !row_ssq) {          // the SiLU and the row scale need complete sums
+    if (epi != R64_SILU_MUL) {          // the SiLU needs complete sums
         if (g_rows64_ksg) {
             ksg = g_rows64_ksg;
         } else {
-            // few row groups (o_proj, down_proj: 64 on 256 CUs): split K over workgroups until every CU has a unit; a slice keeps >= 2
-            // x-stages.  (q|k|v, 72..96 groups: 20.4 us in one piece against 23.4 split in two + the second launch)
-            const int groups = cdiv(N, 64), nst = cdiv(K, R64_KS);
-            while (ksg < 8 && groups * ksg * 4 < r64_cus() * 3 && groups < r64_cus() / 3 && nst / (ksg * 2) >= 2) ksg *= 2;
+            // few row groups (o_proj, down_proj: 56..64 on 256 CUs; q|k|v: 72..96): split K over workgroups until three quarters of the CUs
+            // have a unit; a slice keeps >= 2 x-stages (profiles/r6_rows64_sweep.txt: o_proj 16.0 us at 4 slices against 24.3 in one piece,
+            // down_proj 29.8 against 63.8, q|k|v 18.9 at 2 against 21.9)
+            const int groups = cdiv(N, 64), nst = cdiv(K, 512);
+            while (ksg < 8 && groups * ksg * 4 < r64_cus() * 3 && nst / (ksg * 2) >= 2) ksg *= 2;
         }
     }
     const size_t need = (size_t)ksg * M * N * 4;
@@ -381,8 +414,8 @@ int linear_rows64_launch(const void *x, int ldx, const void *Wp, const float *bi
     const int mb = M <= 32 ? 2 : 4;
 #define LL_R64(EPI_)                                                                                                                     \
     do {                                                                                                                                 \
-        if (mb == 2) LL_TRY((launch_rows64_mb<EPI_, 2>(ksg, s, X, ldx, W, bias, rs, ldr, C, ldc, slab, row_ssq, ssq_chunks, eps, M, N, K))); \
-        else LL_TRY((launch_rows64_mb<EPI_, 4>(ksg, s, X, ldx, W, bias, rs, ldr, C, ldc, slab, row_ssq, ssq_chunks, eps, M, N, K)));        \
+        if (mb == 2) LL_TRY((launch_rows64_mb<EPI_, 2>(ksg, s, X, ldx, W, bias, rs, ldr, C, ldc, slab, slab ? nullptr : row_ssq, ssq_chunks, eps, M, N, K))); \
+        else LL_TRY((launch_rows64_mb<EPI_, 4>(ksg, s, X, ldx, W, bias, rs, ldr, C, ldc, slab, slab ? nullptr : row_ssq, ssq_chunks, eps, M, N, K)));        \
     } while (0)
     if (epi == R64_PLAIN) LL_R64(R64_PLAIN);
     else if (epi == R64_RESIDUAL) LL_R64(R64_RESIDUAL);
@@ -390,9 +423,11 @@ int linear_rows64_launch(const void *x, int ldx, const void *Wp, const float *bi
 #undef LL_R64
     if (slab) {
         if (epi == R64_RESIDUAL)
-            LL_TRY((launch_reduce<R64_RESIDUAL>(s, slab, ksg, bias, rs, ldr, C, ldc, (const bf16_t *)next_norm_w, (bf16_t *)scaled_out, ldn, ssq_out, M, N)));
+            LL_TRY((launch_reduce<R64_RESIDUAL>(s, slab, ksg, bias, rs, ldr, C, ldc, (const bf16_t *)next_norm_w, (bf16_t *)scaled_out, ldn, ssq_out,
+                                                row_ssq, ssq_chunks, eps, K, M, N)));
         else
-            LL_TRY((launch_reduce<R64_PLAIN>(s, slab, ksg, bias, rs, ldr, C, ldc, (const bf16_t *)next_norm_w, (bf16_t *)scaled_out, ldn, ssq_out, M, N)));
+            LL_TRY((launch_reduce<R64_PLAIN>(s, slab, ksg, bias, rs, ldr, C, ldc, (const bf16_t *)next_norm_w, (bf16_t *)scaled_out, ldn, ssq_out, row_ssq,
+                                             ssq_chunks, eps, K, M, N)));
     }
     LL_LAUNCH_CHECK();
     return LL_OK;
@@ -429,7 +464,7 @@ int ll_rows64_prenorm_bf16(const void *x, int ldx, const void *norm_w, void *sca
     LL_CHECK(x && norm_w && scaled_out && ssq_out && M >= 1 && N >= 1 && ldn >= N, "ll_rows64_prenorm_bf16: bad argument");
     // no slabs, no output row: XS = bf16(x * norm_w), ssq = per-chunk sums of squares of x
     LL_TRY((launch_reduce<R64_RESIDUAL>((hipStream_t)stream, nullptr, 0, nullptr, (const bf16_t *)x, ldx, nullptr, 0, (const bf16_t *)norm_w,
-                                        (bf16_t *)scaled_out, ldn, ssq_out, M, N)));
+                                        (bf16_t *)scaled_out, ldn, ssq_out, nullptr, 0, 0.f, 0, M, N)));
     LL_LAUNCH_CHECK();
     return LL_OK;
 }

@@ -75,7 +75,7 @@ def _rows64(lib, x2, ldx, wp: "_Packed64", bias, res, N, epi, row_ssq=None, eps=
         xs = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device)
         ssq = torch.empty(M, int(lib.ll_rows64_ssq_chunks(N)), dtype=torch.float32, device=x2.device)
     ws, wsb = None, 0
-    if epi != 2 and row_ssq is None and (next_norm is not None or N < 128 * 64):
+    if epi != 2 and (next_norm is not None or N < 192 * 64):
         wsb = int(lib.ll_linear_rows64_workspace_bytes(M, N))
         ws = torch.empty(wsb, dtype=torch.uint8, device=x2.device)
     rc = lib.ll_linear_rows64_bf16(x2.data_ptr(), ldx, wp.t.data_ptr(), bias.data_ptr() if bias is not None else None,

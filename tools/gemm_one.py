@@ -1,7 +1,8 @@
 """Run only one dominant kernel a few times: target for rocprofv3 --pmc (no torch import: keeps the profiled process minimal).
 usage: gemm_one.py M [N K]                     ll_linear dispatch (GraphDiT fc1 GEMM / unfused LLM GEMV)
        gemm_one.py fused M N K EPI NORM        ll_gemv_fused_bf16 (EPI 0 plain | 1 residual | 2 silu_mul over 2N rows)
-       gemm_one.py rows16 M N K EPI NORM       ll_linear_rows16_bf16 (same arguments, M <= 16)"""
+       gemm_one.py rows16 M N K EPI NORM       ll_linear_rows16_bf16 (same arguments, M <= 16)
+       gemm_one.py rows64 M N K EPI NORM       ll_linear_rows64_bf16 on packed weights (M <= 64; NORM & 1 output pre-norm, & 2 input row scale)"""
 import ctypes as C
 import os
 import sys
@@ -15,6 +16,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "fused":
     nw = max(2, int(600e6 // (rows * K * 2)))   # > 256 MiB Infinity Cache: every launch streams its weights from HBM
     _lib.check(lib.ll_gemv_fused_bench(M, N, K, epi, norm, 1, 8 * nw, nw, C.byref(ms)))
     print(f"fused M={M} N={N} K={K} epi={epi} norm={norm} avg {ms.value*1e3:.2f} us")
+elif len(sys.argv) > 1 and sys.argv[1] == "rows64":
+    M, N, K, epi, norm = (int(a) for a in sys.argv[2:7])
+    rows = 2 * N if epi == 2 else N
+    nw = max(2, int(600e6 // (rows * K * 2)))
+    _lib.check(lib.ll_rows64_bench(M, N, K, epi, norm, 8 * nw, nw, C.byref(ms)))
+    print(f"rows64 M={M} N={N} K={K} epi={epi} norm={norm} avg {ms.value*1e3:.2f} us")
 elif len(sys.argv) > 1 and sys.argv[1] == "rows16":
     M, N, K, epi, norm = (int(a) for a in sys.argv[2:7])
     rows = 2 * N if epi == 2 else N
