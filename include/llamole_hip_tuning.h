@@ -39,6 +39,15 @@ enum { LL_DIT_PROBE_EMPTY = 0x100, LL_DIT_PROBE_SKIP = 0x200 };
 int ll_dit_class_probe(void *handle, int cls);
 int ll_dit_class_probe_read(void *handle, float *total_us, int *launches);
 
+/* Test probes of the on-device sampling noise (tests/test_noise_gpu.py):
+ * ll_philox_probe : out[i][0..4) = Philox4x32-10 (Salmon et al. 2011; Random123) of counter ctr_key[i][0..4), key ctr_key[i][4..6) through the
+ *     device function the samplers call (known-answer vectors).
+ * ll_dit_noise_probe : the Exp(1) variates a GraphDiT reverse step s (z_T: s = T) draws on the device for `seed`: qx [B,N,16] atom noise,
+ *     qe [B,N,N,5] bond noise (every (i, j); the step uses j > i) -- injecting them through ll_dit_step / ll_dit_init_state must reproduce the
+ *     seed's own result bit for bit. */
+int ll_philox_probe(const uint32_t *ctr_key, uint32_t *out, int n, void *stream);
+int ll_dit_noise_probe(uint64_t seed, int s, int B, int N, float *qx, float *qe, void *stream);
+
 /* Tuning: waves per workgroup of the <= 64-row panel GEMM (4 | 8; default 8); returns the previous value. */
 int ll_set_m64_waves(int waves);
 /* Tuning: 1 (default) = the <= 64-row panel GEMM reads the GraphDiT engine's MFMA-operand-order weight copies where they exist (one

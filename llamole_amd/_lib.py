@@ -91,6 +91,8 @@ SIGNATURES = {
     "ll_debug_guard_selftest": (_I, []),
     "ll_dit_set_overlap": (_I, [_P, _I]),
     "ll_dit_set_option": (_I, [_P, _I, _I]),
+    "ll_philox_probe": (_I, [_P, _P, _I, _P]),
+    "ll_dit_noise_probe": (_I, [_U64, _I, _I, _I, _P, _P, _P]),
     "ll_dit_class_probe": (_I, [_P, _I]),
     "ll_dit_class_probe_read": (_I, [_P, C.POINTER(_F), C.POINTER(_I)]),
     "ll_linear_rows16_bf16": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _I, _I, _I, _I, _P]),

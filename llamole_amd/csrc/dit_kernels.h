@@ -10,6 +10,21 @@
 
 namespace ll {
 
+// ---------------------------------------------------------------------------------------------- on-device sampling noise
+// ONE definition of which Philox4x32-10 counter feeds which Exp(1) variate of a reverse step (s in [0, T)) or of z_T (s = T), used by the
+// posterior kernels, init_state_kernel and the test probe (ll_dit_noise_probe) alike.  key = (seed lo, seed hi).
+//   atom noise  q[b, i, c],      c in [0,16): counter (b * N + i,           s, c >> 2, 0x58), word c & 3
+//   bond noise  q[b, i, j, k],   k in [0, 5): counter ((b * N + i) * N + j, s, k >> 2, 0x45), word k & 3   (pairs j > i only)
+// The last counter word separates the two families, the second the steps, the key the batches: no (family, step, element) pair shares a
+// counter (tests/test_noise_gpu.py checks the dumps pairwise).
+__device__ __forceinline__ uint4 dit_noise_x4(uint2 key, int s, int node, int g) {
+    return philox4x32(make_uint4((uint32_t)node, (uint32_t)s, (uint32_t)g, 0x58u), key);
+}
+__device__ __forceinline__ uint4 dit_noise_e4(uint2 key, int s, int pair, int g) {
+    return philox4x32(make_uint4((uint32_t)pair, (uint32_t)s, (uint32_t)g, 0x45u), key);
+}
+
+
 constexpr int XD = LL_XDIM;
 constexpr int ED = LL_EDIM;
 
@@ -1085,7 +1100,7 @@ __device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b,
             if (a.qx) {
                 q = a.qx[((int64_t)b * N + i) * XD + c];
             } else {
-                const uint4 r = philox4x32(make_uint4((uint32_t)(b * N + i), (uint32_t)s, (uint32_t)(c >> 2), 0x58u), key);
+                const uint4 r = dit_noise_x4(key, s, b * N + i, c >> 2);
                 const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
                 q = exp1_from_bits(rr[c & 3]);
             }
@@ -1157,7 +1172,7 @@ __device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b,
         } else {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const uint4 r = philox4x32(make_uint4((uint32_t)((b * N + i) * N + j), (uint32_t)s, (uint32_t)g, 0x45u), key);
+                const uint4 r = dit_noise_e4(key, s, (b * N + i) * N + j, g);
                 q[g * 4 + 0] = exp1_from_bits(r.x);
                 q[g * 4 + 1] = exp1_from_bits(r.y);
                 q[g * 4 + 2] = exp1_from_bits(r.z);
@@ -1211,7 +1226,7 @@ __global__ __launch_bounds__(256) void init_state_kernel(int8_t *X, int8_t *E, c
                 if (qx) {
                     for (int c = 0; c < 4; ++c) q[c] = qx[((int64_t)b * N + i) * XD + g * 4 + c];
                 } else {
-                    const uint4 r = philox4x32(make_uint4((uint32_t)(b * N + i), (uint32_t)T, (uint32_t)g, 0x58u), key);
+                    const uint4 r = dit_noise_x4(key, T, b * N + i, g);
                     q[0] = exp1_from_bits(r.x); q[1] = exp1_from_bits(r.y);
                     q[2] = exp1_from_bits(r.z); q[3] = exp1_from_bits(r.w);
                 }
@@ -1236,7 +1251,7 @@ __global__ __launch_bounds__(256) void init_state_kernel(int8_t *X, int8_t *E, c
                 for (int k = 0; k < ED; ++k) q[k] = qe[(((int64_t)b * N + i) * N + j) * ED + k];
             } else {
                 for (int g = 0; g < 2; ++g) {
-                    const uint4 r = philox4x32(make_uint4((uint32_t)((b * N + i) * N + j), (uint32_t)T, (uint32_t)g, 0x45u), key);
+                    const uint4 r = dit_noise_e4(key, T, (b * N + i) * N + j, g);
                     q[g * 4 + 0] = exp1_from_bits(r.x); q[g * 4 + 1] = exp1_from_bits(r.y);
                     q[g * 4 + 2] = exp1_from_bits(r.z); q[g * 4 + 3] = exp1_from_bits(r.w);
                 }

@@ -1102,6 +1102,50 @@ int ll_dit_set_option(void *handle, int option, int value) {
     return LL_OK;
 }
 
+// ---- test probes of the on-device noise source (include/llamole_hip_tuning.h)
+static __global__ void philox_probe_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint4 r = philox4x32(make_uint4(in[i * 6 + 0], in[i * 6 + 1], in[i * 6 + 2], in[i * 6 + 3]), make_uint2(in[i * 6 + 4], in[i * 6 + 5]));
+    out[i * 4 + 0] = r.x, out[i * 4 + 1] = r.y, out[i * 4 + 2] = r.z, out[i * 4 + 3] = r.w;
+}
+
+// the Exp(1) variates a reverse step s (z_T: s = T) draws for every (graph, node, atom class) and (graph, i, j, bond class), through the
+// same dit_noise_x4 / dit_noise_e4 / exp1_from_bits the sampling kernels call
+static __global__ void noise_probe_kernel(unsigned long long seed, int s, int B, int N, float *__restrict__ qx, float *__restrict__ qe) {
+    const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+    const int64_t nx = (int64_t)B * N * 4, ne = (int64_t)B * N * N * 2;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nx + ne; t += (int64_t)gridDim.x * 256) {
+        if (t < nx) {
+            const int node = (int)(t >> 2), g = (int)(t & 3);
+            const uint4 r = dit_noise_x4(key, s, node, g);
+            float *o = qx + (int64_t)node * XD + g * 4;
+            o[0] = exp1_from_bits(r.x), o[1] = exp1_from_bits(r.y), o[2] = exp1_from_bits(r.z), o[3] = exp1_from_bits(r.w);
+        } else {
+            const int64_t u = t - nx;
+            const int pair = (int)(u >> 1), g = (int)(u & 1);
+            const uint4 r = dit_noise_e4(key, s, pair, g);
+            const float v[4] = {exp1_from_bits(r.x), exp1_from_bits(r.y), exp1_from_bits(r.z), exp1_from_bits(r.w)};
+            for (int k = 0; k < 4; ++k)
+                if (g * 4 + k < ED) qe[(int64_t)pair * ED + g * 4 + k] = v[k];
+        }
+    }
+}
+
+int ll_philox_probe(const uint32_t *ctr_key, uint32_t *out, int n, void *stream) {
+    LL_CHECK(ctr_key && out && n >= 1, "ll_philox_probe: bad argument");
+    hipLaunchKernelGGL(philox_probe_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ctr_key, out, n);
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+int ll_dit_noise_probe(uint64_t seed, int s, int B, int N, float *qx, float *qe, void *stream) {
+    LL_CHECK(qx && qe && B >= 1 && N >= 1 && s >= 0 && (int64_t)B * N * N < (1ll << 31), "ll_dit_noise_probe: bad argument");
+    hipLaunchKernelGGL(noise_probe_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (unsigned long long)seed, s, B, N, qx, qe);
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
 int ll_dit_class_probe(void *handle, int cls) {
     DitEngine *e = (DitEngine *)handle;
     LL_CHECK(e, "ll_dit_class_probe: null handle");
