@@ -85,21 +85,77 @@ def to_device(batch: Dict[str, Any], device) -> Dict[str, Any]:
     return out
 
 
-def sft_step(model, batch: Dict[str, Any], optimizer=None, bucket_bytes: int = 64 << 20) -> Dict[str, float]:
-    """One SFT step.  Under ``torch.distributed`` every rank calls it on its own shard; gradients are averaged."""
+def sft_step(model, batch: Dict[str, Any], optimizer=None, bucket_bytes: int = 64 << 20, masters: "Optional[MasterWeights]" = None) -> Dict[str, float]:
+    """One SFT step.  Under ``torch.distributed`` every rank calls it on its own shard; gradients are averaged.  ``masters``: the
+    optimizer steps the fp32 twins of the trainable parameters (MasterWeights; the optimizer was built on ``masters.masters``)."""
     from .distributed import allreduce_gradients
     out = model(**batch)
     loss = out.loss
     if optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
+        for p in (masters.params if masters is not None else ()):
+            p.grad = None
     loss.backward()
     params = [p for p in model.parameters() if p.requires_grad]      # fixed list: identical bucket layout on every rank
     allreduce_gradients(params, bucket_bytes=bucket_bytes)
     if optimizer is not None:
+        if masters is not None:
+            masters.grads_to_masters()
         optimizer.step()
+        if masters is not None:
+            masters.masters_to_params()
     log = {k: float(v) for k, v in out.additional_log_info.items()}
     log["loss"] = float(loss.detach())
     return log
+
+
+class MasterWeights:
+    """fp32 master copies of the trainable parameters.  The reference casts every trainable parameter -- LoRA A / B and the
+    ``modules_to_save`` embedding matrices -- to fp32 (adapter.py:263-265, cast_trainable_params_to_fp32) and lets autocast run the forward
+    in bf16; here the model keeps its bf16 tensors (the kernels and fused adapters read those) and the OPTIMIZER steps fp32 twins:
+    ``grads_to_masters`` before ``optimizer.step()``, ``masters_to_params`` after it.  At lr 1e-4 an AdamW step on a bf16 weight of
+    magnitude 0.02 is about one bf16 ulp, so without the twins most updates of the learned-query rows round away once the cosine decay
+    starts.  ``params`` that already are fp32 are stepped in place.  The twin of a parameter is reachable as
+    ``param._ll_master`` -- ``lora_state_dict`` saves that (fp32 on disk, as peft does)."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        self.masters = []
+        for p in self.params:
+            if p.dtype == torch.float32:
+                self.masters.append(p)
+            else:
+                # a resumed adapter was saved in fp32: start the twin from that value when it is the one the bf16 tensor was rounded from
+                src = getattr(p, "_ll_resume_fp32", None)
+                if src is None or tuple(src.shape) != tuple(p.shape) or not torch.equal(src.to(device=p.device).to(p.dtype), p.detach()):
+                    src = p.detach().float()
+                m = torch.nn.Parameter(src.to(device=p.device, dtype=torch.float32).clone(), requires_grad=True)
+                p._ll_master = m
+                self.masters.append(m)
+
+    def grads_to_masters(self):
+        for p, m in zip(self.params, self.masters):
+            if m is not p:
+                m.grad = None if p.grad is None else p.grad.detach().float()
+
+    def masters_to_params(self):
+        with torch.no_grad():
+            for p, m in zip(self.params, self.masters):
+                if m is not p:
+                    p.copy_(m)
+
+    def resync(self):
+        """After the bf16 parameters were overwritten from outside (a resumed adapter, a broadcast from rank 0): masters follow."""
+        with torch.no_grad():
+            for p, m in zip(self.params, self.masters):
+                if m is not p:
+                    m.copy_(p.float())
+
+
+def trained_value(p: torch.Tensor) -> torch.Tensor:
+    """The value to SAVE for a trainable parameter: its fp32 master when training kept one (MasterWeights), else the parameter."""
+    m = getattr(p, "_ll_master", None)
+    return (m if m is not None else p).detach()
 
 
 class _LoRAFunction(torch.autograd.Function):
@@ -271,10 +327,10 @@ def lora_state_dict(model: torch.nn.Module, modules_to_save: Sequence[str] = ())
     out: Dict[str, torch.Tensor] = {}
     for name, mod in model.named_modules():
         if isinstance(mod, LoRALinear):
-            out[f"base_model.model.{name}.lora_A.weight"] = mod.lora_a.detach().cpu().contiguous()
-            out[f"base_model.model.{name}.lora_B.weight"] = mod.lora_b.detach().cpu().contiguous()
+            out[f"base_model.model.{name}.lora_A.weight"] = trained_value(mod.lora_a).cpu().contiguous()
+            out[f"base_model.model.{name}.lora_B.weight"] = trained_value(mod.lora_b).cpu().contiguous()
         elif modules_to_save and name.split(".")[-1] in modules_to_save and getattr(mod, "weight", None) is not None:
-            out[f"base_model.model.{name}.weight"] = mod.weight.detach().cpu().clone().contiguous()
+            out[f"base_model.model.{name}.weight"] = trained_value(mod.weight).cpu().clone().contiguous()
     return out
 
 
@@ -327,6 +383,8 @@ def load_lora_adapter(model: torch.nn.Module, adapter_dir: str) -> int:
                 if tuple(tgt.shape) != tuple(v.shape):
                     raise ValueError(f"adapter tensor {k!r} has shape {tuple(v.shape)}, the model's adapter {tuple(tgt.shape)}")
                 tgt.copy_(v.to(device=tgt.device, dtype=tgt.dtype))
+                if v.dtype == torch.float32 and tgt.dtype != torch.float32:
+                    tgt._ll_resume_fp32 = v.clone()        # MasterWeights starts the fp32 twin from the saved value, not from its rounding
                 n += which == "lora_A"
             else:
                 tgt = params.get(name)
@@ -336,4 +394,6 @@ def load_lora_adapter(model: torch.nn.Module, adapter_dir: str) -> int:
                 if tgt is None:
                     raise KeyError(f"adapter tensor {k!r} has no parameter in the model")
                 tgt.copy_(v.to(device=tgt.device, dtype=tgt.dtype))
+                if v.dtype == torch.float32 and tgt.dtype != torch.float32:
+                    tgt._ll_resume_fp32 = v.clone()
     return n

@@ -151,7 +151,7 @@ def run_train(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> D
     import yaml
     from .distributed import shard_range
     from .modeling_llamole import GraphLLMForCausalMLM
-    from .sft import GraphSFTCollator, add_lora, embedding_module_names, enable_modules_to_save, load_lora_adapter, to_device
+    from .sft import GraphSFTCollator, MasterWeights, add_lora, embedding_module_names, enable_modules_to_save, load_lora_adapter, to_device
     with open(config_path) as f:
         cfg = yaml.safe_load(f) or {}
     cfg.update(overrides or {})
@@ -229,7 +229,9 @@ def run_train(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> D
         for p in params:
             dist.broadcast(p.data, src=0)
     lr = float(cfg.get("learning_rate", 1e-4))
-    opt = torch.optim.AdamW(params, lr=lr, weight_decay=float(cfg.get("weight_decay", 0.0)))
+    # every trainable parameter is optimised in fp32 (reference adapter.py:263-265 casts them; here: fp32 twins of the bf16 tensors)
+    masters = MasterWeights(params)
+    opt = torch.optim.AdamW(masters.masters, lr=lr, weight_decay=float(cfg.get("weight_decay", 0.0)))
     gen = torch.Generator().manual_seed(seed)
     log: List[Dict[str, Any]] = []
     logging_steps, save_steps = int(cfg.get("logging_steps", 10)), int(cfg.get("save_steps", 0))
@@ -245,6 +247,8 @@ def run_train(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> D
         for g in opt.param_groups:
             g["lr"] = cosine_lr(step, total, warmup, lr) if cfg.get("lr_scheduler_type", "cosine") == "cosine" else lr
         opt.zero_grad(set_to_none=True)
+        for p in params:
+            p.grad = None
         agg: Dict[str, float] = {}
         for micro in range(accum):
             if len(order) < bs * world:          # a new epoch: the same permutation on every rank (same seed), each takes its shard
@@ -256,9 +260,11 @@ def run_train(config_path: str, overrides: Optional[Dict[str, Any]] = None) -> D
             out = _micro_step(model, batch, params, accum, reduce=last)
             for k, v in out.items():
                 agg[k] = agg.get(k, 0.0) + v / accum
+        masters.grads_to_masters()
         if cfg.get("max_grad_norm", 1.0):
-            torch.nn.utils.clip_grad_norm_(params, float(cfg.get("max_grad_norm", 1.0)))
+            torch.nn.utils.clip_grad_norm_(masters.masters, float(cfg.get("max_grad_norm", 1.0)))
         opt.step()
+        masters.masters_to_params()
         agg.update(step=step + 1, lr=opt.param_groups[0]["lr"], elapsed_s=time.perf_counter() - t0)
         log.append(agg)
         if rank == 0 and ((step + 1) % logging_steps == 0 or step + 1 == total):
