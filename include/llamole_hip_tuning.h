@@ -1,9 +1,11 @@
-/* libllamole_hip -- tuning, timing and test hooks.  NOT part of the drop-in boundary.
+/* libllamole_hip_tuning -- tuning, timing and test hooks.  NOT part of the drop-in boundary, NOT in the product library.
  *
- * include/llamole_hip.h declares what a maintainer of the reference binds (engines, forward passes, samplers).  Everything in THIS
- * file is process-global A/B switches, micro-benchmarks (HIP events around one kernel) and single-kernel test entry points used by
- * tests/, tools/ and bench.py's roofline objects.  Nothing here changes results beyond documented summation-order effects, and no
- * product code path depends on a non-default setting.  The symbols are exported by the same shared library.
+ * include/llamole_hip.h declares what a maintainer of the reference binds (engines, forward passes, samplers); libllamole_hip.so exports
+ * exactly that.  Everything in THIS file -- process-global A/B switches, micro-benchmarks (HIP events around one kernel), probes and
+ * single-kernel test entry points used by tests/, tools/ and bench.py's roofline objects -- is compiled only with -DLL_TUNING=1, into
+ * libllamole_hip_tuning.so (llamole_amd/build.py builds both from the same sources; LLAMOLE_TUNING=1 makes llamole_amd/_lib.py load the
+ * tuning build).  Nothing here changes results beyond documented summation-order effects, and no product code path calls any of it
+ * (tests/test_abi_cpu.py checks the exports of the product library and the product package's sources).
  */
 #ifndef LLAMOLE_HIP_TUNING_H
 #define LLAMOLE_HIP_TUNING_H

@@ -11,6 +11,14 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libllamole_hip.so")
+TUNING_LIB_PATH = os.path.join(_HERE, "libllamole_hip_tuning.so")
+
+
+def tuning_build() -> bool:
+    """LLAMOLE_TUNING=1 (tests/conftest.py, tools/, bench.py): this process runs the LL_TUNING=1 build, which adds the A/B switches,
+    micro-benchmarks and probes of include/llamole_hip_tuning.h to the same kernels and entry points.  Everything else -- `import
+    llamole_amd`, main.py eval / train -- loads the product library, which exports none of them."""
+    return os.environ.get("LLAMOLE_TUNING") == "1"
 
 LL_F32, LL_BF16 = 0, 1
 
@@ -32,17 +40,12 @@ class LLGinConfig(C.Structure):
 
 _P, _I, _I64, _U64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
 
-# name -> (restype, argtypes); mirrors include/llamole_hip.h one to one
+# name -> (restype, argtypes); mirrors include/llamole_hip.h one to one (the product library exports exactly these)
 SIGNATURES = {
     "ll_version": (_I, []),
     "ll_last_error": (C.c_char_p, []),
     "ll_linear": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ll_linear_splitk_bf16": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
-    "ll_host_launch_probe": (_I, [_I, _I, C.POINTER(_F)]),
-    "ll_gemm_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
-    "ll_linear_cfg": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "ll_launch_bench": (_I, [_I, _I, _I, C.POINTER(_F)]),
-    "ll_launch_bench_set_buffers": (_I, [_P, _P]),
     "ll_dit_param_count": (_I, [C.POINTER(LLDitConfig)]),
     "ll_dit_param_info": (_I, [C.POINTER(LLDitConfig), _I, C.c_char_p, _I, C.POINTER(_I64), C.POINTER(_I64)]),
     "ll_dit_arena_elems": (_I64, [C.POINTER(LLDitConfig)]),
@@ -67,7 +70,6 @@ SIGNATURES = {
     "ll_graph_csr": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ll_gin_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "ll_softmax_topk": (_I, [_P, _I, _I, _I, _P, _P, _P]),
-    "ll_set_topk_single": (_I, [_I]),
     "ll_cost_mlp": (_I, [_P, _P, _I, _P, _P]),
     "ll_rmsnorm_bf16": (_I, [_P, _P, _P, _I, _I, _F, _P]),
     "ll_rope_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), _P]),
@@ -77,6 +79,29 @@ SIGNATURES = {
     "ll_gemv_fused_bf16": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "ll_decode_attn_rope_bf16": (_I, [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _I, _F, _P]),
     "ll_decode_prologue": (_I, [_P, _P, _F, _P, _I64, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ll_dit_set_overlap": (_I, [_P, _I]),
+    "ll_dit_set_option": (_I, [_P, _I, _I]),
+    "ll_linear_rows16_bf16": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "ll_rows64_packed_elems": (_I64, [_I, _I]),
+    "ll_rows64_pack_bf16": (_I, [_P, _I, _I, _I, _P, _P]),
+    "ll_linear_rows64_bf16": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _F, _P, _P, _I, _P, _P, _I64, _P]),
+    "ll_rows64_ssq_chunks": (_I, [_I]),
+    "ll_rows64_prenorm_bf16": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _P]),
+    "ll_linear_rows64_workspace_bytes": (_I64, [_I, _I]),
+    "ll_gin_forward_train": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "ll_gin_backward_c": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "ll_sample_token_bf16": (_I, [_P, _I64, _I, _I, _F, _F, _I, _P, _P, _I, _I64, _P, _P, _P, _I64, _I, _P, _P, _P, _I, _P, _P]),
+    "ll_sample_token_topk_bf16": (_I, [_P, _I64, _I, _I, _F, _F, _I, _I, _P, _P, _I, _I64, _P, _P, _P, _I64, _I, _P, _P, _P, _I, _P, _P]),
+}
+
+# include/llamole_hip_tuning.h: exported by libllamole_hip_tuning.so only (the LL_TUNING=1 build of the same sources)
+TUNING_SIGNATURES = {
+    "ll_host_launch_probe": (_I, [_I, _I, C.POINTER(_F)]),
+    "ll_gemm_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
+    "ll_linear_cfg": (_I, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ll_launch_bench": (_I, [_I, _I, _I, C.POINTER(_F)]),
+    "ll_launch_bench_set_buffers": (_I, [_P, _P]),
+    "ll_set_topk_single": (_I, [_I]),
     "ll_gemv_fused_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "ll_set_gemv_nt": (_I, [_I]),
     "ll_set_gemv_stage": (_I, [_I]),
@@ -89,40 +114,29 @@ SIGNATURES = {
     "ll_set_attn_waves": (_I, [_I]),
     "ll_debug_check_guards": (_I, []),
     "ll_debug_guard_selftest": (_I, []),
-    "ll_dit_set_overlap": (_I, [_P, _I]),
-    "ll_dit_set_option": (_I, [_P, _I, _I]),
     "ll_philox_probe": (_I, [_P, _P, _I, _P]),
     "ll_dit_noise_probe": (_I, [_U64, _I, _I, _I, _P, _P, _P]),
     "ll_dit_class_probe": (_I, [_P, _I]),
     "ll_dit_class_probe_read": (_I, [_P, C.POINTER(_F), C.POINTER(_I)]),
-    "ll_linear_rows16_bf16": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "ll_set_rows16_geometry": (_I, [_I, _I, _I]),
     "ll_rows16_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
-    "ll_rows64_packed_elems": (_I64, [_I, _I]),
-    "ll_rows64_pack_bf16": (_I, [_P, _I, _I, _I, _P, _P]),
-    "ll_linear_rows64_bf16": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _F, _P, _P, _I, _P, _P, _I64, _P]),
-    "ll_rows64_ssq_chunks": (_I, [_I]),
-    "ll_rows64_prenorm_bf16": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _P]),
-    "ll_linear_rows64_workspace_bytes": (_I64, [_I, _I]),
     "ll_set_rows64_ksplit": (_I, [_I]),
     "ll_rows64_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
-    "ll_gin_forward_train": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
-    "ll_gin_backward_c": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
-    "ll_sample_token_bf16": (_I, [_P, _I64, _I, _I, _F, _F, _I, _P, _P, _I, _I64, _P, _P, _P, _I64, _I, _P, _P, _P, _I, _P, _P]),
-    "ll_sample_token_topk_bf16": (_I, [_P, _I64, _I, _I, _F, _F, _I, _I, _P, _P, _I, _I64, _P, _P, _P, _I64, _I, _P, _P, _P, _I, _P, _P]),
 }
 
 _lib = None
 
 
 def load():
-    """Load the shared library (once).  Raises if it has not been built."""
+    """Load the shared library (once): the product build, or the tuning build under LLAMOLE_TUNING=1.  Raises if it has not been built."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    tuning = tuning_build()
+    path = TUNING_LIB_PATH if tuning else LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -m llamole_amd.build` "
+            f"{path} is missing: build it with `python -m llamole_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the graph hot path.")
     # PyTorch-ROCm ships its own HIP runtime; the one that is loaded FIRST in a process is the one that can open the device
     # (build() followed by smoke() in one process loaded this library before torch had touched HIP, and every hipMalloc of the
@@ -134,11 +148,13 @@ def load():
             torch.cuda.init()
     except ImportError:
         pass
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    lib = C.CDLL(path)
+    table = dict(SIGNATURES, **TUNING_SIGNATURES) if tuning else SIGNATURES
+    for name, (res, args) in table.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    lib._ll_path = path
     _lib = lib
     return lib
 

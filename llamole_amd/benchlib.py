@@ -155,6 +155,79 @@ def time_dominant_kernel(args, device):
     return ms.value, nbytes, flops, name, key
 
 
+def token_roofline(args, orch, prompt, mask, gen_kw):
+    """The WHOLE decode token against the HBM roofline (the line's `roofline` is its best kernel, not the token):
+    bytes = every weight matrix a decode step streams (q|k|v, o_proj, gate|up, down_proj of every layer + lm_head; the KV cache and the
+    activations are not counted), time = device time per token of one more `generate` on the idle GPU after the timed region, from HIP
+    events recorded on the LLM's stream at the decode loop's marks (first token sampled -> decode loop done).  Next to it every Linear of
+    the step timed back to back over distinct weights (HIP events; the same micro-benchmark entry points as `roofline`), at this run's
+    row count, so that the share the weight stream does NOT explain -- attention, sampler, the launch chain -- is visible."""
+    import ctypes as C
+    from llamole_amd import _lib, _trace
+    from llamole_amd.e2e import LLM_CONFIGS
+    if args.llm_linear != "hip" or args.llm_decode == "hf" or getattr(orch, "decoder", None) is None:
+        return None
+    lib = _lib.load()
+    spec = LLM_CONFIGS[args.llm]
+    H, I, V, L = spec["hidden_size"], spec["intermediate_size"], spec["vocab_size"], spec["num_hidden_layers"]
+    D = H // spec["num_attention_heads"]
+    nq, nkv = spec["num_attention_heads"] * D, spec["num_key_value_heads"] * D
+    M = int(prompt.shape[0])
+    shapes = {"q|k|v": (nq + 2 * nkv, H, 0), "o_proj": (H, nq, 1), "gate|up": (I, H, 2), "down_proj": (H, I, 1), "lm_head": (V, H, 0)}
+    ms = C.c_float()
+    per = {}
+    fused = bool(args.llm_fuse and args.llm_layer_fuse)
+    for name, (N, K, epi) in shapes.items():
+        rows = 2 * N if epi == 2 else N
+        nbytes = rows * K * 2
+        nw = max(2, int(600e6 // nbytes))
+        norm = 1 if name in ("q|k|v", "gate|up") else 0           # RMSNorm prologue of the five-launch layer
+        try:
+            if fused and 16 < M <= 64 and K % 32 == 0 and (epi != 2 or N % 16 == 0):
+                # seven-launch layer: q|k|v / gate|up finish a split RMSNorm (row scale), o_proj / down_proj produce the next one (+ slab sum)
+                flag = 0 if name == "lm_head" else (2 if norm else 1)
+                _lib.check(lib.ll_rows64_bench(M, N, K, epi, flag, 4 * nw, nw, C.byref(ms)), "ll_rows64_bench")
+                kern = "rows64_kernel" + (" + rows64_reduce_kernel" if flag == 1 else "")
+            elif fused and 3 <= M <= 16 and K % 32 == 0:
+                _lib.check(lib.ll_rows16_bench(M, N, K, epi, norm if name != "lm_head" else 0, 4 * nw, nw, C.byref(ms)), "ll_rows16_bench")
+                kern = "rows16_kernel"
+            elif fused and M <= 4 and name != "lm_head":
+                _lib.check(lib.ll_gemv_fused_bench(M, N, K, epi, norm, 1, 4 * nw, nw, C.byref(ms)), "ll_gemv_fused_bench")
+                kern = "gemv_fused_kernel / gemv_stage_kernel"
+            else:
+                _lib.check(lib.ll_gemm_bench(M, rows, K, -1, 1, 0, 4 * nw, nw, C.byref(ms)), "ll_gemm_bench")
+                kern = "ll_linear dispatch"
+        except RuntimeError as e:       # a shape the micro-benchmark refuses: the token figure below does not depend on it
+            per[name] = {"error": str(e)}
+            continue
+        per[name] = {"kernel": kern, "bytes": nbytes, "ms": ms.value, "gbps": nbytes / (ms.value * 1e-3) / 1e9,
+                     "frac": nbytes / (ms.value * 1e-3) / (HBM_PEAK_GBS * 1e9), "launches_per_token": 1 if name == "lm_head" else L}
+    bytes_token = sum(v["bytes"] * v["launches_per_token"] for v in per.values() if "bytes" in v)
+    lin_ms = sum(v["ms"] * v["launches_per_token"] for v in per.values() if "ms" in v)
+    # one more generation on the idle GPU with a HIP event at every mark of the decode loop
+    torch.cuda.synchronize()
+    _trace.start(device=True)
+    try:
+        torch.manual_seed(4242)
+        orch._llm_generate(inputs=prompt, attention_mask=mask, **gen_kw)
+        torch.cuda.synchronize()
+    finally:
+        ev = _trace.stop()
+    dev = ev[1] if isinstance(ev, tuple) else []
+    first = next((e for n, e in dev if n == "generate: first token sampled"), None)
+    done = next((e for n, e in dev if n == "generate: decode loop done"), None)
+    n_new = int(getattr(orch.decoder, "_last", {}).get("n_new", 0) or 0)
+    if first is None or done is None or n_new < 2:
+        return {"per_linear": per, "bytes_per_token": bytes_token, "note": "the decode loop's marks were not recorded"}
+    token_ms = first.elapsed_time(done) / (n_new - 1)
+    return {"bound": "hbm", "bytes_per_token": bytes_token, "token_ms": token_ms, "tokens_timed": n_new - 1, "rows": M,
+            "achieved": bytes_token / (token_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": bytes_token / (token_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
+            "timed": "HIP events on the LLM stream around the decode loop of one generation on the idle GPU after the timed region",
+            "linears_ms_per_token_back_to_back": lin_ms, "not_weight_stream_ms_per_token": token_ms - lin_ms,
+            "per_linear": per}
+
+
 def time_graphdit_kernel(args, batch: int):
     """The dominant kernel of the GraphDiT step at `batch` graphs: the block-MLP fc1 GEMM at M = 2 * batch * N token rows, on whatever
     kernel the production dispatch picks for that M (32-33 % of the step's GPU time in profiles/r*_graphdit_b{1,8}_kernel_stats.csv),

@@ -11,6 +11,13 @@
 #include "../../include/llamole_hip.h"
 #include "../../include/llamole_hip_tuning.h"
 
+// LL_TUNING=1 (libllamole_hip_tuning.so: tests, tools, bench.py) also compiles the entry points of include/llamole_hip_tuning.h --
+// process-global A/B switches, micro-benchmarks, probes; the product library (libllamole_hip.so, LL_TUNING=0) exports none of them.
+// Kernels and product entry points are the same translation units in both builds.
+#ifndef LL_TUNING
+#define LL_TUNING 0
+#endif
+
 namespace ll {
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits

@@ -1788,6 +1788,7 @@ static const PipeCfg g_pipe_cfgs[] = {
 
 // Times `iters` back-to-back launches of one pipelined-GEMM configuration (HIP events on a private stream),
 // cycling over `nweights` distinct weight matrices so that the weights stream from HBM as in the sampler.
+#if LL_TUNING
 extern "C" int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f32, int iters, int nweights, float *ms) {
     using namespace ll;
     const int ncfg = (int)(sizeof(g_pipe_cfgs) / sizeof(g_pipe_cfgs[0]));
@@ -1839,9 +1840,11 @@ extern "C" int ll_gemm_bench(int M, int N, int K, int cfg, int splits, int out_f
     LL_HIP(he);
     return LL_OK;
 }
+#endif
 
 // One specific configuration of the table above on caller-provided operands (tests: every kernel variant against PyTorch).
 // splits > 1: C receives `splits` raw f32 slabs of M x ldc (slab stride M * ldc), bias / epilogue skipped.
+#if LL_TUNING
 extern "C" int ll_linear_cfg(int cfg, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc, int M, int N,
                              int K, int splits, int epi, int out_f32, void *stream) {
     using namespace ll;
@@ -1853,6 +1856,7 @@ extern "C" int ll_linear_cfg(int cfg, const void *A, int lda, const void *W, int
     LL_LAUNCH_CHECK();
     return LL_OK;
 }
+#endif
 
 namespace ll {
 __global__ void lb_empty_kernel() {}
@@ -1891,6 +1895,7 @@ static void *g_probe_a = nullptr, *g_probe_b = nullptr;
 // Host cost of enqueueing launches (wall time of the issuing loop, no synchronisation inside): kind 0 = empty kernel, 1 = two-argument
 // kernel, 2 = the whole linear_launch path onto gemm_m64_kernel ([64 x 256] x [16 x 256]^T bf16, one workgroup), 3 = the same onto the ring
 // ([200 x 256] x [64 x 256]^T).  n <= 8000 launches (below the queue depth).
+#if LL_TUNING
 extern "C" int ll_host_launch_probe(int kind, int n, float *us_per_launch) {
     using namespace ll;
     LL_CHECK(us_per_launch && n > 0 && n <= 8000 && kind >= 0 && kind <= 3, "bad argument");
@@ -1920,12 +1925,16 @@ extern "C" int ll_host_launch_probe(int kind, int n, float *us_per_launch) {
     (void)hipFree(b);
     return LL_OK;
 }
+#endif
 
+#if LL_TUNING
 extern "C" int ll_launch_bench_set_buffers(void *a, void *b) {
     g_probe_a = a;
     g_probe_b = b;
     return LL_OK;
 }
+#endif
+#if LL_TUNING
 extern "C" int ll_launch_bench(int kind, int n, int graph, float *us) {
     using namespace ll;
     LL_CHECK(us && n > 0 && kind >= 0, "bad argument");
@@ -2004,6 +2013,7 @@ extern "C" int ll_launch_bench(int kind, int n, int graph, float *us) {
     else { (void)hipFree(a); (void)hipFree(b); }
     return LL_OK;
 }
+#endif
 
 namespace ll {
 // out[m][n] = epi(sum_z slabs[z][m][n] + bias[n]) (+ residual) -> bf16; slabs summed in order (deterministic)
@@ -2032,30 +2042,38 @@ extern "C" int ll_linear_splitk_bf16(const void *A, int lda, const void *W, int 
     return LL_OK;
 }
 
+#if LL_TUNING
 extern "C" int ll_set_gemm_krot(int krot) {
     const int old = ll::g_gemm_krot;
     ll::g_gemm_krot = krot < 0 ? 0 : krot;
     return old;
 }
+#endif
 
+#if LL_TUNING
 extern "C" int ll_set_m128_panel(int on) {      // 0 = off, 1 = up to 224 rows (default), 2 = up to 256 rows
     const int old = ll::g_m128_panel ? (ll::g_panel_max_rows > 224 ? 2 : 1) : 0;
     ll::g_m128_panel = on ? 1 : 0;
     if (on) ll::g_panel_max_rows = on >= 2 ? 256 : 224;
     return old;
 }
+#endif
 
+#if LL_TUNING
 extern "C" int ll_set_m64_packed(int on) {
     const int old = ll::g_use_packed;
     ll::g_use_packed = on ? 1 : 0;
     return old;
 }
+#endif
 
+#if LL_TUNING
 extern "C" int ll_set_m64_waves(int waves) {
     const int old = ll::g_m64_waves;
     if (waves == 4 || waves == 8) ll::g_m64_waves = waves;
     return old;
 }
+#endif
 
 extern "C" int ll_linear(int dtype, const void *A, int lda, const void *W, int ldw, const float *bias, void *C, int ldc,
                          int M, int N, int K, int epi, int out_f32, void *stream) {

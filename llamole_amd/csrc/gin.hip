@@ -1975,11 +1975,13 @@ int ll_softmax_topk(const float *logits, int rows, int out_dim, int k, float *pr
     return LL_OK;
 }
 
+#if LL_TUNING
 int ll_set_topk_single(int on) {
     const int old = g_topk_single;
     g_topk_single = on ? 1 : 0;
     return old;
 }
+#endif
 
 int ll_cost_mlp(const float *weights, const float *fps, int n, float *out, void *stream) {
     LL_CHECK(weights && fps && out && n >= 1, "bad argument");

@@ -1132,20 +1132,25 @@ static __global__ void noise_probe_kernel(unsigned long long seed, int s, int B,
     }
 }
 
+#if LL_TUNING
 int ll_philox_probe(const uint32_t *ctr_key, uint32_t *out, int n, void *stream) {
     LL_CHECK(ctr_key && out && n >= 1, "ll_philox_probe: bad argument");
     hipLaunchKernelGGL(philox_probe_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ctr_key, out, n);
     LL_LAUNCH_CHECK();
     return LL_OK;
 }
+#endif
 
+#if LL_TUNING
 int ll_dit_noise_probe(uint64_t seed, int s, int B, int N, float *qx, float *qe, void *stream) {
     LL_CHECK(qx && qe && B >= 1 && N >= 1 && s >= 0 && (int64_t)B * N * N < (1ll << 31), "ll_dit_noise_probe: bad argument");
     hipLaunchKernelGGL(noise_probe_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (unsigned long long)seed, s, B, N, qx, qe);
     LL_LAUNCH_CHECK();
     return LL_OK;
 }
+#endif
 
+#if LL_TUNING
 int ll_dit_class_probe(void *handle, int cls) {
     DitEngine *e = (DitEngine *)handle;
     LL_CHECK(e, "ll_dit_class_probe: null handle");
@@ -1164,7 +1169,9 @@ int ll_dit_class_probe(void *handle, int cls) {
     }
     return LL_OK;
 }
+#endif
 
+#if LL_TUNING
 int ll_dit_class_probe_read(void *handle, float *total_us, int *launches) {
     DitEngine *e = (DitEngine *)handle;
     LL_CHECK(e && total_us && launches, "ll_dit_class_probe_read: null argument");
@@ -1180,7 +1187,9 @@ int ll_dit_class_probe_read(void *handle, float *total_us, int *launches) {
     e->tev_n = 0;
     return LL_OK;
 }
+#endif
 
+#if LL_TUNING
 int ll_debug_check_guards(void) {
     if (!ll::debug_poison()) return 0;
     if (hipDeviceSynchronize() != hipSuccess) return -1;
@@ -1188,7 +1197,9 @@ int ll_debug_check_guards(void) {
     for (const auto &b : ll::g_guarded) bad += ll::debug_guard_damage(b.first, b.second, "ll_debug_check_guards");
     return bad;
 }
+#endif
 
+#if LL_TUNING
 int ll_debug_guard_selftest(void) {
     if (!ll::debug_poison()) return -1;
     void *p = nullptr;
@@ -1200,24 +1211,31 @@ int ll_debug_guard_selftest(void) {
     (void)hipFree(p);
     return (clean == 0 && after == 1) ? 1 : 0;
 }
+#endif
 
+#if LL_TUNING
 int ll_set_attn_waves(int waves) {
     const int old = g_attn_waves;
     if (waves == 1 || waves == 2 || waves == 4) g_attn_waves = waves;
     return old;
 }
+#endif
 
+#if LL_TUNING
 int ll_set_stage_mod(int on) {
     const int old = g_stage_mod;
     g_stage_mod = on ? 1 : 0;
     return old;
 }
+#endif
 
+#if LL_TUNING
 int ll_set_lnmod_multiwave(int on) {
     const int old = g_lnmod_multiwave;
     g_lnmod_multiwave = on ? 1 : 0;
     return old;
 }
+#endif
 
 int ll_dit_last_run_ms(void *handle, float *ms, int *steps) {
     DitEngine *e = (DitEngine *)handle;

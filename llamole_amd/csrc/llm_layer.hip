@@ -688,6 +688,7 @@ int ll_decode_prologue(const int64_t *position_ids, const float *inv_freq, float
 
 // Times ll_gemv_fused_bf16 on synthetic operands, cycling through `nweights` distinct weight matrices (defeats the
 // 256 MiB Infinity Cache).  norm != 0 adds the RMSNorm prologue; nt selects non-temporal weight loads.
+#if LL_TUNING
 int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iters, int nweights, float *ms) {
     LL_CHECK(ms && iters > 0 && nweights > 0 && M >= 1 && M <= 4, "bad argument");
     const int rowsW = epi == GEMV_SILU_MUL ? 2 * N : N;
@@ -730,17 +731,22 @@ int ll_gemv_fused_bench(int M, int N, int K, int epi, int norm, int nt, int iter
     LL_HIP(he);
     return LL_OK;
 }
+#endif
 
+#if LL_TUNING
 int ll_set_gemv_stage(int on) {
     const int old = g_gemv_stage;
     g_gemv_stage = on ? 1 : 0;
     return old;
 }
+#endif
 
+#if LL_TUNING
 int ll_set_gemv_nt(int on) {
     const int old = g_gemv_nt;
     g_gemv_nt = on ? 1 : 0;
     return old;
 }
+#endif
 
 }  // extern "C"

@@ -278,6 +278,7 @@ int ll_linear_rows16_bf16(const void *x, int ldx, const void *W, int ldw, const 
     return linear_rows16_launch(x, ldx, W, ldw, bias, norm_w, eps, residual, ldr, out, ldc, M, N, K, epi, 0, (hipStream_t)stream);
 }
 
+#if LL_TUNING
 int ll_set_rows16_geometry(int seg, int waves, int ksplit) {
     const int old = g_rows16_geom;
     const bool ok = (seg == 128 || seg == 256 || seg == 512) && (waves == 4 || waves == 8) && ksplit >= 1 && ksplit <= waves &&
@@ -285,8 +286,10 @@ int ll_set_rows16_geometry(int seg, int waves, int ksplit) {
     g_rows16_geom = ok ? (seg << 16 | waves << 8 | ksplit) : 0;
     return old;
 }
+#endif
 
 // Times ll_linear_rows16_bf16 on synthetic operands over `nweights` distinct weight matrices (defeats the Infinity Cache).
+#if LL_TUNING
 int ll_rows16_bench(int M, int N, int K, int epi, int norm, int iters, int nweights, float *ms) {
     LL_CHECK(ms && iters > 0 && nweights > 0 && M >= 1 && M <= 16, "bad argument");
     const int out_f32 = (epi & 0x100) ? 1 : 0;      // epi | 0x100: f32 output (the GIN template head), plain epilogue only
@@ -327,5 +330,6 @@ int ll_rows16_bench(int M, int N, int K, int epi, int norm, int iters, int nweig
     LL_HIP(he);
     return LL_OK;
 }
+#endif
 
 }  // extern "C"

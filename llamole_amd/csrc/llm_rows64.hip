@@ -471,14 +471,17 @@ int ll_rows64_prenorm_bf16(const void *x, int ldx, const void *norm_w, void *sca
 
 int64_t ll_linear_rows64_workspace_bytes(int M, int N) { return (int64_t)8 * (M > 0 ? M : 0) * (N > 0 ? N : 0) * 4; }
 
+#if LL_TUNING
 int ll_set_rows64_ksplit(int ksg) {
     const int old = g_rows64_ksg;
     g_rows64_ksg = (ksg >= 1 && ksg <= 8) ? ksg : 0;
     return old;
 }
+#endif
 
 // Times ll_linear_rows64_bf16 on synthetic operands over `nweights` distinct packed weight matrices (defeats the Infinity Cache);
 // norm & 1: with the output pre-norm (two launches); norm & 2: with the input row scale.
+#if LL_TUNING
 int ll_rows64_bench(int M, int N, int K, int epi, int norm, int iters, int nweights, float *ms) {
     LL_CHECK(ms && iters > 0 && nweights > 0 && M >= 1 && M <= 64, "bad argument");
     const int rowsW = epi == R64_SILU_MUL ? 2 * N : N;
@@ -528,5 +531,6 @@ int ll_rows64_bench(int M, int N, int K, int epi, int norm, int iters, int nweig
     LL_HIP(he);
     return LL_OK;
 }
+#endif
 
 }  // extern "C"

@@ -229,6 +229,7 @@ def build_e2e_step(args, graph_decoder, device, props, rank: int):
         return out
 
     step_fn.finish = finish
+    step_fn.prompt, step_fn.mask, step_fn.gen_kw = prompt, mask, kw
     step_fn.dit_ms = dit_ms
     step_fn.pipeline = pipeline
     step_fn.group = group

@@ -130,7 +130,12 @@ class GraphedDecoder:
             return fn(*values)
         if st is None:
             if len(self._side_graphs) >= self.max_side_graphs:      # shapes that do not repeat (A* expansion prompts) stay eager
-                self._side_graphs.pop(next(iter(self._side_graphs)))
+                # evict a shape that was only SEEN, oldest first; captured graphs and "eager" tombstones stay (dropping a live graph means
+                # a re-capture -- a device-wide synchronise inside the pipelined step -- and a forgotten tombstone retries a failed capture)
+                victim = next((k for k, v in self._side_graphs.items() if v == "seen"), None)
+                if victim is None:
+                    return fn(*values)                              # table full of live graphs / tombstones: this shape runs eager
+                self._side_graphs.pop(victim)
             self._side_graphs[key] = "seen"
             return fn(*values)
         if st == "seen":

@@ -457,10 +457,14 @@ class GraphLLMForCausalMLM(nn.Module):
             graph_lists.append((ctx_graphs.to_data_list() if with_context else []) + [product])
             products.append(product)
             live.append(i)
+        shard = self._expansion_shard()
         if not live:
+            # a rank whose replicated search diverged to zero requests must still meet its peers in the agreement check: they would
+            # otherwise block in its all-reduce
+            if shard is not None and hasattr(self.graph_predictor, "topk_templates_batch"):
+                self._assert_ranks_agree(0, shard[2], "expansion requests of a lock-step round")
             return results
         smiles = [requests[i]["product_smiles"] for i in live]
-        shard = self._expansion_shard()
         if shard is not None and hasattr(self.graph_predictor, "topk_templates_batch"):
             # Expansion-level split (second alternative; north_star: "RCCL all-gather of candidate scores"): the host A* is
             # replicated, every rank sees the same requests; rank r decodes and scores requests r, r + world, ..., then ONE all-gather of
@@ -686,9 +690,11 @@ class GraphLLMForCausalMLM(nn.Module):
         prompts open with go through the LLM once per call (``value_prefix_min``)."""
         n = len(items)
         costs = [0.0] * n
-        if n == 0:
-            return costs
         shard = self._expansion_shard()
+        if n == 0:
+            if shard is not None and not getattr(self, "_in_value_shard", False) and not self._language_cost_is_constant():
+                self._assert_ranks_agree(0, shard[2], "value prompts of a lock-step round")      # see expand_batch: no early return past the check
+            return costs
         if shard is not None and not getattr(self, "_in_value_shard", False) and not self._language_cost_is_constant():
             # the round's value prompts split over the ranks (item i on rank i % world), ONE all-gather of the float64 costs
             rank, world, group = shard

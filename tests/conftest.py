@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the tests drive A/B switches, micro-benchmarks and probes: they (and every subprocess they start) run the LL_TUNING=1 build of the
+# library (libllamole_hip_tuning.so; llamole_amd/_lib.py).  tests/test_abi_cpu.py checks the product library on its own.
+os.environ.setdefault("LLAMOLE_TUNING", "1")
 
 
 def pytest_configure(config):

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def lib():
     from llamole_amd.build import build
     build(verbose=False)
-    return _lib.load()
+    return _lib.load()          # tests/conftest.py selects the LL_TUNING=1 build
 
 
 def _declared_in(header):
@@ -45,11 +45,32 @@ def test_tuning_hooks_are_fenced_off_the_product_header():
 
 
 def test_every_declared_symbol_is_exported(lib):
-    names = _declared_functions()
-    assert len(names) >= 25
-    for n in names:
-        assert hasattr(lib, n), f"{n} declared in llamole_hip.h but not exported"
-    assert sorted(_lib.SIGNATURES) == names, "ctypes signature table out of sync with the header"
+    """The tuning build exports both headers; the PRODUCT library exports exactly include/llamole_hip.h and none of the switches, benchmarks
+    or probes -- checked on the file itself, whatever build this process runs."""
+    import ctypes
+    product, tuning = _declared_in("llamole_hip.h"), _declared_in("llamole_hip_tuning.h")
+    assert len(product) >= 25
+    for n in product + tuning:
+        assert hasattr(lib, n), f"{n} declared but not exported by the tuning build"
+    assert sorted(_lib.SIGNATURES) == product, "ctypes signature table out of sync with include/llamole_hip.h"
+    assert sorted(_lib.TUNING_SIGNATURES) == tuning, "ctypes signature table out of sync with include/llamole_hip_tuning.h"
+    prod = ctypes.CDLL(_lib.LIB_PATH)
+    for n in product:
+        assert hasattr(prod, n), f"{n} declared in llamole_hip.h but not exported by the product library"
+    leaked = [n for n in tuning if hasattr(prod, n)]
+    assert not leaked, f"the product library exports tuning hooks: {leaked}"
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r"\b(ll_[a-z0-9_]+)$", syms, flags=re.M)))
+    assert exported == product, (set(exported) ^ set(product))
+
+
+def test_product_library_is_what_a_plain_import_loads(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.delenv("LLAMOLE_TUNING", raising=False)
+    plain = _lib.load()
+    assert plain._ll_path == _lib.LIB_PATH and not hasattr(plain, "ll_set_rows64_ksplit") and hasattr(plain, "ll_linear_rows64_bf16")
+    monkeypatch.setattr(_lib, "_lib", None)
 
 
 def test_version_and_error_string(lib):
@@ -105,6 +126,7 @@ def test_gin_layout_matches_reference_state_dict(lib, kind):
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "TUNING_LIB_PATH", str(tmp_path / "nope_tuning.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
 

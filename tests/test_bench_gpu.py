@@ -87,6 +87,9 @@ def test_bench_total_prompts_picks_the_whole_share_as_one_batch():
     assert c["per_rank_batch"] == 48 and c["per_rank_batches_per_step"] == 1 and "min(share" in c["per_rank_batch_source"]
     assert "BEST single-GPU configuration" in c["scaling_baseline"]
     assert "rows64_kernel" in d["roofline"]["kernel"] and d["roofline"]["bound"] == "hbm"
+    rt = d["roofline_token"]        # the whole decode token against the weight stream, with the per-Linear fractions of this run
+    assert 0 < rt["frac"] < 1 and rt["rows"] == 48 and rt["tokens_timed"] == 7 and set(rt["per_linear"]) == {"q|k|v", "o_proj", "gate|up", "down_proj", "lm_head"}
+    assert all("rows64_kernel" in v["kernel"] for v in rt["per_linear"].values()) and d["library"] == "libllamole_hip_tuning.so"
     assert c["llm_fused_elementwise"]["decoder_layers_5_launches"] == 2
     # 128 prompts on one rank: two batches of 64; --batch still wins when given
     d = _line(_run(["--total-prompts", "128", "--steps", "1"] + E2E_TINY, {}, workload="e2e"))

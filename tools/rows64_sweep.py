@@ -5,6 +5,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("LLAMOLE_TUNING", "1")      # micro-benchmark entry points: the LL_TUNING=1 build
 from llamole_amd import _lib
 
 lib = _lib.load()
