@@ -61,7 +61,7 @@ int ll_linear_splitk_bf16(const void *A, int lda, const void *W, int ldw, const 
 /* Any sizes the reference Transformer constructs are valid (transformer.py:24-37): hidden, heads (dividing hidden) and mlp_hidden need
  * not be multiples of anything -- the engine zero-pads its internal copy of the weights to row pitches of 64 and a head pitch of 32 and
  * takes the true widths for every row statistic; the arena layout below is the checkpoint's own.  Bounds (LL_EINVAL beyond them):
- * hidden <= 2048, hidden / heads <= 128, max_nodes <= 64. */
+ * hidden <= 2048, hidden / heads <= 128, max_nodes <= 128 (65..128 nodes: two wavefronts per row of bond partners, a 128-row attention tile). */
 typedef struct LLDitConfig {
     int hidden;        /* H            (config.yaml hidden_size)      */
     int depth;         /* L            (depth)                        */

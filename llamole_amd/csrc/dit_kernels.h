@@ -60,22 +60,26 @@ __global__ __launch_bounds__(256) void embed_kernel(const int8_t *__restrict__ X
     // H = row pitch (the engine's padded width, a multiple of 64), Ht = the checkpoint's hidden_size: columns [Ht, H) of W_x^T and of
     // the LayerNorm weight / bias are zero, the statistics run over the Ht true columns, the padded columns come out as exact zeros
     __shared__ float red[4];
-    __shared__ int gidx[72];
+    __shared__ int gidx[136];               // the atom class + up to 128 bond partners
     __shared__ int ng;
     const int row = blockIdx.x;  // b*N + i
     const int b = row / N;
     const int i = row - b * N;
-    if (threadIdx.x < 64) {  // wave 0 compacts the non-zero input columns with a ballot (order-preserving)
+    if (threadIdx.x < 64) {  // wave 0 compacts the non-zero input columns with a ballot (order-preserving), 64 partners per pass
         const int lane = threadIdx.x;
         const int half = (*step_ptr + 1) & 1;   // z_{s+1} lives in half (s+1)&1 of the double-buffered state
         const int8_t *er = E + (((int64_t)half * B + b) * N + i) * N;
         const int xi = X[(int64_t)half * B * N + row];
-        const int e = (lane < N) ? (int)er[lane] : -1;
-        const unsigned long long m = __ballot(e >= 0);
-        const int base = (xi >= 0) ? 1 : 0;
+        int base = (xi >= 0) ? 1 : 0;
         if (lane == 0 && xi >= 0) gidx[0] = xi;
-        if (e >= 0) gidx[base + __popcll(m & ((1ull << lane) - 1ull))] = XD + ED * lane + e;
-        if (lane == 0) ng = base + __popcll(m);
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            const int j = j0 + lane;
+            const int e = (j < N) ? (int)er[j] : -1;
+            const unsigned long long m = __ballot(e >= 0);
+            if (e >= 0) gidx[base + __popcll(m & ((1ull << lane) - 1ull))] = XD + ED * j + e;
+            base += __popcll(m);
+        }
+        if (lane == 0) ng = base;
     }
     __syncthreads();
     constexpr int MAXE = 2;  // float4 chunks per thread: H <= 2048
@@ -133,13 +137,14 @@ __global__ __launch_bounds__(256) void embed_kernel(const int8_t *__restrict__ X
 // ------------------------------------------------------------------------------------------ attention (generic)
 // Per (sequence, head): LayerNorm(hd, affine) on q and k rows, key mask valid_i & valid_j with padded
 // query rows opened to all keys, softmax(q k^T / sqrt(hd)) v     (layers.py:56-87).
-// Generic f32 LDS kernel for any N <= 64, hd <= 128; the MFMA variant below covers the bf16 engine.
+// Generic f32 LDS kernel for any N <= 128, hd <= 128; the MFMA variant below covers the bf16 engine.  K and V of the sequence stay in LDS,
+// the queries go through in chunks of QC rows (QC = N whenever that fits: one chunk, the arithmetic of every element is the same either way).
 template <typename T>
 __global__ __launch_bounds__(256) void attn_generic_kernel(const T *__restrict__ qkv, T *__restrict__ o,
                                                             const float *__restrict__ qw, const float *__restrict__ qb,
                                                             const float *__restrict__ kw, const float *__restrict__ kb,
                                                             const int *__restrict__ n_nodes, int B, int N, int H,
-                                                            int hd, int hdp) {
+                                                            int hd, int hdp, int QC) {
     // H = width of each of the q | k | v sections of a qkv row (and of an output row), hdp = column pitch of a head inside a section,
     // hd = the checkpoint's head dimension (hd <= hdp; columns [hd, hdp) of a head are the engine's zero padding and are not touched)
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -148,25 +153,13 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const T *__restrict__
     const int b = seq % B;
     const int nv = n_nodes[b];
     const int ld = hd + 1;
-    float *q = sm;
-    float *k = q + N * ld;
+    float *k = sm;
     float *v = k + N * ld;
-    float *S = v + N * ld;  // [N][N+1]
+    float *q = v + N * ld;   // [QC][ld]
+    float *S = q + QC * ld;  // [QC][N+1]
     const int tid = threadIdx.x;
     const int64_t rbase = (int64_t)seq * N;
-    for (int idx = tid; idx < N * hd; idx += 256) {
-        const int i = idx / hd, d = idx - i * hd;
-        const T *r = qkv + (rbase + i) * (3 * (int64_t)H) + head * hdp + d;
-        q[i * ld + d] = to_f32<T>(r[0]);
-        k[i * ld + d] = to_f32<T>(r[H]);
-        v[i * ld + d] = to_f32<T>(r[2 * H]);
-    }
-    __syncthreads();
-    // LayerNorm over hd for the 2N rows of q and k: 2 threads per row would be enough; use one.
-    if (tid < 2 * N) {
-        float *r = (tid < N) ? (q + tid * ld) : (k + (tid - N) * ld);
-        const float *w = (tid < N) ? qw : kw;
-        const float *bb = (tid < N) ? qb : kb;
+    auto layer_norm_row = [&](float *r, const float *w, const float *bb) {
         float m = 0.f;
         for (int d = 0; d < hd; ++d) m += r[d];
         m /= (float)hd;
@@ -177,36 +170,54 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const T *__restrict__
         }
         const float rstd = rsqrtf(var / (float)hd + 1e-5f);
         for (int d = 0; d < hd; ++d) r[d] = (r[d] - m) * rstd * w[d] + bb[d];
-    }
-    __syncthreads();
-    const float scale = rsqrtf((float)hd);
-    for (int idx = tid; idx < N * N; idx += 256) {
-        const int i = idx / N, j = idx - i * N;
-        float s = 0.f;
-        for (int d = 0; d < hd; ++d) s = fmaf(q[i * ld + d], k[j * ld + d], s);
-        const bool allow = (i >= nv) || (j < nv);  // padded query rows attend to every key
-        S[i * (N + 1) + j] = allow ? s * scale : -INFINITY;
-    }
-    __syncthreads();
-    if (tid < N) {
-        float *r = S + tid * (N + 1);
-        float mx = -INFINITY;
-        for (int j = 0; j < N; ++j) mx = fmaxf(mx, r[j]);
-        float sum = 0.f;
-        for (int j = 0; j < N; ++j) {
-            const float e = expf(r[j] - mx);
-            r[j] = e;
-            sum += e;
-        }
-        const float inv = 1.f / sum;
-        for (int j = 0; j < N; ++j) r[j] *= inv;
-    }
-    __syncthreads();
+    };
     for (int idx = tid; idx < N * hd; idx += 256) {
         const int i = idx / hd, d = idx - i * hd;
-        float acc = 0.f;
-        for (int j = 0; j < N; ++j) acc = fmaf(S[i * (N + 1) + j], v[j * ld + d], acc);
-        o[(rbase + i) * (int64_t)H + head * hdp + d] = from_f32<T>(acc);
+        const T *r = qkv + (rbase + i) * (3 * (int64_t)H) + head * hdp + d;
+        k[i * ld + d] = to_f32<T>(r[H]);
+        v[i * ld + d] = to_f32<T>(r[2 * H]);
+    }
+    __syncthreads();
+    if (tid < N) layer_norm_row(k + tid * ld, kw, kb);      // LayerNorm over hd, one thread per key row
+    const float scale = rsqrtf((float)hd);
+    for (int i0 = 0; i0 < N; i0 += QC) {
+        const int nq = min(QC, N - i0);
+        __syncthreads();                                    // the previous chunk is done with q and S (and k is normalised)
+        for (int idx = tid; idx < nq * hd; idx += 256) {
+            const int i = idx / hd, d = idx - i * hd;
+            q[i * ld + d] = to_f32<T>(qkv[(rbase + i0 + i) * (3 * (int64_t)H) + head * hdp + d]);
+        }
+        __syncthreads();
+        if (tid < nq) layer_norm_row(q + tid * ld, qw, qb);
+        __syncthreads();
+        for (int idx = tid; idx < nq * N; idx += 256) {
+            const int i = idx / N, j = idx - i * N;
+            float s = 0.f;
+            for (int d = 0; d < hd; ++d) s = fmaf(q[i * ld + d], k[j * ld + d], s);
+            const bool allow = (i0 + i >= nv) || (j < nv);  // padded query rows attend to every key
+            S[i * (N + 1) + j] = allow ? s * scale : -INFINITY;
+        }
+        __syncthreads();
+        if (tid < nq) {
+            float *r = S + tid * (N + 1);
+            float mx = -INFINITY;
+            for (int j = 0; j < N; ++j) mx = fmaxf(mx, r[j]);
+            float sum = 0.f;
+            for (int j = 0; j < N; ++j) {
+                const float e = expf(r[j] - mx);
+                r[j] = e;
+                sum += e;
+            }
+            const float inv = 1.f / sum;
+            for (int j = 0; j < N; ++j) r[j] *= inv;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nq * hd; idx += 256) {
+            const int i = idx / hd, d = idx - i * hd;
+            float acc = 0.f;
+            for (int j = 0; j < N; ++j) acc = fmaf(S[i * (N + 1) + j], v[j * ld + d], acc);
+            o[(rbase + i0 + i) * (int64_t)H + head * hdp + d] = from_f32<T>(acc);
+        }
     }
 }
 
@@ -933,6 +944,7 @@ struct PostArgs {
 };
 
 // one wave per decoder row `row` = (p*B + b)*N + i; s_known >= 0: the reverse step (the caller knows it), else read from the arguments
+template <int MAXF>      // 64-column chunks of a decoder row: F = 16 + 5 N <= 64 MAXF (6 up to 64 nodes, 11 up to 128)
 __device__ __forceinline__ void post_rows_body(const PostArgs &a, int row, int lane, int s_known) {
     const int N = a.N, F = a.F, B = a.B;
     if (row < 0 || row >= 2 * B * N) return;
@@ -943,7 +955,6 @@ __device__ __forceinline__ void post_rows_body(const PostArgs &a, int row, int l
     const int ci = p == 0 ? b : B;
     const float *ss = a.modo + ((int64_t)s * (B + 1) + ci) * (2 * F);
     float *r = a.out + (int64_t)row * F;
-    constexpr int MAXF = 6;  // F <= 336 = 16 + 5*64
     float v[MAXF], sh[MAXF], sc[MAXF];
     float sm = 0.f;
 #pragma unroll
@@ -989,12 +1000,28 @@ __device__ __forceinline__ void post_rows_body(const PostArgs &a, int row, int l
     }
 }
 
+template <int MAXF>
 __global__ __launch_bounds__(256) void post_rows_kernel(PostArgs a) {
-    post_rows_body(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, -1);
+    post_rows_body<MAXF>(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, -1);
 }
 
-// one wave per (graph b, node i); lane j = partner node
+// NW waves per (graph b, node i); thread j = partner node (NW = 1 up to 64 nodes, 2 up to 128: the sums and counts over the partners of a
+// row are then added up across the two waves through LDS, wave 0 first -- with one wave the arithmetic is the historical one)
+template <int NW>
 __device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b, int j, int s_known) {
+    __shared__ float xch[NW > 1 ? NW * 16 : 1];
+    const int lane = j & 63, wv = j >> 6;
+    auto row_sum = [&](float x, int slot) -> float {          // sum over all partners j of the row
+        const float w = wave_sum(x);
+        if (NW == 1) return w;
+        __syncthreads();                                      // the slot's previous use has been read
+        if (lane == 0) xch[wv * 16 + slot] = w;
+        __syncthreads();
+        float t = xch[slot];
+#pragma unroll
+        for (int u = 1; u < NW; ++u) t += xch[u * 16 + slot];
+        return t;
+    };
     const int N = a.N, F = a.F, B = a.B;
     const int s = s_known >= 0 ? s_known : *a.step_ptr;
     const int nv = a.n_nodes[b];
@@ -1042,7 +1069,7 @@ __device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b,
 #pragma unroll
         for (int k = 0; k < ED; ++k) {
             e5[p][k] = l[k] * inv;
-            SE[p][k] = wave_sum(j < N ? e5[p][k] : 0.f);
+            SE[p][k] = row_sum(j < N ? e5[p][k] : 0.f, p * ED + k);
             tot += SE[p][k];
         }
         SEt[p] = tot;
@@ -1050,7 +1077,7 @@ __device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b,
     // ---- S[i,f] = sum_g X_t[i,g] u[f,g] in structured form (diffusion_utils.py:296-305)
     float cnt[ED];
 #pragma unroll
-    for (int k = 0; k < ED; ++k) cnt[k] = (float)__popcll(__ballot(eij == k));
+    for (int k = 0; k < ED; ++k) cnt[k] = NW == 1 ? (float)__popcll(__ballot(eij == k)) : row_sum(eij == k ? 1.f : 0.f, 10 + k);
     float emsum = 0.f;
 #pragma unroll
     for (int k = 0; k < ED; ++k) emsum = fmaf(cnt[k], a.e_marg[k], emsum);
@@ -1092,7 +1119,7 @@ __device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b,
                 pf = pc[0];
             }
         }
-        if (a.pX_out && j < 16) a.pX_out[((int64_t)b * N + i) * XD + c] = pf;
+        if (a.pX_out && j < 16) a.pX_out[((int64_t)b * N + i) * XD + c] = pf;      // (every wave computes the classes in its lanes 0..15)
         if (vi) {   // sample_discrete_features (diffusion_utils.py:386-395): clamp, renormalise, race
             const float pcl = fmaxf(pf, 1e-5f);
             const float sum = row16_sum(pcl);
@@ -1106,7 +1133,7 @@ __device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b,
             }
             const float v = (pcl / sum) / q;
             const float best = row16_max(v);
-            const unsigned long long m = __ballot(v == best && j < 16);
+            const unsigned long long m = __ballot(v == best && lane < 16);
             newX = __ffsll((long long)m) - 1;      // first maximum wins, like argmax
         }
     }
@@ -1205,7 +1232,8 @@ __device__ __forceinline__ void post_pairs_body(const PostArgs &a, int i, int b,
     }
 }
 
-__global__ __launch_bounds__(64) void post_pairs_kernel(PostArgs a) { post_pairs_body(a, blockIdx.x, blockIdx.y, threadIdx.x, -1); }
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void post_pairs_kernel(PostArgs a) { post_pairs_body<NW>(a, blockIdx.x, blockIdx.y, threadIdx.x, -1); }
 
 // ------------------------------------------------------------------------------------------ z_T
 // sample_discrete_feature_noise (diffusion_utils.py:495-518): limit marginals, strict upper triangle kept,

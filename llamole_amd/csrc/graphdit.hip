@@ -134,8 +134,9 @@ static std::vector<ParamInfo> dit_layout(const LLDitConfig &c) {
     return v;
 }
 
-// max_nodes <= 64 is the one bound the reference does not have (one 64-lane wave = one row of bond partners in the posterior, one
-// 64-row tile in the attention); hidden <= 2048 and head_dim <= 128 bound the per-row register / LDS footprints of the row kernels.
+// max_nodes <= 128 is the one bound the reference does not have (round 6: up to 64 nodes one 64-lane wave = one row of bond partners in
+// the posterior and one 64-row attention tile; 65..128 take two waves / a 128-row tile); hidden <= 2048 and head_dim <= 128 bound the
+// per-row register / LDS footprints of the row kernels.
 // The Python wrapper reports all three as ValueError naming the limit (graph_decoder.py).
 static int check_cfg(const LLDitConfig *c) {
     LL_CHECK(c != nullptr, "config is null");
@@ -143,7 +144,7 @@ static int check_cfg(const LLDitConfig *c) {
     LL_CHECK(c->heads > 0 && c->hidden % c->heads == 0, "hidden %d not divisible by heads %d", c->hidden, c->heads);
     LL_CHECK(c->hidden / c->heads <= 128, "head_dim %d > 128 unsupported", c->hidden / c->heads);
     LL_CHECK(c->mlp_hidden >= 1 && c->mlp_hidden <= 16384, "mlp_hidden=%d must be in [1,16384]", c->mlp_hidden);
-    LL_CHECK(c->max_nodes >= 1 && c->max_nodes <= 64, "max_nodes=%d must be in [1,64]", c->max_nodes);
+    LL_CHECK(c->max_nodes >= 1 && c->max_nodes <= 128, "max_nodes=%d must be in [1,128]", c->max_nodes);
     LL_CHECK(c->depth >= 1 && c->T >= 1, "depth/T must be positive");
     LL_CHECK(c->dtype == LL_F32 || c->dtype == LL_BF16, "unknown dtype %d", c->dtype);
     return LL_OK;
@@ -331,7 +332,10 @@ static void launch_attn_mfma_t(DitEngine *e, const DitEngine::BlockW &w, hipStre
                        e->qkv.as<bf16_t>(), e->attn_o.as<bf16_t>(), w.qn_w, w.qn_b,                                            \
                        w.kn_w, w.kn_b, e->n_nodes.as<int>(), e->B, e->cfg.max_nodes,                                           \
                        e->d.Ha, e->cfg.heads, e->d.hd)
-    if (g_attn_waves == 4 && HD == 64) LL_ATTN((HD == 64 ? 4 : 2));      // LayerNorm / transpose rows on four waves (eight rows each per pass)
+    if constexpr (NP == 128) {      // 128 token rows always take four waves (two query tiles each): 32 accumulator tiles would not fit two
+        LL_ATTN(4);
+        return;
+    } else if (g_attn_waves == 4 && HD == 64) LL_ATTN((HD == 64 ? 4 : 2));      // LayerNorm / transpose rows on four waves (eight rows each per pass)
     else if (g_attn_waves >= 2) LL_ATTN(2);
     else LL_ATTN(1);
 #undef LL_ATTN
@@ -340,8 +344,9 @@ template <typename T> static void launch_attn(DitEngine *e, int layer, hipStream
     const int N = e->cfg.max_nodes, hd = e->d.hd, hdp = e->d.hdp;
     const DitEngine::BlockW &w = e->bw[layer];
     if (sizeof(T) == 2 && !e->force_generic_attn) {      // bf16: the MFMA kernel at head pitch 32 | 64 | 96 | 128 (any head_dim <= 128)
-        const int NP = N <= 32 ? 32 : 64;
-#define LL_ATTN_HD(HD) do { if (NP == 32) launch_attn_mfma_t<32, HD>(e, w, st); else launch_attn_mfma_t<64, HD>(e, w, st); } while (0)
+        const int NP = N <= 32 ? 32 : N <= 64 ? 64 : 128;      // 65..128 nodes: two 64-key halves, eight 16-row tiles (four waves)
+#define LL_ATTN_HD(HD) do { if (NP == 32) launch_attn_mfma_t<32, HD>(e, w, st); else if (NP == 64) launch_attn_mfma_t<64, HD>(e, w, st); \
+                            else launch_attn_mfma_t<128, HD>(e, w, st); } while (0)
         if (hdp == 32) LL_ATTN_HD(32);
         else if (hdp == 64) LL_ATTN_HD(64);
         else if (hdp == 96) LL_ATTN_HD(96);
@@ -349,10 +354,14 @@ template <typename T> static void launch_attn(DitEngine *e, int layer, hipStream
 #undef LL_ATTN_HD
         return;
     }
-    const size_t lds = (size_t)(3 * N * (hd + 1) + N * (N + 1)) * 4;
+    // K and V of the sequence + a chunk of QC query rows and their score rows in LDS: the largest of N, 64, 32, 16 that fits 160 KB
+    int QC = N;
+    auto lds_of = [&](int qc) { return (size_t)((2 * N + qc) * (hd + 1) + qc * (N + 1)) * 4; };
+    while (QC > 16 && lds_of(QC) > 160 * 1024) QC = QC > 64 ? 64 : QC / 2;
+    const size_t lds = lds_of(QC);
     hipLaunchKernelGGL((attn_generic_kernel<T>), dim3(e->cfg.heads, 2 * e->B), dim3(256), lds, st, e->qkv.as<T>(),
                        e->attn_o.as<T>(), w.qn_w, w.qn_b, w.kn_w, w.kn_b, e->n_nodes.as<int>(), e->B, N,
-                       e->d.Ha, hd, hdp);
+                       e->d.Ha, hd, hdp, QC);
 }
 // q|k|v projection + attention of block `layer` as ONE launch (qkv_attn_kernel); false = not eligible, run the two launches
 static bool qkv_attn_eligible(const DitEngine *e) {
@@ -578,8 +587,13 @@ static int posterior_launch(DitEngine *e, const float *qx, const float *qe, int 
     a.update_state = update;
     if (pX) LL_HIP(hipMemsetAsync(pX, 0, (size_t)a.B * a.N * XD * 4, st));
     if (pE) LL_HIP(hipMemsetAsync(pE, 0, (size_t)a.B * a.N * a.N * ED * 4, st));
-    hipLaunchKernelGGL(post_rows_kernel, dim3(cdiv(2 * a.B * a.N, 4)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(post_pairs_kernel, dim3(a.N, a.B), dim3(64), 0, st, a);
+    if (a.N <= 64) {
+        hipLaunchKernelGGL(post_rows_kernel<6>, dim3(cdiv(2 * a.B * a.N, 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(post_pairs_kernel<1>, dim3(a.N, a.B), dim3(64), 0, st, a);
+    } else {        // 65..128 nodes: eleven 64-column chunks per decoder row, two wavefronts per row of bond partners
+        hipLaunchKernelGGL(post_rows_kernel<11>, dim3(cdiv(2 * a.B * a.N, 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(post_pairs_kernel<2>, dim3(a.N, a.B), dim3(128), 0, st, a);
+    }
     LL_LAUNCH_CHECK();
     return LL_OK;
 }
@@ -720,8 +734,12 @@ int ll_dit_create(const LLDitConfig *cfg, const LLDitTables *t, const float *d_w
         CRH(hipMemcpy(e->steps_tab.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
     }
     // the generic attention kernel may need > 64 KiB of dynamic LDS (N=64, hd>=64)
-    CRH(hipFuncSetAttribute((const void *)attn_generic_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    CRH(hipFuncSetAttribute((const void *)attn_generic_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_generic_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_generic_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<128, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<128, 64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<128, 96, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CRH(hipFuncSetAttribute((const void *)attn_mfma_kernel<128, 128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 #define LL_QA_ATTR(NP, KC) CRH(hipFuncSetAttribute((const void *)(qkv_attn_kernel<NP, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(QkvAttnGeom<NP, KC>::lds_bytes())))
     LL_QA_ATTR(32, 1024); LL_QA_ATTR(32, 512); LL_QA_ATTR(32, 256); LL_QA_ATTR(64, 512); LL_QA_ATTR(64, 256);
     CRH(hipFuncSetAttribute((const void *)(qkv_attn_kernel<64, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(QkvAttnGeom<64, 512>::lds_bytes())));

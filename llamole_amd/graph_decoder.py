@@ -133,7 +133,7 @@ class PendingGraphs:
 
 
 class GraphDiT(nn.Module):
-    MAX_NODES, MAX_HIDDEN, MAX_HEAD_DIM = 64, 2048, 128     # csrc/graphdit.hip: check_cfg
+    MAX_NODES, MAX_HIDDEN, MAX_HEAD_DIM = 128, 2048, 128    # csrc/graphdit.hip: check_cfg
 
     def __init__(self, model_config_path, data_info_path, model_dtype):
         super().__init__()
@@ -161,7 +161,9 @@ class GraphDiT(nn.Module):
             raise ValueError("dim should be divisible by num_heads")          # the reference's own assertion (layers.py:37)
         if self.max_n_nodes > self.MAX_NODES:
             raise ValueError(f"data.meta.json max_node={self.max_n_nodes}: the MI355X engine handles graphs of up to {self.MAX_NODES} "
-                             "atoms (one 64-lane wavefront per row of bond partners, one 64-row attention tile)")
+                             "atoms (two 64-lane wavefronts per row of bond partners, one 128-row attention tile).  The reference reads "
+                             "max_node from the downloaded data.meta.json without a bound (diffusion_utils.py:29-59; transformer.py:27 "
+                             "defaults to 50)")
         if cfgd["hidden_size"] > self.MAX_HIDDEN or cfgd["hidden_size"] // cfgd["num_heads"] > self.MAX_HEAD_DIM:
             raise ValueError(f"hidden_size={cfgd['hidden_size']} / num_heads={cfgd['num_heads']}: the MI355X engine handles "
                              f"hidden_size <= {self.MAX_HIDDEN} and head_dim <= {self.MAX_HEAD_DIM}")

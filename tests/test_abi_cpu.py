@@ -77,13 +77,14 @@ def test_version_and_error_string(lib):
     assert lib.ll_version() >= 100
     odd = _lib.LLDitConfig(100, 2, 4, 250, 32, 50, 2.0, 0)      # any width the reference constructs is a valid config (padded inside the engine)
     assert lib.ll_dit_param_count(C.byref(odd)) > 0
-    bad = _lib.LLDitConfig(4096, 2, 32, 400, 32, 50, 2.0, 0)    # the documented bounds: hidden <= 2048, head_dim <= 128, max_nodes <= 64
+    bad = _lib.LLDitConfig(4096, 2, 32, 400, 32, 50, 2.0, 0)    # the documented bounds: hidden <= 2048, head_dim <= 128, max_nodes <= 128
     assert lib.ll_dit_param_count(C.byref(bad)) < 0
     assert b"hidden" in lib.ll_last_error()
     with pytest.raises(RuntimeError, match="hidden"):
         _lib.check(lib.ll_dit_param_info(C.byref(bad), 0, None, 0, None, None))
     assert lib.ll_dit_param_count(C.byref(_lib.LLDitConfig(512, 2, 2, 2048, 32, 50, 2.0, 0))) < 0 and b"head_dim" in lib.ll_last_error()
-    assert lib.ll_dit_param_count(C.byref(_lib.LLDitConfig(128, 2, 4, 512, 65, 50, 2.0, 0))) < 0 and b"max_nodes" in lib.ll_last_error()
+    assert lib.ll_dit_param_count(C.byref(_lib.LLDitConfig(128, 2, 4, 512, 128, 50, 2.0, 0))) > 0
+    assert lib.ll_dit_param_count(C.byref(_lib.LLDitConfig(128, 2, 4, 512, 129, 50, 2.0, 0))) < 0 and b"max_nodes" in lib.ll_last_error()
 
 
 @pytest.mark.parametrize("H,L,heads,N,ratio", [(128, 2, 4, 32, 4.0), (256, 2, 4, 50, 4.0), (1024, 28, 16, 32, 4.0),

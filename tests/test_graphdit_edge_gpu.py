@@ -122,7 +122,7 @@ def test_c_abi_error_behaviour():
         m.begin(props, text, -200.0, torch.tensor([spec.N + 1]))
     with pytest.raises(ValueError, match="expected properties"):
         m.begin(props[:, :9], text, -200.0, n_nodes)
-    bad = _lib.LLDitConfig(128, 2, 4, 512, 65, 10, 2.0, 0)       # max_nodes > 64
+    bad = _lib.LLDitConfig(128, 2, 4, 512, 129, 10, 2.0, 0)      # max_nodes > 128
     assert lib.ll_dit_param_count(C.byref(bad)) < 0 and b"max_nodes" in lib.ll_last_error()
     assert lib.ll_softmax_topk(C.c_void_p(q.data_ptr()), 1, 8, 65, C.c_void_p(q.data_ptr()), C.c_void_p(q.data_ptr()), None) == -1
     # a correct call still works afterwards

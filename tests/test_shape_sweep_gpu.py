@@ -32,6 +32,13 @@ DIT_CASES = {
     "h100_hd10": (100, 10, 3.0, 20, 1, [20, 11]),                 # ten heads of 10 -> head pitch 32, q|k|v sections of 320
     "h48_hd16": (48, 3, 4.0, 6, 2, [6, 2]),                       # narrower than one 64-column tile
     "n1": (128, 4, 4.0, 1, 1, [1, 1]),
+    # round 6: 65..128 nodes (the reference takes max_node from data.meta.json without a bound): two wavefronts per row of bond partners,
+    # eleven 64-column chunks per decoder row, a 128-row attention tile (MFMA) / chunked query rows (generic f32)
+    "n65_h128": (128, 4, 4.0, 65, 2, [65, 64, 3]),
+    "n100_h256_hd64": (256, 4, 4.0, 100, 2, [100, 71]),
+    "n128_h128_hd32": (128, 4, 2.0, 128, 2, [128, 97, 65]),
+    "n128_h256_hd128": (256, 2, 4.0, 128, 1, [128, 2]),           # generic attention: K, V + 16 query rows per chunk fill the LDS
+    "n96_h144_hd72": (144, 2, 2.5, 96, 1, [96, 50]),              # head pitch 96 at 128 token rows
 }
 
 
@@ -127,7 +134,7 @@ def test_dit_bf16_engine_any_width(name):
 def test_dit_limits_are_value_errors():
     from llamole_amd.graph_decoder import GraphDiT
     d = tempfile.mkdtemp()
-    for cfg, N, pat in ((synth.make_dit_config(128, 1, 4, 4, 2.0), 65, "up to 64"),
+    for cfg, N, pat in ((synth.make_dit_config(128, 1, 4, 4, 2.0), 129, "up to 128"),
                         (synth.make_dit_config(2112, 1, 33, 4, 2.0), 8, "hidden_size <= 2048"),
                         (synth.make_dit_config(512, 1, 2, 4, 2.0), 8, "head_dim <= 128"),
                         (synth.make_dit_config(100, 1, 3, 4, 2.0), 8, "divisible by num_heads")):
