@@ -330,14 +330,19 @@ def roofline_object(args, dom):
         roof = {"bound": "mfma", "achieved": kflops / (kms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["traffic"] = None
-    for pmc_file in ("r5_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):     # newest first; the kernels are unchanged since round 3
+    # newest first (r6 holds only what round 6 measured; r5 carried round-3 entries over under its own name, so an entry's own `method`
+    # field says which round it is from -- printed in traffic_source)
+    for pmc_file in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
         except Exception:
             continue
         if kkey in pmc and args.dtype == "bf16" and (not kkey.startswith("fc1") or args.hidden == 1024):
             roof["traffic"] = pmc[kkey]["hbm_bytes_per_launch"]
-            roof["traffic_source"] = f"profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
+            meth = str(pmc[kkey].get("method", ""))
+            rnd = next((r for r in ("r6", "r5", "r4", "r3", "r2", "r1") if f"({r})" in meth), None)
+            roof["traffic_source"] = (f"profiles/{pmc_file}" + (f", entry measured in round {rnd[1:]}" if rnd else ", entry carried over from an earlier round")
+                                      + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, FETCH doubled per MI355X_MICROARCH.md)")
             break
     roof["algorithmic_bytes"] = kbytes
     roof["algorithmic_flops"] = kflops

@@ -344,21 +344,22 @@ __global__ __launch_bounds__(ATTN_THREADS) void decode_attn_rope_kernel(const bf
 // a wave instruction covers RPI whole rows, lane (r, c) holds 16 bytes of row r -- with G query pieces in registers per lane: G dot
 // products per loaded key piece, G axpys per value piece.  Softmax statistics in f32 per head.  The first 256 keys / values are requested
 // before the rotary arithmetic.  Arithmetic per head as decode_attn_rope_kernel up to the f32 summation order of P.V.
-template <int D, int G>
-__global__ __launch_bounds__(ATTN_THREADS) void decode_attn_rope_gqa_kernel(const bf16_t *__restrict__ qkv, int64_t ld_qkv,
+template <int D, int G, int W>      // W waves per workgroup (8 | 16): a wave takes 256 / W keys of a tile
+__global__ __launch_bounds__(64 * W) void decode_attn_rope_gqa_kernel(const bf16_t *__restrict__ qkv, int64_t ld_qkv,
                                                                    const bf16_t *__restrict__ cs, const bf16_t *__restrict__ sn,
                                                                    int64_t cs0, bf16_t *__restrict__ K, bf16_t *__restrict__ V,
                                                                    const long long *__restrict__ pos_ptr,
                                                                    const unsigned char *__restrict__ mask, int64_t ms0,
                                                                    bf16_t *__restrict__ out, int nh, int nkv, int maxlen, float scale) {
-    constexpr int LPR = AttnGeom<D>::LPR, RPI = AttnGeom<D>::RPI, NI = AttnGeom<D>::NI, half = D / 2;
+    constexpr int LPR = AttnGeom<D>::LPR, RPI = AttnGeom<D>::RPI, KPW = 256 / W, NI = KPW / RPI, half = D / 2, THREADS = 64 * W;
+    auto key_of = [](int j0, int wave, int i, int lane) { return j0 + wave * KPW + i * RPI + lane / LPR; };
     extern __shared__ __attribute__((aligned(16))) float sm_attn3[];
     float *qs = sm_attn3;                         // [G][D] rotated queries, f32 of their bf16 values
     float *part = qs + G * D;                     // [waves][G][D] partial outputs
-    bf16_t *kn = reinterpret_cast<bf16_t *>(part + ATTN_WAVES * G * D);      // [D] rotated new key (bf16)
+    bf16_t *kn = reinterpret_cast<bf16_t *>(part + W * G * D);      // [D] rotated new key (bf16)
     bf16_t *vn = kn + D;                          // [D] new value
     float *sc = reinterpret_cast<float *>(vn + D);                           // [G][maxlen] scores -> probabilities
-    __shared__ float red[2 * G * ATTN_WAVES];
+    __shared__ float red[2 * G * W];
     const int kvh = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long p = *pos_ptr;
@@ -368,9 +369,18 @@ __global__ __launch_bounds__(ATTN_THREADS) void decode_attn_rope_gqa_kernel(cons
     bf16_t *Kb = K + ((int64_t)b * nkv + kvh) * maxlen * D;
     bf16_t *Vb = V + ((int64_t)b * nkv + kvh) * maxlen * D;
     const unsigned char *mrow = mask + b * ms0;
-    AttnTile0<D> t0;
-    attn_prefetch<D>(t0, Kb, Vb, mrow, maxlen, tid, lane, wave);
-    for (int role = wave; role < G + 2; role += ATTN_WAVES) {        // roles 0..G-1: query heads; G: the new key; G+1: the new value
+    // the first 256 keys (and the mask byte of key `tid`) are requested before the rotary arithmetic; the values of that tile are requested
+    // right behind the score pass, into the registers the keys leave free -- <= 128 VGPRs for groups of up to four heads, i.e. two
+    // workgroups per CU: at 64 sequences x 8 KV heads all 512 workgroups are resident at once (one round instead of two)
+    const int cc = lane % LPR, r = lane / LPR;
+    au32x4 k0[NI], v0[NI];
+    const unsigned char mk0 = tid < maxlen ? mrow[tid] : (unsigned char)0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = key_of(0, wave, i, lane);
+        k0[i] = j < maxlen ? *reinterpret_cast<const au32x4 *>(Kb + (int64_t)j * D + cc * 8) : (au32x4)(0);
+    }
+    for (int role = wave; role < G + 2; role += W) {        // roles 0..G-1: query heads; G: the new key; G+1: the new value
         if (role < G) {
             if (lane < half) {
                 const bf16_t *src = row + (kvh * G + role) * D;
@@ -404,40 +414,42 @@ __global__ __launch_bounds__(ATTN_THREADS) void decode_attn_rope_gqa_kernel(cons
         }
     }
     __syncthreads();
-    const int cc = lane % LPR, r = lane / LPR;
     const long long pn = pvalid ? p : -1;
     float q[G][8];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int e = 0; e < 8; ++e) q[g][e] = qs[g * D + cc * 8 + e];
-    // ---- scores
-    for (int j0 = 0; j0 < maxlen; j0 += 256) {
-        au32x4 kk[NI];
+    // ---- scores: the prefetched tile first (its registers are free afterwards), then any further tile of a longer context
+    auto score_tile = [&](int j0, au32x4 (&kk)[NI]) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int j = attn_key<D>(j0, wave, i, lane);
-            if (j0 == 0) kk[i] = t0.k[i];
-            else kk[i] = (j < maxlen && mrow[j] != 0) ? *reinterpret_cast<const au32x4 *>(Kb + (int64_t)j * D + cc * 8) : (au32x4)(0);
+            const int j = key_of(j0, wave, i, lane);
             if (j == pn) kk[i] = *reinterpret_cast<const au32x4 *>(kn + cc * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int j = attn_key<D>(j0, wave, i, lane);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const float d = attn_row_sum<LPR>(attn_dot8(q[g], kk[i]));
                 if (cc == 0 && j < maxlen) sc[g * maxlen + j] = d * scale;
             }
         }
+    };
+    score_tile(0, k0);
+    for (int j0 = 256; j0 < maxlen; j0 += 256) {
+        au32x4 kk[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = key_of(j0, wave, i, lane);
+            kk[i] = (j < maxlen && mrow[j] != 0) ? *reinterpret_cast<const au32x4 *>(Kb + (int64_t)j * D + cc * 8) : (au32x4)(0);
+        }
+        score_tile(j0, kk);
     }
     __syncthreads();
     // ---- softmax statistics per head over the unmasked keys
     float mx[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
-    for (int j = tid; j < maxlen; j += ATTN_THREADS) {
-        const bool ok = (j == tid ? t0.mk : mrow[j]) != 0;
+    for (int j = tid; j < maxlen; j += THREADS) {
+        const bool ok = (j == tid ? mk0 : mrow[j]) != 0;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float s = ok ? sc[g * maxlen + j] : -INFINITY;
@@ -448,19 +460,19 @@ __global__ __launch_bounds__(ATTN_THREADS) void decode_attn_rope_gqa_kernel(cons
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const float m = wave_max(mx[g]);
-        if (lane == 0) red[g * ATTN_WAVES + wave] = m;
+        if (lane == 0) red[g * W + wave] = m;
     }
     __syncthreads();
     float sum[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        float m = red[g * ATTN_WAVES];
+        float m = red[g * W];
 #pragma unroll
-        for (int w = 1; w < ATTN_WAVES; ++w) m = fmaxf(m, red[g * ATTN_WAVES + w]);
+        for (int w = 1; w < W; ++w) m = fmaxf(m, red[g * W + w]);
         mx[g] = m;
         sum[g] = 0.f;
     }
-    for (int j = tid; j < maxlen; j += ATTN_THREADS) {
+    for (int j = tid; j < maxlen; j += THREADS) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float s = sc[g * maxlen + j];
@@ -472,7 +484,12 @@ __global__ __launch_bounds__(ATTN_THREADS) void decode_attn_rope_gqa_kernel(cons
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const float t = wave_sum(sum[g]);
-        if (lane == 0) red[(G + g) * ATTN_WAVES + wave] = t;
+        if (lane == 0) red[(G + g) * W + wave] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {          // the values of the first tile, into the registers the keys and queries have left
+        const int j = key_of(0, wave, i, lane);
+        v0[i] = j < maxlen ? *reinterpret_cast<const au32x4 *>(Vb + (int64_t)j * D + cc * 8) : (au32x4)(0);
     }
     __syncthreads();
     // ---- out = P V: lane (r, c) accumulates columns 8c..8c+7 of every head over the rows it sees
@@ -481,19 +498,27 @@ __global__ __launch_bounds__(ATTN_THREADS) void decode_attn_rope_gqa_kernel(cons
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
-    for (int j0 = 0; j0 < maxlen; j0 += 256) {
+    auto pv_tile = [&](int j0, au32x4 (&vt)[NI]) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int j = attn_key<D>(j0, wave, i, lane);
+            const int j = key_of(j0, wave, i, lane);
             const bool live = j < maxlen && mrow[j < maxlen ? j : 0] != 0;
-            au32x4 vv;
-            if (j0 == 0) vv = t0.v[i];
-            else vv = live ? *reinterpret_cast<const au32x4 *>(Vb + (int64_t)j * D + cc * 8) : (au32x4)(0);
+            au32x4 vv = vt[i];
             if (j == pn) vv = *reinterpret_cast<const au32x4 *>(vn + cc * 8);
             if (!live) vv = (au32x4)(0);          // masked rows may hold anything (NaN from padded positions)
 #pragma unroll
             for (int g = 0; g < G; ++g) attn_axpy8(acc[g], live ? sc[g * maxlen + j] : 0.f, vv);
         }
+    };
+    pv_tile(0, v0);
+    for (int j0 = 256; j0 < maxlen; j0 += 256) {
+        au32x4 vt[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = key_of(j0, wave, i, lane);
+            vt[i] = (j < maxlen && mrow[j] != 0) ? *reinterpret_cast<const au32x4 *>(Vb + (int64_t)j * D + cc * 8) : (au32x4)(0);
+        }
+        pv_tile(j0, vt);
     }
     // rows of one wave instruction -> one partial per wave (lanes c, c + LPR, ...), then across waves through LDS
 #pragma unroll
@@ -512,14 +537,14 @@ __global__ __launch_bounds__(ATTN_THREADS) void decode_attn_rope_gqa_kernel(cons
             for (int e = 0; e < 8; ++e) part[(wave * G + g) * D + cc * 8 + e] = acc[g][e];
     }
     __syncthreads();
-    for (int i = tid; i < G * D; i += ATTN_THREADS) {
+    for (int i = tid; i < G * D; i += THREADS) {
         const int g = i / D, d = i % D;
         float o = 0.f;
 #pragma unroll
-        for (int w = 0; w < ATTN_WAVES; ++w) o += part[(w * G + g) * D + d];
-        float den = red[(G + g) * ATTN_WAVES];
+        for (int w = 0; w < W; ++w) o += part[(w * G + g) * D + d];
+        float den = red[(G + g) * W];
 #pragma unroll
-        for (int w = 1; w < ATTN_WAVES; ++w) den += red[(G + g) * ATTN_WAVES + w];
+        for (int w = 1; w < W; ++w) den += red[(G + g) * W + w];
         const float inv = den > 0.f ? 1.f / den : 0.f;      // a fully masked query row (left padding) yields zeros, not NaN
         out[((int64_t)b * nh + kvh * G + g) * D + d] = f32_to_bf16(o * inv);
     }
@@ -636,24 +661,26 @@ int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, c
     // Qwen2-7B 7, the toy models 2); up to 16 sequences keep the per-head kernel (bit-identical to the op-by-op path)
     const int G = nh / nkv;
     if (B > 16 && (G == 2 || G == 4 || G == 7)) {
-        const size_t l3 = (size_t)(G * D + ATTN_WAVES * G * D) * 4 + (size_t)2 * D * 2 + (size_t)G * maxlen * 4;
+        const int gw = G <= 4 ? 16 : 8;
+        const size_t l3 = (size_t)(G * D + gw * G * D) * 4 + (size_t)2 * D * 2 + (size_t)G * maxlen * 4;
         if (l3 <= 150 * 1024) {
             dim3 g3(nkv, B);
-#define LL_GQA(D_, G_)                                                                                                                   \
+#define LL_GQA(D_, G_, W_)                                                                                                               \
     do {                                                                                                                                 \
         static size_t attr = 0;                                                                                                          \
         if (l3 > attr) {                                                                                                                 \
-            LL_HIP(hipFuncSetAttribute((const void *)decode_attn_rope_gqa_kernel<D_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3)); \
+            LL_HIP(hipFuncSetAttribute((const void *)decode_attn_rope_gqa_kernel<D_, G_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3)); \
             attr = l3;                                                                                                                   \
         }                                                                                                                                \
-        hipLaunchKernelGGL((decode_attn_rope_gqa_kernel<D_, G_>), g3, dim3(ATTN_THREADS), l3, (hipStream_t)stream, (const bf16_t *)qkv, ld_qkv, \
+        hipLaunchKernelGGL((decode_attn_rope_gqa_kernel<D_, G_, W_>), g3, dim3(64 * W_), l3, (hipStream_t)stream, (const bf16_t *)qkv, ld_qkv, \
                            (const bf16_t *)cos, (const bf16_t *)sin, cs_stride, (bf16_t *)Kc, (bf16_t *)Vc, (const long long *)pos,      \
                            (const unsigned char *)mask, mask_stride, (bf16_t *)out, nh, nkv, maxlen, scale);                            \
     } while (0)
+            // sixteen waves for groups of up to four heads (16 keys per wave and tile: <= 128 VGPRs), eight for seven (Qwen2-7B)
             if (D == 128) {
-                if (G == 2) LL_GQA(128, 2); else if (G == 4) LL_GQA(128, 4); else LL_GQA(128, 7);
+                if (G == 2) LL_GQA(128, 2, 16); else if (G == 4) LL_GQA(128, 4, 16); else LL_GQA(128, 7, 8);
             } else {
-                if (G == 2) LL_GQA(64, 2); else if (G == 4) LL_GQA(64, 4); else LL_GQA(64, 7);
+                if (G == 2) LL_GQA(64, 2, 16); else if (G == 4) LL_GQA(64, 4, 16); else LL_GQA(64, 7, 8);
             }
 #undef LL_GQA
             LL_LAUNCH_CHECK();

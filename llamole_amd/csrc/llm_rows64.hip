@@ -33,9 +33,10 @@ enum { R64_PLAIN = 0, R64_RESIDUAL = 1, R64_SILU_MUL = 2 };
 __device__ __forceinline__ float r64_bfr(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 
 constexpr int R64_WAVES = 8, R64_KP = 4;        // waves per workgroup; k-parts
-// KS = k per x stage (512: 16 MFMA k-steps; LDS row pitch KS * 2 + 16 bytes = 260 dwords = 4 mod 64).  KS = 256 halves the ring (67 KB)
-// and the registers (<= 128: two workgroups per CU): measured level with 512 on every decode shape (47.3 vs 47.9 us on gate|up at 64
-// rows), so only 512 is instantiated
+// KS = k per x stage (512: 16 MFMA k-steps; LDS row pitch KS * 2 + 16 bytes = 260 dwords = 4 mod 64).  KS = 256 halves the ring (67 KB) and
+// the registers (<= 128: two workgroups per CU, or one next to another stream's): measured level with 512 alone (47.3 vs 47.9 us on gate|up
+// at 64 rows) AND under the overlapped GraphDiT trajectory (66.2 vs 66.3 molecules/s, profiles/r6_ab_rows64_stage*.json): only 512 is
+// instantiated
 
 // [N, K] row-major (row pitch ldw) -> MFMA A-operand order, rows padded to a multiple of 16 with zeros:
 // out[((tile * K/32 + kstep) * 64 + lane) * 8 + e] = W[tile * 16 + (lane & 15)][kstep * 32 + (lane >> 4) * 8 + e]
