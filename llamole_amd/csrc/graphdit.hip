@@ -383,7 +383,10 @@ static int qkv_attn_mode(const DitEngine *e) {
     // Next to another stream's kernels (overlap mode: the trajectory under the LLM decode) every launch costs
     // the other stream a dispatch slot as well: fused from batch 1 (e2e 369.4 -> 366.9 ms per molecule).
     const int wgs = 2 * e->B * e->cfg.heads;
-    if (e->overlap) return 1;
+    // ... up to the batch where the launch has more than ~four rounds of workgroups per CU: at 64 graphs (2048 workgroups, each streaming the
+    // head's 384 KB of q|k|v weights) the fused launch took 66.6 us per block under the 64-sequence decode against 31 + 9 us for the 128-row
+    // GEMM tiles + the attention launch (profiles/r6_llama64_kernel_stats.csv)
+    if (e->overlap) return wgs <= 2 * g_fuse_qkv_max_wgs ? 1 : 0;
     // up to 128 token rows the q|k|v projection runs on the all-in-flight panel kernels (gemm_m64 / gemm_m128), which beat the fused launch
     // (graphs of more than 32 nodes stage their 64-row panel in two K chunks: there the fused launch needs twice the workgroups to pay)
     const int min_wgs = e->cfg.max_nodes <= 32 ? g_fuse_qkv_min_wgs : 2 * g_fuse_qkv_min_wgs;

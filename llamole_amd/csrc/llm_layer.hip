@@ -443,6 +443,11 @@ __global__ __launch_bounds__(64 * W) void decode_attn_rope_gqa_kernel(const bf16
         }
         score_tile(j0, kk);
     }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {          // the values of the first tile, into the registers the keys and queries have left: in flight under the softmax
+        const int j = key_of(0, wave, i, lane);
+        v0[i] = j < maxlen ? *reinterpret_cast<const au32x4 *>(Vb + (int64_t)j * D + cc * 8) : (au32x4)(0);
+    }
     __syncthreads();
     // ---- softmax statistics per head over the unmasked keys
     float mx[G];
@@ -485,11 +490,6 @@ __global__ __launch_bounds__(64 * W) void decode_attn_rope_gqa_kernel(const bf16
     for (int g = 0; g < G; ++g) {
         const float t = wave_sum(sum[g]);
         if (lane == 0) red[(G + g) * W + wave] = t;
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {          // the values of the first tile, into the registers the keys and queries have left
-        const int j = key_of(0, wave, i, lane);
-        v0[i] = j < maxlen ? *reinterpret_cast<const au32x4 *>(Vb + (int64_t)j * D + cc * 8) : (au32x4)(0);
     }
     __syncthreads();
     // ---- out = P V: lane (r, c) accumulates columns 8c..8c+7 of every head over the rows it sees
