@@ -65,7 +65,7 @@ def test_same_seed_same_molecules_in_two_fresh_processes():
     try:
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "r5_determinism.json"), "w") as f:
+        with open(os.path.join(out, "r6_determinism.json"), "w") as f:
             json.dump({"process_1": a, "process_2": b, "identical": a == b}, f, indent=1, sort_keys=True)
     except OSError:
         pass

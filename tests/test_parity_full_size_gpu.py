@@ -37,7 +37,7 @@ def _report(key, val):
     try:
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "r5_parity_full_size.json"), "w") as f:
+        with open(os.path.join(out, "r6_parity_full_size.json"), "w") as f:
             json.dump(REPORT, f, indent=1, sort_keys=True)
     except OSError:
         pass
