@@ -771,25 +771,30 @@ def test_fused_stack_on_llama_and_mistral_layouts(arch):
 
 
 @pytest.mark.gpu
-def test_weight_copies_follow_their_sources():
+@pytest.mark.parametrize("rows", [2, 24])
+def test_weight_copies_follow_their_sources(rows, monkeypatch):
     """the concatenated q|k|v / gate|up copies and f32 biases of the fused decode path were never invalidated.  After an
-    in-place weight update the fused stack must decode exactly like a freshly fused copy of the updated model (same graph object)."""
-    from llamole_amd import e2e
+    in-place weight update the fused stack must decode exactly like a freshly fused copy of the updated model (same graph object).
+    24 rows (round 6): the copies in MFMA operand order of the seven-launch layer and of lm_head are re-packed in place as well."""
+    from llamole_amd import e2e, llm_accel
     from llamole_amd.llm_accel import accelerate_llm, refresh_weight_copies
     from llamole_amd.llm_decode import GraphedDecoder
+    monkeypatch.setattr(llm_accel, "PACK64_MIN_N", 1024)       # the toy lm_head (2048 rows) takes the packed-copy path of a real one
     llm = e2e.build_llm("tiny", "cuda", torch.bfloat16)
     accelerate_llm(llm)
     g = torch.Generator().manual_seed(2)
-    prompt = torch.randint(5, 2000, (2, 12), generator=g).cuda()
+    prompt = torch.randint(5, 2000, (rows, 12), generator=g).cuda()
     kw = dict(max_new_tokens=6, do_sample=False, pad_token_id=0, eos_token_id=[])
     dec = GraphedDecoder(llm, use_graph=True, fused_cache=True)
     before = dec.generate(prompt, torch.ones_like(prompt), **kw)
     assert refresh_weight_copies(llm) == 0
     with torch.no_grad():
         for n, p in llm.named_parameters():
-            if any(t in n for t in ("q_proj", "k_proj", "gate_proj", "up_proj", "o_proj")):
+            if any(t in n for t in ("q_proj", "k_proj", "gate_proj", "up_proj", "o_proj", "down_proj", "lm_head")):
                 p.mul_(1.5)
                 p.add_(0.01)
+    if rows > 16:
+        assert llm.model.layers[0]._ll_fused.p64 is not None and "_ll_w64" in llm.lm_head.__dict__      # the packed copies exist
     after = dec.generate(prompt, torch.ones_like(prompt), **kw)          # refreshes in place, replays the same captured graph
     fresh = e2e.build_llm("tiny", "cuda", torch.bfloat16)
     fresh.load_state_dict(llm.state_dict())
