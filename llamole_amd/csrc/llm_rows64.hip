@@ -166,22 +166,29 @@ __global__ __launch_bounds__(512, KS == 256 ? 4 : 2) void rows64_kernel(const bf
     // end of a unit (the barrier behind its last stage has passed: ring slot `slot` is free until the next stage's x write): the partial
     // tiles of the four k-parts -> LDS; k-part wave kp finishes column block kp of its tile pair (summed in k-part order); accumulators reset
     auto finish = [&](int u, int slot) {
-        float *part = reinterpret_cast<float *>(sm_r64 + slot * SLOT);        // [waves][MB][64 lanes][4], one tile of the pair at a time
+        // [tile][waves][MB][64 lanes][4]: both tiles of the pair at once when the slot holds them (512-k stages), else one tile at a time
+        float *part = reinterpret_cast<float *>(sm_r64 + slot * SLOT);
+        constexpr bool BOTH = 2 * R64_WAVES * MB * 1024 <= SLOT;
+        constexpr int TSTRIDE = BOTH ? R64_WAVES * MB * 256 : 0;
         const int cb = kp, m = cb * 16 + (lane & 15);
         r64_f32x4 s0 = (r64_f32x4)(0.f), s1 = (r64_f32x4)(0.f);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int c = 0; c < MB; ++c) {
-                *reinterpret_cast<r64_f32x4 *>(part + ((wid * MB + c) * 64 + lane) * 4) = acc[t][c];
+                *reinterpret_cast<r64_f32x4 *>(part + t * TSTRIDE + ((wid * MB + c) * 64 + lane) * 4) = acc[t][c];
                 acc[t][c] = (r64_f32x4)(0.f);
             }
+            if (BOTH && t == 0) continue;
             __syncthreads();
             if (kp < MB) {
-                r64_f32x4 sum = (r64_f32x4)(0.f);
 #pragma unroll
-                for (int q = 0; q < R64_KP; ++q) sum += *reinterpret_cast<const r64_f32x4 *>(part + (((q * 2 + tp) * MB + cb) * 64 + lane) * 4);
-                if (t == 0) s0 = sum; else s1 = sum;
+                for (int tt = (BOTH ? 0 : t); tt <= t; ++tt) {
+                    r64_f32x4 sum = (r64_f32x4)(0.f);
+#pragma unroll
+                    for (int q = 0; q < R64_KP; ++q) sum += *reinterpret_cast<const r64_f32x4 *>(part + tt * TSTRIDE + (((q * 2 + tp) * MB + cb) * 64 + lane) * 4);
+                    if (tt == 0) s0 = sum; else s1 = sum;
+                }
             }
             __syncthreads();        // the exchange buffer is free again (the second tile; then a ring slot)
         }
@@ -399,10 +406,10 @@ int linear_rows64_launch(const void *x, int ldx, const void *Wp, const float *bi
             ksg = g_rows64_ksg;
         } else {
             // few row groups (o_proj, down_proj: 56..64 on 256 CUs; q|k|v: 72..96): split K over workgroups until three quarters of the CUs
-            // have a unit; a slice keeps >= 2 x-stages (profiles/r6_rows64_sweep.txt: o_proj 16.0 us at 4 slices against 24.3 in one piece,
+            // have a unit; a slice keeps >= 1-2 x-stages (profiles/r6_rows64_sweep.txt: o_proj 16.0 us at 4 slices against 24.3 in one piece,
             // down_proj 29.8 against 63.8, q|k|v 18.9 at 2 against 21.9)
             const int groups = cdiv(N, 64), nst = cdiv(K, 512);
-            while (ksg < 8 && groups * ksg * 4 < r64_cus() * 3 && nst / (ksg * 2) >= 2) ksg *= 2;
+            while (ksg < 8 && groups * ksg * 4 < r64_cus() * 3 && nst / (ksg * 2) >= 1) ksg *= 2;      // Qwen2-7B o_proj (K = 3584: 7 stages): 15.0 us at 4 slices, 17.0 at 2
         }
     }
     const size_t need = (size_t)ksg * M * N * 4;
