@@ -96,6 +96,9 @@ def test_bench_total_prompts_picks_the_whole_share_as_one_batch():
     assert d["config"]["per_rank_batch"] == 64 and d["config"]["per_rank_batches_per_step"] == 2 and d["config"]["gathered_molecules"] == 128
     d = _line(_run(["--total-prompts", "16", "--batch", "4", "--steps", "1"] + E2E_TINY, {}, workload="e2e"))
     assert d["config"]["per_rank_batch"] == 4 and d["config"]["per_rank_batches_per_step"] == 4 and d["config"]["per_rank_batch_source"] == "--batch"
+    # two ranks (sharing this box's GPU over gloo): 24 sequences each on the seven-launch layers, one gather of 48 molecules
+    d = _line(_run(["--gpus", "2", "--total-prompts", "48", "--steps", "1"] + E2E_TINY, SHARED, workload="e2e"))
+    assert d["n_gpus"] == 2 and d["config"]["per_rank_batch"] == 24 and d["config"]["gathered_molecules"] == 48 and "rows64_kernel" in d["roofline"]["kernel"]
 
 
 def test_bench_rank_failure_ends_the_job():
