@@ -1,10 +1,14 @@
 """Optional MI355X acceleration of the untouched HuggingFace LLM's decode step.
 
-The HF model code is not modified; what changes is the kernel underneath ``nn.Linear`` for decode-shaped calls
-(<= 64 token rows, bf16, no grad): hipBLASLt picks ~0.7-2.4 TB/s skinny-GEMM kernels there, while the weight-streaming
-GEMV / 64x64 LDS-DMA tiles of ``libllamole_hip`` (``ll_linear``) run at 4.7-5.3 TB/s.  Prefill and any other shape fall
-through to ``F.linear``.  Everything is enqueued on the caller's current stream, so it composes with the captured
-hipGraph of ``llm_decode.GraphedDecoder``.
+The HF model code is not modified; what changes is the kernel underneath its modules for decode-shaped calls (bf16, no grad):
+  * 1-2 sequences : five launches per decoder layer on the f32-FMA GEMVs (RMSNorm prologue, residual / SiLU*mul epilogues; bit-identical
+                    to HF's op order), rope + KV append + attention in one launch, one-launch prologue and sampler;
+  * 3-16 sequences: the same five launches on the weight-streaming MFMA Linear (``ll_linear_rows16_bf16``);
+  * 17-64 sequences (round 6): seven launches per layer on copies of the weights in MFMA operand order (``ll_linear_rows64_bf16``), the
+                    RMSNorm between two Linears split over producer and consumer, grouped-query attention with one workgroup per
+                    (KV head, sequence) -- the batch the reference's DataLoader hands ``language_model.generate`` (eval/workflow.py:89-91);
+  * anything else (prefill, larger batches, a dynamic cache) falls through to the HF code, with ``ll_linear`` under ``nn.Linear`` up to 128 rows.
+Everything is enqueued on the caller's current stream, so it composes with the captured hipGraph of ``llm_decode.GraphedDecoder``.
 """
 from __future__ import annotations
 
