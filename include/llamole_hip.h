@@ -246,7 +246,8 @@ int ll_decode_attn_bf16(const void *q, const void *K, const void *V, const void 
  * ll_decode_attn_rope_bf16 : apply_rotary_pos_emb + StaticLayer.update + attention for ONE new position per sequence.
  *     qkv [B, (nh+2*nkv)*D] rows (stride ld_qkv) = fused q|k|v projection; cos/sin [B or 1, D] (batch stride cs_stride, 0 to
  *     broadcast); Kc/Vc [B,nkv,maxlen,D] static cache, appended at *pos (device int64); mask bool [B,maxlen] rows
- *     (stride mask_stride) for the new query; out [B, nh*D].  D in {64,128}.
+ *     (stride mask_stride) for the new query (causal decode: cache slots behind *pos hold no keys yet and must be masked -- with more than 16
+ *     sequences, where one workgroup serves the whole KV group, they are not even fetched); out [B, nh*D].  D in {64,128}.
  * (timing / tuning hooks of these kernels: include/llamole_hip_tuning.h) */
 #define LL_GEMV_PLAIN 0
 #define LL_GEMV_RESIDUAL 1

@@ -373,12 +373,15 @@ __global__ __launch_bounds__(64 * W) void decode_attn_rope_gqa_kernel(const bf16
     // right behind the score pass, into the registers the keys leave free -- <= 128 VGPRs for groups of up to four heads, i.e. two
     // workgroups per CU: at 64 sequences x 8 KV heads all 512 workgroups are resident at once (one round instead of two)
     const int cc = lane % LPR, r = lane / LPR;
+    // cache slots behind the position being written hold no keys yet (every mask this kernel is handed hides them: causal decode), so the
+    // first tile is only requested up to it: a quarter of the key / value bytes at the average length of a 128 + 128 token generation
+    const int jlim = pvalid ? (int)min((long long)maxlen, p + 1) : maxlen;
     au32x4 k0[NI], v0[NI];
     const unsigned char mk0 = tid < maxlen ? mrow[tid] : (unsigned char)0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int j = key_of(0, wave, i, lane);
-        k0[i] = j < maxlen ? *reinterpret_cast<const au32x4 *>(Kb + (int64_t)j * D + cc * 8) : (au32x4)(0);
+        k0[i] = j < jlim ? *reinterpret_cast<const au32x4 *>(Kb + (int64_t)j * D + cc * 8) : (au32x4)(0);
     }
     for (int role = wave; role < G + 2; role += W) {        // roles 0..G-1: query heads; G: the new key; G+1: the new value
         if (role < G) {
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(64 * W) void decode_attn_rope_gqa_kernel(const bf16
 #pragma unroll
     for (int i = 0; i < NI; ++i) {          // the values of the first tile, into the registers the keys and queries have left: in flight under the softmax
         const int j = key_of(0, wave, i, lane);
-        v0[i] = j < maxlen ? *reinterpret_cast<const au32x4 *>(Vb + (int64_t)j * D + cc * 8) : (au32x4)(0);
+        v0[i] = j < jlim ? *reinterpret_cast<const au32x4 *>(Vb + (int64_t)j * D + cc * 8) : (au32x4)(0);
     }
     __syncthreads();
     // ---- softmax statistics per head over the unmasked keys
