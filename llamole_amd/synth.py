@@ -477,7 +477,8 @@ def write_molqa_dataset(dataset_dir: str, name: str = "molqa_synth", n: int = 5)
     return name
 
 
-def write_eval_fixture(root: str, special_tokens, with_adapter: bool = True, dit_shape=(128, 4, 4.0), gin_hidden: int = 64) -> str:
+def write_eval_fixture(root: str, special_tokens, with_adapter: bool = True, dit_shape=(128, 4, 4.0), gin_hidden: int = 64, n_prompts: int = 5,
+                       batch_size: int = 2) -> str:
     """Everything `python main.py eval cfg.yaml` reads, synthetic and local: LLM + tokenizer, LoRA adapter + connectors, the
     three graph checkpoints, a dataset, and the YAML with the reference's keys (config/generate/qwen_material.yaml)."""
     import yaml
@@ -494,14 +495,14 @@ def write_eval_fixture(root: str, special_tokens, with_adapter: bool = True, dit
     if with_adapter:
         write_lora_adapter_dir(adapter, e2e.build_llm("tiny", "cpu", torch.bfloat16))
     write_connector_dir(os.path.join(adapter, "connector"), hid, gin_hidden)
-    ds = write_molqa_dataset(os.path.join(root, "data"))
+    ds = write_molqa_dataset(os.path.join(root, "data"), n=n_prompts)
     y = {"model_name_or_path": llm_dir, "new_special_tokens": ",".join(special_tokens),
          "graph_decoder_path": os.path.join(root, "graph_decoder"), "graph_encoder_path": os.path.join(root, "graph_encoder"),
          "graph_predictor_path": os.path.join(root, "graph_predictor"), "adapter_name_or_path": adapter,
          "graph_lm_connector_path": os.path.join(adapter, "connector"), "stage": "mmsft", "do_train": False,
          "finetuning_type": "lora", "max_new_tokens": 16, "temperature": 0.6, "top_p": 0.9, "learned_query_size": 8,
          "dataset": ds, "dataset_dir": os.path.join(root, "data"), "template": "qwen", "cutoff_len": 32, "bf16": True,
-         "pure_bf16": True, "per_device_eval_batch_size": 2, "output_dir": os.path.join(root, "out")}
+         "pure_bf16": True, "per_device_eval_batch_size": batch_size, "output_dir": os.path.join(root, "out")}
     if not with_adapter:
         y.pop("adapter_name_or_path")
     path = os.path.join(root, "generate.yaml")

@@ -99,6 +99,31 @@ def test_main_eval_with_checkpoint_shapes_that_need_padding(tmp_path, monkeypatc
     assert any(r["llm_reactions"] for r in res) or all(isinstance(r["response_retro"], str) for r in res)
 
 
+def test_main_eval_with_a_batch_of_twenty_prompts(tmp_path, monkeypatch, capsys):
+    """per_device_eval_batch_size 20 (the reference decodes whatever batch its DataLoader yields in one language_model.generate,
+    eval/workflow.py:89-91,110-124): the design phase of `main.py eval` decodes the 20 sequences together on the seven-launch layers
+    (ll_linear_rows64_bf16, grouped-query attention) and every record comes out in order with its own property row."""
+    from llamole_amd import eval as ev
+    from llamole_amd import llm_accel, synth
+    from llamole_amd.modeling_llamole import SPECIAL_TOKENS
+    seen = _script_chemistry(monkeypatch)
+    cfg = synth.write_eval_fixture(str(tmp_path), SPECIAL_TOKENS, n_prompts=20, batch_size=20)
+    calls = []
+    orig = llm_accel._FusedLayer.run64
+    monkeypatch.setattr(llm_accel._FusedLayer, "run64", lambda self, *a, **k: (calls.append(a[0].shape[0]), orig(self, *a, **k))[1])
+    torch.manual_seed(0)
+    try:
+        out = ev.run_eval(cfg, overrides={"retro_iterations": 1, "retro_max_planning_time": 10})
+    finally:
+        from transformers.models.qwen2 import modeling_qwen2 as mq
+        if hasattr(mq.apply_rotary_pos_emb, "_ll_orig"):
+            mq.apply_rotary_pos_emb = mq.apply_rotary_pos_emb._ll_orig
+    res = out["results"]
+    assert [r["qa_idx"] for r in res] == list(range(20)) and len(seen["graphs"]) == 20
+    assert all(set(r) == RECORD_FIELDS and r["property"]["CO2"] == 10.0 + 7 * r["qa_idx"] and r["llm_smiles"].startswith("M") for r in res)
+    assert calls and set(calls) == {20}                       # the 20 sequences went through the 17..64-row layers together
+
+
 def test_main_eval_cli_and_adapter_merge(tmp_path):
     """`python main.py eval <yaml>` as a process (no scripted chemistry: design phase only would need rdkit, so the CLI is run on
     the argument-error path), and the LoRA merge that replaces peft: merged weights == W + (alpha/r) B A."""
