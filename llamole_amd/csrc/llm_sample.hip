@@ -58,6 +58,23 @@ __device__ __forceinline__ uint32_t keys_of_pair(uint32_t wv) {
     const uint32_t msk = (((x >> 15) & 0x00010001u) * 0xffffu) | 0x80008000u;   // negative: flip all bits; else set the sign bit
     return x ^ msk;
 }
+typedef short pk_i16 __attribute__((ext_vector_type(2)));
+typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
+// keys of a pair WITHOUT the inf / NaN canonicalisation: valid when neither half has an all-ones exponent (pair_special == 0)
+__device__ __forceinline__ uint32_t keys_of_finite_pair(uint32_t wv) {
+    const pk_i16 sg = __builtin_bit_cast(pk_i16, wv) >> 15;                     // 0xffff per negative half
+    return wv ^ (__builtin_bit_cast(uint32_t, sg) | 0x80008000u);                // negative: flip all bits; else set the sign bit
+}
+// bit 15 / 31 set iff that half is inf or NaN (0x7f80 + 0x0080 carries into the half's top bit, never beyond it)
+__device__ __forceinline__ uint32_t pair_special(uint32_t wv) { return (wv & 0x7f807f80u) + 0x00800080u; }
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pk_u16, a), __builtin_bit_cast(pk_u16, b)));
+}
+// a value every lane of the wave holds alike -> scalar registers (the sampler is short of vector registers, not of scalar ones)
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)), lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __forceinline__ float val_of(uint32_t k) {
     const uint32_t x = (k & 0x8000u) ? (k & 0x7fffu) : (~k & 0xffffu);
     return __uint_as_float(x << 16);
@@ -79,6 +96,7 @@ template <int CH> __device__ __forceinline__ void reg_fence(uint32_t (&w)[CH][4]
 
 constexpr int SAMPLE_BPT = 36;                      // histogram bins per thread
 constexpr int SAMPLE_W = SAMPLE_BPT * 1024;         // key window below the row maximum held in LDS (147 KB of counters)
+constexpr int SAMPLE_TM_BINS = SAMPLE_W / 32;       // 1152
 
 template <int CH>
 __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
@@ -89,6 +107,8 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
     __shared__ unsigned long long sh_tail, sh_R;
     __shared__ unsigned int sh_d, sh_key, sh_rank, sh_tok, sh_dk;
     __shared__ unsigned long long sh_Zk;
+    __shared__ uint32_t tmh[SAMPLE_TM_BINS + 1];    // thread maxima per 32-key bin below the row maximum (top-k lower bound)
+    __shared__ unsigned int sh_klo;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bf16_t *row = a.logits + (int64_t)b * a.ld;
     const int nchunk = a.V / 8;
@@ -96,7 +116,7 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
         const int c = tid + k * 1024;
-        uint4 v = make_uint4(0, 0, 0, 0);
+        uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);          // past the end of the row: NaN, which converts to key 0 = no element
         if (c < nchunk) v = *reinterpret_cast<const uint4 *>(row + (int64_t)c * 8);
         w[k][0] = v.x; w[k][1] = v.y; w[k][2] = v.z; w[k][3] = v.w;
     }
@@ -104,57 +124,113 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
 #pragma unroll
         for (int i = 0; i < SAMPLE_BPT; ++i) cnt[i * 1024 + tid] = 0;
     }
-    if (tid == 0) { sh_tail = 0; sh_d = 0; sh_tok = 0; sh_dk = 0xffffffffu; sh_Zk = 0; }
+    if (tid == 0) { sh_tail = 0; sh_d = 0; sh_tok = 0; sh_dk = 0xffffffffu; sh_Zk = 0; sh_klo = 0; }
+    for (int i = tid; i < SAMPLE_TM_BINS + 1; i += 1024) tmh[i] = 0;
     reg_fence<CH>(w);
-    uint32_t kmaxi = 0;
+    // keys: the finite conversion for every pair (7 VALU instructions per pair instead of ~25 with the inf / NaN canonicalisation);
+    // the inf / NaN test is taken per 16-byte chunk and such a chunk (rare) is converted again; the all-ones fill past the end of the
+    // row becomes key 0 = no element
+    uint32_t kmaxp = 0;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
-        const bool ok = tid + k * 1024 < nchunk;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const uint32_t kk = ok ? keys_of_pair(w[k][t]) : 0u;
-            w[k][t] = kk;
-            kmaxi = max(kmaxi, max(kk & 0xffffu, kk >> 16));
+        const uint32_t r0 = w[k][0], r1 = w[k][1], r2 = w[k][2], r3 = w[k][3];
+        uint32_t k0 = keys_of_finite_pair(r0), k1 = keys_of_finite_pair(r1), k2_ = keys_of_finite_pair(r2), k3 = keys_of_finite_pair(r3);
+        if (((pair_special(r0) | pair_special(r1) | pair_special(r2) | pair_special(r3)) & 0x80008000u) && tid + k * 1024 < nchunk) {
+            k0 = keys_of_pair(r0); k1 = keys_of_pair(r1); k2_ = keys_of_pair(r2); k3 = keys_of_pair(r3);
         }
+        w[k][0] = k0; w[k][1] = k1; w[k][2] = k2_; w[k][3] = k3;
+        kmaxp = pk_max_u16(pk_max_u16(kmaxp, k0), pk_max_u16(pk_max_u16(k1, k2_), k3));
         __builtin_amdgcn_sched_barrier(0);
     }
+    const uint32_t kmaxi = max(kmaxp & 0xffffu, kmaxp >> 16);
     float kmaxf = wave_max((float)kmaxi);
     if (lane == 0) redf[wave] = kmaxf;
     __syncthreads();
     float km = redf[0];
 #pragma unroll
     for (int i = 1; i < 16; ++i) km = fmaxf(km, redf[i]);
-    const uint32_t kmax = (uint32_t)km;
+    const uint32_t kmax = __builtin_amdgcn_readfirstlane((uint32_t)km);      // uniform values live in scalar registers
     const float m = scaled(kmax, a.inv_temp);
     uint32_t k2 = kmax;      // the value to pick a token of
     uint32_t rank = 0;
     if (!a.greedy) {
+        // ---- 1b. with top-k on, a lower bound of the k-th largest key: at least k THREADS hold a key >= klo, so nothing below klo
+        // survives TopKLogitsWarper and it need not be counted.  klo = lower edge of the 32-key bin in which the count of thread
+        // maxima, taken from the row maximum down, reaches k (0 = no bound: k > 1024 threads, or the maxima leave the window).
+        // The dbg tap reports the mass of the whole row, so it counts everything.
+        uint32_t klo = 0;
+        if (a.top_k > 0 && a.top_k <= 1024 && !a.dbg) {
+            const uint32_t dm = kmax - kmaxi;
+            if (kmaxi) atomicAdd(&tmh[dm < (uint32_t)SAMPLE_W ? (dm >> 5) : SAMPLE_TM_BINS], 1u);
+            __syncthreads();
+            const uint32_t c0 = 2 * tid < SAMPLE_TM_BINS ? tmh[2 * tid] : 0u, c1 = 2 * tid + 1 < SAMPLE_TM_BINS ? tmh[2 * tid + 1] : 0u;
+            uint32_t inct = c0 + c1;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const uint32_t o = __shfl_up(inct, dd, 64);
+                if (lane >= dd) inct += o;
+            }
+            if (lane == 63) redu[wave] = inct;
+            __syncthreads();
+            uint32_t baset = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i < wave) baset += redu[i];
+            const uint32_t exclt = baset + inct - c0 - c1, kk = (uint32_t)a.top_k;
+            if (exclt < kk && exclt + c0 + c1 >= kk) {
+                const uint32_t bin = exclt + c0 >= kk ? 2 * tid : 2 * tid + 1;
+                const uint32_t dlow = bin * 32 + 31;                 // the lowest key of that bin is kmax - dlow
+                sh_klo = dlow < kmax ? kmax - dlow : 1u;
+            }
+            __syncthreads();
+            klo = __builtin_amdgcn_readfirstlane(sh_klo);
+        }
         // ---- 2. exact count histogram over the key window [kmax - W + 1, kmax]; anything below goes to one tail mass
         reg_fence<CH>(w);
+        if (klo) {
+            // nothing below klo is counted and the tail mass is not needed (it only enters Z, which top-k replaces by the survivors'
+            // mass): one packed compare per pair of keys, the counting itself is rare
+            const uint32_t below = (klo - 1u) * 0x00010001u;
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
+            for (int k = 0; k < CH; ++k) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t kk = w[k][t];
+                    if (pk_max_u16(kk, below) != below) {
+                        if ((kk & 0xffffu) >= klo) atomicAdd(&cnt[kmax - (kk & 0xffffu)], 1u);
+                        if ((kk >> 16) >= klo) atomicAdd(&cnt[kmax - (kk >> 16)], 1u);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const uint32_t key = hh ? (w[k][t] >> 16) : (w[k][t] & 0xffffu);
-                    const uint32_t d = kmax - key;
-                    if (key) {
-                        if (d < (uint32_t)SAMPLE_W) atomicAdd(&cnt[d], 1u);
-                        else {
-                            const unsigned long long q = mass_of(key, a.inv_temp, m);
-                            if (q) atomicAdd(&sh_tail, q);
+            for (int k = 0; k < CH; ++k) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const uint32_t key = hh ? (w[k][t] >> 16) : (w[k][t] & 0xffffu);
+                        const uint32_t d = kmax - key;
+                        if (key) {
+                            if (d < (uint32_t)SAMPLE_W) atomicAdd(&cnt[d], 1u);
+                            else {
+                                const unsigned long long q = mass_of(key, a.inv_temp, m);
+                                if (q) atomicAdd(&sh_tail, q);
+                            }
                         }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-        // ---- 3. thread t owns d in [36 t, 36 t + 36), descending values: masses = count * 2^-40 fixed-point exp
-        const int d0 = tid * SAMPLE_BPT;
+        // ---- 3. thread t owns d in [bpt t, bpt t + bpt), descending values: masses = count * 2^-40 fixed-point exp.  All 36 bins per
+        // thread without the bound; with it only [0, kmax - klo] can be non-empty (typically one bin per thread)
+        const int bpt = klo ? (int)((kmax - klo) >> 10) + 1 : SAMPLE_BPT;
+        const int d0 = tid * bpt;
         unsigned long long lsum = 0;
-        for (int i = 0; i < SAMPLE_BPT; ++i) {
+        for (int i = 0; i < bpt; ++i) {
             const uint32_t c = cnt[d0 + i];
             if (c && (uint32_t)(d0 + i) < kmax) lsum += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
         }
@@ -172,6 +248,8 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
             if (i < wave) base += wsum[i];
             Z += wsum[i];
         }
+        base = uniform64(base);
+        Z = uniform64(Z);
         const unsigned long long excl = base + inc - lsum;
         // top-k ahead of top-p (HF order: temperature, TopKLogitsWarper, TopPLogitsWarper; the reference's GeneratingArguments
         // default top_k = 50): the cut is the value of the k-th largest token, tokens tied with it stay (HF removes
@@ -180,7 +258,7 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
         unsigned long long Zk = Z;
         if (a.top_k > 0) {
             uint32_t lc = 0;
-            for (int i = 0; i < SAMPLE_BPT; ++i) {
+            for (int i = 0; i < bpt; ++i) {
                 const uint32_t c = cnt[d0 + i];
                 if (c && (uint32_t)(d0 + i) < kmax) lc += c;
             }
@@ -201,7 +279,7 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
             if (exclc < kk && exclc + lc >= kk) {        // exactly one thread: its bins hold the k-th largest token
                 uint32_t run = exclc;
                 unsigned long long A = excl;
-                for (int i = 0; i < SAMPLE_BPT; ++i) {
+                for (int i = 0; i < bpt; ++i) {
                     const uint32_t c = cnt[d0 + i];
                     if (c && (uint32_t)(d0 + i) < kmax) {
                         run += c;
@@ -215,15 +293,15 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
                 }
             }
             __syncthreads();
-            dk = sh_dk;                                  // stays ~0 when fewer than k tokens lie in the window: nothing is cut
-            if (dk != 0xffffffffu) Zk = sh_Zk;
+            dk = __builtin_amdgcn_readfirstlane(sh_dk);                                  // stays ~0 when fewer than k tokens lie in the window: nothing is cut
+            if (dk != 0xffffffffu) Zk = uniform64(sh_Zk);
         }
         const unsigned long long Tq = a.top_p >= 1.f ? ~0ull : (unsigned long long)((double)a.top_p * (double)Zk);
         // boundary: the lowest value whose mass-above is still < Tq (mass-above is non-decreasing in d)
         {
             unsigned long long A = excl;
             int last = -1;
-            for (int i = 0; i < SAMPLE_BPT; ++i) {
+            for (int i = 0; i < bpt; ++i) {
                 const uint32_t c = cnt[d0 + i];
                 if (c && (uint32_t)(d0 + i) < kmax) {
                     if (A < Tq && (uint32_t)(d0 + i) <= dk) last = d0 + i;
@@ -233,10 +311,10 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
             if (last >= 0) atomicMax(&sh_d, (unsigned int)last);
         }
         __syncthreads();
-        const uint32_t dtau = sh_d;      // 0 when nothing else qualifies: the top value is always kept
-        if (dtau >= (uint32_t)d0 && dtau < (uint32_t)(d0 + SAMPLE_BPT)) {
+        const uint32_t dtau = __builtin_amdgcn_readfirstlane(sh_d);      // 0 when nothing else qualifies: the top value is always kept
+        if (dtau >= (uint32_t)d0 && dtau < (uint32_t)(d0 + bpt)) {
             unsigned long long A = excl;
-            for (int i = 0; i < SAMPLE_BPT; ++i) {
+            for (int i = 0; i < bpt; ++i) {
                 const uint32_t c = cnt[d0 + i];
                 if (c && (uint32_t)(d0 + i) < kmax) {
                     A += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
@@ -256,10 +334,10 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
         if (tid == 0) { sh_key = kmax; sh_rank = 0; }
         __syncthreads();
         // ---- 4. the value whose mass interval contains R, and the rank among the tokens sharing it
-        const unsigned long long R = sh_R;
+        const unsigned long long R = uniform64(sh_R);
         if (R >= excl && R < excl + lsum) {
             unsigned long long A = excl;
-            for (int i = 0; i < SAMPLE_BPT; ++i) {
+            for (int i = 0; i < bpt; ++i) {
                 const uint32_t c = cnt[d0 + i];
                 if (c && (uint32_t)(d0 + i) < kmax) {
                     const unsigned long long q = mass_of(kmax - (d0 + i), a.inv_temp, m);
@@ -276,8 +354,8 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
             }
         }
         __syncthreads();
-        k2 = sh_key;      // (R in the tail mass, possible only with top_p >= 1 and a > 288-binade spread: the top value)
-        rank = sh_rank;
+        k2 = __builtin_amdgcn_readfirstlane(sh_key);      // (R in the tail mass, possible only with top_p >= 1 and a > 288-binade spread: the top value)
+        rank = __builtin_amdgcn_readfirstlane(sh_rank);
         if (a.dbg && tid == 0) a.dbg[b * 4 + 3] = k2;
     }
     // ---- 5. the rank-th token whose key is k2 (greedy: the lowest index holding the maximum, like torch.argmax)
@@ -285,13 +363,17 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
     uint32_t cntm = 0, minidx = 0xffffffffu;
     uint32_t tid_a = tid;                       // opaque copies: keep the 4*CH token indices from being hoisted and
     asm volatile("" : "+v"(tid_a));             // held live across the two passes below
+    const uint32_t k2x2 = k2 * 0x00010001u;
 #pragma unroll
     for (int k = 0; k < CH; ++k)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const uint32_t base_idx = (tid_a + k * 1024) * 8 + t * 2;
-            if ((w[k][t] & 0xffffu) == k2) { ++cntm; minidx = min(minidx, base_idx); }
-            if ((w[k][t] >> 16) == k2) { ++cntm; minidx = min(minidx, base_idx + 1); }
+            const uint32_t x = w[k][t] ^ k2x2;                    // a zero half = a token with the value k2
+            if ((x - 0x00010001u) & ~x & 0x80008000u) {           // some half may be zero (never misses one): look closer, rarely
+                const uint32_t base_idx = (tid_a + k * 1024) * 8 + t * 2;
+                if ((x & 0xffffu) == 0u) { ++cntm; minidx = min(minidx, base_idx); }
+                if ((x >> 16) == 0u) { ++cntm; minidx = min(minidx, base_idx + 1); }
+            }
         }
     if (a.greedy) {
         float mi = -(float)minidx;            // indices < 2^24: exact in f32
@@ -386,6 +468,7 @@ extern "C" int ll_sample_token_topk_bf16(const void *logits, int64_t ld, int B, 
     if (per <= 2) hipLaunchKernelGGL((sample_token_kernel<2>), dim3(B), dim3(1024), 0, s, a);
     else if (per <= 8) hipLaunchKernelGGL((sample_token_kernel<8>), dim3(B), dim3(1024), 0, s, a);
     else if (per <= 16) hipLaunchKernelGGL((sample_token_kernel<16>), dim3(B), dim3(1024), 0, s, a);
+    else if (per <= 19) hipLaunchKernelGGL((sample_token_kernel<19>), dim3(B), dim3(1024), 0, s, a);     // 152 064 (Qwen2): 76 key registers
     else hipLaunchKernelGGL((sample_token_kernel<20>), dim3(B), dim3(1024), 0, s, a);
     LL_LAUNCH_CHECK();
     return LL_OK;

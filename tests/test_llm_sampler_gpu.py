@@ -16,8 +16,9 @@ def _key_to_value(key: int) -> float:
 
 
 class Sampler:
-    def __init__(self, B, V, max_new=64, eos=(), pad=0):
+    def __init__(self, B, V, max_new=64, eos=(), pad=0, tap=True):
         from llamole_amd import _lib
+        self.tap = tap          # False: no dbg tap, the way the decode loop calls it (top-k then counts only what can survive it)
         self.lib, self._lib = _lib.load(), _lib
         d = "cuda"
         self.B, self.V = B, V
@@ -39,13 +40,46 @@ class Sampler:
         tail = (self.seed.data_ptr(), self.eos.data_ptr(), 8, self.pad, self.done.data_ptr(),
                 self.tok.data_ptr(), self.out.data_ptr(), self.out.stride(0), self.out.shape[1],
                 self.step.data_ptr(), self.posid.data_ptr(), self.pos.data_ptr(), advance,
-                self.dbg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                self.dbg.data_ptr() if self.tap else None, torch.cuda.current_stream().cuda_stream)
         if top_k is None:
             rc = self.lib.ll_sample_token_bf16(logits.data_ptr(), logits.stride(0), self.B, self.V, inv, top_p, int(greedy), *tail)
         else:
             rc = self.lib.ll_sample_token_topk_bf16(logits.data_ptr(), logits.stride(0), self.B, self.V, inv, top_p, int(top_k), int(greedy), *tail)
         self._lib.check(rc, "ll_sample_token_bf16")
         return self.tok.clone()
+
+
+def _rows_for_bound_test(V, g):
+    """Eight rows that stress the top-k lower bound: smooth, peaked, heavily tied, constant, inf / NaN, a handful of tokens far above a
+    floor that lies outside the key window, everything negative, one dominant token."""
+    r = torch.randn(8, V, generator=g)
+    rows = [r[0] * 2.5, r[1] * 8.0, (r[2] * 2).round() / 2, torch.full((V,), 1.5), r[4] * 3.0, torch.full((V,), -1.0e30), -r[6].abs() * 5 - 3, r[7] * 0.3]
+    rows[4][torch.randint(0, V, (40,), generator=g)] = float("inf")
+    rows[4][torch.randint(0, V, (40,), generator=g)] = float("nan")
+    rows[4][torch.randint(0, V, (40,), generator=g)] = float("-inf")
+    rows[5][torch.randint(0, V, (10,), generator=g)] = 1000.0
+    rows[5][torch.randint(0, V, (10,), generator=g)] = 996.0
+    rows[7][V // 3] = 40.0
+    return torch.stack(rows).bfloat16().cuda()
+
+
+@pytest.mark.parametrize("V", [2048, 32000, 128256, 152064, 163840])
+def test_top_k_lower_bound_leaves_every_token_unchanged(V):
+    """Without the dbg tap the sampler counts, under top-k, only keys that can survive it (a lower bound from the per-thread maxima,
+    one packed compare per pair of keys, a histogram scan over the few bins above the bound).  Same seeds, same rows: every token equals
+    the one of the whole-row count that the tests above pin to the HF warpers."""
+    g = torch.Generator().manual_seed(V + 1)
+    logits = _rows_for_bound_test(V, g)
+    for top_k, top_p, temperature in ((50, 0.9, 0.7), (1, 1.0, 1.0), (5, 0.5, 1.3), (300, 0.95, 0.6), (1024, 1.0, 1.0), (2000, 0.9, 1.0), (0, 0.9, 0.7)):
+        a, b = Sampler(8, V, max_new=48), Sampler(8, V, max_new=48, tap=False)
+        a.seed.fill_(1234 + top_k)
+        b.seed.fill_(1234 + top_k)
+        for _ in range(48):
+            a(logits, temperature=temperature, top_p=top_p, top_k=top_k)
+            b(logits, temperature=temperature, top_p=top_p, top_k=top_k)
+        assert torch.equal(a.out, b.out), (V, top_k)
+        if top_k == 50:
+            assert len(set(a.out[0].tolist())) > 8 and len(set(a.out[3].tolist())) > 8     # real draws, not a constant
 
 
 @pytest.mark.parametrize("V", [2048, 32000, 128256, 152064])
