@@ -264,6 +264,17 @@ int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, c
 int ll_decode_prologue(const int64_t *position_ids, const float *inv_freq, float attention_scaling, const int64_t *mask2d,
                        int64_t mask_stride, const int64_t *pos, void *cos, void *sin, void *mask_out, int B, int D, int maxlen,
                        void *stream);
+/* ll_suffix_prologue / ll_suffix_attn_rope_bf16 : the same pair for S consecutive new positions per sequence -- the reference's query-token
+ *     re-forward (modeling_llamole.py:641-646: <design_start> + the body tokens) run on top of the decode's KV cache at slots
+ *     *pos .. *pos+S-1.  Rows r = b*S + s.  Prologue: cos/sin [B*S,D] for position_ids [B*S], key mask [B*S,maxlen]: key j visible to row
+ *     (b,s) iff j <= *pos + s and mask2d[b][j] != 0.  Attention: qkv [B*S, (nh+2*nkv)*D] (row stride ld_qkv); rotary on q and k, the
+ *     new keys / values stored to Kc/Vc [B,nkv,maxlen,D], softmax(q K^T * scale + mask) V over the cache -> out [B*S, nh*D]; bit for
+ *     bit ll_rope_bf16 + ll_kv_append_bf16 + ll_decode_attn_bf16.  S <= 16, D in {64,128}. */
+int ll_suffix_prologue(const int64_t *position_ids, const float *inv_freq, float attention_scaling, const int64_t *mask2d,
+                       int64_t mask_stride, const int64_t *pos, void *cos, void *sin, void *mask_out, int B, int S, int D, int maxlen,
+                       void *stream);
+int ll_suffix_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, const void *sin, void *Kc, void *Vc, const int64_t *pos,
+                             const void *mask, void *out, int B, int S, int nh, int nkv, int maxlen, int D, float scale, void *stream);
 
 /* ll_linear_rows16_bf16 : out[M,N] = epilogue(x[M,K] . W^T + bias), M in 1..16, K % 32 == 0, bf16 operands, f32 accumulation on MFMA:
  *     the nn.Linear of a batched decode step (5..16 sequences: lock-step A* searches, several prompts per GPU) as a weight

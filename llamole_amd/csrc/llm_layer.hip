@@ -338,6 +338,65 @@ __global__ __launch_bounds__(ATTN_THREADS) void decode_attn_rope_kernel(const bf
                          out + ((int64_t)b * nh + h) * D, tid, lane, wave);
 }
 
+// The same for S consecutive NEW positions of every sequence (the query-token forward on top of the decode's cache,
+// modeling_llamole.py:641-646: <design_start> + 8 body tokens at cache slots *pos .. *pos + S - 1).  grid (nh, B*S), row r = b*S + s.
+// Query row s attends to the cache up to slot *pos + s, i.e. also to the keys of rows 0..s of THIS launch: the workgroup rotates and
+// stores those rows of its KV head itself before it reads them (every workgroup of the sequence that needs a row writes the same bits,
+// so nobody waits for anybody), then runs the plain cache attention of decode_attn_bf16_kernel -- bit for bit what rope_bf16_kernel +
+// kv_append_bf16_kernel + decode_attn_bf16_kernel compute in three launches.
+template <int D>
+__global__ __launch_bounds__(ATTN_THREADS) void suffix_attn_rope_kernel(const bf16_t *__restrict__ qkv, int64_t ld_qkv,
+                                                               const bf16_t *__restrict__ cs, const bf16_t *__restrict__ sn, bf16_t *K,
+                                                               bf16_t *V, const long long *__restrict__ pos_ptr,
+                                                               const unsigned char *__restrict__ mask, bf16_t *__restrict__ out, int nh,
+                                                               int nkv, int S, int maxlen, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm_attn3[];
+    float *qs = sm_attn3;                 // [D]  rotated query, f32 of its bf16 value
+    float *part = qs + D;                 // ATTN_PART_FLOATS
+    float *sc = part + ATTN_PART_FLOATS;  // [maxlen]
+    __shared__ float red[2 * ATTN_WAVES];
+    const int h = blockIdx.x, r = blockIdx.y;
+    const int b = r / S, s = r - b * S;
+    const int group = nh / nkv, kvh = h / group;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long p0 = *pos_ptr;
+    constexpr int half = D / 2;
+    bf16_t *Kb = K + ((int64_t)b * nkv + kvh) * maxlen * D;
+    bf16_t *Vb = V + ((int64_t)b * nkv + kvh) * maxlen * D;
+    const unsigned char *mrow = mask + (int64_t)r * maxlen;
+    if (wave == ATTN_WAVES - 1) {
+        if (lane < half) {
+            const bf16_t *src = qkv + (int64_t)r * ld_qkv + h * D;
+            const bf16_t *c = cs + (int64_t)r * D, *sv = sn + (int64_t)r * D;
+            const float x1 = bf16_to_f32(src[lane]), x2 = bf16_to_f32(src[lane + half]);
+            const float c1 = bf16_to_f32(c[lane]), c2 = bf16_to_f32(c[lane + half]);
+            const float s1 = bf16_to_f32(sv[lane]), s2 = bf16_to_f32(sv[lane + half]);
+            qs[lane] = bfr2(bfr2(x1 * c1) + bfr2(-x2 * s1));
+            qs[lane + half] = bfr2(bfr2(x2 * c2) + bfr2(x1 * s2));
+        }
+    }
+    for (int t = wave; t <= s; t += ATTN_WAVES) {
+        const long long p = p0 + t;
+        if (p < 0 || p >= maxlen || lane >= half) continue;
+        const int rt = b * S + t;
+        const bf16_t *src = qkv + (int64_t)rt * ld_qkv + (nh + kvh) * D;
+        const bf16_t *c = cs + (int64_t)rt * D, *sv = sn + (int64_t)rt * D;
+        const float x1 = bf16_to_f32(src[lane]), x2 = bf16_to_f32(src[lane + half]);
+        const float c1 = bf16_to_f32(c[lane]), c2 = bf16_to_f32(c[lane + half]);
+        const float s1 = bf16_to_f32(sv[lane]), s2 = bf16_to_f32(sv[lane + half]);
+        Kb[p * D + lane] = f32_to_bf16(bfr2(x1 * c1) + bfr2(-x2 * s1));
+        Kb[p * D + lane + half] = f32_to_bf16(bfr2(x2 * c2) + bfr2(x1 * s2));
+        const bf16_t *vsrc = qkv + (int64_t)rt * ld_qkv + (nh + nkv + kvh) * D;
+        *reinterpret_cast<uint32_t *>(Vb + p * D + lane * 2) = *reinterpret_cast<const uint32_t *>(vsrc + lane * 2);
+    }
+    __threadfence_block();
+    __syncthreads();            // the rows are in the cache (this CU's L1 is write-through and shared by the workgroup's waves)
+    AttnTile0<D> t0;
+    attn_prefetch<D>(t0, Kb, Vb, mrow, maxlen, tid, lane, wave);
+    attn_finish<D, false>(t0, qs, part, sc, red, Kb, Vb, mrow, maxlen, -1, nullptr, nullptr, scale, out + ((int64_t)r * nh + h) * D, tid,
+                          lane, wave);
+}
+
 // The same for MANY sequences per step (17..64: BASELINE configs[3] on one GPU): one workgroup per (KV head, sequence) serves all G = nh / nkv
 // query heads of the group, so a key / value row is fetched once instead of G times (at 64 sequences x 32 heads the per-head kernel took
 // 55 us per layer, most of it G-fold re-reads through L2: profiles/r6_llama64_kernel_stats.csv).  Same access pattern as attn_decode.h --
@@ -560,19 +619,21 @@ __global__ __launch_bounds__(256) void decode_prologue_kernel(const long long *_
                                                               float scaling, const long long *__restrict__ mask2d, int64_t ms,
                                                               const long long *__restrict__ pos_ptr, bf16_t *__restrict__ cos_o,
                                                               bf16_t *__restrict__ sin_o, unsigned char *__restrict__ mask_o,
-                                                              int D, int maxlen) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+                                                              int D, int maxlen, int S) {
+    // row r = b*S + s: the s-th new position of sequence b (S = 1: a decode step)
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int b = r / S, s = r - b * S;
     const int half = D / 2;
     if (tid < half) {
-        const float f = inv_freq[tid] * (float)posid[b];
-        const bf16_t c = f32_to_bf16(cosf(f) * scaling), s = f32_to_bf16(sinf(f) * scaling);
-        cos_o[(int64_t)b * D + tid] = c;
-        cos_o[(int64_t)b * D + tid + half] = c;
-        sin_o[(int64_t)b * D + tid] = s;
-        sin_o[(int64_t)b * D + tid + half] = s;
+        const float f = inv_freq[tid] * (float)posid[r];
+        const bf16_t c = f32_to_bf16(cosf(f) * scaling), sn = f32_to_bf16(sinf(f) * scaling);
+        cos_o[(int64_t)r * D + tid] = c;
+        cos_o[(int64_t)r * D + tid + half] = c;
+        sin_o[(int64_t)r * D + tid] = sn;
+        sin_o[(int64_t)r * D + tid + half] = sn;
     }
-    const long long p = *pos_ptr;
-    for (int j = tid; j < maxlen; j += 256) mask_o[(int64_t)b * maxlen + j] = (j <= p && mask2d[b * ms + j] != 0) ? 1 : 0;
+    const long long p = *pos_ptr + s;
+    for (int j = tid; j < maxlen; j += 256) mask_o[(int64_t)r * maxlen + j] = (j <= p && mask2d[b * ms + j] != 0) ? 1 : 0;
 }
 
 static int g_gemv_nt = 1;   // non-temporal weight loads (tools/gemv_fused_sweep.py)
@@ -711,7 +772,39 @@ int ll_decode_prologue(const int64_t *position_ids, const float *inv_freq, float
     LL_CHECK(B >= 1 && D >= 2 && D % 2 == 0 && D <= 512 && maxlen >= 1, "ll_decode_prologue: unsupported shape");
     hipLaunchKernelGGL(decode_prologue_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long *)position_ids, inv_freq,
                        attention_scaling, (const long long *)mask2d, mask_stride, (const long long *)pos, (bf16_t *)cos, (bf16_t *)sin,
-                       (unsigned char *)mask_out, D, maxlen);
+                       (unsigned char *)mask_out, D, maxlen, 1);
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+int ll_suffix_prologue(const int64_t *position_ids, const float *inv_freq, float attention_scaling, const int64_t *mask2d,
+                       int64_t mask_stride, const int64_t *pos, void *cos, void *sin, void *mask_out, int B, int S, int D, int maxlen,
+                       void *stream) {
+    LL_CHECK(position_ids && inv_freq && mask2d && pos && cos && sin && mask_out, "ll_suffix_prologue: null argument");
+    LL_CHECK(B >= 1 && S >= 1 && D >= 2 && D % 2 == 0 && D <= 512 && maxlen >= 1, "ll_suffix_prologue: unsupported shape");
+    hipLaunchKernelGGL(decode_prologue_kernel, dim3(B * S), dim3(256), 0, (hipStream_t)stream, (const long long *)position_ids, inv_freq,
+                       attention_scaling, (const long long *)mask2d, mask_stride, (const long long *)pos, (bf16_t *)cos, (bf16_t *)sin,
+                       (unsigned char *)mask_out, D, maxlen, S);
+    LL_LAUNCH_CHECK();
+    return LL_OK;
+}
+
+int ll_suffix_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, const void *sin, void *Kc, void *Vc, const int64_t *pos,
+                             const void *mask, void *out, int B, int S, int nh, int nkv, int maxlen, int D, float scale, void *stream) {
+    LL_CHECK(qkv && cos && sin && Kc && Vc && pos && mask && out, "ll_suffix_attn_rope_bf16: null argument");
+    LL_CHECK((D == 64 || D == 128) && B >= 1 && S >= 1 && S <= 16 && nkv >= 1 && nh % nkv == 0 && maxlen >= 1 && maxlen <= 16384 &&
+                 ld_qkv % 8 == 0,
+             "ll_suffix_attn_rope_bf16: unsupported shape");
+    const size_t lds = ((size_t)maxlen + D + ATTN_PART_FLOATS) * 4;
+    dim3 grid(nh, B * S);
+    if (D == 128)
+        hipLaunchKernelGGL((suffix_attn_rope_kernel<128>), grid, dim3(ATTN_THREADS), lds, (hipStream_t)stream, (const bf16_t *)qkv, ld_qkv,
+                           (const bf16_t *)cos, (const bf16_t *)sin, (bf16_t *)Kc, (bf16_t *)Vc, (const long long *)pos,
+                           (const unsigned char *)mask, (bf16_t *)out, nh, nkv, S, maxlen, scale);
+    else
+        hipLaunchKernelGGL((suffix_attn_rope_kernel<64>), grid, dim3(ATTN_THREADS), lds, (hipStream_t)stream, (const bf16_t *)qkv, ld_qkv,
+                           (const bf16_t *)cos, (const bf16_t *)sin, (bf16_t *)Kc, (bf16_t *)Vc, (const long long *)pos,
+                           (const unsigned char *)mask, (bf16_t *)out, nh, nkv, S, maxlen, scale);
     LL_LAUNCH_CHECK();
     return LL_OK;
 }

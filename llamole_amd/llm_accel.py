@@ -674,6 +674,28 @@ class _FusedLayer:
         return h2.view(B, 1, H)
 
 
+    def run_suffix(self, h, mask, cache, pe, B, S):
+        """S consecutive new positions per sequence (B*S <= 16 rows: the query-token forward on the decode's cache): the five launches of
+        ``run`` with ll_suffix_attn_rope_bf16 in the middle -- query row s sees the cache up to slot pos + s, the keys of rows 0..s included."""
+        H, R = self.H, B * S
+        x = h.view(R, H)
+        cl = cache.layers[self.layer_idx]
+        pos = cache.layers[0].cumulative_length
+        cos, sin = pe
+        nqkv = self.nq + 2 * self.nkv_dim
+        qkv = self._gemv(x, self.wqkv, self.bqkv, self.n1.weight, self.eps1, None, nqkv, H, 0)
+        att = torch.empty(R, self.nq, dtype=torch.bfloat16, device=h.device)
+        rc = self.lib.ll_suffix_attn_rope_bf16(qkv.data_ptr(), nqkv, cos.data_ptr(), sin.data_ptr(), cl.keys.data_ptr(), cl.values.data_ptr(),
+                                               pos.data_ptr(), mask.data_ptr(), att.data_ptr(), B, S, self.nh, self.nkv, cl.keys.shape[2],
+                                               self.D, self.scaling, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "ll_suffix_attn_rope_bf16")
+        h1 = self._gemv(att, self.wo, self.bo, None, 0.0, x, H, self.nq, 1)
+        act = self._gemv(h1, self.wgu, None, self.n2.weight, self.eps2, None, self.I, H, 2)
+        h2 = self._gemv(act, self.wdown, None, None, 0.0, h1, H, self.I, 1)
+        return h2.view(B, S, H)
+
+
 def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
                    position_embeddings=None, **kwargs):
     st = self._ll_fused
@@ -772,8 +794,61 @@ def _model_forward(self, input_ids=None, attention_mask=None, position_ids=None,
                 h = self.norm(h)
                 from transformers.modeling_outputs import BaseModelOutputWithPast
                 return BaseModelOutputWithPast(last_hidden_state=h, past_key_values=past_key_values if use_cache else None)
+    if st.get("suffix") and input_ids is not None and inputs_embeds is None and input_ids.dim() == 2:
+        out = _suffix_forward(self, st, layers, input_ids, attention_mask, position_ids, past_key_values, use_cache, kwargs)
+        if out is not None:
+            return out
     return self._ll_model_orig(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
                                past_key_values=past_key_values, inputs_embeds=inputs_embeds, use_cache=use_cache, **kwargs)
+
+
+def _suffix_forward(self, st, layers, input_ids, attention_mask, position_ids, cache, use_cache, kwargs):
+    """[B,S] new tokens (3 <= B*S <= 16) appended at the cache position held by layer 0's counter -- GraphedDecoder.continue_hidden, the
+    reference's query-token re-forward -- on the five-launch layers: one prologue launch (cos/sin per row, key mask per row: slot
+    j <= pos + s and not padding), then per layer q|k|v with the RMSNorm prologue, rope + append + attention, o_proj + residual, gate|up
+    + SiLU*mul, down_proj + residual (ll_linear_rows16_bf16).  None = not this shape: the caller takes the HF forward."""
+    B, S = input_ids.shape
+    R = B * S
+    clayers = getattr(cache, "layers", None)
+    if not (S >= 2 and FMA_GEMV_ROWS < R <= MAX_ROWS16 and input_ids.is_cuda and not torch.is_grad_enabled() and clayers
+            and all(getattr(l, "_ll_fused_update", False) for l in clayers) and attention_mask is not None and attention_mask.dim() == 2
+            and attention_mask.dtype == torch.long and attention_mask.stride(1) == 1 and attention_mask.shape[0] == B
+            and attention_mask.shape[1] == clayers[0].keys.shape[2] and clayers[0].keys.dtype == torch.bfloat16
+            and clayers[0].keys.is_contiguous() and clayers[0].values.is_contiguous() and clayers[0].keys.shape[0] == B
+            and position_ids is not None and position_ids.shape == input_ids.shape and position_ids.dtype == torch.long
+            and not kwargs.get("output_hidden_states") and not kwargs.get("output_attentions")
+            and all(l._ll_fused.stream_ok for l in layers)):
+        return None
+    h = self.embed_tokens(input_ids)
+    if h.dtype != torch.bfloat16 or not h.is_contiguous():
+        return None
+    maxlen, D, dev = attention_mask.shape[1], st["D"], input_ids.device
+    cos = torch.empty(R, D, dtype=torch.bfloat16, device=dev)
+    sin = torch.empty(R, D, dtype=torch.bfloat16, device=dev)
+    mask = torch.empty(R, maxlen, dtype=torch.bool, device=dev)
+    posid = position_ids.contiguous()
+    rc = st["lib"].ll_suffix_prologue(posid.data_ptr(), self.rotary_emb.inv_freq.data_ptr(), float(self.rotary_emb.attention_scaling),
+                                      attention_mask.data_ptr(), attention_mask.stride(0), clayers[0].cumulative_length.data_ptr(),
+                                      cos.data_ptr(), sin.data_ptr(), mask.data_ptr(), B, S, D, maxlen, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        _lib.check(rc, "ll_suffix_prologue")
+    for layer in layers:
+        h = layer._ll_fused.run_suffix(h, mask, cache, (cos, sin), B, S)
+    h = self.norm(h)
+    from transformers.modeling_outputs import BaseModelOutputWithPast
+    return BaseModelOutputWithPast(last_hidden_state=h, past_key_values=cache if use_cache else None)
+
+
+def suffix_on_fused_layers(model: nn.Module, on: bool) -> bool:
+    """Switch for the query-token forward of ``fuse_model_decode``-patched models: while on, a [B,S] call with B*S <= 16 rows that
+    continues a fused static cache runs on the five-launch layers (GraphedDecoder.continue_hidden turns it on around its call).
+    Returns whether the model has the patch."""
+    base = getattr(model, "model", model)
+    st = base.__dict__.get("_ll_decode")
+    if st is None:
+        return False
+    st["suffix"] = bool(on)
+    return True
 
 
 def fuse_model_decode(model: nn.Module) -> bool:

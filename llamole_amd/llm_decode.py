@@ -194,7 +194,13 @@ class GraphedDecoder:
             return base(input_ids=ids, attention_mask=self.mask, past_key_values=self.cache, cache_position=cache_pos,
                         position_ids=pos_ids, use_cache=True, return_dict=True).last_hidden_state
 
-        hidden = self._captured(("suffix", B, S), [(torch.empty_like, tail_ids), (torch.empty_like, pos), (torch.empty_like, posid)], fwd)
+        from .llm_accel import suffix_on_fused_layers
+        fused = self._cache_fused and os.environ.get("LLAMOLE_FUSED_SUFFIX", "1") != "0" and suffix_on_fused_layers(self.model, True)
+        try:
+            hidden = self._captured(("suffix", B, S), [(torch.empty_like, tail_ids), (torch.empty_like, pos), (torch.empty_like, posid)], fwd)
+        finally:
+            if fused:
+                suffix_on_fused_layers(self.model, False)
         if self._cache_fused:
             self.cache.layers[0].cumulative_length.add_(S)
         return hidden

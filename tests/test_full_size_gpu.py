@@ -116,10 +116,11 @@ def test_batched_decode_on_the_mfma_stream_at_full_size(name, rows):
         restore_elementwise(llm)
 
 
-def test_captured_query_forward_at_full_size():
-    """Qwen2-7B shapes: the query-token forward over the decode's KV cache (9 rows; rows16 Linears, fused KV append, the library's attention
-    for <= 16 new positions) as a replayed hipGraph equals the eager forward bit for bit -- hidden states and the 9 cache slots it writes --
-    on three prompts in a row (eager, captured, replayed) with a cache position that differs per call."""
+def test_captured_query_forward_at_full_size(monkeypatch):
+    """Qwen2-7B shapes: the query-token forward over the decode's KV cache (9 rows on the five-launch layers: rows16 Linears with the RMSNorm
+    prologue / residual / SiLU*mul epilogues, rope + append + attention for the 9 positions in one launch) as a replayed hipGraph equals the
+    eager forward bit for bit -- hidden states and the 9 cache slots it writes -- on prompts in a row (eager, captured, replayed) with a
+    cache position that differs per call; and it stays within bf16 rounding of the op-by-op forward (LLAMOLE_FUSED_SUFFIX=0)."""
     from llamole_amd import e2e
     from llamole_amd.llm_accel import accelerate_llm, restore_elementwise
     from llamole_amd.llm_decode import GraphedDecoder
@@ -146,6 +147,21 @@ def test_captured_query_forward_at_full_size():
                 assert torch.equal(k0, k1) and torch.equal(v0, v1), i
             assert torch.isfinite(outs[1][0].float()).all()
         assert isinstance(dg._side_graphs[("suffix", 1, 9)], tuple) and not de._side_graphs
+        monkeypatch.setenv("LLAMOLE_FUSED_SUFFIX", "0")
+        h_ops = de.continue_hidden(tail, P + new - 9).float()           # same cache prefix, op by op
+        h_fused = outs[0][0].float()
+        # yardstick as for the batched decode above: an f32 forward of the same weights over prompt + kept analysis + query tokens; two
+        # bf16 pipelines that round in different places drift apart over 28 random-init layers, each must stay as close to f32 as the other
+        seq = torch.cat([prompt, de.out_buf[:, :new - 9], tail], dim=1)
+        llm32 = e2e.build_llm("qwen2-7b", "cuda", torch.float32)
+        llm32.load_state_dict({k: v.float() for k, v in llm.state_dict().items()})
+        with torch.no_grad():
+            ref32 = llm32.model(input_ids=seq, attention_mask=torch.ones_like(seq)).last_hidden_state[:, -9:].float()
+        del llm32
+        scale = ref32.abs().max().item()
+        e_ops, e_fused = (h_ops - ref32).abs().max().item(), (h_fused - ref32).abs().max().item()
+        assert e_fused <= 1.5 * e_ops + 0.01 * scale, (e_fused, e_ops, scale)
+        assert (h_fused - ref32).abs().mean().item() <= 1.5 * (h_ops - ref32).abs().mean().item() + 0.002 * scale
     finally:
         restore_elementwise(llm)
 

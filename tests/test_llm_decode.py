@@ -685,6 +685,110 @@ def test_captured_query_forward_equals_the_eager_one(arch, monkeypatch):
         restore_elementwise(llm)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,S,D,nh,nkv", [(1, 9, 128, 28, 4), (1, 9, 128, 32, 8), (2, 8, 64, 4, 2), (1, 16, 64, 16, 4), (3, 5, 128, 6, 2), (1, 2, 64, 4, 4)])
+def test_suffix_attention_equals_rope_append_attention(B, S, D, nh, nkv):
+    """ll_suffix_prologue + ll_suffix_attn_rope_bf16 (S new positions per sequence in one launch: the query-token forward on the decode's
+    cache) against the three launches it replaces -- ll_rope_bf16, ll_kv_append_bf16, ll_decode_attn_bf16 with a torch-built causal +
+    padding mask: the same attention output and the same cache, bit for bit; cos / sin / mask rows equal ll_decode_prologue's."""
+    import ctypes as C
+    from llamole_amd import _lib
+    lib = _lib.load()
+    dev, maxlen, R = "cuda", 96, B * S
+    g = torch.Generator().manual_seed(B * 100 + S)
+    nqkv = (nh + 2 * nkv) * D
+    qkv = torch.randn(R, nqkv, generator=g).bfloat16().to(dev)
+    K0 = torch.randn(B, nkv, maxlen, D, generator=g).bfloat16().to(dev)
+    V0 = torch.randn(B, nkv, maxlen, D, generator=g).bfloat16().to(dev)
+    pos = torch.tensor([41], dtype=torch.long, device=dev)
+    mask2d = torch.ones(B, maxlen, dtype=torch.long, device=dev)
+    mask2d[0, :5] = 0                                        # left padding of the first sequence
+    posid = (torch.arange(S).unsqueeze(0) + torch.tensor([[36 + 7 * b] for b in range(B)])).to(dev)
+    inv_freq = (1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    cos = torch.empty(R, D, dtype=torch.bfloat16, device=dev)
+    sin = torch.empty_like(cos)
+    mask = torch.empty(R, maxlen, dtype=torch.bool, device=dev)
+    _lib.check(lib.ll_suffix_prologue(posid.data_ptr(), inv_freq.data_ptr(), 1.0, mask2d.data_ptr(), mask2d.stride(0), pos.data_ptr(), cos.data_ptr(),
+                                      sin.data_ptr(), mask.data_ptr(), B, S, D, maxlen, st), "ll_suffix_prologue")
+    for b in range(B):
+        for s in range(S):
+            c1, s1 = torch.empty(1, D, dtype=torch.bfloat16, device=dev), torch.empty(1, D, dtype=torch.bfloat16, device=dev)
+            m1 = torch.empty(1, maxlen, dtype=torch.bool, device=dev)
+            _lib.check(lib.ll_decode_prologue(posid[b, s:s + 1].contiguous().data_ptr(), inv_freq.data_ptr(), 1.0, mask2d[b:b + 1].data_ptr(), maxlen,
+                                              (pos + s).data_ptr(), c1.data_ptr(), s1.data_ptr(), m1.data_ptr(), 1, D, maxlen, st), "ll_decode_prologue")
+            r = b * S + s
+            assert torch.equal(cos[r], c1[0]) and torch.equal(sin[r], s1[0]) and torch.equal(mask[r], m1[0])
+    want_mask = (torch.arange(maxlen, device=dev)[None, None, :] <= (41 + torch.arange(S, device=dev))[None, :, None]) & mask2d.bool()[:, None, :]
+    assert torch.equal(mask.view(B, S, maxlen), want_mask)
+    # one launch
+    Ka, Va = K0.clone(), V0.clone()
+    out = torch.empty(R, nh * D, dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.ll_suffix_attn_rope_bf16(qkv.data_ptr(), nqkv, cos.data_ptr(), sin.data_ptr(), Ka.data_ptr(), Va.data_ptr(), pos.data_ptr(),
+                                            mask.data_ptr(), out.data_ptr(), B, S, nh, nkv, maxlen, D, D ** -0.5, st), "ll_suffix_attn_rope_bf16")
+    # three launches on views of the same q|k|v rows
+    Kb, Vb = K0.clone(), V0.clone()
+    q = qkv[:, :nh * D].view(B, S, nh, D).transpose(1, 2)
+    k = qkv[:, nh * D:(nh + nkv) * D].view(B, S, nkv, D).transpose(1, 2)
+    v = qkv[:, (nh + nkv) * D:].view(B, S, nkv, D).transpose(1, 2)
+    I3, I2 = C.c_int64 * 3, C.c_int64 * 2
+    qo = torch.empty(B, nh, S, D, dtype=torch.bfloat16, device=dev)
+    ko = torch.empty(B, nkv, S, D, dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.ll_rope_bf16(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), qo.data_ptr(), ko.data_ptr(), B, nh, nkv, S, D,
+                                I3(q.stride(0), q.stride(1), q.stride(2)), I3(k.stride(0), k.stride(1), k.stride(2)), I2(S * D, D), st), "ll_rope_bf16")
+    _lib.check(lib.ll_kv_append_bf16(Kb.data_ptr(), Vb.data_ptr(), ko.data_ptr(), v.data_ptr(), pos.data_ptr(), B, nkv, S, maxlen, D,
+                                     I3(ko.stride(0), ko.stride(1), ko.stride(2)), I3(v.stride(0), v.stride(1), v.stride(2)), st), "ll_kv_append_bf16")
+    m4 = want_mask.view(B, 1, S, maxlen).contiguous()
+    ref = torch.empty(B, S, nh, D, dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.ll_decode_attn_bf16(qo.data_ptr(), Kb.data_ptr(), Vb.data_ptr(), m4.data_ptr(), ref.data_ptr(), B, nh, nkv, S, maxlen, D, D ** -0.5,
+                                       I3(qo.stride(0), qo.stride(1), qo.stride(2)), I2(m4.stride(0), m4.stride(2)), st), "ll_decode_attn_bf16")
+    assert torch.equal(Ka, Kb) and torch.equal(Va, Vb)
+    assert not torch.equal(Ka, K0)
+    assert torch.equal(out.view(B, S, nh, D), ref)
+    assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ["tiny", "tiny-llama"])
+def test_query_forward_runs_on_the_five_launch_layers(arch, monkeypatch):
+    """GraphedDecoder.continue_hidden on a model with the whole decode stack: the 9 query tokens go through _FusedLayer.run_suffix
+    (five launches per layer) -- hidden states and the nine cache slots within bf16 rounding of the op-by-op path
+    (LLAMOLE_FUSED_SUFFIX=0: RMSNorm, q|k|v, rotary, append, attention, o_proj, add, RMSNorm, gate|up, SiLU*mul, down_proj, add)."""
+    from llamole_amd.llm_accel import _FusedLayer, accelerate_llm, restore_elementwise
+    llm = e2e.build_llm(arch, "cuda", torch.bfloat16)
+    info = accelerate_llm(llm)
+    assert info.get("decode_prologue_1_launch")
+    try:
+        g = torch.Generator().manual_seed(11)
+        prompt = torch.randint(5, 1000, (1, 20), generator=g).cuda()
+        mask = torch.ones_like(prompt)
+        tail = torch.randint(5, 1000, (1, 9), generator=g).cuda()
+        kw = dict(max_new_tokens=16, do_sample=False, pad_token_id=0, eos_token_id=[])
+        calls = []
+        orig = _FusedLayer.run_suffix
+        monkeypatch.setattr(_FusedLayer, "run_suffix", lambda self, *a, **k: (calls.append(a[4:]), orig(self, *a, **k))[1])
+        outs = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("LLAMOLE_FUSED_SUFFIX", mode)
+            d = GraphedDecoder(llm, use_graph=True, fused_cache=True)
+            hs = []
+            for _ in range(3):                       # eager, captured, replayed
+                d.generate(prompt, mask, **kw)
+                hs.append(d.continue_hidden(tail, 20 + 16 - 9).clone())
+            assert torch.equal(hs[0], hs[1]) and torch.equal(hs[0], hs[2])
+            outs[mode] = (hs[0], [(l.keys[:, :, 27:36].clone(), l.values[:, :, 27:36].clone()) for l in d.cache.layers])
+            assert int(d.cache.layers[0].cumulative_length) == 36
+        L = llm.config.num_hidden_layers
+        assert len(calls) == 2 * L and all(c == (1, 9) for c in calls)        # the eager call and the capture; replays launch nothing from Python
+        h0, h1 = outs["0"][0].float(), outs["1"][0].float()
+        assert (h0 - h1).abs().max() <= 3e-2 * h0.abs().max()
+        for (k0, v0), (k1, v1) in zip(outs["0"][1], outs["1"][1]):
+            assert (k0.float() - k1.float()).abs().max() <= 3e-2 * k0.float().abs().max()
+            assert (v0.float() - v1.float()).abs().max() <= 3e-2 * v0.float().abs().max()
+    finally:
+        restore_elementwise(llm)
+
+
 def test_enable_mi355x_decode_on_cpu_model_is_a_plain_static_cache_decoder():
     llm = e2e.build_llm("tiny", "cpu", torch.float32)
     orch, tok = _orchestrator(llm, "cpu", torch.float32)
