@@ -37,6 +37,7 @@ MAX_EW_ROWS = 1 << 20
 # vocabulary-sized outputs for a few hundred rows (the lm_head of a batched `logits_to_keep = 1` forward: 256 x 152 064 x 3584): hipBLASLt
 # picks a 256 x 16 tile there and takes 32 ms (8.6 TFLOP/s); the LDS-DMA ring GEMM streams the 1.09 GB of weights once
 MAX_WIDE_ROWS, WIDE_N = 1024, 65536
+PREFILL_SPLITK = os.environ.get("LLAMOLE_PREFILL_SPLITK", "1") != "0"
 
 
 def _versions(*tensors):
@@ -142,6 +143,14 @@ def _hip_linear_forward(self: nn.Linear, x: torch.Tensor) -> torch.Tensor:
             if bias is None or bias.device != x.device:
                 bias = self.bias.detach().float().contiguous()
                 self._ll_bias_f32, self._ll_bias_key = bias, _versions(self.bias)
+        splits = _prefill_splits(M, N, K)
+        if splits > 1:
+            ws = torch.empty(splits * M * N, dtype=torch.float32, device=x.device)
+            rc = self._ll_lib.ll_linear_splitk_bf16(x2.data_ptr(), K, self.weight.data_ptr(), K, bias.data_ptr() if bias is not None else None,
+                                                    out.data_ptr(), N, M, N, K, 0, splits, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                _lib.check(rc, "ll_linear_splitk_bf16")
+            return out.reshape(*x.shape[:-1], N)
         rc = self._ll_lib.ll_linear(_lib.LL_BF16, x2.data_ptr(), K, self.weight.data_ptr(), K,
                                     bias.data_ptr() if bias is not None else None, out.data_ptr(), N, M, N, K, 0, 0,
                                     torch.cuda.current_stream().cuda_stream)
@@ -252,9 +261,26 @@ def _rmsnorm_forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
     return self._ll_orig_forward(hidden_states)
 
 
+def _prefill_splits(M: int, N: int, K: int) -> int:
+    """65..128 token rows x a matrix of at most ~6 k output rows (q|k|v, o_proj, down_proj of a 7-8 B model at prefill): 64 x 64 output tiles
+    number fewer than half the CUs' worth of workgroups, so K is split in two f32 slabs + a slab sum (tools/prefill_splitk_sweep.py, 128 rows:
+    down_proj 76.7 -> 51.7 us, o_proj 18.4 -> 15.1, q|k|v 20.3 -> 18.7 incl. the sum; gate|up with its 296+ tiles loses: one piece)."""
+    if PREFILL_SPLITK and 64 < M <= MAX_ROWS and K % 128 == 0 and K >= 2048 and 2 * ((N + 63) // 64) < 200:
+        return 2
+    return 1
+
+
 def _gemv(lib, x2: torch.Tensor, w: torch.Tensor, bias, N: int) -> torch.Tensor:
     M, K = x2.shape
     out = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device)
+    splits = _prefill_splits(M, N, K)
+    if splits > 1:
+        ws = torch.empty(splits * M * N, dtype=torch.float32, device=x2.device)
+        rc = lib.ll_linear_splitk_bf16(x2.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if bias is not None else None, out.data_ptr(), N, M, N, K,
+                                       0, splits, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "ll_linear_splitk_bf16")
+        return out
     rc = lib.ll_linear(_lib.LL_BF16, x2.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
                        out.data_ptr(), N, M, N, K, 0, 0, torch.cuda.current_stream().cuda_stream)
     if rc != 0:

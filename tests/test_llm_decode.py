@@ -175,6 +175,40 @@ def test_prefill_sized_rows_and_vocabulary_wide_linear():
 
 
 @pytest.mark.gpu
+def test_prefill_rows_split_k_linear():
+    """65..128 token rows x a matrix with few output tiles (q|k|v, o_proj, down_proj at prefill): K in two f32 slabs + slab sum
+    (ll_linear_splitk_bf16) -- the same product as one piece up to the f32 summation order, bias included; wide outputs and other row
+    counts stay in one piece."""
+    import torch.nn as nn
+    from llamole_amd import llm_accel
+    from llamole_amd.llm_accel import accelerate_linears, restore_linears
+    assert llm_accel._prefill_splits(128, 3584, 18944) == 2 and llm_accel._prefill_splits(128, 4608, 3584) == 2
+    assert llm_accel._prefill_splits(96, 4096, 14336) == 2 and llm_accel._prefill_splits(65, 4096, 4096) == 2
+    assert llm_accel._prefill_splits(128, 2 * 18944, 3584) == 1 and llm_accel._prefill_splits(64, 3584, 18944) == 1
+    assert llm_accel._prefill_splits(129, 3584, 18944) == 1 and llm_accel._prefill_splits(128, 3584, 1024) == 1
+    torch.manual_seed(4)
+    lin = nn.Linear(4096, 1536, bias=True, device="cuda", dtype=torch.bfloat16)
+    holder = nn.ModuleDict({"l": lin})
+    x = torch.randn(2, 50, 4096, device="cuda", dtype=torch.bfloat16)            # 100 rows
+    ref = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double())
+    assert accelerate_linears(holder, min_weight_elems=1) == 1
+    try:
+        with torch.no_grad():
+            got = lin(x)
+            llm_accel.PREFILL_SPLITK = False
+            one = lin(x)
+            llm_accel.PREFILL_SPLITK = True
+    finally:
+        llm_accel.PREFILL_SPLITK = True
+        restore_linears(holder)
+    assert got.shape == (2, 50, 1536) and got.dtype == torch.bfloat16
+    err = (got.double() - ref).abs()
+    assert (err <= 2 ** -8 * ref.abs() + 2e-3).all(), float(err.max())
+    assert ((one.double() - ref).abs() <= 2 ** -8 * ref.abs() + 2e-3).all()
+    assert (got.float() - one.float()).abs().max() <= 2 ** -7 * ref.abs().max()
+
+
+@pytest.mark.gpu
 def test_decode_attention_and_fused_cache():
     """Fused GQA decode attention + KV append vs HF sdpa + StaticLayer.update: logits within bf16 tolerance, identical
     token stream eager vs hipGraph, and cache contents identical to the unfused run."""
