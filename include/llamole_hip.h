@@ -264,6 +264,11 @@ int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, c
 int ll_decode_prologue(const int64_t *position_ids, const float *inv_freq, float attention_scaling, const int64_t *mask2d,
                        int64_t mask_stride, const int64_t *pos, void *cos, void *sin, void *mask_out, int B, int D, int maxlen,
                        void *stream);
+/* ll_decode_prologue_embed : ll_decode_prologue + the embedding rows of the step's input ids (nn.Embedding forward: hidden_out[b] =
+ *     embed_weight[input_ids[b]], bf16 [vocab,H] contiguous, H % 8 == 0; ids must lie in [0, vocab)) in the same launch. */
+int ll_decode_prologue_embed(const int64_t *position_ids, const float *inv_freq, float attention_scaling, const int64_t *mask2d,
+                             int64_t mask_stride, const int64_t *pos, void *cos, void *sin, void *mask_out, const int64_t *input_ids,
+                             const void *embed_weight, int64_t vocab, void *hidden_out, int B, int D, int H, int maxlen, void *stream);
 /* ll_suffix_prologue / ll_suffix_attn_rope_bf16 : the same pair for S consecutive new positions per sequence -- the reference's query-token
  *     re-forward (modeling_llamole.py:641-646: <design_start> + the body tokens) run on top of the decode's KV cache at slots
  *     *pos .. *pos+S-1.  Rows r = b*S + s.  Prologue: cos/sin [B*S,D] for position_ids [B*S], key mask [B*S,maxlen]: key j visible to row
@@ -333,6 +338,16 @@ int ll_sample_token_topk_bf16(const void *logits, int64_t ld, int B, int V, floa
                               const int64_t *seed, const int64_t *eos, int n_eos, int64_t pad, void *done, int64_t *tok,
                               int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid, int64_t *pos,
                               int advance, uint64_t *dbg, void *stream);
+/* ll_sample_token_topk_ws_bf16 : the same with a workspace (ll_sample_workspace_bytes(B) bytes, 16-byte aligned, zero-filled ONCE by the
+ *     caller, one per stream in flight).  With 1 <= top_k <= 128, sampling and no dbg tap the work is split: a first launch of V/2048
+ *     workgroups per row hands on the tokens that can be among the row's k largest, one workgroup per row then finishes on those -- the
+ *     same token as without a workspace for every seed (the one-workgroup path also takes over, on the device, when a row has more than
+ *     16384 candidates).  workspace NULL: ll_sample_token_topk_bf16. */
+int64_t ll_sample_workspace_bytes(int B);
+int ll_sample_token_topk_ws_bf16(const void *logits, int64_t ld, int B, int V, float inv_temp, float top_p, int top_k, int greedy,
+                                 const int64_t *seed, const int64_t *eos, int n_eos, int64_t pad, void *done, int64_t *tok,
+                                 int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid, int64_t *pos, int advance,
+                                 uint64_t *dbg, void *workspace, int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,7 @@ SIGNATURES = {
     "ll_gemv_fused_bf16": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "ll_decode_attn_rope_bf16": (_I, [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _I, _F, _P]),
     "ll_decode_prologue": (_I, [_P, _P, _F, _P, _I64, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ll_decode_prologue_embed": (_I, [_P, _P, _F, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P]),
     "ll_suffix_prologue": (_I, [_P, _P, _F, _P, _I64, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ll_suffix_attn_rope_bf16": (_I, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "ll_dit_set_overlap": (_I, [_P, _I]),
@@ -94,6 +95,8 @@ SIGNATURES = {
     "ll_gin_backward_c": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "ll_sample_token_bf16": (_I, [_P, _I64, _I, _I, _F, _F, _I, _P, _P, _I, _I64, _P, _P, _P, _I64, _I, _P, _P, _P, _I, _P, _P]),
     "ll_sample_token_topk_bf16": (_I, [_P, _I64, _I, _I, _F, _F, _I, _I, _P, _P, _I, _I64, _P, _P, _P, _I64, _I, _P, _P, _P, _I, _P, _P]),
+    "ll_sample_workspace_bytes": (_I64, [_I]),
+    "ll_sample_token_topk_ws_bf16": (_I, [_P, _I64, _I, _I, _F, _F, _I, _I, _P, _P, _I, _I64, _P, _P, _P, _I64, _I, _P, _P, _P, _I, _P, _P, _I64, _P]),
 }
 
 # include/llamole_hip_tuning.h: exported by libllamole_hip_tuning.so only (the LL_TUNING=1 build of the same sources)

@@ -41,6 +41,8 @@ struct SampleArgs {
     long long *pos;            // [1] or null
     int advance;               // also advance posid / pos (decode-loop use)
     unsigned long long *dbg;   // optional [B,4]: Z, kept mass, boundary key, sampled key
+    unsigned int *cand_total;  // optional [B,4]: row header of sample_candidates_kernel -- count, largest key, 0xffff - smallest key (reset to 0 here)
+    const uint2 *cand;         // [B, SAMPLE_CAND_CAP] (key, token index)
 };
 
 __device__ __forceinline__ uint32_t key_of(uint32_t x) {   // x: raw bf16 bits (16 low bits), NaN -> 0, inf -> +-max
@@ -97,18 +99,354 @@ template <int CH> __device__ __forceinline__ void reg_fence(uint32_t (&w)[CH][4]
 constexpr int SAMPLE_BPT = 36;                      // histogram bins per thread
 constexpr int SAMPLE_W = SAMPLE_BPT * 1024;         // key window below the row maximum held in LDS (147 KB of counters)
 constexpr int SAMPLE_TM_BINS = SAMPLE_W / 32;       // 1152
+constexpr int SAMPLE_CAND_CAP = 16384;              // candidates per row the split sampler keeps (more: the one-workgroup path)
+constexpr int SAMPLE_SPLIT_MAX_K = 128;             // ~1.15 k candidates per 2048 tokens: 128 x 1.15 x 80 workgroups < the cap
+
+// First half of the split top-k sampler: 256 threads x 8 tokens per workgroup, many workgroups per row.  Every workgroup hands on the
+// tokens that can be among the row's k largest: those with key >= klo_w, where at least k of the workgroup's THREADS hold such a key (so
+// the row's k-th largest key is >= klo_w, and a token of this workgroup below klo_w cannot survive TopKLogitsWarper).  klo_w = the
+// smallest, over the four waves, of the ceil(k/4)-th largest thread maximum of the wave (64-lane bitonic sort).  Candidates
+// (key, token index) are appended to the row's list in the workspace; the list's order is arbitrary and nothing downstream depends on it.
+__global__ __launch_bounds__(256) void sample_candidates_kernel(const bf16_t *__restrict__ logits, int64_t ld, int V, int top_k,
+                                                                unsigned int *__restrict__ hdr, uint2 *__restrict__ cand) {
+    __shared__ uint32_t list[2048];
+    __shared__ uint32_t sh_b[4];
+    __shared__ unsigned int sh_n, sh_base, sh_mx, sh_mninv;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunk = V / 8, first = blockIdx.x * 256;
+    // the last workgroup of a row looks at the row's LAST 256 chunks (a full set of thread maxima for the bound: the tokens it shares
+    // with its neighbour are tokens of the row all the same) and hands on only the ones from its own range
+    const int start = (first + 256 > nchunk && nchunk >= 256) ? nchunk - 256 : first;
+    const int c = start + tid;
+    const bool own = c >= first;
+    uint32_t k[4] = {0u, 0u, 0u, 0u};
+    if (c < nchunk) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(logits + (int64_t)b * ld + (int64_t)c * 8);
+        const uint32_t r[4] = {v.x, v.y, v.z, v.w};
+        const bool special = ((pair_special(r[0]) | pair_special(r[1]) | pair_special(r[2]) | pair_special(r[3])) & 0x80008000u) != 0u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) k[t] = special ? keys_of_pair(r[t]) : keys_of_finite_pair(r[t]);
+    }
+    const uint32_t kp = pk_max_u16(pk_max_u16(k[0], k[1]), pk_max_u16(k[2], k[3]));
+    uint32_t v = max(kp & 0xffffu, kp >> 16);         // thread maximum (0: no token)
+    if (tid == 0) { sh_n = 0; sh_mx = 0; sh_mninv = 0; }
+    // ascending bitonic sort of the wave's 64 thread maxima
+#pragma unroll
+    for (int sz = 2; sz <= 64; sz <<= 1) {
+#pragma unroll
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+            const uint32_t o = __shfl_xor(v, st, 64);
+            v = (((lane & sz) == 0) == ((lane & st) == 0)) ? min(v, o) : max(v, o);
+        }
+    }
+    const int kq = (top_k + 3) / 4;                   // 1..64
+    const uint32_t bw = __shfl(v, 64 - kq, 64);       // the kq-th largest of this wave
+    if (lane == 0) sh_b[wave] = bw;
+    __syncthreads();
+    const uint32_t klo = max(1u, min(min(sh_b[0], sh_b[1]), min(sh_b[2], sh_b[3])));
+    uint32_t mx = 0, mninv = 0;
+    if (own) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const uint32_t key = hh ? (k[t] >> 16) : (k[t] & 0xffffu);
+                if (key >= klo) {
+                    list[atomicAdd(&sh_n, 1u)] = key | ((uint32_t)(tid * 8 + t * 2 + hh) << 16);
+                    mx = max(mx, key);
+                    mninv = max(mninv, 0xffffu - key);
+                }
+            }
+        }
+    }
+    if (mx) { atomicMax(&sh_mx, mx); atomicMax(&sh_mninv, mninv); }
+    __syncthreads();
+    const uint32_t n = sh_n;
+    if (tid == 0 && n) {
+        // row header: [0] candidates so far, [1] their largest key, [2] 0xffff - their smallest key (all three start from, and are put
+        // back to, zero)
+        sh_base = atomicAdd(&hdr[b * 4], n);
+        atomicMax(&hdr[b * 4 + 1], sh_mx);
+        atomicMax(&hdr[b * 4 + 2], sh_mninv);
+    }
+    __syncthreads();
+    const uint32_t base = sh_base;
+    uint2 *dst = cand + (int64_t)b * SAMPLE_CAND_CAP;
+    for (uint32_t j = tid; j < n; j += 256) {
+        if (base + j < (uint32_t)SAMPLE_CAND_CAP) {
+            const uint32_t e = list[j];
+            dst[base + j] = make_uint2(e & 0xffffu, (uint32_t)start * 8u + (e >> 16));
+        }
+    }
+}
+
+// LDS of the per-row workgroup (1024 threads)
+struct SampleLds {
+    uint32_t cnt[SAMPLE_W];              // cnt[d] = number of tokens whose key is kmax - d
+    unsigned long long wsum[16];
+    float redf[16];
+    unsigned int redu[16];
+    unsigned long long tail, R, Zk;
+    unsigned int d, key, rank, tok, dk, klo, nm;
+    uint32_t tmh[SAMPLE_TM_BINS + 1];    // thread maxima per 32-key bin below the row maximum (top-k lower bound)
+    long long eos[64];                   // the first EOS ids, the row's step counter and stop flag: requested at kernel start
+    long long step;
+    unsigned int done, stop;
+};
+
+// Steps 3 and 4 on the histogram cnt[0 .. kmax - klo]: top-k cut, nucleus boundary, one Philox draw -> the sampled VALUE k2 and the rank
+// of the token among those sharing it.  Expects a barrier behind the last histogram update.
+__device__ __forceinline__ void nucleus_scan(SampleLds &L, const SampleArgs &a, int b, int tid, int lane, int wave, uint32_t kmax,
+                                             uint32_t klo, float m, uint32_t &k2, uint32_t &rank) {
+    uint32_t (&cnt)[SAMPLE_W] = L.cnt;
+    unsigned long long (&wsum)[16] = L.wsum;
+    float (&redf)[16] = L.redf;
+    unsigned int (&redu)[16] = L.redu;
+    uint32_t (&tmh)[SAMPLE_TM_BINS + 1] = L.tmh;
+    unsigned long long &sh_tail = L.tail, &sh_R = L.R, &sh_Zk = L.Zk;
+    unsigned int &sh_d = L.d, &sh_key = L.key, &sh_rank = L.rank, &sh_tok = L.tok, &sh_dk = L.dk, &sh_klo = L.klo, &sh_nm = L.nm;
+    (void)cnt; (void)wsum; (void)redf; (void)redu; (void)tmh; (void)sh_tail; (void)sh_R; (void)sh_Zk; (void)sh_d; (void)sh_key; (void)sh_rank;
+    (void)sh_tok; (void)sh_dk; (void)sh_klo; (void)sh_nm;
+    // ---- 3. thread t owns d in [bpt t, bpt t + bpt), descending values: masses = count * 2^-40 fixed-point exp.  All 36 bins per
+    // thread without the bound; with it only [0, kmax - klo] can be non-empty (typically one bin per thread)
+    const int bpt = klo ? (int)((kmax - klo) >> 10) + 1 : SAMPLE_BPT;
+    const int d0 = tid * bpt;
+    unsigned long long lsum = 0;
+    for (int i = 0; i < bpt; ++i) {
+        const uint32_t c = cnt[d0 + i];
+        if (c && (uint32_t)(d0 + i) < kmax) lsum += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
+    }
+    unsigned long long inc = lsum;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const unsigned long long o = __shfl_up(inc, dd, 64);
+        if (lane >= dd) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned long long base = 0, Z = sh_tail;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < wave) base += wsum[i];
+        Z += wsum[i];
+    }
+    base = uniform64(base);
+    Z = uniform64(Z);
+    const unsigned long long excl = base + inc - lsum;
+    // top-k ahead of top-p (HF order: temperature, TopKLogitsWarper, TopPLogitsWarper; the reference's GeneratingArguments
+    // default top_k = 50): the cut is the value of the k-th largest token, tokens tied with it stay (HF removes
+    // logits < kth value); the nucleus is then taken over the renormalised survivors, i.e. against their mass Zk
+    uint32_t dk = 0xffffffffu;
+    unsigned long long Zk = Z;
+    if (a.top_k > 0) {
+        uint32_t lc = 0;
+        for (int i = 0; i < bpt; ++i) {
+            const uint32_t c = cnt[d0 + i];
+            if (c && (uint32_t)(d0 + i) < kmax) lc += c;
+        }
+        uint32_t incc = lc;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t o = __shfl_up(incc, dd, 64);
+            if (lane >= dd) incc += o;
+        }
+        if (lane == 63) redu[wave] = incc;
+        __syncthreads();
+        uint32_t basec = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < wave) basec += redu[i];
+        const uint32_t exclc = basec + incc - lc;
+        const uint32_t kk = (uint32_t)a.top_k;
+        if (exclc < kk && exclc + lc >= kk) {        // exactly one thread: its bins hold the k-th largest token
+            uint32_t run = exclc;
+            unsigned long long A = excl;
+            for (int i = 0; i < bpt; ++i) {
+                const uint32_t c = cnt[d0 + i];
+                if (c && (uint32_t)(d0 + i) < kmax) {
+                    run += c;
+                    A += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
+                    if (run >= kk) {
+                        sh_dk = (unsigned int)(d0 + i);
+                        sh_Zk = A;
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        dk = __builtin_amdgcn_readfirstlane(sh_dk);                                  // stays ~0 when fewer than k tokens lie in the window: nothing is cut
+        if (dk != 0xffffffffu) Zk = uniform64(sh_Zk);
+    }
+    const unsigned long long Tq = a.top_p >= 1.f ? ~0ull : (unsigned long long)((double)a.top_p * (double)Zk);
+    // boundary: the lowest value whose mass-above is still < Tq (mass-above is non-decreasing in d)
+    {
+        unsigned long long A = excl;
+        int last = -1;
+        for (int i = 0; i < bpt; ++i) {
+            const uint32_t c = cnt[d0 + i];
+            if (c && (uint32_t)(d0 + i) < kmax) {
+                if (A < Tq && (uint32_t)(d0 + i) <= dk) last = d0 + i;
+                A += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
+            }
+        }
+        if (last >= 0) atomicMax(&sh_d, (unsigned int)last);
+    }
+    __syncthreads();
+    const uint32_t dtau = __builtin_amdgcn_readfirstlane(sh_d);      // 0 when nothing else qualifies: the top value is always kept
+    if (dtau >= (uint32_t)d0 && dtau < (uint32_t)(d0 + bpt)) {
+        unsigned long long A = excl;
+        for (int i = 0; i < bpt; ++i) {
+            const uint32_t c = cnt[d0 + i];
+            if (c && (uint32_t)(d0 + i) < kmax) {
+                A += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
+                if ((uint32_t)(d0 + i) == dtau) break;
+            }
+        }
+        unsigned long long M = A;    // kept mass: everything down to and including the boundary value
+        if (a.top_p >= 1.f && dk == 0xffffffffu) M = Z;   // tail included when nothing is filtered
+        const unsigned long long sd = (unsigned long long)*a.seed;
+        const unsigned long long st = (unsigned long long)a.step[b];
+        const uint4 rnd = philox4x32(make_uint4((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)b, 0x5A17u),
+                                     make_uint2((uint32_t)sd, (uint32_t)(sd >> 32)));
+        const unsigned long long r64 = ((unsigned long long)rnd.x << 32) | rnd.y;
+        sh_R = __umul64hi(r64, M);
+        if (a.dbg) { a.dbg[b * 4 + 0] = Z; a.dbg[b * 4 + 1] = M; a.dbg[b * 4 + 2] = kmax - dtau; }
+    }
+    if (tid == 0) { sh_key = kmax; sh_rank = 0; }
+    __syncthreads();
+    // ---- 4. the value whose mass interval contains R, and the rank among the tokens sharing it
+    const unsigned long long R = uniform64(sh_R);
+    if (R >= excl && R < excl + lsum) {
+        unsigned long long A = excl;
+        for (int i = 0; i < bpt; ++i) {
+            const uint32_t c = cnt[d0 + i];
+            if (c && (uint32_t)(d0 + i) < kmax) {
+                const unsigned long long q = mass_of(kmax - (d0 + i), a.inv_temp, m);
+                const unsigned long long ms = (unsigned long long)c * q;
+                if (R < A + ms) {
+                    unsigned long long r = q ? (R - A) / q : 0;
+                    if (r >= c) r = c - 1;
+                    sh_key = kmax - (d0 + i);
+                    sh_rank = (uint32_t)r;
+                    break;
+                }
+                A += ms;
+            }
+        }
+    }
+    __syncthreads();
+    k2 = __builtin_amdgcn_readfirstlane(sh_key);      // (R in the tail mass, possible only with top_p >= 1 and a > 288-binade spread: the top value)
+    rank = __builtin_amdgcn_readfirstlane(sh_rank);
+    if (a.dbg && tid == 0) a.dbg[b * 4 + 3] = k2;
+}
+
+// Requested at kernel start, used by sample_finish behind many barriers: the row's step counter / stop flag and the EOS ids.
+__device__ __forceinline__ void sample_prefetch(SampleLds &L, const SampleArgs &a, int b, int tid) {
+    if (tid < 64 && tid < a.n_eos) L.eos[tid] = a.eos[tid];
+    if (tid == 64) { L.step = a.step[b]; L.done = a.done[b]; L.stop = 0; }
+}
+
+// Loop bookkeeping of the row (after a barrier): pad rows that already stopped, EOS test, token -> output buffer and next input, counters.
+__device__ __forceinline__ void sample_finish(SampleLds &L, const SampleArgs &a, int b, int tid) {
+    __syncthreads();
+    if (tid < 64) {
+        const long long t = L.step;
+        const long long nxt = L.done ? a.pad : (long long)L.tok;
+        bool hit = tid < a.n_eos && L.eos[tid] == nxt;
+        for (int i = 64 + tid; i < a.n_eos; i += 64) hit = hit || (a.eos[i] == nxt);
+        const bool stop = __any(hit);
+        if (tid == 0) {
+            if (a.cand_total) *reinterpret_cast<uint4 *>(a.cand_total + b * 4) = make_uint4(0, 0, 0, 0);   // the row's list is consumed
+            if (t >= 0 && t < a.max_new) a.out_tokens[(int64_t)b * a.ld_out + t] = nxt;
+            a.tok[b] = nxt;
+            if (stop) a.done[b] = 1;
+            a.step[b] = t + 1;
+            if (a.advance) {
+                if (a.posid) a.posid[b] += 1;
+                if (a.pos && b == 0) a.pos[0] += 1;
+            }
+        }
+    }
+}
+
+// Second half of the split top-k sampler: the row's candidates (sample_candidates_kernel) instead of the row.  Every token whose key
+// is >= the row's k-th largest key is a candidate, so the histogram bins down to the top-k cut are complete; bins further down may
+// miss tokens of other workgroups and nothing reads them (the nucleus boundary lies above the cut).  Returns false -- nothing but LDS
+// scratch touched -- when the list overflowed (ties) or spans more than the key window: the caller then reads the row.
+template <int CH>
+__device__ __forceinline__ bool sample_fast(SampleLds &L, const SampleArgs &a, int b, int tid, int lane, int wave) {
+    uint32_t (&cnt)[SAMPLE_W] = L.cnt;
+    unsigned long long (&wsum)[16] = L.wsum;
+    float (&redf)[16] = L.redf;
+    unsigned int (&redu)[16] = L.redu;
+    uint32_t (&tmh)[SAMPLE_TM_BINS + 1] = L.tmh;
+    unsigned long long &sh_tail = L.tail, &sh_R = L.R, &sh_Zk = L.Zk;
+    unsigned int &sh_d = L.d, &sh_key = L.key, &sh_rank = L.rank, &sh_tok = L.tok, &sh_dk = L.dk, &sh_klo = L.klo, &sh_nm = L.nm;
+    (void)cnt; (void)wsum; (void)redf; (void)redu; (void)tmh; (void)sh_tail; (void)sh_R; (void)sh_Zk; (void)sh_d; (void)sh_key; (void)sh_rank;
+    (void)sh_tok; (void)sh_dk; (void)sh_klo; (void)sh_nm;
+    const uint4 hd = *reinterpret_cast<const uint4 *>(a.cand_total + b * 4);
+    const uint32_t ncand = __builtin_amdgcn_readfirstlane(hd.x), kmax = __builtin_amdgcn_readfirstlane(hd.y),
+                   klo = 0xffffu - __builtin_amdgcn_readfirstlane(hd.z);
+    if (a.greedy || a.top_k <= 0 || ncand < 1u || ncand > (uint32_t)SAMPLE_CAND_CAP) return false;
+    if (klo == 0u || kmax < klo || kmax - klo >= (uint32_t)SAMPLE_W) return false;       // (a spread of more than 288 binades among the candidates)
+    // the candidates stay in registers: up to 16 per thread = the cap
+    const uint2 *cand = a.cand + (int64_t)b * SAMPLE_CAND_CAP;
+    uint2 cr[SAMPLE_CAND_CAP / 1024];
+#pragma unroll
+    for (int i = 0; i < SAMPLE_CAND_CAP / 1024; ++i) {
+        const uint32_t j = tid + i * 1024;
+        cr[i] = j < ncand ? cand[j] : make_uint2(0u, 0u);                               // key 0 = none
+    }
+    if (tid == 0) { sh_tail = 0; sh_d = 0; sh_tok = 0; sh_dk = 0xffffffffu; sh_Zk = 0; sh_nm = 0; }
+    const int bpt = (int)((kmax - klo) >> 10) + 1;     // the scan's bins per thread: zero exactly those
+    for (int i = 0; i < bpt; ++i) cnt[tid * bpt + i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SAMPLE_CAND_CAP / 1024; ++i)
+        if (cr[i].x) atomicAdd(&cnt[kmax - cr[i].x], 1u);
+    __syncthreads();
+    uint32_t k2 = kmax, rank = 0;
+    nucleus_scan(L, a, b, tid, lane, wave, kmax, klo, scaled(kmax, a.inv_temp), k2, rank);
+    // the rank-th token with the value k2, counted in the order the one-workgroup path enumerates a row -- thread (chunk mod 1024)
+    // first, then chunk / 1024, then the element -- so both paths pick the same token.  The matches' order keys go to the histogram's
+    // LDS (free now); each match counts the smaller ones.
+#pragma unroll
+    for (int i = 0; i < SAMPLE_CAND_CAP / 1024; ++i) {
+        if (cr[i].x == k2) {
+            const uint32_t c = cr[i].y >> 3;
+            cnt[atomicAdd(&sh_nm, 1u)] = (c & 1023u) * (uint32_t)(CH * 8) + (c >> 10) * 8u + (cr[i].y & 7u);
+        }
+    }
+    __syncthreads();
+    const uint32_t nm = sh_nm;
+    for (uint32_t t = tid; t < nm; t += 1024) {
+        const uint32_t o = cnt[t];
+        uint32_t below = 0;
+        for (uint32_t j = 0; j < nm; ++j) below += cnt[j] < o ? 1u : 0u;
+        if (below == rank) {
+            const uint32_t rem = o % (uint32_t)(CH * 8);
+            sh_tok = ((rem >> 3) * 1024u + o / (uint32_t)(CH * 8)) * 8u + (rem & 7u);
+        }
+    }
+    sample_finish(L, a, b, tid);
+    return true;
+}
 
 template <int CH>
 __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
-    __shared__ uint32_t cnt[SAMPLE_W];              // cnt[d] = number of tokens whose key is kmax - d
-    __shared__ unsigned long long wsum[16];
-    __shared__ float redf[16];
-    __shared__ unsigned int redu[16];
-    __shared__ unsigned long long sh_tail, sh_R;
-    __shared__ unsigned int sh_d, sh_key, sh_rank, sh_tok, sh_dk;
-    __shared__ unsigned long long sh_Zk;
-    __shared__ uint32_t tmh[SAMPLE_TM_BINS + 1];    // thread maxima per 32-key bin below the row maximum (top-k lower bound)
-    __shared__ unsigned int sh_klo;
+    __shared__ SampleLds L;
+    sample_prefetch(L, a, blockIdx.x, threadIdx.x);
+    if (a.cand_total && sample_fast<CH>(L, a, blockIdx.x, threadIdx.x, threadIdx.x & 63, threadIdx.x >> 6)) return;
+    uint32_t (&cnt)[SAMPLE_W] = L.cnt;
+    unsigned long long (&wsum)[16] = L.wsum;
+    float (&redf)[16] = L.redf;
+    unsigned int (&redu)[16] = L.redu;
+    uint32_t (&tmh)[SAMPLE_TM_BINS + 1] = L.tmh;
+    unsigned long long &sh_tail = L.tail, &sh_R = L.R, &sh_Zk = L.Zk;
+    unsigned int &sh_d = L.d, &sh_key = L.key, &sh_rank = L.rank, &sh_tok = L.tok, &sh_dk = L.dk, &sh_klo = L.klo, &sh_nm = L.nm;
+    (void)cnt; (void)wsum; (void)redf; (void)redu; (void)tmh; (void)sh_tail; (void)sh_R; (void)sh_Zk; (void)sh_d; (void)sh_key; (void)sh_rank;
+    (void)sh_tok; (void)sh_dk; (void)sh_klo; (void)sh_nm;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bf16_t *row = a.logits + (int64_t)b * a.ld;
     const int nchunk = a.V / 8;
@@ -225,138 +563,7 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
             }
         }
         __syncthreads();
-        // ---- 3. thread t owns d in [bpt t, bpt t + bpt), descending values: masses = count * 2^-40 fixed-point exp.  All 36 bins per
-        // thread without the bound; with it only [0, kmax - klo] can be non-empty (typically one bin per thread)
-        const int bpt = klo ? (int)((kmax - klo) >> 10) + 1 : SAMPLE_BPT;
-        const int d0 = tid * bpt;
-        unsigned long long lsum = 0;
-        for (int i = 0; i < bpt; ++i) {
-            const uint32_t c = cnt[d0 + i];
-            if (c && (uint32_t)(d0 + i) < kmax) lsum += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
-        }
-        unsigned long long inc = lsum;
-#pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-            const unsigned long long o = __shfl_up(inc, dd, 64);
-            if (lane >= dd) inc += o;
-        }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        unsigned long long base = 0, Z = sh_tail;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (i < wave) base += wsum[i];
-            Z += wsum[i];
-        }
-        base = uniform64(base);
-        Z = uniform64(Z);
-        const unsigned long long excl = base + inc - lsum;
-        // top-k ahead of top-p (HF order: temperature, TopKLogitsWarper, TopPLogitsWarper; the reference's GeneratingArguments
-        // default top_k = 50): the cut is the value of the k-th largest token, tokens tied with it stay (HF removes
-        // logits < kth value); the nucleus is then taken over the renormalised survivors, i.e. against their mass Zk
-        uint32_t dk = 0xffffffffu;
-        unsigned long long Zk = Z;
-        if (a.top_k > 0) {
-            uint32_t lc = 0;
-            for (int i = 0; i < bpt; ++i) {
-                const uint32_t c = cnt[d0 + i];
-                if (c && (uint32_t)(d0 + i) < kmax) lc += c;
-            }
-            uint32_t incc = lc;
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                const uint32_t o = __shfl_up(incc, dd, 64);
-                if (lane >= dd) incc += o;
-            }
-            if (lane == 63) redu[wave] = incc;
-            __syncthreads();
-            uint32_t basec = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (i < wave) basec += redu[i];
-            const uint32_t exclc = basec + incc - lc;
-            const uint32_t kk = (uint32_t)a.top_k;
-            if (exclc < kk && exclc + lc >= kk) {        // exactly one thread: its bins hold the k-th largest token
-                uint32_t run = exclc;
-                unsigned long long A = excl;
-                for (int i = 0; i < bpt; ++i) {
-                    const uint32_t c = cnt[d0 + i];
-                    if (c && (uint32_t)(d0 + i) < kmax) {
-                        run += c;
-                        A += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
-                        if (run >= kk) {
-                            sh_dk = (unsigned int)(d0 + i);
-                            sh_Zk = A;
-                            break;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            dk = __builtin_amdgcn_readfirstlane(sh_dk);                                  // stays ~0 when fewer than k tokens lie in the window: nothing is cut
-            if (dk != 0xffffffffu) Zk = uniform64(sh_Zk);
-        }
-        const unsigned long long Tq = a.top_p >= 1.f ? ~0ull : (unsigned long long)((double)a.top_p * (double)Zk);
-        // boundary: the lowest value whose mass-above is still < Tq (mass-above is non-decreasing in d)
-        {
-            unsigned long long A = excl;
-            int last = -1;
-            for (int i = 0; i < bpt; ++i) {
-                const uint32_t c = cnt[d0 + i];
-                if (c && (uint32_t)(d0 + i) < kmax) {
-                    if (A < Tq && (uint32_t)(d0 + i) <= dk) last = d0 + i;
-                    A += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
-                }
-            }
-            if (last >= 0) atomicMax(&sh_d, (unsigned int)last);
-        }
-        __syncthreads();
-        const uint32_t dtau = __builtin_amdgcn_readfirstlane(sh_d);      // 0 when nothing else qualifies: the top value is always kept
-        if (dtau >= (uint32_t)d0 && dtau < (uint32_t)(d0 + bpt)) {
-            unsigned long long A = excl;
-            for (int i = 0; i < bpt; ++i) {
-                const uint32_t c = cnt[d0 + i];
-                if (c && (uint32_t)(d0 + i) < kmax) {
-                    A += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
-                    if ((uint32_t)(d0 + i) == dtau) break;
-                }
-            }
-            unsigned long long M = A;    // kept mass: everything down to and including the boundary value
-            if (a.top_p >= 1.f && dk == 0xffffffffu) M = Z;   // tail included when nothing is filtered
-            const unsigned long long sd = (unsigned long long)*a.seed;
-            const unsigned long long st = (unsigned long long)a.step[b];
-            const uint4 rnd = philox4x32(make_uint4((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)b, 0x5A17u),
-                                         make_uint2((uint32_t)sd, (uint32_t)(sd >> 32)));
-            const unsigned long long r64 = ((unsigned long long)rnd.x << 32) | rnd.y;
-            sh_R = __umul64hi(r64, M);
-            if (a.dbg) { a.dbg[b * 4 + 0] = Z; a.dbg[b * 4 + 1] = M; a.dbg[b * 4 + 2] = kmax - dtau; }
-        }
-        if (tid == 0) { sh_key = kmax; sh_rank = 0; }
-        __syncthreads();
-        // ---- 4. the value whose mass interval contains R, and the rank among the tokens sharing it
-        const unsigned long long R = uniform64(sh_R);
-        if (R >= excl && R < excl + lsum) {
-            unsigned long long A = excl;
-            for (int i = 0; i < bpt; ++i) {
-                const uint32_t c = cnt[d0 + i];
-                if (c && (uint32_t)(d0 + i) < kmax) {
-                    const unsigned long long q = mass_of(kmax - (d0 + i), a.inv_temp, m);
-                    const unsigned long long ms = (unsigned long long)c * q;
-                    if (R < A + ms) {
-                        unsigned long long r = q ? (R - A) / q : 0;
-                        if (r >= c) r = c - 1;
-                        sh_key = kmax - (d0 + i);
-                        sh_rank = (uint32_t)r;
-                        break;
-                    }
-                    A += ms;
-                }
-            }
-        }
-        __syncthreads();
-        k2 = __builtin_amdgcn_readfirstlane(sh_key);      // (R in the tail mass, possible only with top_p >= 1 and a > 288-binade spread: the top value)
-        rank = __builtin_amdgcn_readfirstlane(sh_rank);
-        if (a.dbg && tid == 0) a.dbg[b * 4 + 3] = k2;
+        nucleus_scan(L, a, b, tid, lane, wave, kmax, klo, m, k2, rank);
     }
     // ---- 5. the rank-th token whose key is k2 (greedy: the lowest index holding the maximum, like torch.argmax)
     reg_fence<CH>(w);
@@ -415,55 +622,63 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
             sh_tok = found;
         }
     }
-    __syncthreads();
-    if (tid == 0) {
-        const long long t = a.step[b];
-        long long nxt = a.done[b] ? a.pad : (long long)sh_tok;
-        if (t >= 0 && t < a.max_new) a.out_tokens[(int64_t)b * a.ld_out + t] = nxt;
-        a.tok[b] = nxt;
-        bool stop = false;
-        for (int i = 0; i < a.n_eos; ++i) stop = stop || (a.eos[i] == nxt);
-        if (stop) a.done[b] = 1;
-        a.step[b] = t + 1;
-        if (a.advance) {
-            if (a.posid) a.posid[b] += 1;
-            if (a.pos && b == 0) a.pos[0] += 1;
-        }
-    }
+    sample_finish(L, a, b, tid);
 }
 
 }  // namespace ll
 
 using namespace ll;
 
-extern "C" int ll_sample_token_topk_bf16(const void *logits, int64_t ld, int B, int V, float inv_temp, float top_p, int top_k, int greedy,
-                                         const int64_t *seed, const int64_t *eos, int n_eos, int64_t pad, void *done, int64_t *tok,
-                                         int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid,
-                                         int64_t *pos, int advance, uint64_t *dbg, void *stream);
+extern "C" int ll_sample_token_topk_ws_bf16(const void *logits, int64_t ld, int B, int V, float inv_temp, float top_p, int top_k, int greedy,
+                                            const int64_t *seed, const int64_t *eos, int n_eos, int64_t pad, void *done, int64_t *tok,
+                                            int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid,
+                                            int64_t *pos, int advance, uint64_t *dbg, void *workspace, int64_t workspace_bytes, void *stream);
 
 extern "C" int ll_sample_token_bf16(const void *logits, int64_t ld, int B, int V, float inv_temp, float top_p, int greedy,
                                     const int64_t *seed, const int64_t *eos, int n_eos, int64_t pad, void *done, int64_t *tok,
                                     int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid,
                                     int64_t *pos, int advance, uint64_t *dbg, void *stream) {
-    return ll_sample_token_topk_bf16(logits, ld, B, V, inv_temp, top_p, 0, greedy, seed, eos, n_eos, pad, done, tok, out_tokens, ld_out,
-                                     max_new, step, posid, pos, advance, dbg, stream);
+    return ll_sample_token_topk_ws_bf16(logits, ld, B, V, inv_temp, top_p, 0, greedy, seed, eos, n_eos, pad, done, tok, out_tokens, ld_out,
+                                        max_new, step, posid, pos, advance, dbg, nullptr, 0, stream);
 }
 
 extern "C" int ll_sample_token_topk_bf16(const void *logits, int64_t ld, int B, int V, float inv_temp, float top_p, int top_k, int greedy,
                                          const int64_t *seed, const int64_t *eos, int n_eos, int64_t pad, void *done, int64_t *tok,
                                          int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid,
                                          int64_t *pos, int advance, uint64_t *dbg, void *stream) {
+    return ll_sample_token_topk_ws_bf16(logits, ld, B, V, inv_temp, top_p, top_k, greedy, seed, eos, n_eos, pad, done, tok, out_tokens, ld_out,
+                                        max_new, step, posid, pos, advance, dbg, nullptr, 0, stream);
+}
+
+extern "C" int64_t ll_sample_workspace_bytes(int B) { return B <= 0 ? 0 : (int64_t)B * (16 + (int64_t)SAMPLE_CAND_CAP * 8); }
+
+extern "C" int ll_sample_token_topk_ws_bf16(const void *logits, int64_t ld, int B, int V, float inv_temp, float top_p, int top_k, int greedy,
+                                            const int64_t *seed, const int64_t *eos, int n_eos, int64_t pad, void *done, int64_t *tok,
+                                            int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid,
+                                            int64_t *pos, int advance, uint64_t *dbg, void *workspace, int64_t workspace_bytes, void *stream) {
     LL_CHECK(logits && seed && done && tok && out_tokens && step && (n_eos == 0 || eos), "ll_sample_token_bf16: null argument");
     LL_CHECK(B >= 1 && V >= 8 && V % 8 == 0 && V <= 1024 * 8 * 20 && ld % 8 == 0,
              "ll_sample_token_bf16: vocabulary %d must be a multiple of 8 and <= 163840", V);
     LL_CHECK(greedy || (inv_temp > 0.f && top_p >= 0.f), "ll_sample_token_bf16: temperature and top_p must be positive");
+    LL_CHECK(!workspace || (workspace_bytes >= ll_sample_workspace_bytes(B) && ((uintptr_t)workspace & 15) == 0),
+             "ll_sample_token_topk_ws_bf16: workspace of %lld bytes, need %lld (16-byte aligned)", (long long)workspace_bytes,
+             (long long)ll_sample_workspace_bytes(B));
     SampleArgs a;
     a.logits = (const bf16_t *)logits; a.ld = ld; a.V = V; a.inv_temp = inv_temp; a.top_p = top_p; a.top_k = top_k < 0 ? 0 : top_k; a.greedy = greedy;
     a.seed = (const long long *)seed; a.eos = (const long long *)eos; a.n_eos = n_eos; a.pad = pad;
     a.done = (unsigned char *)done; a.tok = (long long *)tok; a.out_tokens = (long long *)out_tokens; a.ld_out = ld_out;
     a.max_new = max_new; a.step = (long long *)step; a.posid = (long long *)posid; a.pos = (long long *)pos;
     a.advance = advance; a.dbg = (unsigned long long *)dbg;
+    a.cand_total = nullptr; a.cand = nullptr;
     hipStream_t s = (hipStream_t)stream;
+    // sampling with top-k of at most 128 and a workspace: many workgroups pick the row's candidates, one workgroup per row finishes on them
+    // (the same token as the one-workgroup path, which still takes over when a row has more than 16384 candidates)
+    if (workspace && !greedy && a.top_k >= 1 && a.top_k <= SAMPLE_SPLIT_MAX_K && !dbg) {
+        a.cand_total = (unsigned int *)workspace;
+        a.cand = (const uint2 *)((char *)workspace + (size_t)B * 16);
+        hipLaunchKernelGGL(sample_candidates_kernel, dim3(cdiv(V / 8, 256), B), dim3(256), 0, s, (const bf16_t *)logits, ld, V, a.top_k,
+                           a.cand_total, (uint2 *)a.cand);
+    }
     const int per = cdiv(V, 8 * 1024);
     if (per <= 2) hipLaunchKernelGGL((sample_token_kernel<2>), dim3(B), dim3(1024), 0, s, a);
     else if (per <= 8) hipLaunchKernelGGL((sample_token_kernel<8>), dim3(B), dim3(1024), 0, s, a);

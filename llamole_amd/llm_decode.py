@@ -89,6 +89,10 @@ class GraphedDecoder:
         # other mask decisions while a stream is capturing (masking_utils.is_tracing), i.e. other SDPA kernels and roundings than the
         # eager prefill, and under the overlapped trajectory the prefill is device-bound anyway (HISTORY R5.8).
         self.graph_suffix = self.use_graph and os.environ.get("LLAMOLE_GRAPH_SUFFIX", "1") != "0"
+        # token tail at one sequence: final RMSNorm inside the lm_head GEMV, the fused sampler advances the cache position (no add_ launch)
+        self.fuse_head = os.environ.get("LLAMOLE_FUSE_HEAD", "1") != "0"
+        self.split_sampler = os.environ.get("LLAMOLE_SPLIT_SAMPLER", "1") != "0"     # top-k sampling as two launches (candidates, finish)
+        self.sample_ws = None
         self.max_side_graphs = 4
         self._side_graphs = {}
         self._sample_key = None
@@ -116,6 +120,7 @@ class GraphedDecoder:
         self.seed_buf = torch.zeros(1, dtype=torch.long, device=device)
         self.eos_buf = torch.full((N_EOS_SLOTS,), -1, dtype=torch.long, device=device)
         self.logits = None
+        self.sample_ws = None
         self._graph = None
         self._cache_fused = False
         self._side_graphs = {}          # captured against the buffers above
@@ -159,12 +164,31 @@ class GraphedDecoder:
         g.replay()
         return out
 
-    def _step(self):
-        out = self.model(input_ids=self.tok, attention_mask=self.mask, past_key_values=self.cache,
-                         cache_position=self.pos, position_ids=self.posid, use_cache=True, return_dict=True)
-        if self._cache_fused:   # the fused per-layer appends all used layer 0's counter; advance it once per forward
+    def _step(self, advance: bool = True):
+        """One forward over ``self.tok`` at the cache position.  ``advance=False``: the caller's next launch (the fused sampler) moves the
+        fused cache's position counter."""
+        head = None
+        if self._cache_fused and self.tok.shape[0] == 1 and self.tok.shape[1] == 1 and self.fuse_head:
+            from .llm_accel import head_fusable, norm_head
+            head = head_fusable(self.model)
+        if head is not None:
+            # one sequence on the fused stack: the base model hands back the un-normed hidden state and the final RMSNorm runs as the
+            # prologue of the vocabulary GEMV (one launch less per token, same arithmetic)
+            base, st = head
+            st["skip_norm"], st["norm_skipped"] = True, False
+            try:
+                h = base(input_ids=self.tok, attention_mask=self.mask, past_key_values=self.cache, cache_position=self.pos,
+                         position_ids=self.posid, use_cache=True, return_dict=True).last_hidden_state[:, -1, :]
+            finally:
+                st["skip_norm"] = False
+            logits = norm_head(self.model, h) if st["norm_skipped"] else self.model.lm_head(h)
+        else:
+            out = self.model(input_ids=self.tok, attention_mask=self.mask, past_key_values=self.cache,
+                             cache_position=self.pos, position_ids=self.posid, use_cache=True, return_dict=True)
+            logits = out.logits[:, -1, :]
+        if self._cache_fused and advance:   # the fused per-layer appends all used layer 0's counter; advance it once per forward
             self.cache.layers[0].cumulative_length.add_(self.tok.shape[1])
-        return out.logits[:, -1, :]
+        return logits
 
     def _rewind(self, n: int):
         layers = self.cache.layers[:1] if self._cache_fused else self.cache.layers
@@ -211,14 +235,19 @@ class GraphedDecoder:
         from . import _lib
         greedy, inv_temp, top_p, pad, top_k = sp
         B, V = logits.shape
-        rc = _lib.load().ll_sample_token_topk_bf16(logits.data_ptr(), logits.stride(0), B, V, inv_temp, top_p, int(top_k), int(greedy),
-                                                   self.seed_buf.data_ptr(), self.eos_buf.data_ptr(), N_EOS_SLOTS, pad,
-                                                   self.done.data_ptr(), self.tok.data_ptr(), self.out_buf.data_ptr(),
-                                                   self.out_buf.stride(0), self.out_buf.shape[1], self.stepc.data_ptr(),
-                                                   self.posid.data_ptr(), self.pos.data_ptr(), advance, None,
-                                                   torch.cuda.current_stream().cuda_stream)
+        lib = _lib.load()
+        if self.sample_ws is None or self.sample_ws.device != logits.device:
+            # workspace of the split top-k sampler (candidate lists; zero-filled once, the sampler leaves it clean): a static buffer of the graph
+            self.sample_ws = torch.zeros(int(lib.ll_sample_workspace_bytes(B)), dtype=torch.uint8, device=logits.device)
+        rc = lib.ll_sample_token_topk_ws_bf16(logits.data_ptr(), logits.stride(0), B, V, inv_temp, top_p, int(top_k), int(greedy),
+                                              self.seed_buf.data_ptr(), self.eos_buf.data_ptr(), N_EOS_SLOTS, pad,
+                                              self.done.data_ptr(), self.tok.data_ptr(), self.out_buf.data_ptr(),
+                                              self.out_buf.stride(0), self.out_buf.shape[1], self.stepc.data_ptr(),
+                                              self.posid.data_ptr(), self.pos.data_ptr(), advance, None,
+                                              self.sample_ws.data_ptr() if self.split_sampler else None, self.sample_ws.numel(),
+                                              torch.cuda.current_stream().cuda_stream)
         if rc != 0:
-            _lib.check(rc, "ll_sample_token_topk_bf16")
+            _lib.check(rc, "ll_sample_token_topk_ws_bf16")
 
     def _generate_hip(self, logits, sp, P, plen, eos_list, max_new_tokens, generator, device):
         """Decode loop with the fused sampler: per token the host only replays ONE graph (forward + sampler)."""
@@ -238,6 +267,8 @@ class GraphedDecoder:
         self._hip_sample(logits, sp, 0)
         from ._trace import mark
         mark("generate: first token sampled")
+        # the sampler's "advance" moves self.pos; when that buffer is the fused cache's position counter the forward must not move it too
+        own = not (self._cache_fused and self.pos.data_ptr() == self.cache.layers[0].cumulative_length.data_ptr())
         n = 1
         for t in range(1, max_new_tokens):
             if eos_list and t % self.sync_every == 0:
@@ -249,17 +280,18 @@ class GraphedDecoder:
                     s = torch.cuda.Stream()
                     s.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(s):
-                        self._step()                              # warm-up of the forward only; state rewound below
-                        self._rewind(self.tok.shape[1])
+                        self._step(advance=own)                   # warm-up of the forward only; state rewound below
+                        if own:
+                            self._rewind(self.tok.shape[1])
                     torch.cuda.current_stream().wait_stream(s)
                     self._graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-                        self.logits = self._step()
+                        self.logits = self._step(advance=own)
                         self._hip_sample(self.logits, sp, 1)
                 self._graph.replay()
                 logits = self.logits
             else:
-                logits = self._step()
+                logits = self._step(advance=own)
                 self._hip_sample(logits, sp, 1)
             n = t + 1
         self.last_logits = logits
@@ -314,6 +346,13 @@ class GraphedDecoder:
         if self.fused_cache and not self._cache_fused and device.type == "cuda":
             from .llm_accel import fuse_cache_update
             self._cache_fused = fuse_cache_update(self.cache) > 0
+        if self._cache_fused and self.fuse_head:
+            # the decode loop's position buffer IS the fused cache's position counter from here on: the fused sampler's "advance" then
+            # moves both and the per-token add_ launch goes away
+            cl = self.cache.layers[0].cumulative_length
+            if self.pos.data_ptr() != cl.data_ptr():
+                self.pos = cl.view(1)
+                self._graph = None
         if (self.sampler == "hip" and logits.is_cuda and logits.dtype == torch.bfloat16 and logits.shape[1] % 8 == 0
                 and logits.shape[1] <= MAX_HIP_VOCAB and logits.stride(1) == 1 and eos.numel() <= N_EOS_SLOTS
                 and (not do_sample or (temperature or 1.0) > 0)):

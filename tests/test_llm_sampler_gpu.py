@@ -16,9 +16,11 @@ def _key_to_value(key: int) -> float:
 
 
 class Sampler:
-    def __init__(self, B, V, max_new=64, eos=(), pad=0, tap=True):
+    def __init__(self, B, V, max_new=64, eos=(), pad=0, tap=True, split=False):
         from llamole_amd import _lib
         self.tap = tap          # False: no dbg tap, the way the decode loop calls it (top-k then counts only what can survive it)
+        self.split = split      # True: with a workspace (ll_sample_token_topk_ws_bf16): candidates launch + finish launch under top-k
+        self.ws = None
         self.lib, self._lib = _lib.load(), _lib
         d = "cuda"
         self.B, self.V = B, V
@@ -41,7 +43,12 @@ class Sampler:
                 self.tok.data_ptr(), self.out.data_ptr(), self.out.stride(0), self.out.shape[1],
                 self.step.data_ptr(), self.posid.data_ptr(), self.pos.data_ptr(), advance,
                 self.dbg.data_ptr() if self.tap else None, torch.cuda.current_stream().cuda_stream)
-        if top_k is None:
+        if self.split:
+            if self.ws is None:
+                self.ws = torch.zeros(int(self.lib.ll_sample_workspace_bytes(self.B)), dtype=torch.uint8, device="cuda")
+            rc = self.lib.ll_sample_token_topk_ws_bf16(logits.data_ptr(), logits.stride(0), self.B, self.V, inv, top_p, int(top_k or 0), int(greedy),
+                                                       *tail[:-1], self.ws.data_ptr(), self.ws.numel(), tail[-1])
+        elif top_k is None:
             rc = self.lib.ll_sample_token_bf16(logits.data_ptr(), logits.stride(0), self.B, self.V, inv, top_p, int(greedy), *tail)
         else:
             rc = self.lib.ll_sample_token_topk_bf16(logits.data_ptr(), logits.stride(0), self.B, self.V, inv, top_p, int(top_k), int(greedy), *tail)
@@ -64,22 +71,44 @@ def _rows_for_bound_test(V, g):
 
 
 @pytest.mark.parametrize("V", [2048, 32000, 128256, 152064, 163840])
-def test_top_k_lower_bound_leaves_every_token_unchanged(V):
-    """Without the dbg tap the sampler counts, under top-k, only keys that can survive it (a lower bound from the per-thread maxima,
-    one packed compare per pair of keys, a histogram scan over the few bins above the bound).  Same seeds, same rows: every token equals
-    the one of the whole-row count that the tests above pin to the HF warpers."""
+def test_top_k_shortcuts_leave_every_token_unchanged(V):
+    """Two shortcuts under top-k, both against the whole-row count that the tests below pin to the HF warpers (same seeds, same rows,
+    every token equal): (a) without the dbg tap the one-workgroup sampler counts only keys that can survive top-k (a lower bound from the
+    per-thread maxima, one packed compare per pair of keys, a histogram scan over the few bins above the bound); (b) with a workspace and
+    top_k <= 128 the work is split -- V/2048 workgroups per row hand on candidates, one workgroup per row finishes on them; rows whose
+    candidates overflow the list (the constant row: every token ties) or leave the key window fall back on the device."""
     g = torch.Generator().manual_seed(V + 1)
     logits = _rows_for_bound_test(V, g)
-    for top_k, top_p, temperature in ((50, 0.9, 0.7), (1, 1.0, 1.0), (5, 0.5, 1.3), (300, 0.95, 0.6), (1024, 1.0, 1.0), (2000, 0.9, 1.0), (0, 0.9, 0.7)):
-        a, b = Sampler(8, V, max_new=48), Sampler(8, V, max_new=48, tap=False)
-        a.seed.fill_(1234 + top_k)
-        b.seed.fill_(1234 + top_k)
+    for top_k, top_p, temperature in ((50, 0.9, 0.7), (1, 1.0, 1.0), (5, 0.5, 1.3), (128, 0.95, 0.6), (300, 0.95, 0.6), (1024, 1.0, 1.0), (2000, 0.9, 1.0),
+                                      (0, 0.9, 0.7)):
+        a, b, c = Sampler(8, V, max_new=48), Sampler(8, V, max_new=48, tap=False), Sampler(8, V, max_new=48, tap=False, split=True)
+        for s in (a, b, c):
+            s.seed.fill_(1234 + top_k)
         for _ in range(48):
-            a(logits, temperature=temperature, top_p=top_p, top_k=top_k)
-            b(logits, temperature=temperature, top_p=top_p, top_k=top_k)
+            for s in (a, b, c):
+                s(logits, temperature=temperature, top_p=top_p, top_k=top_k)
         assert torch.equal(a.out, b.out), (V, top_k)
+        assert torch.equal(a.out, c.out), (V, top_k, (a.out != c.out).any(dim=1).tolist())
+        assert torch.equal(a.step, c.step) and torch.equal(a.tok, c.tok) and torch.equal(a.posid, c.posid) and torch.equal(a.pos, c.pos)
+        assert int(c.ws[:8 * 16].view(torch.int32).abs().sum()) == 0                          # every row's list header is back at zero
         if top_k == 50:
             assert len(set(a.out[0].tolist())) > 8 and len(set(a.out[3].tolist())) > 8     # real draws, not a constant
+
+
+def test_split_sampler_greedy_and_single_row():
+    """The workspace changes nothing for greedy decoding (one launch as before) and works at one row (the decode loop's shape)."""
+    V = 152064
+    g = torch.Generator().manual_seed(5)
+    logits = (torch.randn(1, V, generator=g) * 3).bfloat16().cuda()
+    a, c = Sampler(1, V, max_new=32, tap=False), Sampler(1, V, max_new=32, tap=False, split=True)
+    for _ in range(16):
+        a(logits, greedy=True, top_k=50)
+        c(logits, greedy=True, top_k=50)
+    for _ in range(16):
+        a(logits, temperature=0.6, top_p=0.9, top_k=50)
+        c(logits, temperature=0.6, top_p=0.9, top_k=50)
+    assert torch.equal(a.out, c.out) and a.out[0, 0].item() == int(logits.float().argmax())
+    assert len(set(a.out[0, 16:].tolist())) > 1
 
 
 @pytest.mark.parametrize("V", [2048, 32000, 128256, 152064])

@@ -1,5 +1,5 @@
 """Times ll_sample_token_topk_bf16 on one row of synthetic logits: with the dbg tap (counts the whole row) and without
-(top-k lower bound).  python tools/sample_time.py [V] [top_k]"""
+(top-k lower bound), and with the workspace (candidates launch + finish launch).  python tools/sample_time.py [V] [top_k] [B]"""
 import os
 import sys
 
@@ -26,10 +26,14 @@ dbg = torch.zeros(B, 4, dtype=torch.int64, device=d)
 st = torch.cuda.current_stream().cuda_stream
 
 
+ws = torch.zeros(int(lib.ll_sample_workspace_bytes(B)), dtype=torch.uint8, device=d)
+
+
 def run(with_dbg, k=top_k, greedy=0):
-    rc = lib.ll_sample_token_topk_bf16(logits.data_ptr(), logits.stride(0), B, V, 1.0 / 0.7, 0.9, k, greedy, seed.data_ptr(), eos.data_ptr(), 32, 0,
-                                       done.data_ptr(), tok.data_ptr(), out.data_ptr(), out.stride(0), out.shape[1], step.data_ptr(), None, None,
-                                       0, dbg.data_ptr() if with_dbg else None, st)
+    split = with_dbg == "split"
+    rc = lib.ll_sample_token_topk_ws_bf16(logits.data_ptr(), logits.stride(0), B, V, 1.0 / 0.7, 0.9, k, greedy, seed.data_ptr(), eos.data_ptr(), 32, 0,
+                                          done.data_ptr(), tok.data_ptr(), out.data_ptr(), out.stride(0), out.shape[1], step.data_ptr(), None, None,
+                                          0, dbg.data_ptr() if with_dbg is True else None, ws.data_ptr() if split else None, ws.numel(), st)
     assert rc == 0
 
 
@@ -47,9 +51,10 @@ def timed(with_dbg, k=top_k, greedy=0, iters=300):
     return e0.elapsed_time(e1) / iters * 1e3, out[:, :iters].clone()
 
 
-for name, wd, k, gr in (("whole row (dbg tap)", True, top_k, 0), ("top-k bound", False, top_k, 0), ("top_k off", False, 0, 0), ("greedy", False, 0, 1)):
+for name, wd, k, gr in (("whole row (dbg tap)", True, top_k, 0), ("top-k bound", False, top_k, 0), ("top-k split (2 launches)", "split", top_k, 0),
+                        ("top_k off", False, 0, 0), ("greedy", False, 0, 1)):
     us, toks = timed(wd, k, gr)
-    line = f"{name:22s} {us:7.2f} us per launch (back to back, B={B}, V={V})"
+    line = f"{name:26s} {us:7.2f} us per launch (back to back, B={B}, V={V})"
     print(line)
     if name.startswith("whole"):
         ref = toks
