@@ -339,7 +339,7 @@ int ll_sample_token_topk_bf16(const void *logits, int64_t ld, int B, int V, floa
                               int64_t *out_tokens, int64_t ld_out, int max_new, int64_t *step, int64_t *posid, int64_t *pos,
                               int advance, uint64_t *dbg, void *stream);
 /* ll_sample_token_topk_ws_bf16 : the same with a workspace (ll_sample_workspace_bytes(B) bytes, 16-byte aligned, zero-filled ONCE by the
- *     caller, one per stream in flight).  With 1 <= top_k <= 128, sampling and no dbg tap the work is split: a first launch of V/2048
+ *     caller, one per stream in flight).  With B <= 4 rows, 1 <= top_k <= 128, sampling and no dbg tap the work is split: a first launch of V/2048
  *     workgroups per row hands on the tokens that can be among the row's k largest, one workgroup per row then finishes on those -- the
  *     same token as without a workspace for every seed (the one-workgroup path also takes over, on the device, when a row has more than
  *     16384 candidates).  workspace NULL: ll_sample_token_topk_bf16. */

@@ -78,21 +78,29 @@ def test_top_k_shortcuts_leave_every_token_unchanged(V):
     top_k <= 128 the work is split -- V/2048 workgroups per row hand on candidates, one workgroup per row finishes on them; rows whose
     candidates overflow the list (the constant row: every token ties) or leave the key window fall back on the device."""
     g = torch.Generator().manual_seed(V + 1)
-    logits = _rows_for_bound_test(V, g)
+    rows = _rows_for_bound_test(V, g)
     for top_k, top_p, temperature in ((50, 0.9, 0.7), (1, 1.0, 1.0), (5, 0.5, 1.3), (128, 0.95, 0.6), (300, 0.95, 0.6), (1024, 1.0, 1.0), (2000, 0.9, 1.0),
                                       (0, 0.9, 0.7)):
-        a, b, c = Sampler(8, V, max_new=48), Sampler(8, V, max_new=48, tap=False), Sampler(8, V, max_new=48, tap=False, split=True)
-        for s in (a, b, c):
-            s.seed.fill_(1234 + top_k)
-        for _ in range(48):
+        for lo in (0, 4):                        # the split takes up to four rows per call: the eight stress rows in two halves
+            logits = rows[lo:lo + 4].contiguous()
+            a, b, c = Sampler(4, V, max_new=48), Sampler(4, V, max_new=48, tap=False), Sampler(4, V, max_new=48, tap=False, split=True)
             for s in (a, b, c):
-                s(logits, temperature=temperature, top_p=top_p, top_k=top_k)
-        assert torch.equal(a.out, b.out), (V, top_k)
-        assert torch.equal(a.out, c.out), (V, top_k, (a.out != c.out).any(dim=1).tolist())
-        assert torch.equal(a.step, c.step) and torch.equal(a.tok, c.tok) and torch.equal(a.posid, c.posid) and torch.equal(a.pos, c.pos)
-        assert int(c.ws[:8 * 16].view(torch.int32).abs().sum()) == 0                          # every row's list header is back at zero
-        if top_k == 50:
-            assert len(set(a.out[0].tolist())) > 8 and len(set(a.out[3].tolist())) > 8     # real draws, not a constant
+                s.seed.fill_(1234 + top_k)
+            for _ in range(48):
+                for s in (a, b, c):
+                    s(logits, temperature=temperature, top_p=top_p, top_k=top_k)
+            assert torch.equal(a.out, b.out), (V, top_k)
+            assert torch.equal(a.out, c.out), (V, top_k, (a.out != c.out).any(dim=1).tolist())
+            assert torch.equal(a.step, c.step) and torch.equal(a.tok, c.tok) and torch.equal(a.posid, c.posid) and torch.equal(a.pos, c.pos)
+            assert int(c.ws[:4 * 16].view(torch.int32).abs().sum()) == 0                          # every row's list header is back at zero
+            if top_k == 50 and lo == 0:
+                assert len(set(a.out[0].tolist())) > 8 and len(set(a.out[3].tolist())) > 8     # real draws, not a constant
+    big = Sampler(8, V, max_new=8, tap=False, split=True)         # more than four rows with a workspace: one launch, same tokens
+    ref = Sampler(8, V, max_new=8, tap=False)
+    for _ in range(8):
+        big(rows, temperature=0.7, top_p=0.9, top_k=50)
+        ref(rows, temperature=0.7, top_p=0.9, top_k=50)
+    assert torch.equal(big.out, ref.out) and int(big.ws[:8 * 16].view(torch.int32).abs().sum()) == 0
 
 
 def test_split_sampler_greedy_and_single_row():
