@@ -264,11 +264,6 @@ int ll_decode_attn_rope_bf16(const void *qkv, int64_t ld_qkv, const void *cos, c
 int ll_decode_prologue(const int64_t *position_ids, const float *inv_freq, float attention_scaling, const int64_t *mask2d,
                        int64_t mask_stride, const int64_t *pos, void *cos, void *sin, void *mask_out, int B, int D, int maxlen,
                        void *stream);
-/* ll_decode_prologue_embed : ll_decode_prologue + the embedding rows of the step's input ids (nn.Embedding forward: hidden_out[b] =
- *     embed_weight[input_ids[b]], bf16 [vocab,H] contiguous, H % 8 == 0; ids must lie in [0, vocab)) in the same launch. */
-int ll_decode_prologue_embed(const int64_t *position_ids, const float *inv_freq, float attention_scaling, const int64_t *mask2d,
-                             int64_t mask_stride, const int64_t *pos, void *cos, void *sin, void *mask_out, const int64_t *input_ids,
-                             const void *embed_weight, int64_t vocab, void *hidden_out, int B, int D, int H, int maxlen, void *stream);
 /* ll_suffix_prologue / ll_suffix_attn_rope_bf16 : the same pair for S consecutive new positions per sequence -- the reference's query-token
  *     re-forward (modeling_llamole.py:641-646: <design_start> + the body tokens) run on top of the decode's KV cache at slots
  *     *pos .. *pos+S-1.  Rows r = b*S + s.  Prologue: cos/sin [B*S,D] for position_ids [B*S], key mask [B*S,maxlen]: key j visible to row

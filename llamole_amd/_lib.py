@@ -79,7 +79,6 @@ SIGNATURES = {
     "ll_gemv_fused_bf16": (_I, [_P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "ll_decode_attn_rope_bf16": (_I, [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _I, _F, _P]),
     "ll_decode_prologue": (_I, [_P, _P, _F, _P, _I64, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "ll_decode_prologue_embed": (_I, [_P, _P, _F, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _P, _I, _I, _I, _I, _P]),
     "ll_suffix_prologue": (_I, [_P, _P, _F, _P, _I64, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ll_suffix_attn_rope_bf16": (_I, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "ll_dit_set_overlap": (_I, [_P, _I]),

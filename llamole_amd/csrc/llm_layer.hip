@@ -619,8 +619,7 @@ __global__ __launch_bounds__(256) void decode_prologue_kernel(const long long *_
                                                               float scaling, const long long *__restrict__ mask2d, int64_t ms,
                                                               const long long *__restrict__ pos_ptr, bf16_t *__restrict__ cos_o,
                                                               bf16_t *__restrict__ sin_o, unsigned char *__restrict__ mask_o,
-                                                              int D, int maxlen, int S, const long long *__restrict__ tok,
-                                                              const bf16_t *__restrict__ emb, bf16_t *__restrict__ h_o, int H, long long vocab) {
+                                                              int D, int maxlen, int S) {
     // row r = b*S + s: the s-th new position of sequence b (S = 1: a decode step)
     const int r = blockIdx.x, tid = threadIdx.x;
     const int b = r / S, s = r - b * S;
@@ -635,13 +634,6 @@ __global__ __launch_bounds__(256) void decode_prologue_kernel(const long long *_
     }
     const long long p = *pos_ptr + s;
     for (int j = tid; j < maxlen; j += 256) mask_o[(int64_t)r * maxlen + j] = (j <= p && mask2d[b * ms + j] != 0) ? 1 : 0;
-    if (emb) {      // embed_tokens(input_ids) of the row as well: one launch less per token (H % 8 == 0)
-        const long long t = tok[r];
-        const bool ok = t >= 0 && t < vocab;                      // (nn.Embedding traps on such an id; here the row reads as zeros)
-        const uint4 *src = reinterpret_cast<const uint4 *>(emb + (ok ? t : 0) * (int64_t)H);
-        uint4 *dst = reinterpret_cast<uint4 *>(h_o + (int64_t)r * H);
-        for (int c = tid; c < H / 8; c += 256) dst[c] = ok ? src[c] : make_uint4(0, 0, 0, 0);
-    }
 }
 
 static int g_gemv_nt = 1;   // non-temporal weight loads (tools/gemv_fused_sweep.py)
@@ -780,22 +772,7 @@ int ll_decode_prologue(const int64_t *position_ids, const float *inv_freq, float
     LL_CHECK(B >= 1 && D >= 2 && D % 2 == 0 && D <= 512 && maxlen >= 1, "ll_decode_prologue: unsupported shape");
     hipLaunchKernelGGL(decode_prologue_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long *)position_ids, inv_freq,
                        attention_scaling, (const long long *)mask2d, mask_stride, (const long long *)pos, (bf16_t *)cos, (bf16_t *)sin,
-                       (unsigned char *)mask_out, D, maxlen, 1, nullptr, nullptr, nullptr, 0, 0);
-    LL_LAUNCH_CHECK();
-    return LL_OK;
-}
-
-int ll_decode_prologue_embed(const int64_t *position_ids, const float *inv_freq, float attention_scaling, const int64_t *mask2d,
-                             int64_t mask_stride, const int64_t *pos, void *cos, void *sin, void *mask_out, const int64_t *input_ids,
-                             const void *embed_weight, int64_t vocab, void *hidden_out, int B, int D, int H, int maxlen, void *stream) {
-    LL_CHECK(position_ids && inv_freq && mask2d && pos && cos && sin && mask_out && input_ids && embed_weight && hidden_out,
-             "ll_decode_prologue_embed: null argument");
-    LL_CHECK(B >= 1 && D >= 2 && D % 2 == 0 && D <= 512 && maxlen >= 1 && H >= 8 && H % 8 == 0 && vocab >= 1,
-             "ll_decode_prologue_embed: unsupported shape");
-    hipLaunchKernelGGL(decode_prologue_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long *)position_ids, inv_freq,
-                       attention_scaling, (const long long *)mask2d, mask_stride, (const long long *)pos, (bf16_t *)cos, (bf16_t *)sin,
-                       (unsigned char *)mask_out, D, maxlen, 1, (const long long *)input_ids, (const bf16_t *)embed_weight,
-                       (bf16_t *)hidden_out, H, (long long)vocab);
+                       (unsigned char *)mask_out, D, maxlen, 1);
     LL_LAUNCH_CHECK();
     return LL_OK;
 }
@@ -807,7 +784,7 @@ int ll_suffix_prologue(const int64_t *position_ids, const float *inv_freq, float
     LL_CHECK(B >= 1 && S >= 1 && D >= 2 && D % 2 == 0 && D <= 512 && maxlen >= 1, "ll_suffix_prologue: unsupported shape");
     hipLaunchKernelGGL(decode_prologue_kernel, dim3(B * S), dim3(256), 0, (hipStream_t)stream, (const long long *)position_ids, inv_freq,
                        attention_scaling, (const long long *)mask2d, mask_stride, (const long long *)pos, (bf16_t *)cos, (bf16_t *)sin,
-                       (unsigned char *)mask_out, D, maxlen, S, nullptr, nullptr, nullptr, 0, 0);
+                       (unsigned char *)mask_out, D, maxlen, S);
     LL_LAUNCH_CHECK();
     return LL_OK;
 }

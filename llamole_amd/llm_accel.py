@@ -793,11 +793,7 @@ def _model_forward(self, input_ids=None, attention_mask=None, position_ids=None,
             and past_key_values.layers[0].keys.dtype == torch.bfloat16):
         B, maxlen, D = input_ids.shape[0], attention_mask.shape[1], st["D"]
         dev = input_ids.device
-        emb = self.embed_tokens
-        ew = emb.weight
-        fused_embed = (type(emb) is nn.Embedding and ew.dtype == torch.bfloat16 and ew.is_contiguous() and ew.shape[1] % 8 == 0
-                       and input_ids.dtype == torch.long and input_ids.is_contiguous() and getattr(emb, "max_norm", None) is None)
-        h = torch.empty(B, 1, ew.shape[1], dtype=torch.bfloat16, device=dev) if fused_embed else emb(input_ids)
+        h = self.embed_tokens(input_ids)
         if h.dtype == torch.bfloat16 and h.is_contiguous():
             cos = torch.empty(B, 1, D, dtype=torch.bfloat16, device=dev)
             sin = torch.empty(B, 1, D, dtype=torch.bfloat16, device=dev)
@@ -805,15 +801,9 @@ def _model_forward(self, input_ids=None, attention_mask=None, position_ids=None,
             inv_freq = self.rotary_emb.inv_freq
             pos = past_key_values.layers[0].cumulative_length
             posid = position_ids.contiguous()
-            if fused_embed:      # the embedding rows come out of the prologue launch
-                rc = st["lib"].ll_decode_prologue_embed(posid.data_ptr(), inv_freq.data_ptr(), float(self.rotary_emb.attention_scaling),
-                                                        attention_mask.data_ptr(), attention_mask.stride(0), pos.data_ptr(), cos.data_ptr(),
-                                                        sin.data_ptr(), mask.data_ptr(), input_ids.data_ptr(), ew.data_ptr(), ew.shape[0],
-                                                        h.data_ptr(), B, D, ew.shape[1], maxlen, torch.cuda.current_stream().cuda_stream)
-            else:
-                rc = st["lib"].ll_decode_prologue(posid.data_ptr(), inv_freq.data_ptr(), float(self.rotary_emb.attention_scaling),
-                                                  attention_mask.data_ptr(), attention_mask.stride(0), pos.data_ptr(), cos.data_ptr(),
-                                                  sin.data_ptr(), mask.data_ptr(), B, D, maxlen, torch.cuda.current_stream().cuda_stream)
+            rc = st["lib"].ll_decode_prologue(posid.data_ptr(), inv_freq.data_ptr(), float(self.rotary_emb.attention_scaling),
+                                              attention_mask.data_ptr(), attention_mask.stride(0), pos.data_ptr(), cos.data_ptr(),
+                                              sin.data_ptr(), mask.data_ptr(), B, D, maxlen, torch.cuda.current_stream().cuda_stream)
             if rc != 0:
                 _lib.check(rc, "ll_decode_prologue")
             pe = (cos, sin)
@@ -827,10 +817,7 @@ def _model_forward(self, input_ids=None, attention_mask=None, position_ids=None,
                 else:
                     for layer in layers:
                         h = layer._ll_fused.run(h, mask, past_key_values, pe)
-                if st.get("skip_norm") and B == 1:
-                    st["norm_skipped"] = True      # the caller folds the final RMSNorm into the lm_head GEMV (norm_head)
-                else:
-                    h = self.norm(h)
+                h = self.norm(h)
                 from transformers.modeling_outputs import BaseModelOutputWithPast
                 return BaseModelOutputWithPast(last_hidden_state=h, past_key_values=past_key_values if use_cache else None)
     if st.get("suffix") and input_ids is not None and inputs_embeds is None and input_ids.dim() == 2:
@@ -876,40 +863,6 @@ def _suffix_forward(self, st, layers, input_ids, attention_mask, position_ids, c
     h = self.norm(h)
     from transformers.modeling_outputs import BaseModelOutputWithPast
     return BaseModelOutputWithPast(last_hidden_state=h, past_key_values=cache if use_cache else None)
-
-
-def head_fusable(model: nn.Module):
-    """(base model, decode state) when the causal LM is a plain ``lm_head(norm(hidden))`` on a base model with the one-launch
-    decode prologue -- Qwen2 / Llama / Mistral ForCausalLM: no logit scaling or soft-capping, no lm_head bias -- else None."""
-    base = getattr(model, "model", None)
-    head = getattr(model, "lm_head", None)
-    if base is None or head is None or "_ll_decode" not in base.__dict__ or type(head) is not nn.Linear or head.bias is not None:
-        return None
-    cfg = model.config
-    if any(getattr(cfg, k, None) for k in ("final_logit_softcapping", "logit_scale", "logits_scaling", "output_multiplier_scale")):
-        return None
-    norm = getattr(base, "norm", None)
-    w = head.weight
-    if (norm is None or not hasattr(norm, "variance_epsilon") or norm.weight.dtype != torch.bfloat16 or w.dtype != torch.bfloat16
-            or not w.is_cuda or not w.is_contiguous() or w.shape[1] % 8 != 0 or w.shape[1] > 8192):
-        return None
-    return base, base._ll_decode
-
-
-def norm_head(model: nn.Module, h: torch.Tensor) -> torch.Tensor:
-    """``lm_head(norm(h))`` for ONE row as one launch: the final RMSNorm is the prologue of the vocabulary GEMV (ll_gemv_fused_bf16; its
-    arithmetic is the op-by-op one, so the logits are those of rmsnorm kernel + GEMV bit for bit).  h [1, H] bf16 -> logits [1, V]."""
-    base, st = model.model, model.model._ll_decode
-    w = model.lm_head.weight
-    V, H = w.shape
-    x = h.reshape(1, H)
-    out = torch.empty(1, V, dtype=torch.bfloat16, device=h.device)
-    rc = st["lib"].ll_gemv_fused_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), H, None, base.norm.weight.data_ptr(),
-                                      float(base.norm.variance_epsilon), None, 0, out.data_ptr(), V, 1, V, H, 0,
-                                      torch.cuda.current_stream().cuda_stream)
-    if rc != 0:
-        _lib.check(rc, "ll_gemv_fused_bf16")
-    return out
 
 
 def suffix_on_fused_layers(model: nn.Module, on: bool) -> bool:

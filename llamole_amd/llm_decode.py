@@ -89,8 +89,6 @@ class GraphedDecoder:
         # other mask decisions while a stream is capturing (masking_utils.is_tracing), i.e. other SDPA kernels and roundings than the
         # eager prefill, and under the overlapped trajectory the prefill is device-bound anyway (HISTORY R5.8).
         self.graph_suffix = self.use_graph and os.environ.get("LLAMOLE_GRAPH_SUFFIX", "1") != "0"
-        # token tail at one sequence: final RMSNorm inside the lm_head GEMV, the fused sampler advances the cache position (no add_ launch)
-        self.fuse_head = os.environ.get("LLAMOLE_FUSE_HEAD", "1") != "0"
         self.split_sampler = os.environ.get("LLAMOLE_SPLIT_SAMPLER", "1") != "0"     # top-k sampling as two launches (candidates, finish)
         self.sample_ws = None
         self.max_side_graphs = 4
@@ -164,31 +162,12 @@ class GraphedDecoder:
         g.replay()
         return out
 
-    def _step(self, advance: bool = True):
-        """One forward over ``self.tok`` at the cache position.  ``advance=False``: the caller's next launch (the fused sampler) moves the
-        fused cache's position counter."""
-        head = None
-        if self._cache_fused and self.tok.shape[0] == 1 and self.tok.shape[1] == 1 and self.fuse_head:
-            from .llm_accel import head_fusable, norm_head
-            head = head_fusable(self.model)
-        if head is not None:
-            # one sequence on the fused stack: the base model hands back the un-normed hidden state and the final RMSNorm runs as the
-            # prologue of the vocabulary GEMV (one launch less per token, same arithmetic)
-            base, st = head
-            st["skip_norm"], st["norm_skipped"] = True, False
-            try:
-                h = base(input_ids=self.tok, attention_mask=self.mask, past_key_values=self.cache, cache_position=self.pos,
-                         position_ids=self.posid, use_cache=True, return_dict=True).last_hidden_state[:, -1, :]
-            finally:
-                st["skip_norm"] = False
-            logits = norm_head(self.model, h) if st["norm_skipped"] else self.model.lm_head(h)
-        else:
-            out = self.model(input_ids=self.tok, attention_mask=self.mask, past_key_values=self.cache,
-                             cache_position=self.pos, position_ids=self.posid, use_cache=True, return_dict=True)
-            logits = out.logits[:, -1, :]
-        if self._cache_fused and advance:   # the fused per-layer appends all used layer 0's counter; advance it once per forward
+    def _step(self):
+        out = self.model(input_ids=self.tok, attention_mask=self.mask, past_key_values=self.cache,
+                         cache_position=self.pos, position_ids=self.posid, use_cache=True, return_dict=True)
+        if self._cache_fused:   # the fused per-layer appends all used layer 0's counter; advance it once per forward
             self.cache.layers[0].cumulative_length.add_(self.tok.shape[1])
-        return logits
+        return out.logits[:, -1, :]
 
     def _rewind(self, n: int):
         layers = self.cache.layers[:1] if self._cache_fused else self.cache.layers
@@ -267,8 +246,6 @@ class GraphedDecoder:
         self._hip_sample(logits, sp, 0)
         from ._trace import mark
         mark("generate: first token sampled")
-        # the sampler's "advance" moves self.pos; when that buffer is the fused cache's position counter the forward must not move it too
-        own = not (self._cache_fused and self.pos.data_ptr() == self.cache.layers[0].cumulative_length.data_ptr())
         n = 1
         for t in range(1, max_new_tokens):
             if eos_list and t % self.sync_every == 0:
@@ -280,18 +257,17 @@ class GraphedDecoder:
                     s = torch.cuda.Stream()
                     s.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(s):
-                        self._step(advance=own)                   # warm-up of the forward only; state rewound below
-                        if own:
-                            self._rewind(self.tok.shape[1])
+                        self._step()                              # warm-up of the forward only; state rewound below
+                        self._rewind(self.tok.shape[1])
                     torch.cuda.current_stream().wait_stream(s)
                     self._graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-                        self.logits = self._step(advance=own)
+                        self.logits = self._step()
                         self._hip_sample(self.logits, sp, 1)
                 self._graph.replay()
                 logits = self.logits
             else:
-                logits = self._step(advance=own)
+                logits = self._step()
                 self._hip_sample(logits, sp, 1)
             n = t + 1
         self.last_logits = logits
@@ -346,13 +322,6 @@ class GraphedDecoder:
         if self.fused_cache and not self._cache_fused and device.type == "cuda":
             from .llm_accel import fuse_cache_update
             self._cache_fused = fuse_cache_update(self.cache) > 0
-        if self._cache_fused and self.fuse_head:
-            # the decode loop's position buffer IS the fused cache's position counter from here on: the fused sampler's "advance" then
-            # moves both and the per-token add_ launch goes away
-            cl = self.cache.layers[0].cumulative_length
-            if self.pos.data_ptr() != cl.data_ptr():
-                self.pos = cl.view(1)
-                self._graph = None
         if (self.sampler == "hip" and logits.is_cuda and logits.dtype == torch.bfloat16 and logits.shape[1] % 8 == 0
                 and logits.shape[1] <= MAX_HIP_VOCAB and logits.stride(1) == 1 and eos.numel() <= N_EOS_SLOTS
                 and (not do_sample or (temperature or 1.0) > 0)):
