@@ -1,4 +1,4 @@
-// Next-token sampler of the LLM decode loop as ONE launch: HF TemperatureLogitsWarper +
+// Next-token sampler of the LLM decode loop as one launch (two for top-k at a few rows): HF TemperatureLogitsWarper +
 // TopPLogitsWarper + softmax + multinomial (transformers generation/logits_process.py; the reference calls them through
 // language_model.generate(do_sample, temperature, top_p), modeling_llamole.py:599/:849) plus the loop's bookkeeping
 // (pad rows that already stopped, EOS test, write the token into the output buffer and the next step's input, advance the
@@ -15,6 +15,10 @@
 // exp is evaluated per distinct value (a few thousand), not per token; the per-token work is integer compares.
 // Nucleus semantics: a value v is kept iff the probability mass strictly above v is < top_p (HF: ascending cumulative sum
 // > 1 - top_p); tokens tied with the boundary value are all kept (torch.sort leaves their order unspecified).
+// Two shortcuts under top-k, each producing the same token as the whole-row count for every seed (tests/test_llm_sampler_gpu.py):
+//   * sample_token_kernel counts only keys >= a lower bound of the row's k-th largest key (at least k threads hold such a key);
+//   * with a workspace and <= 4 rows, sample_candidates_kernel (V/2048 workgroups per row) first hands on the tokens that can be
+//     among the k largest, and sample_token_kernel finishes on that list (sample_fast) instead of reading the row.
 #include "common.h"
 
 namespace ll {
@@ -192,29 +196,20 @@ struct SampleLds {
     uint32_t tmh[SAMPLE_TM_BINS + 1];    // thread maxima per 32-key bin below the row maximum (top-k lower bound)
     long long eos[64];                   // the first EOS ids, the row's step counter and stop flag: requested at kernel start
     long long step;
-    unsigned int done, stop;
+    unsigned int done;
 };
 
-// Steps 3 and 4 on the histogram cnt[0 .. kmax - klo]: top-k cut, nucleus boundary, one Philox draw -> the sampled VALUE k2 and the rank
+// Steps 3 and 4 on the histogram L.cnt[0 .. kmax - klo]: top-k cut, nucleus boundary, one Philox draw -> the sampled VALUE k2 and the rank
 // of the token among those sharing it.  Expects a barrier behind the last histogram update.
 __device__ __forceinline__ void nucleus_scan(SampleLds &L, const SampleArgs &a, int b, int tid, int lane, int wave, uint32_t kmax,
                                              uint32_t klo, float m, uint32_t &k2, uint32_t &rank) {
-    uint32_t (&cnt)[SAMPLE_W] = L.cnt;
-    unsigned long long (&wsum)[16] = L.wsum;
-    float (&redf)[16] = L.redf;
-    unsigned int (&redu)[16] = L.redu;
-    uint32_t (&tmh)[SAMPLE_TM_BINS + 1] = L.tmh;
-    unsigned long long &sh_tail = L.tail, &sh_R = L.R, &sh_Zk = L.Zk;
-    unsigned int &sh_d = L.d, &sh_key = L.key, &sh_rank = L.rank, &sh_tok = L.tok, &sh_dk = L.dk, &sh_klo = L.klo, &sh_nm = L.nm;
-    (void)cnt; (void)wsum; (void)redf; (void)redu; (void)tmh; (void)sh_tail; (void)sh_R; (void)sh_Zk; (void)sh_d; (void)sh_key; (void)sh_rank;
-    (void)sh_tok; (void)sh_dk; (void)sh_klo; (void)sh_nm;
     // ---- 3. thread t owns d in [bpt t, bpt t + bpt), descending values: masses = count * 2^-40 fixed-point exp.  All 36 bins per
     // thread without the bound; with it only [0, kmax - klo] can be non-empty (typically one bin per thread)
     const int bpt = klo ? (int)((kmax - klo) >> 10) + 1 : SAMPLE_BPT;
     const int d0 = tid * bpt;
     unsigned long long lsum = 0;
     for (int i = 0; i < bpt; ++i) {
-        const uint32_t c = cnt[d0 + i];
+        const uint32_t c = L.cnt[d0 + i];
         if (c && (uint32_t)(d0 + i) < kmax) lsum += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
     }
     unsigned long long inc = lsum;
@@ -223,13 +218,13 @@ __device__ __forceinline__ void nucleus_scan(SampleLds &L, const SampleArgs &a, 
         const unsigned long long o = __shfl_up(inc, dd, 64);
         if (lane >= dd) inc += o;
     }
-    if (lane == 63) wsum[wave] = inc;
+    if (lane == 63) L.wsum[wave] = inc;
     __syncthreads();
-    unsigned long long base = 0, Z = sh_tail;
+    unsigned long long base = 0, Z = L.tail;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        if (i < wave) base += wsum[i];
-        Z += wsum[i];
+        if (i < wave) base += L.wsum[i];
+        Z += L.wsum[i];
     }
     base = uniform64(base);
     Z = uniform64(Z);
@@ -242,7 +237,7 @@ __device__ __forceinline__ void nucleus_scan(SampleLds &L, const SampleArgs &a, 
     if (a.top_k > 0) {
         uint32_t lc = 0;
         for (int i = 0; i < bpt; ++i) {
-            const uint32_t c = cnt[d0 + i];
+            const uint32_t c = L.cnt[d0 + i];
             if (c && (uint32_t)(d0 + i) < kmax) lc += c;
         }
         uint32_t incc = lc;
@@ -251,33 +246,33 @@ __device__ __forceinline__ void nucleus_scan(SampleLds &L, const SampleArgs &a, 
             const uint32_t o = __shfl_up(incc, dd, 64);
             if (lane >= dd) incc += o;
         }
-        if (lane == 63) redu[wave] = incc;
+        if (lane == 63) L.redu[wave] = incc;
         __syncthreads();
         uint32_t basec = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            if (i < wave) basec += redu[i];
+            if (i < wave) basec += L.redu[i];
         const uint32_t exclc = basec + incc - lc;
         const uint32_t kk = (uint32_t)a.top_k;
         if (exclc < kk && exclc + lc >= kk) {        // exactly one thread: its bins hold the k-th largest token
             uint32_t run = exclc;
             unsigned long long A = excl;
             for (int i = 0; i < bpt; ++i) {
-                const uint32_t c = cnt[d0 + i];
+                const uint32_t c = L.cnt[d0 + i];
                 if (c && (uint32_t)(d0 + i) < kmax) {
                     run += c;
                     A += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
                     if (run >= kk) {
-                        sh_dk = (unsigned int)(d0 + i);
-                        sh_Zk = A;
+                        L.dk = (unsigned int)(d0 + i);
+                        L.Zk = A;
                         break;
                     }
                 }
             }
         }
         __syncthreads();
-        dk = __builtin_amdgcn_readfirstlane(sh_dk);                                  // stays ~0 when fewer than k tokens lie in the window: nothing is cut
-        if (dk != 0xffffffffu) Zk = uniform64(sh_Zk);
+        dk = __builtin_amdgcn_readfirstlane(L.dk);                                  // stays ~0 when fewer than k tokens lie in the window: nothing is cut
+        if (dk != 0xffffffffu) Zk = uniform64(L.Zk);
     }
     const unsigned long long Tq = a.top_p >= 1.f ? ~0ull : (unsigned long long)((double)a.top_p * (double)Zk);
     // boundary: the lowest value whose mass-above is still < Tq (mass-above is non-decreasing in d)
@@ -285,20 +280,20 @@ __device__ __forceinline__ void nucleus_scan(SampleLds &L, const SampleArgs &a, 
         unsigned long long A = excl;
         int last = -1;
         for (int i = 0; i < bpt; ++i) {
-            const uint32_t c = cnt[d0 + i];
+            const uint32_t c = L.cnt[d0 + i];
             if (c && (uint32_t)(d0 + i) < kmax) {
                 if (A < Tq && (uint32_t)(d0 + i) <= dk) last = d0 + i;
                 A += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
             }
         }
-        if (last >= 0) atomicMax(&sh_d, (unsigned int)last);
+        if (last >= 0) atomicMax(&L.d, (unsigned int)last);
     }
     __syncthreads();
-    const uint32_t dtau = __builtin_amdgcn_readfirstlane(sh_d);      // 0 when nothing else qualifies: the top value is always kept
+    const uint32_t dtau = __builtin_amdgcn_readfirstlane(L.d);      // 0 when nothing else qualifies: the top value is always kept
     if (dtau >= (uint32_t)d0 && dtau < (uint32_t)(d0 + bpt)) {
         unsigned long long A = excl;
         for (int i = 0; i < bpt; ++i) {
-            const uint32_t c = cnt[d0 + i];
+            const uint32_t c = L.cnt[d0 + i];
             if (c && (uint32_t)(d0 + i) < kmax) {
                 A += (unsigned long long)c * mass_of(kmax - (d0 + i), a.inv_temp, m);
                 if ((uint32_t)(d0 + i) == dtau) break;
@@ -311,25 +306,25 @@ __device__ __forceinline__ void nucleus_scan(SampleLds &L, const SampleArgs &a, 
         const uint4 rnd = philox4x32(make_uint4((uint32_t)st, (uint32_t)(st >> 32), (uint32_t)b, 0x5A17u),
                                      make_uint2((uint32_t)sd, (uint32_t)(sd >> 32)));
         const unsigned long long r64 = ((unsigned long long)rnd.x << 32) | rnd.y;
-        sh_R = __umul64hi(r64, M);
+        L.R = __umul64hi(r64, M);
         if (a.dbg) { a.dbg[b * 4 + 0] = Z; a.dbg[b * 4 + 1] = M; a.dbg[b * 4 + 2] = kmax - dtau; }
     }
-    if (tid == 0) { sh_key = kmax; sh_rank = 0; }
+    if (tid == 0) { L.key = kmax; L.rank = 0; }
     __syncthreads();
     // ---- 4. the value whose mass interval contains R, and the rank among the tokens sharing it
-    const unsigned long long R = uniform64(sh_R);
+    const unsigned long long R = uniform64(L.R);
     if (R >= excl && R < excl + lsum) {
         unsigned long long A = excl;
         for (int i = 0; i < bpt; ++i) {
-            const uint32_t c = cnt[d0 + i];
+            const uint32_t c = L.cnt[d0 + i];
             if (c && (uint32_t)(d0 + i) < kmax) {
                 const unsigned long long q = mass_of(kmax - (d0 + i), a.inv_temp, m);
                 const unsigned long long ms = (unsigned long long)c * q;
                 if (R < A + ms) {
                     unsigned long long r = q ? (R - A) / q : 0;
                     if (r >= c) r = c - 1;
-                    sh_key = kmax - (d0 + i);
-                    sh_rank = (uint32_t)r;
+                    L.key = kmax - (d0 + i);
+                    L.rank = (uint32_t)r;
                     break;
                 }
                 A += ms;
@@ -337,15 +332,15 @@ __device__ __forceinline__ void nucleus_scan(SampleLds &L, const SampleArgs &a, 
         }
     }
     __syncthreads();
-    k2 = __builtin_amdgcn_readfirstlane(sh_key);      // (R in the tail mass, possible only with top_p >= 1 and a > 288-binade spread: the top value)
-    rank = __builtin_amdgcn_readfirstlane(sh_rank);
+    k2 = __builtin_amdgcn_readfirstlane(L.key);      // (R in the tail mass, possible only with top_p >= 1 and a > 288-binade spread: the top value)
+    rank = __builtin_amdgcn_readfirstlane(L.rank);
     if (a.dbg && tid == 0) a.dbg[b * 4 + 3] = k2;
 }
 
 // Requested at kernel start, used by sample_finish behind many barriers: the row's step counter / stop flag and the EOS ids.
 __device__ __forceinline__ void sample_prefetch(SampleLds &L, const SampleArgs &a, int b, int tid) {
     if (tid < 64 && tid < a.n_eos) L.eos[tid] = a.eos[tid];
-    if (tid == 64) { L.step = a.step[b]; L.done = a.done[b]; L.stop = 0; }
+    if (tid == 64) { L.step = a.step[b]; L.done = a.done[b]; }
 }
 
 // Loop bookkeeping of the row (after a barrier): pad rows that already stopped, EOS test, token -> output buffer and next input, counters.
@@ -377,15 +372,6 @@ __device__ __forceinline__ void sample_finish(SampleLds &L, const SampleArgs &a,
 // scratch touched -- when the list overflowed (ties) or spans more than the key window: the caller then reads the row.
 template <int CH>
 __device__ __forceinline__ bool sample_fast(SampleLds &L, const SampleArgs &a, int b, int tid, int lane, int wave) {
-    uint32_t (&cnt)[SAMPLE_W] = L.cnt;
-    unsigned long long (&wsum)[16] = L.wsum;
-    float (&redf)[16] = L.redf;
-    unsigned int (&redu)[16] = L.redu;
-    uint32_t (&tmh)[SAMPLE_TM_BINS + 1] = L.tmh;
-    unsigned long long &sh_tail = L.tail, &sh_R = L.R, &sh_Zk = L.Zk;
-    unsigned int &sh_d = L.d, &sh_key = L.key, &sh_rank = L.rank, &sh_tok = L.tok, &sh_dk = L.dk, &sh_klo = L.klo, &sh_nm = L.nm;
-    (void)cnt; (void)wsum; (void)redf; (void)redu; (void)tmh; (void)sh_tail; (void)sh_R; (void)sh_Zk; (void)sh_d; (void)sh_key; (void)sh_rank;
-    (void)sh_tok; (void)sh_dk; (void)sh_klo; (void)sh_nm;
     const uint4 hd = *reinterpret_cast<const uint4 *>(a.cand_total + b * 4);
     const uint32_t ncand = __builtin_amdgcn_readfirstlane(hd.x), kmax = __builtin_amdgcn_readfirstlane(hd.y),
                    klo = 0xffffu - __builtin_amdgcn_readfirstlane(hd.z);
@@ -399,13 +385,13 @@ __device__ __forceinline__ bool sample_fast(SampleLds &L, const SampleArgs &a, i
         const uint32_t j = tid + i * 1024;
         cr[i] = j < ncand ? cand[j] : make_uint2(0u, 0u);                               // key 0 = none
     }
-    if (tid == 0) { sh_tail = 0; sh_d = 0; sh_tok = 0; sh_dk = 0xffffffffu; sh_Zk = 0; sh_nm = 0; }
+    if (tid == 0) { L.tail = 0; L.d = 0; L.tok = 0; L.dk = 0xffffffffu; L.Zk = 0; L.nm = 0; }
     const int bpt = (int)((kmax - klo) >> 10) + 1;     // the scan's bins per thread: zero exactly those
-    for (int i = 0; i < bpt; ++i) cnt[tid * bpt + i] = 0;
+    for (int i = 0; i < bpt; ++i) L.cnt[tid * bpt + i] = 0;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < SAMPLE_CAND_CAP / 1024; ++i)
-        if (cr[i].x) atomicAdd(&cnt[kmax - cr[i].x], 1u);
+        if (cr[i].x) atomicAdd(&L.cnt[kmax - cr[i].x], 1u);
     __syncthreads();
     uint32_t k2 = kmax, rank = 0;
     nucleus_scan(L, a, b, tid, lane, wave, kmax, klo, scaled(kmax, a.inv_temp), k2, rank);
@@ -416,18 +402,18 @@ __device__ __forceinline__ bool sample_fast(SampleLds &L, const SampleArgs &a, i
     for (int i = 0; i < SAMPLE_CAND_CAP / 1024; ++i) {
         if (cr[i].x == k2) {
             const uint32_t c = cr[i].y >> 3;
-            cnt[atomicAdd(&sh_nm, 1u)] = (c & 1023u) * (uint32_t)(CH * 8) + (c >> 10) * 8u + (cr[i].y & 7u);
+            L.cnt[atomicAdd(&L.nm, 1u)] = (c & 1023u) * (uint32_t)(CH * 8) + (c >> 10) * 8u + (cr[i].y & 7u);
         }
     }
     __syncthreads();
-    const uint32_t nm = sh_nm;
+    const uint32_t nm = L.nm;
     for (uint32_t t = tid; t < nm; t += 1024) {
-        const uint32_t o = cnt[t];
+        const uint32_t o = L.cnt[t];
         uint32_t below = 0;
-        for (uint32_t j = 0; j < nm; ++j) below += cnt[j] < o ? 1u : 0u;
+        for (uint32_t j = 0; j < nm; ++j) below += L.cnt[j] < o ? 1u : 0u;
         if (below == rank) {
             const uint32_t rem = o % (uint32_t)(CH * 8);
-            sh_tok = ((rem >> 3) * 1024u + o / (uint32_t)(CH * 8)) * 8u + (rem & 7u);
+            L.tok = ((rem >> 3) * 1024u + o / (uint32_t)(CH * 8)) * 8u + (rem & 7u);
         }
     }
     sample_finish(L, a, b, tid);
@@ -439,15 +425,6 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
     __shared__ SampleLds L;
     sample_prefetch(L, a, blockIdx.x, threadIdx.x);
     if (a.cand_total && sample_fast<CH>(L, a, blockIdx.x, threadIdx.x, threadIdx.x & 63, threadIdx.x >> 6)) return;
-    uint32_t (&cnt)[SAMPLE_W] = L.cnt;
-    unsigned long long (&wsum)[16] = L.wsum;
-    float (&redf)[16] = L.redf;
-    unsigned int (&redu)[16] = L.redu;
-    uint32_t (&tmh)[SAMPLE_TM_BINS + 1] = L.tmh;
-    unsigned long long &sh_tail = L.tail, &sh_R = L.R, &sh_Zk = L.Zk;
-    unsigned int &sh_d = L.d, &sh_key = L.key, &sh_rank = L.rank, &sh_tok = L.tok, &sh_dk = L.dk, &sh_klo = L.klo, &sh_nm = L.nm;
-    (void)cnt; (void)wsum; (void)redf; (void)redu; (void)tmh; (void)sh_tail; (void)sh_R; (void)sh_Zk; (void)sh_d; (void)sh_key; (void)sh_rank;
-    (void)sh_tok; (void)sh_dk; (void)sh_klo; (void)sh_nm;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bf16_t *row = a.logits + (int64_t)b * a.ld;
     const int nchunk = a.V / 8;
@@ -461,10 +438,10 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
     }
     if (!a.greedy) {
 #pragma unroll
-        for (int i = 0; i < SAMPLE_BPT; ++i) cnt[i * 1024 + tid] = 0;
+        for (int i = 0; i < SAMPLE_BPT; ++i) L.cnt[i * 1024 + tid] = 0;
     }
-    if (tid == 0) { sh_tail = 0; sh_d = 0; sh_tok = 0; sh_dk = 0xffffffffu; sh_Zk = 0; sh_klo = 0; }
-    for (int i = tid; i < SAMPLE_TM_BINS + 1; i += 1024) tmh[i] = 0;
+    if (tid == 0) { L.tail = 0; L.d = 0; L.tok = 0; L.dk = 0xffffffffu; L.Zk = 0; L.klo = 0; }
+    for (int i = tid; i < SAMPLE_TM_BINS + 1; i += 1024) L.tmh[i] = 0;
     reg_fence<CH>(w);
     // keys: the finite conversion for every pair (7 VALU instructions per pair instead of ~25 with the inf / NaN canonicalisation);
     // the inf / NaN test is taken per 16-byte chunk and such a chunk (rare) is converted again; the all-ones fill past the end of the
@@ -483,11 +460,11 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
     }
     const uint32_t kmaxi = max(kmaxp & 0xffffu, kmaxp >> 16);
     float kmaxf = wave_max((float)kmaxi);
-    if (lane == 0) redf[wave] = kmaxf;
+    if (lane == 0) L.redf[wave] = kmaxf;
     __syncthreads();
-    float km = redf[0];
+    float km = L.redf[0];
 #pragma unroll
-    for (int i = 1; i < 16; ++i) km = fmaxf(km, redf[i]);
+    for (int i = 1; i < 16; ++i) km = fmaxf(km, L.redf[i]);
     const uint32_t kmax = __builtin_amdgcn_readfirstlane((uint32_t)km);      // uniform values live in scalar registers
     const float m = scaled(kmax, a.inv_temp);
     uint32_t k2 = kmax;      // the value to pick a token of
@@ -500,29 +477,29 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
         uint32_t klo = 0;
         if (a.top_k > 0 && a.top_k <= 1024 && !a.dbg) {
             const uint32_t dm = kmax - kmaxi;
-            if (kmaxi) atomicAdd(&tmh[dm < (uint32_t)SAMPLE_W ? (dm >> 5) : SAMPLE_TM_BINS], 1u);
+            if (kmaxi) atomicAdd(&L.tmh[dm < (uint32_t)SAMPLE_W ? (dm >> 5) : SAMPLE_TM_BINS], 1u);
             __syncthreads();
-            const uint32_t c0 = 2 * tid < SAMPLE_TM_BINS ? tmh[2 * tid] : 0u, c1 = 2 * tid + 1 < SAMPLE_TM_BINS ? tmh[2 * tid + 1] : 0u;
+            const uint32_t c0 = 2 * tid < SAMPLE_TM_BINS ? L.tmh[2 * tid] : 0u, c1 = 2 * tid + 1 < SAMPLE_TM_BINS ? L.tmh[2 * tid + 1] : 0u;
             uint32_t inct = c0 + c1;
 #pragma unroll
             for (int dd = 1; dd < 64; dd <<= 1) {
                 const uint32_t o = __shfl_up(inct, dd, 64);
                 if (lane >= dd) inct += o;
             }
-            if (lane == 63) redu[wave] = inct;
+            if (lane == 63) L.redu[wave] = inct;
             __syncthreads();
             uint32_t baset = 0;
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                if (i < wave) baset += redu[i];
+                if (i < wave) baset += L.redu[i];
             const uint32_t exclt = baset + inct - c0 - c1, kk = (uint32_t)a.top_k;
             if (exclt < kk && exclt + c0 + c1 >= kk) {
                 const uint32_t bin = exclt + c0 >= kk ? 2 * tid : 2 * tid + 1;
                 const uint32_t dlow = bin * 32 + 31;                 // the lowest key of that bin is kmax - dlow
-                sh_klo = dlow < kmax ? kmax - dlow : 1u;
+                L.klo = dlow < kmax ? kmax - dlow : 1u;
             }
             __syncthreads();
-            klo = __builtin_amdgcn_readfirstlane(sh_klo);
+            klo = __builtin_amdgcn_readfirstlane(L.klo);
         }
         // ---- 2. exact count histogram over the key window [kmax - W + 1, kmax]; anything below goes to one tail mass
         reg_fence<CH>(w);
@@ -536,8 +513,8 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
                 for (int t = 0; t < 4; ++t) {
                     const uint32_t kk = w[k][t];
                     if (pk_max_u16(kk, below) != below) {
-                        if ((kk & 0xffffu) >= klo) atomicAdd(&cnt[kmax - (kk & 0xffffu)], 1u);
-                        if ((kk >> 16) >= klo) atomicAdd(&cnt[kmax - (kk >> 16)], 1u);
+                        if ((kk & 0xffffu) >= klo) atomicAdd(&L.cnt[kmax - (kk & 0xffffu)], 1u);
+                        if ((kk >> 16) >= klo) atomicAdd(&L.cnt[kmax - (kk >> 16)], 1u);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -552,10 +529,10 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
                         const uint32_t key = hh ? (w[k][t] >> 16) : (w[k][t] & 0xffffu);
                         const uint32_t d = kmax - key;
                         if (key) {
-                            if (d < (uint32_t)SAMPLE_W) atomicAdd(&cnt[d], 1u);
+                            if (d < (uint32_t)SAMPLE_W) atomicAdd(&L.cnt[d], 1u);
                             else {
                                 const unsigned long long q = mass_of(key, a.inv_temp, m);
-                                if (q) atomicAdd(&sh_tail, q);
+                                if (q) atomicAdd(&L.tail, q);
                             }
                         }
                     }
@@ -586,12 +563,12 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
     if (a.greedy) {
         float mi = -(float)minidx;            // indices < 2^24: exact in f32
         mi = wave_max(mi);
-        if (lane == 0) redf[wave] = mi;
+        if (lane == 0) L.redf[wave] = mi;
         __syncthreads();
         if (tid == 0) {
-            float best = redf[0];
-            for (int i = 1; i < 16; ++i) best = fmaxf(best, redf[i]);
-            sh_tok = (uint32_t)(-best);
+            float best = L.redf[0];
+            for (int i = 1; i < 16; ++i) best = fmaxf(best, L.redf[i]);
+            L.tok = (uint32_t)(-best);
         }
     } else {
         uint32_t inc = cntm;
@@ -600,12 +577,12 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
             const uint32_t o = __shfl_up(inc, dd, 64);
             if (lane >= dd) inc += o;
         }
-        if (lane == 63) redu[wave] = inc;
+        if (lane == 63) L.redu[wave] = inc;
         __syncthreads();
         uint32_t base = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            if (i < wave) base += redu[i];
+            if (i < wave) base += L.redu[i];
         const uint32_t excl = base + inc - cntm;
         if (cntm && rank >= excl && rank < excl + cntm) {
             uint32_t left = rank - excl, found = 0xffffffffu;
@@ -620,7 +597,7 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs a) {
                     if ((w[k][t] & 0xffffu) == k2) { if (left == 0 && found == 0xffffffffu) found = base_idx; --left; }
                     if ((w[k][t] >> 16) == k2) { if (left == 0 && found == 0xffffffffu) found = base_idx + 1; --left; }
                 }
-            sh_tok = found;
+            L.tok = found;
         }
     }
     sample_finish(L, a, b, tid);
